@@ -1,0 +1,200 @@
+"""Synthetic sliding-window inputs for the MSCKF update path.
+
+Produces the flat (SoA / CSR) buffers the C-ABI in ``include/orcvio_msckf.h``
+consumes.  The recipe is the one written down in SURVEY.md Appendix A /
+§8(d): a smooth 6-DoF trajectory, point features in the frustum of the middle
+clone, normalised-coordinate observations with pixel noise, a noisy world
+position standing in for the triangulation step, and a dense SPD prior
+covariance with the extrinsic / time-offset rows zeroed (reference
+``config/euroc.yaml``: estimate_extrin = estimate_td = 0).
+
+Nothing here touches the oracle; it is input generation only.
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+LEG_DIM = 22  # reference src/orcvio.cpp:196-199 (no IMU-intrinsic calibration)
+
+# Kalibr T_cam_imu of reference config/euroc.yaml:29-37 (body -> camera)
+_T_CAM_IMU_EUROC = np.array(
+    [[0.014865542981794, 0.999557249008346, -0.025774436697440, 0.065222909535531],
+     [-0.999880929698575, 0.014967213324719, 0.003756188357967, -0.020706385492719],
+     [0.004140296794224, 0.025715529947966, 0.999660727177902, -0.008054602460030],
+     [0.0, 0.0, 0.0, 1.0]])
+
+
+def so3_exp(w: np.ndarray) -> np.ndarray:
+    th = float(np.linalg.norm(w))
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+    if th < 1e-10:
+        return np.eye(3) + K + 0.5 * K @ K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def euroc_extrinsics():
+    """(R_b2c, t_c_b) exactly as reference src/orcvio.cpp:232-246 derives them."""
+    T_inv = np.linalg.inv(_T_CAM_IMU_EUROC)
+    R_b2c = T_inv[:3, :3].T
+    t_c_b = T_inv[:3, 3].copy()
+    return R_b2c, t_c_b
+
+
+@dataclasses.dataclass
+class Flags:
+    """Switches that change hot-path arithmetic (SURVEY.md §5 'Config / flags')."""
+    use_larvio: int = 1          # config/euroc.yaml:118
+    use_left_perturbation: int = 0
+    if_fej: int = 0
+    estimate_td: int = 0
+    leg_dim: int = LEG_DIM
+    noise_feature: float = 0.008  # sigma, squared inside (src/orcvio.cpp:106,113)
+    chi2_prob: float = 0.95
+    discard_large_update: int = 0
+
+
+@dataclasses.dataclass
+class Window:
+    """One update's worth of flat inputs (all float64, C-contiguous)."""
+    R_b2w: np.ndarray      # [N,3,3] row-major
+    t_b_w: np.ndarray      # [N,3]
+    t_fej: np.ndarray      # [N,3]
+    R_b2c: np.ndarray      # [N,3,3]
+    t_c_b: np.ndarray      # [N,3]
+    p_w: np.ndarray        # [F,3]
+    obs_ptr: np.ndarray    # [F+1] int32, CSR
+    obs_clone: np.ndarray  # [nobs] int32, ascending within a feature
+    obs_z: np.ndarray      # [nobs,2]
+    obs_zvel: np.ndarray   # [nobs,2]
+    P: np.ndarray          # [n,n] symmetric
+    flags: Flags
+
+    @property
+    def N(self):
+        return self.R_b2w.shape[0]
+
+    @property
+    def F(self):
+        return self.p_w.shape[0]
+
+    @property
+    def n(self):
+        return self.flags.leg_dim + 6 * self.N
+
+
+def make_prior_cov(N: int, rng: np.random.Generator, leg_dim: int = LEG_DIM,
+                   estimate_extrin: bool = False, estimate_td: bool = False) -> np.ndarray:
+    """P = 1e-4*A*A^T + diag(initial covariances of config/euroc.yaml:76-82)."""
+    n = leg_dim + 6 * N
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    P = 1e-4 * (A @ A.T)
+    d = np.zeros(n)
+    d[0:3] = 4e-4
+    d[3:6] = 0.25
+    d[6:9] = 1.0
+    d[9:12] = 4e-4
+    d[12:15] = 0.01
+    d[15:18] = 3.0462e-8
+    d[18:21] = 9e-8
+    d[21] = 4e-6
+    for i in range(N):
+        d[leg_dim + 6 * i: leg_dim + 6 * i + 3] = 1e-3
+        d[leg_dim + 6 * i + 3: leg_dim + 6 * i + 6] = 1e-2
+    P += np.diag(d)
+    lo = 15 if not estimate_extrin else 21
+    hi = 22 if not estimate_td else 21
+    if hi > lo:
+        P[lo:hi, :] = 0.0
+        P[:, lo:hi] = 0.0
+    if leg_dim > 22:
+        pass  # IMU-intrinsic block keeps its generic SPD values
+    return 0.5 * (P + P.T)
+
+
+def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,
+                flags: Flags | None = None, estimate_extrin: bool = False,
+                sigma_px: float | None = None, outlier_frac: float = 0.0) -> Window:
+    """SURVEY.md Appendix A synthetic generator.
+
+    track_len: None -> every feature seen in all N clones; int M -> contiguous
+    run of M clones at a random start; (lo, hi) -> ragged M_j in [lo, hi].
+    outlier_frac: fraction of features whose estimate is corrupted so that the
+    chi-square gate rejects them (exercises the accept mask).
+    """
+    flags = flags or Flags()
+    rng = np.random.default_rng(seed)
+    sig = flags.noise_feature if sigma_px is None else sigma_px
+    R_b2c0, t_c_b0 = euroc_extrinsics()
+
+    R_b2w = np.empty((N, 3, 3))
+    t_b_w = np.empty((N, 3))
+    for i in range(N):
+        R_b2w[i] = so3_exp(np.array([0.02 * i, 0.01 * np.sin(i), 0.015 * i]))
+        t_b_w[i] = [0.15 * i, 0.05 * np.sin(0.3 * i), 0.03 * i]
+    t_fej = t_b_w + 1e-3 * rng.standard_normal((N, 3))
+    R_b2c = np.broadcast_to(R_b2c0, (N, 3, 3)).copy()
+    t_c_b = np.broadcast_to(t_c_b0, (N, 3)).copy()
+
+    # camera poses
+    R_c2w = np.einsum('nij,nkj->nik', R_b2w, R_b2c)            # R_b2w * R_b2c^T
+    t_c_w = t_b_w + np.einsum('nij,nj->ni', R_b2w, t_c_b)
+
+    mid = N // 2
+    depth = rng.uniform(4.0, 12.0, F)
+    xy = rng.uniform(-0.35, 0.35, (F, 2))
+    p_c_mid = np.stack([xy[:, 0] * depth, xy[:, 1] * depth, depth], axis=1)
+    p_true = p_c_mid @ R_c2w[mid].T + t_c_w[mid]
+    p_w = p_true + 0.02 * rng.standard_normal((F, 3))
+    if outlier_frac > 0:
+        bad = rng.random(F) < outlier_frac
+        p_w[bad] += rng.standard_normal((int(bad.sum()), 3)) * 1.5
+
+    obs_ptr = [0]
+    obs_clone, obs_z, obs_zvel = [], [], []
+    for j in range(F):
+        if track_len is None:
+            ids = np.arange(N)
+        else:
+            if isinstance(track_len, (tuple, list)):
+                M = int(rng.integers(track_len[0], track_len[1] + 1))
+            else:
+                M = int(track_len)
+            M = min(M, N)
+            s = int(rng.integers(0, N - M + 1))
+            ids = np.arange(s, s + M)
+        for i in ids:
+            pc = R_c2w[i].T @ (p_true[j] - t_c_w[i])
+            z = pc[:2] / pc[2] + sig * rng.standard_normal(2)
+            obs_clone.append(i)
+            obs_z.append(z)
+            obs_zvel.append(0.05 * rng.standard_normal(2))
+        obs_ptr.append(len(obs_clone))
+
+    P = make_prior_cov(N, rng, flags.leg_dim, estimate_extrin, bool(flags.estimate_td))
+    return Window(
+        R_b2w=np.ascontiguousarray(R_b2w), t_b_w=np.ascontiguousarray(t_b_w),
+        t_fej=np.ascontiguousarray(t_fej), R_b2c=R_b2c, t_c_b=t_c_b,
+        p_w=np.ascontiguousarray(p_w),
+        obs_ptr=np.asarray(obs_ptr, dtype=np.int32),
+        obs_clone=np.asarray(obs_clone, dtype=np.int32),
+        obs_z=np.asarray(obs_z, dtype=np.float64).reshape(-1, 2),
+        obs_zvel=np.asarray(obs_zvel, dtype=np.float64).reshape(-1, 2),
+        P=np.ascontiguousarray(P), flags=flags)
+
+
+def config_window(config: int, seed: int = 0) -> Window:
+    """BASELINE.json configs (feature part)."""
+    if config == 1:   # euroc.yaml shape: N=20, tracks 3..6, LARVIO Jacobians
+        return make_window(N=20, F=120, seed=seed, track_len=(3, 6), flags=Flags(use_larvio=1))
+    if config == 2:   # the metric's configuration
+        return make_window(N=30, F=400, seed=seed, flags=Flags(use_larvio=1))
+    if config == 3:   # feature half of config 3 (objects are added by synth_objects)
+        return make_window(N=30, F=400, seed=seed, flags=Flags(use_larvio=0, use_left_perturbation=0))
+    if config == 4:
+        return make_window(N=30, F=2000, seed=seed, flags=Flags(use_larvio=1))
+    if config == 5:   # kitti_raw.yaml flags: OrcVIO right perturbation, sigma=1, discard on
+        return make_window(N=30, F=2000, seed=seed, sigma_px=0.008,
+                           flags=Flags(use_larvio=0, use_left_perturbation=0,
+                                       noise_feature=1.0, discard_large_update=1))
+    raise ValueError(config)
