@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- EKF (MSCKF) updates/s on the BASELINE.json configuration, one process per GPU.
+
+A "step" is one complete measurement update (Jacobians -> nullspace -> gate -> stacked H ->
+Gram compression -> Kalman solve -> dx, P+) on inputs already resident in HBM.
+N=1: config 2 (30 clones x 400 features x 30 observations).  N>1 (weak scaling): every rank
+holds its own shard of 400 features of one joint update; per step the ranks all-gather their
+compressed blocks over RCCL and each performs the (replicated) Kalman solve.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector / matrix peak (not listed in MI355X_MICROARCH.md)
+
+
+def algorithmic_flops(N, F, M, leg=22):
+    """SURVEY.md 8(d) minimum-work count W = W_J + W_N + W_G + W_Q + W_U for full-length tracks."""
+    n = leg + 6 * N
+    n_a = 6 + 6 * N
+    rho = 2 * M - 3
+    m = F * rho
+    W_J = 350.0 * F * M
+    W_N = F * 4.0 * sum((2 * M - k) * (n_a + 1) for k in range(3))
+    W_G = F * (2.0 * rho * n_a ** 2 + rho ** 2 * n_a + rho ** 3 / 3.0)
+    W_Q = 2.0 * m * n_a ** 2 - (2.0 / 3.0) * n_a ** 3
+    W_U = 6.0 * n_a ** 2 * n + n_a ** 3 / 3.0
+    return dict(W_J=W_J, W_N=W_N, W_G=W_G, W_Q=W_Q, W_U=W_U, total=W_J + W_N + W_G + W_Q + W_U)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--clones', type=int, default=30)
+    ap.add_argument('--features', type=int, default=400)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from orcvio_amd import capi, synth
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU path')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    N, F = args.clones, args.features
+    # same window on every rank (seed 0), own feature shard per rank (seed 0 + rank for the tracks)
+    win = synth.make_window(N=N, F=F, seed=0, flags=synth.Flags(use_larvio=1))
+    if world > 1:
+        import dataclasses
+        wr = synth.make_window(N=N, F=F, seed=1000 + rank, flags=synth.Flags(use_larvio=1))
+        win = dataclasses.replace(wr, P=win.P)   # one common prior
+    upd = capi.MsckfUpdater(device=local_rank, max_clones=max(32, N), max_features=max(2048, F),
+                            max_observations=max(65536, F * N))
+    upd.upload(win)
+    stream = torch.cuda.current_stream().cuda_stream
+    gathered = None
+    if world > 1:
+        ptr, ne = upd.block_ptr()
+        gathered = torch.empty(world * ne, dtype=torch.float64, device='cuda')
+        local = torch.empty(ne, dtype=torch.float64, device='cuda')
+        import ctypes as C
+        hip = C.CDLL('libamdhip64.so')
+
+    def step():
+        if world == 1:
+            upd.run_update(stream)
+        else:
+            upd.run_local(stream)
+            # the handle's block lives in its own allocation: copy it into the collective's input
+            hip.hipMemcpyAsync(C.c_void_p(local.data_ptr()), C.c_void_p(ptr), C.c_size_t(ne * 8), 3, C.c_void_p(stream))
+            dist.all_gather_into_tensor(gathered, local)
+            upd.run_finish(gathered.data_ptr(), world, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+
+    out = None
+    if rank == 0:
+        M = N
+        W = algorithmic_flops(N, F * world, M)
+        # roofline of the dominant kernel, timed live with HIP events on the launch stream
+        prof = upd.profile(reps=20, stream=stream)
+        dom = max(prof, key=prof.get)
+        kflops = {'k_feature': W['W_J'] + W['W_N'] + W['W_G'], 'k_gram': W['W_Q'], 'k_gram_reduce': 0.0}
+        solve_share = W['W_U']
+        dom_flops = kflops.get(dom, solve_share) / (world if dom in ('k_feature', 'k_gram') else 1)
+        achieved = dom_flops / (prof[dom] * 1e-3) / 1e12
+        roofline = dict(bound='mfma', kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
+                        kernel_ms={k: round(v, 5) for k, v in prof.items()},
+                        whole_update_tflops=W['total'] / (ms * 1e-3) / 1e12)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle as orc   # checker used as the reported CPU baseline ("port")
+            reps = 2
+            t = []
+            for _ in range(reps):
+                t.append(orc.msckf_update(win, want_blocks=False, want_K=False)['seconds'])
+            cpu = dict(value=1.0 / min(t), unit='updates/s', cores=1, kind='port',
+                       sample=f'{reps} full updates of the same workload, best of {reps} ({min(t):.2f} s each), '
+                              'single-threaded plain-C restatement of the reference algorithm')
+        out = dict(metric='EKF updates/sec, 30 clones x 400 feats', value=args.steps / dt, unit='updates/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
+                   scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+                   config=dict(workload='config2: synthetic 30-clone window, 400 point features x 30 observations '
+                                        'per GPU (22 800 stacked rows x 202 columns), LARVIO Jacobians',
+                               clones=N, features_per_gpu=F, observations_per_feature=N,
+                               parallelism=f'features sharded over {world} GPU(s), all-gather of compressed blocks'),
+                   roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    upd.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,199 @@
+/*
+ * orcvio_msckf.h -- C-ABI of the MI355X-native MSCKF measurement-update path.
+ *
+ * This is the drop-in boundary for ONE hot path of shanmo/OrcVIO: everything the
+ * reference does between "a set of feature tracks / object residual rows is ready"
+ * and "delta_x and the updated covariance are available" (SURVEY.md section 8).
+ * The reference has no FFI layer; the seam is cut inside class OrcVIO
+ * (reference include/orcvio/orcvio.h:200-214,393-396).  Each entry point below
+ * names the reference code it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C, caller-owned buffers, no exceptions, int status codes;
+ *   - all floating point is FP64, ids / indices are int32;
+ *   - matrices handed over by the host are dense.  P is symmetric so row- and
+ *     column-major coincide; every other matrix states its layout;
+ *   - error-state order is the reference's (src/orcvio.cpp:202-225,4497-4533):
+ *       theta(0:3) v(3:6) p(6:9) bg(9:12) ba(12:15) theta_ext(15:18) t_ext(18:21)
+ *       td(21) [IMU intrinsics 22:46 if leg_dim==46] | clone i: theta,p at leg_dim+6i
+ *   - one update in flight per handle; calls return after the result is in the
+ *     caller's buffers unless the name says _async / _device.
+ */
+#ifndef ORCVIO_MSCKF_H
+#define ORCVIO_MSCKF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORCVIO_MSCKF_ABI_VERSION 1
+
+/* status codes */
+enum {
+    ORCVIO_OK = 0,
+    ORCVIO_ERR_INVALID = 1,        /* bad argument / null pointer / size mismatch      */
+    ORCVIO_ERR_NO_DEVICE = 2,      /* no gfx950 device or HIP runtime failure at create */
+    ORCVIO_ERR_CAPACITY = 3,       /* window / tracks exceed the handle's capacity      */
+    ORCVIO_ERR_TRACK_TOO_LONG = 4, /* a track has more than ORCVIO_MAX_TRACK observations */
+    ORCVIO_ERR_HIP = 5,            /* HIP runtime error during the call (see last_error) */
+    ORCVIO_ERR_NOT_SPD = 6         /* S = H P H^T + sigma^2 I not positive definite      */
+};
+
+#define ORCVIO_MAX_TRACK 32   /* observations per feature track handled by the wave kernel */
+#define ORCVIO_MAX_CLONES 60  /* sliding-window clones per handle                          */
+#define ORCVIO_CHI2_TABLE 500 /* reference chi_squre_num_threshold, src/orcvio.cpp:483      */
+
+/* Flags that change hot-path arithmetic (reference YAML keys; src/orcvio.cpp:62-415). */
+typedef struct orcvio_msckf_flags {
+    int32_t leg_dim;               /* 22, or 46 with calib_imu_instrinsic (src/orcvio.cpp:196-199) */
+    int32_t use_larvio;            /* use_larvio_flag                                      */
+    int32_t use_left_perturbation; /* use_left_perturbation_flag                           */
+    int32_t if_fej;                /* if_FEJ: position_FEJ in the Jacobians (:1104)         */
+    int32_t estimate_td;           /* estimate_td: column 21 = observations_vel (:1211)     */
+    int32_t discard_large_update;  /* discard_large_update_flag (:4479-4494), see stats     */
+    double noise_feature;          /* noise_feature (sigma); squared inside (:106,113)      */
+    double chi2_prob;              /* chi_square_threshold_feat, e.g. 0.95                  */
+} orcvio_msckf_flags;
+
+/* Sliding window of augmented IMU states (reference struct IMUState_Aug,
+ * include/orcvio/imu_state.h:103-148; std::map order = index order here). */
+typedef struct orcvio_msckf_window {
+    int32_t n_clones;
+    const double* R_b2w; /* [N][9] row-major: orientation (body -> world)          */
+    const double* t_b_w; /* [N][3] position                                        */
+    const double* t_fej; /* [N][3] position_FEJ (may alias t_b_w when !if_fej)      */
+    const double* R_b2c; /* [N][9] row-major: R_imu_cam0 (per-clone copy)           */
+    const double* t_c_b; /* [N][3] t_cam0_imu                                       */
+} orcvio_msckf_window;
+
+/* Feature tracks to be used in this update, CSR over observations (reference struct
+ * Feature / MapServer, include/orcvio/feat/feature.hpp:34-269).  The caller lists
+ * only the observations that take part: all of them for removeLostFeatures
+ * (src/orcvio.cpp:2503-2519), only those of the clones being removed for
+ * pruneImuStateBuffer (:2810-2845).  Tracks with fewer than 2 listed observations
+ * are skipped (accept = 0, gamma = NaN). */
+typedef struct orcvio_msckf_tracks {
+    int32_t n_features;
+    const double* p_w;        /* [F][3] Feature::position (world)                          */
+    const int32_t* obs_ptr;   /* [F+1]                                                     */
+    const int32_t* obs_clone; /* [nobs] window index of the observing clone, ascending     */
+    const double* obs_z;      /* [nobs][2] Feature::observations (normalised coordinates)   */
+    const double* obs_zvel;   /* [nobs][2] Feature::observations_vel; may be NULL if !estimate_td */
+} orcvio_msckf_tracks;
+
+/* Pre-evaluated object residual rows in window coordinates: the output of
+ * OrcVIO::constructObjectResidualJacobians (src/orcvio.cpp:2017-2151) for one object,
+ * i.e. the arguments of OrcVIO::removeLostObjects (:2154-2193), in compact form:
+ * every row touches exactly one clone. */
+typedef struct orcvio_msckf_object_rows {
+    int32_t n_rows;           /* rows of Hx / Hf / res                                     */
+    int32_t n_obj_cols;       /* columns of Hf (object state dim, 45 for a 12-keypoint car) */
+    const int32_t* row_clone; /* [n_rows] window index of the clone the row belongs to     */
+    const double* Hx6;        /* [n_rows][6] the 6 non-zeros of the Hx row (theta, p of that clone) */
+    const double* Hf;         /* [n_rows][n_obj_cols] row-major                            */
+    const double* res;        /* [n_rows]                                                  */
+} orcvio_msckf_object_rows;
+
+/* Caller-allocated outputs.  NULL pointers are skipped. */
+typedef struct orcvio_msckf_result {
+    double* dx;       /* [n]    delta_x = K r                      (src/orcvio.cpp:1697,1824) */
+    double* P_out;    /* [n*n]  (I-KH)P, symmetrised              (:1741-1753)               */
+    int32_t* accept;  /* [F]    chi-square gate result             (:1953-1976)               */
+    double* gamma;    /* [F]    Mahalanobis distance of each block                            */
+    double* H_thin;   /* [(n-15)*n] row-major compressed Jacobian (upper-triangular R placed in
+                         state columns 15..n-1; rows of rank-deficient directions are zero)   */
+    double* r_thin;   /* [n-15]                                                              */
+    double* K;        /* [n*(n-15)] row-major Kalman gain w.r.t. H_thin                       */
+    double* G;        /* [n*n] row-major K*H_thin (basis independent, SURVEY.md note N1)      */
+    int32_t stats[8]; /* [0] stacked rows (accepted)  [1] rows of H_thin  [2] accepted blocks
+                         [3] 1 if an update was applied to P  [4] 1 if the reference's
+                         large-update test (:4479) would discard delta_x  [5] zero pivots met
+                         while compressing  [6..7] reserved                                   */
+} orcvio_msckf_result;
+
+typedef struct orcvio_msckf_handle orcvio_msckf_handle;
+
+/* Version / capability probes (no device needed). */
+int32_t orcvio_msckf_abi_version(void);
+const char* orcvio_msckf_last_error(void);
+
+/* Chi-square quantile used for the gating tables: replaces boost::math::quantile
+ * (src/orcvio.cpp:486-494, 1962-1968).  Host-side, no device needed. */
+double orcvio_msckf_chi2_quantile(int32_t dof, double prob);
+
+/* Create / destroy a handle that owns device buffers, streams and a captured launch
+ * graph.  device = HIP device ordinal.  Capacity bounds what later calls may pass. */
+int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_features,
+                            int32_t max_observations, orcvio_msckf_handle** out);
+void orcvio_msckf_destroy(orcvio_msckf_handle* h);
+
+/* Feature update: replaces the loop + compression + update of
+ * OrcVIO::removeLostFeatures (src/orcvio.cpp:2497-2560) and of
+ * OrcVIO::pruneImuStateBuffer (:2803-2851): featureJacobian_msckf ->
+ * nullspace_project_inplace_svd -> gatingTestFeature -> stack -> QR compression ->
+ * measurementUpdate_{hybrid(pure MSCKF case),msckf}.  Host buffers in, host buffers out;
+ * P is n x n with n = leg_dim + 6*n_clones. */
+int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
+                                     const orcvio_msckf_window* window,
+                                     const orcvio_msckf_tracks* tracks, const double* P,
+                                     orcvio_msckf_result* result);
+
+/* Object update: replaces OrcVIO::removeLostObjects (src/orcvio.cpp:2154-2193) for one
+ * object block (nullspace projection against Hf -> gate with dof = rows -> NaN check ->
+ * measurementUpdate_msckf).  result->accept/gamma have length 1. */
+int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
+                                    int32_t n_clones, const orcvio_msckf_object_rows* rows,
+                                    int32_t n_objects, const double* P,
+                                    orcvio_msckf_result* result);
+
+/* ---- staged, device-resident form (what bench.py times; also the multi-GPU path) ----
+ * upload:      copy window / tracks / P to the handle's device buffers (host -> HBM);
+ * run_local:   Jacobians -> nullspace -> gate -> stacked [H'|r'] -> Gram compression.
+ *              Leaves this rank's compressed block [A | b] ((n-14) x (n-14), symmetric,
+ *              row-major, padded to a multiple of 16) in device memory;
+ * block_ptr:   device pointer / element count of that block (for an RCCL all-gather);
+ * run_finish:  sums `n_blocks` compressed blocks found at d_blocks (device pointer,
+ *              consecutive, same size) and performs the Kalman solve: dx, P+ on device;
+ * run_update:  run_local + run_finish on the handle's own block (single GPU);
+ * download:    copy results to host buffers.
+ * `stream` is a hipStream_t passed as void* (NULL = the handle's own stream). */
+int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
+                            const orcvio_msckf_window* window, const orcvio_msckf_tracks* tracks,
+                            const double* P);
+int32_t orcvio_msckf_run_local(orcvio_msckf_handle* h, void* stream);
+int32_t orcvio_msckf_block_ptr(orcvio_msckf_handle* h, double** d_block, int64_t* n_elems);
+int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks,
+                                void* stream);
+int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream);
+int32_t orcvio_msckf_sync(orcvio_msckf_handle* h, void* stream);
+int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* result);
+
+/* Per-kernel device time of the last run_update, measured with HIP events on the launch
+ * stream.  names[i] / ms[i] for i < *count (count in: capacity, out: filled). */
+int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_t reps,
+                                    const char** names, double* ms, int32_t* count);
+
+/* State correction: replaces OrcVIO::incrementState_IMUCam (src/orcvio.cpp:4468-4567).
+ * Pure host arithmetic (15 + 6N small updates); returns 1 if the correction was applied,
+ * 0 if the reference's large-update test discarded it. */
+typedef struct orcvio_msckf_state {
+    double R_b2w_imu[9]; /* current IMU orientation (row-major) */
+    double v[3], p[3], bg[3], ba[3];
+    double R_b2c[9], t_c_b[3]; /* extrinsics of the current IMU state */
+    double td;
+    double imu_intrinsics[24]; /* T1..M2 when leg_dim == 46 */
+    int32_t n_clones;
+    double* clone_R_b2w; /* [N][9] in/out */
+    double* clone_t_b_w; /* [N][3] in/out */
+    double* clone_R_c2w; /* [N][9] out: orientation_cam */
+    double* clone_t_c_w; /* [N][3] out: position_cam    */
+} orcvio_msckf_state;
+int32_t orcvio_msckf_increment_state(const orcvio_msckf_flags* flags, const double* dx,
+                                     orcvio_msckf_state* state);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORCVIO_MSCKF_H */

@@ -1,0 +1,279 @@
+"""ctypes binding of the C-ABI in include/orcvio_msckf.h (plumbing only).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``orcvio_amd.build.build_library()`` into ``orcvio_amd/lib/liborcvio_msckf.so``.
+There is no CPU fallback: if the shared object is missing, or no gfx950 device is
+visible, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'liborcvio_msckf.so')
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+STATUS = {0: 'OK', 1: 'ERR_INVALID', 2: 'ERR_NO_DEVICE', 3: 'ERR_CAPACITY', 4: 'ERR_TRACK_TOO_LONG',
+          5: 'ERR_HIP', 6: 'ERR_NOT_SPD'}
+
+# every symbol include/orcvio_msckf.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    'orcvio_msckf_abi_version', 'orcvio_msckf_last_error', 'orcvio_msckf_chi2_quantile',
+    'orcvio_msckf_create', 'orcvio_msckf_destroy', 'orcvio_msckf_update_features',
+    'orcvio_msckf_update_objects', 'orcvio_msckf_upload', 'orcvio_msckf_run_local',
+    'orcvio_msckf_block_ptr', 'orcvio_msckf_run_finish', 'orcvio_msckf_run_update',
+    'orcvio_msckf_sync', 'orcvio_msckf_download', 'orcvio_msckf_profile_update',
+    'orcvio_msckf_increment_state',
+]
+
+
+class MsckfFlags(C.Structure):
+    _fields_ = [('leg_dim', C.c_int32), ('use_larvio', C.c_int32), ('use_left_perturbation', C.c_int32),
+                ('if_fej', C.c_int32), ('estimate_td', C.c_int32), ('discard_large_update', C.c_int32),
+                ('noise_feature', C.c_double), ('chi2_prob', C.c_double)]
+
+
+class MsckfWindow(C.Structure):
+    _fields_ = [('n_clones', C.c_int32), ('R_b2w', _dp), ('t_b_w', _dp), ('t_fej', _dp), ('R_b2c', _dp), ('t_c_b', _dp)]
+
+
+class MsckfTracks(C.Structure):
+    _fields_ = [('n_features', C.c_int32), ('p_w', _dp), ('obs_ptr', _ip), ('obs_clone', _ip), ('obs_z', _dp),
+                ('obs_zvel', _dp)]
+
+
+class MsckfObjectRows(C.Structure):
+    _fields_ = [('n_rows', C.c_int32), ('n_obj_cols', C.c_int32), ('row_clone', _ip), ('Hx6', _dp), ('Hf', _dp),
+                ('res', _dp)]
+
+
+class MsckfResult(C.Structure):
+    _fields_ = [('dx', _dp), ('P_out', _dp), ('accept', _ip), ('gamma', _dp), ('H_thin', _dp), ('r_thin', _dp),
+                ('K', _dp), ('G', _dp), ('stats', C.c_int32 * 8)]
+
+
+class MsckfState(C.Structure):
+    _fields_ = [('R_b2w_imu', C.c_double * 9), ('v', C.c_double * 3), ('p', C.c_double * 3), ('bg', C.c_double * 3),
+                ('ba', C.c_double * 3), ('R_b2c', C.c_double * 9), ('t_c_b', C.c_double * 3), ('td', C.c_double),
+                ('imu_intrinsics', C.c_double * 24), ('n_clones', C.c_int32), ('clone_R_b2w', _dp),
+                ('clone_t_b_w', _dp), ('clone_R_c2w', _dp), ('clone_t_c_w', _dp)]
+
+
+_LIB = None
+
+
+def load():
+    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)')
+    lib = C.CDLL(LIB_PATH)
+    lib.orcvio_msckf_abi_version.restype = C.c_int32
+    lib.orcvio_msckf_last_error.restype = C.c_char_p
+    lib.orcvio_msckf_chi2_quantile.restype = C.c_double
+    lib.orcvio_msckf_chi2_quantile.argtypes = [C.c_int32, C.c_double]
+    lib.orcvio_msckf_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.orcvio_msckf_destroy.argtypes = [C.c_void_p]
+    lib.orcvio_msckf_destroy.restype = None
+    lib.orcvio_msckf_update_features.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(MsckfWindow),
+                                                 C.POINTER(MsckfTracks), _dp, C.POINTER(MsckfResult)]
+    lib.orcvio_msckf_update_objects.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.c_int32,
+                                                C.POINTER(MsckfObjectRows), C.c_int32, _dp, C.POINTER(MsckfResult)]
+    lib.orcvio_msckf_upload.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(MsckfWindow),
+                                        C.POINTER(MsckfTracks), _dp]
+    lib.orcvio_msckf_run_local.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orcvio_msckf_block_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.orcvio_msckf_run_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.orcvio_msckf_run_update.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orcvio_msckf_sync.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orcvio_msckf_download.argtypes = [C.c_void_p, C.POINTER(MsckfResult)]
+    lib.orcvio_msckf_profile_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), _dp,
+                                                C.POINTER(C.c_int32)]
+    lib.orcvio_msckf_increment_state.argtypes = [C.POINTER(MsckfFlags), _dp, C.POINTER(MsckfState)]
+    _LIB = lib
+    return lib
+
+
+class MsckfError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = load().orcvio_msckf_last_error().decode(errors='replace')
+        super().__init__(f'{where}: {STATUS.get(code, code)}: {msg}')
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def make_flags(f) -> MsckfFlags:
+    return MsckfFlags(int(f.leg_dim), int(f.use_larvio), int(f.use_left_perturbation), int(f.if_fej),
+                      int(f.estimate_td), int(f.discard_large_update), float(f.noise_feature), float(f.chi2_prob))
+
+
+class MsckfUpdater:
+    """Thin owner of one ``orcvio_msckf_handle`` taking ``synth.Window``-shaped inputs."""
+
+    def __init__(self, device=0, max_clones=32, max_features=2048, max_observations=65536):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.orcvio_msckf_create(device, max_clones, max_features, max_observations, C.byref(self.h))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_create')
+        self._keep = None
+        self.n = None
+        self.F = None
+
+    def close(self):
+        if self.h:
+            self.lib.orcvio_msckf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- argument marshalling -------------------------------------------------------------
+    def _structs(self, win):
+        fl = make_flags(win.flags)
+        arrs = dict(R_b2w=np.ascontiguousarray(win.R_b2w, dtype=np.float64),
+                    t_b_w=np.ascontiguousarray(win.t_b_w, dtype=np.float64),
+                    t_fej=np.ascontiguousarray(win.t_fej, dtype=np.float64),
+                    R_b2c=np.ascontiguousarray(win.R_b2c, dtype=np.float64),
+                    t_c_b=np.ascontiguousarray(win.t_c_b, dtype=np.float64),
+                    p_w=np.ascontiguousarray(win.p_w, dtype=np.float64),
+                    obs_ptr=np.ascontiguousarray(win.obs_ptr, dtype=np.int32),
+                    obs_clone=np.ascontiguousarray(win.obs_clone, dtype=np.int32),
+                    obs_z=np.ascontiguousarray(win.obs_z, dtype=np.float64),
+                    obs_zvel=np.ascontiguousarray(win.obs_zvel, dtype=np.float64),
+                    P=np.ascontiguousarray(win.P, dtype=np.float64))
+        w = MsckfWindow(win.N, _d(arrs['R_b2w']), _d(arrs['t_b_w']), _d(arrs['t_fej']), _d(arrs['R_b2c']),
+                        _d(arrs['t_c_b']))
+        t = MsckfTracks(win.F, _d(arrs['p_w']), _i(arrs['obs_ptr']), _i(arrs['obs_clone']), _d(arrs['obs_z']),
+                        _d(arrs['obs_zvel']))
+        return fl, w, t, arrs
+
+    def _result(self, n, F, want_K=False, want_G=False, want_thin=False):
+        out = dict(dx=np.zeros(n), P_new=np.zeros((n, n)), accept=np.zeros(max(F, 1), dtype=np.int32),
+                   gamma=np.zeros(max(F, 1)))
+        if want_thin:
+            out['H_thin'] = np.zeros((n - 15, n))
+            out['r_thin'] = np.zeros(n - 15)
+        if want_K:
+            out['K'] = np.zeros((n, n - 15))
+        if want_G:
+            out['G'] = np.zeros((n, n))
+        res = MsckfResult(_d(out['dx']), _d(out['P_new']), _i(out['accept']), _d(out['gamma']),
+                          _d(out.get('H_thin')), _d(out.get('r_thin')), _d(out.get('K')), _d(out.get('G')))
+        return out, res
+
+    @staticmethod
+    def _finish(out, res, F):
+        out['accept'] = out['accept'][:F]
+        out['gamma'] = out['gamma'][:F]
+        out['stats'] = np.array(list(res.stats), dtype=np.int32)
+        out['updated'] = bool(out['stats'][3])
+        return out
+
+    # -- one-shot host-buffer update (the reference call sites) ---------------------------
+    def update_features(self, win, want_K=False, want_G=False, want_thin=False):
+        fl, w, t, arrs = self._structs(win)
+        out, res = self._result(win.n, win.F, want_K, want_G, want_thin)
+        rc = self.lib.orcvio_msckf_update_features(self.h, C.byref(fl), C.byref(w), C.byref(t), _d(arrs['P']),
+                                                   C.byref(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_update_features')
+        return self._finish(out, res, win.F)
+
+    # -- staged, device-resident form -----------------------------------------------------
+    def upload(self, win):
+        fl, w, t, arrs = self._structs(win)
+        rc = self.lib.orcvio_msckf_upload(self.h, C.byref(fl), C.byref(w), C.byref(t), _d(arrs['P']))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_upload')
+        self.n, self.F = win.n, win.F
+
+    def run_update(self, stream=None):
+        rc = self.lib.orcvio_msckf_run_update(self.h, C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_run_update')
+
+    def run_local(self, stream=None):
+        rc = self.lib.orcvio_msckf_run_local(self.h, C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_run_local')
+
+    def block_ptr(self):
+        p = C.c_void_p()
+        ne = C.c_int64()
+        rc = self.lib.orcvio_msckf_block_ptr(self.h, C.byref(p), C.byref(ne))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_block_ptr')
+        return p.value, ne.value
+
+    def run_finish(self, d_blocks, n_blocks, stream=None):
+        rc = self.lib.orcvio_msckf_run_finish(self.h, C.c_void_p(d_blocks), n_blocks,
+                                              C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_run_finish')
+
+    def sync(self, stream=None):
+        rc = self.lib.orcvio_msckf_sync(self.h, C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_sync')
+
+    def download(self, want_K=False, want_G=False, want_thin=False):
+        out, res = self._result(self.n, self.F, want_K, want_G, want_thin)
+        rc = self.lib.orcvio_msckf_download(self.h, C.byref(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_download')
+        return self._finish(out, res, self.F)
+
+    def profile(self, reps=20, stream=None):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        cnt = C.c_int32(16)
+        rc = self.lib.orcvio_msckf_profile_update(self.h, C.c_void_p(stream) if stream else None, reps, names, ms,
+                                                  C.byref(cnt))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_profile_update')
+        return {names[i].decode(): ms[i] for i in range(cnt.value)}
+
+
+def chi2_quantile(dof, prob=0.95):
+    return float(load().orcvio_msckf_chi2_quantile(int(dof), float(prob)))
+
+
+def debug_read(upd: MsckfUpdater, which: str):
+    """Test helper: copies an intermediate device buffer of the last run to the host."""
+    lib = upd.lib
+    lib.orcvio_msckf_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    dims = np.zeros(8, dtype=np.int32)
+    rc = lib.orcvio_msckf_debug_read(upd.h, 7, dims.ctypes.data_as(C.c_void_p), dims.nbytes)
+    if rc != 0:
+        raise MsckfError(rc, 'debug_read dims')
+    n, NA, NAP, ldt, m_tot = (int(x) for x in dims[:5])
+    if which == 'dims':
+        return dict(n=n, NA=NA, NAP=NAP, ldt=ldt, m_tot=m_tot, Mmax=int(dims[5]), chunks=int(dims[6]),
+                    rows_per_chunk=int(dims[7]))
+    shapes = {'Hs': (0, (m_tot, NAP)), 'Ab': (1, (NAP, NAP)), 'La': (2, (NAP, NAP)), 'T': (3, (NA, ldt)),
+              'S': (4, (NAP, NAP)), 'Z': (5, (NA, ldt)), 'Gpart0': (6, (NAP, NAP))}
+    code, shape = shapes[which]
+    out = np.zeros(shape)
+    if out.size:
+        rc = lib.orcvio_msckf_debug_read(upd.h, code, out.ctypes.data_as(C.c_void_p), out.nbytes)
+        if rc != 0:
+            raise MsckfError(rc, f'debug_read {which}')
+    return out

@@ -1,0 +1,676 @@
+// msckf_capi.hip -- C-ABI (include/orcvio_msckf.h) over the gfx950 kernels.
+// No CPU fallback exists: every compute entry point fails with ORCVIO_ERR_NO_DEVICE /
+// ORCVIO_ERR_HIP when the HIP runtime or a gfx950 device is missing.
+#include "../../include/orcvio_msckf.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "msckf_kernels.hpp"
+
+using namespace orcvio_amd;
+
+static thread_local std::string g_last_error;
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                \
+            return ORCVIO_ERR_HIP;                                                           \
+        }                                                                                    \
+    } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct orcvio_msckf_handle {
+    int device = 0;
+    int maxN = 0, maxF = 0, maxObs = 0;
+    int n_max = 0, NAP_max = 0;
+    hipStream_t stream = nullptr;
+    // problem of the current upload
+    orcvio_msckf_flags flags{};
+    int N = 0, F = 0, nobs = 0, n = 0, NA = 0, NAP = 0, ldt = 0, m_tot = 0, Mmax = 0;
+    int chunks = 0, rows_per_chunk = 0;
+    bool uploaded = false, ran = false;
+    // device buffers
+    double *d_poses = nullptr, *d_pw = nullptr, *d_obs_z = nullptr, *d_obs_zvel = nullptr, *d_P = nullptr;
+    int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_nzero = nullptr;
+    double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_La = nullptr;
+    double *d_Dinv1 = nullptr, *d_Dinv2 = nullptr, *d_T = nullptr, *d_S = nullptr, *d_Z = nullptr, *d_Pout = nullptr, *d_dx = nullptr;
+    size_t hs_rows_cap = 0;
+    int gram_chunks_cap = 64;
+    // host staging
+    std::vector<double> h_poses, h_chi2;
+    std::vector<int> h_row_ptr;
+    double chi2_prob_cached = -1.0;
+};
+
+extern "C" {
+
+int32_t orcvio_msckf_abi_version(void) { return ORCVIO_MSCKF_ABI_VERSION; }
+const char* orcvio_msckf_last_error(void) { return g_last_error.c_str(); }
+
+// ---- chi-square quantile (replaces boost::math::quantile, src/orcvio.cpp:486-494) --------
+static double reg_lower_gamma(double a, double x) {
+    if (x <= 0.0) return 0.0;
+    const double lg = std::lgamma(a);
+    if (x < a + 1.0) {   // series
+        double term = 1.0 / a, sum = term, ap = a;
+        for (int i = 0; i < 200000; ++i) {
+            ap += 1.0;
+            term *= x / ap;
+            sum += term;
+            if (std::fabs(term) < std::fabs(sum) * 1e-17) break;
+        }
+        return sum * std::exp(a * std::log(x) - x - lg);
+    }
+    // modified Lentz continued fraction for Q(a,x)
+    const double tiny = 1e-300;
+    double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
+    for (int i = 1; i < 200000; ++i) {
+        const double an = -(double)i * ((double)i - a);
+        b += 2.0;
+        d = an * d + b;
+        if (std::fabs(d) < tiny) d = tiny;
+        c = b + an / c;
+        if (std::fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (std::fabs(del - 1.0) < 1e-16) break;
+    }
+    return 1.0 - std::exp(a * std::log(x) - x - lg) * h;
+}
+
+double orcvio_msckf_chi2_quantile(int32_t dof, double prob) {
+    if (dof < 1 || !(prob > 0.0 && prob < 1.0)) return NAN;
+    const double a = 0.5 * dof;
+    // normal quantile by bisection, Wilson-Hilferty start, then safeguarded Newton
+    double zl = -12.0, zh = 12.0;
+    for (int i = 0; i < 100; ++i) {
+        const double zm = 0.5 * (zl + zh);
+        if (0.5 * std::erfc(-zm / std::sqrt(2.0)) < prob) zl = zm; else zh = zm;
+    }
+    const double zq = 0.5 * (zl + zh);
+    const double wh = 1.0 - 2.0 / (9.0 * dof) + zq * std::sqrt(2.0 / (9.0 * dof));
+    double x = dof * wh * wh * wh;
+    if (!(x > 0.0)) x = 1e-3;
+    double lo = 0.0, hi = 4.0 * x + 60.0;
+    for (int it = 0; it < 300; ++it) {
+        const double f = reg_lower_gamma(a, 0.5 * x) - prob;
+        if (f > 0.0) hi = x; else lo = x;
+        const double lpdf = (a - 1.0) * std::log(0.5 * x) - 0.5 * x - std::lgamma(a) - std::log(2.0);
+        double xn = x - f / std::exp(lpdf);
+        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+        const bool done = std::fabs(xn - x) <= 1e-15 * std::fabs(x);
+        x = xn;
+        if (done) break;
+    }
+    return x;
+}
+
+// ---- create / destroy ---------------------------------------------------------------------
+static void free_all(orcvio_msckf_handle* h) {
+    void* ptrs[] = {h->d_poses, h->d_pw, h->d_obs_z, h->d_obs_zvel, h->d_P, h->d_obs_ptr, h->d_obs_clone, h->d_row_ptr,
+                    h->d_accept, h->d_nzero, h->d_chi2, h->d_Hs, h->d_gamma, h->d_Gpart, h->d_Ab, h->d_La, h->d_Dinv1,
+                    h->d_Dinv2, h->d_T, h->d_S, h->d_Z, h->d_Pout, h->d_dx};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_features, int32_t max_observations,
+                            orcvio_msckf_handle** out) {
+    if (!out || max_clones < 1 || max_clones > ORCVIO_MAX_CLONES || max_features < 1 || max_observations < 1) {
+        g_last_error = "orcvio_msckf_create: invalid capacity";
+        return ORCVIO_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_last_error = "orcvio_msckf_create: no HIP device (this library has no CPU path)";
+        return ORCVIO_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        g_last_error = "hipGetDeviceProperties failed";
+        return ORCVIO_ERR_NO_DEVICE;
+    }
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_last_error = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+        return ORCVIO_ERR_NO_DEVICE;
+    }
+    auto* h = new orcvio_msckf_handle();
+    h->device = device;
+    h->maxN = max_clones;
+    h->maxF = max_features;
+    h->maxObs = max_observations;
+    h->n_max = 46 + 6 * max_clones;
+    h->NAP_max = round_up(h->n_max - 15 + 1, 16);
+    if (h->NAP_max > POTRF_MAXN || h->NAP_max / 16 > TRSM_MAXBLK) {
+        delete h;
+        g_last_error = "orcvio_msckf_create: window too large for the single-workgroup factorisation";
+        return ORCVIO_ERR_CAPACITY;
+    }
+    int rc = [&]() -> int {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        const size_t nn = (size_t)h->n_max * h->n_max, pp = (size_t)h->NAP_max * h->NAP_max;
+        const size_t ldt = (size_t)round_up(h->n_max + 1, 16);
+        h->hs_rows_cap = (size_t)2 * max_observations + 16;
+        HIPCHK(hipMalloc(&h->d_poses, sizeof(double) * POSE_STRIDE * max_clones));
+        HIPCHK(hipMalloc(&h->d_pw, sizeof(double) * 3 * max_features));
+        HIPCHK(hipMalloc(&h->d_obs_z, sizeof(double) * 2 * max_observations));
+        HIPCHK(hipMalloc(&h->d_obs_zvel, sizeof(double) * 2 * max_observations));
+        HIPCHK(hipMalloc(&h->d_P, sizeof(double) * nn));
+        HIPCHK(hipMalloc(&h->d_obs_ptr, sizeof(int) * (max_features + 1)));
+        HIPCHK(hipMalloc(&h->d_obs_clone, sizeof(int) * max_observations));
+        HIPCHK(hipMalloc(&h->d_row_ptr, sizeof(int) * (max_features + 1)));
+        HIPCHK(hipMalloc(&h->d_accept, sizeof(int) * max_features));
+        HIPCHK(hipMalloc(&h->d_nzero, sizeof(int) * 4));
+        HIPCHK(hipMalloc(&h->d_chi2, sizeof(double) * ORCVIO_CHI2_TABLE));
+        HIPCHK(hipMalloc(&h->d_Hs, sizeof(double) * h->hs_rows_cap * h->NAP_max));
+        HIPCHK(hipMalloc(&h->d_gamma, sizeof(double) * max_features));
+        HIPCHK(hipMalloc(&h->d_Gpart, sizeof(double) * pp * h->gram_chunks_cap));
+        HIPCHK(hipMalloc(&h->d_Ab, sizeof(double) * pp));
+        HIPCHK(hipMalloc(&h->d_La, sizeof(double) * pp));
+        HIPCHK(hipMalloc(&h->d_Dinv1, sizeof(double) * 256 * TRSM_MAXBLK));
+        HIPCHK(hipMalloc(&h->d_Dinv2, sizeof(double) * 256 * TRSM_MAXBLK));
+        HIPCHK(hipMalloc(&h->d_T, sizeof(double) * h->NAP_max * ldt));
+        HIPCHK(hipMalloc(&h->d_S, sizeof(double) * pp));
+        HIPCHK(hipMalloc(&h->d_Z, sizeof(double) * h->NAP_max * ldt));
+        HIPCHK(hipMalloc(&h->d_Pout, sizeof(double) * nn));
+        HIPCHK(hipMalloc(&h->d_dx, sizeof(double) * h->n_max));
+        HIPCHK(hipMemset(h->d_nzero, 0, sizeof(int) * 4));
+        HIPCHK(hipMemset(h->d_obs_zvel, 0, sizeof(double) * 2 * max_observations));
+        // opt in to large dynamic LDS for the feature kernel instantiations
+        const int lds_max = 160 * 1024;
+        HIPCHK(hipFuncSetAttribute((const void*)k_feature<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        HIPCHK(hipFuncSetAttribute((const void*)k_feature<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        HIPCHK(hipFuncSetAttribute((const void*)k_feature<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        HIPCHK(hipFuncSetAttribute((const void*)k_feature<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        HIPCHK(hipFuncSetAttribute((const void*)k_feature<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        HIPCHK(hipFuncSetAttribute((const void*)k_feature<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        HIPCHK(hipFuncSetAttribute((const void*)k_feature<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        return ORCVIO_OK;
+    }();
+    if (rc != ORCVIO_OK) {
+        free_all(h);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return ORCVIO_OK;
+}
+
+void orcvio_msckf_destroy(orcvio_msckf_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    free_all(h);
+    delete h;
+}
+
+// ---- upload --------------------------------------------------------------------------------
+int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
+                            const orcvio_msckf_tracks* tr, const double* P) {
+    if (!h || !flags || !w || !tr || !P || !w->R_b2w || !w->t_b_w || !w->R_b2c || !w->t_c_b || !tr->obs_ptr) {
+        g_last_error = "orcvio_msckf_upload: null argument";
+        return ORCVIO_ERR_INVALID;
+    }
+    if (flags->leg_dim != 22 && flags->leg_dim != 46) {
+        g_last_error = "orcvio_msckf_upload: leg_dim must be 22 or 46";
+        return ORCVIO_ERR_INVALID;
+    }
+    const int N = w->n_clones, F = tr->n_features;
+    if (N < 1 || F < 0) { g_last_error = "orcvio_msckf_upload: bad sizes"; return ORCVIO_ERR_INVALID; }
+    if (N > h->maxN || F > h->maxF) { g_last_error = "orcvio_msckf_upload: exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
+    const int nobs = F > 0 ? tr->obs_ptr[F] : 0;
+    if (nobs > h->maxObs) { g_last_error = "orcvio_msckf_upload: too many observations"; return ORCVIO_ERR_CAPACITY; }
+    if (F > 0 && (!tr->p_w || !tr->obs_clone || !tr->obs_z)) { g_last_error = "orcvio_msckf_upload: null track arrays"; return ORCVIO_ERR_INVALID; }
+    if (flags->estimate_td && F > 0 && !tr->obs_zvel) { g_last_error = "orcvio_msckf_upload: obs_zvel required with estimate_td"; return ORCVIO_ERR_INVALID; }
+    // row offsets, track-length limits, index validation
+    h->h_row_ptr.assign(F + 1, 0);
+    int Mmax = 2;
+    for (int j = 0; j < F; ++j) {
+        const int M = tr->obs_ptr[j + 1] - tr->obs_ptr[j];
+        if (M < 0) { g_last_error = "orcvio_msckf_upload: obs_ptr not monotone"; return ORCVIO_ERR_INVALID; }
+        if (M > ORCVIO_MAX_TRACK) { g_last_error = "orcvio_msckf_upload: track longer than ORCVIO_MAX_TRACK"; return ORCVIO_ERR_TRACK_TOO_LONG; }
+        if (M > Mmax) Mmax = M;
+        h->h_row_ptr[j + 1] = h->h_row_ptr[j] + (M >= 2 ? 2 * M - 3 : 0);
+    }
+    for (int o = 0; o < nobs; ++o)
+        if (tr->obs_clone[o] < 0 || tr->obs_clone[o] >= N) { g_last_error = "orcvio_msckf_upload: obs_clone out of range"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    h->flags = *flags;
+    h->N = N; h->F = F; h->nobs = nobs;
+    h->n = flags->leg_dim + 6 * N;
+    h->NA = h->n - 15;
+    h->NAP = round_up(h->NA + 1, 16);
+    h->ldt = round_up(h->n + 1, 16);
+    h->m_tot = h->h_row_ptr[F];
+    h->Mmax = Mmax;
+    // chi-square table (src/orcvio.cpp:481-494)
+    if (h->chi2_prob_cached != flags->chi2_prob) {
+        h->h_chi2.assign(ORCVIO_CHI2_TABLE, 0.0);
+        for (int d = 1; d < ORCVIO_CHI2_TABLE; ++d) h->h_chi2[d] = orcvio_msckf_chi2_quantile(d, flags->chi2_prob);
+        HIPCHK(hipMemcpyAsync(h->d_chi2, h->h_chi2.data(), sizeof(double) * ORCVIO_CHI2_TABLE, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->chi2_prob_cached = flags->chi2_prob;
+    }
+    // pose records
+    h->h_poses.assign((size_t)POSE_STRIDE * N, 0.0);
+    const double* tfej = w->t_fej ? w->t_fej : w->t_b_w;
+    for (int i = 0; i < N; ++i) {
+        double* r = &h->h_poses[(size_t)POSE_STRIDE * i];
+        std::memcpy(r + POSE_R_B2W, w->R_b2w + 9 * i, 9 * sizeof(double));
+        std::memcpy(r + POSE_T_B_W, w->t_b_w + 3 * i, 3 * sizeof(double));
+        std::memcpy(r + POSE_T_FEJ, tfej + 3 * i, 3 * sizeof(double));
+        std::memcpy(r + POSE_R_B2C, w->R_b2c + 9 * i, 9 * sizeof(double));
+        std::memcpy(r + POSE_T_C_B, w->t_c_b + 3 * i, 3 * sizeof(double));
+    }
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_poses, h->h_poses.data(), sizeof(double) * POSE_STRIDE * N, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)h->n * h->n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_obs_ptr, tr->obs_ptr, sizeof(int) * (F + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_row_ptr, h->h_row_ptr.data(), sizeof(int) * (F + 1), hipMemcpyHostToDevice, s));
+    if (F > 0) {
+        HIPCHK(hipMemcpyAsync(h->d_pw, tr->p_w, sizeof(double) * 3 * F, hipMemcpyHostToDevice, s));
+        if (nobs > 0) {
+            HIPCHK(hipMemcpyAsync(h->d_obs_clone, tr->obs_clone, sizeof(int) * nobs, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(h->d_obs_z, tr->obs_z, sizeof(double) * 2 * nobs, hipMemcpyHostToDevice, s));
+            if (tr->obs_zvel) HIPCHK(hipMemcpyAsync(h->d_obs_zvel, tr->obs_zvel, sizeof(double) * 2 * nobs, hipMemcpyHostToDevice, s));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    // Gram chunking: enough (chunk, tile) wavefronts to fill 256 CUs
+    const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
+    int chunks = (2048 + ntiles - 1) / ntiles;
+    if (chunks > h->gram_chunks_cap) chunks = h->gram_chunks_cap;
+    if (chunks < 1) chunks = 1;
+    int rpc = round_up((h->m_tot + chunks - 1) / chunks, 8);
+    if (rpc < 8) rpc = 8;
+    h->rows_per_chunk = rpc;
+    h->chunks = h->m_tot > 0 ? (h->m_tot + rpc - 1) / rpc : 1;
+    h->uploaded = true;
+    h->ran = false;
+    return ORCVIO_OK;
+}
+
+// ---- launches --------------------------------------------------------------------------------
+static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
+    if (h->F == 0) return ORCVIO_OK;
+    FeatArgs a;
+    a.poses = h->d_poses; a.p_w = h->d_pw; a.obs_ptr = h->d_obs_ptr; a.obs_clone = h->d_obs_clone;
+    a.obs_z = h->d_obs_z; a.obs_zvel = h->d_obs_zvel; a.P = h->d_P; a.row_ptr = h->d_row_ptr; a.chi2 = h->d_chi2;
+    a.Hs = h->d_Hs; a.gamma = h->d_gamma; a.accept = h->d_accept;
+    a.sigma2 = h->flags.noise_feature * h->flags.noise_feature;
+    a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP; a.Mmax = h->Mmax; a.F = h->F;
+    a.use_larvio = h->flags.use_larvio; a.use_left = h->flags.use_left_perturbation; a.if_fej = h->flags.if_fej;
+    a.estimate_td = h->flags.estimate_td;
+    const size_t lds = feat_lds_bytes(h->Mmax, h->NAP, h->N);
+    const int npass = (h->NAP + 63) / 64;
+    dim3 grid(h->F), block(64);
+    switch (npass) {
+        case 1: hipLaunchKernelGGL(k_feature<1>, grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL(k_feature<2>, grid, block, lds, s, a); break;
+        case 3: hipLaunchKernelGGL(k_feature<3>, grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL(k_feature<4>, grid, block, lds, s, a); break;
+        case 5: hipLaunchKernelGGL(k_feature<5>, grid, block, lds, s, a); break;
+        case 6: hipLaunchKernelGGL(k_feature<6>, grid, block, lds, s, a); break;
+        case 7: hipLaunchKernelGGL(k_feature<7>, grid, block, lds, s, a); break;
+        default: g_last_error = "window too wide for k_feature"; return ORCVIO_ERR_CAPACITY;
+    }
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+static int launch_gram(orcvio_msckf_handle* h, hipStream_t s) {
+    const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
+    if (h->m_tot == 0) {
+        HIPCHK(hipMemsetAsync(h->d_Gpart, 0, sizeof(double) * (size_t)h->NAP * h->NAP, s));
+        return ORCVIO_OK;
+    }
+    dim3 grid((ntiles + 3) / 4, h->chunks), block(256);
+    hipLaunchKernelGGL(k_gram, grid, block, 0, s, h->d_Hs, h->m_tot, h->NAP, h->rows_per_chunk, h->d_Gpart);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+static int launch_reduce(orcvio_msckf_handle* h, hipStream_t s, const double* parts, int nparts, double* dst) {
+    const int total = h->NAP * h->NAP;
+    hipLaunchKernelGGL(k_gram_reduce, dim3((total + 255) / 256), dim3(256), 0, s, parts, nparts, (size_t)total, h->NAP, dst);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+enum { ST_POTRF_A = 0, ST_FORM_T, ST_FORM_S, ST_POTRF_S, ST_TRSM, ST_FINISH, ST_COUNT };
+
+static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) {
+    const int NA = h->NA, NAP = h->NAP, n = h->n, ldt = h->ldt;
+    const double sigma2 = h->flags.noise_feature * h->flags.noise_feature;
+    switch (stage) {
+        case ST_POTRF_A:
+            hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, h->d_La, NA + 1, NAP, (double)(NA + 1) * 2.220446049250313e-16,
+                               h->d_Dinv1, h->d_nzero);
+            break;
+        case ST_FORM_T: {
+            const int tiles = ((NA + 15) / 16) * ((n + 1 + 15) / 16);
+            hipLaunchKernelGGL(k_form_T, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_La, NAP, h->d_P, n, NA, h->d_T, ldt);
+            break;
+        }
+        case ST_FORM_S: {
+            const int nb = (NA + 15) / 16, tiles = nb * (nb + 1) / 2;
+            hipLaunchKernelGGL(k_form_S, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_T, ldt, h->d_La, NAP, NA, sigma2, h->d_S, NAP);
+            break;
+        }
+        case ST_POTRF_S:
+            hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, h->d_S, NA, NAP, 0.0, h->d_Dinv2, h->d_nzero + 1);
+            break;
+        case ST_TRSM:
+            hipLaunchKernelGGL(k_trsm, dim3((n + 1 + 15) / 16), dim3(64), 0, s, h->d_S, NAP, h->d_Dinv2, NA, h->d_T, ldt, n + 1,
+                               h->d_Z, ldt);
+            break;
+        case ST_FINISH: {
+            const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
+            hipLaunchKernelGGL(k_finish, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_Z, ldt, NA, h->d_P, n, h->d_Pout, h->d_dx);
+            break;
+        }
+        default: return ORCVIO_ERR_INVALID;
+    }
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+static int launch_finish_from(orcvio_msckf_handle* h, hipStream_t s, const double* parts, int nparts) {
+    int rc = launch_reduce(h, s, parts, nparts, h->d_La);
+    for (int st = 0; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
+    return rc;
+}
+
+static hipStream_t pick_stream(orcvio_msckf_handle* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
+
+int32_t orcvio_msckf_run_local(orcvio_msckf_handle* h, void* stream) {
+    if (!h || !h->uploaded) { g_last_error = "run_local: nothing uploaded"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    int rc = launch_feature(h, s);
+    if (rc == ORCVIO_OK) rc = launch_gram(h, s);
+    if (rc == ORCVIO_OK) rc = launch_reduce(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1, h->d_Ab);
+    return rc;
+}
+
+int32_t orcvio_msckf_block_ptr(orcvio_msckf_handle* h, double** d_block, int64_t* n_elems) {
+    if (!h || !h->uploaded || !d_block || !n_elems) { g_last_error = "block_ptr: invalid"; return ORCVIO_ERR_INVALID; }
+    *d_block = h->d_Ab;
+    *n_elems = (int64_t)h->NAP * h->NAP;
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks, void* stream) {
+    if (!h || !h->uploaded || !d_blocks || n_blocks < 1) { g_last_error = "run_finish: invalid"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = launch_finish_from(h, pick_stream(h, stream), d_blocks, n_blocks);
+    if (rc == ORCVIO_OK) h->ran = true;
+    return rc;
+}
+
+int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
+    if (!h || !h->uploaded) { g_last_error = "run_update: nothing uploaded"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    int rc = launch_feature(h, s);
+    if (rc == ORCVIO_OK) rc = launch_gram(h, s);
+    if (rc == ORCVIO_OK) rc = launch_finish_from(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1);
+    if (rc == ORCVIO_OK) h->ran = true;
+    return rc;
+}
+
+int32_t orcvio_msckf_sync(orcvio_msckf_handle* h, void* stream) {
+    if (!h) return ORCVIO_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(pick_stream(h, stream)));
+    return ORCVIO_OK;
+}
+
+// ---- download --------------------------------------------------------------------------------
+int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) {
+    if (!h || !res || !h->ran) { g_last_error = "download: no finished update"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int n = h->n, NA = h->NA, NAP = h->NAP, F = h->F, ldt = h->ldt;
+    std::vector<int> acc(F > 0 ? F : 1, 0);
+    std::vector<double> dx(n);
+    if (F > 0) HIPCHK(hipMemcpy(acc.data(), h->d_accept, sizeof(int) * F, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dx.data(), h->d_dx, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (res->dx) std::memcpy(res->dx, dx.data(), sizeof(double) * n);
+    if (res->P_out) HIPCHK(hipMemcpy(res->P_out, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+    if (res->accept && F > 0) std::memcpy(res->accept, acc.data(), sizeof(int) * F);
+    if (res->gamma && F > 0) HIPCHK(hipMemcpy(res->gamma, h->d_gamma, sizeof(double) * F, hipMemcpyDeviceToHost));
+    int nz[2] = {0, 0};
+    HIPCHK(hipMemcpy(nz, h->d_nzero, sizeof(int) * 2, hipMemcpyDeviceToHost));
+    int stacked = 0, nacc = 0;
+    for (int j = 0; j < F; ++j)
+        if (acc[j]) { stacked += h->h_row_ptr[j + 1] - h->h_row_ptr[j]; ++nacc; }
+    std::memset(res->stats, 0, sizeof(res->stats));
+    res->stats[0] = stacked;
+    res->stats[1] = stacked > 0 ? NA : 0;
+    res->stats[2] = nacc;
+    res->stats[3] = stacked > 0 ? 1 : 0;
+    if (h->flags.discard_large_update) {
+        const double nv = std::sqrt(dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
+        const double np = std::sqrt(dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8]);
+        res->stats[4] = (nv > 1.0 || np > 1.5) ? 1 : 0;   // src/orcvio.cpp:4479-4494
+    }
+    res->stats[5] = nz[0];
+    if (nz[1] != 0) { g_last_error = "S = H P H^T + sigma^2 I is not positive definite"; return ORCVIO_ERR_NOT_SPD; }
+    if (res->H_thin || res->r_thin || res->K || res->G) {
+        std::vector<double> La((size_t)NAP * NAP);
+        HIPCHK(hipMemcpy(La.data(), h->d_La, sizeof(double) * La.size(), hipMemcpyDeviceToHost));
+        if (res->H_thin) {
+            std::memset(res->H_thin, 0, sizeof(double) * (size_t)NA * n);
+            for (int i = 0; i < NA; ++i)
+                for (int k = i; k < NA; ++k) res->H_thin[(size_t)i * n + 15 + k] = La[(size_t)k * NAP + i];
+        }
+        if (res->r_thin)
+            for (int i = 0; i < NA; ++i) res->r_thin[i] = La[(size_t)NA * NAP + i];
+        if (res->K || res->G) {
+            // K^T = L_S^-T Z_n (back substitution on the host: optional diagnostic outputs)
+            std::vector<double> Ls((size_t)NAP * NAP), Z((size_t)NA * ldt);
+            HIPCHK(hipMemcpy(Ls.data(), h->d_S, sizeof(double) * Ls.size(), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(Z.data(), h->d_Z, sizeof(double) * Z.size(), hipMemcpyDeviceToHost));
+            std::vector<double> KT((size_t)NA * n);
+            for (int i = NA - 1; i >= 0; --i)
+                for (int c = 0; c < n; ++c) {
+                    double sres = Z[(size_t)i * ldt + c];
+                    for (int k = i + 1; k < NA; ++k) sres -= Ls[(size_t)k * NAP + i] * KT[(size_t)k * n + c];
+                    KT[(size_t)i * n + c] = sres / Ls[(size_t)i * NAP + i];
+                }
+            if (res->K)
+                for (int c = 0; c < n; ++c)
+                    for (int i = 0; i < NA; ++i) res->K[(size_t)c * NA + i] = KT[(size_t)i * n + c];
+            if (res->G) {
+                std::memset(res->G, 0, sizeof(double) * (size_t)n * n);
+                for (int i = 0; i < NA; ++i)
+                    for (int c = 0; c < n; ++c) {
+                        const double kv = KT[(size_t)i * n + c];
+                        if (kv == 0.0) continue;
+                        for (int k = i; k < NA; ++k) res->G[(size_t)c * n + 15 + k] += kv * La[(size_t)k * NAP + i];
+                    }
+            }
+        }
+    }
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* window,
+                                     const orcvio_msckf_tracks* tracks, const double* P, orcvio_msckf_result* result) {
+    int rc = orcvio_msckf_upload(h, flags, window, tracks, P);
+    if (rc != ORCVIO_OK) return rc;
+    rc = orcvio_msckf_run_update(h, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    rc = orcvio_msckf_sync(h, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    return orcvio_msckf_download(h, result);
+}
+
+int32_t orcvio_msckf_update_objects(orcvio_msckf_handle*, const orcvio_msckf_flags*, int32_t, const orcvio_msckf_object_rows*,
+                                    int32_t, const double*, orcvio_msckf_result*) {
+    g_last_error = "orcvio_msckf_update_objects: object rows are not built yet";
+    return ORCVIO_ERR_INVALID;
+}
+
+// ---- per-kernel profile -------------------------------------------------------------------------
+int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_t reps, const char** names, double* ms,
+                                    int32_t* count) {
+    if (!h || !h->uploaded || !names || !ms || !count || reps < 1) { g_last_error = "profile_update: invalid"; return ORCVIO_ERR_INVALID; }
+    static const char* kn[] = {"k_feature", "k_gram", "k_gram_reduce", "k_potrf(A)", "k_form_T", "k_form_S", "k_potrf(S)", "k_trsm", "k_finish"};
+    const int nk = 9;
+    if (*count < nk) { g_last_error = "profile_update: need room for 9 entries"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int k = 0; k < nk; ++k) ms[k] = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        for (int k = 0; k < nk; ++k) {
+            HIPCHK(hipEventRecord(e0, s));
+            int rc = ORCVIO_OK;
+            if (k == 0) rc = launch_feature(h, s);
+            else if (k == 1) rc = launch_gram(h, s);
+            else if (k == 2) rc = launch_reduce(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1, h->d_La);
+            else rc = launch_solve_stage(h, s, k - 3);
+            if (rc != ORCVIO_OK) return rc;
+            HIPCHK(hipEventRecord(e1, s));
+            HIPCHK(hipEventSynchronize(e1));
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, e0, e1));
+            ms[k] += t;
+        }
+    }
+    for (int k = 0; k < nk; ++k) { ms[k] /= reps; names[k] = kn[k]; }
+    *count = nk;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    h->ran = true;
+    return ORCVIO_OK;
+}
+
+// ---- incrementState_IMUCam (src/orcvio.cpp:4468-4567): host arithmetic -------------------------
+static void so3_exp(const double w[3], double R[9]) {
+    // Sophus v1.0.0 SO3d::exp: unit quaternion from the rotation vector, then to a matrix
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th = std::sqrt(th2);
+    double imag, real;
+    if (th < 1e-10) {
+        const double th4 = th2 * th2;
+        imag = 0.5 - th2 / 48.0 + th4 / 3840.0;
+        real = 1.0 - th2 / 8.0 + th4 / 384.0;
+    } else {
+        imag = std::sin(0.5 * th) / th;
+        real = std::cos(0.5 * th);
+    }
+    const double x = imag * w[0], y = imag * w[1], z = imag * w[2], q = real;
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * q); R[2] = 2 * (x * z + y * q);
+    R[3] = 2 * (x * y + z * q); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * q);
+    R[6] = 2 * (x * z - y * q); R[7] = 2 * (y * z + x * q); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void mat3_mul(const double* A, const double* B, double* C) {
+    double T[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    std::memcpy(C, T, sizeof(T));
+}
+
+int32_t orcvio_msckf_increment_state(const orcvio_msckf_flags* f, const double* dx, orcvio_msckf_state* st) {
+    if (!f || !dx || !st || !st->clone_R_b2w || !st->clone_t_b_w) { g_last_error = "increment_state: null argument"; return -1; }
+    const int leg = f->leg_dim;
+    const double nv = std::sqrt(dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
+    const double np = std::sqrt(dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8]);
+    if ((nv > 1.0 || np > 1.5) && f->discard_large_update) return 0;   // :4479-4494
+    const bool left = f->use_larvio || f->use_left_perturbation;          // :4498, :4543
+    double Rt[9];
+    so3_exp(dx, Rt);
+    if (left) mat3_mul(Rt, st->R_b2w_imu, st->R_b2w_imu); else mat3_mul(st->R_b2w_imu, Rt, st->R_b2w_imu);
+    for (int i = 0; i < 3; ++i) {
+        st->v[i] += dx[3 + i];
+        st->p[i] += dx[6 + i];
+        st->bg[i] += dx[9 + i];
+        st->ba[i] += dx[12 + i];
+    }
+    {   // extrinsic: R_b2c <- R_b2c * R(smallAngleQuaternion(dtheta))^T  (:4512-4516, math_utils.hpp:104-121)
+        double q[4] = {0.5 * dx[15], 0.5 * dx[16], 0.5 * dx[17], 0.0};
+        const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+        if (n2 <= 1.0) q[3] = std::sqrt(1.0 - n2);
+        else {
+            q[3] = 1.0;
+            const double s = 1.0 / std::sqrt(1.0 + n2);
+            for (double& v : q) v *= s;
+        }
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        // Eigen Quaterniond(w,x,y,z).toRotationMatrix() -- no normalisation, as Eigen does
+        const double Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                              2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                              2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+        double RqT[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) RqT[i * 3 + j] = Rq[j * 3 + i];
+        mat3_mul(st->R_b2c, RqT, st->R_b2c);
+        for (int i = 0; i < 3; ++i) st->t_c_b[i] += dx[18 + i];
+    }
+    st->td += dx[21];
+    if (leg == 46) for (int i = 0; i < 24; ++i) st->imu_intrinsics[i] += dx[22 + i];   // :4522-4533
+    for (int c = 0; c < st->n_clones; ++c) {
+        const double* da = dx + leg + 6 * c;
+        double* R = st->clone_R_b2w + 9 * c;
+        double* t = st->clone_t_b_w + 3 * c;
+        so3_exp(da, Rt);
+        if (left) mat3_mul(Rt, R, R); else mat3_mul(R, Rt, R);
+        for (int i = 0; i < 3; ++i) t[i] += da[3 + i];
+        if (st->clone_R_c2w) {   // orientation_cam = R_b2w * R_b2c^T (:4555-4561)
+            double RbcT[9];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) RbcT[i * 3 + j] = st->R_b2c[j * 3 + i];
+            mat3_mul(R, RbcT, st->clone_R_c2w + 9 * c);
+        }
+        if (st->clone_t_c_w)
+            for (int i = 0; i < 3; ++i)
+                st->clone_t_c_w[3 * c + i] = t[i] + R[i * 3] * st->t_c_b[0] + R[i * 3 + 1] * st->t_c_b[1] + R[i * 3 + 2] * st->t_c_b[2];
+    }
+    return 1;
+}
+
+// ---- debug access to intermediate device buffers (tests only; not part of the public header) ---
+// which: 0 Hs [m_tot x NAP], 1 Ab, 2 La, 3 T, 4 S, 5 Z, 6 Gpart (chunk 0), 7 dims -> int32[8]
+int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst, int64_t max_bytes) {
+    if (!h || !dst) return ORCVIO_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t pp = (size_t)h->NAP * h->NAP * sizeof(double);
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = h->d_Hs; bytes = (size_t)h->m_tot * h->NAP * sizeof(double); break;
+        case 1: src = h->d_Ab; bytes = pp; break;
+        case 2: src = h->d_La; bytes = pp; break;
+        case 3: src = h->d_T; bytes = (size_t)h->NA * h->ldt * sizeof(double); break;
+        case 4: src = h->d_S; bytes = pp; break;
+        case 5: src = h->d_Z; bytes = (size_t)h->NA * h->ldt * sizeof(double); break;
+        case 6: src = h->d_Gpart; bytes = pp; break;
+        case 7: {
+            int32_t dims[8] = {h->n, h->NA, h->NAP, h->ldt, h->m_tot, h->Mmax, h->chunks, h->rows_per_chunk};
+            if ((size_t)max_bytes < sizeof(dims)) return ORCVIO_ERR_INVALID;
+            std::memcpy(dst, dims, sizeof(dims));
+            return ORCVIO_OK;
+        }
+        default: return ORCVIO_ERR_INVALID;
+    }
+    if ((size_t)max_bytes < bytes) { g_last_error = "debug_read: buffer too small"; return ORCVIO_ERR_INVALID; }
+    if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return ORCVIO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,746 @@
+// msckf_kernels.hpp -- hand-written gfx950 (CDNA4) kernels of the MSCKF update path.
+//
+// Data layout in HBM (all FP64):
+//   poses  [N][28]        clone pose records (msckf_math.hpp)
+//   P      [n][n]         prior covariance (symmetric)
+//   Hs     [m][NAP]       stacked projected blocks [H' | r' | 0-pad], row-major;
+//                         column a <-> state column 15+a (a < NA = n-15), column NA = r'
+//   Gpart  [C][NAP][NAP]  per-row-chunk partial Gram matrices (lower tiles only)
+//   Ab     [NAP][NAP]     Gram block [A b; b^T c] of this rank (lower, row-major)
+//   La     [NAP][NAP]     lower Cholesky factor of the summed Gram block (R = La^T)
+//   T      [NA][ldt]      R * P[15:n, :]
+//   S      [NA][NAP]      R P_aa R^T + sigma^2 I, then its lower Cholesky factor
+//   Z      [NA][ldt]      L_S^-1 [T | r_thin]
+//
+// Kernels (one wavefront = 64 lanes everywhere):
+//   k_feature     one wavefront per feature track: Jacobians (reference
+//                 src/orcvio.cpp:1071-1226), Householder nullspace projection
+//                 (math_utils.hpp:287-312), chi-square gate (:1953-1976), coalesced
+//                 write of the projected block into Hs.
+//   k_gram        FP64-MFMA (v_mfma_f64_16x16x4_f64) tall-skinny Gram of Hs -- the
+//                 compression step of :2532-2552 in CholeskyQR form.
+//   k_gram_reduce sums partial Gram blocks (chunks of this rank, or the blocks of all
+//                 ranks after the RCCL all-gather).
+//   k_potrf       single-workgroup blocked Cholesky with MFMA trailing updates.
+//   k_gemm_*      small FP64-MFMA products of the Kalman solve (:1682-1753).
+//   k_trsm        blocked forward substitution, accumulators fed back as MFMA operands.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "msckf_math.hpp"
+
+namespace orcvio_amd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+    // D(16x16) += A(16x4) * B(4x16).  lane l: a = A[l&15][l>>4], b = B[l>>4][l&15],
+    // c[r] = C[(l>>4) + 4r][l&15]   (cdna_hip_programming.md section 3, f64 layout)
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+__device__ __forceinline__ void wave_sync() {
+    // single-wave workgroups: LDS operations of one wave execute in order; this only
+    // stops the compiler from moving LDS accesses across the point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------
+// k_feature
+// ---------------------------------------------------------------------------------------
+struct FeatArgs {
+    const double* poses;
+    const double* p_w;
+    const int* obs_ptr;
+    const int* obs_clone;
+    const double* obs_z;
+    const double* obs_zvel;
+    const double* P;
+    const int* row_ptr;   // [F+1] row offsets into Hs (rho_j = 2M_j-3, 0 if M_j < 2)
+    const double* chi2;   // [ORCVIO_CHI2_TABLE]
+    double* Hs;
+    double* gamma;
+    int* accept;
+    double sigma2;
+    int n, leg, N, NA, NAP, Mmax, F;
+    int use_larvio, use_left, if_fej, estimate_td;
+};
+
+__host__ __device__ inline int feat_lde(int Mmax) { return 2 * Mmax + 1; }
+__host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
+    const int R2 = 2 * Mmax;
+    size_t dbl = (size_t)R2 * 7 + (size_t)R2 * 6 + R2 + (size_t)R2 * 4 + (size_t)R2 * 4 + 128 + 2 * (size_t)NAP + 4 + 64 +
+                 (size_t)R2 * feat_lde(Mmax);
+    size_t bytes = dbl * 8 + (size_t)(N + Mmax) * 4;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+template <int NPASS>
+__global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int j = blockIdx.x;
+    const int t = threadIdx.x;
+    const int lo = p.obs_ptr[j];
+    const int M = p.obs_ptr[j + 1] - lo;
+    if (M < 2) {
+        if (t == 0) { p.gamma[j] = NAN; p.accept[j] = 0; }
+        return;
+    }
+    const int M2 = 2 * M;
+    const int R2 = 2 * p.Mmax;
+    const int LDE = feat_lde(p.Mmax);
+    const int NA = p.NA, NAP = p.NAP, n = p.n;
+    const int cb0 = p.leg - 15;   // active index of the first clone column
+    double* sJe = smem;               // [R2][7]  ext(6)+td
+    double* sJx = sJe + R2 * 7;       // [R2][6]
+    double* sR = sJx + R2 * 6;        // [R2]
+    double* sV = sR + R2;             // [R2][4]  Householder vectors
+    double* sX = sV + R2 * 4;         // [R2][4]
+    double* sCol = sX + R2 * 4;       // [2][64]
+    double* sU = sCol + 128;          // [NAP][2]
+    double* sYr = sU + 2 * NAP;       // [4]
+    double* sZ = sYr + 4;             // [64]
+    double* sE = sZ + 64;             // [R2][LDE]
+    int* sC2O = (int*)(sE + (size_t)R2 * LDE);   // [N]
+    int* sOC = sC2O + p.N;                        // [Mmax]
+
+    for (int i = t; i < p.N; i += 64) sC2O[i] = -1;
+    wave_sync();
+
+    // ---- B: per-observation Jacobians (lane t <-> observation t) ---------------------
+    double a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};   // rows 2t, 2t+1 of H_f
+    if (t < M) {
+        const int o = lo + t;
+        const int ci = p.obs_clone[o];
+        double Hx[12], He[12], Hf[6], rr[2];
+        double pw[3] = {p.p_w[3 * j], p.p_w[3 * j + 1], p.p_w[3 * j + 2]};
+        double z[2] = {p.obs_z[2 * o], p.obs_z[2 * o + 1]};
+        ObsFlags f{p.use_larvio, p.use_left, p.if_fej};
+        obs_jacobian(p.poses + (size_t)ci * POSE_STRIDE, pw, z, f, Hx, He, Hf, rr);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int row = 2 * t + s;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) sJe[row * 7 + e] = He[s * 6 + e];
+            sJe[row * 7 + 6] = p.estimate_td ? p.obs_zvel[2 * o + s] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sJx[row * 6 + c] = Hx[s * 6 + c];
+            sR[row] = rr[s];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a0[c] = Hf[c]; a1[c] = Hf[3 + c]; }
+        sOC[t] = ci;
+        sC2O[ci] = t;
+    }
+
+    // ---- C: Householder QR of H_f (2M x 3), LAPACK dgeqr2 convention ------------------
+    const int g0 = 2 * t, g1 = 2 * t + 1;
+    double v0[3], v1[3], beta[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double s = 0.0;
+        if (g0 > q) s += a0[q] * a0[q];
+        if (g1 > q) s += a1[q] * a1[q];
+        const double nrm2 = wave_sum(s);
+        const double alpha = __shfl((q & 1) ? a1[q] : a0[q], q >> 1);
+        double bq = 0.0, sc = 0.0;
+        if (nrm2 != 0.0) {
+            const double nu = sqrt(alpha * alpha + nrm2);
+            const double bk = (alpha >= 0.0) ? -nu : nu;
+            bq = (bk - alpha) / bk;
+            sc = 1.0 / (alpha - bk);
+        }
+        beta[q] = bq;
+        v0[q] = (g0 > q) ? a0[q] * sc : ((g0 == q) ? 1.0 : 0.0);
+        v1[q] = (g1 > q) ? a1[q] * sc : ((g1 == q) ? 1.0 : 0.0);
+#pragma unroll
+        for (int c = q + 1; c < 3; ++c) {
+            const double w = wave_sum(v0[q] * a0[c] + v1[q] * a1[c]) * bq;
+            a0[c] -= w * v0[q];
+            a1[c] -= w * v1[q];
+        }
+    }
+    if (t < M) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { sV[g0 * 4 + q] = v0[q]; sV[g1 * 4 + q] = v1[q]; }
+        sV[g0 * 4 + 3] = 0.0;
+        sV[g1 * 4 + 3] = 0.0;
+    }
+    const double g10 = wave_sum(v0[1] * v0[0] + v1[1] * v1[0]);
+    const double g20 = wave_sum(v0[2] * v0[0] + v1[2] * v1[0]);
+    const double g21 = wave_sum(v0[2] * v0[1] + v1[2] * v1[1]);
+    wave_sync();
+
+    // ---- D: compact-WY coefficients y_q[a] of Q^T [J | r] for the columns this lane owns
+    double yq[NPASS][3];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int a = t + 64 * ps;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+        if (a < 7 || a == NA) {
+            for (int i = 0; i < M2; ++i) {
+                const double val = (a < 7) ? sJe[i * 7 + a] : sR[i];
+                w0 += sV[i * 4 + 0] * val;
+                w1 += sV[i * 4 + 1] * val;
+                w2 += sV[i * 4 + 2] * val;
+            }
+        } else if (a >= cb0 && a < NA) {
+            const int cl = (a - cb0) / 6, cc = (a - cb0) - 6 * cl;
+            const int k = sC2O[cl];
+            if (k >= 0) {
+                const double x0 = sJx[(2 * k) * 6 + cc], x1 = sJx[(2 * k + 1) * 6 + cc];
+                w0 = sV[(2 * k) * 4 + 0] * x0 + sV[(2 * k + 1) * 4 + 0] * x1;
+                w1 = sV[(2 * k) * 4 + 1] * x0 + sV[(2 * k + 1) * 4 + 1] * x1;
+                w2 = sV[(2 * k) * 4 + 2] * x0 + sV[(2 * k + 1) * 4 + 2] * x1;
+            }
+        }
+        const double y0 = beta[0] * w0;
+        const double y1 = beta[1] * (w1 - g10 * y0);
+        const double y2 = beta[2] * (w2 - g20 * y0 - g21 * y1);
+        yq[ps][0] = y0; yq[ps][1] = y1; yq[ps][2] = y2;
+        if (a == NA) { sYr[0] = y0; sYr[1] = y1; sYr[2] = y2; }
+    }
+    wave_sync();
+
+    // row-lane data: lane t <-> row t of the 2M-row block
+    const bool rowlane = t < M2;
+    double je[7], jx[6], vr[3];
+    int ja0 = 0;
+#pragma unroll
+    for (int e = 0; e < 7; ++e) je[e] = rowlane ? sJe[t * 7 + e] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) jx[c] = rowlane ? sJx[t * 6 + c] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) vr[q] = rowlane ? sV[t * 4 + q] : 0.0;
+    if (rowlane) ja0 = cb0 + 6 * sOC[t >> 1];
+    double rp = 0.0;   // projected residual of this row
+    if (rowlane) rp = sR[t] - (vr[0] * sYr[0] + vr[1] * sYr[1] + vr[2] * sYr[2]);
+
+    // ---- E: E = J P_aa J^T via u_l = (J_l P_aa) with coalesced P row loads ------------
+    double pe[NPASS][7];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int a = t + 64 * ps;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) pe[ps][e] = (a < NA) ? p.P[(size_t)(15 + e) * n + 15 + a] : 0.0;
+    }
+    for (int l = 0; l < M; ++l) {
+        const int cl = sOC[l];
+        const double* Prow = p.P + (size_t)(p.leg + 6 * cl) * n + 15;
+        double jl0e[7], jl1e[7], jl0x[6], jl1x[6];
+#pragma unroll
+        for (int e = 0; e < 7; ++e) { jl0e[e] = sJe[(2 * l) * 7 + e]; jl1e[e] = sJe[(2 * l + 1) * 7 + e]; }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { jl0x[c] = sJx[(2 * l) * 6 + c]; jl1x[c] = sJx[(2 * l + 1) * 6 + c]; }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int a = t + 64 * ps;
+            if (a < NA) {
+                double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 7; ++e) { u0 += jl0e[e] * pe[ps][e]; u1 += jl1e[e] * pe[ps][e]; }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double pc = Prow[(size_t)c * n + a];
+                    u0 += jl0x[c] * pc;
+                    u1 += jl1x[c] * pc;
+                }
+                sU[2 * a] = u0;
+                sU[2 * a + 1] = u1;
+            }
+        }
+        wave_sync();
+        if (rowlane) {
+            double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < 7; ++e) { e0 += je[e] * sU[2 * e]; e1 += je[e] * sU[2 * e + 1]; }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { e0 += jx[c] * sU[2 * (ja0 + c)]; e1 += jx[c] * sU[2 * (ja0 + c) + 1]; }
+            sE[t * LDE + 2 * l] = e0;
+            sE[t * LDE + 2 * l + 1] = e1;
+        }
+        wave_sync();
+    }
+
+    // row of E into registers (static indexing: full unroll)
+    double row[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) row[c] = (rowlane && c < M2) ? sE[t * LDE + c] : 0.0;
+
+    // ---- F: E' = Q^T E Q through the compact-WY form ----------------------------------
+    {
+        double W0 = 0.0, W1 = 0.0, W2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            if (c < M2) {
+                W0 += row[c] * sV[c * 4 + 0];
+                W1 += row[c] * sV[c * 4 + 1];
+                W2 += row[c] * sV[c * 4 + 2];
+            }
+        }
+        const double c00 = wave_sum(vr[0] * W0), c01 = wave_sum(vr[0] * W1), c02 = wave_sum(vr[0] * W2);
+        const double c11 = wave_sum(vr[1] * W1), c12 = wave_sum(vr[1] * W2), c22 = wave_sum(vr[2] * W2);
+        const double T00 = beta[0], T11 = beta[1], T22 = beta[2];
+        const double T01 = -beta[0] * g10 * beta[1];
+        const double T02 = -beta[2] * (T00 * g20 + T01 * g21);
+        const double T12 = -beta[2] * T11 * g21;
+        // X = W T
+        const double X0 = W0 * T00;
+        const double X1 = W0 * T01 + W1 * T11;
+        const double X2 = W0 * T02 + W1 * T12 + W2 * T22;
+        // Mid = T^T C3 T  (C3 symmetric)
+        const double d00 = c00 * T00, d01 = c00 * T01 + c01 * T11, d02 = c00 * T02 + c01 * T12 + c02 * T22;
+        const double d10 = c01 * T00, d11 = c01 * T01 + c11 * T11, d12 = c01 * T02 + c11 * T12 + c12 * T22;
+        const double d20 = c02 * T00, d21 = c02 * T01 + c12 * T11, d22 = c02 * T02 + c12 * T12 + c22 * T22;
+        const double m00 = T00 * d00, m01 = T00 * d01, m02 = T00 * d02;
+        const double m11 = T01 * d01 + T11 * d11, m12 = T01 * d02 + T11 * d12;
+        const double m22 = T02 * d02 + T12 * d12 + T22 * d22;
+        (void)d10; (void)d20; (void)d21;
+        const double xt0 = X0 - 0.5 * (vr[0] * m00 + vr[1] * m01 + vr[2] * m02);
+        const double xt1 = X1 - 0.5 * (vr[0] * m01 + vr[1] * m11 + vr[2] * m12);
+        const double xt2 = X2 - 0.5 * (vr[0] * m02 + vr[1] * m12 + vr[2] * m22);
+        if (rowlane) { sX[t * 4 + 0] = xt0; sX[t * 4 + 1] = xt1; sX[t * 4 + 2] = xt2; sX[t * 4 + 3] = 0.0; }
+        sZ[t] = rp;
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            if (c < M2) {
+                row[c] -= vr[0] * sX[c * 4 + 0] + vr[1] * sX[c * 4 + 1] + vr[2] * sX[c * 4 + 2] +
+                          xt0 * sV[c * 4 + 0] + xt1 * sV[c * 4 + 1] + xt2 * sV[c * 4 + 2];
+            }
+        }
+        // lane 0 becomes the augmented right-hand-side row (rows 0..2 are the discarded part)
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            if (c < M2) {
+                const double rc = sZ[c];
+                if (t == 0) row[c] = rc;
+            }
+        }
+    }
+
+    // ---- G: gamma = r'^T (E'[3:,3:] + sigma2 I)^-1 r' by a right-looking Cholesky with the
+    //         matrix rows in registers and the pivot column broadcast through LDS -------------
+    double gam = 0.0;
+    bool fail = false;
+#pragma unroll
+    for (int jc = 3; jc < 64; ++jc) {
+        if (jc < M2) {
+            const double d = __shfl(row[jc], jc) + p.sigma2;
+            if (!(d > 0.0)) fail = true;
+            const double inv = 1.0 / sqrt(d);
+            const double lr = row[jc] * inv;
+            double* col = sCol + 64 * (jc & 1);
+            col[t] = lr;
+            wave_sync();
+            if (t == 0) gam += lr * lr;
+#pragma unroll
+            for (int c = jc + 1; c < 64; ++c) row[c] -= lr * col[c];
+        }
+    }
+    gam = __shfl(gam, 0);
+    const int dof = M2 - 3;
+    const bool ok = (!fail) && (gam < p.chi2[dof]);
+    if (t == 0) {
+        p.gamma[j] = fail ? NAN : gam;
+        p.accept[j] = ok ? 1 : 0;
+    }
+
+    // ---- I: coalesced write of the projected block rows 3..2M-1 -------------------------
+    const size_t row0 = (size_t)p.row_ptr[j];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int a = t + 64 * ps;
+        if (a < NAP) {
+            int kobs = -1, cc = 0;
+            if (a >= cb0 && a < NA) {
+                const int cl = (a - cb0) / 6;
+                cc = (a - cb0) - 6 * cl;
+                kobs = sC2O[cl];
+            }
+            for (int i = 3; i < M2; ++i) {
+                double val = 0.0;
+                if (ok) {
+                    double jv = 0.0;
+                    if (a < 7) jv = sJe[i * 7 + a];
+                    else if (a == NA) jv = sR[i];
+                    else if (kobs == (i >> 1)) jv = sJx[i * 6 + cc];
+                    val = jv - (sV[i * 4 + 0] * yq[ps][0] + sV[i * 4 + 1] * yq[ps][1] + sV[i * 4 + 2] * yq[ps][2]);
+                    if (a > NA) val = 0.0;
+                }
+                p.Hs[(row0 + i - 3) * NAP + a] = val;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_gram: partial Gram G_c = X_c^T X_c over a chunk of rows, lower 16x16 tiles only.
+// One wavefront per (chunk, tile).  grid.x = ceil(ntiles/4), grid.y = chunks, block 256.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_from_linear(int tl, int& bi, int& bj) {
+    // lower-triangular tile index tl -> (bi >= bj)
+    int b = (int)((sqrt(8.0 * tl + 1.0) - 1.0) * 0.5);
+    while ((b + 1) * (b + 2) / 2 <= tl) ++b;
+    while (b * (b + 1) / 2 > tl) --b;
+    bi = b;
+    bj = tl - b * (b + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int m, int NAP, int rows_per_chunk,
+                                              double* __restrict__ Gpart) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nb = NAP >> 4;
+    const int ntiles = nb * (nb + 1) / 2;
+    const int tl = blockIdx.x * 4 + wave;
+    if (tl >= ntiles) return;
+    int bi, bj;
+    tile_from_linear(tl, bi, bj);
+    const int chunk = blockIdx.y;
+    const int r0 = chunk * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    if (r1 > m) r1 = m;
+    const int kk = l >> 4, cc = l & 15;
+    const double* pa = X + (size_t)(r0 + kk) * NAP + 16 * bi + cc;
+    const double* pb = X + (size_t)(r0 + kk) * NAP + 16 * bj + cc;
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    int k = r0;
+    // two independent accumulators to cover the MFMA dependent-issue latency
+    for (; k + 8 <= r1; k += 8) {
+        const double a0 = pa[0], b0 = pb[0];
+        const double a1 = pa[(size_t)4 * NAP], b1 = pb[(size_t)4 * NAP];
+        acc0 = mfma_f64(a0, b0, acc0);
+        acc1 = mfma_f64(a1, b1, acc1);
+        pa += (size_t)8 * NAP;
+        pb += (size_t)8 * NAP;
+    }
+    for (; k < r1; k += 4) {
+        const bool in = (k + kk) < r1;
+        const double a0 = in ? pa[0] : 0.0, b0 = in ? pb[0] : 0.0;
+        acc0 = mfma_f64(a0, b0, acc0);
+        pa += (size_t)4 * NAP;
+        pb += (size_t)4 * NAP;
+    }
+    double* out = Gpart + (size_t)chunk * NAP * NAP;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+        out[(size_t)i * NAP + jj] = acc0[r] + acc1[r];
+    }
+}
+
+// Sums `nparts` blocks (lower tiles) into dst; used for the chunk partials of one rank and
+// for the all-gathered blocks of all ranks.  Strictly-upper tiles are written as zero.
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ parts, int nparts, size_t part_stride,
+                                                     int NAP, double* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NAP * NAP) return;
+    const int i = idx / NAP, jj = idx - i * NAP;
+    double s = 0.0;
+    if ((i >> 4) >= (jj >> 4)) {
+        for (int c = 0; c < nparts; ++c) s += parts[(size_t)c * part_stride + idx];
+    }
+    dst[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_potrf: single-workgroup (1024 threads) blocked right-looking Cholesky, in place, lower.
+//   A (n x n, ld) symmetric positive SEMI-definite: a pivot <= tol zeroes its column
+//   (rank-deficient directions of the Gram block: gauge freedom, unobserved columns).
+//   Also writes the inverses of the 16x16 diagonal blocks (Dinv[nblk][16][16], generalised
+//   inverse on zero pivots) for k_trsm, zeroes the strict upper triangle, and counts zero
+//   pivots in *nzero.
+// ---------------------------------------------------------------------------------------
+#define POTRF_MAXN 416
+__global__ __launch_bounds__(1024) void k_potrf(double* __restrict__ A, int n, int ld, double tol_rel,
+                                                double* __restrict__ Dinv, int* __restrict__ nzero) {
+    __shared__ double sD[16][17];
+    __shared__ double sDi[16][17];
+    __shared__ double sdinv[16];
+    __shared__ double sP[POTRF_MAXN][17];   // panel rows below the diagonal block
+    __shared__ double sred[16];
+    __shared__ int szero;
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int nblk = (n + 15) >> 4;
+    // tolerance from the largest diagonal entry
+    double mx = 0.0;
+    for (int i = tid; i < n; i += 1024) mx = fmax(mx, A[(size_t)i * ld + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if (l == 0) sred[wave] = mx;
+    if (tid == 0) szero = 0;
+    __syncthreads();
+    mx = 0.0;
+    for (int w = 0; w < 16; ++w) mx = fmax(mx, sred[w]);
+    const double tol = tol_rel * mx;
+
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int k0 = kb * 16;
+        const int kw = (n - k0) < 16 ? (n - k0) : 16;   // width of this block column
+        // (1) diagonal block -> LDS, unblocked factorisation by wave 0
+        if (tid < 256) {
+            const int r = tid >> 4, c = tid & 15;
+            double v = 0.0;
+            if (r < kw && c < kw && c <= r) v = A[(size_t)(k0 + r) * ld + k0 + c];
+            sD[r][c] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int r = l & 15, cg = l >> 4;
+            for (int jc = 0; jc < 16; ++jc) {
+                const double d = sD[jc][jc];
+                double inv = 0.0, sq = 0.0;
+                if (jc < kw && d > tol) { sq = sqrt(d); inv = 1.0 / sq; }
+                __builtin_amdgcn_wave_barrier();
+                if (l == 0) {
+                    sdinv[jc] = inv;
+                    sD[jc][jc] = sq;
+                    if (jc < kw && !(d > tol)) szero += 1;
+                }
+                if (cg == 0 && r > jc) sD[r][jc] = sD[r][jc] * inv;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // trailing update inside the block: columns c = jc+1+cg, +4, ...
+                for (int c = jc + 1 + cg; c <= r; c += 4) sD[r][c] -= sD[r][jc] * sD[c][jc];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // generalised inverse of the diagonal block: Di = D^-1 (lower), column per lane
+            if (l < 16) {
+                const int c = l;
+                double x[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k < i) s -= sD[i][k] * x[k];
+                    x[i] = (i >= c) ? s * sdinv[i] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sDi[i][c] = x[i];
+            }
+        }
+        __syncthreads();
+        // write back the factored diagonal block (+ zero strict upper) and its inverse
+        if (tid < 256) {
+            const int r = tid >> 4, c = tid & 15;
+            if (r < kw && c < kw) A[(size_t)(k0 + r) * ld + k0 + c] = (c <= r) ? sD[r][c] : 0.0;
+            Dinv[(size_t)kb * 256 + r * 16 + c] = sDi[r][c];
+        }
+        // (2) panel: rows below, x <- x * D^-T by forward substitution (thread per row)
+        const int prow0 = k0 + 16;
+        const int np = n - prow0;   // rows below
+        for (int pr = tid; pr < np; pr += 1024) {
+            double x[16];
+            const double* src = A + (size_t)(prow0 + pr) * ld + k0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = src[c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double s = x[c];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < c) s -= x[k] * sD[c][k];
+                x[c] = s * sdinv[c];
+            }
+            double* dst = A + (size_t)(prow0 + pr) * ld + k0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { dst[c] = x[c]; sP[pr][c] = x[c]; }
+        }
+        // zero the strict-upper part right of the diagonal block (rows of this block)
+        for (int idx = tid; idx < 16 * np; idx += 1024) {
+            const int r = idx / np, c = idx - r * np;
+            if (r < kw) A[(size_t)(k0 + r) * ld + prow0 + c] = 0.0;
+        }
+        __syncthreads();
+        // (3) trailing update A22 -= L21 L21^T (lower tiles) with FP64 MFMA, K = 16
+        const int nbt = (np + 15) >> 4;
+        const int ntile = nbt * (nbt + 1) / 2;
+        for (int tl = wave; tl < ntile; tl += 16) {
+            int bi, bj;
+            tile_from_linear(tl, bi, bj);
+            const int kk = l >> 4, cc = l & 15;
+            d4 acc = {0, 0, 0, 0};
+            const int ra = 16 * bi + cc, rb = 16 * bj + cc;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double a = (ra < np) ? sP[ra][kk + 4 * s] : 0.0;
+                const double b = (rb < np) ? sP[rb][kk + 4 * s] : 0.0;
+                acc = mfma_f64(a, b, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+                if (i < np && jj < np && jj <= i) A[(size_t)(prow0 + i) * ld + prow0 + jj] -= acc[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *nzero = szero;
+}
+
+// ---------------------------------------------------------------------------------------
+// generic small FP64-MFMA product: one wavefront per 16x16 output tile.
+//   C[i][j] = sum_k A(i,k) * B(k,j),  A(i,k) = A[i*sAi + k*sAk], B(k,j) = B[k*sBk + j*sBj]
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ d4 tile_product(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
+                                           long sBk, long sBj, int M, int N, int K, int i0, int j0, int l) {
+    const int kk = l >> 4, cc = l & 15;
+    const bool ia = (i0 + cc) < M, jb = (j0 + cc) < N;
+    const double* pa = A + (long)(i0 + cc) * sAi + (long)kk * sAk;
+    const double* pb = B + (long)kk * sBk + (long)(j0 + cc) * sBj;
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        const double a0 = ia ? pa[0] : 0.0, b0 = jb ? pb[0] : 0.0;
+        const double a1 = ia ? pa[4 * sAk] : 0.0, b1 = jb ? pb[4 * sBk] : 0.0;
+        acc0 = mfma_f64(a0, b0, acc0);
+        acc1 = mfma_f64(a1, b1, acc1);
+        pa += 8 * sAk;
+        pb += 8 * sBk;
+    }
+    for (; k < K; k += 4) {
+        const bool kin = (k + kk) < K;
+        const double a0 = (ia && kin) ? pa[0] : 0.0, b0 = (jb && kin) ? pb[0] : 0.0;
+        acc0 = mfma_f64(a0, b0, acc0);
+        pa += 4 * sAk;
+        pb += 4 * sBk;
+    }
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
+    return acc;
+}
+
+// T[NA][ldt] = La^T[NA x NA] * P[15:n, 0:n] ; column n of T <- r_thin = La[NA][0:NA]
+__global__ __launch_bounds__(256) void k_form_T(const double* __restrict__ La, int NAP, const double* __restrict__ P, int n,
+                                                int NA, double* __restrict__ T, int ldt) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int ntj = (n + 1 + 15) >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    const int nti = (NA + 15) >> 4;
+    if (tile >= nti * ntj) return;
+    const int bi = tile / ntj, bj = tile - bi * ntj;
+    // A(i,k) = La[k][i]  (R = La^T), B(k,j) = P[15+k][j]
+    d4 acc = tile_product(La, 1, NAP, P + (size_t)15 * n, n, 1, NA, n, NA, 16 * bi, 16 * bj, l);
+    const int kk = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+        if (i < NA) {
+            if (jj < n) T[(size_t)i * ldt + jj] = acc[r];
+            else if (jj == n) T[(size_t)i * ldt + n] = La[(size_t)NA * NAP + i];   // r_thin
+        }
+    }
+}
+
+// S[NA][lds] (lower tiles) = T[:, 15:n] * La + sigma2 I
+__global__ __launch_bounds__(256) void k_form_S(const double* __restrict__ T, int ldt, const double* __restrict__ La, int NAP,
+                                                int NA, double sigma2, double* __restrict__ S, int lds) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nb = (NA + 15) >> 4;
+    const int ntiles = nb * (nb + 1) / 2;
+    const int tl = blockIdx.x * 4 + wave;
+    if (tl >= ntiles) return;
+    int bi, bj;
+    tile_from_linear(tl, bi, bj);
+    // A(i,k) = T[i][15+k], B(k,j) = La[k][j]
+    d4 acc = tile_product(T + 15, ldt, 1, La, NAP, 1, NA, NA, NA, 16 * bi, 16 * bj, l);
+    const int kk = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+        if (i < NA && jj < NA) S[(size_t)i * lds + jj] = acc[r] + ((i == jj) ? sigma2 : 0.0);
+    }
+}
+
+// P_out = sym(P) - Zn^T Zn (lower tiles mirrored), dx = Zn^T z  with Z = [Zn | z] (NA x (n+1))
+__global__ __launch_bounds__(256) void k_finish(const double* __restrict__ Z, int ldz, int NA, const double* __restrict__ P, int n,
+                                                double* __restrict__ P_out, double* __restrict__ dx) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nb = (n + 1 + 15) >> 4;
+    const int ntiles = nb * (nb + 1) / 2;
+    const int tl = blockIdx.x * 4 + wave;
+    if (tl >= ntiles) return;
+    int bi, bj;
+    tile_from_linear(tl, bi, bj);
+    // A(i,k) = Z[k][i], B(k,j) = Z[k][j]
+    d4 acc = tile_product(Z, 1, ldz, Z, ldz, 1, n + 1, n + 1, NA, 16 * bi, 16 * bj, l);
+    const int kk = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+        if (i < n && jj < n && jj <= i) {
+            const double pv = 0.5 * (P[(size_t)i * n + jj] + P[(size_t)jj * n + i]) - acc[r];
+            P_out[(size_t)i * n + jj] = pv;
+            P_out[(size_t)jj * n + i] = pv;
+        } else if (i == n && jj < n) {
+            dx[jj] = acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_trsm: Z = L^-1 B for a lower-triangular L (NA x NA, ldl) with precomputed inverses of
+// its 16x16 diagonal blocks.  One wavefront per 16 right-hand-side columns; the solved
+// tiles stay in registers in the MFMA C layout, which is also the B-operand layout.
+// ---------------------------------------------------------------------------------------
+#define TRSM_MAXBLK 26
+__global__ __launch_bounds__(64) void k_trsm(const double* __restrict__ L, int ldl, const double* __restrict__ Dinv, int NA,
+                                             const double* __restrict__ B, int ldb, int nrhs, double* __restrict__ Z, int ldz) {
+    const int l = threadIdx.x;
+    const int j0 = blockIdx.x * 16;
+    const int kk = l >> 4, cc = l & 15;
+    const int nblk = (NA + 15) >> 4;
+    const bool jin = (j0 + cc) < nrhs;
+    d4 X[TRSM_MAXBLK];
+#pragma unroll
+    for (int kb = 0; kb < TRSM_MAXBLK; ++kb) {
+        if (kb < nblk) {
+            d4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * kb + kk + 4 * r;
+                acc[r] = (jin && i < NA) ? B[(size_t)i * ldb + j0 + cc] : 0.0;
+            }
+            // acc -= L[kb][jb] * X[jb]
+#pragma unroll
+            for (int jb = 0; jb < TRSM_MAXBLK; ++jb) {
+                if (jb < kb) {
+                    const int ia = 16 * kb + cc;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const double a = (ia < NA) ? -L[(size_t)ia * ldl + 16 * jb + kk + 4 * s] : 0.0;
+                        acc = mfma_f64(a, X[jb][s], acc);
+                    }
+                }
+            }
+            // X[kb] = Dinv[kb] * acc
+            d4 x = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double a = Dinv[(size_t)kb * 256 + cc * 16 + kk + 4 * s];
+                x = mfma_f64(a, acc[s], x);
+            }
+            X[kb] = x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * kb + kk + 4 * r;
+                if (jin && i < NA) Z[(size_t)i * ldz + j0 + cc] = x[r];
+            }
+        }
+    }
+}
+
+}  // namespace orcvio_amd

@@ -119,8 +119,8 @@ def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,
 
     track_len: None -> every feature seen in all N clones; int M -> contiguous
     run of M clones at a random start; (lo, hi) -> ragged M_j in [lo, hi].
-    outlier_frac: fraction of features whose estimate is corrupted so that the
-    chi-square gate rejects them (exercises the accept mask).
+    outlier_frac: fraction of tracks with 12x observation noise, which the
+    chi-square gate rejects (exercises the accept mask).
     """
     flags = flags or Flags()
     rng = np.random.default_rng(seed)
@@ -146,9 +146,11 @@ def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,
     p_c_mid = np.stack([xy[:, 0] * depth, xy[:, 1] * depth, depth], axis=1)
     p_true = p_c_mid @ R_c2w[mid].T + t_c_w[mid]
     p_w = p_true + 0.02 * rng.standard_normal((F, 3))
+    bad = np.zeros(F, dtype=bool)
     if outlier_frac > 0:
+        # mismatched tracks: observation noise far above noise_feature, so that the
+        # chi-square gate (src/orcvio.cpp:1953-1976) rejects the block
         bad = rng.random(F) < outlier_frac
-        p_w[bad] += rng.standard_normal((int(bad.sum()), 3)) * 1.5
 
     obs_ptr = [0]
     obs_clone, obs_z, obs_zvel = [], [], []
@@ -165,7 +167,7 @@ def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,
             ids = np.arange(s, s + M)
         for i in ids:
             pc = R_c2w[i].T @ (p_true[j] - t_c_w[i])
-            z = pc[:2] / pc[2] + sig * rng.standard_normal(2)
+            z = pc[:2] / pc[2] + (12.0 * sig if bad[j] else sig) * rng.standard_normal(2)
             obs_clone.append(i)
             obs_z.append(z)
             obs_zvel.append(0.05 * rng.standard_normal(2))

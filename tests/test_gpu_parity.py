@@ -1,0 +1,223 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the oracle.
+
+Tolerance (BASELINE.json north_star): 1e-6 relative Frobenius on delta_x and on the gain.  The
+gain itself is basis dependent (SURVEY.md note N1), so it is compared through G = K*H_thin; the
+tests also hold the tighter figures the path actually reaches.  Accept masks must be identical."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from orcvio_amd import capi, synth
+from oracle import oracle
+from helpers import rel, golden_files, window_from_golden, subset_window
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+@pytest.fixture(scope='module')
+def upd(built):
+    u = capi.MsckfUpdater(device=0, max_clones=40, max_features=2048, max_observations=65536)
+    yield u
+    u.close()
+
+
+def _compare(got, ref, win, tol=TOL):
+    assert np.array_equal(got['accept'], ref['accept'])
+    fin = np.isfinite(ref['gamma'])
+    assert np.array_equal(np.isfinite(got['gamma']), fin)
+    if fin.any():
+        assert rel(got['gamma'][fin], ref['gamma'][fin]) < 1e-9
+    assert rel(got['dx'], ref['dx']) < tol
+    assert rel(got['P_new'], ref['P_new']) < tol
+    dP_ref = ref['P_new'] - win.P
+    if np.linalg.norm(dP_ref) > 0:
+        assert rel(got['P_new'] - win.P, dP_ref) < tol
+    if 'G' in got:
+        assert rel(got['G'], ref['G']) < tol
+    assert np.array_equal(got['P_new'], got['P_new'].T)
+
+
+@pytest.mark.parametrize('path', golden_files(), ids=lambda p: p.split('feat_')[-1][:-4])
+def test_golden_vectors(upd, path):
+    w, g = window_from_golden(path)
+    got = upd.update_features(w, want_G=True, want_K=True, want_thin=True)
+    assert np.array_equal(got['accept'], g['exp_accept'])
+    assert rel(got['gamma'], g['exp_gamma']) < 1e-9
+    assert rel(got['dx'], g['exp_dx']) < TOL
+    assert rel(got['P_new'], g['exp_P']) < TOL
+    assert rel(got['G'], g['exp_G']) < TOL
+    # the returned factors are consistent: G = K H_thin, dx = K r_thin
+    assert rel(got['K'] @ got['H_thin'], got['G']) < 1e-10
+    assert rel(got['K'] @ got['r_thin'], got['dx']) < 1e-8
+    # projected blocks: basis-invariant Gram data of every accepted block
+    Hs = capi.debug_read(upd, 'Hs')
+    NA = w.n - 15
+    row = 0
+    for j in range(w.F):
+        M = int(w.obs_ptr[j + 1] - w.obs_ptr[j])
+        rho = 2 * M - 3 if M >= 2 else 0
+        blk = Hs[row:row + rho]
+        row += rho
+        if not g['exp_accept'][j]:
+            assert not blk.any()
+            continue
+        H, r = blk[:, :NA], blk[:, NA]
+        assert rel(H.T @ H, g['exp_block_gram'][j][15:, 15:]) < 1e-9
+        assert rel(H.T @ r, g['exp_block_Htr'][j][15:]) < 1e-8
+        assert abs(r @ r - g['exp_block_rr'][j]) < 1e-9 * max(1.0, g['exp_block_rr'][j])
+
+
+@pytest.mark.parametrize('larvio,left,fej,td', [(1, 0, 0, 0), (1, 0, 1, 1), (0, 0, 0, 0), (0, 1, 0, 0), (0, 1, 1, 1), (0, 0, 1, 0)])
+@pytest.mark.parametrize('seed', [0, 1])
+def test_flag_variants_ragged(upd, larvio, left, fej, td, seed):
+    f = synth.Flags(use_larvio=larvio, use_left_perturbation=left, if_fej=fej, estimate_td=td)
+    w = synth.make_window(N=9, F=37, seed=100 + seed, track_len=(2, 9), flags=f, outlier_frac=0.25,
+                          estimate_extrin=bool(td))
+    ref = oracle.msckf_update(w)
+    got = upd.update_features(w, want_G=True)
+    assert 0 < ref['accept'].sum() < w.F
+    _compare(got, ref, w)
+
+
+def test_config1_euroc_shape(upd):
+    w = synth.config_window(1)
+    _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
+
+
+def test_config2_full_size(upd):
+    """30 clones x 400 features x 30 observations: 22 800 stacked rows."""
+    w = synth.config_window(2)
+    ref = oracle.msckf_update(w)
+    got = upd.update_features(w, want_G=True)
+    assert got['stats'][0] == 22800 and got['accept'].all()
+    _compare(got, ref, w)
+    # size-independent properties: information only shrinks P, and P+ stays PSD
+    ev = np.linalg.eigvalsh(got['P_new'])
+    assert ev.min() > -1e-12
+    assert np.linalg.eigvalsh(w.P - got['P_new']).min() > -1e-10
+
+
+def test_prune_variant(upd):
+    """pruneImuStateBuffer (src/orcvio.cpp:2803-2851): the CSR lists only the removed clones."""
+    w = synth.make_window(N=12, F=60, seed=9, track_len=(4, 12))
+    ws = subset_window(w, [2, 3])
+    mask = np.zeros(w.N, dtype=np.int32)
+    mask[[2, 3]] = 1
+    ref = oracle.msckf_update(w, clone_mask=mask)
+    got = upd.update_features(ws, want_G=True)
+    assert ref['accept'].sum() > 0
+    _compare(got, ref, ws)
+
+
+def test_rows_fewer_than_columns(upd):
+    """No compression in the reference when rows <= cols (:1664, :2533); same update here."""
+    w = synth.make_window(N=10, F=3, seed=4, track_len=(3, 5))
+    ref = oracle.msckf_update(w)
+    assert ref['stacked_rows'] < w.n
+    _compare(upd.update_features(w, want_G=True), ref, w)
+
+
+def test_short_and_empty_tracks(upd):
+    """Tracks with < 2 observations are skipped; an update with no usable track leaves P alone."""
+    w = synth.make_window(N=6, F=10, seed=2, track_len=(3, 6))
+    ptr = w.obs_ptr.copy()
+    # cut feature 0 to one observation and feature 1 to none
+    keep = np.ones(len(w.obs_clone), dtype=bool)
+    keep[ptr[0] + 1:ptr[1]] = False
+    keep[ptr[1]:ptr[2]] = False
+    newptr = [0]
+    for j in range(w.F):
+        newptr.append(newptr[-1] + int(keep[ptr[j]:ptr[j + 1]].sum()))
+    w2 = dataclasses.replace(w, obs_ptr=np.asarray(newptr, dtype=np.int32), obs_clone=w.obs_clone[keep].copy(),
+                             obs_z=w.obs_z[keep].copy(), obs_zvel=w.obs_zvel[keep].copy())
+    ref = oracle.msckf_update(w2)
+    got = upd.update_features(w2, want_G=True)
+    assert got['accept'][0] == 0 and got['accept'][1] == 0 and np.isnan(got['gamma'][0]) and np.isnan(got['gamma'][1])
+    _compare(got, ref, w2)
+    # nothing usable at all
+    w3 = dataclasses.replace(w, obs_ptr=np.zeros(w.F + 1, dtype=np.int32), obs_clone=np.zeros(0, dtype=np.int32),
+                             obs_z=np.zeros((0, 2)), obs_zvel=np.zeros((0, 2)))
+    got3 = upd.update_features(w3)
+    assert not got3['updated'] and not got3['dx'].any()
+    assert rel(got3['P_new'], w.P) < 1e-15
+    # F = 0
+    w4 = dataclasses.replace(w3, p_w=np.zeros((0, 3)), obs_ptr=np.zeros(1, dtype=np.int32))
+    got4 = upd.update_features(w4)
+    assert not got4['updated'] and rel(got4['P_new'], w.P) < 1e-15
+
+
+def test_all_rejected(upd):
+    w = synth.make_window(N=6, F=8, seed=6, track_len=(4, 6), outlier_frac=1.0)
+    ref = oracle.msckf_update(w)
+    assert ref['accept'].sum() == 0
+    got = upd.update_features(w)
+    assert got['accept'].sum() == 0 and not got['updated']
+    assert not got['dx'].any() and rel(got['P_new'], w.P) < 1e-15
+
+
+def test_max_track_length_and_limits(upd):
+    w = synth.make_window(N=32, F=12, seed=8, track_len=32)
+    _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
+    w_long = synth.make_window(N=34, F=2, seed=8, track_len=34)
+    with pytest.raises(capi.MsckfError) as e:
+        upd.update_features(w_long)
+    assert e.value.code == 4   # ORCVIO_ERR_TRACK_TOO_LONG
+
+
+def test_leg_dim_46(upd):
+    """calib_imu_instrinsic: 24 more legacy columns (src/orcvio.cpp:196-199)."""
+    f = synth.Flags(leg_dim=46)
+    w = synth.make_window(N=7, F=30, seed=12, track_len=(3, 7), flags=f)
+    _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
+
+
+def test_kitti_flags_large_noise(upd):
+    """config/kitti_raw.yaml: OrcVIO right perturbation, noise_feature 1, discard flag on."""
+    f = synth.Flags(use_larvio=0, use_left_perturbation=0, noise_feature=1.0, discard_large_update=1)
+    w = synth.make_window(N=20, F=200, seed=31, track_len=(3, 6), flags=f, sigma_px=0.008)
+    ref = oracle.msckf_update(w)
+    got = upd.update_features(w, want_G=True)
+    _compare(got, ref, w)
+    assert got['stats'][4] == 0
+
+
+def test_staged_equals_one_shot_and_multi_block_finish(upd):
+    """run_local + run_finish (the multi-GPU form) on one device: sharding the tracks in two,
+    summing the two compressed blocks, equals the single update."""
+    import torch
+    w = synth.make_window(N=10, F=64, seed=17, track_len=(3, 10), outlier_frac=0.1)
+    one = upd.update_features(w, want_G=True)
+    # shard features round-robin into two windows
+    blocks = []
+    accepts = {}
+    for rank in range(2):
+        idx = np.arange(rank, w.F, 2)
+        ptr = [0]
+        sel = []
+        for j in idx:
+            sel += list(range(w.obs_ptr[j], w.obs_ptr[j + 1]))
+            ptr.append(len(sel))
+        sel = np.asarray(sel, dtype=np.int64)
+        ws = dataclasses.replace(w, p_w=w.p_w[idx].copy(), obs_ptr=np.asarray(ptr, dtype=np.int32),
+                                 obs_clone=w.obs_clone[sel].copy(), obs_z=w.obs_z[sel].copy(), obs_zvel=w.obs_zvel[sel].copy())
+        upd.upload(ws)
+        upd.run_local()
+        upd.sync()
+        ptr_dev, ne = upd.block_ptr()
+        t = torch.empty(ne, dtype=torch.float64, device='cuda:0')
+        # device-to-device copy of the compressed block (what the all-gather moves)
+        import ctypes as C
+        hip = C.CDLL('libamdhip64.so')
+        assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr_dev), C.c_size_t(ne * 8), 3) == 0
+        blocks.append(t)
+        accepts[rank] = idx
+    gathered = torch.cat(blocks)
+    torch.cuda.synchronize()
+    upd.run_finish(gathered.data_ptr(), 2)
+    upd.sync()
+    got = upd.download()
+    assert rel(got['dx'], one['dx']) < 1e-9
+    assert rel(got['P_new'], one['P_new']) < 1e-10
