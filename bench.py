@@ -116,14 +116,28 @@ def main():
         W = algorithmic_flops(N, F * world, M)
         # roofline of the dominant kernel, timed live with HIP events on the launch stream
         prof = upd.profile(reps=20, stream=stream)
-        dom = max(prof, key=prof.get)
-        kflops = {'k_feature': W['W_J'] + W['W_N'] + W['W_G'], 'k_gram': W['W_Q'], 'k_gram_reduce': 0.0}
-        solve_share = W['W_U']
-        dom_flops = kflops.get(dom, solve_share) / (world if dom in ('k_feature', 'k_gram') else 1)
-        achieved = dom_flops / (prof[dom] * 1e-3) / 1e12
+        n = 22 + 6 * N
+        NA = n - 15
+        # algorithmic FP64 work attributed to each kernel (DESIGN.md "Roofline accounting")
+        kflops = {
+            'k_feature': (W['W_J'] + W['W_N'] + W['W_G']) / world,   # Jacobians + nullspace + gate
+            'k_gram': W['W_Q'] / world,                                # stack compression
+            'k_gram_reduce': 0.0,
+            'k_potrf(P)': n ** 3 / 3.0,
+            'k_gemm(U)': 2.0 * (NA + 1) * NA * n,
+            'k_gemm(M)': 2.0 * NA * n * n / 2.0,
+            'k_potrf(M)': n ** 3 / 3.0,
+            'k_trsm': 1.0 * n * n * (n + 1),
+            'k_finish': 1.0 * n * (n + 1) * (n + 1),
+        }
+        # k_potrf(P) runs on a side stream, overlapped with k_feature/k_gram: not on the critical path
+        crit = {k: v for k, v in prof.items() if k != 'k_potrf(P)'}
+        dom = max(crit, key=crit.get)
+        achieved = kflops[dom] / (prof[dom] * 1e-3) / 1e12
         roofline = dict(bound='mfma', kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},
+                        kernel_tflops={k: round(kflops[k] / (prof[k] * 1e-3) / 1e12, 4) for k in prof},
                         whole_update_tflops=W['total'] / (ms * 1e-3) / 1e12)
         cpu = None
         if not args.no_cpu_baseline and world == 1:

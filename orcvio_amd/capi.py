@@ -74,6 +74,12 @@ def load():
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f'{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)')
+    try:
+        # PyTorch ships its own libamdhip64; importing it first makes this process use ONE HIP
+        # runtime (two runtimes in one process cannot both own the device).
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.orcvio_msckf_abi_version.restype = C.c_int32
     lib.orcvio_msckf_last_error.restype = C.c_char_p
@@ -264,12 +270,12 @@ def debug_read(upd: MsckfUpdater, which: str):
     rc = lib.orcvio_msckf_debug_read(upd.h, 7, dims.ctypes.data_as(C.c_void_p), dims.nbytes)
     if rc != 0:
         raise MsckfError(rc, 'debug_read dims')
-    n, NA, NAP, ldt, m_tot = (int(x) for x in dims[:5])
+    n, NA, NAP, NP, m_tot = (int(x) for x in dims[:5])
+    ldz = int(dims[6])
     if which == 'dims':
-        return dict(n=n, NA=NA, NAP=NAP, ldt=ldt, m_tot=m_tot, Mmax=int(dims[5]), chunks=int(dims[6]),
-                    rows_per_chunk=int(dims[7]))
-    shapes = {'Hs': (0, (m_tot, NAP)), 'Ab': (1, (NAP, NAP)), 'La': (2, (NAP, NAP)), 'T': (3, (NA, ldt)),
-              'S': (4, (NAP, NAP)), 'Z': (5, (NA, ldt)), 'Gpart0': (6, (NAP, NAP))}
+        return dict(n=n, NA=NA, NAP=NAP, NP=NP, m_tot=m_tot, Mmax=int(dims[5]), ldz=ldz, reg_path=int(dims[7]))
+    shapes = {'Hs': (0, (m_tot, NAP)), 'Ab': (1, (NAP, NAP)), 'A': (2, (NAP, NAP)), 'RP': (3, (NP, NP)),
+              'M': (4, (NP, NP)), 'RM': (5, (NP, NP)), 'Z': (6, (n, ldz)), 'U': (8, (NP, NP))}
     code, shape = shapes[which]
     out = np.zeros(shape)
     if out.size:
@@ -277,3 +283,33 @@ def debug_read(upd: MsckfUpdater, which: str):
         if rc != 0:
             raise MsckfError(rc, f'debug_read {which}')
     return out
+
+
+def debug_potrf(upd: MsckfUpdater, X, tol_rel=0.0, force_lds_path=False):
+    """Test helper: Cholesky factor (lower), block inverses and pivot info of a host matrix."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n = X.shape[0]
+    L = np.zeros((n, n))
+    nb = (n + 15) // 16
+    Dinv = np.zeros((nb, 16, 16))
+    info = np.zeros(2, dtype=np.int32)
+    lib = upd.lib
+    lib.orcvio_msckf_debug_potrf.argtypes = [C.c_void_p, _dp, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _ip]
+    rc = lib.orcvio_msckf_debug_potrf(upd.h, _d(X), n, float(tol_rel), int(force_lds_path), _d(L), _d(Dinv), _i(info))
+    if rc != 0:
+        raise MsckfError(rc, 'debug_potrf')
+    return L, Dinv, info
+
+
+def debug_trsm(upd: MsckfUpdater, X, B):
+    """Test helper: Z = chol(X)^-1 B."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    n, nrhs = B.shape
+    Z = np.zeros((n, nrhs))
+    lib = upd.lib
+    lib.orcvio_msckf_debug_trsm.argtypes = [C.c_void_p, _dp, C.c_int32, _dp, C.c_int32, _dp]
+    rc = lib.orcvio_msckf_debug_trsm(upd.h, _d(X), n, _d(B), nrhs, _d(Z))
+    if rc != 0:
+        raise MsckfError(rc, 'debug_trsm')
+    return Z

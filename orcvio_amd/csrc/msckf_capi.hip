@@ -31,18 +31,23 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 struct orcvio_msckf_handle {
     int device = 0;
     int maxN = 0, maxF = 0, maxObs = 0;
-    int n_max = 0, NAP_max = 0;
-    hipStream_t stream = nullptr;
+    int n_max = 0, NAP_max = 0, NP_max = 0;
+    hipStream_t stream = nullptr;       // default launch stream
+    hipStream_t side = nullptr;         // Cholesky of the prior, overlapped with the feature kernels
+    hipEvent_t ev_fork = nullptr, ev_side = nullptr;
     // problem of the current upload
     orcvio_msckf_flags flags{};
-    int N = 0, F = 0, nobs = 0, n = 0, NA = 0, NAP = 0, ldt = 0, m_tot = 0, Mmax = 0;
+    int N = 0, F = 0, nobs = 0, n = 0, NA = 0, NAP = 0, NP = 0, ldz = 0, m_tot = 0, Mmax = 0;
     int chunks = 0, rows_per_chunk = 0;
     bool uploaded = false, ran = false;
+    bool reg_path = true;               // register-resident Cholesky (n <= 224), else the LDS-panel kernel
     // device buffers
     double *d_poses = nullptr, *d_pw = nullptr, *d_obs_z = nullptr, *d_obs_zvel = nullptr, *d_P = nullptr;
-    int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_nzero = nullptr;
-    double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_La = nullptr;
-    double *d_Dinv1 = nullptr, *d_Dinv2 = nullptr, *d_T = nullptr, *d_S = nullptr, *d_Z = nullptr, *d_Pout = nullptr, *d_dx = nullptr;
+    int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_info = nullptr;
+    double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_A = nullptr;
+    double *d_RP = nullptr, *d_DinvP = nullptr, *d_U = nullptr, *d_M = nullptr, *d_RM = nullptr, *d_DinvM = nullptr;
+    double *d_Z = nullptr, *d_Pout = nullptr, *d_dx = nullptr;
+    double *d_La = nullptr, *d_DinvA = nullptr, *d_W = nullptr, *d_Y = nullptr, *d_KG = nullptr;   // optional outputs
     size_t hs_rows_cap = 0;
     int gram_chunks_cap = 64;
     // host staging
@@ -118,11 +123,15 @@ double orcvio_msckf_chi2_quantile(int32_t dof, double prob) {
 // ---- create / destroy ---------------------------------------------------------------------
 static void free_all(orcvio_msckf_handle* h) {
     void* ptrs[] = {h->d_poses, h->d_pw, h->d_obs_z, h->d_obs_zvel, h->d_P, h->d_obs_ptr, h->d_obs_clone, h->d_row_ptr,
-                    h->d_accept, h->d_nzero, h->d_chi2, h->d_Hs, h->d_gamma, h->d_Gpart, h->d_Ab, h->d_La, h->d_Dinv1,
-                    h->d_Dinv2, h->d_T, h->d_S, h->d_Z, h->d_Pout, h->d_dx};
+                    h->d_accept, h->d_info, h->d_chi2, h->d_Hs, h->d_gamma, h->d_Gpart, h->d_Ab, h->d_A, h->d_RP,
+                    h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_Pout, h->d_dx, h->d_La, h->d_DinvA,
+                    h->d_W, h->d_Y, h->d_KG};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->side) (void)hipStreamDestroy(h->side);
 }
 
 int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_features, int32_t max_observations,
@@ -152,7 +161,8 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
     h->maxObs = max_observations;
     h->n_max = 46 + 6 * max_clones;
     h->NAP_max = round_up(h->n_max - 15 + 1, 16);
-    if (h->NAP_max > POTRF_MAXN || h->NAP_max / 16 > TRSM_MAXBLK) {
+    h->NP_max = round_up(h->n_max + 1, 16);
+    if (h->NP_max > POTRF_MAXN || h->NP_max / 16 > TRSM_MAXBLK) {
         delete h;
         g_last_error = "orcvio_msckf_create: window too large for the single-workgroup factorisation";
         return ORCVIO_ERR_CAPACITY;
@@ -160,8 +170,11 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
     int rc = [&]() -> int {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
         const size_t nn = (size_t)h->n_max * h->n_max, pp = (size_t)h->NAP_max * h->NAP_max;
-        const size_t ldt = (size_t)round_up(h->n_max + 1, 16);
+        const size_t np2 = (size_t)h->NP_max * h->NP_max;
         h->hs_rows_cap = (size_t)2 * max_observations + 16;
         HIPCHK(hipMalloc(&h->d_poses, sizeof(double) * POSE_STRIDE * max_clones));
         HIPCHK(hipMalloc(&h->d_pw, sizeof(double) * 3 * max_features));
@@ -172,22 +185,31 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_obs_clone, sizeof(int) * max_observations));
         HIPCHK(hipMalloc(&h->d_row_ptr, sizeof(int) * (max_features + 1)));
         HIPCHK(hipMalloc(&h->d_accept, sizeof(int) * max_features));
-        HIPCHK(hipMalloc(&h->d_nzero, sizeof(int) * 4));
+        HIPCHK(hipMalloc(&h->d_info, sizeof(int) * 8));
         HIPCHK(hipMalloc(&h->d_chi2, sizeof(double) * ORCVIO_CHI2_TABLE));
         HIPCHK(hipMalloc(&h->d_Hs, sizeof(double) * h->hs_rows_cap * h->NAP_max));
         HIPCHK(hipMalloc(&h->d_gamma, sizeof(double) * max_features));
         HIPCHK(hipMalloc(&h->d_Gpart, sizeof(double) * pp * h->gram_chunks_cap));
         HIPCHK(hipMalloc(&h->d_Ab, sizeof(double) * pp));
-        HIPCHK(hipMalloc(&h->d_La, sizeof(double) * pp));
-        HIPCHK(hipMalloc(&h->d_Dinv1, sizeof(double) * 256 * TRSM_MAXBLK));
-        HIPCHK(hipMalloc(&h->d_Dinv2, sizeof(double) * 256 * TRSM_MAXBLK));
-        HIPCHK(hipMalloc(&h->d_T, sizeof(double) * h->NAP_max * ldt));
-        HIPCHK(hipMalloc(&h->d_S, sizeof(double) * pp));
-        HIPCHK(hipMalloc(&h->d_Z, sizeof(double) * h->NAP_max * ldt));
+        HIPCHK(hipMalloc(&h->d_A, sizeof(double) * pp));
+        HIPCHK(hipMalloc(&h->d_RP, sizeof(double) * np2));
+        HIPCHK(hipMalloc(&h->d_DinvP, sizeof(double) * 256 * TRSM_MAXBLK));
+        HIPCHK(hipMalloc(&h->d_U, sizeof(double) * np2));
+        HIPCHK(hipMalloc(&h->d_M, sizeof(double) * np2));
+        HIPCHK(hipMalloc(&h->d_RM, sizeof(double) * np2));
+        HIPCHK(hipMalloc(&h->d_DinvM, sizeof(double) * 256 * TRSM_MAXBLK));
+        HIPCHK(hipMalloc(&h->d_Z, sizeof(double) * np2));
         HIPCHK(hipMalloc(&h->d_Pout, sizeof(double) * nn));
         HIPCHK(hipMalloc(&h->d_dx, sizeof(double) * h->n_max));
-        HIPCHK(hipMemset(h->d_nzero, 0, sizeof(int) * 4));
+        HIPCHK(hipMalloc(&h->d_La, sizeof(double) * pp));
+        HIPCHK(hipMalloc(&h->d_DinvA, sizeof(double) * 256 * TRSM_MAXBLK));
+        HIPCHK(hipMalloc(&h->d_W, sizeof(double) * np2));
+        HIPCHK(hipMalloc(&h->d_Y, sizeof(double) * np2));
+        HIPCHK(hipMalloc(&h->d_KG, sizeof(double) * np2));
+        HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 8));
         HIPCHK(hipMemset(h->d_obs_zvel, 0, sizeof(double) * 2 * max_observations));
+        HIPCHK(hipMemset(h->d_RP, 0, sizeof(double) * np2));   // strictly-lower tiles of the upper factors stay 0
+        HIPCHK(hipMemset(h->d_RM, 0, sizeof(double) * np2));
         // opt in to large dynamic LDS for the feature kernel instantiations
         const int lds_max = 160 * 1024;
         HIPCHK(hipFuncSetAttribute((const void*)k_feature<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -251,7 +273,9 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->n = flags->leg_dim + 6 * N;
     h->NA = h->n - 15;
     h->NAP = round_up(h->NA + 1, 16);
-    h->ldt = round_up(h->n + 1, 16);
+    h->NP = round_up(h->n, 16);
+    h->ldz = round_up(h->n + 1, 16);
+    h->reg_path = (h->NP / 16) <= 14;
     h->m_tot = h->h_row_ptr[F];
     h->Mmax = Mmax;
     // chi-square table (src/orcvio.cpp:481-494)
@@ -348,47 +372,101 @@ static int launch_reduce(orcvio_msckf_handle* h, hipStream_t s, const double* pa
     return ORCVIO_OK;
 }
 
-enum { ST_POTRF_A = 0, ST_FORM_T, ST_FORM_S, ST_POTRF_S, ST_TRSM, ST_FINISH, ST_COUNT };
-
-static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) {
-    const int NA = h->NA, NAP = h->NAP, n = h->n, ldt = h->ldt;
-    const double sigma2 = h->flags.noise_feature * h->flags.noise_feature;
-    switch (stage) {
-        case ST_POTRF_A:
-            hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, h->d_La, NA + 1, NAP, (double)(NA + 1) * 2.220446049250313e-16,
-                               h->d_Dinv1, h->d_nzero);
-            break;
-        case ST_FORM_T: {
-            const int tiles = ((NA + 15) / 16) * ((n + 1 + 15) / 16);
-            hipLaunchKernelGGL(k_form_T, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_La, NAP, h->d_P, n, NA, h->d_T, ldt);
-            break;
-        }
-        case ST_FORM_S: {
-            const int nb = (NA + 15) / 16, tiles = nb * (nb + 1) / 2;
-            hipLaunchKernelGGL(k_form_S, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_T, ldt, h->d_La, NAP, NA, sigma2, h->d_S, NAP);
-            break;
-        }
-        case ST_POTRF_S:
-            hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, h->d_S, NA, NAP, 0.0, h->d_Dinv2, h->d_nzero + 1);
-            break;
-        case ST_TRSM:
-            hipLaunchKernelGGL(k_trsm, dim3((n + 1 + 15) / 16), dim3(64), 0, s, h->d_S, NAP, h->d_Dinv2, NA, h->d_T, ldt, n + 1,
-                               h->d_Z, ldt);
-            break;
-        case ST_FINISH: {
-            const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
-            hipLaunchKernelGGL(k_finish, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_Z, ldt, NA, h->d_P, n, h->d_Pout, h->d_dx);
-            break;
-        }
-        default: return ORCVIO_ERR_INVALID;
+// Cholesky X = L L^T.  reg path: upper factor R (L = R^T) written to `out` (ld = NP), L(i,j) = out[j*NP + i];
+// LDS-panel path: X copied to `out`, factored in place (lower), L(i,j) = out[i*NP + j].
+static int launch_potrf(orcvio_msckf_handle* h, hipStream_t s, const double* X, int ldx, int nn, double tol_rel, double* out,
+                        double* Dinv, int* info) {
+    const int NP = h->NP;
+    if (h->reg_path) {
+        const int nb = (nn + 15) / 16, ntiles = nb * (nb + 1) / 2, need = (ntiles + 7) / 8;
+        if (need <= 4) hipLaunchKernelGGL(k_potrf_reg<4>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
+        else if (need <= 8) hipLaunchKernelGGL(k_potrf_reg<8>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
+        else if (need <= 12) hipLaunchKernelGGL(k_potrf_reg<12>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
+        else hipLaunchKernelGGL(k_potrf_reg<14>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
+    } else {
+        HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * NP, X, sizeof(double) * ldx, sizeof(double) * nn, nn, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, out, nn, NP, tol_rel, Dinv, info);
     }
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
 
+static inline void factor_strides(const orcvio_msckf_handle* h, long& sLi, long& sLj) {
+    if (h->reg_path) { sLi = 1; sLj = h->NP; } else { sLi = h->NP; sLj = 1; }
+}
+
+static int launch_gemm(hipStream_t s, const double* A, long sAi, long sAk, const double* B, long sBk, long sBj, int M, int N,
+                       int K, double alpha, double diag_add, int upper_only, double* C, long sCi, long sCj) {
+    const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
+    hipLaunchKernelGGL(k_gemm, dim3((tiles + 3) / 4), dim3(256), 0, s, A, sAi, sAk, B, sBk, sBj, M, N, K, alpha, diag_add,
+                       upper_only, C, sCi, sCj);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+static int launch_trsm(orcvio_msckf_handle* h, hipStream_t s, const double* L, const double* Dinv, int nn, const double* B1,
+                       long sB1i, long sB1c, int nc1, const double* bx, long sbx, double* Z, int ldz) {
+    const int ncols = nc1 + (bx ? 1 : 0);
+    if (h->reg_path) {   // L = R^T, R row-major with ld NP: LDS-staged panels
+        const int nwave = (ncols + 15) / 16;
+        hipLaunchKernelGGL(k_trsm_lds, dim3((nwave + 3) / 4), dim3(256), 0, s, L, h->NP, Dinv, nn, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz);
+    } else {
+        long sLi, sLj;
+        factor_strides(h, sLi, sLj);
+        hipLaunchKernelGGL(k_trsm_rl<TRSM_MAXBLK>, dim3((ncols + 15) / 16), dim3(64), 0, s, L, sLi, sLj, Dinv, nn, B1, sB1i, sB1c,
+                           nc1, bx, sbx, Z, ldz);
+    }
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+// stages of the square-root Kalman solve (see msckf_kernels.hpp)
+enum { ST_POTRF_P = 0, ST_FORM_U, ST_FORM_M, ST_POTRF_M, ST_TRSM, ST_FINISH, ST_COUNT };
+
+static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) {
+    const int NA = h->NA, NAP = h->NAP, n = h->n, NP = h->NP, ldz = h->ldz;
+    const double sigma2 = h->flags.noise_feature * h->flags.noise_feature;
+    const double eps = 2.220446049250313e-16;
+    long sLi, sLj;
+    factor_strides(h, sLi, sLj);
+    const double* La = h->d_RP + 15 * sLi;   // L_a(k, j) = Lf(15 + k, j)
+    switch (stage) {
+        case ST_POTRF_P:   // P = Lf Lf^T
+            return launch_potrf(h, s, h->d_P, n, n, 8.0 * eps, h->d_RP, h->d_DinvP, h->d_info);
+        case ST_FORM_U:    // U[(NA+1) x n] = [A; b^T] * L_a
+            return launch_gemm(s, h->d_A, NAP, 1, La, sLi, sLj, NA + 1, n, NA, 1.0, 0.0, 0, h->d_U, NP, 1);
+        case ST_FORM_M:    // M = s2 I + L_a^T U[0:NA]   (upper tiles)
+            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, n, n, NA, 1.0, sigma2, 1, h->d_M, NP, 1);
+        case ST_POTRF_M:
+            return launch_potrf(h, s, h->d_M, NP, n, 0.0, h->d_RM, h->d_DinvM, h->d_info + 2);
+        case ST_TRSM:      // Z = L_M^-1 [Lf^T | g],  g = U[NA][:]
+            return launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_RP, sLj, sLi, n, h->d_U + (size_t)NA * NP, 1, h->d_Z, ldz);
+        case ST_FINISH: {
+            const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
+            hipLaunchKernelGGL(k_finish_sqrt, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_Z, ldz, n, sigma2, h->d_Pout, h->d_dx);
+            HIPCHK(hipGetLastError());
+            return ORCVIO_OK;
+        }
+        default: return ORCVIO_ERR_INVALID;
+    }
+}
+
+// fork: Cholesky of the prior on the side stream (depends on P only)
+static int launch_prior_fork(orcvio_msckf_handle* h, hipStream_t s) {
+    HIPCHK(hipEventRecord(h->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int) * 8, h->side));
+    int rc = launch_solve_stage(h, h->side, ST_POTRF_P);
+    if (rc != ORCVIO_OK) return rc;
+    HIPCHK(hipEventRecord(h->ev_side, h->side));
+    return ORCVIO_OK;
+}
+
 static int launch_finish_from(orcvio_msckf_handle* h, hipStream_t s, const double* parts, int nparts) {
-    int rc = launch_reduce(h, s, parts, nparts, h->d_La);
-    for (int st = 0; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
+    int rc = launch_reduce(h, s, parts, nparts, h->d_A);
+    if (rc != ORCVIO_OK) return rc;
+    HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));   // join
+    for (int st = ST_FORM_U; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
     return rc;
 }
 
@@ -398,7 +476,8 @@ int32_t orcvio_msckf_run_local(orcvio_msckf_handle* h, void* stream) {
     if (!h || !h->uploaded) { g_last_error = "run_local: nothing uploaded"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
-    int rc = launch_feature(h, s);
+    int rc = launch_prior_fork(h, s);
+    if (rc == ORCVIO_OK) rc = launch_feature(h, s);
     if (rc == ORCVIO_OK) rc = launch_gram(h, s);
     if (rc == ORCVIO_OK) rc = launch_reduce(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1, h->d_Ab);
     return rc;
@@ -423,7 +502,8 @@ int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     if (!h || !h->uploaded) { g_last_error = "run_update: nothing uploaded"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
-    int rc = launch_feature(h, s);
+    int rc = launch_prior_fork(h, s);
+    if (rc == ORCVIO_OK) rc = launch_feature(h, s);
     if (rc == ORCVIO_OK) rc = launch_gram(h, s);
     if (rc == ORCVIO_OK) rc = launch_finish_from(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1);
     if (rc == ORCVIO_OK) h->ran = true;
@@ -434,15 +514,46 @@ int32_t orcvio_msckf_sync(orcvio_msckf_handle* h, void* stream) {
     if (!h) return ORCVIO_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(pick_stream(h, stream)));
+    HIPCHK(hipStreamSynchronize(h->side));
     return ORCVIO_OK;
 }
 
 // ---- download --------------------------------------------------------------------------------
+// Optional outputs in the reference's own terms (computed on the device, on request only):
+//   H_thin = R_A (A = R_A^T R_A, zero rows on rank-deficient directions), r_thin = R_A^-T b,
+//   K = P H_thin^T S^-1 = Lf M^-1 L_a^T R_A^T,   G = K H_thin = Lf M^-1 L_a^T A.
+static int compute_optional(orcvio_msckf_handle* h, bool want_thin_or_K, bool want_K, bool want_G) {
+    const int NA = h->NA, NAP = h->NAP, n = h->n, NP = h->NP, ldz = h->ldz;
+    hipStream_t s = h->stream;
+    long sLi, sLj;
+    factor_strides(h, sLi, sLj);
+    const double* La_P = h->d_RP + 15 * sLi;
+    if (want_thin_or_K) {   // lower Cholesky factor of the Gram block with the LDS-panel kernel
+        HIPCHK(hipMemcpyAsync(h->d_La, h->d_A, sizeof(double) * (size_t)NAP * NAP, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, h->d_La, NA + 1, NAP, (double)(NA + 1) * 2.220446049250313e-16,
+                           h->d_DinvA, h->d_info + 4);
+        HIPCHK(hipGetLastError());
+    }
+    if (want_G) {   // W = L_M^-1 U[0:NA]^T (n x NA);  G[:, 15:] = Zn^T W
+        int rc = launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_U, 1, NP, NA, nullptr, 0, h->d_W, NP);
+        if (rc == ORCVIO_OK) rc = launch_gemm(s, h->d_Z, 1, ldz, h->d_W, NP, 1, n, NA, n, 1.0, 0.0, 0, h->d_KG, NP, 1);
+        if (rc != ORCVIO_OK) return rc;
+    }
+    if (want_K) {   // Y = L_a^T R_A^T (n x NA); W = L_M^-1 Y; K = Zn^T W  -> stored after G in d_KG
+        int rc = launch_gemm(s, La_P, sLj, sLi, h->d_La, NAP, 1, n, NA, NA, 1.0, 0.0, 0, h->d_Y, NP, 1);
+        if (rc == ORCVIO_OK) rc = launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_Y, NP, 1, NA, nullptr, 0, h->d_W, NP);
+        if (rc == ORCVIO_OK) rc = launch_gemm(s, h->d_Z, 1, ldz, h->d_W, NP, 1, n, NA, n, 1.0, 0.0, 0, h->d_Y, NP, 1);
+        if (rc != ORCVIO_OK) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return ORCVIO_OK;
+}
+
 int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) {
     if (!h || !res || !h->ran) { g_last_error = "download: no finished update"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
-    const int n = h->n, NA = h->NA, NAP = h->NAP, F = h->F, ldt = h->ldt;
+    const int n = h->n, NA = h->NA, NAP = h->NAP, NP = h->NP, F = h->F;
     std::vector<int> acc(F > 0 ? F : 1, 0);
     std::vector<double> dx(n);
     if (F > 0) HIPCHK(hipMemcpy(acc.data(), h->d_accept, sizeof(int) * F, hipMemcpyDeviceToHost));
@@ -451,8 +562,8 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
     if (res->P_out) HIPCHK(hipMemcpy(res->P_out, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
     if (res->accept && F > 0) std::memcpy(res->accept, acc.data(), sizeof(int) * F);
     if (res->gamma && F > 0) HIPCHK(hipMemcpy(res->gamma, h->d_gamma, sizeof(double) * F, hipMemcpyDeviceToHost));
-    int nz[2] = {0, 0};
-    HIPCHK(hipMemcpy(nz, h->d_nzero, sizeof(int) * 2, hipMemcpyDeviceToHost));
+    int info[8] = {0};
+    HIPCHK(hipMemcpy(info, h->d_info, sizeof(int) * 8, hipMemcpyDeviceToHost));
     int stacked = 0, nacc = 0;
     for (int j = 0; j < F; ++j)
         if (acc[j]) { stacked += h->h_row_ptr[j + 1] - h->h_row_ptr[j]; ++nacc; }
@@ -466,42 +577,36 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
         const double np = std::sqrt(dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8]);
         res->stats[4] = (nv > 1.0 || np > 1.5) ? 1 : 0;   // src/orcvio.cpp:4479-4494
     }
-    res->stats[5] = nz[0];
-    if (nz[1] != 0) { g_last_error = "S = H P H^T + sigma^2 I is not positive definite"; return ORCVIO_ERR_NOT_SPD; }
-    if (res->H_thin || res->r_thin || res->K || res->G) {
-        std::vector<double> La((size_t)NAP * NAP);
-        HIPCHK(hipMemcpy(La.data(), h->d_La, sizeof(double) * La.size(), hipMemcpyDeviceToHost));
-        if (res->H_thin) {
-            std::memset(res->H_thin, 0, sizeof(double) * (size_t)NA * n);
-            for (int i = 0; i < NA; ++i)
-                for (int k = i; k < NA; ++k) res->H_thin[(size_t)i * n + 15 + k] = La[(size_t)k * NAP + i];
-        }
-        if (res->r_thin)
-            for (int i = 0; i < NA; ++i) res->r_thin[i] = La[(size_t)NA * NAP + i];
-        if (res->K || res->G) {
-            // K^T = L_S^-T Z_n (back substitution on the host: optional diagnostic outputs)
-            std::vector<double> Ls((size_t)NAP * NAP), Z((size_t)NA * ldt);
-            HIPCHK(hipMemcpy(Ls.data(), h->d_S, sizeof(double) * Ls.size(), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(Z.data(), h->d_Z, sizeof(double) * Z.size(), hipMemcpyDeviceToHost));
-            std::vector<double> KT((size_t)NA * n);
-            for (int i = NA - 1; i >= 0; --i)
-                for (int c = 0; c < n; ++c) {
-                    double sres = Z[(size_t)i * ldt + c];
-                    for (int k = i + 1; k < NA; ++k) sres -= Ls[(size_t)k * NAP + i] * KT[(size_t)k * n + c];
-                    KT[(size_t)i * n + c] = sres / Ls[(size_t)i * NAP + i];
-                }
-            if (res->K)
-                for (int c = 0; c < n; ++c)
-                    for (int i = 0; i < NA; ++i) res->K[(size_t)c * NA + i] = KT[(size_t)i * n + c];
-            if (res->G) {
-                std::memset(res->G, 0, sizeof(double) * (size_t)n * n);
+    res->stats[5] = info[0];   // zero-variance directions of the prior (dropped pivots of chol(P))
+    res->stats[6] = info[1];   // pivots of chol(P) below -tol: the prior was not PSD
+    if (info[2] != 0) { g_last_error = "M = s2 I + L^T A L is not positive definite (non-finite input?)"; return ORCVIO_ERR_NOT_SPD; }
+    const bool want_thin = res->H_thin || res->r_thin;
+    if (want_thin || res->K || res->G) {
+        int rc = compute_optional(h, want_thin || res->K, res->K != nullptr, res->G != nullptr);
+        if (rc != ORCVIO_OK) return rc;
+        if (want_thin) {
+            std::vector<double> La((size_t)NAP * NAP);
+            HIPCHK(hipMemcpy(La.data(), h->d_La, sizeof(double) * La.size(), hipMemcpyDeviceToHost));
+            if (res->H_thin) {
+                std::memset(res->H_thin, 0, sizeof(double) * (size_t)NA * n);
                 for (int i = 0; i < NA; ++i)
-                    for (int c = 0; c < n; ++c) {
-                        const double kv = KT[(size_t)i * n + c];
-                        if (kv == 0.0) continue;
-                        for (int k = i; k < NA; ++k) res->G[(size_t)c * n + 15 + k] += kv * La[(size_t)k * NAP + i];
-                    }
+                    for (int k = i; k < NA; ++k) res->H_thin[(size_t)i * n + 15 + k] = La[(size_t)k * NAP + i];
             }
+            if (res->r_thin)
+                for (int i = 0; i < NA; ++i) res->r_thin[i] = La[(size_t)NA * NAP + i];
+        }
+        if (res->G) {
+            std::vector<double> Gd((size_t)n * NP);
+            HIPCHK(hipMemcpy(Gd.data(), h->d_KG, sizeof(double) * Gd.size(), hipMemcpyDeviceToHost));
+            std::memset(res->G, 0, sizeof(double) * (size_t)n * n);
+            for (int i = 0; i < n; ++i)
+                for (int c = 0; c < NA; ++c) res->G[(size_t)i * n + 15 + c] = Gd[(size_t)i * NP + c];
+        }
+        if (res->K) {
+            std::vector<double> Kd((size_t)n * NP);
+            HIPCHK(hipMemcpy(Kd.data(), h->d_Y, sizeof(double) * Kd.size(), hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i)
+                for (int c = 0; c < NA; ++c) res->K[(size_t)i * NA + c] = Kd[(size_t)i * NP + c];
         }
     }
     return ORCVIO_OK;
@@ -528,7 +633,7 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle*, const orcvio_msckf_fla
 int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_t reps, const char** names, double* ms,
                                     int32_t* count) {
     if (!h || !h->uploaded || !names || !ms || !count || reps < 1) { g_last_error = "profile_update: invalid"; return ORCVIO_ERR_INVALID; }
-    static const char* kn[] = {"k_feature", "k_gram", "k_gram_reduce", "k_potrf(A)", "k_form_T", "k_form_S", "k_potrf(S)", "k_trsm", "k_finish"};
+    static const char* kn[] = {"k_feature", "k_gram", "k_gram_reduce", "k_potrf(P)", "k_gemm(U)", "k_gemm(M)", "k_potrf(M)", "k_trsm", "k_finish"};
     const int nk = 9;
     if (*count < nk) { g_last_error = "profile_update: need room for 9 entries"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
@@ -543,7 +648,7 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
             int rc = ORCVIO_OK;
             if (k == 0) rc = launch_feature(h, s);
             else if (k == 1) rc = launch_gram(h, s);
-            else if (k == 2) rc = launch_reduce(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1, h->d_La);
+            else if (k == 2) rc = launch_reduce(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1, h->d_A);
             else rc = launch_solve_stage(h, s, k - 3);
             if (rc != ORCVIO_OK) return rc;
             HIPCHK(hipEventRecord(e1, s));
@@ -557,6 +662,8 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
     *count = nk;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int) * 8, s));
+    HIPCHK(hipStreamSynchronize(s));
     h->ran = true;
     return ORCVIO_OK;
 }
@@ -644,24 +751,26 @@ int32_t orcvio_msckf_increment_state(const orcvio_msckf_flags* f, const double* 
 }
 
 // ---- debug access to intermediate device buffers (tests only; not part of the public header) ---
-// which: 0 Hs [m_tot x NAP], 1 Ab, 2 La, 3 T, 4 S, 5 Z, 6 Gpart (chunk 0), 7 dims -> int32[8]
+// which: 0 Hs [m_tot x NAP], 1 Ab, 2 A (summed block), 3 RP, 4 M, 5 RM, 6 Z, 8 U, 7 dims -> int32[8]
 int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst, int64_t max_bytes) {
     if (!h || !dst) return ORCVIO_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
     const size_t pp = (size_t)h->NAP * h->NAP * sizeof(double);
+    const size_t np2 = (size_t)h->NP * h->NP * sizeof(double);
     const void* src = nullptr;
     size_t bytes = 0;
     switch (which) {
         case 0: src = h->d_Hs; bytes = (size_t)h->m_tot * h->NAP * sizeof(double); break;
         case 1: src = h->d_Ab; bytes = pp; break;
-        case 2: src = h->d_La; bytes = pp; break;
-        case 3: src = h->d_T; bytes = (size_t)h->NA * h->ldt * sizeof(double); break;
-        case 4: src = h->d_S; bytes = pp; break;
-        case 5: src = h->d_Z; bytes = (size_t)h->NA * h->ldt * sizeof(double); break;
-        case 6: src = h->d_Gpart; bytes = pp; break;
+        case 2: src = h->d_A; bytes = pp; break;
+        case 3: src = h->d_RP; bytes = np2; break;
+        case 4: src = h->d_M; bytes = np2; break;
+        case 5: src = h->d_RM; bytes = np2; break;
+        case 6: src = h->d_Z; bytes = (size_t)h->n * h->ldz * sizeof(double); break;
+        case 8: src = h->d_U; bytes = np2; break;
         case 7: {
-            int32_t dims[8] = {h->n, h->NA, h->NAP, h->ldt, h->m_tot, h->Mmax, h->chunks, h->rows_per_chunk};
+            int32_t dims[8] = {h->n, h->NA, h->NAP, h->NP, h->m_tot, h->Mmax, h->ldz, h->reg_path ? 1 : 0};
             if ((size_t)max_bytes < sizeof(dims)) return ORCVIO_ERR_INVALID;
             std::memcpy(dst, dims, sizeof(dims));
             return ORCVIO_OK;
@@ -670,6 +779,86 @@ int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst
     }
     if ((size_t)max_bytes < bytes) { g_last_error = "debug_read: buffer too small"; return ORCVIO_ERR_INVALID; }
     if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return ORCVIO_OK;
+}
+
+// Test hook: factor an arbitrary symmetric n x n host matrix with the same kernels the update uses.
+// Out: L (n x n lower, row-major, host), Dinv ([nb][16][16]), info[2] (dropped / negative pivots).
+int32_t orcvio_msckf_debug_potrf(orcvio_msckf_handle* h, const double* X, int32_t n, double tol_rel, int32_t force_lds_path,
+                                 double* L_out, double* Dinv_out, int32_t* info_out) {
+    if (!h || !X || n < 1 || n > h->n_max) return ORCVIO_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    const int saveNP = h->NP;
+    const bool save_path = h->reg_path;
+    h->NP = round_up(n, 16);
+    h->reg_path = !force_lds_path && (h->NP / 16) <= 14;
+    const int NP = h->NP;
+    HIPCHK(hipMemcpy(h->d_M, X, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 8));
+    int rc = launch_potrf(h, h->stream, h->d_M, n, n, tol_rel, h->d_RM, h->d_DinvM, h->d_info);
+    if (rc == ORCVIO_OK) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::vector<double> buf((size_t)NP * NP);
+        HIPCHK(hipMemcpy(buf.data(), h->d_RM, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+        long sLi, sLj;
+        factor_strides(h, sLi, sLj);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) L_out[(size_t)i * n + j] = buf[(size_t)i * sLi + (size_t)j * sLj];
+        if (Dinv_out) HIPCHK(hipMemcpy(Dinv_out, h->d_DinvM, sizeof(double) * 256 * ((n + 15) / 16), hipMemcpyDeviceToHost));
+        if (info_out) HIPCHK(hipMemcpy(info_out, h->d_info, sizeof(int) * 2, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 8));
+        // d_RM lower tiles may now hold data of another leading dimension: restore the invariant
+        HIPCHK(hipMemset(h->d_RM, 0, sizeof(double) * (size_t)h->NP_max * h->NP_max));
+    }
+    h->NP = saveNP;
+    h->reg_path = save_path;
+    return rc;
+}
+
+// Test hook: Z = L^-1 B with the factor left in the handle by orcvio_msckf_debug_potrf_keep (same call
+// with keep = 1 semantics: call debug_potrf first, then this before anything else).
+int32_t orcvio_msckf_debug_trsm(orcvio_msckf_handle* h, const double* X, int32_t n, const double* B, int32_t nrhs, double* Z_out) {
+    if (!h || !X || !B || n < 1 || n > h->n_max || nrhs < 1 || nrhs > h->NP_max) return ORCVIO_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    const int saveNP = h->NP, saveldz = h->ldz;
+    const bool save_path = h->reg_path;
+    h->NP = round_up(n, 16);
+    h->reg_path = (h->NP / 16) <= 14;
+    const int NP = h->NP;
+    HIPCHK(hipMemcpy(h->d_M, X, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_U, B, sizeof(double) * (size_t)n * nrhs, hipMemcpyHostToDevice));
+    int rc = launch_potrf(h, h->stream, h->d_M, n, n, 0.0, h->d_RM, h->d_DinvM, h->d_info);
+    if (rc == ORCVIO_OK) rc = launch_trsm(h, h->stream, h->d_RM, h->d_DinvM, n, h->d_U, nrhs, 1, nrhs, nullptr, 0, h->d_Z, h->NP_max);
+    if (rc == ORCVIO_OK) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::vector<double> buf((size_t)n * h->NP_max);
+        HIPCHK(hipMemcpy(buf.data(), h->d_Z, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < nrhs; ++c) Z_out[(size_t)i * nrhs + c] = buf[(size_t)i * h->NP_max + c];
+        HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 8));
+        HIPCHK(hipMemset(h->d_RM, 0, sizeof(double) * (size_t)h->NP_max * h->NP_max));
+    }
+    (void)NP;
+    h->NP = saveNP; h->ldz = saveldz; h->reg_path = save_path;
+    return rc;
+}
+
+// Diagnostic: in-kernel cycle stamps of k_potrf_reg<12> on the handle's current P (phase boundaries
+// per block step and wave).  stamps_out: [nb][4][8] uint64.
+int32_t orcvio_msckf_debug_potrf_stamps(orcvio_msckf_handle* h, unsigned long long* stamps_out, int32_t nb_cap) {
+    if (!h || !h->uploaded || !h->reg_path) return ORCVIO_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->n, NP = h->NP, nb = NP / 16;
+    if (nb > nb_cap) return ORCVIO_ERR_INVALID;
+    unsigned long long* d_st = nullptr;
+    HIPCHK(hipMalloc(&d_st, sizeof(unsigned long long) * nb * 64));
+    HIPCHK(hipMemset(d_st, 0, sizeof(unsigned long long) * nb * 64));
+    for (int rep = 0; rep < 3; ++rep)
+        hipLaunchKernelGGL(k_potrf_reg<14>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
+                           h->d_info + 6, d_st);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(stamps_out, d_st, sizeof(unsigned long long) * nb * 64, hipMemcpyDeviceToHost));
+    (void)hipFree(d_st);
     return ORCVIO_OK;
 }
 

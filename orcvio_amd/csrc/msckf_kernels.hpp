@@ -45,6 +45,76 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
+// broadcast of a double from a lane known at compile time: v_readlane (no LDS traffic)
+__device__ __forceinline__ double bcast_lane(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
+// ---- FP64 DPP row broadcasts (gfx90a+): lane C of every 16-lane row feeds all lanes of that row.
+// One instruction does broadcast + multiply-add; the compiler never emits these.  hipcc does not
+// insert VALU->DPP wait states around inline asm, so every consumer block starts with s_nop 1.
+template <int C>
+__device__ __forceinline__ double dpp_row_bcast(double a) {
+    double d;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=&v"(d) : "v"(a), "n"(C));
+    return d;
+}
+template <int C>
+__device__ __forceinline__ void dpp_fnmac(double& acc, double a, double b) {   // acc -= a[lane C of the row] * b
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(C));
+}
+template <int J, int C>
+struct DiagUpd {
+    static __device__ __forceinline__ void run(double (&v)[16], double (&y)[16], double m, double x) {
+        dpp_fnmac<C>(v[C], m, m);   // A[r][C] -= L[C][J] * L[r][J]
+        dpp_fnmac<C>(y[C], m, x);   // Linv[C][r] -= L[C][J] * Linv[J][r]
+        DiagUpd<J, C + 1>::run(v, y, m, x);
+    }
+};
+template <int J>
+struct DiagUpd<J, 16> {
+    static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double, double) {}
+};
+// right-looking Cholesky + inverse of a 16x16 tile: lane (l & 15) holds row r of the tile in v[] and
+// column r of the inverse in y[]; the four 16-lane rows of the wavefront work redundantly.
+template <int J>
+struct DiagStep {
+    static __device__ __forceinline__ void run(double (&v)[16], double (&y)[16], double tol, int nlive, int& nzero, int& nneg) {
+        const double d = dpp_row_bcast<J>(v[J]);
+        const bool live = J < nlive;
+        const bool ok = live && (d > tol);
+        nzero += (live && !ok) ? 1 : 0;
+        nneg += (live && d < -tol) ? 1 : 0;
+        double inv = __builtin_amdgcn_rsq(ok ? d : 1.0);
+        const double h = 0.5 * d;
+        inv = inv * (1.5 - h * inv * inv);
+        inv = inv * (1.5 - h * inv * inv);
+        inv = ok ? inv : 0.0;
+        const double m = v[J] * inv;
+        const double x = y[J] * inv;
+        v[J] = m;
+        y[J] = x;
+        asm volatile("s_nop 1" ::"v"(m), "v"(x));
+        DiagUpd<J, J + 1>::run(v, y, m, x);
+        DiagStep<J + 1>::run(v, y, tol, nlive, nzero, nneg);
+    }
+};
+template <>
+struct DiagStep<16> {
+    static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double, int, int&, int&) {}
+};
+
 __device__ __forceinline__ void wave_sync() {
     // single-wave workgroups: LDS operations of one wave execute in order; this only
     // stops the compiler from moving LDS accesses across the point.
@@ -232,9 +302,28 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
 #pragma unroll
         for (int e = 0; e < 7; ++e) pe[ps][e] = (a < NA) ? p.P[(size_t)(15 + e) * n + 15 + a] : 0.0;
     }
+    // P rows of the clone of observation l are prefetched one iteration ahead (18 coalesced loads in
+    // flight while the previous observation is being consumed)
+    double pcur[NPASS][6], pnxt[NPASS][6];
+    {
+        const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[0]) * n + 15;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int a = t + 64 * ps;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pcur[ps][c] = (a < NA) ? Prow[(size_t)c * n + a] : 0.0;
+        }
+    }
     for (int l = 0; l < M; ++l) {
-        const int cl = sOC[l];
-        const double* Prow = p.P + (size_t)(p.leg + 6 * cl) * n + 15;
+        if (l + 1 < M) {
+            const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[l + 1]) * n + 15;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int a = t + 64 * ps;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) pnxt[ps][c] = (a < NA) ? Prow[(size_t)c * n + a] : 0.0;
+            }
+        }
         double jl0e[7], jl1e[7], jl0x[6], jl1x[6];
 #pragma unroll
         for (int e = 0; e < 7; ++e) { jl0e[e] = sJe[(2 * l) * 7 + e]; jl1e[e] = sJe[(2 * l + 1) * 7 + e]; }
@@ -249,9 +338,8 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
                 for (int e = 0; e < 7; ++e) { u0 += jl0e[e] * pe[ps][e]; u1 += jl1e[e] * pe[ps][e]; }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
-                    const double pc = Prow[(size_t)c * n + a];
-                    u0 += jl0x[c] * pc;
-                    u1 += jl1x[c] * pc;
+                    u0 += jl0x[c] * pcur[ps][c];
+                    u1 += jl1x[c] * pcur[ps][c];
                 }
                 sU[2 * a] = u0;
                 sU[2 * a + 1] = u1;
@@ -268,6 +356,10 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
             sE[t * LDE + 2 * l + 1] = e1;
         }
         wave_sync();
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pcur[ps][c] = pnxt[ps][c];
     }
 
     // row of E into registers (static indexing: full unroll)
@@ -336,7 +428,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
         if (jc < M2) {
             const double d = __shfl(row[jc], jc) + p.sigma2;
             if (!(d > 0.0)) fail = true;
-            const double inv = 1.0 / sqrt(d);
+            const double inv = rsqrt_nr(d);
             const double lr = row[jc] * inv;
             double* col = sCol + 64 * (jc & 1);
             col[t] = lr;
@@ -412,22 +504,22 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int 
     const double* pa = X + (size_t)(r0 + kk) * NAP + 16 * bi + cc;
     const double* pb = X + (size_t)(r0 + kk) * NAP + 16 * bj + cc;
     d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    int k = r0;
-    // two independent accumulators to cover the MFMA dependent-issue latency
-    for (; k + 8 <= r1; k += 8) {
-        const double a0 = pa[0], b0 = pb[0];
-        const double a1 = pa[(size_t)4 * NAP], b1 = pb[(size_t)4 * NAP];
-        acc0 = mfma_f64(a0, b0, acc0);
-        acc1 = mfma_f64(a1, b1, acc1);
-        pa += (size_t)8 * NAP;
-        pb += (size_t)8 * NAP;
-    }
-    for (; k < r1; k += 4) {
-        const bool in = (k + kk) < r1;
-        const double a0 = in ? pa[0] : 0.0, b0 = in ? pb[0] : 0.0;
-        acc0 = mfma_f64(a0, b0, acc0);
-        pa += (size_t)4 * NAP;
-        pb += (size_t)4 * NAP;
+    constexpr int GB = 16;   // k-steps (of 4 rows) whose operands are in flight together
+    for (int k = r0; k < r1; k += 4 * GB) {
+        double a[GB], b[GB];
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+            const bool in = (k + 4 * q + kk) < r1;
+            a[q] = in ? pa[(size_t)(4 * q) * NAP] : 0.0;
+            b[q] = in ? pb[(size_t)(4 * q) * NAP] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < GB; q += 2) {
+            acc0 = mfma_f64(a[q], b[q], acc0);
+            acc1 = mfma_f64(a[q + 1], b[q + 1], acc1);
+        }
+        pa += (size_t)(4 * GB) * NAP;
+        pb += (size_t)(4 * GB) * NAP;
     }
     double* out = Gpart + (size_t)chunk * NAP * NAP;
 #pragma unroll
@@ -437,18 +529,24 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int 
     }
 }
 
-// Sums `nparts` blocks (lower tiles) into dst; used for the chunk partials of one rank and
-// for the all-gathered blocks of all ranks.  Strictly-upper tiles are written as zero.
+// Sums `nparts` blocks into dst (full symmetric result); used for the chunk partials of one
+// rank (lower tiles valid) and for the all-gathered blocks of all ranks.
 __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ parts, int nparts, size_t part_stride,
                                                      int NAP, double* __restrict__ dst) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= NAP * NAP) return;
     const int i = idx / NAP, jj = idx - i * NAP;
-    double s = 0.0;
-    if ((i >> 4) >= (jj >> 4)) {
-        for (int c = 0; c < nparts; ++c) s += parts[(size_t)c * part_stride + idx];
+    // parts hold lower tiles only; mirror them so that dst is the full symmetric block
+    const int src = ((i >> 4) >= (jj >> 4)) ? idx : jj * NAP + i;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 0;
+    for (; c + 4 <= nparts; c += 4) {   // four loads in flight; fixed summation order (deterministic)
+        const double v0 = parts[(size_t)c * part_stride + src], v1 = parts[(size_t)(c + 1) * part_stride + src];
+        const double v2 = parts[(size_t)(c + 2) * part_stride + src], v3 = parts[(size_t)(c + 3) * part_stride + src];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
-    dst[idx] = s;
+    for (; c < nparts; ++c) s0 += parts[(size_t)c * part_stride + src];
+    dst[idx] = (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -596,26 +694,29 @@ __global__ __launch_bounds__(1024) void k_potrf(double* __restrict__ A, int n, i
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ d4 tile_product(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
                                            long sBk, long sBj, int M, int N, int K, int i0, int j0, int l) {
+    // Operands of TP_BATCH k-steps are loaded before the first MFMA of the batch: the kernels built on
+    // this are latency-bound (one tile per wavefront), so loads must be in flight together.
+    constexpr int TP_BATCH = 12;
     const int kk = l >> 4, cc = l & 15;
     const bool ia = (i0 + cc) < M, jb = (j0 + cc) < N;
     const double* pa = A + (long)(i0 + cc) * sAi + (long)kk * sAk;
     const double* pb = B + (long)kk * sBk + (long)(j0 + cc) * sBj;
     d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    int k = 0;
-    for (; k + 8 <= K; k += 8) {
-        const double a0 = ia ? pa[0] : 0.0, b0 = jb ? pb[0] : 0.0;
-        const double a1 = ia ? pa[4 * sAk] : 0.0, b1 = jb ? pb[4 * sBk] : 0.0;
-        acc0 = mfma_f64(a0, b0, acc0);
-        acc1 = mfma_f64(a1, b1, acc1);
-        pa += 8 * sAk;
-        pb += 8 * sBk;
-    }
-    for (; k < K; k += 4) {
-        const bool kin = (k + kk) < K;
-        const double a0 = (ia && kin) ? pa[0] : 0.0, b0 = (jb && kin) ? pb[0] : 0.0;
-        acc0 = mfma_f64(a0, b0, acc0);
-        pa += 4 * sAk;
-        pb += 4 * sBk;
+    for (int k = 0; k < K; k += 4 * TP_BATCH) {
+        double a[TP_BATCH], b[TP_BATCH];
+#pragma unroll
+        for (int q = 0; q < TP_BATCH; ++q) {
+            const bool kin = (k + 4 * q + kk) < K;
+            a[q] = (ia && kin) ? pa[(long)(4 * q) * sAk] : 0.0;
+            b[q] = (jb && kin) ? pb[(long)(4 * q) * sBk] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < TP_BATCH; q += 2) {
+            acc0 = mfma_f64(a[q], b[q], acc0);
+            acc1 = mfma_f64(a[q + 1], b[q + 1], acc1);
+        }
+        pa += (long)(4 * TP_BATCH) * sAk;
+        pb += (long)(4 * TP_BATCH) * sBk;
     }
     d4 acc;
 #pragma unroll
@@ -739,6 +840,413 @@ __global__ __launch_bounds__(64) void k_trsm(const double* __restrict__ L, int l
                 const int i = 16 * kb + kk + 4 * r;
                 if (jin && i < NA) Z[(size_t)i * ldz + j0 + cc] = x[r];
             }
+        }
+    }
+}
+
+
+// =======================================================================================
+// Register-resident Cholesky and the square-root form of the Kalman solve
+// =======================================================================================
+//
+// With P = Lf Lf^T (Cholesky of the prior covariance, zero-variance states give zero
+// columns) and L_a = Lf[15:n, :], the update of reference src/orcvio.cpp:1682-1753
+//     S = H P H^T + s2 I,  K = P H^T S^-1,  dx = K r,  P+ = (I - K H) P
+// is, exactly,
+//     M  = s2 I + L_a^T A L_a            (A = H^T H, b = H^T r: the compressed block)
+//     dx = Lf M^-1 L_a^T b,   P+ = s2 Lf M^-1 Lf^T.
+// M is SPD with eigenvalues >= s2 whatever the rank of H, so no rank decision is needed
+// (the Gram block A is singular in every update: gauge freedom), and P+ is PSD by
+// construction.  Factors are stored as UPPER triangles R (X = R^T R, row-major), so that
+// both operands of every trailing update are MFMA accumulator tiles as they stand.
+
+// k_potrf_reg: one workgroup of 8 wavefronts; every 16x16 tile of the upper triangle lives
+// in the registers of one wavefront (slot s of wave w <-> tile index 8 s + w) from the
+// first load to the last store.  Per block step: the owner of the diagonal tile factors it
+// (rows in lanes, pivots broadcast with v_readlane) and publishes inv(L11) through LDS;
+// panel tiles become inv(L11) * tile with 4 MFMAs and are published through LDS in the
+// accumulator layout; trailing tiles subtract panel_a^T panel_b with 4 MFMAs.
+//   X  : symmetric input (full diagonal tiles + upper tiles are read), n x n, ldx
+//   R  : output upper factor, row-major ldr (lower parts of diagonal tiles written as 0)
+//   Dinv[nb][16][16] : inv(L11) of every diagonal block (generalised inverse on zero pivots)
+//   info[0] += pivots <= tol (dropped), info[1] += pivots < -tol (matrix not PSD)
+template <int NSLOT>
+__global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X, int ldx, int n, double tol_rel,
+                                                   double* __restrict__ R, int ldr, double* __restrict__ Dinv,
+                                                   int* __restrict__ info, unsigned long long* __restrict__ stamps = nullptr) {
+    __shared__ __attribute__((aligned(16))) double sD[16][16];
+    __shared__ __attribute__((aligned(16))) double sDi[16][16];
+    __shared__ __attribute__((aligned(16))) double sPan[14][4][64];   // published panel tiles, accumulator layout
+    __shared__ __attribute__((aligned(16))) double sDall[14 * 256];   // inv(L11) of every block step
+    __shared__ double sred[8];
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int kk = l >> 4, cc = l & 15;
+    const int nb = (n + 15) >> 4;
+    const int ntiles = nb * (nb + 1) / 2;
+
+    // largest diagonal entry -> pivot tolerance
+    double mx = 0.0;
+    for (int i = tid; i < n; i += 512) mx = fmax(mx, X[(size_t)i * ldx + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if (l == 0) sred[wave] = mx;
+    __syncthreads();
+    mx = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) mx = fmax(mx, sred[w]);
+    const double tol = tol_rel * mx;
+
+    // tile ownership (wave-uniform -> scalar registers) and load
+    d4 acc[NSLOT];
+    int ta[NSLOT], tb[NSLOT];   // tile (a <= b): rows 16a.., cols 16b..
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int tl = s * 8 + wave;
+        int bi = 0, bj = 0;
+        if (tl < ntiles) tile_from_linear(tl, bi, bj);
+        ta[s] = __builtin_amdgcn_readfirstlane((tl < ntiles) ? bj : -1);
+        tb[s] = __builtin_amdgcn_readfirstlane((tl < ntiles) ? bi : -1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * bj + kk + 4 * r, j = 16 * bi + cc;
+            acc[s][r] = (tl < ntiles && i < n && j < n) ? X[(size_t)i * ldx + j] : 0.0;
+            // the mirrored (strictly lower) tile of the output is never touched again: zero it
+            if (tl < ntiles && bi != bj) {
+                const int i2 = 16 * bi + kk + 4 * r, j2 = 16 * bj + cc;
+                if (i2 < n && j2 < n) R[(size_t)i2 * ldr + j2] = 0.0;
+            }
+        }
+    }
+    int nzero = 0, nneg = 0;
+
+    // Factor + invert one 16x16 diagonal tile held in the accumulator layout; returns R11 = L11^T
+    // in the same layout and publishes inv(L11) in sDi / sDall[kb].  One right-looking sweep
+    // (DiagStep): every rank-1 update is ONE v_fmac_f64_dpp (row broadcast fused into the FMA).
+    auto factor_diag = [&](d4 t, int kb) -> d4 {
+        int z = 0;
+        asm volatile("" : "+v"(z));   // opaque zero: keeps LDS address arithmetic out of loop-invariant hoisting
+        double* pD = &sD[0][0] + z;
+        double* pDi = &sDi[0][0] + z;
+        double* pDall = &sDall[0] + z;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pD[(kk + 4 * r) * 16 + cc] = t[r];
+        wave_sync();
+        double v[16], y[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const double a = pD[cc * 16 + c];
+            v[c] = (c <= cc) ? a : 0.0;
+            y[c] = (c == cc) ? 1.0 : 0.0;
+        }
+        DiagStep<0>::run(v, y, tol, n - 16 * kb, nzero, nneg);
+        wave_sync();
+        if (l < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                pD[l * 16 + c] = (c <= l) ? v[c] : 0.0;   // L11 row l
+                pDi[c * 16 + l] = y[c];                    // Linv[c][l]
+                pDall[kb * 256 + c * 16 + l] = y[c];
+            }
+        }
+        wave_sync();
+        d4 rt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rt[r] = pD[cc * 16 + kk + 4 * r];   // R11[kk+4r][cc] = L11[cc][kk+4r]
+        return rt;
+    };
+
+    // prologue: diagonal tile 0
+    if (wave == 0) {   // tile index 0 -> wave 0, slot 0
+        acc[0] = factor_diag(acc[0], 0);
+    }
+    for (int kb = 0; kb < nb; ++kb) {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        double* pDi = &sDi[0][0] + z;
+        double* pPan = &sPan[0][0][0] + z;
+        if (stamps && l == 0) stamps[(kb * 8 + 0) * 8 + wave] = __builtin_amdgcn_s_memtime();
+        __syncthreads();   // A: inv(L11) of step kb visible; every trailing update of step kb-1 done
+        if (stamps && l == 0) stamps[(kb * 8 + 1) * 8 + wave] = __builtin_amdgcn_s_memtime();
+        // ---- panel tiles (a == kb < b): tile <- inv(L11) * tile ------------------------------
+        double li[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) li[s4] = pDi[cc * 16 + kk + 4 * s4];   // A operand: Linv[m = cc][k = kk + 4 s4]
+        if (stamps) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(li[0]), "v"(li[1]), "v"(li[2]), "v"(li[3]));
+            if (l == 0) stamps[(kb * 8 + 4) * 8 + wave] = __builtin_amdgcn_s_memtime();
+        }
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (stamps && l == 0 && s == NSLOT / 2) stamps[(kb * 8 + 5) * 8 + wave] = __builtin_amdgcn_s_memtime();
+            if (ta[s] == kb && tb[s] > kb) {
+                d4 x = {0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], acc[s][s4], x);
+                acc[s] = x;
+                double* dst = pPan + tb[s] * 256 + l;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r * 64] = x[r];
+            }
+        }
+        if (stamps && l == 0) stamps[(kb * 8 + 2) * 8 + wave] = __builtin_amdgcn_s_memtime();
+        __syncthreads();   // B: panel published
+        if (stamps && l == 0) stamps[(kb * 8 + 3) * 8 + wave] = __builtin_amdgcn_s_memtime();
+        // ---- look-ahead: the owner of the next diagonal tile updates and factors it first -----
+        const int kn = kb + 1;
+        const int tln = kn * (kn + 1) / 2 + kn;
+        const bool next_owner = (kn < nb) && ((tln & 7) == wave);
+        if (next_owner) {
+            const double* q = pPan + kn * 256 + l;
+            d4 t = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s)
+                if (s == (tln >> 3)) t = acc[s];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-q[s4 * 64], q[s4 * 64], t);
+            if (stamps && l == 0) stamps[(kb * 8 + 6) * 8 + wave] = __builtin_amdgcn_s_memtime();
+            t = factor_diag(t, kn);
+            if (stamps && l == 0) stamps[(kb * 8 + 7) * 8 + wave] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s)
+                if (s == (tln >> 3)) acc[s] = t;
+        }
+        // ---- trailing tiles (a > kb): tile -= panel_a^T panel_b ------------------------------
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (ta[s] > kb && !(ta[s] == kn && tb[s] == kn)) {
+                const double* qa = pPan + ta[s] * 256 + l;
+                const double* qb = pPan + tb[s] * 256 + l;
+                d4 x = acc[s];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(-qa[s4 * 64], qb[s4 * 64], x);
+                acc[s] = x;
+            }
+        }
+    }
+    __syncthreads();
+    // all tiles are final: one pass of global stores (none inside the barrier loop)
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        if (ta[s] >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ta[s] + kk + 4 * r, j = 16 * tb[s] + cc;
+                if (i < n && j < n) R[(size_t)i * ldr + j] = acc[s][r];
+            }
+        }
+    }
+    for (int e = tid; e < nb * 256; e += 512) Dinv[e] = sDall[e];
+    if (l == 0) {
+        if (nzero) atomicAdd(&info[0], nzero);
+        if (nneg) atomicAdd(&info[1], nneg);
+    }
+}
+
+// generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j]; tiles with
+// bi <= bj only when upper_only.  One wavefront per tile.
+__global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
+                                              long sBk, long sBj, int M, int N, int K, double alpha, double diag_add,
+                                              int upper_only, double* __restrict__ C, long sCi, long sCj) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nti = (M + 15) >> 4, ntj = (N + 15) >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= nti * ntj) return;
+    const int bi = tile / ntj, bj = tile - bi * ntj;
+    if (upper_only && bi > bj) return;
+    d4 acc = tile_product(A, sAi, sAk, B, sBk, sBj, M, N, K, 16 * bi, 16 * bj, l);
+    const int kk = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 16 * bi + kk + 4 * r, j = 16 * bj + cc;
+        if (i < M && j < N) C[(long)i * sCi + (long)j * sCj] = alpha * acc[r] + ((i == j) ? diag_add : 0.0);
+    }
+}
+
+// Z = L^-1 B with L given through strides (L(i,j) = L[i*sLi + j*sLj]; an upper factor R stored
+// row-major is L = R^T: sLi = 1, sLj = ldr).  B(i,c) = B1[i*ldb1 + c] for c < nc1, the single
+// extra column c == nc1 is bx[i*sbx].  Right-looking: after Z_kb is final, every later block
+// row is updated with independent MFMAs (loads of L tiles are issued a block step ahead).
+template <int NBLK>
+__global__ __launch_bounds__(64) void k_trsm_rl(const double* __restrict__ L, long sLi, long sLj, const double* __restrict__ Dinv,
+                                                int NA, const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
+                                                const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz) {
+    const int l = threadIdx.x;
+    const int j0 = blockIdx.x * 16;
+    const int kk = l >> 4, cc = l & 15;
+    const int nblk = (NA + 15) >> 4;
+    const int col = j0 + cc;
+    const int ncols = nc1 + (bx ? 1 : 0);
+    d4 acc[NBLK];
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * kb + kk + 4 * r;
+            double v = 0.0;
+            if (kb < nblk && i < NA) {
+                if (col < nc1) v = B1[(long)i * sB1i + (long)col * sB1c];
+                else if (col == nc1 && bx) v = bx[(long)i * sbx];
+            }
+            acc[kb][r] = v;
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+        if (kb < nblk) {
+            // Z_kb = Dinv_kb * acc_kb
+            d4 x = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) x = mfma_f64(Dinv[(size_t)kb * 256 + cc * 16 + kk + 4 * s], acc[kb][s], x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * kb + kk + 4 * r;
+                if (col < ncols && i < NA) Z[(size_t)i * ldz + col] = x[r];
+            }
+            // acc_ib -= L[ib][kb] * Z_kb for every later block row
+#pragma unroll
+            for (int ib = 0; ib < NBLK; ++ib) {
+                if (ib > kb && ib < nblk) {
+                    const int ia = 16 * ib + cc;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const double a = (ia < NA) ? -L[(long)ia * sLi + (long)(16 * kb + kk + 4 * s) * sLj] : 0.0;
+                        acc[ib] = mfma_f64(a, x[s], acc[ib]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// k_trsm_lds: Z = L^-1 B for L = R^T with R an upper factor stored row-major (ldr), nn <= 224.
+// One workgroup = 4 wavefronts x 16 right-hand-side columns; the 16-column panel of L needed by
+// block step kb (rows 16kb..16kb+15 of R) is staged through LDS once per workgroup, double
+// buffered, and prefetched one step ahead; solved tiles stay in registers (accumulator layout =
+// B-operand layout), later block rows are updated right-looking with independent MFMAs.
+//   B(i,c) = B1[i*sB1i + c*sB1c] for c < nc1; the optional extra column c == nc1 is bx[i*sbx].
+#define TRSM_LDP 240
+__global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, int ldr, const double* __restrict__ Dinv, int nn,
+                                                  const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
+                                                  const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz) {
+    __shared__ __attribute__((aligned(16))) double sL[2][16][TRSM_LDP];
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int kk = l >> 4, cc = l & 15;
+    const int nblk = (nn + 15) >> 4;
+    const int ncols = nc1 + (bx ? 1 : 0);
+    const int col = (blockIdx.x * 4 + wave) * 16 + cc;
+    const bool wave_live = (blockIdx.x * 4 + wave) * 16 < ncols;
+    d4 acc[14];
+#pragma unroll
+    for (int kb = 0; kb < 14; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * kb + kk + 4 * r;
+            double v = 0.0;
+            if (kb < nblk && i < nn) {
+                if (col < nc1) v = B1[(long)i * sB1i + (long)col * sB1c];
+                else if (col == nc1 && bx) v = bx[(long)i * sbx];
+            }
+            acc[kb][r] = v;
+        }
+    }
+    // panel loader: element pair e = tid + 256 q  <->  (row c = e / npair, columns 2*(e % npair) + c0 ..)
+    double2 pf[7];
+    auto panel_load = [&](int kb) {
+        const int c0 = 16 * (kb + 1);           // first column needed (even)
+        const int ncol = nn - c0;
+        const int npair = (ncol + 1) >> 1;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int e = tid + 256 * q;
+            double2 v = {0.0, 0.0};
+            if (ncol > 0 && e < 16 * npair) {
+                const int c = e / npair, pi = e - c * npair;
+                const double* src = R + (size_t)(16 * kb + c) * ldr + c0 + 2 * pi;
+                v = *reinterpret_cast<const double2*>(src);   // ldr and c0 even -> 16-byte aligned
+            }
+            pf[q] = v;
+        }
+    };
+    auto panel_store = [&](int kb, int buf) {
+        const int c0 = 16 * (kb + 1);
+        const int ncol = nn - c0;
+        const int npair = (ncol + 1) >> 1;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int e = tid + 256 * q;
+            if (ncol > 0 && e < 16 * npair) {
+                const int c = e / npair, pi = e - c * npair;
+                *reinterpret_cast<double2*>(&sL[buf][c][c0 + 2 * pi]) = pf[q];
+            }
+        }
+    };
+    panel_load(0);
+    panel_store(0, 0);
+    double di[4], din[4];   // inv(L11) operands of the current / next block step
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { di[s] = Dinv[cc * 16 + kk + 4 * s]; din[s] = 0.0; }
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 14; ++kb) {
+        if (kb < nblk) {
+            if (kb + 1 < nblk) {
+                panel_load(kb + 1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) din[s] = Dinv[(size_t)(kb + 1) * 256 + cc * 16 + kk + 4 * s];
+            }
+            if (wave_live) {
+                d4 x = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) x = mfma_f64(di[s], acc[kb][s], x);
+                acc[kb] = x;   // final; stored after the loop (no global stores ahead of a barrier)
+#pragma unroll
+                for (int ib = 0; ib < 14; ++ib) {
+                    if (ib > kb && ib < nblk) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[ib] = mfma_f64((16 * ib + cc < nn) ? -sL[kb & 1][kk + 4 * s][16 * ib + cc] : 0.0, x[s], acc[ib]);
+                    }
+                }
+            }
+            if (kb + 1 < nblk) panel_store(kb + 1, (kb + 1) & 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) di[s] = din[s];
+            __syncthreads();
+        }
+    }
+    if (wave_live && col < ncols) {
+#pragma unroll
+        for (int kb = 0; kb < 14; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * kb + kk + 4 * r;
+                if (kb < nblk && i < nn) Z[(size_t)i * ldz + col] = acc[kb][r];
+            }
+        }
+    }
+}
+
+// P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (n x (n+1), ldz)
+__global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, double s2,
+                                                     double* __restrict__ P_out, double* __restrict__ dx) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nb = (n + 1 + 15) >> 4;
+    const int ntiles = nb * (nb + 1) / 2;
+    const int tl = blockIdx.x * 4 + wave;
+    if (tl >= ntiles) return;
+    int bi, bj;
+    tile_from_linear(tl, bi, bj);
+    d4 acc = tile_product(Z, 1, ldz, Z, ldz, 1, n + 1, n + 1, n, 16 * bi, 16 * bj, l);
+    const int kk = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+        if (i < n && jj < n && jj <= i) {
+            const double pv = s2 * acc[r];
+            P_out[(size_t)i * n + jj] = pv;
+            P_out[(size_t)jj * n + i] = pv;
+        } else if (i == n && jj < n) {
+            dx[jj] = acc[r];
         }
     }
 }

@@ -34,14 +34,28 @@ def check(win, name, upd, detail=False):
             rg = Hs[bp[j]:bp[j + 1], NA]
             worst = max(worst, rel(Hg.T @ Hg, Ho.T @ Ho), rel(Hg.T @ rg, Ho.T @ ro))
         print('  block gram worst rel', worst)
-        A = capi.debug_read(upd, 'La')
+        A = capi.debug_read(upd, 'A')
         Hacc = o['H_all'][:, 15:]
-        # La La^T vs Gram of accepted rows
         mask = np.concatenate([np.full(bp[j + 1] - bp[j], bool(o['accept'][j])) for j in range(win.F)]) if win.F else np.zeros(0, bool)
         X = np.hstack([Hacc[mask], o['r_all'][mask][:, None]])
         Gref = X.T @ X
-        L = np.tril(A[:NA + 1, :NA + 1])
-        print('  La La^T vs gram', rel(L @ L.T, Gref))
+        print('  Gram block vs oracle', rel(A[:NA + 1, :NA + 1], Gref))
+        n = d['n']
+        RP = capi.debug_read(upd, 'RP')[:n, :n]
+        if d['reg_path']:
+            print('  R_P^T R_P vs P', rel(np.triu(RP).T @ np.triu(RP), win.P), 'lower part max', np.abs(np.tril(RP, -1)).max())
+            Lf = np.triu(RP).T
+        else:
+            Lf = np.tril(RP)
+            print('  Lf Lf^T vs P', rel(Lf @ Lf.T, win.P))
+        La = Lf[15:, :]
+        s2 = win.flags.noise_feature ** 2
+        Mref = s2 * np.eye(n) + La.T @ Gref[:NA, :NA] @ La
+        M = capi.debug_read(upd, 'M')[:n, :n]
+        print('  M (upper) vs ref', rel(np.triu(M), np.triu(Mref)))
+        RM = capi.debug_read(upd, 'RM')[:n, :n]
+        if d['reg_path']:
+            print('  R_M^T R_M vs M', rel(np.triu(RM).T @ np.triu(RM), Mref))
     return line
 
 

@@ -1,0 +1,53 @@
+// Diagnostic: cycles of the 16x16 diagonal-tile factor+inverse sweep (DiagStep) in isolation.
+#include "../../orcvio_amd/csrc/msckf_kernels.hpp"
+#include <cstdio>
+using namespace orcvio_amd;
+
+template <int MODE>
+__global__ void k_diag(const double* X, double* out, unsigned long long* st, int reps) {
+    const int l = threadIdx.x, cc = l & 15;
+    double v0[16], y0[16];
+    for (int c = 0; c < 16; ++c) { v0[c] = (c <= cc) ? X[cc * 16 + c] : 0.0; y0[c] = (c == cc) ? 1.0 : 0.0; }
+    double acc = 0;
+    int nz = 0, nn = 0;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int rep = 0; rep < reps; ++rep) {
+        double v[16], y[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { v[c] = v0[c] + rep * 1e-12; y[c] = y0[c]; }
+        if (MODE == 0) DiagStep<0>::run(v, y, 1e-300, 16, nz, nn);
+        if (MODE == 1) {   // updates only (no pivot math): issue cost of the 240 DPP FMAs
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { }
+            DiagUpd<0, 1>::run(v, y, v[0], y[0]); DiagUpd<1, 2>::run(v, y, v[1], y[1]); DiagUpd<2, 3>::run(v, y, v[2], y[2]);
+            DiagUpd<3, 4>::run(v, y, v[3], y[3]); DiagUpd<4, 5>::run(v, y, v[4], y[4]); DiagUpd<5, 6>::run(v, y, v[5], y[5]);
+            DiagUpd<6, 7>::run(v, y, v[6], y[6]); DiagUpd<7, 8>::run(v, y, v[7], y[7]); DiagUpd<8, 9>::run(v, y, v[8], y[8]);
+            DiagUpd<9, 10>::run(v, y, v[9], y[9]); DiagUpd<10, 11>::run(v, y, v[10], y[10]); DiagUpd<11, 12>::run(v, y, v[11], y[11]);
+            DiagUpd<12, 13>::run(v, y, v[12], y[12]); DiagUpd<13, 14>::run(v, y, v[13], y[13]); DiagUpd<14, 15>::run(v, y, v[14], y[14]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc += v[c] + y[c];
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[l] = acc + nz + nn;
+    if (l == 0) st[0] = t1 - t0;
+}
+
+int main() {
+    double h[256];
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) h[i * 16 + j] = (i == j) ? 20.0 + i : 1.0 / (1 + i + j);
+    double *dX, *dO; unsigned long long* dS;
+    hipMalloc(&dX, sizeof(h)); hipMalloc(&dO, 64 * 8); hipMalloc(&dS, 8);
+    hipMemcpy(dX, h, sizeof(h), hipMemcpyHostToDevice);
+    const int reps = 200;
+    for (int mode = 0; mode < 2; ++mode) {
+        for (int it = 0; it < 2; ++it) {
+            if (mode == 0) hipLaunchKernelGGL(k_diag<0>, dim3(1), dim3(64), 0, 0, dX, dO, dS, reps);
+            else hipLaunchKernelGGL(k_diag<1>, dim3(1), dim3(64), 0, 0, dX, dO, dS, reps);
+            hipDeviceSynchronize();
+        }
+        unsigned long long s; hipMemcpy(&s, dS, 8, hipMemcpyDeviceToHost);
+        printf("mode %d: %.0f cycles per 16x16 tile\n", mode, (double)s / reps);
+    }
+    return 0;
+}

@@ -1,0 +1,66 @@
+"""GPU unit tests of the factorisation kernels against numpy (every template instantiation)."""
+import numpy as np
+import pytest
+
+from orcvio_amd import capi
+from helpers import rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def upd(built):
+    u = capi.MsckfUpdater(device=0, max_clones=40, max_features=64, max_observations=1024)
+    yield u
+    u.close()
+
+
+def _spd(n, seed, cond=1e4):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.logspace(0, -np.log10(cond), n)
+    return (Q * ev) @ Q.T
+
+
+@pytest.mark.parametrize('n', [5, 16, 17, 52, 64, 94, 100, 128, 142, 160, 187, 202, 208, 214, 224])
+def test_potrf_register_path(upd, n):
+    X = _spd(n, n)
+    L, Dinv, info = capi.debug_potrf(upd, X)
+    assert np.isfinite(L).all()
+    assert info[0] == 0 and info[1] == 0
+    assert rel(L @ L.T, X) < 1e-13
+    assert np.abs(np.triu(L, 1)).max() == 0.0
+    for kb in range((n + 15) // 16):
+        k0, k1 = 16 * kb, min(n, 16 * kb + 16)
+        D = L[k0:k1, k0:k1]
+        assert rel(Dinv[kb][:k1 - k0, :k1 - k0] @ D, np.eye(k1 - k0)) < 1e-10
+
+
+@pytest.mark.parametrize('n', [40, 202, 250, 286])
+def test_potrf_lds_panel_path(upd, n):
+    X = _spd(n, n + 1)
+    L, Dinv, info = capi.debug_potrf(upd, X, force_lds_path=True)
+    assert rel(L @ L.T, X) < 1e-13
+
+
+@pytest.mark.parametrize('n', [30, 120, 202])
+def test_potrf_semidefinite_zero_variance_states(upd, n):
+    """Zero rows/columns (states that are not estimated) give zero columns of the factor."""
+    X = _spd(n, 3 * n)
+    dead = [3, 4, 17, n - 2]
+    X[dead, :] = 0.0
+    X[:, dead] = 0.0
+    L, Dinv, info = capi.debug_potrf(upd, X, tol_rel=8 * 2.2e-16)
+    assert info[0] == len(dead) and info[1] == 0
+    assert rel(L @ L.T, X) < 1e-13
+    assert not L[:, dead].any()
+
+
+@pytest.mark.parametrize('n,nrhs', [(20, 7), (100, 33), (202, 203), (214, 215), (187, 16), (250, 40)])
+def test_trsm(upd, n, nrhs):
+    X = _spd(n, 7 * n)
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, nrhs))
+    Z = capi.debug_trsm(upd, X, B)
+    L = np.linalg.cholesky(X)
+    assert rel(Z, np.linalg.solve(L, B)) < 1e-10
