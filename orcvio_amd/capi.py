@@ -203,6 +203,30 @@ class MsckfUpdater:
             raise MsckfError(rc, 'orcvio_msckf_update_features')
         return self._finish(out, res, win.F)
 
+    # -- object blocks (OrcVIO::removeLostObjects) ---------------------------------------------
+    def update_objects(self, flags, n_clones, blocks, P, want_G=False):
+        """blocks: list of dict(row_clone [rows] int32, Hx6 [rows,6], Hf [rows,no], res [rows])."""
+        fl = make_flags(flags)
+        n = flags.leg_dim + 6 * n_clones
+        keep = []
+        arr = (MsckfObjectRows * max(len(blocks), 1))()
+        for k, b in enumerate(blocks):
+            rc_ = np.ascontiguousarray(b['row_clone'], dtype=np.int32)
+            hx = np.ascontiguousarray(b['Hx6'], dtype=np.float64)
+            hf = np.ascontiguousarray(b['Hf'], dtype=np.float64)
+            rs = np.ascontiguousarray(b['res'], dtype=np.float64)
+            keep += [rc_, hx, hf, rs]
+            arr[k] = MsckfObjectRows(len(rs), hf.shape[1] if hf.ndim == 2 else 0, _i(rc_), _d(hx), _d(hf), _d(rs))
+        Pc = np.ascontiguousarray(P, dtype=np.float64)
+        out, res = self._result(n, 1, False, want_G, False)
+        rc = self.lib.orcvio_msckf_update_objects(self.h, C.byref(fl), n_clones, arr, len(blocks), _d(Pc), C.byref(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_update_objects')
+        out = self._finish(out, res, 1)
+        out['gamma'] = float(out['gamma'][0])
+        out['accept'] = int(out['accept'][0])
+        return out
+
     # -- staged, device-resident form -----------------------------------------------------
     def upload(self, win):
         fl, w, t, arrs = self._structs(win)

@@ -48,6 +48,13 @@ struct orcvio_msckf_handle {
     double *d_RP = nullptr, *d_DinvP = nullptr, *d_U = nullptr, *d_M = nullptr, *d_RM = nullptr, *d_DinvM = nullptr;
     double *d_Z = nullptr, *d_Pout = nullptr, *d_dx = nullptr;
     double *d_La = nullptr, *d_DinvA = nullptr, *d_W = nullptr, *d_Y = nullptr, *d_KG = nullptr;   // optional outputs
+    // object blocks (allocated on first use, grown on demand)
+    double *d_Xaug = nullptr, *d_Gobj = nullptr, *d_RF = nullptr, *d_DinvF = nullptr, *d_Yobj = nullptr, *d_objH = nullptr;
+    double *d_obj_gamma = nullptr;
+    int *d_obj_i = nullptr, *d_obj_accept = nullptr;
+    size_t cap_Xaug = 0, cap_Gobj = 0, cap_RF = 0, cap_Yobj = 0, cap_objH = 0, cap_obj_i = 0;
+    bool objects_mode = false;
+    int obj_dof = 0, obj_rows = 0, obj_count = 0;
     size_t hs_rows_cap = 0;
     int gram_chunks_cap = 64;
     // host staging
@@ -55,6 +62,17 @@ struct orcvio_msckf_handle {
     std::vector<int> h_row_ptr;
     double chi2_prob_cached = -1.0;
 };
+
+template <typename T>
+static int grow(T** p, size_t* cap, size_t need) {
+    if (*cap >= need) return ORCVIO_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(hipMalloc(p, sizeof(T) * need));
+    *cap = need;
+    return ORCVIO_OK;
+}
 
 extern "C" {
 
@@ -125,7 +143,8 @@ static void free_all(orcvio_msckf_handle* h) {
     void* ptrs[] = {h->d_poses, h->d_pw, h->d_obs_z, h->d_obs_zvel, h->d_P, h->d_obs_ptr, h->d_obs_clone, h->d_row_ptr,
                     h->d_accept, h->d_info, h->d_chi2, h->d_Hs, h->d_gamma, h->d_Gpart, h->d_Ab, h->d_A, h->d_RP,
                     h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_Pout, h->d_dx, h->d_La, h->d_DinvA,
-                    h->d_W, h->d_Y, h->d_KG};
+                    h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
+                    h->d_obj_gamma, h->d_obj_i, h->d_obj_accept};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -443,7 +462,8 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
             return launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_RP, sLj, sLi, n, h->d_U + (size_t)NA * NP, 1, h->d_Z, ldz);
         case ST_FINISH: {
             const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
-            hipLaunchKernelGGL(k_finish_sqrt, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_Z, ldz, n, sigma2, h->d_Pout, h->d_dx);
+            hipLaunchKernelGGL(k_finish_sqrt, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_Z, ldz, n, sigma2, h->d_Pout, h->d_dx,
+                               h->objects_mode ? h->d_obj_accept : (const int*)nullptr, h->d_P);
             HIPCHK(hipGetLastError());
             return ORCVIO_OK;
         }
@@ -623,10 +643,189 @@ int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_
     return orcvio_msckf_download(h, result);
 }
 
-int32_t orcvio_msckf_update_objects(orcvio_msckf_handle*, const orcvio_msckf_flags*, int32_t, const orcvio_msckf_object_rows*,
-                                    int32_t, const double*, orcvio_msckf_result*) {
-    g_last_error = "orcvio_msckf_update_objects: object rows are not built yet";
-    return ORCVIO_ERR_INVALID;
+// Object update: OrcVIO::removeLostObjects (src/orcvio.cpp:2154-2193).  Every object block is projected
+// onto the left nullspace of its own Hf (SURVEY.md note N3: equal to the reference whenever one object
+// arrives per call); the blocks are stacked, gated jointly with dof = sum(rows - cols) and applied in one
+// update.  Objects with rows <= cols cannot be projected (math_utils.hpp:292) and are skipped.
+int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
+                                    const orcvio_msckf_object_rows* objs, int32_t n_objects, const double* P,
+                                    orcvio_msckf_result* res) {
+    if (!h || !flags || !P || !res || n_objects < 0 || (n_objects > 0 && !objs)) { g_last_error = "update_objects: null argument"; return ORCVIO_ERR_INVALID; }
+    if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = "update_objects: leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
+    if (n_clones < 1 || n_clones > h->maxN) { g_last_error = "update_objects: window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    const int N = n_clones;
+    h->flags = *flags;
+    h->N = N; h->F = 0; h->nobs = 0;
+    h->n = flags->leg_dim + 6 * N;
+    h->NA = h->n - 15;
+    h->NAP = round_up(h->NA + 1, 16);
+    h->NP = round_up(h->n, 16);
+    h->ldz = round_up(h->n + 1, 16);
+    h->reg_path = (h->NP / 16) <= 14;
+    h->m_tot = 0; h->Mmax = 2; h->chunks = 1; h->rows_per_chunk = 8;
+    h->h_row_ptr.assign(1, 0);
+    const int n = h->n, NA = h->NA, NAP = h->NAP;
+    // usable objects, row offsets, widest object state
+    std::vector<int> use, chunk_ptr(1, 0);
+    int no_max = 0, rows_tot = 0, dof = 0;
+    for (int o = 0; o < n_objects; ++o) {
+        const orcvio_msckf_object_rows& ob = objs[o];
+        if (ob.n_rows < 0 || ob.n_obj_cols < 1 || ob.n_obj_cols > 112) { g_last_error = "update_objects: bad block shape (object state columns must be 1..112)"; return ORCVIO_ERR_INVALID; }
+        if (ob.n_rows > 0 && (!ob.row_clone || !ob.Hx6 || !ob.Hf || !ob.res)) { g_last_error = "update_objects: null block arrays"; return ORCVIO_ERR_INVALID; }
+        if (ob.n_rows <= ob.n_obj_cols) continue;   // nullspace_project_inplace_svd returns false
+        for (int r = 0; r < ob.n_rows; ++r)
+            if (ob.row_clone[r] < 0 || ob.row_clone[r] >= N) { g_last_error = "update_objects: row_clone out of range"; return ORCVIO_ERR_INVALID; }
+        use.push_back(o);
+        rows_tot += ob.n_rows;
+        chunk_ptr.push_back(rows_tot);
+        dof += ob.n_rows - ob.n_obj_cols;
+        if (ob.n_obj_cols > no_max) no_max = ob.n_obj_cols;
+    }
+    const int nobj = (int)use.size();
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
+    h->uploaded = true;
+    h->objects_mode = true;
+    h->obj_dof = dof; h->obj_rows = rows_tot; h->obj_count = nobj;
+    int rc = ORCVIO_OK;
+    if (!h->d_obj_accept) { HIPCHK(hipMalloc(&h->d_obj_accept, sizeof(int) * 4)); HIPCHK(hipMalloc(&h->d_obj_gamma, sizeof(double) * 4)); }
+    const double sigma2 = flags->noise_feature * flags->noise_feature;
+    if (nobj == 0) {   // nothing usable: P unchanged, dx = 0
+        HIPCHK(hipStreamSynchronize(s));
+        if (res->dx) std::memset(res->dx, 0, sizeof(double) * n);
+        if (res->P_out) std::memcpy(res->P_out, P, sizeof(double) * (size_t)n * n);
+        if (res->accept) res->accept[0] = 0;
+        if (res->gamma) res->gamma[0] = NAN;
+        std::memset(res->stats, 0, sizeof(res->stats));
+        h->objects_mode = false;
+        return ORCVIO_OK;
+    }
+    const int NOP = round_up(no_max, 16), W = NAP + NOP;
+    // host staging of the compact rows (one contiguous upload per array)
+    std::vector<int> h_clone(rows_tot), h_cols(rows_tot);
+    std::vector<double> h_hx((size_t)rows_tot * 6), h_hf((size_t)rows_tot * no_max, 0.0), h_res(rows_tot);
+    {
+        int r0 = 0;
+        for (int o : use) {
+            const orcvio_msckf_object_rows& ob = objs[o];
+            for (int r = 0; r < ob.n_rows; ++r) {
+                h_clone[r0 + r] = ob.row_clone[r];
+                h_cols[r0 + r] = ob.n_obj_cols;
+                std::memcpy(&h_hx[(size_t)(r0 + r) * 6], ob.Hx6 + (size_t)r * 6, 6 * sizeof(double));
+                std::memcpy(&h_hf[(size_t)(r0 + r) * no_max], ob.Hf + (size_t)r * ob.n_obj_cols, ob.n_obj_cols * sizeof(double));
+                h_res[r0 + r] = ob.res[r];
+            }
+            r0 += ob.n_rows;
+        }
+    }
+    const size_t need_i = (size_t)2 * rows_tot + nobj + 1;
+    const size_t need_h = (size_t)rows_tot * (6 + no_max + 1);
+    if ((rc = grow(&h->d_obj_i, &h->cap_obj_i, need_i)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_objH, &h->cap_objH, need_h)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Xaug, &h->cap_Xaug, (size_t)rows_tot * W)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, (size_t)nobj * W * W)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_RF, &h->cap_RF, (size_t)nobj * (NOP * NOP + 7 * 256))) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Yobj, &h->cap_Yobj, (size_t)nobj * NOP * NAP)) != ORCVIO_OK) return rc;
+    int* d_clone = h->d_obj_i;
+    int* d_cols = h->d_obj_i + rows_tot;
+    int* d_chunk = h->d_obj_i + 2 * rows_tot;
+    double* d_hx = h->d_objH;
+    double* d_hf = d_hx + (size_t)rows_tot * 6;
+    double* d_res = d_hf + (size_t)rows_tot * no_max;
+    double* d_RF = h->d_RF;
+    double* d_DinvF = h->d_RF + (size_t)nobj * NOP * NOP;
+    HIPCHK(hipMemcpyAsync(d_clone, h_clone.data(), sizeof(int) * rows_tot, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_cols, h_cols.data(), sizeof(int) * rows_tot, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_chunk, chunk_ptr.data(), sizeof(int) * (nobj + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_hx, h_hx.data(), sizeof(double) * h_hx.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_hf, h_hf.data(), sizeof(double) * h_hf.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_res, h_res.data(), sizeof(double) * rows_tot, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->d_Yobj, 0, sizeof(double) * (size_t)nobj * NOP * NAP, s));
+    HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
+    rc = launch_prior_fork(h, s);   // Cholesky of P on the side stream
+    if (rc != ORCVIO_OK) return rc;
+    // augmented stack and its per-object Gram
+    hipLaunchKernelGGL(k_obj_build, dim3(rows_tot), dim3(256), 0, s, d_clone, d_hx, d_hf, d_res, d_cols, rows_tot, no_max,
+                       flags->leg_dim, NA, NAP, W, h->d_Xaug);
+    {
+        const int nbw = W / 16, ntiles = nbw * (nbw + 1) / 2;
+        hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, nobj), dim3(256), 0, s, h->d_Xaug, rows_tot, W, 0, h->d_Gobj, d_chunk);
+    }
+    // F_o = Hf^T Hf (lower tiles of the bottom-right block) -> R_F ; Y_o = L_F^-1 C_o
+    {
+        const int nbf = NOP / 16, need = (nbf * (nbf + 1) / 2 + 7) / 8;
+        const double* F0 = h->d_Gobj + (size_t)NAP * W + NAP;
+        const double tolF = (double)no_max * 2.220446049250313e-16;
+        if (need <= 4)
+            hipLaunchKernelGGL(k_potrf_reg<4>, dim3(nobj), dim3(512), 0, s, F0, W, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
+                               (unsigned long long*)nullptr, (size_t)W * W, (size_t)NOP * NOP, (size_t)7 * 256, 1);
+        else
+            hipLaunchKernelGGL(k_potrf_reg<8>, dim3(nobj), dim3(512), 0, s, F0, W, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
+                               (unsigned long long*)nullptr, (size_t)W * W, (size_t)NOP * NOP, (size_t)7 * 256, 1);
+        const int nwave = (NA + 1 + 15) / 16;
+        hipLaunchKernelGGL(k_trsm_lds, dim3((nwave + 3) / 4, nobj), dim3(256), 0, s, d_RF, NOP, d_DinvF, no_max,
+                           h->d_Gobj + (size_t)NAP * W, (long)W, 1L, NA + 1, (const double*)nullptr, 0L, h->d_Yobj, NAP,
+                           (size_t)NOP * NOP, (size_t)7 * 256, (size_t)W * W, (size_t)NOP * NAP);
+    }
+    // A' = sum_o B_o - Y^T Y  (Y = all Y_o stacked; padded rows are zero)
+    hipLaunchKernelGGL(k_obj_sum_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, h->d_Gobj, nobj, W, NAP, h->d_Ab);
+    hipLaunchKernelGGL(k_gemm, dim3(((NAP / 16) * (NAP / 16) + 3) / 4), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
+                       NAP, NAP, nobj * NOP, -1.0, 0.0, 0, h->d_A, (long)NAP, 1L, h->d_Ab);
+    HIPCHK(hipGetLastError());
+    // Kalman solve in square-root form, gate, gated write-back
+    HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
+    for (int st = ST_FORM_U; st <= ST_TRSM && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
+    if (rc != ORCVIO_OK) return rc;
+    const double thr = orcvio_msckf_chi2_quantile(dof, flags->chi2_prob);   // table value below 500 dof, on the fly above (:1962-1968)
+    hipLaunchKernelGGL(k_obj_gate, dim3(1), dim3(64), 0, s, h->d_A, NAP, NA, h->d_Z, h->ldz, n, sigma2, thr, h->d_obj_gamma, h->d_obj_accept);
+    HIPCHK(hipGetLastError());
+    rc = launch_solve_stage(h, s, ST_FINISH);
+    if (rc != ORCVIO_OK) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipStreamSynchronize(h->side));
+    h->ran = true;
+    // results
+    int acc = 0;
+    double gam = NAN;
+    HIPCHK(hipMemcpy(&acc, h->d_obj_accept, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&gam, h->d_obj_gamma, sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> dx(n);
+    HIPCHK(hipMemcpy(dx.data(), h->d_dx, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (res->dx) std::memcpy(res->dx, dx.data(), sizeof(double) * n);
+    if (res->P_out) HIPCHK(hipMemcpy(res->P_out, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+    if (res->accept) res->accept[0] = acc;
+    if (res->gamma) res->gamma[0] = gam;
+    int info[8] = {0};
+    HIPCHK(hipMemcpy(info, h->d_info, sizeof(int) * 8, hipMemcpyDeviceToHost));
+    std::memset(res->stats, 0, sizeof(res->stats));
+    res->stats[0] = acc ? dof : 0;
+    res->stats[1] = acc ? NA : 0;
+    res->stats[2] = acc ? nobj : 0;
+    res->stats[3] = acc;
+    if (flags->discard_large_update) {
+        const double nv = std::sqrt(dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
+        const double np = std::sqrt(dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8]);
+        res->stats[4] = (nv > 1.0 || np > 1.5) ? 1 : 0;
+    }
+    res->stats[5] = info[0];
+    res->stats[6] = info[1];
+    res->stats[7] = info[4];   // rank-deficient directions met in some Hf
+    if (res->G) {   // basis-independent K*H of the applied update (zero if rejected)
+        if (acc) {
+            rc = compute_optional(h, false, false, true);
+            if (rc != ORCVIO_OK) return rc;
+            std::vector<double> Gd((size_t)n * h->NP);
+            HIPCHK(hipMemcpy(Gd.data(), h->d_KG, sizeof(double) * Gd.size(), hipMemcpyDeviceToHost));
+            std::memset(res->G, 0, sizeof(double) * (size_t)n * n);
+            for (int i = 0; i < n; ++i)
+                for (int c = 0; c < NA; ++c) res->G[(size_t)i * n + 15 + c] = Gd[(size_t)i * h->NP + c];
+        } else {
+            std::memset(res->G, 0, sizeof(double) * (size_t)n * n);
+        }
+    }
+    h->objects_mode = false;
+    return ORCVIO_OK;
 }
 
 // ---- per-kernel profile -------------------------------------------------------------------------

@@ -488,7 +488,7 @@ __device__ __forceinline__ void tile_from_linear(int tl, int& bi, int& bj) {
 }
 
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int m, int NAP, int rows_per_chunk,
-                                              double* __restrict__ Gpart) {
+                                              double* __restrict__ Gpart, const int* __restrict__ chunk_ptr = nullptr) {
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nb = NAP >> 4;
     const int ntiles = nb * (nb + 1) / 2;
@@ -497,8 +497,9 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int 
     int bi, bj;
     tile_from_linear(tl, bi, bj);
     const int chunk = blockIdx.y;
-    const int r0 = chunk * rows_per_chunk;
+    int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk;
+    if (chunk_ptr) { r0 = chunk_ptr[chunk]; r1 = chunk_ptr[chunk + 1]; }   // ragged chunks (one per object block)
     if (r1 > m) r1 = m;
     const int kk = l >> 4, cc = l & 15;
     const double* pa = X + (size_t)(r0 + kk) * NAP + 16 * bi + cc;
@@ -873,7 +874,14 @@ __global__ __launch_bounds__(64) void k_trsm(const double* __restrict__ L, int l
 template <int NSLOT>
 __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X, int ldx, int n, double tol_rel,
                                                    double* __restrict__ R, int ldr, double* __restrict__ Dinv,
-                                                   int* __restrict__ info, unsigned long long* __restrict__ stamps = nullptr) {
+                                                   int* __restrict__ info, unsigned long long* __restrict__ stamps = nullptr,
+                                                   size_t strideX = 0, size_t strideR = 0, size_t strideD = 0,
+                                                   int from_lower = 0) {
+    // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
+    // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
+    X += (size_t)blockIdx.x * strideX;
+    R += (size_t)blockIdx.x * strideR;
+    Dinv += (size_t)blockIdx.x * strideD;
     __shared__ __attribute__((aligned(16))) double sD[16][16];
     __shared__ __attribute__((aligned(16))) double sDi[16][16];
     __shared__ __attribute__((aligned(16))) double sPan[14][4][64];   // published panel tiles, accumulator layout
@@ -909,7 +917,7 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 16 * bj + kk + 4 * r, j = 16 * bi + cc;
-            acc[s][r] = (tl < ntiles && i < n && j < n) ? X[(size_t)i * ldx + j] : 0.0;
+            acc[s][r] = (tl < ntiles && i < n && j < n) ? (from_lower ? X[(size_t)j * ldx + i] : X[(size_t)i * ldx + j]) : 0.0;
             // the mirrored (strictly lower) tile of the output is never touched again: zero it
             if (tl < ntiles && bi != bj) {
                 const int i2 = 16 * bi + kk + 4 * r, j2 = 16 * bj + cc;
@@ -1046,7 +1054,8 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
 // bi <= bj only when upper_only.  One wavefront per tile.
 __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
                                               long sBk, long sBj, int M, int N, int K, double alpha, double diag_add,
-                                              int upper_only, double* __restrict__ C, long sCi, long sCj) {
+                                              int upper_only, double* __restrict__ C, long sCi, long sCj,
+                                              const double* __restrict__ Cin = nullptr) {
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nti = (M + 15) >> 4, ntj = (N + 15) >> 4;
     const int tile = blockIdx.x * 4 + wave;
@@ -1058,7 +1067,8 @@ __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = 16 * bi + kk + 4 * r, j = 16 * bj + cc;
-        if (i < M && j < N) C[(long)i * sCi + (long)j * sCj] = alpha * acc[r] + ((i == j) ? diag_add : 0.0);
+        if (i < M && j < N)
+            C[(long)i * sCi + (long)j * sCj] = alpha * acc[r] + ((i == j) ? diag_add : 0.0) + (Cin ? Cin[(long)i * sCi + (long)j * sCj] : 0.0);
     }
 }
 
@@ -1127,8 +1137,14 @@ __global__ __launch_bounds__(64) void k_trsm_rl(const double* __restrict__ L, lo
 #define TRSM_LDP 240
 __global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, int ldr, const double* __restrict__ Dinv, int nn,
                                                   const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
-                                                  const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz) {
+                                                  const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
+                                                  size_t strideR = 0, size_t strideD = 0, size_t strideB = 0, size_t strideZ = 0) {
     __shared__ __attribute__((aligned(16))) double sL[2][16][TRSM_LDP];
+    // batched use: blockIdx.y selects the system
+    R += (size_t)blockIdx.y * strideR;
+    Dinv += (size_t)blockIdx.y * strideD;
+    B1 += (size_t)blockIdx.y * strideB;
+    Z += (size_t)blockIdx.y * strideZ;
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nblk = (nn + 15) >> 4;
@@ -1228,7 +1244,8 @@ __global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, 
 
 // P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (n x (n+1), ldz)
 __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, double s2,
-                                                     double* __restrict__ P_out, double* __restrict__ dx) {
+                                                     double* __restrict__ P_out, double* __restrict__ dx,
+                                                     const int* __restrict__ apply = nullptr, const double* __restrict__ P = nullptr) {
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nb = (n + 1 + 15) >> 4;
     const int ntiles = nb * (nb + 1) / 2;
@@ -1241,13 +1258,65 @@ __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+        const bool app = apply ? (*apply != 0) : true;   // gated object update: leave P and x alone if rejected
         if (i < n && jj < n && jj <= i) {
-            const double pv = s2 * acc[r];
+            const double pv = app ? s2 * acc[r] : 0.5 * (P[(size_t)i * n + jj] + P[(size_t)jj * n + i]);
             P_out[(size_t)i * n + jj] = pv;
             P_out[(size_t)jj * n + i] = pv;
         } else if (i == n && jj < n) {
-            dx[jj] = acc[r];
+            dx[jj] = app ? acc[r] : 0.0;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Object blocks (reference OrcVIO::removeLostObjects, src/orcvio.cpp:2154-2193)
+// ---------------------------------------------------------------------------------------
+// Every object row touches one clone (6 non-zeros of Hx) and the object's own state columns Hf.
+// k_obj_build writes the augmented stack  Xaug[row] = [Hx scattered | res | 0-pad (NAP) | Hf | 0-pad],
+// width W = NAP + NOP.  Its Gram per object holds  B = X^T X, C = Hf^T X, F = Hf^T Hf, and the
+// left-nullspace projection of math_utils.hpp:287-312 is the Schur complement  A' = B - C^T F^-1 C
+// (any orthonormal basis of the left nullspace of Hf gives the same A'), formed with the Cholesky
+// factor of F:  Y = L_F^-1 C,  A' = B - Y^T Y.
+__global__ __launch_bounds__(256) void k_obj_build(const int* __restrict__ row_clone, const double* __restrict__ Hx6,
+                                                   const double* __restrict__ Hf, const double* __restrict__ res,
+                                                   const int* __restrict__ row_obj_cols, int rows, int no_max, int leg, int NA,
+                                                   int NAP, int W, double* __restrict__ Xaug) {
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    const int cb = leg - 15 + 6 * row_clone[row];
+    const int no = row_obj_cols[row];
+    for (int c = threadIdx.x; c < W; c += 256) {
+        double v = 0.0;
+        if (c >= cb && c < cb + 6) v = Hx6[(size_t)row * 6 + (c - cb)];
+        else if (c == NA) v = res[row];
+        else if (c >= NAP && c < NAP + no) v = Hf[(size_t)row * no_max + (c - NAP)];
+        Xaug[(size_t)row * W + c] = v;
+    }
+}
+
+// dst (NAP x NAP, full symmetric) = sum over objects of the top-left NAP x NAP block of G_o (lower tiles, ld W)
+__global__ __launch_bounds__(256) void k_obj_sum_B(const double* __restrict__ G, int nobj, int W, int NAP, double* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NAP * NAP) return;
+    const int i = idx / NAP, j = idx - i * NAP;
+    const int si = ((i >> 4) >= (j >> 4)) ? i : j, sj = ((i >> 4) >= (j >> 4)) ? j : i;
+    double s = 0.0;
+    for (int o = 0; o < nobj; ++o) s += G[(size_t)o * W * W + (size_t)si * W + sj];
+    dst[idx] = s;
+}
+
+// gamma = (|r'|^2 - |z|^2) / s2 for the joint object block (identity in DESIGN.md), chi-square gate and the
+// NaN check of src/orcvio.cpp:2172-2182.  A[NA][NA] = |r'|^2, z = Z[:, n].
+__global__ void k_obj_gate(const double* __restrict__ A, int NAP, int NA, const double* __restrict__ Z, int ldz, int n, double s2,
+                           double chi2_thr, double* __restrict__ gamma, int* __restrict__ accept) {
+    double zz = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) { const double v = Z[(size_t)i * ldz + n]; zz += v * v; }
+    zz = wave_sum(zz);
+    if (threadIdx.x == 0) {
+        const double g = (A[(size_t)NA * NAP + NA] - zz) / s2;
+        *gamma = g;
+        *accept = (g == g && g < chi2_thr) ? 1 : 0;   // NaN anywhere in the rows makes g NaN -> rejected
     }
 }
 

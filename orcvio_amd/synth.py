@@ -200,3 +200,77 @@ def config_window(config: int, seed: int = 0) -> Window:
                            flags=Flags(use_larvio=0, use_left_perturbation=0,
                                        noise_feature=1.0, discard_large_update=1))
     raise ValueError(config)
+
+
+# ---------------------------------------------------------------------------------------------
+# objects (BASELINE.json config 3): cars with 12 semantic keypoints and a bounding box per frame
+# ---------------------------------------------------------------------------------------------
+# reference config/object_feat_unity.yaml:6-19 (class "car")
+CAR_KEYPOINTS_MEAN = np.array(
+    [[-0.568, 0.568, 0.482, -0.482, -0.582, 0.582, 0.702, -0.702, -0.805, -0.805, 0.805, 0.805],
+     [-0.253, -0.253, 1.570, 1.570, -1.988, -1.988, 1.961, 1.961, -1.286, 1.355, -1.286, 1.355],
+     [1.331, 1.331, 1.331, 1.331, 0.702, 0.702, 0.924, 0.924, 0.329, 0.329, 0.329, 0.329]]).T
+CAR_MEAN_SHAPE = np.array([1.6, 3.9, 1.0])
+
+
+@dataclasses.dataclass
+class ObjectTrack:
+    """One object at a fixed state (GT + noise: stands in for the LM optimum) and its observations."""
+    wTo: np.ndarray      # [4,4] object -> world
+    shape: np.ndarray    # [3] ellipsoid semi-axes
+    kps: np.ndarray      # [K,3] keypoints in the object frame
+    frames: list         # per frame: dict(clone=int, wTc=[4,4], zs=[K,2] (NaN rows = not detected), bbox=[4])
+
+
+def camera_poses(win: Window) -> np.ndarray:
+    """wTc (camera -> world) of every clone, as src/orcvio.cpp:954-961."""
+    T = np.tile(np.eye(4), (win.N, 1, 1))
+    for i in range(win.N):
+        T[i, :3, :3] = win.R_b2w[i] @ win.R_b2c[i].T
+        T[i, :3, 3] = win.t_b_w[i] + win.R_b2w[i] @ win.t_c_b[i]
+    return T
+
+
+def make_objects(win: Window, n_objects: int = 20, seed: int = 0, missing_frac: float = 0.1,
+                 frames_per_object=None, sigma_kp: float | None = None) -> list:
+    rng = np.random.default_rng(seed + 7919)
+    sig = win.flags.noise_feature if sigma_kp is None else sigma_kp
+    wTc = camera_poses(win)
+    mid = win.N // 2
+    objs = []
+    for o in range(n_objects):
+        # pose: in front of the middle camera, random yaw, car "up" roughly along -y of the camera
+        depth = rng.uniform(8.0, 20.0)
+        pc = np.array([rng.uniform(-0.3, 0.3) * depth, rng.uniform(-0.1, 0.2) * depth, depth, 1.0])
+        pw = wTc[mid] @ pc
+        yaw = rng.uniform(-np.pi, np.pi)
+        Rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1.0]])
+        Rx = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0.0]])      # object z (up) -> camera -y
+        T = np.eye(4)
+        T[:3, :3] = wTc[mid][:3, :3] @ Rx @ Rz
+        T[:3, 3] = pw[:3]
+        kps = CAR_KEYPOINTS_MEAN + 0.03 * rng.standard_normal(CAR_KEYPOINTS_MEAN.shape)
+        shape = CAR_MEAN_SHAPE * (1 + 0.05 * rng.standard_normal(3))
+        # estimate = truth + small noise (the state the residuals are evaluated at)
+        dxi = 0.01 * rng.standard_normal(6)
+        T_est = T.copy()
+        T_est[:3, 3] += dxi[:3]
+        T_est[:3, :3] = T[:3, :3] @ so3_exp(dxi[3:])
+        kps_est = kps + 0.01 * rng.standard_normal(kps.shape)
+        ids = range(win.N) if frames_per_object is None else sorted(rng.choice(win.N, frames_per_object, replace=False))
+        frames = []
+        for i in ids:
+            cTw = np.linalg.inv(wTc[i])
+            Xc = (cTw @ T @ np.hstack([kps, np.ones((len(kps), 1))]).T).T
+            uv = Xc[:, :2] / Xc[:, 2:3]
+            zs = uv + sig * rng.standard_normal(uv.shape)
+            miss = rng.random(len(kps)) < missing_frac
+            zs[miss] = np.nan
+            # box around the projected ellipsoid corners
+            cor = np.array([[sx * shape[0], sy * shape[1], sz * shape[2], 1.0] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+            Cc = (cTw @ T @ cor.T).T
+            cuv = Cc[:, :2] / Cc[:, 2:3]
+            bbox = np.array([cuv[:, 0].min(), cuv[:, 1].min(), cuv[:, 0].max(), cuv[:, 1].max()]) + sig * rng.standard_normal(4)
+            frames.append(dict(clone=int(i), wTc=wTc[i].copy(), zs=zs, bbox=bbox))
+        objs.append(ObjectTrack(wTo=T_est, shape=shape, kps=kps_est, frames=frames))
+    return objs

@@ -1,0 +1,117 @@
+"""GPU parity of the object update (reference OrcVIO::removeLostObjects, src/orcvio.cpp:2154-2193)
+against the numpy mirror.  The rows fed to both come from the mirror's restatement of the residual
+functors (pinned by the reference's HDF5 goldens, tests/test_oracle_objects.py)."""
+import numpy as np
+import pytest
+
+from orcvio_amd import capi, synth
+from oracle import mirror_objects as mo
+from helpers import rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope='module')
+def upd(built):
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=64, max_observations=1024)
+    yield u
+    u.close()
+
+
+def _rows_for(win, obj, obj_left, new_bbox, vio_left):
+    res, Hf, Jc, counts = mo.object_rows(obj.wTo, obj.shape, obj.kps, obj.frames, obj_left, new_bbox)
+    f2c = [fr['clone'] for fr in obj.frames]
+    out = mo.construct_object_residual_jacobians(Jc, f2c, Hf, res, counts, [fr['wTc'] for fr in obj.frames],
+                                                 win.R_b2c[0], win.t_c_b[0], vio_left, win.flags.leg_dim, win.N)
+    return out
+
+
+@pytest.mark.parametrize('obj_left,new_bbox,vio_left', [(True, False, 0), (False, False, 0), (True, True, 0), (True, False, 1)])
+def test_single_object_matches_reference_semantics(upd, obj_left, new_bbox, vio_left):
+    """One object per call: per-object projection == the reference's stacked projection (note N3)."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=vio_left)
+    win = synth.make_window(N=12, F=4, seed=3, flags=flags, track_len=4)
+    obj = synth.make_objects(win, n_objects=1, seed=5, sigma_kp=0.004)[0]
+    Hx, Hf, r, rc, hx6 = _rows_for(win, obj, obj_left, new_bbox, vio_left)
+    ref = mo.remove_lost_objects(Hx, Hf, r, win.P, flags.noise_feature ** 2)
+    got = upd.update_objects(flags, win.N, [dict(row_clone=rc, Hx6=hx6, Hf=Hf, res=r)], win.P, want_G=True)
+    assert got['accept'] == int(ref['updated'])
+    assert abs(got['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+    assert rel(got['dx'], ref['dx']) < TOL
+    assert rel(got['P_new'], ref['P_new']) < TOL
+    assert rel(got['G'], ref['G']) < TOL
+    assert got['stats'][0] == ref['dof']
+
+
+def test_rejected_object_leaves_state_alone(upd):
+    flags = synth.Flags(use_larvio=0)
+    win = synth.make_window(N=10, F=4, seed=4, flags=flags, track_len=4)
+    obj = synth.make_objects(win, n_objects=1, seed=6, sigma_kp=0.2)[0]   # 25 sigma keypoint noise -> gate fails
+    Hx, Hf, r, rc, hx6 = _rows_for(win, obj, True, False, 0)
+    ref = mo.remove_lost_objects(Hx, Hf, r, win.P, flags.noise_feature ** 2)
+    assert not ref['updated']
+    got = upd.update_objects(flags, win.N, [dict(row_clone=rc, Hx6=hx6, Hf=Hf, res=r)], win.P)
+    assert got['accept'] == 0 and not got['dx'].any()
+    assert rel(got['P_new'], win.P) < 1e-15
+    assert abs(got['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+
+
+def test_nan_rows_are_rejected(upd):
+    """check_nan guard (src/orcvio.cpp:2178-2182): no update."""
+    flags = synth.Flags(use_larvio=0)
+    win = synth.make_window(N=8, F=4, seed=4, flags=flags, track_len=4)
+    obj = synth.make_objects(win, n_objects=1, seed=8, sigma_kp=0.004)[0]
+    Hx, Hf, r, rc, hx6 = _rows_for(win, obj, True, False, 0)
+    r = r.copy()
+    r[5] = np.nan
+    got = upd.update_objects(flags, win.N, [dict(row_clone=rc, Hx6=hx6, Hf=Hf, res=r)], win.P)
+    assert got['accept'] == 0 and not got['dx'].any() and rel(got['P_new'], win.P) < 1e-15
+
+
+def test_too_few_rows_and_empty(upd):
+    flags = synth.Flags(use_larvio=0)
+    win = synth.make_window(N=6, F=4, seed=4, flags=flags, track_len=4)
+    rng = np.random.default_rng(0)
+    blk = dict(row_clone=np.zeros(30, dtype=np.int32), Hx6=rng.standard_normal((30, 6)), Hf=rng.standard_normal((30, 45)),
+               res=rng.standard_normal(30))
+    got = upd.update_objects(flags, win.N, [blk], win.P)     # rows <= cols: nullspace trick fails, no update
+    assert got['accept'] == 0 and rel(got['P_new'], win.P) < 1e-15
+    got = upd.update_objects(flags, win.N, [], win.P)
+    assert got['accept'] == 0 and rel(got['P_new'], win.P) < 1e-15
+
+
+@pytest.mark.parametrize('new_bbox', [False, True])
+def test_config3_twenty_objects(upd, new_bbox):
+    """30 clones, 20 cars x 12 keypoints x 30 frames, 10 % keypoints missing: per-object projection,
+    joint gate.  The comparison stacks the per-object projected blocks of the mirror.  new_bbox=True are
+    the shipped launch-file flags (left perturbation, new bbox residual, SURVEY.md note N8)."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=30, F=4, seed=0, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=20, seed=1, sigma_kp=0.004)
+    from oracle import mirror
+    blocks, Hp, rp = [], [], []
+    for ob in objs:
+        Hx, Hf, r, rc, hx6 = _rows_for(win, ob, True, new_bbox, 0)
+        blocks.append(dict(row_clone=rc, Hx6=hx6, Hf=Hf, res=r))
+        ok, H1, r1 = mirror.nullspace_project_svd(Hf, Hx, r)
+        Hp.append(H1); rp.append(r1)
+    H = np.vstack(Hp); r = np.concatenate(rp)
+    s2 = flags.noise_feature ** 2
+    Ht, rt = mirror.qr_compress(H, r)
+    # gamma of the joint block through the compressed form (SURVEY.md Appendix A identity)
+    Q1, R = np.linalg.qr(H)
+    r1 = Q1.T @ r
+    g_ref = float(r1 @ np.linalg.solve(R @ win.P @ R.T + s2 * np.eye(R.shape[0]), r1) + (r @ r - r1 @ r1) / s2)
+    dx, K, Pn = mirror.measurement_update(Ht, rt, win.P, s2)
+    got = upd.update_objects(flags, win.N, blocks, win.P, want_G=True)
+    assert abs(got['gamma'] - g_ref) < 1e-6 * abs(g_ref)
+    thr = mirror.chi2_threshold(H.shape[0])
+    assert got['accept'] == int(g_ref < thr)
+    if got['accept']:
+        assert got['stats'][0] == H.shape[0]
+        assert rel(got['dx'], dx) < TOL and rel(got['P_new'], Pn) < TOL and rel(got['G'], K @ Ht) < TOL
+    else:
+        assert not got['dx'].any() and rel(got['P_new'], win.P) < 1e-15
+    if not new_bbox:
+        assert got['accept'] == 1   # consistent Jacobians: the joint block passes the gate
