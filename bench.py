@@ -62,14 +62,12 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     N, F = args.clones, args.features
-    # same window on every rank (seed 0), own feature shard per rank (seed 0 + rank for the tracks)
-    win = synth.make_window(N=N, F=F, seed=0, flags=synth.Flags(use_larvio=1))
-    if world > 1:
-        import dataclasses
-        wr = synth.make_window(N=N, F=F, seed=1000 + rank, flags=synth.Flags(use_larvio=1))
-        win = dataclasses.replace(wr, P=win.P)   # one common prior
-    upd = capi.MsckfUpdater(device=local_rank, max_clones=max(32, N), max_features=max(2048, F),
-                            max_observations=max(65536, F * N))
+    # weak scaling: one joint update of F*world tracks, dealt across the ranks
+    from orcvio_amd import sharding
+    full = synth.make_window(N=N, F=F * world, seed=0, flags=synth.Flags(use_larvio=1))
+    win, _ = sharding.shard_window(full, rank, world)
+    upd = capi.MsckfUpdater(device=local_rank, max_clones=max(32, N), max_features=max(2048, win.F),
+                            max_observations=max(65536, int(win.obs_ptr[-1])))
     upd.upload(win)
     stream = torch.cuda.current_stream().cuda_stream
     gathered = None

@@ -1,0 +1,318 @@
+// orcvio_msckf_host.hpp -- host-side mirror of the reference's filter back-end surface for the
+// MSCKF update path, written above the C-ABI (include/orcvio_msckf.h).
+//
+// The reference keeps this logic inside class OrcVIO (include/orcvio/orcvio.h:128-214) on Eigen /
+// std::map containers.  Eigen, Sophus and SuiteSparse are not available in this image, so the
+// mirror is dependency-free C++17 with the SAME container and method names (IMUState_Aug,
+// StateServer, Feature, MapServer, featureJacobian_msckf's callers, removeLostObjects,
+// constructObjectResidualJacobians, incrementState_IMUCam) on plain row-major std::vector storage.
+// A maintainer of the reference replaces the three call sites listed in INTEGRATION.md with the
+// flatten -> C call -> apply sequence implemented here.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/orcvio_msckf.h"
+
+namespace orcvio_amd {
+
+typedef long long StateIDType;    // reference include/orcvio/imu_state.h:24
+typedef long long FeatureIDType;  // reference include/orcvio/feat/feature.hpp
+
+struct Vec2 { double x = 0, y = 0; };
+
+// reference include/orcvio/imu_state.h:103-148 (fields the update path reads or writes)
+struct IMUState_Aug {
+    StateIDType id = 0;
+    double time = 0, dt = 0;
+    double orientation[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // R_b2w, row-major
+    double position[3] = {0, 0, 0};
+    double position_FEJ[3] = {0, 0, 0};
+    double R_imu_cam0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};    // R_b2c
+    double t_cam0_imu[3] = {0, 0, 0};                      // t_c_b
+    double orientation_cam[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double position_cam[3] = {0, 0, 0};
+};
+typedef std::map<StateIDType, IMUState_Aug> IMUStateServer;
+
+// reference include/orcvio/imu_state.h:34-95 (current IMU state, fields touched by incrementState_IMUCam)
+struct IMUState {
+    StateIDType id = 0;
+    double time = 0;
+    double orientation[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double velocity[3] = {0, 0, 0}, position[3] = {0, 0, 0}, gyro_bias[3] = {0, 0, 0}, acc_bias[3] = {0, 0, 0};
+    double R_imu_cam0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double t_cam0_imu[3] = {0, 0, 0};
+};
+
+// reference include/orcvio/orcvio.h:128-172
+struct StateServer {
+    IMUState imu_state;
+    IMUStateServer imu_states_augment;
+    double td = 0;
+    double imu_intrinsics[24] = {0};
+    std::vector<double> state_cov;   // n x n, symmetric
+    int dim() const { return (int)std::lround(std::sqrt((double)state_cov.size())); }
+};
+
+// reference include/orcvio/feat/feature.hpp:34-269 (fields the update path reads)
+struct Feature {
+    FeatureIDType id = 0;
+    double position[3] = {0, 0, 0};
+    std::map<StateIDType, Vec2> observations;
+    std::map<StateIDType, Vec2> observations_vel;
+    bool is_initialized = false;
+};
+typedef std::map<FeatureIDType, Feature> MapServer;
+
+struct UpdateOutcome {
+    int status = ORCVIO_OK;
+    bool updated = false;          // an update was applied to state_cov
+    bool state_incremented = false;   // delta_x applied (false if the large-update test discarded it, :4479)
+    std::vector<int> accepted;     // per listed feature
+    std::vector<double> gamma;
+    std::vector<double> delta_x;
+};
+
+class MsckfBackend {
+  public:
+    orcvio_msckf_flags flags{};
+
+    MsckfBackend(int device, int max_clones, int max_features, int max_observations) {
+        flags.leg_dim = 22; flags.use_larvio = 1; flags.noise_feature = 0.008; flags.chi2_prob = 0.95;
+        int rc = orcvio_msckf_create(device, max_clones, max_features, max_observations, &h_);
+        if (rc != ORCVIO_OK) throw std::runtime_error(std::string("orcvio_msckf_create: ") + orcvio_msckf_last_error());
+    }
+    ~MsckfBackend() { orcvio_msckf_destroy(h_); }
+    MsckfBackend(const MsckfBackend&) = delete;
+    MsckfBackend& operator=(const MsckfBackend&) = delete;
+
+    // ---- flatten: std::map window -> SoA (index = rank of the clone id in the ordered map, :1205-1210)
+    static void flattenWindow(const StateServer& ss, std::vector<double>& R_b2w, std::vector<double>& t_b_w,
+                              std::vector<double>& t_fej, std::vector<double>& R_b2c, std::vector<double>& t_c_b,
+                              std::map<StateIDType, int>& index_of) {
+        const size_t N = ss.imu_states_augment.size();
+        R_b2w.resize(9 * N); t_b_w.resize(3 * N); t_fej.resize(3 * N); R_b2c.resize(9 * N); t_c_b.resize(3 * N);
+        index_of.clear();
+        int i = 0;
+        for (const auto& kv : ss.imu_states_augment) {
+            const IMUState_Aug& a = kv.second;
+            std::memcpy(&R_b2w[9 * i], a.orientation, sizeof(a.orientation));
+            std::memcpy(&t_b_w[3 * i], a.position, sizeof(a.position));
+            std::memcpy(&t_fej[3 * i], a.position_FEJ, sizeof(a.position_FEJ));
+            std::memcpy(&R_b2c[9 * i], a.R_imu_cam0, sizeof(a.R_imu_cam0));
+            std::memcpy(&t_c_b[3 * i], a.t_cam0_imu, sizeof(a.t_cam0_imu));
+            index_of[kv.first] = i++;
+        }
+    }
+
+    // CSR of the listed features.  `only_states` empty -> every observation (removeLostFeatures,
+    // src/orcvio.cpp:2503-2519); otherwise only the observations of those clones (pruneImuStateBuffer,
+    // :2810-2845: involved_state_ids).
+    static void flattenTracks(const MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                              const std::map<StateIDType, int>& index_of, const std::vector<StateIDType>& only_states,
+                              std::vector<double>& p_w, std::vector<int32_t>& obs_ptr, std::vector<int32_t>& obs_clone,
+                              std::vector<double>& obs_z, std::vector<double>& obs_zvel) {
+        p_w.clear(); obs_clone.clear(); obs_z.clear(); obs_zvel.clear();
+        obs_ptr.assign(1, 0);
+        for (FeatureIDType fid : ids) {
+            const Feature& f = map_server.at(fid);
+            p_w.insert(p_w.end(), f.position, f.position + 3);
+            for (const auto& ob : f.observations) {
+                if (!only_states.empty() && std::find(only_states.begin(), only_states.end(), ob.first) == only_states.end()) continue;
+                auto it = index_of.find(ob.first);
+                if (it == index_of.end()) continue;   // observation of a clone that left the window
+                obs_clone.push_back(it->second);
+                obs_z.push_back(ob.second.x); obs_z.push_back(ob.second.y);
+                auto v = f.observations_vel.find(ob.first);
+                obs_zvel.push_back(v == f.observations_vel.end() ? 0.0 : v->second.x);
+                obs_zvel.push_back(v == f.observations_vel.end() ? 0.0 : v->second.y);
+            }
+            obs_ptr.push_back((int32_t)obs_clone.size());
+        }
+    }
+
+    // ---- the two feature call sites -----------------------------------------------------------
+    // Replaces the stacking loop + compression + measurementUpdate_hybrid of OrcVIO::removeLostFeatures
+    // (src/orcvio.cpp:2497-2560) when only_states is empty, and the loop + measurementUpdate_msckf of
+    // OrcVIO::pruneImuStateBuffer (:2803-2851) when only_states = rm_imu_state_ids.
+    UpdateOutcome msckfUpdate(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                              const std::vector<StateIDType>& only_states = {}) {
+        UpdateOutcome out;
+        if (ids.empty()) return out;
+        std::vector<double> R_b2w, t_b_w, t_fej, R_b2c, t_c_b, p_w, obs_z, obs_zvel;
+        std::vector<int32_t> obs_ptr, obs_clone;
+        std::map<StateIDType, int> index_of;
+        flattenWindow(ss, R_b2w, t_b_w, t_fej, R_b2c, t_c_b, index_of);
+        flattenTracks(map_server, ids, index_of, only_states, p_w, obs_ptr, obs_clone, obs_z, obs_zvel);
+        const int N = (int)index_of.size(), n = flags.leg_dim + 6 * N;
+        if (ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        orcvio_msckf_window w{N, R_b2w.data(), t_b_w.data(), t_fej.data(), R_b2c.data(), t_c_b.data()};
+        orcvio_msckf_tracks t{(int32_t)ids.size(), p_w.data(), obs_ptr.data(), obs_clone.data(), obs_z.data(), obs_zvel.data()};
+        out.accepted.assign(ids.size(), 0);
+        out.gamma.assign(ids.size(), 0.0);
+        out.delta_x.assign(n, 0.0);
+        std::vector<double> P_new((size_t)n * n);
+        orcvio_msckf_result r{};
+        r.dx = out.delta_x.data(); r.P_out = P_new.data(); r.accept = out.accepted.data(); r.gamma = out.gamma.data();
+        out.status = orcvio_msckf_update_features(h_, &flags, &w, &t, ss.state_cov.data(), &r);
+        if (out.status != ORCVIO_OK) return out;
+        out.updated = r.stats[3] != 0;
+        if (out.updated) {
+            ss.state_cov.swap(P_new);                       // P is updated even when delta_x is discarded (:4479-4494)
+            out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
+        }
+        return out;
+    }
+
+    // ---- objects --------------------------------------------------------------------------------
+    // OrcVIO::constructObjectResidualJacobians (src/orcvio.cpp:2017-2151) in compact form: returns false if
+    // no frame of the object is in the window.  jacobian_wrt_sensor_state: rows x 6 row-major, ordered
+    // [keypoint rows of all frames ; 4 bbox rows of all frames]; Hf rows x obj_cols; on return the rows
+    // are interleaved per in-window frame and row_clone / Hx6 describe Hx.
+    bool constructObjectResidualJacobians(const StateServer& ss, const std::vector<double>& cur_window_timestamps,
+                                          const std::vector<double>& jacobian_wrt_sensor_state,
+                                          const std::vector<double>& object_timestamps, const std::vector<int>& zs_num_wrt_timestamps,
+                                          const std::vector<double>& valid_camera_wTc /* frames x 16, row-major */,
+                                          int obj_cols, std::vector<double>& Hf, std::vector<double>& res,
+                                          std::vector<int32_t>& row_clone, std::vector<double>& Hx6,
+                                          bool dcampose_dimupose_fixed_to_identity = false) const {
+        const int F = (int)object_timestamps.size();
+        int sum_zs = 0;
+        for (int c : zs_num_wrt_timestamps) sum_zs += 2 * c;
+        std::vector<double> Hf_out, res_out;
+        row_clone.clear(); Hx6.clear();
+        int src = 0;
+        for (int f = 0; f < F; ++f) {
+            const int zf = 2 * zs_num_wrt_timestamps[f];
+            auto it = std::find(cur_window_timestamps.begin(), cur_window_timestamps.end(), object_timestamps[f]);   // exact match (:2073)
+            if (it != cur_window_timestamps.end()) {
+                const int idx = (int)std::distance(cur_window_timestamps.begin(), it);
+                double D[36];
+                camWrtImuJacobian(ss, &valid_camera_wTc[16 * f], dcampose_dimupose_fixed_to_identity, D);
+                auto emit = [&](int q) {
+                    const double* j = &jacobian_wrt_sensor_state[(size_t)q * 6];
+                    for (int c = 0; c < 6; ++c) {
+                        double s = 0;
+                        for (int k = 0; k < 6; ++k) s += j[k] * D[k * 6 + c];
+                        Hx6.push_back(s);
+                    }
+                    row_clone.push_back(idx);
+                    Hf_out.insert(Hf_out.end(), Hf.begin() + (size_t)q * obj_cols, Hf.begin() + (size_t)(q + 1) * obj_cols);
+                    res_out.push_back(res[q]);
+                };
+                for (int q = src; q < src + zf; ++q) emit(q);
+                for (int q = sum_zs + 4 * f; q < sum_zs + 4 * f + 4; ++q) emit(q);
+            }
+            src += zf;
+        }
+        if (row_clone.empty()) return false;
+        Hf.swap(Hf_out);
+        res.swap(res_out);
+        return true;
+    }
+
+    // OrcVIO::removeLostObjects (src/orcvio.cpp:2154-2193) for one or more object blocks.
+    UpdateOutcome removeLostObjects(StateServer& ss, const std::vector<orcvio_msckf_object_rows>& blocks) {
+        UpdateOutcome out;
+        const int N = (int)ss.imu_states_augment.size(), n = flags.leg_dim + 6 * N;
+        if (ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        out.accepted.assign(1, 0);
+        out.gamma.assign(1, 0.0);
+        out.delta_x.assign(n, 0.0);
+        std::vector<double> P_new((size_t)n * n);
+        orcvio_msckf_result r{};
+        r.dx = out.delta_x.data(); r.P_out = P_new.data(); r.accept = out.accepted.data(); r.gamma = out.gamma.data();
+        out.status = orcvio_msckf_update_objects(h_, &flags, N, blocks.data(), (int32_t)blocks.size(), ss.state_cov.data(), &r);
+        if (out.status != ORCVIO_OK) return out;
+        out.updated = r.stats[3] != 0;
+        if (out.updated) {
+            ss.state_cov.swap(P_new);
+            out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
+        }
+        return out;
+    }
+
+    // OrcVIO::incrementState_IMUCam (src/orcvio.cpp:4468-4567)
+    bool incrementState_IMUCam(StateServer& ss, const std::vector<double>& delta_x) const {
+        const int N = (int)ss.imu_states_augment.size();
+        std::vector<double> R(9 * N), t(3 * N), Rc(9 * N), tc(3 * N);
+        int i = 0;
+        for (auto& kv : ss.imu_states_augment) {
+            std::memcpy(&R[9 * i], kv.second.orientation, 72);
+            std::memcpy(&t[3 * i], kv.second.position, 24);
+            ++i;
+        }
+        orcvio_msckf_state st{};
+        std::memcpy(st.R_b2w_imu, ss.imu_state.orientation, 72);
+        std::memcpy(st.v, ss.imu_state.velocity, 24); std::memcpy(st.p, ss.imu_state.position, 24);
+        std::memcpy(st.bg, ss.imu_state.gyro_bias, 24); std::memcpy(st.ba, ss.imu_state.acc_bias, 24);
+        std::memcpy(st.R_b2c, ss.imu_state.R_imu_cam0, 72); std::memcpy(st.t_c_b, ss.imu_state.t_cam0_imu, 24);
+        st.td = ss.td;
+        std::memcpy(st.imu_intrinsics, ss.imu_intrinsics, sizeof(st.imu_intrinsics));
+        st.n_clones = N;
+        st.clone_R_b2w = R.data(); st.clone_t_b_w = t.data(); st.clone_R_c2w = Rc.data(); st.clone_t_c_w = tc.data();
+        const int applied = orcvio_msckf_increment_state(&flags, delta_x.data(), &st);
+        if (applied != 1) return false;
+        std::memcpy(ss.imu_state.orientation, st.R_b2w_imu, 72);
+        std::memcpy(ss.imu_state.velocity, st.v, 24); std::memcpy(ss.imu_state.position, st.p, 24);
+        std::memcpy(ss.imu_state.gyro_bias, st.bg, 24); std::memcpy(ss.imu_state.acc_bias, st.ba, 24);
+        std::memcpy(ss.imu_state.R_imu_cam0, st.R_b2c, 72); std::memcpy(ss.imu_state.t_cam0_imu, st.t_c_b, 24);
+        ss.td = st.td;
+        std::memcpy(ss.imu_intrinsics, st.imu_intrinsics, sizeof(st.imu_intrinsics));
+        i = 0;
+        for (auto& kv : ss.imu_states_augment) {
+            std::memcpy(kv.second.orientation, &R[9 * i], 72);
+            std::memcpy(kv.second.position, &t[3 * i], 24);
+            std::memcpy(kv.second.orientation_cam, &Rc[9 * i], 72);
+            std::memcpy(kv.second.position_cam, &tc[3 * i], 24);
+            ++i;
+        }
+        return true;
+    }
+
+    orcvio_msckf_handle* handle() { return h_; }
+
+  private:
+    orcvio_msckf_handle* h_ = nullptr;
+
+    // get_cam_wrt_imu_se3_jacobian (include/orcvio/utils/se3_ops.hpp:531-552) for the camera pose wTc of an
+    // object frame, with the CURRENT extrinsics (src/orcvio.cpp:2079-2093)
+    void camWrtImuJacobian(const StateServer& ss, const double* wTc, bool identity, double D[36]) const {
+        std::memset(D, 0, 36 * sizeof(double));
+        if (identity) { for (int i = 0; i < 6; ++i) D[i * 6 + i] = 1.0; return; }
+        const double* Rbc = ss.imu_state.R_imu_cam0;
+        const double* tcb = ss.imu_state.t_cam0_imu;
+        double Rcw[9], v[3], tbw[3];   // wTc[:3,:3] = R_c2w
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rcw[i * 3 + j] = wTc[i * 4 + j];
+        for (int i = 0; i < 3; ++i) v[i] = -(Rbc[i * 3] * tcb[0] + Rbc[i * 3 + 1] * tcb[1] + Rbc[i * 3 + 2] * tcb[2]);
+        for (int i = 0; i < 3; ++i) tbw[i] = Rcw[i * 3] * v[0] + Rcw[i * 3 + 1] * v[1] + Rcw[i * 3 + 2] * v[2] + wTc[i * 4 + 3];
+        auto skew = [](const double* w, double* S) { S[0] = 0; S[1] = -w[2]; S[2] = w[1]; S[3] = w[2]; S[4] = 0; S[5] = -w[0]; S[6] = -w[1]; S[7] = w[0]; S[8] = 0; };
+        double S[9];
+        if (flags.use_left_perturbation) {
+            skew(tbw, S);
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) D[i * 6 + j] = S[i * 3 + j];
+                D[(3 + i) * 6 + i] = 1.0;
+                D[i * 6 + 3 + i] = 1.0;
+            }
+        } else {
+            skew(tcb, S);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double s = 0;
+                    for (int k = 0; k < 3; ++k) s += Rbc[i * 3 + k] * S[k * 3 + j];
+                    D[i * 6 + j] = -s;
+                    D[(3 + i) * 6 + j] = Rbc[i * 3 + j];
+                    D[i * 6 + 3 + j] = Rcw[j * 3 + i];   // R_w2c = R_c2w^T
+                }
+        }
+    }
+};
+
+}  // namespace orcvio_amd

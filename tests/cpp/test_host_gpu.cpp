@@ -1,0 +1,124 @@
+// GPU test of the C++ host mirror end to end: std::map containers -> MsckfBackend::msckfUpdate (HIP path
+// through the C-ABI) against the plain-C oracle on the same window.  Also the pruneImuStateBuffer variant.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "../../orcvio_amd/csrc/host/orcvio_msckf_host.hpp"
+
+extern "C" int orc_oracle_msckf_update(int N, int F, const int* flags, double sigma, double chi2_prob, const double* chi2_table,
+                                       int chi2_table_len, const double* R_b2w, const double* t_b_w, const double* t_fej,
+                                       const double* R_b2c, const double* t_c_b, const double* p_w, const int* obs_ptr,
+                                       const int* obs_clone, const double* obs_z, const double* obs_zvel, const int* clone_mask,
+                                       const double* P, double* dx, double* P_out, int* accept, double* gamma, double* H_all,
+                                       double* r_all, int* block_ptr, double* H_thin, double* r_thin, double* K, double* G, int* info);
+extern "C" double orc_oracle_chi2_quantile(int dof, double p);
+
+using namespace orcvio_amd;
+
+static void rotz(double a, double* R) { R[0] = cos(a); R[1] = -sin(a); R[2] = 0; R[3] = sin(a); R[4] = cos(a); R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1; }
+
+static double relerr(const std::vector<double>& a, const std::vector<double>& b) {
+    double d = 0, n = 0;
+    for (size_t i = 0; i < a.size(); ++i) { d += (a[i] - b[i]) * (a[i] - b[i]); n += b[i] * b[i]; }
+    return std::sqrt(d / (n > 0 ? n : 1));
+}
+
+int main() {
+    const int N = 8, F = 40;
+    std::mt19937 rng(3);
+    std::normal_distribution<double> G(0, 1);
+    std::uniform_real_distribution<double> U(0, 1);
+    StateServer ss;
+    for (int i = 0; i < N; ++i) {
+        IMUState_Aug a; a.id = 100 + 2 * i;
+        rotz(0.03 * i, a.orientation);
+        a.position[0] = 0.2 * i; a.position[1] = 0.05 * std::sin(0.4 * i); a.position[2] = 0.02 * i;
+        for (int k = 0; k < 3; ++k) a.position_FEJ[k] = a.position[k];
+        // camera looks along body x: R_b2c rows = (cam x = -body y, cam y = -body z, cam z = body x)
+        const double Rbc[9] = {0, -1, 0, 0, 0, -1, 1, 0, 0};
+        std::memcpy(a.R_imu_cam0, Rbc, sizeof(Rbc));
+        a.t_cam0_imu[0] = 0.05; a.t_cam0_imu[1] = 0.02; a.t_cam0_imu[2] = -0.01;
+        ss.imu_states_augment[a.id] = a;
+    }
+    ss.imu_state = IMUState();
+    std::memcpy(ss.imu_state.R_imu_cam0, ss.imu_states_augment.begin()->second.R_imu_cam0, 72);
+    std::memcpy(ss.imu_state.t_cam0_imu, ss.imu_states_augment.begin()->second.t_cam0_imu, 24);
+    const int n = 22 + 6 * N;
+    ss.state_cov.assign((size_t)n * n, 0.0);
+    {   // SPD prior with the extrinsic / td block zeroed
+        std::vector<double> A((size_t)n * n);
+        for (auto& v : A) v = G(rng) / std::sqrt((double)n);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double s = 0;
+                for (int k = 0; k < n; ++k) s += A[(size_t)i * n + k] * A[(size_t)j * n + k];
+                ss.state_cov[(size_t)i * n + j] = 1e-4 * s + (i == j ? 1e-3 : 0.0);
+            }
+        for (int i = 15; i < 22; ++i)
+            for (int j = 0; j < n; ++j) ss.state_cov[(size_t)i * n + j] = ss.state_cov[(size_t)j * n + i] = 0.0;
+    }
+    MapServer map_server;
+    std::vector<FeatureIDType> ids;
+    for (int j = 0; j < F; ++j) {
+        Feature f; f.id = 1000 + 3 * j;
+        const double pt[3] = {6.0 + 6.0 * U(rng), -2.0 + 4.0 * U(rng), -1.0 + 2.0 * U(rng)};
+        const int M = 3 + (int)(U(rng) * (N - 3)), s0 = (int)(U(rng) * (N - M + 1));
+        int i = 0;
+        for (auto& kv : ss.imu_states_augment) {
+            if (i >= s0 && i < s0 + M) {
+                const IMUState_Aug& a = kv.second;
+                double tcw[3], d[3], pc[3];
+                for (int k = 0; k < 3; ++k) tcw[k] = a.position[k] + a.orientation[k * 3] * a.t_cam0_imu[0] + a.orientation[k * 3 + 1] * a.t_cam0_imu[1] + a.orientation[k * 3 + 2] * a.t_cam0_imu[2];
+                for (int k = 0; k < 3; ++k) d[k] = pt[k] - tcw[k];
+                double Rwc[9];
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rwc[r * 3 + c] = a.R_imu_cam0[r * 3] * a.orientation[c * 3] + a.R_imu_cam0[r * 3 + 1] * a.orientation[c * 3 + 1] + a.R_imu_cam0[r * 3 + 2] * a.orientation[c * 3 + 2];
+                for (int k = 0; k < 3; ++k) pc[k] = Rwc[k * 3] * d[0] + Rwc[k * 3 + 1] * d[1] + Rwc[k * 3 + 2] * d[2];
+                const double noise = (j % 7 == 0) ? 0.1 : 0.008;   // every 7th track is an outlier
+                f.observations[kv.first] = {pc[0] / pc[2] + noise * G(rng), pc[1] / pc[2] + noise * G(rng)};
+                f.observations_vel[kv.first] = {0.01 * G(rng), 0.01 * G(rng)};
+            }
+            ++i;
+        }
+        for (int k = 0; k < 3; ++k) f.position[k] = pt[k] + 0.02 * G(rng);
+        map_server[f.id] = f;
+        ids.push_back(f.id);
+    }
+    MsckfBackend be(0, 16, 256, 8192);
+    int fails = 0;
+    for (int variant = 0; variant < 2; ++variant) {
+        std::vector<StateIDType> only;
+        if (variant == 1) { auto it = ss.imu_states_augment.begin(); ++it; only.push_back(it->first); ++it; only.push_back(it->first); }
+        // oracle on the same flat data
+        std::vector<double> R, t, tf, Rc, tc, p_w, z, zv;
+        std::vector<int32_t> ptr, clone;
+        std::map<StateIDType, int> index_of;
+        MsckfBackend::flattenWindow(ss, R, t, tf, Rc, tc, index_of);
+        MsckfBackend::flattenTracks(map_server, ids, index_of, only, p_w, ptr, clone, z, zv);
+        std::vector<double> table(500, 0.0);
+        for (int d = 1; d < 500; ++d) table[d] = orc_oracle_chi2_quantile(d, 0.95);
+        const int fl[5] = {22, 1, 0, 0, 0};
+        std::vector<double> dx(n), Pn((size_t)n * n), gam(F), Gm((size_t)n * n), Ht((size_t)n * n), rt(n);
+        std::vector<int> acc(F);
+        int info[2];
+        StateServer ss_copy = ss;
+        int rc = orc_oracle_msckf_update(N, F, fl, 0.008, 0.95, table.data(), 500, R.data(), t.data(), tf.data(), Rc.data(), tc.data(),
+                                         p_w.data(), ptr.data(), clone.data(), z.data(), zv.data(), nullptr, ss.state_cov.data(), dx.data(),
+                                         Pn.data(), acc.data(), gam.data(), nullptr, nullptr, nullptr, Ht.data(), rt.data(), nullptr, Gm.data(), info);
+        UpdateOutcome out = be.msckfUpdate(ss_copy, map_server, ids, only);
+        if (rc != 0 || out.status != ORCVIO_OK) { std::printf("status oracle %d gpu %d (%s)\n", rc, out.status, orcvio_msckf_last_error()); return 1; }
+        int nacc = 0, same = 1;
+        for (int j = 0; j < F; ++j) { nacc += acc[j]; same &= (acc[j] == out.accepted[j]); }
+        const double e_dx = relerr(out.delta_x, dx), e_P = relerr(ss_copy.state_cov, Pn);
+        std::printf("variant %d: accepted %d/%d same mask %d  dx rel %.2e  P rel %.2e  incremented %d\n", variant, nacc, F, same, e_dx, e_P,
+                    (int)out.state_incremented);
+        if (!same || !(e_dx < 1e-6) || !(e_P < 1e-6) || nacc == 0 || (variant == 0 && nacc == F)) ++fails;
+        // the state was incremented: clone 0 position moved by delta_x[22+3..22+5]
+        const IMUState_Aug& c0 = ss_copy.imu_states_augment.begin()->second;
+        const IMUState_Aug& b0 = ss.imu_states_augment.begin()->second;
+        for (int k = 0; k < 3; ++k)
+            if (std::fabs((c0.position[k] - b0.position[k]) - out.delta_x[22 + 3 + k]) > 1e-12) ++fails;
+    }
+    std::printf(fails ? "FAILED\n" : "host gpu ok\n");
+    return fails;
+}
