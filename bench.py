@@ -58,7 +58,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # ORCVIO_BENCH_FORCE_DIST=1 drives the multi-GPU code path (RCCL all-gather included) with world size 1
+    use_dist = world > 1 or os.environ.get('ORCVIO_BENCH_FORCE_DIST') == '1'
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     N, F = args.clones, args.features
@@ -69,36 +73,36 @@ def main():
     upd = capi.MsckfUpdater(device=local_rank, max_clones=max(32, N), max_features=max(2048, win.F),
                             max_observations=max(65536, int(win.obs_ptr[-1])))
     upd.upload(win)
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit (non-default) stream carries the kernels AND the collective, so RCCL is ordered after the
+    # rank's block is written and before the solve reads the gathered blocks
+    tstream = torch.cuda.Stream()
+    stream = tstream.cuda_stream
     gathered = None
-    if world > 1:
-        ptr, ne = upd.block_ptr()
+    if use_dist:
+        _, ne = upd.block_ptr()
         gathered = torch.empty(world * ne, dtype=torch.float64, device='cuda')
         local = torch.empty(ne, dtype=torch.float64, device='cuda')
-        import ctypes as C
-        hip = C.CDLL('libamdhip64.so')
 
     def step():
-        if world == 1:
-            upd.run_update(stream)
-        else:
-            upd.run_local(stream)
-            # the handle's block lives in its own allocation: copy it into the collective's input
-            hip.hipMemcpyAsync(C.c_void_p(local.data_ptr()), C.c_void_p(ptr), C.c_size_t(ne * 8), 3, C.c_void_p(stream))
-            dist.all_gather_into_tensor(gathered, local)
-            upd.run_finish(gathered.data_ptr(), world, stream)
+        with torch.cuda.stream(tstream):
+            if not use_dist:
+                upd.run_update(stream)
+            else:
+                upd.run_local_to(local.data_ptr(), stream)          # this rank's compressed block -> send buffer
+                dist.all_gather_into_tensor(gathered, local)        # the one data-path collective (RCCL over xGMI)
+                upd.run_finish(gathered.data_ptr(), world, stream)  # rank-ordered sum + replicated Kalman solve
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -120,7 +124,7 @@ def main():
         kflops = {
             'k_feature': (W['W_J'] + W['W_N'] + W['W_G']) / world,   # Jacobians + nullspace + gate
             'k_gram': W['W_Q'] / world,                                # stack compression
-            'k_gram_reduce': 0.0,
+            'k_assemble': 0.0,
             'k_potrf(P)': n ** 3 / 3.0,
             'k_gemm(U)': 2.0 * (NA + 1) * NA * n,
             'k_gemm(M)': 2.0 * NA * n * n / 2.0,
@@ -156,7 +160,7 @@ def main():
                                parallelism=f'features sharded over {world} GPU(s), all-gather of compressed blocks'),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     upd.close()

@@ -102,15 +102,17 @@ typedef struct orcvio_msckf_result {
     double* P_out;    /* [n*n]  (I-KH)P, symmetrised              (:1741-1753)               */
     int32_t* accept;  /* [F]    chi-square gate result             (:1953-1976)               */
     double* gamma;    /* [F]    Mahalanobis distance of each block                            */
-    double* H_thin;   /* [(n-15)*n] row-major compressed Jacobian (upper-triangular R placed in
-                         state columns 15..n-1; rows of rank-deficient directions are zero)   */
+    double* H_thin;   /* [(n-15)*n] row-major compressed Jacobian: upper-triangular R placed in state
+                         columns 15..n-1 with R^T R = H^T H (+1e-11 max(diag) I: the stacked Jacobian is
+                         rank deficient in every update, the shift avoids a rank decision)           */
     double* r_thin;   /* [n-15]                                                              */
     double* K;        /* [n*(n-15)] row-major Kalman gain w.r.t. H_thin                       */
     double* G;        /* [n*n] row-major K*H_thin (basis independent, SURVEY.md note N1)      */
     int32_t stats[8]; /* [0] stacked rows (accepted)  [1] rows of H_thin  [2] accepted blocks
                          [3] 1 if an update was applied to P  [4] 1 if the reference's
-                         large-update test (:4479) would discard delta_x  [5] zero pivots met
-                         while compressing  [6..7] reserved                                   */
+                         large-update test (:4479) would discard delta_x  [5] zero-variance
+                         directions of the prior (dropped pivots of chol(P))  [6] pivots of chol(P)
+                         below -tol (the prior was not PSD)  [7] objects: rank-deficient H_f columns */
 } orcvio_msckf_result;
 
 typedef struct orcvio_msckf_handle orcvio_msckf_handle;
@@ -128,6 +130,12 @@ double orcvio_msckf_chi2_quantile(int32_t dof, double prob);
 int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_features,
                             int32_t max_observations, orcvio_msckf_handle** out);
 void orcvio_msckf_destroy(orcvio_msckf_handle* h);
+
+/* Options.  ORCVIO_OPT_MATERIALIZE_STACK (default 0): also write the stacked projected blocks
+ * [H' | r'] (what the reference builds in H_msckf, src/orcvio.cpp:2497-2527) to device memory.  The
+ * update itself never needs them; tests and callers that want H' switch it on. */
+enum { ORCVIO_OPT_MATERIALIZE_STACK = 1 };
+int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* Feature update: replaces the loop + compression + update of
  * OrcVIO::removeLostFeatures (src/orcvio.cpp:2497-2560) and of
@@ -164,6 +172,9 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
                             const double* P);
 int32_t orcvio_msckf_run_local(orcvio_msckf_handle* h, void* stream);
 int32_t orcvio_msckf_block_ptr(orcvio_msckf_handle* h, double** d_block, int64_t* n_elems);
+/* run_local writing the block straight into caller-owned device memory (e.g. the send buffer of the
+ * all-gather), n_elems doubles as reported by block_ptr. */
+int32_t orcvio_msckf_run_local_to(orcvio_msckf_handle* h, double* d_dst, void* stream);
 int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks,
                                 void* stream);
 int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream);

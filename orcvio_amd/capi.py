@@ -28,7 +28,7 @@ EXPORTS = [
     'orcvio_msckf_update_objects', 'orcvio_msckf_upload', 'orcvio_msckf_run_local',
     'orcvio_msckf_block_ptr', 'orcvio_msckf_run_finish', 'orcvio_msckf_run_update',
     'orcvio_msckf_sync', 'orcvio_msckf_download', 'orcvio_msckf_profile_update',
-    'orcvio_msckf_increment_state',
+    'orcvio_msckf_increment_state', 'orcvio_msckf_set_option', 'orcvio_msckf_run_local_to',
 ]
 
 
@@ -103,6 +103,8 @@ def load():
     lib.orcvio_msckf_profile_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), _dp,
                                                 C.POINTER(C.c_int32)]
     lib.orcvio_msckf_increment_state.argtypes = [C.POINTER(MsckfFlags), _dp, C.POINTER(MsckfState)]
+    lib.orcvio_msckf_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.orcvio_msckf_run_local_to.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -139,6 +141,12 @@ class MsckfUpdater:
         self._keep = None
         self.n = None
         self.F = None
+
+    def set_materialize_stack(self, on: bool):
+        """ORCVIO_OPT_MATERIALIZE_STACK: also write the stacked projected blocks [H' | r'] (debug_read 'Hs')."""
+        rc = self.lib.orcvio_msckf_set_option(self.h, 1, int(bool(on)))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_set_option')
 
     def close(self):
         if self.h:
@@ -244,6 +252,11 @@ class MsckfUpdater:
         rc = self.lib.orcvio_msckf_run_local(self.h, C.c_void_p(stream) if stream else None)
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_run_local')
+
+    def run_local_to(self, d_dst, stream=None):
+        rc = self.lib.orcvio_msckf_run_local_to(self.h, C.c_void_p(d_dst), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_run_local_to')
 
     def block_ptr(self):
         p = C.c_void_p()

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -55,6 +56,11 @@ struct orcvio_msckf_handle {
     size_t cap_Xaug = 0, cap_Gobj = 0, cap_RF = 0, cap_Yobj = 0, cap_objH = 0, cap_obj_i = 0;
     bool objects_mode = false;
     int obj_dof = 0, obj_rows = 0, obj_count = 0;
+    double *d_T3 = nullptr, *d_Xobs = nullptr, *d_S = nullptr;
+    int *d_clone_ptr = nullptr, *d_clone_obs = nullptr;   // d_clone_ptr: [0..N] chunk_of_clone, then row chunk_ptr; d_clone_obs: obs_pos
+    std::vector<int> h_clone_ptr, h_clone_obs;
+    int s_chunks = 0;
+    bool materialize = false;
     size_t hs_rows_cap = 0;
     int gram_chunks_cap = 64;
     // host staging
@@ -144,7 +150,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_accept, h->d_info, h->d_chi2, h->d_Hs, h->d_gamma, h->d_Gpart, h->d_Ab, h->d_A, h->d_RP,
                     h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_Pout, h->d_dx, h->d_La, h->d_DinvA,
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
-                    h->d_obj_gamma, h->d_obj_i, h->d_obj_accept};
+                    h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_ptr, h->d_clone_obs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -206,7 +212,11 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_accept, sizeof(int) * max_features));
         HIPCHK(hipMalloc(&h->d_info, sizeof(int) * 8));
         HIPCHK(hipMalloc(&h->d_chi2, sizeof(double) * ORCVIO_CHI2_TABLE));
-        HIPCHK(hipMalloc(&h->d_Hs, sizeof(double) * h->hs_rows_cap * h->NAP_max));
+        HIPCHK(hipMalloc(&h->d_T3, sizeof(double) * (size_t)3 * max_features * h->NAP_max));
+        HIPCHK(hipMalloc(&h->d_Xobs, sizeof(double) * (size_t)32 * max_observations));
+        HIPCHK(hipMalloc(&h->d_S, sizeof(double) * (size_t)256 * (2 * max_observations / 256 + max_clones + 2)));
+        HIPCHK(hipMalloc(&h->d_clone_ptr, sizeof(int) * (2 * max_observations / 256 + 2 * max_clones + 4)));
+        HIPCHK(hipMalloc(&h->d_clone_obs, sizeof(int) * max_observations));
         HIPCHK(hipMalloc(&h->d_gamma, sizeof(double) * max_features));
         HIPCHK(hipMalloc(&h->d_Gpart, sizeof(double) * pp * h->gram_chunks_cap));
         HIPCHK(hipMalloc(&h->d_Ab, sizeof(double) * pp));
@@ -254,6 +264,18 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h) {
     (void)hipSetDevice(h->device);
     free_all(h);
     delete h;
+}
+
+int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value) {
+    if (!h) return ORCVIO_ERR_INVALID;
+    if (option == ORCVIO_OPT_MATERIALIZE_STACK) {
+        HIPCHK(hipSetDevice(h->device));
+        if (value && !h->d_Hs) HIPCHK(hipMalloc(&h->d_Hs, sizeof(double) * h->hs_rows_cap * h->NAP_max));
+        h->materialize = value != 0;
+        return ORCVIO_OK;
+    }
+    g_last_error = "orcvio_msckf_set_option: unknown option";
+    return ORCVIO_ERR_INVALID;
 }
 
 // ---- upload --------------------------------------------------------------------------------
@@ -329,16 +351,39 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
             if (tr->obs_zvel) HIPCHK(hipMemcpyAsync(h->d_obs_zvel, tr->obs_zvel, sizeof(double) * 2 * nobs, hipMemcpyHostToDevice, s));
         }
     }
+    // observations grouped by clone: position of every observation in the clone-sorted order, and row chunks
+    // (<= 256 rows, never across clones) for the sparse part of the compression
+    {
+        std::vector<int> cnt(N + 1, 0);
+        for (int o = 0; o < nobs; ++o) cnt[tr->obs_clone[o] + 1]++;
+        for (int i = 0; i < N; ++i) cnt[i + 1] += cnt[i];
+        h->h_clone_obs.assign(nobs > 0 ? nobs : 1, 0);
+        std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+        for (int o = 0; o < nobs; ++o) h->h_clone_obs[o] = fill[tr->obs_clone[o]]++;
+        // layout of h_clone_ptr: [0..N] chunk_of_clone, then chunk_ptr[0..nchunks] (row offsets)
+        std::vector<int> chunk_of_clone(N + 1, 0), chunk_ptr(1, 0);
+        for (int i = 0; i < N; ++i) {
+            const int r0 = 2 * cnt[i], r1 = 2 * cnt[i + 1];
+            for (int r = r0; r < r1; r += 256) chunk_ptr.push_back(r + 256 < r1 ? r + 256 : r1);
+            chunk_of_clone[i + 1] = (int)chunk_ptr.size() - 1;
+        }
+        h->s_chunks = (int)chunk_ptr.size() - 1;
+        h->h_clone_ptr = chunk_of_clone;
+        h->h_clone_ptr.insert(h->h_clone_ptr.end(), chunk_ptr.begin(), chunk_ptr.end());
+    }
+    HIPCHK(hipMemcpyAsync(h->d_clone_ptr, h->h_clone_ptr.data(), sizeof(int) * h->h_clone_ptr.size(), hipMemcpyHostToDevice, s));
+    if (nobs > 0) HIPCHK(hipMemcpyAsync(h->d_clone_obs, h->h_clone_obs.data(), sizeof(int) * nobs, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     // Gram chunking: enough (chunk, tile) wavefronts to fill 256 CUs
     const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
     int chunks = (2048 + ntiles - 1) / ntiles;
     if (chunks > h->gram_chunks_cap) chunks = h->gram_chunks_cap;
     if (chunks < 1) chunks = 1;
-    int rpc = round_up((h->m_tot + chunks - 1) / chunks, 8);
+    const int t3rows = 3 * F;   // the dense part of the compression: three rows per track
+    int rpc = round_up((t3rows + chunks - 1) / chunks, 8);
     if (rpc < 8) rpc = 8;
     h->rows_per_chunk = rpc;
-    h->chunks = h->m_tot > 0 ? (h->m_tot + rpc - 1) / rpc : 1;
+    h->chunks = t3rows > 0 ? (t3rows + rpc - 1) / rpc : 1;
     h->uploaded = true;
     h->ran = false;
     return ORCVIO_OK;
@@ -350,7 +395,7 @@ static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
     FeatArgs a;
     a.poses = h->d_poses; a.p_w = h->d_pw; a.obs_ptr = h->d_obs_ptr; a.obs_clone = h->d_obs_clone;
     a.obs_z = h->d_obs_z; a.obs_zvel = h->d_obs_zvel; a.P = h->d_P; a.row_ptr = h->d_row_ptr; a.chi2 = h->d_chi2;
-    a.Hs = h->d_Hs; a.gamma = h->d_gamma; a.accept = h->d_accept;
+    a.Hs = h->materialize ? h->d_Hs : nullptr; a.T3 = h->d_T3; a.Xobs = h->d_Xobs; a.obs_pos = h->d_clone_obs; a.gamma = h->d_gamma; a.accept = h->d_accept;
     a.sigma2 = h->flags.noise_feature * h->flags.noise_feature;
     a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP; a.Mmax = h->Mmax; a.F = h->F;
     a.use_larvio = h->flags.use_larvio; a.use_left = h->flags.use_left_perturbation; a.if_fej = h->flags.if_fej;
@@ -372,14 +417,27 @@ static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
     return ORCVIO_OK;
 }
 
+// compression: A = X^T X - T3^T T3  (sparse rows summed per clone, dense rows by MFMA Gram)
 static int launch_gram(orcvio_msckf_handle* h, hipStream_t s) {
     const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
-    if (h->m_tot == 0) {
+    if (h->F == 0) {
         HIPCHK(hipMemsetAsync(h->d_Gpart, 0, sizeof(double) * (size_t)h->NAP * h->NAP, s));
         return ORCVIO_OK;
     }
+    // sparse rows: one 16x16 tile per row chunk (wave 0 of each workgroup), chunks never span two clones
+    if (h->s_chunks > 0)
+        hipLaunchKernelGGL(k_gram, dim3(1, h->s_chunks), dim3(64), 0, s, h->d_Xobs, 2 * h->nobs, 16, 0, h->d_S,
+                           (const int*)(h->d_clone_ptr + h->N + 1));
     dim3 grid((ntiles + 3) / 4, h->chunks), block(256);
-    hipLaunchKernelGGL(k_gram, grid, block, 0, s, h->d_Hs, h->m_tot, h->NAP, h->rows_per_chunk, h->d_Gpart);
+    hipLaunchKernelGGL(k_gram, grid, block, 0, s, h->d_T3, 3 * h->F, h->NAP, h->rows_per_chunk, h->d_Gpart, (const int*)nullptr);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+static int launch_assemble(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
+    const int total = h->NAP * h->NAP;
+    hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->d_clone_ptr, h->F > 0 ? h->N : 0,
+                       h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->chunks, (size_t)total, dst);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -397,7 +455,8 @@ static int launch_potrf(orcvio_msckf_handle* h, hipStream_t s, const double* X, 
                         double* Dinv, int* info) {
     const int NP = h->NP;
     if (h->reg_path) {
-        const int nb = (nn + 15) / 16, ntiles = nb * (nb + 1) / 2, need = (ntiles + 7) / 8;
+        const int nb = (nn + 15) / 16, noff = nb * (nb - 1) / 2;
+        const int need = (noff + 6) / 7;   // wave 0 keeps the diagonal tiles in LDS, waves 1..7 the rest in registers
         if (need <= 4) hipLaunchKernelGGL(k_potrf_reg<4>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
         else if (need <= 8) hipLaunchKernelGGL(k_potrf_reg<8>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
         else if (need <= 12) hipLaunchKernelGGL(k_potrf_reg<12>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
@@ -482,10 +541,9 @@ static int launch_prior_fork(orcvio_msckf_handle* h, hipStream_t s) {
     return ORCVIO_OK;
 }
 
-static int launch_finish_from(orcvio_msckf_handle* h, hipStream_t s, const double* parts, int nparts) {
-    int rc = launch_reduce(h, s, parts, nparts, h->d_A);
-    if (rc != ORCVIO_OK) return rc;
-    HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));   // join
+static int launch_solve_tail(orcvio_msckf_handle* h, hipStream_t s) {
+    HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));   // join the Cholesky of the prior
+    int rc = ORCVIO_OK;
     for (int st = ST_FORM_U; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
     return rc;
 }
@@ -499,7 +557,18 @@ int32_t orcvio_msckf_run_local(orcvio_msckf_handle* h, void* stream) {
     int rc = launch_prior_fork(h, s);
     if (rc == ORCVIO_OK) rc = launch_feature(h, s);
     if (rc == ORCVIO_OK) rc = launch_gram(h, s);
-    if (rc == ORCVIO_OK) rc = launch_reduce(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1, h->d_Ab);
+    if (rc == ORCVIO_OK) rc = launch_assemble(h, s, h->d_Ab);
+    return rc;
+}
+
+int32_t orcvio_msckf_run_local_to(orcvio_msckf_handle* h, double* d_dst, void* stream) {
+    if (!h || !h->uploaded || !d_dst) { g_last_error = "run_local_to: invalid"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    int rc = launch_prior_fork(h, s);
+    if (rc == ORCVIO_OK) rc = launch_feature(h, s);
+    if (rc == ORCVIO_OK) rc = launch_gram(h, s);
+    if (rc == ORCVIO_OK) rc = launch_assemble(h, s, d_dst);
     return rc;
 }
 
@@ -513,7 +582,9 @@ int32_t orcvio_msckf_block_ptr(orcvio_msckf_handle* h, double** d_block, int64_t
 int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks, void* stream) {
     if (!h || !h->uploaded || !d_blocks || n_blocks < 1) { g_last_error = "run_finish: invalid"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    int rc = launch_finish_from(h, pick_stream(h, stream), d_blocks, n_blocks);
+    hipStream_t s = pick_stream(h, stream);
+    int rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);   // rank-ordered sum of the gathered blocks
+    if (rc == ORCVIO_OK) rc = launch_solve_tail(h, s);
     if (rc == ORCVIO_OK) h->ran = true;
     return rc;
 }
@@ -525,7 +596,8 @@ int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     int rc = launch_prior_fork(h, s);
     if (rc == ORCVIO_OK) rc = launch_feature(h, s);
     if (rc == ORCVIO_OK) rc = launch_gram(h, s);
-    if (rc == ORCVIO_OK) rc = launch_finish_from(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1);
+    if (rc == ORCVIO_OK) rc = launch_assemble(h, s, h->d_A);
+    if (rc == ORCVIO_OK) rc = launch_solve_tail(h, s);
     if (rc == ORCVIO_OK) h->ran = true;
     return rc;
 }
@@ -550,8 +622,9 @@ static int compute_optional(orcvio_msckf_handle* h, bool want_thin_or_K, bool wa
     const double* La_P = h->d_RP + 15 * sLi;
     if (want_thin_or_K) {   // lower Cholesky factor of the Gram block with the LDS-panel kernel
         HIPCHK(hipMemcpyAsync(h->d_La, h->d_A, sizeof(double) * (size_t)NAP * NAP, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, h->d_La, NA + 1, NAP, (double)(NA + 1) * 2.220446049250313e-16,
-                           h->d_DinvA, h->d_info + 4);
+        // the Gram block is singular in every update (gauge freedom): factor A + 1e-11 max(diag) I, which needs no
+        // rank decision and changes H_thin^T H_thin by 1e-11 relative
+        hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, h->d_La, NA + 1, NAP, 0.0, h->d_DinvA, h->d_info + 4, 1e-11);
         HIPCHK(hipGetLastError());
     }
     if (want_G) {   // W = L_M^-1 U[0:NA]^T (n x NA);  G[:, 15:] = Zn^T W
@@ -754,7 +827,7 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     }
     // F_o = Hf^T Hf (lower tiles of the bottom-right block) -> R_F ; Y_o = L_F^-1 C_o
     {
-        const int nbf = NOP / 16, need = (nbf * (nbf + 1) / 2 + 7) / 8;
+        const int nbf = NOP / 16, need = (nbf * (nbf - 1) / 2 + 6) / 7;
         const double* F0 = h->d_Gobj + (size_t)NAP * W + NAP;
         const double tolF = (double)no_max * 2.220446049250313e-16;
         if (need <= 4)
@@ -832,7 +905,7 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
 int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_t reps, const char** names, double* ms,
                                     int32_t* count) {
     if (!h || !h->uploaded || !names || !ms || !count || reps < 1) { g_last_error = "profile_update: invalid"; return ORCVIO_ERR_INVALID; }
-    static const char* kn[] = {"k_feature", "k_gram", "k_gram_reduce", "k_potrf(P)", "k_gemm(U)", "k_gemm(M)", "k_potrf(M)", "k_trsm", "k_finish"};
+    static const char* kn[] = {"k_feature", "k_gram", "k_assemble", "k_potrf(P)", "k_gemm(U)", "k_gemm(M)", "k_potrf(M)", "k_trsm", "k_finish"};
     const int nk = 9;
     if (*count < nk) { g_last_error = "profile_update: need room for 9 entries"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
@@ -847,7 +920,7 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
             int rc = ORCVIO_OK;
             if (k == 0) rc = launch_feature(h, s);
             else if (k == 1) rc = launch_gram(h, s);
-            else if (k == 2) rc = launch_reduce(h, s, h->d_Gpart, h->m_tot > 0 ? h->chunks : 1, h->d_A);
+            else if (k == 2) rc = launch_assemble(h, s, h->d_A);
             else rc = launch_solve_stage(h, s, k - 3);
             if (rc != ORCVIO_OK) return rc;
             HIPCHK(hipEventRecord(e1, s));
@@ -960,7 +1033,9 @@ int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst
     const void* src = nullptr;
     size_t bytes = 0;
     switch (which) {
-        case 0: src = h->d_Hs; bytes = (size_t)h->m_tot * h->NAP * sizeof(double); break;
+        case 0:
+            if (!h->materialize) { g_last_error = "debug_read: stack not materialised (ORCVIO_OPT_MATERIALIZE_STACK)"; return ORCVIO_ERR_INVALID; }
+            src = h->d_Hs; bytes = (size_t)h->m_tot * h->NAP * sizeof(double); break;
         case 1: src = h->d_Ab; bytes = pp; break;
         case 2: src = h->d_A; bytes = pp; break;
         case 3: src = h->d_RP; bytes = np2; break;
@@ -1042,22 +1117,29 @@ int32_t orcvio_msckf_debug_trsm(orcvio_msckf_handle* h, const double* X, int32_t
     return rc;
 }
 
-// Diagnostic: in-kernel cycle stamps of k_potrf_reg<12> on the handle's current P (phase boundaries
-// per block step and wave).  stamps_out: [nb][4][8] uint64.
-int32_t orcvio_msckf_debug_potrf_stamps(orcvio_msckf_handle* h, unsigned long long* stamps_out, int32_t nb_cap) {
-    if (!h || !h->uploaded || !h->reg_path) return ORCVIO_ERR_INVALID;
+// Diagnostic: time k_potrf_reg on the handle's current P with parts of the algorithm switched off
+// (results are garbage for ablate != 0).  Returns the average kernel time in microseconds.
+int32_t orcvio_msckf_debug_potrf_ablate(orcvio_msckf_handle* h, int32_t ablate, int32_t reps, double* us_out) {
+    if (!h || !h->uploaded || !h->reg_path || !us_out) return ORCVIO_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
-    const int n = h->n, NP = h->NP, nb = NP / 16;
-    if (nb > nb_cap) return ORCVIO_ERR_INVALID;
-    unsigned long long* d_st = nullptr;
-    HIPCHK(hipMalloc(&d_st, sizeof(unsigned long long) * nb * 64));
-    HIPCHK(hipMemset(d_st, 0, sizeof(unsigned long long) * nb * 64));
+    const int n = h->n, NP = h->NP;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep)
-        hipLaunchKernelGGL(k_potrf_reg<14>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
-                           h->d_info + 6, d_st);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(stamps_out, d_st, sizeof(unsigned long long) * nb * 64, hipMemcpyDeviceToHost));
-    (void)hipFree(d_st);
+        hipLaunchKernelGGL(k_potrf_reg<12>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
+                           h->d_info + 6, (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, ablate);
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int rep = 0; rep < reps; ++rep)
+        hipLaunchKernelGGL(k_potrf_reg<12>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
+                           h->d_info + 6, (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, ablate);
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *us_out = 1e3 * ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return ORCVIO_OK;
 }
 

@@ -136,7 +136,10 @@ struct FeatArgs {
     const double* P;
     const int* row_ptr;   // [F+1] row offsets into Hs (rho_j = 2M_j-3, 0 if M_j < 2)
     const double* chi2;   // [ORCVIO_CHI2_TABLE]
-    double* Hs;
+    double* Hs;           // optional: stacked projected blocks (nullptr = not materialised)
+    double* T3;           // [3F][NAP]  first three rows of Q^T [J | r] of every track (zero if rejected)
+    double* Xobs;         // [2 nobs][16] un-projected rows [H_e(6) td H_x(6) r 0 0], grouped by clone (zero if rejected)
+    const int* obs_pos;   // [nobs] position of every observation in the clone-sorted order
     double* gamma;
     int* accept;
     double sigma2;
@@ -162,6 +165,8 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
     const int M = p.obs_ptr[j + 1] - lo;
     if (M < 2) {
         if (t == 0) { p.gamma[j] = NAN; p.accept[j] = 0; }
+        for (int e = t; e < 3 * p.NAP; e += 64) p.T3[(size_t)3 * j * p.NAP + e] = 0.0;
+        for (int e = t; e < 32 * M; e += 64) p.Xobs[(size_t)32 * p.obs_pos[lo + (e >> 5)] + (e & 31)] = 0.0;
         return;
     }
     const int M2 = 2 * M;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
     for (int ps = 0; ps < NPASS; ++ps) {
         const int a = t + 64 * ps;
 #pragma unroll
-        for (int e = 0; e < 7; ++e) pe[ps][e] = (a < NA) ? p.P[(size_t)(15 + e) * n + 15 + a] : 0.0;
+        for (int e = 0; e < 7; ++e) pe[ps][e] = p.P[(size_t)(15 + e) * n + 15 + (a < NA ? a : NA - 1)];
     }
     // P rows of the clone of observation l are prefetched one iteration ahead (18 coalesced loads in
     // flight while the previous observation is being consumed)
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
         for (int ps = 0; ps < NPASS; ++ps) {
             const int a = t + 64 * ps;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) pcur[ps][c] = (a < NA) ? Prow[(size_t)c * n + a] : 0.0;
+            for (int c = 0; c < 6; ++c) pcur[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
         }
     }
     for (int l = 0; l < M; ++l) {
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int a = t + 64 * ps;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) pnxt[ps][c] = (a < NA) ? Prow[(size_t)c * n + a] : 0.0;
+                for (int c = 0; c < 6; ++c) pnxt[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
             }
         }
         double jl0e[7], jl1e[7], jl0x[6], jl1x[6];
@@ -446,8 +451,11 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
         p.accept[j] = ok ? 1 : 0;
     }
 
-    // ---- I: coalesced write of the projected block rows 3..2M-1 -------------------------
-    const size_t row0 = (size_t)p.row_ptr[j];
+    // ---- I: outputs -------------------------------------------------------------------------
+    // The compression needs only  H'^T H' = X^T X - T3^T T3  (X = [J | r] un-projected, T3 = rows 0..2 of
+    // Q^T X: Q is orthogonal), so the 2M-3 dense projected rows are NOT needed downstream: the track
+    // hands over its 2M sparse rows (14 non-zeros each) and the three dense rows T3.  The projected block
+    // itself is materialised only on request (p.Hs != nullptr; tests and callers that want H').
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         const int a = t + 64 * ps;
@@ -458,20 +466,92 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
                 cc = (a - cb0) - 6 * cl;
                 kobs = sC2O[cl];
             }
-            for (int i = 3; i < M2; ++i) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
                 double val = 0.0;
-                if (ok) {
+                if (ok && a <= NA) {
                     double jv = 0.0;
                     if (a < 7) jv = sJe[i * 7 + a];
                     else if (a == NA) jv = sR[i];
                     else if (kobs == (i >> 1)) jv = sJx[i * 6 + cc];
                     val = jv - (sV[i * 4 + 0] * yq[ps][0] + sV[i * 4 + 1] * yq[ps][1] + sV[i * 4 + 2] * yq[ps][2]);
-                    if (a > NA) val = 0.0;
                 }
-                p.Hs[(row0 + i - 3) * NAP + a] = val;
+                p.T3[((size_t)3 * j + i) * NAP + a] = val;
+            }
+            if (p.Hs) {
+                const size_t row0 = (size_t)p.row_ptr[j];
+                for (int i = 3; i < M2; ++i) {
+                    double val = 0.0;
+                    if (ok && a <= NA) {
+                        double jv = 0.0;
+                        if (a < 7) jv = sJe[i * 7 + a];
+                        else if (a == NA) jv = sR[i];
+                        else if (kobs == (i >> 1)) jv = sJx[i * 6 + cc];
+                        val = jv - (sV[i * 4 + 0] * yq[ps][0] + sV[i * 4 + 1] * yq[ps][1] + sV[i * 4 + 2] * yq[ps][2]);
+                    }
+                    p.Hs[(row0 + i - 3) * NAP + a] = val;
+                }
             }
         }
     }
+    // un-projected rows of this track: [H_e(6) td | H_x(6) | r | 0 0], 16 doubles per row, stored at the
+    // observation's position in the clone-sorted order (so that k_gram reads every clone contiguously)
+    for (int e = t; e < 16 * M2; e += 64) {
+        const int row = e >> 4, c = e & 15;
+        double v = 0.0;
+        if (ok && c < 14) v = (c < 7) ? sJe[row * 7 + c] : ((c < 13) ? sJx[row * 6 + (c - 7)] : sR[row]);
+        p.Xobs[(size_t)32 * p.obs_pos[lo + (row >> 1)] + 16 * (row & 1) + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Sparse part of the compression.  Every row of X = [J | r] touches exactly one clone, so X^T X is
+// "arrow + block diagonal": (ext|r) x (ext|r), (ext|r) x clone_i, clone_i x clone_i.  The rows are stored
+// grouped by clone, 16 doubles each, so S_i = X_i^T X_i is ONE 16x16 MFMA tile per chunk of rows: k_gram
+// with NAP = 16 and ragged chunks (chunk_ptr) computes it.
+//
+// k_assemble_A:  A (NAP x NAP, full symmetric) = scatter(sum of S chunks) - sum_c Gpart[c], with Gpart the
+// partial Grams of T3 (lower tiles valid).  Column map of a sparse-row entry e: 0..6 -> a = e (ext, td),
+// 7..12 -> clone block, 13 -> a = NA (right-hand side).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ Sp, const int* __restrict__ chunk_of_clone, int N,
+                                                    int cb0, int NA, int NAP, const double* __restrict__ parts, int nparts,
+                                                    size_t part_stride, double* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NAP * NAP) return;
+    const int i = idx / NAP, j = idx - i * NAP;
+    int ei = -1, ci = -1, ej = -1, cj = -1;
+    if (i < 7) ei = i; else if (i == NA) ei = 13; else if (i >= cb0 && i < NA) { ci = (i - cb0) / 6; ei = 7 + (i - cb0) - 6 * ci; }
+    if (j < 7) ej = j; else if (j == NA) ej = 13; else if (j >= cb0 && j < NA) { cj = (j - cb0) / 6; ej = 7 + (j - cb0) - 6 * cj; }
+    double s = 0.0;
+    if (ei >= 0 && ej >= 0) {
+        // the 16x16 tiles hold both triangles (diagonal tile of k_gram): read [max][min]
+        const int e = (ei >= ej) ? ei * 16 + ej : ej * 16 + ei;
+        int c0 = 0, c1 = 0;
+        if (ci < 0 && cj < 0) { c0 = 0; c1 = chunk_of_clone[N]; }
+        else if (ci >= 0 && cj >= 0) { if (ci == cj) { c0 = chunk_of_clone[ci]; c1 = chunk_of_clone[ci + 1]; } }
+        else { const int c = ci >= 0 ? ci : cj; c0 = chunk_of_clone[c]; c1 = chunk_of_clone[c + 1]; }
+        // fixed summation order (deterministic); eight loads in flight: the shared (ext|r) entries sum every chunk
+        double sa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sa[u] += Sp[(size_t)(c + u) * 256 + e];
+        }
+        for (; c < c1; ++c) sa[0] += Sp[(size_t)c * 256 + e];
+        s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
+    }
+    const int src = ((i >> 4) >= (j >> 4)) ? idx : j * NAP + i;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    int c = 0;
+    for (; c + 4 <= nparts; c += 4) {
+        g0 += parts[(size_t)c * part_stride + src];
+        g1 += parts[(size_t)(c + 1) * part_stride + src];
+        g2 += parts[(size_t)(c + 2) * part_stride + src];
+        g3 += parts[(size_t)(c + 3) * part_stride + src];
+    }
+    for (; c < nparts; ++c) g0 += parts[(size_t)c * part_stride + src];
+    dst[idx] = s - ((g0 + g1) + (g2 + g3));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -502,26 +582,27 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int 
     if (chunk_ptr) { r0 = chunk_ptr[chunk]; r1 = chunk_ptr[chunk + 1]; }   // ragged chunks (one per object block)
     if (r1 > m) r1 = m;
     const int kk = l >> 4, cc = l & 15;
-    const double* pa = X + (size_t)(r0 + kk) * NAP + 16 * bi + cc;
-    const double* pb = X + (size_t)(r0 + kk) * NAP + 16 * bj + cc;
+    const double* pa = X + 16 * bi + cc;
+    const double* pb = X + 16 * bj + cc;
     d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     constexpr int GB = 16;   // k-steps (of 4 rows) whose operands are in flight together
     for (int k = r0; k < r1; k += 4 * GB) {
         double a[GB], b[GB];
 #pragma unroll
-        for (int q = 0; q < GB; ++q) {
-            const bool in = (k + 4 * q + kk) < r1;
-            a[q] = in ? pa[(size_t)(4 * q) * NAP] : 0.0;
-            b[q] = in ? pb[(size_t)(4 * q) * NAP] : 0.0;
+        for (int q = 0; q < GB; ++q) {   // clamped address + select (no branch, no vmcnt(0) per load)
+            const int rq = k + 4 * q + kk;
+            const int rc = rq < r1 ? rq : r1 - 1;
+            const double av = pa[(size_t)rc * NAP], bv = pb[(size_t)rc * NAP];
+            a[q] = rq < r1 ? av : 0.0;
+            b[q] = rq < r1 ? bv : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < GB; q += 2) {
             acc0 = mfma_f64(a[q], b[q], acc0);
             acc1 = mfma_f64(a[q + 1], b[q + 1], acc1);
         }
-        pa += (size_t)(4 * GB) * NAP;
-        pb += (size_t)(4 * GB) * NAP;
     }
+    if (r1 <= r0) { acc0 = d4{0, 0, 0, 0}; acc1 = d4{0, 0, 0, 0}; }
     double* out = Gpart + (size_t)chunk * NAP * NAP;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -560,7 +641,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
 // ---------------------------------------------------------------------------------------
 #define POTRF_MAXN 416
 __global__ __launch_bounds__(1024) void k_potrf(double* __restrict__ A, int n, int ld, double tol_rel,
-                                                double* __restrict__ Dinv, int* __restrict__ nzero) {
+                                                double* __restrict__ Dinv, int* __restrict__ nzero, double shift_rel = 0.0) {
     __shared__ double sD[16][17];
     __shared__ double sDi[16][17];
     __shared__ double sdinv[16];
@@ -580,6 +661,7 @@ __global__ __launch_bounds__(1024) void k_potrf(double* __restrict__ A, int n, i
     mx = 0.0;
     for (int w = 0; w < 16; ++w) mx = fmax(mx, sred[w]);
     const double tol = tol_rel * mx;
+    const double shift = shift_rel * mx;   // optional Tikhonov shift of the diagonal (factor of A + shift I)
 
     for (int kb = 0; kb < nblk; ++kb) {
         const int k0 = kb * 16;
@@ -588,7 +670,7 @@ __global__ __launch_bounds__(1024) void k_potrf(double* __restrict__ A, int n, i
         if (tid < 256) {
             const int r = tid >> 4, c = tid & 15;
             double v = 0.0;
-            if (r < kw && c < kw && c <= r) v = A[(size_t)(k0 + r) * ld + k0 + c];
+            if (r < kw && c < kw && c <= r) v = A[(size_t)(k0 + r) * ld + k0 + c] + ((r == c) ? shift : 0.0);
             sD[r][c] = v;
         }
         __syncthreads();
@@ -698,26 +780,50 @@ __device__ __forceinline__ d4 tile_product(const double* __restrict__ A, long sA
     // Operands of TP_BATCH k-steps are loaded before the first MFMA of the batch: the kernels built on
     // this are latency-bound (one tile per wavefront), so loads must be in flight together.
     constexpr int TP_BATCH = 12;
+    // Out-of-range rows / columns are loaded from a clamped (valid) address and zeroed by a select (a
+    // predicated load is a branch and serialises the loads); full batches advance plain pointers, only the
+    // K tail pays for index clamping.
     const int kk = l >> 4, cc = l & 15;
     const bool ia = (i0 + cc) < M, jb = (j0 + cc) < N;
-    const double* pa = A + (long)(i0 + cc) * sAi + (long)kk * sAk;
-    const double* pb = B + (long)kk * sBk + (long)(j0 + cc) * sBj;
+    const double* pa = A + (long)(ia ? i0 + cc : M - 1) * sAi + (long)kk * sAk;
+    const double* pb = B + (long)(jb ? j0 + cc : N - 1) * sBj + (long)kk * sBk;
+    const long stepA = 4 * sAk, stepB = 4 * sBk;
     d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int k = 0; k < K; k += 4 * TP_BATCH) {
+    int k = 0;
+    for (; k + 4 * TP_BATCH <= K; k += 4 * TP_BATCH) {
         double a[TP_BATCH], b[TP_BATCH];
 #pragma unroll
         for (int q = 0; q < TP_BATCH; ++q) {
-            const bool kin = (k + 4 * q + kk) < K;
-            a[q] = (ia && kin) ? pa[(long)(4 * q) * sAk] : 0.0;
-            b[q] = (jb && kin) ? pb[(long)(4 * q) * sBk] : 0.0;
+            const double av = pa[q * stepA], bv = pb[q * stepB];
+            a[q] = ia ? av : 0.0;
+            b[q] = jb ? bv : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < TP_BATCH; q += 2) {
             acc0 = mfma_f64(a[q], b[q], acc0);
             acc1 = mfma_f64(a[q + 1], b[q + 1], acc1);
         }
-        pa += (long)(4 * TP_BATCH) * sAk;
-        pb += (long)(4 * TP_BATCH) * sBk;
+        pa += TP_BATCH * stepA;
+        pb += TP_BATCH * stepB;
+    }
+    if (k < K) {   // tail batch
+        double a[TP_BATCH], b[TP_BATCH];
+        const int klast = K - 1 - k - kk;   // last valid k-offset of this lane (may be negative)
+#pragma unroll
+        for (int q = 0; q < TP_BATCH; ++q) {
+            const bool kin = 4 * q <= klast;
+            const int qc = kin ? q : 0;
+            const bool any = klast >= 0;
+            const double av = pa[(any ? qc : 0) * stepA - (any ? 0 : (long)kk * sAk)];
+            const double bv = pb[(any ? qc : 0) * stepB - (any ? 0 : (long)kk * sBk)];
+            a[q] = (ia && kin) ? av : 0.0;
+            b[q] = (jb && kin) ? bv : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < TP_BATCH; q += 2) {
+            acc0 = mfma_f64(a[q], b[q], acc0);
+            acc1 = mfma_f64(a[q + 1], b[q + 1], acc1);
+        }
     }
     d4 acc;
 #pragma unroll
@@ -871,26 +977,33 @@ __global__ __launch_bounds__(64) void k_trsm(const double* __restrict__ L, int l
 //   R  : output upper factor, row-major ldr (lower parts of diagonal tiles written as 0)
 //   Dinv[nb][16][16] : inv(L11) of every diagonal block (generalised inverse on zero pivots)
 //   info[0] += pivots <= tol (dropped), info[1] += pivots < -tol (matrix not PSD)
+// LDS-only workgroup barrier: orders LDS traffic (lgkmcnt) but does not wait for global stores in flight
+// (a __syncthreads() would also drain vmcnt, i.e. stall ~1 us per step on the stores of finished tiles).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NSLOT>
 __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X, int ldx, int n, double tol_rel,
                                                    double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                    int* __restrict__ info, unsigned long long* __restrict__ stamps = nullptr,
                                                    size_t strideX = 0, size_t strideR = 0, size_t strideD = 0,
-                                                   int from_lower = 0) {
+                                                   int from_lower = 0, int ablate = 0) {
+    // ablate (diagnostic only, scripts/gpu_ablate.py): 1 skip the diagonal sweep, 2 skip trailing MFMAs, 4 skip panel
+    // MFMAs, 8 skip the later-diagonal updates.  Results are garbage when non-zero.
     // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
     // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
     X += (size_t)blockIdx.x * strideX;
     R += (size_t)blockIdx.x * strideR;
     Dinv += (size_t)blockIdx.x * strideD;
-    __shared__ __attribute__((aligned(16))) double sD[16][16];
-    __shared__ __attribute__((aligned(16))) double sDi[16][16];
-    __shared__ __attribute__((aligned(16))) double sPan[14][4][64];   // published panel tiles, accumulator layout
-    __shared__ __attribute__((aligned(16))) double sDall[14 * 256];   // inv(L11) of every block step
+    __shared__ __attribute__((aligned(16))) double sD[16][16];       // diagonal tile being factored (row view)
+    __shared__ __attribute__((aligned(16))) double sDi[16][16];      // inv(L11) of the current block step
+    __shared__ __attribute__((aligned(16))) double sPan[14][4][64];  // published panel tiles, accumulator layout
+    __shared__ __attribute__((aligned(16))) double sDg[14][4][64];   // the diagonal tiles (owned by wave 0)
     __shared__ double sred[8];
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nb = (n + 15) >> 4;
-    const int ntiles = nb * (nb + 1) / 2;
 
     // largest diagonal entry -> pivot tolerance
     double mx = 0.0;
@@ -904,150 +1017,188 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
     for (int w = 0; w < 8; ++w) mx = fmax(mx, sred[w]);
     const double tol = tol_rel * mx;
 
-    // tile ownership (wave-uniform -> scalar registers) and load
-    d4 acc[NSLOT];
-    int ta[NSLOT], tb[NSLOT];   // tile (a <= b): rows 16a.., cols 16b..
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        const int tl = s * 8 + wave;
-        int bi = 0, bj = 0;
-        if (tl < ntiles) tile_from_linear(tl, bi, bj);
-        ta[s] = __builtin_amdgcn_readfirstlane((tl < ntiles) ? bj : -1);
-        tb[s] = __builtin_amdgcn_readfirstlane((tl < ntiles) ? bi : -1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 16 * bj + kk + 4 * r, j = 16 * bi + cc;
-            acc[s][r] = (tl < ntiles && i < n && j < n) ? (from_lower ? X[(size_t)j * ldx + i] : X[(size_t)i * ldx + j]) : 0.0;
-            // the mirrored (strictly lower) tile of the output is never touched again: zero it
-            if (tl < ntiles && bi != bj) {
-                const int i2 = 16 * bi + kk + 4 * r, j2 = 16 * bj + cc;
-                if (i2 < n && j2 < n) R[(size_t)i2 * ldr + j2] = 0.0;
-            }
-        }
-    }
-    int nzero = 0, nneg = 0;
-
-    // Factor + invert one 16x16 diagonal tile held in the accumulator layout; returns R11 = L11^T
-    // in the same layout and publishes inv(L11) in sDi / sDall[kb].  One right-looking sweep
-    // (DiagStep): every rank-1 update is ONE v_fmac_f64_dpp (row broadcast fused into the FMA).
-    auto factor_diag = [&](d4 t, int kb) -> d4 {
-        int z = 0;
-        asm volatile("" : "+v"(z));   // opaque zero: keeps LDS address arithmetic out of loop-invariant hoisting
-        double* pD = &sD[0][0] + z;
-        double* pDi = &sDi[0][0] + z;
-        double* pDall = &sDall[0] + z;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pD[(kk + 4 * r) * 16 + cc] = t[r];
-        wave_sync();
-        double v[16], y[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const double a = pD[cc * 16 + c];
-            v[c] = (c <= cc) ? a : 0.0;
-            y[c] = (c == cc) ? 1.0 : 0.0;
-        }
-        DiagStep<0>::run(v, y, tol, n - 16 * kb, nzero, nneg);
-        wave_sync();
-        if (l < 16) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                pD[l * 16 + c] = (c <= l) ? v[c] : 0.0;   // L11 row l
-                pDi[c * 16 + l] = y[c];                    // Linv[c][l]
-                pDall[kb * 256 + c * 16 + l] = y[c];
-            }
-        }
-        wave_sync();
-        d4 rt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rt[r] = pD[cc * 16 + kk + 4 * r];   // R11[kk+4r][cc] = L11[cc][kk+4r]
-        return rt;
-    };
-
-    // prologue: diagonal tile 0
-    if (wave == 0) {   // tile index 0 -> wave 0, slot 0
-        acc[0] = factor_diag(acc[0], 0);
-    }
-    for (int kb = 0; kb < nb; ++kb) {
-        int z = 0;
-        asm volatile("" : "+v"(z));
-        double* pDi = &sDi[0][0] + z;
-        double* pPan = &sPan[0][0][0] + z;
-        if (stamps && l == 0) stamps[(kb * 8 + 0) * 8 + wave] = __builtin_amdgcn_s_memtime();
-        __syncthreads();   // A: inv(L11) of step kb visible; every trailing update of step kb-1 done
-        if (stamps && l == 0) stamps[(kb * 8 + 1) * 8 + wave] = __builtin_amdgcn_s_memtime();
-        // ---- panel tiles (a == kb < b): tile <- inv(L11) * tile ------------------------------
-        double li[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) li[s4] = pDi[cc * 16 + kk + 4 * s4];   // A operand: Linv[m = cc][k = kk + 4 s4]
-        if (stamps) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(li[0]), "v"(li[1]), "v"(li[2]), "v"(li[3]));
-            if (l == 0) stamps[(kb * 8 + 4) * 8 + wave] = __builtin_amdgcn_s_memtime();
-        }
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (stamps && l == 0 && s == NSLOT / 2) stamps[(kb * 8 + 5) * 8 + wave] = __builtin_amdgcn_s_memtime();
-            if (ta[s] == kb && tb[s] > kb) {
-                d4 x = {0, 0, 0, 0};
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], acc[s][s4], x);
-                acc[s] = x;
-                double* dst = pPan + tb[s] * 256 + l;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r * 64] = x[r];
-            }
-        }
-        if (stamps && l == 0) stamps[(kb * 8 + 2) * 8 + wave] = __builtin_amdgcn_s_memtime();
-        __syncthreads();   // B: panel published
-        if (stamps && l == 0) stamps[(kb * 8 + 3) * 8 + wave] = __builtin_amdgcn_s_memtime();
-        // ---- look-ahead: the owner of the next diagonal tile updates and factors it first -----
-        const int kn = kb + 1;
-        const int tln = kn * (kn + 1) / 2 + kn;
-        const bool next_owner = (kn < nb) && ((tln & 7) == wave);
-        if (next_owner) {
-            const double* q = pPan + kn * 256 + l;
-            d4 t = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s)
-                if (s == (tln >> 3)) t = acc[s];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-q[s4 * 64], q[s4 * 64], t);
-            if (stamps && l == 0) stamps[(kb * 8 + 6) * 8 + wave] = __builtin_amdgcn_s_memtime();
-            t = factor_diag(t, kn);
-            if (stamps && l == 0) stamps[(kb * 8 + 7) * 8 + wave] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s)
-                if (s == (tln >> 3)) acc[s] = t;
-        }
-        // ---- trailing tiles (a > kb): tile -= panel_a^T panel_b ------------------------------
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (ta[s] > kb && !(ta[s] == kn && tb[s] == kn)) {
-                const double* qa = pPan + ta[s] * 256 + l;
-                const double* qb = pPan + tb[s] * 256 + l;
-                d4 x = acc[s];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(-qa[s4 * 64], qb[s4 * 64], x);
-                acc[s] = x;
-            }
-        }
-    }
-    __syncthreads();
-    // all tiles are final: one pass of global stores (none inside the barrier loop)
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        if (ta[s] >= 0) {
+    if (wave == 0) {
+        // =====================================================================================
+        // Role 1 -- the critical chain.  Wave 0 owns every diagonal tile (kept in LDS: dynamic index, no
+        // register array) and does nothing but: update the next diagonal tile, factor + invert it in one
+        // DPP sweep, publish inv(L11), then bring the later diagonal tiles up to date.
+        // =====================================================================================
+        int nzero = 0, nneg = 0;
+        for (int k = 0; k < nb; ++k) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ta[s] + kk + 4 * r, j = 16 * tb[s] + cc;
-                if (i < n && j < n) R[(size_t)i * ldr + j] = acc[s][r];
+                const int i = 16 * k + kk + 4 * r, j = 16 * k + cc;
+                const bool in = i < n && j < n;
+                const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
+                sDg[k][r][l] = in ? xv : 0.0;
+            }
+        }
+        auto factor_diag = [&](int kb) {
+            int z = 0;
+            asm volatile("" : "+v"(z));   // opaque zero: keeps LDS address arithmetic out of loop-invariant hoisting
+            double* pD = &sD[0][0] + z;
+            double* pDi = &sDi[0][0] + z;
+            double* pG = &sDg[0][0][0] + z + kb * 256 + l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pD[(kk + 4 * r) * 16 + cc] = pG[r * 64];
+            wave_sync();
+            double v[16], y[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double a = pD[cc * 16 + c];
+                v[c] = (c <= cc) ? a : 0.0;
+                y[c] = (c == cc) ? 1.0 : 0.0;
+            }
+            if (!(ablate & 1)) DiagStep<0>::run(v, y, tol, n - 16 * kb, nzero, nneg);
+            if (l < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    pDi[c * 16 + l] = y[c];                               // Linv[c][l]
+                    Dinv[(size_t)kb * 256 + c * 16 + l] = y[c];           // straight to memory (barriers do not wait for it)
+                }
+            }
+            // R11[kk+4r][cc] = L11[cc][kk+4r] = v[kk+4r] of this very lane (every 16-lane row holds all rows)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double x0 = v[4 * r], x1 = v[4 * r + 1], x2 = v[4 * r + 2], x3 = v[4 * r + 3];
+                const double xs = (kk == 0) ? x0 : ((kk == 1) ? x1 : ((kk == 2) ? x2 : x3));
+                const double rv = (kk + 4 * r <= cc) ? xs : 0.0;
+                pG[r * 64] = rv;
+                const int i = 16 * kb + kk + 4 * r, j = 16 * kb + cc;
+                if (i < n && j < n) R[(size_t)i * ldr + j] = rv;
+            }
+        };
+        __builtin_amdgcn_s_setprio(3);   // win VALU arbitration against the co-resident wave of this SIMD
+        if (!(ablate & 64)) factor_diag(0);
+        for (int kb = 0; kb < nb; ++kb) {
+            lds_barrier();   // A: inv(L11) of step kb visible
+            lds_barrier();   // B: panel of step kb published
+            const int kn = kb + 1;
+            if (kn < nb && !(ablate & 16)) {
+                int z = 0;
+                asm volatile("" : "+v"(z));
+                const double* pPan = &sPan[0][0][0] + z + l;
+                double* pG = &sDg[0][0][0] + z + l;
+                {   // next diagonal tile: -= panel^T panel, then factor
+                    d4 t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = pG[kn * 256 + r * 64];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) { const double q = pPan[kn * 256 + s4 * 64]; t = mfma_f64(-q, q, t); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pG[kn * 256 + r * 64] = t[r];
+                }
+                factor_diag(kn);
+                // the later diagonal tiles (k > kn) are brought up to date by waves 1..7 (they live in LDS)
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (l == 0) {
+            if (nzero) atomicAdd(&info[0], nzero);
+            if (nneg) atomicAdd(&info[1], nneg);
+        }
+    } else {
+        // =====================================================================================
+        // Role 2 -- waves 1..7 hold the off-diagonal tiles in registers.  Tiles are enumerated row by row,
+        // t = T(a) + (b - a - 1) with T(a) = a nb - a(a+1)/2, and dealt round-robin (wave 1 + t % 7, slot
+        // t / 7): within a wave the slots ascend in a, so at step kb the panel tiles (a == kb) are the slot
+        // range [s_lo, s_hi) and the trailing tiles (a > kb) exactly the slots >= s_hi.
+        // =====================================================================================
+        d4 acc[NSLOT];
+        int tab[NSLOT];   // packed a | b << 8 (wave-uniform), -1 if the slot is empty
+        const int noff = nb * (nb - 1) / 2;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int a = -1, b = -1;
+            const int t = s * 7 + (wave - 1);
+            if (t < noff) {
+                int aa = 0, base = 0;
+                while (base + (nb - 1 - aa) <= t) { base += nb - 1 - aa; ++aa; }
+                a = aa;
+                b = aa + 1 + (t - base);
+            }
+            tab[s] = __builtin_amdgcn_readfirstlane(a < 0 ? -1 : (a | (b << 8)));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * a + kk + 4 * r, j = 16 * b + cc;
+                const bool in = a >= 0 && i < n && j < n;
+                const int ic = in ? i : 0, jc = in ? j : 0;   // clamped address + select: keeps the loads unpredicated
+                const double xv = from_lower ? X[(size_t)jc * ldx + ic] : X[(size_t)ic * ldx + jc];
+                acc[s][r] = in ? xv : 0.0;
+                if (a >= 0) {   // the mirrored (strictly lower) tile of the output is never touched again: zero it
+                    const int i2 = 16 * b + kk + 4 * r, j2 = 16 * a + cc;
+                    if (i2 < n && j2 < n) R[(size_t)i2 * ldr + j2] = 0.0;
+                }
+            }
+        }
+        auto slots_below = [&](int x) -> int {   // slots of this wave whose tile index is < x
+            const int v = x - (wave - 1);
+            return v <= 0 ? 0 : (v + 6) / 7;
+        };
+        for (int kb = 0; kb < nb; ++kb) {
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            double* pDi = &sDi[0][0] + z;
+            double* pPan = &sPan[0][0][0] + z;
+            lds_barrier();   // A
+            // ---- panel tiles (a == kb < b): tile <- inv(L11) * tile, published and stored ---------------
+            const int Tkb = kb * nb - kb * (kb + 1) / 2;
+            const int s_lo = slots_below(Tkb), s_hi = slots_below(Tkb + (nb - 1 - kb));
+            if (s_hi > s_lo && !(ablate & 32)) {
+                double li[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) li[s4] = pDi[cc * 16 + kk + 4 * s4];   // A operand: Linv[m = cc][k = kk + 4 s4]
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    if (s >= s_lo && s < s_hi) {
+                        d4 x = {0, 0, 0, 0};
+                        if (!(ablate & 4)) {
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], acc[s][s4], x);
+                        }
+                        acc[s] = x;
+                        const int b = tab[s] >> 8;
+                        double* dst = pPan + b * 256 + l;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            dst[r * 64] = x[r];
+                            const int i = 16 * kb + kk + 4 * r, j = 16 * b + cc;
+                            if (i < n && j < n) R[(size_t)i * ldr + j] = x[r];   // final: row block kb of R
+                        }
+                    }
+                }
+            }
+            lds_barrier();   // B
+            // ---- trailing tiles (a > kb): tile -= panel_a^T panel_b ---------------------------------------
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                if (s >= s_hi && tab[s] >= 0 && !(ablate & 2)) {
+                    const double* qa = pPan + (tab[s] & 255) * 256 + l;
+                    const double* qb = pPan + (tab[s] >> 8) * 256 + l;
+                    d4 x = acc[s];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(-qa[s4 * 64], qb[s4 * 64], x);
+                    acc[s] = x;
+                }
+            }
+            // later diagonal tiles k > kb+1 live in LDS and are off the critical chain: wave 1 + k % 7 updates them
+            if (!(ablate & 8)) {
+                for (int k = kb + 2; k < nb; ++k) {
+                    if ((k % 7) != wave - 1) continue;
+                    const double* q = pPan + k * 256 + l;
+                    double* g = &sDg[0][0][0] + z + k * 256 + l;
+                    d4 t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = g[r * 64];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) { const double qv = q[s4 * 64]; t = mfma_f64(-qv, qv, t); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[r * 64] = t[r];
+                }
             }
         }
     }
-    for (int e = tid; e < nb * 256; e += 512) Dinv[e] = sDall[e];
-    if (l == 0) {
-        if (nzero) atomicAdd(&info[0], nzero);
-        if (nneg) atomicAdd(&info[1], nneg);
-    }
+    (void)stamps;
 }
 
 // generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j]; tiles with

@@ -61,6 +61,7 @@ def check(win, name, upd, detail=False):
 
 def main():
     upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536)
+    upd.set_materialize_stack(True)
     ok = True
     cases = []
     for fl in [synth.Flags(use_larvio=1), synth.Flags(use_larvio=0, use_left_perturbation=0),
@@ -78,6 +79,7 @@ def main():
     t0 = time.time()
     line = check(w2, 'config2', upd, detail=True)
     print('config2 total check s', time.time() - t0)
+    upd.set_materialize_stack(False)
     upd.upload(w2)
     for _ in range(3):
         upd.run_update(); upd.sync()
