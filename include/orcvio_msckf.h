@@ -156,6 +156,40 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
                                     int32_t n_objects, const double* P,
                                     orcvio_msckf_result* result);
 
+/* Object residual rows at a fixed state: the CameraLM / ObjectLM functor evaluation exported by
+ * ObjectFeatureInitializer::single_levenberg_marquardt (src/obj/ObjectFeatureInitializer.cpp:394-434; functors
+ * src/obj/ObjectResJacCam.cpp:153-519, src/obj/ObjectLM.cpp:250-632) followed by
+ * OrcVIO::constructObjectResidualJacobians (src/orcvio.cpp:2017-2151), evaluated on the device.  Output rows are
+ * interleaved per in-window frame [keypoint rows ; 4 bbox rows] and can be passed to
+ * orcvio_msckf_update_objects as they are.  The LM *solver* is not part of this library: the caller supplies
+ * the state at which the rows are evaluated. */
+typedef struct orcvio_object_eval_flags {
+    int32_t use_left_perturbation;      /* the object mapper's flag (ObjectInitNode.cpp:140)             */
+    int32_t use_new_bbox_residual;      /* use_new_bbox_residual_flag (:206); restated literally (note N8) */
+    int32_t vio_use_left_perturbation;  /* the filter's flag: selects D (src/orcvio.cpp:2092)            */
+    int32_t fix_dcampose_dimupose_to_identity; /* OrcVIO::fixDcamposeDimuposeToI (orcvio.h:115-119)      */
+    double R_b2c[9];                    /* current extrinsics: state_server.imu_state.R_imu_cam0         */
+    double t_c_b[3];                    /*                      state_server.imu_state.t_cam0_imu         */
+} orcvio_object_eval_flags;
+
+typedef struct orcvio_object_track {
+    int32_t n_keypoints;        /* K (12 for the car class, config/object_feat_unity.yaml)              */
+    int32_t n_frames;
+    const double* wTo;          /* [16] row-major object -> world                                        */
+    const double* shape;        /* [3]  ellipsoid semi-axes                                              */
+    const double* kps;          /* [K][3] keypoints in the object frame                                  */
+    const double* frame_wTc;    /* [F][16] camera -> world of every frame (exp of valid_camera_pose_mat) */
+    const double* frame_zs;     /* [F][K][2] normalised keypoint detections, NaN = not detected          */
+    const double* frame_bbox;   /* [F][4] xmin, ymin, xmax, ymax (normalised)                            */
+    const int32_t* frame_clone; /* [F] window index of the clone with that exact timestamp, or -1 (:2073) */
+} orcvio_object_track;
+
+/* Returns ORCVIO_OK and *n_rows = 0 if no frame of the object is in the window (the reference returns false,
+ * :2149).  Hf has 9 + 3K columns.  cap_rows bounds the caller's buffers. */
+int32_t orcvio_msckf_object_rows_eval(orcvio_msckf_handle* h, const orcvio_object_eval_flags* flags,
+                                      const orcvio_object_track* obj, int32_t cap_rows, int32_t* n_rows,
+                                      int32_t* row_clone, double* Hx6, double* Hf, double* res);
+
 /* ---- staged, device-resident form (what bench.py times; also the multi-GPU path) ----
  * upload:      copy window / tracks / P to the handle's device buffers (host -> HBM);
  * run_local:   Jacobians -> nullspace -> gate -> stacked [H'|r'] -> Gram compression.

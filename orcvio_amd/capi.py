@@ -29,6 +29,7 @@ EXPORTS = [
     'orcvio_msckf_block_ptr', 'orcvio_msckf_run_finish', 'orcvio_msckf_run_update',
     'orcvio_msckf_sync', 'orcvio_msckf_download', 'orcvio_msckf_profile_update',
     'orcvio_msckf_increment_state', 'orcvio_msckf_set_option', 'orcvio_msckf_run_local_to',
+    'orcvio_msckf_object_rows_eval',
 ]
 
 
@@ -50,6 +51,17 @@ class MsckfTracks(C.Structure):
 class MsckfObjectRows(C.Structure):
     _fields_ = [('n_rows', C.c_int32), ('n_obj_cols', C.c_int32), ('row_clone', _ip), ('Hx6', _dp), ('Hf', _dp),
                 ('res', _dp)]
+
+
+class ObjectEvalFlags(C.Structure):
+    _fields_ = [('use_left_perturbation', C.c_int32), ('use_new_bbox_residual', C.c_int32),
+                ('vio_use_left_perturbation', C.c_int32), ('fix_dcampose_dimupose_to_identity', C.c_int32),
+                ('R_b2c', C.c_double * 9), ('t_c_b', C.c_double * 3)]
+
+
+class ObjectTrackC(C.Structure):
+    _fields_ = [('n_keypoints', C.c_int32), ('n_frames', C.c_int32), ('wTo', _dp), ('shape', _dp), ('kps', _dp),
+                ('frame_wTc', _dp), ('frame_zs', _dp), ('frame_bbox', _dp), ('frame_clone', _ip)]
 
 
 class MsckfResult(C.Structure):
@@ -234,6 +246,38 @@ class MsckfUpdater:
         out['gamma'] = float(out['gamma'][0])
         out['accept'] = int(out['accept'][0])
         return out
+
+    def object_rows_eval(self, obj, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D=False):
+        """Residual rows of one object track (synth.ObjectTrack-shaped) in window coordinates, evaluated on the GPU.
+        Returns dict(row_clone, Hx6, Hf, res) ready for update_objects, or None if no frame is in the window."""
+        K = obj.kps.shape[0]
+        F = len(obj.frames)
+        fl = ObjectEvalFlags(int(obj_left), int(new_bbox), int(vio_left), int(fix_D))
+        fl.R_b2c[:] = list(np.asarray(R_b2c, dtype=np.float64).ravel())
+        fl.t_c_b[:] = list(np.asarray(t_c_b, dtype=np.float64).ravel())
+        wTo = np.ascontiguousarray(obj.wTo, dtype=np.float64)
+        shape = np.ascontiguousarray(obj.shape, dtype=np.float64)
+        kps = np.ascontiguousarray(obj.kps, dtype=np.float64)
+        wTc = np.ascontiguousarray(np.stack([fr['wTc'] for fr in obj.frames]), dtype=np.float64)
+        zs = np.ascontiguousarray(np.stack([fr['zs'] for fr in obj.frames]), dtype=np.float64)
+        bb = np.ascontiguousarray(np.stack([fr['bbox'] for fr in obj.frames]), dtype=np.float64)
+        cl = np.ascontiguousarray([fr['clone'] for fr in obj.frames], dtype=np.int32)
+        tr = ObjectTrackC(K, F, _d(wTo), _d(shape), _d(kps), _d(wTc), _d(zs), _d(bb), _i(cl))
+        cap = F * (2 * K + 4)
+        ncol = 9 + 3 * K
+        row_clone = np.zeros(cap, dtype=np.int32)
+        Hx6 = np.zeros((cap, 6)); Hf = np.zeros((cap, ncol)); res = np.zeros(cap)
+        n_rows = C.c_int32(0)
+        self.lib.orcvio_msckf_object_rows_eval.argtypes = [C.c_void_p, C.POINTER(ObjectEvalFlags), C.POINTER(ObjectTrackC),
+                                                           C.c_int32, C.POINTER(C.c_int32), _ip, _dp, _dp, _dp]
+        rc = self.lib.orcvio_msckf_object_rows_eval(self.h, C.byref(fl), C.byref(tr), cap, C.byref(n_rows), _i(row_clone),
+                                                    _d(Hx6), _d(Hf), _d(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_object_rows_eval')
+        m = n_rows.value
+        if m == 0:
+            return None
+        return dict(row_clone=row_clone[:m].copy(), Hx6=Hx6[:m].copy(), Hf=Hf[:m].copy(), res=res[:m].copy())
 
     # -- staged, device-resident form -----------------------------------------------------
     def upload(self, win):

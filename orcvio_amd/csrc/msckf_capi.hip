@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "msckf_kernels.hpp"
+#include "object_rows.hpp"
 
 using namespace orcvio_amd;
 
@@ -898,6 +899,72 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
         }
     }
     h->objects_mode = false;
+    return ORCVIO_OK;
+}
+
+// ---- object residual rows ------------------------------------------------------
+int32_t orcvio_msckf_object_rows_eval(orcvio_msckf_handle* h, const orcvio_object_eval_flags* fl, const orcvio_object_track* ob,
+                                      int32_t cap_rows, int32_t* n_rows, int32_t* row_clone, double* Hx6, double* Hf, double* res) {
+    if (!h || !fl || !ob || !n_rows || !ob->wTo || !ob->shape || !ob->kps || !ob->frame_wTc || !ob->frame_zs || !ob->frame_bbox ||
+        !ob->frame_clone) { g_last_error = "object_rows_eval: null argument"; return ORCVIO_ERR_INVALID; }
+    const int K = ob->n_keypoints, F = ob->n_frames;
+    if (K < 1 || K > 60 || F < 1) { g_last_error = "object_rows_eval: 1..60 keypoints (one wavefront per frame), >= 1 frame"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    const int ncol = 9 + 3 * K;
+    // row offsets of the in-window frames (valid keypoint rows first, then 4 bbox rows)
+    std::vector<int> row0(F, 0);
+    int rows = 0;
+    for (int f = 0; f < F; ++f) {
+        if (ob->frame_clone[f] < 0) continue;
+        int nv = 0;
+        for (int k = 0; k < K; ++k) {
+            const double a = ob->frame_zs[((size_t)f * K + k) * 2], b = ob->frame_zs[((size_t)f * K + k) * 2 + 1];
+            if (std::isfinite(a) && std::isfinite(b)) ++nv;   // row finite test, ObjectLM.cpp:171-198
+        }
+        row0[f] = rows;
+        rows += 2 * nv + 4;
+    }
+    *n_rows = rows;
+    if (rows == 0) return ORCVIO_OK;
+    if (rows > cap_rows || !row_clone || !Hx6 || !Hf || !res) { g_last_error = "object_rows_eval: output buffers too small"; return ORCVIO_ERR_CAPACITY; }
+    // pack inputs / outputs into the (growable) object scratch buffers
+    const size_t in_d = 16 + 3 + (size_t)3 * K + (size_t)F * (16 + 2 * K + 4);
+    const size_t out_d = (size_t)rows * (6 + ncol + 1);
+    int rc;
+    if ((rc = grow(&h->d_objH, &h->cap_objH, in_d + out_d)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_obj_i, &h->cap_obj_i, (size_t)2 * F + rows)) != ORCVIO_OK) return rc;
+    std::vector<double> hin(in_d);
+    double* q = hin.data();
+    std::memcpy(q, ob->wTo, 16 * 8); q += 16;
+    std::memcpy(q, ob->shape, 3 * 8); q += 3;
+    std::memcpy(q, ob->kps, (size_t)3 * K * 8); q += 3 * K;
+    std::memcpy(q, ob->frame_wTc, (size_t)16 * F * 8); q += (size_t)16 * F;
+    std::memcpy(q, ob->frame_zs, (size_t)2 * K * F * 8); q += (size_t)2 * K * F;
+    std::memcpy(q, ob->frame_bbox, (size_t)4 * F * 8);
+    std::vector<int> hi(2 * F);
+    for (int f = 0; f < F; ++f) { hi[f] = ob->frame_clone[f]; hi[F + f] = row0[f]; }
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_objH, hin.data(), sizeof(double) * in_d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_obj_i, hi.data(), sizeof(int) * 2 * F, hipMemcpyHostToDevice, s));
+    ObjEvalArgs a;
+    a.wTo = h->d_objH; a.shape = a.wTo + 16; a.kps = a.shape + 3; a.frame_wTc = a.kps + 3 * K;
+    a.frame_zs = a.frame_wTc + (size_t)16 * F; a.frame_bbox = a.frame_zs + (size_t)2 * K * F;
+    a.frame_clone = h->d_obj_i; a.frame_row0 = h->d_obj_i + F;
+    a.K = K; a.F = F; a.ncol = ncol;
+    a.obj_left = fl->use_left_perturbation; a.new_bbox = fl->use_new_bbox_residual; a.vio_left = fl->vio_use_left_perturbation;
+    a.fix_D = fl->fix_dcampose_dimupose_to_identity;
+    std::memcpy(a.R_b2c, fl->R_b2c, sizeof(a.R_b2c));
+    std::memcpy(a.t_c_b, fl->t_c_b, sizeof(a.t_c_b));
+    double* outd = h->d_objH + in_d;
+    a.Hx6 = outd; a.Hf = outd + (size_t)rows * 6; a.res = a.Hf + (size_t)rows * ncol;
+    a.row_clone = h->d_obj_i + 2 * F;
+    hipLaunchKernelGGL(k_object_rows, dim3(F), dim3(64), 0, s, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(Hx6, a.Hx6, sizeof(double) * (size_t)rows * 6, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(Hf, a.Hf, sizeof(double) * (size_t)rows * ncol, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(res, a.res, sizeof(double) * rows, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(row_clone, a.row_clone, sizeof(int) * rows, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return ORCVIO_OK;
 }
 

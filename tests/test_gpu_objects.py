@@ -115,3 +115,51 @@ def test_config3_twenty_objects(upd, new_bbox):
         assert not got['dx'].any() and rel(got['P_new'], win.P) < 1e-15
     if not new_bbox:
         assert got['accept'] == 1   # consistent Jacobians: the joint block passes the gate
+
+
+@pytest.mark.parametrize('obj_left,new_bbox,vio_left', [(True, False, 0), (False, False, 0), (True, True, 0), (False, True, 1),
+                                                          (True, False, 1)])
+def test_object_rows_eval_matches_mirror(upd, obj_left, new_bbox, vio_left):
+    """Rows 12-16 on the GPU (k_object_rows) against the restatement pinned by the reference's HDF5 goldens."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=vio_left)
+    win = synth.make_window(N=14, F=4, seed=21, flags=flags, track_len=4)
+    obj = synth.make_objects(win, n_objects=1, seed=9, sigma_kp=0.004, missing_frac=0.25)[0]
+    # two frames fall outside the window (exact-timestamp match fails, src/orcvio.cpp:2073)
+    obj.frames[3]['clone'] = -1
+    obj.frames[8]['clone'] = -1
+    res, Hf, Jc, counts = mo.object_rows(obj.wTo, obj.shape, obj.kps, obj.frames, obj_left, new_bbox)
+    ref = mo.construct_object_residual_jacobians(Jc, [fr['clone'] for fr in obj.frames], Hf, res, counts,
+                                                 [fr['wTc'] for fr in obj.frames], win.R_b2c[0], win.t_c_b[0], vio_left,
+                                                 flags.leg_dim, win.N)
+    Hx_ref, Hf_ref, r_ref, rc_ref, hx6_ref = ref
+    got = upd.object_rows_eval(obj, win.R_b2c[0], win.t_c_b[0], obj_left, new_bbox, vio_left)
+    assert np.array_equal(got['row_clone'], rc_ref)
+    assert rel(got['res'], r_ref) < 1e-9    # residuals are differences of O(1) projections
+    assert rel(got['Hx6'], hx6_ref) < 1e-10
+    assert rel(got['Hf'], Hf_ref) < 1e-10
+    # and straight into the update: same result as with the mirror's rows
+    a = upd.update_objects(flags, win.N, [got], win.P)
+    b = upd.update_objects(flags, win.N, [dict(row_clone=rc_ref, Hx6=hx6_ref, Hf=Hf_ref, res=r_ref)], win.P)
+    assert a['accept'] == b['accept'] and (not b['dx'].any() or rel(a['dx'], b['dx']) < 1e-6)
+
+
+def test_object_rows_eval_reference_golden(upd):
+    """The reference's own fixture (src/tests/data/test_error_feature_quadric.h5): one frame, 12 keypoints, left
+    perturbation; Hf rows = the stored 24x45 Jacobian, residual = the stored error (test_object_lm.cpp:90-152)."""
+    from helpers import GOLDEN
+    g = np.load(GOLDEN + '/ref_test_error_feature_quadric.npz')
+    obj = synth.ObjectTrack(wTo=g['T'], shape=np.ones(3), kps=g['M'][:, :3].copy(),
+                            frames=[dict(clone=0, wTc=np.linalg.inv(g['S']), zs=g['zs'], bbox=np.array([-0.1, -0.1, 0.1, 0.1]))])
+    got = upd.object_rows_eval(obj, np.eye(3), np.zeros(3), True, False, 0, fix_D=True)
+    assert got['res'].shape[0] == 28
+    assert np.abs(got['res'][:24] - g['error'].ravel()).max() < 1e-12
+    assert np.abs(got['Hf'][:24] - g['jacobian']).max() < 1e-12
+
+
+def test_object_rows_eval_no_frame_in_window(upd):
+    flags = synth.Flags(use_larvio=0)
+    win = synth.make_window(N=6, F=4, seed=2, flags=flags, track_len=4)
+    obj = synth.make_objects(win, n_objects=1, seed=3)[0]
+    for fr in obj.frames:
+        fr['clone'] = -1
+    assert upd.object_rows_eval(obj, win.R_b2c[0], win.t_c_b[0], True, False, 0) is None
