@@ -62,6 +62,7 @@ struct orcvio_msckf_handle {
     std::vector<int> h_clone_ptr, h_clone_obs;
     int s_chunks = 0;
     bool materialize = false;
+    int feat_ablate = 0;
     size_t hs_rows_cap = 0;
     int gram_chunks_cap = 64;
     // host staging
@@ -401,6 +402,7 @@ static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
     a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP; a.Mmax = h->Mmax; a.F = h->F;
     a.use_larvio = h->flags.use_larvio; a.use_left = h->flags.use_left_perturbation; a.if_fej = h->flags.if_fej;
     a.estimate_td = h->flags.estimate_td;
+    a.ablate = h->feat_ablate;
     const size_t lds = feat_lds_bytes(h->Mmax, h->NAP, h->N);
     const int npass = (h->NAP + 63) / 64;
     dim3 grid(h->F), block(64);
@@ -1205,6 +1207,28 @@ int32_t orcvio_msckf_debug_potrf_ablate(orcvio_msckf_handle* h, int32_t ablate, 
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *us_out = 1e3 * ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ORCVIO_OK;
+}
+
+// Diagnostic: average time of k_feature with phases switched off (outputs are garbage for ablate != 0).
+int32_t orcvio_msckf_debug_feature_ablate(orcvio_msckf_handle* h, int32_t ablate, int32_t reps, double* us_out) {
+    if (!h || !h->uploaded || !us_out) return ORCVIO_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    h->feat_ablate = ablate;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int r = 0; r < 3; ++r) launch_feature(h, h->stream);
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r) launch_feature(h, h->stream);
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *us_out = 1e3 * ms / reps;
+    h->feat_ablate = 0;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return ORCVIO_OK;

@@ -145,6 +145,7 @@ struct FeatArgs {
     double sigma2;
     int n, leg, N, NA, NAP, Mmax, F;
     int use_larvio, use_left, if_fej, estimate_td;
+    int ablate;   // diagnostic only (scripts/gpu_ablate_feature.py): 1 skip E, 2 skip Q^T E Q, 4 skip Cholesky, 8 skip outputs
 };
 
 __host__ __device__ inline int feat_lde(int Mmax) { return 2 * Mmax + 1; }
@@ -307,6 +308,14 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
 #pragma unroll
         for (int e = 0; e < 7; ++e) pe[ps][e] = p.P[(size_t)(15 + e) * n + 15 + (a < NA ? a : NA - 1)];
     }
+    // With estimate_extrin = estimate_td = 0 (every shipped config) the extrinsic / td rows and columns of P are
+    // exactly zero (src/orcvio.cpp:213-221): those 7 of the 13 terms then vanish identically and are skipped.
+    bool pe_nz = false;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int e = 0; e < 7; ++e) pe_nz |= (pe[ps][e] != 0.0);
+    const bool ext_live = __any(pe_nz);   // wave-uniform
     // P rows of the clone of observation l are prefetched one iteration ahead (18 coalesced loads in
     // flight while the previous observation is being consumed)
     double pcur[NPASS][6], pnxt[NPASS][6];
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
             for (int c = 0; c < 6; ++c) pcur[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
         }
     }
-    for (int l = 0; l < M; ++l) {
+    for (int l = 0; l < ((p.ablate & 1) ? 0 : M); ++l) {
         if (l + 1 < M) {
             const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[l + 1]) * n + 15;
 #pragma unroll
@@ -339,8 +348,10 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
             const int a = t + 64 * ps;
             if (a < NA) {
                 double u0 = 0.0, u1 = 0.0;
+                if (ext_live) {
 #pragma unroll
-                for (int e = 0; e < 7; ++e) { u0 += jl0e[e] * pe[ps][e]; u1 += jl1e[e] * pe[ps][e]; }
+                    for (int e = 0; e < 7; ++e) { u0 += jl0e[e] * pe[ps][e]; u1 += jl1e[e] * pe[ps][e]; }
+                }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     u0 += jl0x[c] * pcur[ps][c];
@@ -353,8 +364,10 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
         wave_sync();
         if (rowlane) {
             double e0 = 0.0, e1 = 0.0;
+            if (ext_live) {   // P symmetric: zero rows <=> zero columns, so u at the ext columns is zero too
 #pragma unroll
-            for (int e = 0; e < 7; ++e) { e0 += je[e] * sU[2 * e]; e1 += je[e] * sU[2 * e + 1]; }
+                for (int e = 0; e < 7; ++e) { e0 += je[e] * sU[2 * e]; e1 += je[e] * sU[2 * e + 1]; }
+            }
 #pragma unroll
             for (int c = 0; c < 6; ++c) { e0 += jx[c] * sU[2 * (ja0 + c)]; e1 += jx[c] * sU[2 * (ja0 + c) + 1]; }
             sE[t * LDE + 2 * l] = e0;
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
     for (int c = 0; c < 64; ++c) row[c] = (rowlane && c < M2) ? sE[t * LDE + c] : 0.0;
 
     // ---- F: E' = Q^T E Q through the compact-WY form ----------------------------------
-    {
+    if (!(p.ablate & 2)) {
         double W0 = 0.0, W1 = 0.0, W2 = 0.0;
 #pragma unroll
         for (int c = 0; c < 64; ++c) {
@@ -430,8 +443,8 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
     bool fail = false;
 #pragma unroll
     for (int jc = 3; jc < 64; ++jc) {
-        if (jc < M2) {
-            const double d = __shfl(row[jc], jc) + p.sigma2;
+        if (jc < M2 && !(p.ablate & 4)) {
+            const double d = bcast_lane(row[jc], jc) + p.sigma2;
             if (!(d > 0.0)) fail = true;
             const double inv = rsqrt_nr(d);
             const double lr = row[jc] * inv;
@@ -456,6 +469,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
     // Q^T X: Q is orthogonal), so the 2M-3 dense projected rows are NOT needed downstream: the track
     // hands over its 2M sparse rows (14 non-zeros each) and the three dense rows T3.  The projected block
     // itself is materialised only on request (p.Hs != nullptr; tests and callers that want H').
+    if (p.ablate & 8) return;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         const int a = t + 64 * ps;
