@@ -63,6 +63,12 @@ struct orcvio_msckf_handle {
     int s_chunks = 0;
     bool materialize = false;
     int feat_ablate = 0;
+    // captured launch graph of run_update (valid for the current upload and launch stream)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;
+    bool graph_valid = false;
+    bool use_graph = true;
     size_t hs_rows_cap = 0;
     int gram_chunks_cap = 64;
     // host staging
@@ -157,6 +163,8 @@ static void free_all(orcvio_msckf_handle* h) {
         if (p) (void)hipFree(p);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->side) (void)hipStreamDestroy(h->side);
 }
@@ -274,6 +282,7 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
         HIPCHK(hipSetDevice(h->device));
         if (value && !h->d_Hs) HIPCHK(hipMalloc(&h->d_Hs, sizeof(double) * h->hs_rows_cap * h->NAP_max));
         h->materialize = value != 0;
+        h->graph_valid = false;
         return ORCVIO_OK;
     }
     g_last_error = "orcvio_msckf_set_option: unknown option";
@@ -388,6 +397,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->chunks = t3rows > 0 ? (t3rows + rpc - 1) / rpc : 1;
     h->uploaded = true;
     h->ran = false;
+    h->graph_valid = false;
     return ORCVIO_OK;
 }
 
@@ -592,15 +602,52 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
     return rc;
 }
 
-int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
-    if (!h || !h->uploaded) { g_last_error = "run_update: nothing uploaded"; return ORCVIO_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = pick_stream(h, stream);
+static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
     int rc = launch_prior_fork(h, s);
     if (rc == ORCVIO_OK) rc = launch_feature(h, s);
     if (rc == ORCVIO_OK) rc = launch_gram(h, s);
     if (rc == ORCVIO_OK) rc = launch_assemble(h, s, h->d_A);
     if (rc == ORCVIO_OK) rc = launch_solve_tail(h, s);
+    return rc;
+}
+
+int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
+    if (!h || !h->uploaded) { g_last_error = "run_update: nothing uploaded"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    // The eleven launches (and the side-stream fork/join) are captured once per upload into a hipGraph and
+    // replayed: same kernels, same arguments, fewer host calls and tighter dispatch.
+    if (h->use_graph && s != nullptr) {
+        if (!h->graph_valid || h->graph_stream != s) {
+            if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+            h->graph_valid = false;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                const int rc_c = enqueue_update(h, s);
+                hipGraph_t g = nullptr;
+                const hipError_t e_end = hipStreamEndCapture(s, &g);
+                if (rc_c == ORCVIO_OK && e_end == hipSuccess && g &&
+                    hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                    h->graph = g;
+                    h->graph_stream = s;
+                    h->graph_valid = true;
+                } else {
+                    if (g) (void)hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                    h->use_graph = false;   // capture is not available here: plain launches from now on
+                }
+            } else {
+                (void)hipGetLastError();
+                h->use_graph = false;
+            }
+        }
+        if (h->graph_valid) {
+            HIPCHK(hipGraphLaunch(h->graph_exec, s));
+            h->ran = true;
+            return ORCVIO_OK;
+        }
+    }
+    int rc = enqueue_update(h, s);
     if (rc == ORCVIO_OK) h->ran = true;
     return rc;
 }
