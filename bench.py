@@ -136,8 +136,18 @@ def main():
         crit = {k: v for k, v in prof.items() if k != 'k_potrf(P)'}
         dom = max(crit, key=crit.get)
         achieved = kflops[dom] / (prof[dom] * 1e-3) / 1e12
+        # HBM traffic of the dominant kernel: PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes) of the
+        # committed profile of this round, bytes per launch; null if that profile does not list the kernel
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r1b_pmc_traffic.json')))['kernels']
+            key = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<12>', 'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt'}.get(dom)
+            if key in pm and N == 30 and F == 400:
+                traffic = 1024.0 * (pm[key]['FETCH_SIZE_KB_median'] + pm[key]['WRITE_SIZE_KB_median'])
+        except Exception:
+            traffic = None
         roofline = dict(bound='mfma', kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=achieved / FP64_PEAK_TFLOPS, traffic=None,
+                        frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic,
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},
                         kernel_tflops={k: round(kflops[k] / (prof[k] * 1e-3) / 1e12, 4) for k in prof},
                         whole_update_tflops=W['total'] / (ms * 1e-3) / 1e12)
@@ -159,11 +169,13 @@ def main():
                                clones=N, features_per_gpu=F, observations_per_feature=N,
                                parallelism=f'features sharded over {world} GPU(s), all-gather of compressed blocks'),
                    roofline=roofline, cpu_baseline=cpu)
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     upd.close()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)   # the one JSON line, last thing on stdout
 
 
 if __name__ == '__main__':

@@ -387,7 +387,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     HIPCHK(hipStreamSynchronize(s));
     // Gram chunking: enough (chunk, tile) wavefronts to fill 256 CUs
     const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
-    int chunks = (2048 + ntiles - 1) / ntiles;
+    int chunks = (640 + ntiles - 1) / ntiles;   // >= 640 (chunk, tile) wavefronts; few chunks keep the partials small
     if (chunks > h->gram_chunks_cap) chunks = h->gram_chunks_cap;
     if (chunks < 1) chunks = 1;
     const int t3rows = 3 * F;   // the dense part of the compression: three rows per track
