@@ -130,6 +130,7 @@ def main():
             'k_gemm(M)': 2.0 * NA * n * n / 2.0,
             'k_potrf(M)': n ** 3 / 3.0,
             'k_trsm': 1.0 * n * n * (n + 1),
+            'k_potrf_solve(M)': n ** 3 / 3.0 + 1.0 * n * n * (n + 1),   # factorisation + trailing solve, one launch
             'k_finish': 1.0 * n * (n + 1) * (n + 1),
         }
         # k_potrf(P) runs on a side stream, overlapped with k_feature/k_gram: not on the critical path
@@ -141,7 +142,7 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r1b_pmc_traffic.json')))['kernels']
-            key = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<12>', 'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt'}.get(dom)
+            key = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<12>', 'k_potrf_solve(M)': 'k_potrf_solve<12>', 'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt'}.get(dom)
             if key in pm and N == 30 and F == 400:
                 traffic = 1024.0 * (pm[key]['FETCH_SIZE_KB_median'] + pm[key]['WRITE_SIZE_KB_median'])
         except Exception:

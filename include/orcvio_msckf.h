@@ -134,7 +134,9 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
 /* Options.  ORCVIO_OPT_MATERIALIZE_STACK (default 0): also write the stacked projected blocks
  * [H' | r'] (what the reference builds in H_msckf, src/orcvio.cpp:2497-2527) to device memory.  The
  * update itself never needs them; tests and callers that want H' switch it on. */
-enum { ORCVIO_OPT_MATERIALIZE_STACK = 1 };
+/* ORCVIO_OPT_FUSED_SOLVE (default 1): factor M and solve for Z in one launch (solver workgroups trail the
+ * factorisation block step by block step); 0 = two launches (k_potrf_reg, k_trsm_lds).  Same arithmetic. */
+enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* Feature update: replaces the loop + compression + update of

@@ -160,6 +160,12 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_set_option')
 
+    def set_fused_solve(self, on: bool):
+        """ORCVIO_OPT_FUSED_SOLVE: chol(M) and the triangular solve in one launch (default) or in two."""
+        rc = self.lib.orcvio_msckf_set_option(self.h, 2, int(bool(on)))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_set_option')
+
     def close(self):
         if self.h:
             self.lib.orcvio_msckf_destroy(self.h)

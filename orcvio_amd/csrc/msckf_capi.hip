@@ -43,6 +43,8 @@ struct orcvio_msckf_handle {
     int chunks = 0, rows_per_chunk = 0;
     bool uploaded = false, ran = false;
     bool reg_path = true;               // register-resident Cholesky (n <= 224), else the LDS-panel kernel
+    bool fused_solve = true;            // chol(M) and the triangular solve in one launch (k_potrf_solve), reg path only
+    int* d_flag = nullptr;              // step counter of that launch (inside the d_info allocation, own 128-byte line)
     // device buffers
     double *d_poses = nullptr, *d_pw = nullptr, *d_obs_z = nullptr, *d_obs_zvel = nullptr, *d_P = nullptr;
     int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_info = nullptr;
@@ -220,7 +222,8 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_obs_clone, sizeof(int) * max_observations));
         HIPCHK(hipMalloc(&h->d_row_ptr, sizeof(int) * (max_features + 1)));
         HIPCHK(hipMalloc(&h->d_accept, sizeof(int) * max_features));
-        HIPCHK(hipMalloc(&h->d_info, sizeof(int) * 8));
+        HIPCHK(hipMalloc(&h->d_info, sizeof(int) * 64));
+        h->d_flag = h->d_info + 32;
         HIPCHK(hipMalloc(&h->d_chi2, sizeof(double) * ORCVIO_CHI2_TABLE));
         HIPCHK(hipMalloc(&h->d_T3, sizeof(double) * (size_t)3 * max_features * h->NAP_max));
         HIPCHK(hipMalloc(&h->d_Xobs, sizeof(double) * (size_t)32 * max_observations));
@@ -245,7 +248,7 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_W, sizeof(double) * np2));
         HIPCHK(hipMalloc(&h->d_Y, sizeof(double) * np2));
         HIPCHK(hipMalloc(&h->d_KG, sizeof(double) * np2));
-        HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 8));
+        HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 64));
         HIPCHK(hipMemset(h->d_obs_zvel, 0, sizeof(double) * 2 * max_observations));
         HIPCHK(hipMemset(h->d_RP, 0, sizeof(double) * np2));   // strictly-lower tiles of the upper factors stay 0
         HIPCHK(hipMemset(h->d_RM, 0, sizeof(double) * np2));
@@ -282,6 +285,11 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
         HIPCHK(hipSetDevice(h->device));
         if (value && !h->d_Hs) HIPCHK(hipMalloc(&h->d_Hs, sizeof(double) * h->hs_rows_cap * h->NAP_max));
         h->materialize = value != 0;
+        h->graph_valid = false;
+        return ORCVIO_OK;
+    }
+    if (option == ORCVIO_OPT_FUSED_SOLVE) {
+        h->fused_solve = value != 0;
         h->graph_valid = false;
         return ORCVIO_OK;
     }
@@ -487,10 +495,10 @@ static inline void factor_strides(const orcvio_msckf_handle* h, long& sLi, long&
 }
 
 static int launch_gemm(hipStream_t s, const double* A, long sAi, long sAk, const double* B, long sBk, long sBj, int M, int N,
-                       int K, double alpha, double diag_add, int upper_only, double* C, long sCi, long sCj) {
+                       int K, double alpha, double diag_add, int upper_only, double* C, long sCi, long sCj, int* clear = nullptr) {
     const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
     hipLaunchKernelGGL(k_gemm, dim3((tiles + 3) / 4), dim3(256), 0, s, A, sAi, sAk, B, sBk, sBj, M, N, K, alpha, diag_add,
-                       upper_only, C, sCi, sCj);
+                       upper_only, C, sCi, sCj, (const double*)nullptr, clear);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -511,6 +519,8 @@ static int launch_trsm(orcvio_msckf_handle* h, hipStream_t s, const double* L, c
     return ORCVIO_OK;
 }
 
+static inline bool fused_solve_active(const orcvio_msckf_handle* h) { return h->reg_path && h->fused_solve; }
+
 // stages of the square-root Kalman solve (see msckf_kernels.hpp)
 enum { ST_POTRF_P = 0, ST_FORM_U, ST_FORM_M, ST_POTRF_M, ST_TRSM, ST_FINISH, ST_COUNT };
 
@@ -527,10 +537,26 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
         case ST_FORM_U:    // U[(NA+1) x n] = [A; b^T] * L_a
             return launch_gemm(s, h->d_A, NAP, 1, La, sLi, sLj, NA + 1, n, NA, 1.0, 0.0, 0, h->d_U, NP, 1);
         case ST_FORM_M:    // M = s2 I + L_a^T U[0:NA]   (upper tiles)
-            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, n, n, NA, 1.0, sigma2, 1, h->d_M, NP, 1);
+            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, n, n, NA, 1.0, sigma2, 1, h->d_M, NP, 1, h->d_flag);
         case ST_POTRF_M:
+            if (fused_solve_active(h)) {   // chol(M) + Z = L_M^-1 [Lf^T | g] in one launch (solver workgroups trail the factorisation)
+                const int nbm = (n + 15) / 16, noff = nbm * (nbm - 1) / 2, need = (noff + 6) / 7;
+                const int ncb = (n + 1 + 15) / 16;
+                const dim3 grid(1 + (ncb + SOLVE_WPB - 1) / SOLVE_WPB), block(512);
+                const double* g = h->d_U + (size_t)NA * NP;
+#define LAUNCH_PS(NS) hipLaunchKernelGGL(k_potrf_solve<NS>, grid, block, 0, s, h->d_M, NP, n, 0.0, h->d_RM, NP, h->d_DinvM, h->d_info + 2, \
+                                         h->d_flag, h->d_RP, sLj, sLi, n, g, 1L, h->d_Z, ldz)
+                if (need <= 4) LAUNCH_PS(4);
+                else if (need <= 8) LAUNCH_PS(8);
+                else if (need <= 12) LAUNCH_PS(12);
+                else LAUNCH_PS(14);
+#undef LAUNCH_PS
+                HIPCHK(hipGetLastError());
+                return ORCVIO_OK;
+            }
             return launch_potrf(h, s, h->d_M, NP, n, 0.0, h->d_RM, h->d_DinvM, h->d_info + 2);
         case ST_TRSM:      // Z = L_M^-1 [Lf^T | g],  g = U[NA][:]
+            if (fused_solve_active(h)) return ORCVIO_OK;   // done inside k_potrf_solve
             return launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_RP, sLj, sLi, n, h->d_U + (size_t)NA * NP, 1, h->d_Z, ldz);
         case ST_FINISH: {
             const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
@@ -1046,8 +1072,14 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
             ms[k] += t;
         }
     }
-    for (int k = 0; k < nk; ++k) { ms[k] /= reps; names[k] = kn[k]; }
-    *count = nk;
+    int no = 0;
+    for (int k = 0; k < nk; ++k) {
+        if (k == 3 + ST_TRSM && fused_solve_active(h)) continue;   // nothing launched: part of k_potrf_solve(M)
+        ms[no] = ms[k] / reps;
+        names[no] = (k == 3 + ST_POTRF_M && fused_solve_active(h)) ? "k_potrf_solve(M)" : kn[k];
+        ++no;
+    }
+    *count = no;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int) * 8, s));

@@ -997,19 +997,30 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int NSLOT>
-__global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X, int ldx, int n, double tol_rel,
-                                                   double* __restrict__ R, int ldr, double* __restrict__ Dinv,
-                                                   int* __restrict__ info, unsigned long long* __restrict__ stamps = nullptr,
-                                                   size_t strideX = 0, size_t strideR = 0, size_t strideD = 0,
-                                                   int from_lower = 0, int ablate = 0) {
+// Stores / loads of bytes that another workgroup of the SAME launch consumes (k_potrf_solve): agent-scope relaxed
+// atomics = global_store/load ... sc1 (write-through, L1-bypassing); MI355X_MICROARCH.md "inter-workgroup visibility".
+template <bool PUB>
+__device__ __forceinline__ void st_pub(double* p, double v) {
+    if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ double ld_pub(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// workgroup barrier that also drains this wave's global stores (publishing waves, one block step after issuing them)
+__device__ __forceinline__ void lds_barrier_drain() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// PUB: every byte of R (full tiles, padding included: R must be allocated 16 nb x ldr) and of Dinv is stored sc1, and
+// flag[0] = number of block steps whose row block of R and inv(L11) are complete in memory (monotonic, set by one
+// lane behind a workgroup barrier that every storing wave reaches after draining its stores).
+template <int NSLOT, bool PUB>
+__device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int ldx, int n, double tol_rel,
+                                               double* __restrict__ R, int ldr, double* __restrict__ Dinv,
+                                               int* __restrict__ info, int from_lower, int ablate, int* __restrict__ flag) {
     // ablate (diagnostic only, scripts/gpu_ablate.py): 1 skip the diagonal sweep, 2 skip trailing MFMAs, 4 skip panel
     // MFMAs, 8 skip the later-diagonal updates.  Results are garbage when non-zero.
-    // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
-    // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
-    X += (size_t)blockIdx.x * strideX;
-    R += (size_t)blockIdx.x * strideR;
-    Dinv += (size_t)blockIdx.x * strideD;
     __shared__ __attribute__((aligned(16))) double sD[16][16];       // diagonal tile being factored (row view)
     __shared__ __attribute__((aligned(16))) double sDi[16][16];      // inv(L11) of the current block step
     __shared__ __attribute__((aligned(16))) double sPan[14][4][64];  // published panel tiles, accumulator layout
@@ -1066,20 +1077,15 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
             if (!(ablate & 1)) DiagStep<0>::run(v, y, tol, n - 16 * kb, nzero, nneg);
             if (l < 16) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    pDi[c * 16 + l] = y[c];                               // Linv[c][l]
-                    Dinv[(size_t)kb * 256 + c * 16 + l] = y[c];           // straight to memory (barriers do not wait for it)
-                }
+                for (int c = 0; c < 16; ++c) pDi[c * 16 + l] = y[c];   // Linv[c][l]
             }
-            // R11[kk+4r][cc] = L11[cc][kk+4r] = v[kk+4r] of this very lane (every 16-lane row holds all rows)
+            // R11[kk+4r][cc] = L11[cc][kk+4r] = v[kk+4r] of this very lane (every 16-lane row holds all rows);
+            // inv(L11) and R11 go to memory from LDS by a helper wave of role 2 (no global stores on this chain)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double x0 = v[4 * r], x1 = v[4 * r + 1], x2 = v[4 * r + 2], x3 = v[4 * r + 3];
                 const double xs = (kk == 0) ? x0 : ((kk == 1) ? x1 : ((kk == 2) ? x2 : x3));
-                const double rv = (kk + 4 * r <= cc) ? xs : 0.0;
-                pG[r * 64] = rv;
-                const int i = 16 * kb + kk + 4 * r, j = 16 * kb + cc;
-                if (i < n && j < n) R[(size_t)i * ldr + j] = rv;
+                pG[r * 64] = (kk + 4 * r <= cc) ? xs : 0.0;
             }
         };
         __builtin_amdgcn_s_setprio(3);   // win VALU arbitration against the co-resident wave of this SIMD
@@ -1154,10 +1160,25 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
             asm volatile("" : "+v"(z));
             double* pDi = &sDi[0][0] + z;
             double* pPan = &sPan[0][0][0] + z;
-            lds_barrier();   // A
+            if (PUB) {
+                lds_barrier_drain();   // A (+ the stores of step kb-1 of this wave have landed)
+                if (wave == 1 && l == 0 && kb > 0) __hip_atomic_store(flag, kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                lds_barrier();   // A
+            }
             // ---- panel tiles (a == kb < b): tile <- inv(L11) * tile, published and stored ---------------
             const int Tkb = kb * nb - kb * (kb + 1) / 2;
             const int s_lo = slots_below(Tkb), s_hi = slots_below(Tkb + (nb - 1 - kb));
+            if (wave == 1 + (Tkb + (nb - 1 - kb)) % 7) {   // helper: inv(L11) and R11 of this step, LDS -> memory
+                const double* g = &sDg[0][0][0] + z + kb * 256 + l;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_pub<PUB>(Dinv + (size_t)kb * 256 + l + 64 * r, pDi[l + 64 * r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * kb + kk + 4 * r, j = 16 * kb + cc;
+                    if (PUB || (i < n && j < n)) st_pub<PUB>(R + (size_t)i * ldr + j, g[r * 64]);
+                }
+            }
             if (s_hi > s_lo && !(ablate & 32)) {
                 double li[4];
 #pragma unroll
@@ -1177,7 +1198,7 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
                         for (int r = 0; r < 4; ++r) {
                             dst[r * 64] = x[r];
                             const int i = 16 * kb + kk + 4 * r, j = 16 * b + cc;
-                            if (i < n && j < n) R[(size_t)i * ldr + j] = x[r];   // final: row block kb of R
+                            if (PUB || (i < n && j < n)) st_pub<PUB>(R + (size_t)i * ldr + j, x[r]);   // final: row block kb of R
                         }
                     }
                 }
@@ -1212,7 +1233,24 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
             }
         }
     }
+    if (PUB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave == 1 && l == 0) __hip_atomic_store(flag, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NSLOT>
+__global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X, int ldx, int n, double tol_rel,
+                                                   double* __restrict__ R, int ldr, double* __restrict__ Dinv,
+                                                   int* __restrict__ info, unsigned long long* __restrict__ stamps = nullptr,
+                                                   size_t strideX = 0, size_t strideR = 0, size_t strideD = 0,
+                                                   int from_lower = 0, int ablate = 0) {
+    // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
+    // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
     (void)stamps;
+    potrf_reg_body<NSLOT, false>(X + (size_t)blockIdx.x * strideX, ldx, n, tol_rel, R + (size_t)blockIdx.x * strideR, ldr,
+                                 Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr);
 }
 
 // generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j]; tiles with
@@ -1220,7 +1258,9 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
 __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
                                               long sBk, long sBj, int M, int N, int K, double alpha, double diag_add,
                                               int upper_only, double* __restrict__ C, long sCi, long sCj,
-                                              const double* __restrict__ Cin = nullptr) {
+                                              const double* __restrict__ Cin = nullptr, int* __restrict__ clear = nullptr) {
+    // clear: step counter of the k_potrf_solve launch that follows in the stream (reset here, one kernel ahead)
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nti = (M + 15) >> 4, ntj = (N + 15) >> 4;
     const int tile = blockIdx.x * 4 + wave;
@@ -1405,6 +1445,110 @@ __global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, 
             }
         }
     }
+}
+
+// k_potrf_solve: Cholesky M = R^T R and the triangular solve Z = R^-T B in ONE launch.  Workgroup 0 is the
+// factorisation (potrf_reg_body, publishing); every wavefront of workgroups 1.. owns 16 right-hand-side columns
+// (all block rows in registers) and runs the right-looking solve one block step behind the factorisation: it polls
+// the step counter, reads row block k of R and inv(L11) with L1-bypassing loads, finishes Z_k and updates the later
+// block rows with independent MFMAs.  The solve is off the critical chain: the launch ends a few microseconds after
+// the factorisation instead of a whole k_trsm later.  SOLVE_WPB live wavefronts per solver workgroup (one per SIMD).
+#define SOLVE_WPB 4
+#define SOLVE_CH 4
+template <int NSLOT>
+__global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ X, int ldx, int n, double tol_rel,
+                                                     double* __restrict__ R, int ldr, double* __restrict__ Dinv,
+                                                     int* __restrict__ info, int* __restrict__ flag,
+                                                     const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
+                                                     const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz) {
+    if (blockIdx.x == 0) {
+        potrf_reg_body<NSLOT, true>(X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag);
+        return;
+    }
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int kk = l >> 4, cc = l & 15;
+    const int nblk = (n + 15) >> 4;
+    const int ncols = nc1 + (bx ? 1 : 0);
+    const int cb = (blockIdx.x - 1) * SOLVE_WPB + wave;
+    if (wave >= SOLVE_WPB || cb * 16 >= ncols) return;
+    const int col = cb * 16 + cc;
+    d4 acc[14];
+#pragma unroll
+    for (int kb = 0; kb < 14; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * kb + kk + 4 * r;
+            double v = 0.0;
+            if (kb < nblk && i < n) {
+                if (col < nc1) v = B1[(long)i * sB1i + (long)col * sB1c];
+                else if (col == nc1 && bx) v = bx[(long)i * sbx];
+            }
+            acc[kb][r] = v;
+        }
+    }
+    int seen = 0;
+    bool lost = false;
+    const int l4 = cc * 16 + kk;                    // inv(L11) operand: Linv[m = cc][k = kk + 4s]
+    const size_t lane_off = (size_t)kk * ldr + cc;  // lane part of every R address
+#pragma unroll
+    for (int kb = 0; kb < 14; ++kb) {
+        if (kb < nblk) {
+            // wait until row block kb of R and inv(L11)_kb are in memory (bounded spin: a lost producer must not hang the GPU)
+            if (seen <= kb && !lost) {
+#pragma unroll 1
+                for (int it = 0; it < (1 << 24); ++it) {
+                    seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen > kb) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                lost = seen <= kb;   // never on a healthy device; the solve then runs through on stale bytes and is flagged
+            }
+            asm volatile("" ::: "memory");
+            double di[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) di[s] = ld_pub(Dinv + (size_t)kb * 256 + l4 + 4 * s);
+            // A operands of the later block rows, SOLVE_CH tiles at a time (register budget: 256 per wave), the next
+            // chunk in flight while the current one is consumed: element (16kb + kk + 4s, 16ib + cc) of R
+            const double* Rk = R + (size_t)(16 * kb) * ldr;   // wave-uniform
+            double a[2][SOLVE_CH][4];
+#pragma unroll
+            for (int q = 0; q < SOLVE_CH; ++q) {
+                const int ib = kb + 1 + q;
+                if (ib < 14 && ib < nblk) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) a[0][q][s] = ld_pub(Rk + (size_t)(4 * s) * ldr + 16 * ib + lane_off);
+                }
+            }
+            d4 x = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) x = mfma_f64(di[s], acc[kb][s], x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * kb + kk + 4 * r;
+                if (col < ncols && i < n) Z[(size_t)i * ldz + col] = x[r];
+            }
+#pragma unroll
+            for (int c = 0; c * SOLVE_CH < 13 - kb; ++c) {
+#pragma unroll
+                for (int q = 0; q < SOLVE_CH; ++q) {   // prefetch chunk c + 1
+                    const int ib = kb + 1 + (c + 1) * SOLVE_CH + q;
+                    if (ib < 14 && ib < nblk) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) a[(c + 1) & 1][q][s] = ld_pub(Rk + (size_t)(4 * s) * ldr + 16 * ib + lane_off);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SOLVE_CH; ++q) {
+                    const int ib = kb + 1 + c * SOLVE_CH + q;
+                    if (ib < 14 && ib < nblk) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc[ib] = mfma_f64(-a[c & 1][q][s], x[s], acc[ib]);
+                    }
+                }
+            }
+        }
+    }
+    if (lost && l == 0) atomicAdd(&info[0], 1 << 20);   // reported as ORCVIO_ERR_NOT_SPD by the host
 }
 
 // P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (n x (n+1), ldz)

@@ -222,3 +222,18 @@ def test_staged_equals_one_shot_and_multi_block_finish(upd):
     got = upd.download()
     assert rel(got['dx'], one['dx']) < 1e-9
     assert rel(got['P_new'], one['P_new']) < 1e-10
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 5])
+def test_fused_solve_equals_two_launch_solve(upd, cfg):
+    """ORCVIO_OPT_FUSED_SOLVE: the solver workgroups trailing the factorisation inside one launch give the same Z
+    (same MFMA sequence per tile) as k_potrf_reg followed by k_trsm_lds; repeated to catch a stale hand-off."""
+    w = synth.config_window(cfg)
+    upd.set_fused_solve(False)
+    ref = upd.update_features(w)
+    upd.set_fused_solve(True)
+    for _ in range(20):
+        got = upd.update_features(w)
+        assert np.array_equal(got['accept'], ref['accept'])
+        assert rel(got['dx'], ref['dx']) < 1e-12
+        assert rel(got['P_new'], ref['P_new']) < 1e-12
