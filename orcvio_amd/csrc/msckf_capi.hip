@@ -446,11 +446,9 @@ static int launch_gram(orcvio_msckf_handle* h, hipStream_t s) {
         return ORCVIO_OK;
     }
     // sparse rows: one 16x16 tile per row chunk (wave 0 of each workgroup), chunks never span two clones
-    if (h->s_chunks > 0)
-        hipLaunchKernelGGL(k_gram, dim3(1, h->s_chunks), dim3(64), 0, s, h->d_Xobs, 2 * h->nobs, 16, 0, h->d_S,
-                           (const int*)(h->d_clone_ptr + h->N + 1));
-    dim3 grid((ntiles + 3) / 4, h->chunks), block(256);
-    hipLaunchKernelGGL(k_gram, grid, block, 0, s, h->d_T3, 3 * h->F, h->NAP, h->rows_per_chunk, h->d_Gpart, (const int*)nullptr);
+    dim3 grid((ntiles + 3) / 4, h->chunks + h->s_chunks), block(256);
+    hipLaunchKernelGGL(k_gram_pair, grid, block, 0, s, h->d_T3, 3 * h->F, h->NAP, h->rows_per_chunk, h->chunks, h->d_Gpart, h->d_Xobs,
+                       2 * h->nobs, h->d_S, (const int*)(h->d_clone_ptr + h->N + 1));
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -497,7 +495,7 @@ static inline void factor_strides(const orcvio_msckf_handle* h, long& sLi, long&
 static int launch_gemm(hipStream_t s, const double* A, long sAi, long sAk, const double* B, long sBk, long sBj, int M, int N,
                        int K, double alpha, double diag_add, int upper_only, double* C, long sCi, long sCj, int* clear = nullptr) {
     const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
-    hipLaunchKernelGGL(k_gemm, dim3((tiles + 3) / 4), dim3(256), 0, s, A, sAi, sAk, B, sBk, sBj, M, N, K, alpha, diag_add,
+    hipLaunchKernelGGL(k_gemm, dim3(tiles), dim3(256), 0, s, A, sAi, sAk, B, sBk, sBj, M, N, K, alpha, diag_add,
                        upper_only, C, sCi, sCj, (const double*)nullptr, clear);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
@@ -560,7 +558,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
             return launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_RP, sLj, sLi, n, h->d_U + (size_t)NA * NP, 1, h->d_Z, ldz);
         case ST_FINISH: {
             const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
-            hipLaunchKernelGGL(k_finish_sqrt, dim3((tiles + 3) / 4), dim3(256), 0, s, h->d_Z, ldz, n, sigma2, h->d_Pout, h->d_dx,
+            hipLaunchKernelGGL(k_finish_sqrt, dim3(tiles), dim3(256), 0, s, h->d_Z, ldz, n, sigma2, h->d_Pout, h->d_dx,
                                h->objects_mode ? h->d_obj_accept : (const int*)nullptr, h->d_P);
             HIPCHK(hipGetLastError());
             return ORCVIO_OK;
@@ -919,7 +917,7 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     }
     // A' = sum_o B_o - Y^T Y  (Y = all Y_o stacked; padded rows are zero)
     hipLaunchKernelGGL(k_obj_sum_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, h->d_Gobj, nobj, W, NAP, h->d_Ab);
-    hipLaunchKernelGGL(k_gemm, dim3(((NAP / 16) * (NAP / 16) + 3) / 4), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
+    hipLaunchKernelGGL(k_gemm, dim3((NAP / 16) * (NAP / 16)), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
                        NAP, NAP, nobj * NOP, -1.0, 0.0, 0, h->d_A, (long)NAP, 1L, h->d_Ab);
     HIPCHK(hipGetLastError());
     // Kalman solve in square-root form, gate, gated write-back

@@ -581,16 +581,15 @@ __device__ __forceinline__ void tile_from_linear(int tl, int& bi, int& bj) {
     bj = tl - b * (b + 1) / 2;
 }
 
-__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int m, int NAP, int rows_per_chunk,
-                                              double* __restrict__ Gpart, const int* __restrict__ chunk_ptr = nullptr) {
+__device__ __forceinline__ void gram_body(const double* __restrict__ X, int m, int NAP, int rows_per_chunk,
+                                          double* __restrict__ Gpart, const int* __restrict__ chunk_ptr, int bx, int chunk) {
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int nb = NAP >> 4;
     const int ntiles = nb * (nb + 1) / 2;
-    const int tl = blockIdx.x * 4 + wave;
+    const int tl = bx * 4 + wave;
     if (tl >= ntiles) return;
     int bi, bj;
     tile_from_linear(tl, bi, bj);
-    const int chunk = blockIdx.y;
     int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk;
     if (chunk_ptr) { r0 = chunk_ptr[chunk]; r1 = chunk_ptr[chunk + 1]; }   // ragged chunks (one per object block)
@@ -623,6 +622,18 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int 
         const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
         out[(size_t)i * NAP + jj] = acc0[r] + acc1[r];
     }
+}
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int m, int NAP, int rows_per_chunk,
+                                              double* __restrict__ Gpart, const int* __restrict__ chunk_ptr = nullptr) {
+    gram_body(X, m, NAP, rows_per_chunk, Gpart, chunk_ptr, blockIdx.x, blockIdx.y);
+}
+// both Grams of the compression in one launch: blockIdx.y < chunks -> dense rows T3 (width NAP, uniform chunks),
+// the rest -> the sparse rows Xobs (width 16, one tile, clone-aligned ragged chunks)
+__global__ __launch_bounds__(256) void k_gram_pair(const double* __restrict__ T3, int m3, int NAP, int rows_per_chunk, int chunks,
+                                                   double* __restrict__ Gpart, const double* __restrict__ Xobs, int mx,
+                                                   double* __restrict__ S, const int* __restrict__ chunk_ptr) {
+    if ((int)blockIdx.y < chunks) gram_body(T3, m3, NAP, rows_per_chunk, Gpart, nullptr, blockIdx.x, blockIdx.y);
+    else if (blockIdx.x == 0) gram_body(Xobs, mx, 16, 0, S, chunk_ptr, 0, (int)blockIdx.y - chunks);
 }
 
 // Sums `nparts` blocks into dst (full symmetric result); used for the chunk partials of one
@@ -1031,16 +1042,19 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
     const int nb = (n + 15) >> 4;
 
     // largest diagonal entry -> pivot tolerance
-    double mx = 0.0;
-    for (int i = tid; i < n; i += 512) mx = fmax(mx, X[(size_t)i * ldx + i]);
+    double tol = 0.0;
+    if (tol_rel > 0.0) {   // uniform; chol(M) passes 0 (M >= s2 I) and skips this dependent pass over the diagonal
+        double mx = 0.0;
+        for (int i = tid; i < n; i += 512) mx = fmax(mx, X[(size_t)i * ldx + i]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-    if (l == 0) sred[wave] = mx;
-    __syncthreads();
-    mx = 0.0;
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        if (l == 0) sred[wave] = mx;
+        __syncthreads();
+        mx = 0.0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) mx = fmax(mx, sred[w]);
-    const double tol = tol_rel * mx;
+        for (int w = 0; w < 8; ++w) mx = fmax(mx, sred[w]);
+        tol = tol_rel * mx;
+    }
 
     if (wave == 0) {
         // =====================================================================================
@@ -1253,27 +1267,39 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
                                  Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr);
 }
 
-// generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j]; tiles with
-// bi <= bj only when upper_only.  One wavefront per tile.
+// generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j] [+ Cin(i,j)]; tiles with
+// bi <= bj only when upper_only.  One workgroup per 16x16 tile, split-K over its 4 wavefronts (these products
+// are latency-bound: a K = 187 chain of dependent MFMAs and its operand loads, cut to a quarter), partial tiles
+// summed through LDS in wave order (deterministic).
 __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
                                               long sBk, long sBj, int M, int N, int K, double alpha, double diag_add,
                                               int upper_only, double* __restrict__ C, long sCi, long sCj,
                                               const double* __restrict__ Cin = nullptr, int* __restrict__ clear = nullptr) {
     // clear: step counter of the k_potrf_solve launch that follows in the stream (reset here, one kernel ahead)
     if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ double sPart[3][4][64];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nti = (M + 15) >> 4, ntj = (N + 15) >> 4;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= nti * ntj) return;
+    const int ntj = (N + 15) >> 4;
+    const int tile = blockIdx.x;
     const int bi = tile / ntj, bj = tile - bi * ntj;
-    if (upper_only && bi > bj) return;
-    d4 acc = tile_product(A, sAi, sAk, B, sBk, sBj, M, N, K, 16 * bi, 16 * bj, l);
+    if (upper_only && bi > bj) return;   // whole workgroup
+    const int KS = ((K + 15) >> 4) << 2;   // k-slice per wavefront, a multiple of the MFMA depth
+    const int k0 = wave * KS;
+    const int Kw = (K - k0 < KS) ? (K - k0) : KS;   // may be <= 0: empty slice
+    d4 acc = tile_product(A + (long)k0 * sAk, sAi, sAk, B + (long)k0 * sBk, sBk, sBj, M, N, Kw, 16 * bi, 16 * bj, l);
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPart[wave - 1][r][l] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
     const int kk = l >> 4, cc = l & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+        const double v = ((acc[r] + sPart[0][r][l]) + sPart[1][r][l]) + sPart[2][r][l];
         const int i = 16 * bi + kk + 4 * r, j = 16 * bj + cc;
         if (i < M && j < N)
-            C[(long)i * sCi + (long)j * sCj] = alpha * acc[r] + ((i == j) ? diag_add : 0.0) + (Cin ? Cin[(long)i * sCi + (long)j * sCj] : 0.0);
+            C[(long)i * sCi + (long)j * sCj] = alpha * v + ((i == j) ? diag_add : 0.0) + (Cin ? Cin[(long)i * sCi + (long)j * sCj] : 0.0);
     }
 }
 
@@ -1551,29 +1577,37 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
     if (lost && l == 0) atomicAdd(&info[0], 1 << 20);   // reported as ORCVIO_ERR_NOT_SPD by the host
 }
 
-// P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (n x (n+1), ldz)
+// P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (n x (n+1), ldz).  One workgroup per lower
+// tile, split-K over its 4 wavefronts (as k_gemm).
 __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, double s2,
                                                      double* __restrict__ P_out, double* __restrict__ dx,
                                                      const int* __restrict__ apply = nullptr, const double* __restrict__ P = nullptr) {
+    __shared__ double sPart[3][4][64];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nb = (n + 1 + 15) >> 4;
-    const int ntiles = nb * (nb + 1) / 2;
-    const int tl = blockIdx.x * 4 + wave;
-    if (tl >= ntiles) return;
     int bi, bj;
-    tile_from_linear(tl, bi, bj);
-    d4 acc = tile_product(Z, 1, ldz, Z, ldz, 1, n + 1, n + 1, n, 16 * bi, 16 * bj, l);
+    tile_from_linear(blockIdx.x, bi, bj);
+    const int KS = ((n + 15) >> 4) << 2;
+    const int k0 = wave * KS;
+    const int Kw = (n - k0 < KS) ? (n - k0) : KS;
+    d4 acc = tile_product(Z + (size_t)k0 * ldz, 1, ldz, Z + (size_t)k0 * ldz, ldz, 1, n + 1, n + 1, Kw, 16 * bi, 16 * bj, l);
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPart[wave - 1][r][l] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
     const int kk = l >> 4, cc = l & 15;
+    const bool app = apply ? (*apply != 0) : true;   // gated object update: leave P and x alone if rejected
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+        const double v = ((acc[r] + sPart[0][r][l]) + sPart[1][r][l]) + sPart[2][r][l];
         const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
-        const bool app = apply ? (*apply != 0) : true;   // gated object update: leave P and x alone if rejected
         if (i < n && jj < n && jj <= i) {
-            const double pv = app ? s2 * acc[r] : 0.5 * (P[(size_t)i * n + jj] + P[(size_t)jj * n + i]);
+            const double pv = app ? s2 * v : 0.5 * (P[(size_t)i * n + jj] + P[(size_t)jj * n + i]);
             P_out[(size_t)i * n + jj] = pv;
             P_out[(size_t)jj * n + i] = pv;
         } else if (i == n && jj < n) {
-            dx[jj] = app ? acc[r] : 0.0;
+            dx[jj] = app ? v : 0.0;
         }
     }
 }
