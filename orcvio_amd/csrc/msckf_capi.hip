@@ -423,7 +423,7 @@ static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
     a.ablate = h->feat_ablate;
     const size_t lds = feat_lds_bytes(h->Mmax, h->NAP, h->N);
     const int npass = (h->NAP + 63) / 64;
-    dim3 grid(h->F), block(64);
+    dim3 grid(h->F), block(256);
     switch (npass) {
         case 1: hipLaunchKernelGGL(k_feature<1>, grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL(k_feature<2>, grid, block, lds, s, a); break;

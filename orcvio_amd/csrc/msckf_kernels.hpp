@@ -151,23 +151,38 @@ struct FeatArgs {
 __host__ __device__ inline int feat_lde(int Mmax) { return 2 * Mmax + 1; }
 __host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
     const int R2 = 2 * Mmax;
-    size_t dbl = (size_t)R2 * 7 + (size_t)R2 * 6 + R2 + (size_t)R2 * 4 + (size_t)R2 * 4 + 128 + 2 * (size_t)NAP + 4 + 64 +
+    size_t dbl = (size_t)R2 * 7 + (size_t)R2 * 6 + R2 + (size_t)R2 * 4 + 64 * 4 + 16 + 4 + 8 * (size_t)NAP + 256 + 256 +
                  (size_t)R2 * feat_lde(Mmax);
-    size_t bytes = dbl * 8 + (size_t)(N + Mmax) * 4;
+    size_t bytes = dbl * 8 + (size_t)(N + Mmax + 4) * 4;
     return (bytes + 15) & ~(size_t)15;
 }
 
+// One workgroup of four wavefronts per feature track.
+//   B, C  (wave 0)   per-observation Jacobians, Householder QR of H_f (LAPACK dgeqr2 convention)
+//   D     (all)      compact-WY coefficients of Q^T [J | r] for the column each thread owns (needed for T3)
+//   E     (4 waves)  E = J P J^T, observation l on wave l % 4: u_l = J_l P_aa from coalesced P rows (prefetched one
+//                    observation ahead), E[:, 2l..2l+1] = J u_l^T with the rows of the block in lanes
+//   G     (wave 0)   the chi-square gate WITHOUT forming the projected block: with Sh = E + s2 I (2M x 2M), Q1 the
+//                    first three columns of Q (range of H_f) and N0 the rest,
+//                        gamma = r'^T (N0^T Sh N0)^-1 r' = || (I - Pi) L^-1 r ||^2,   Sh = L L^T,
+//                    Pi the orthogonal projector onto range(L^-1 Q1)  (generalised least squares identity
+//                    N0 (N0^T Sh N0)^-1 N0^T = Sh^-1 - Sh^-1 Q1 (Q1^T Sh^-1 Q1)^-1 Q1^T Sh^-1).  Sh is factored as
+//                    16x16 MFMA tiles held in registers (DPP diagonal sweep of the Cholesky kernels, panel and
+//                    trailing tiles by MFMA on accumulator-layout operands), the four right-hand sides
+//                    [r | Q1] ride along as one more tile column, the projection is modified Gram-Schmidt.
+//   I     (all)      outputs: T3 (three dense rows), the un-projected sparse rows Xobs, optionally H'.
 template <int NPASS>
-__global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
+__global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
+    constexpr int NP4 = (NPASS + 3) / 4;   // passes of 256 threads over the NAP columns
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int j = blockIdx.x;
-    const int t = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, t = tid & 63;
     const int lo = p.obs_ptr[j];
     const int M = p.obs_ptr[j + 1] - lo;
-    if (M < 2) {
-        if (t == 0) { p.gamma[j] = NAN; p.accept[j] = 0; }
-        for (int e = t; e < 3 * p.NAP; e += 64) p.T3[(size_t)3 * j * p.NAP + e] = 0.0;
-        for (int e = t; e < 32 * M; e += 64) p.Xobs[(size_t)32 * p.obs_pos[lo + (e >> 5)] + (e & 31)] = 0.0;
+    if (M < 2) {   // whole workgroup
+        if (tid == 0) { p.gamma[j] = NAN; p.accept[j] = 0; }
+        for (int e = tid; e < 3 * p.NAP; e += 256) p.T3[(size_t)3 * j * p.NAP + e] = 0.0;
+        for (int e = tid; e < 32 * M; e += 256) p.Xobs[(size_t)32 * p.obs_pos[lo + (e >> 5)] + (e & 31)] = 0.0;
         return;
     }
     const int M2 = 2 * M;
@@ -179,290 +194,365 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
     double* sJx = sJe + R2 * 7;       // [R2][6]
     double* sR = sJx + R2 * 6;        // [R2]
     double* sV = sR + R2;             // [R2][4]  Householder vectors
-    double* sX = sV + R2 * 4;         // [R2][4]
-    double* sCol = sX + R2 * 4;       // [2][64]
-    double* sU = sCol + 128;          // [NAP][2]
-    double* sYr = sU + 2 * NAP;       // [4]
-    double* sZ = sYr + 4;             // [64]
-    double* sE = sZ + 64;             // [R2][LDE]
+    double* sB = sV + R2 * 4;         // [64][4]  right-hand sides of the gate: r, Q1
+    double* sQ = sB + 256;            // [16]     beta(3), g10, g20, g21
+    double* sYr = sQ + 16;            // [4]
+    double* sUall = sYr + 4;          // [4 waves][NAP][2]
+    double* sD = sUall + 8 * NAP;     // [16][16] diagonal tile, row view
+    double* sDi = sD + 256;           // [16][16] its inverse factor
+    double* sE = sDi + 256;           // [R2][LDE]
     int* sC2O = (int*)(sE + (size_t)R2 * LDE);   // [N]
     int* sOC = sC2O + p.N;                        // [Mmax]
+    int* sFlag = sOC + p.Mmax;                    // [4]
 
-    for (int i = t; i < p.N; i += 64) sC2O[i] = -1;
-    wave_sync();
+    for (int i = tid; i < p.N; i += 256) sC2O[i] = -1;
+    __syncthreads();
 
-    // ---- B: per-observation Jacobians (lane t <-> observation t) ---------------------
-    double a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};   // rows 2t, 2t+1 of H_f
-    if (t < M) {
-        const int o = lo + t;
-        const int ci = p.obs_clone[o];
-        double Hx[12], He[12], Hf[6], rr[2];
-        double pw[3] = {p.p_w[3 * j], p.p_w[3 * j + 1], p.p_w[3 * j + 2]};
-        double z[2] = {p.obs_z[2 * o], p.obs_z[2 * o + 1]};
-        ObsFlags f{p.use_larvio, p.use_left, p.if_fej};
-        obs_jacobian(p.poses + (size_t)ci * POSE_STRIDE, pw, z, f, Hx, He, Hf, rr);
+    if (wave == 0) {
+        // ---- B: per-observation Jacobians (lane t <-> observation t) ---------------------
+        double a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};   // rows 2t, 2t+1 of H_f
+        if (t < M) {
+            const int o = lo + t;
+            const int ci = p.obs_clone[o];
+            double Hx[12], He[12], Hf[6], rr[2];
+            double pw[3] = {p.p_w[3 * j], p.p_w[3 * j + 1], p.p_w[3 * j + 2]};
+            double z[2] = {p.obs_z[2 * o], p.obs_z[2 * o + 1]};
+            ObsFlags f{p.use_larvio, p.use_left, p.if_fej};
+            obs_jacobian(p.poses + (size_t)ci * POSE_STRIDE, pw, z, f, Hx, He, Hf, rr);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int row = 2 * t + s;
+            for (int s = 0; s < 2; ++s) {
+                const int row = 2 * t + s;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) sJe[row * 7 + e] = He[s * 6 + e];
-            sJe[row * 7 + 6] = p.estimate_td ? p.obs_zvel[2 * o + s] : 0.0;
+                for (int e = 0; e < 6; ++e) sJe[row * 7 + e] = He[s * 6 + e];
+                sJe[row * 7 + 6] = p.estimate_td ? p.obs_zvel[2 * o + s] : 0.0;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) sJx[row * 6 + c] = Hx[s * 6 + c];
-            sR[row] = rr[s];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { a0[c] = Hf[c]; a1[c] = Hf[3 + c]; }
-        sOC[t] = ci;
-        sC2O[ci] = t;
-    }
-
-    // ---- C: Householder QR of H_f (2M x 3), LAPACK dgeqr2 convention ------------------
-    const int g0 = 2 * t, g1 = 2 * t + 1;
-    double v0[3], v1[3], beta[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        double s = 0.0;
-        if (g0 > q) s += a0[q] * a0[q];
-        if (g1 > q) s += a1[q] * a1[q];
-        const double nrm2 = wave_sum(s);
-        const double alpha = __shfl((q & 1) ? a1[q] : a0[q], q >> 1);
-        double bq = 0.0, sc = 0.0;
-        if (nrm2 != 0.0) {
-            const double nu = sqrt(alpha * alpha + nrm2);
-            const double bk = (alpha >= 0.0) ? -nu : nu;
-            bq = (bk - alpha) / bk;
-            sc = 1.0 / (alpha - bk);
-        }
-        beta[q] = bq;
-        v0[q] = (g0 > q) ? a0[q] * sc : ((g0 == q) ? 1.0 : 0.0);
-        v1[q] = (g1 > q) ? a1[q] * sc : ((g1 == q) ? 1.0 : 0.0);
-#pragma unroll
-        for (int c = q + 1; c < 3; ++c) {
-            const double w = wave_sum(v0[q] * a0[c] + v1[q] * a1[c]) * bq;
-            a0[c] -= w * v0[q];
-            a1[c] -= w * v1[q];
-        }
-    }
-    if (t < M) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { sV[g0 * 4 + q] = v0[q]; sV[g1 * 4 + q] = v1[q]; }
-        sV[g0 * 4 + 3] = 0.0;
-        sV[g1 * 4 + 3] = 0.0;
-    }
-    const double g10 = wave_sum(v0[1] * v0[0] + v1[1] * v1[0]);
-    const double g20 = wave_sum(v0[2] * v0[0] + v1[2] * v1[0]);
-    const double g21 = wave_sum(v0[2] * v0[1] + v1[2] * v1[1]);
-    wave_sync();
-
-    // ---- D: compact-WY coefficients y_q[a] of Q^T [J | r] for the columns this lane owns
-    double yq[NPASS][3];
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        const int a = t + 64 * ps;
-        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-        if (a < 7 || a == NA) {
-            for (int i = 0; i < M2; ++i) {
-                const double val = (a < 7) ? sJe[i * 7 + a] : sR[i];
-                w0 += sV[i * 4 + 0] * val;
-                w1 += sV[i * 4 + 1] * val;
-                w2 += sV[i * 4 + 2] * val;
+                for (int c = 0; c < 6; ++c) sJx[row * 6 + c] = Hx[s * 6 + c];
+                sR[row] = rr[s];
             }
-        } else if (a >= cb0 && a < NA) {
-            const int cl = (a - cb0) / 6, cc = (a - cb0) - 6 * cl;
-            const int k = sC2O[cl];
-            if (k >= 0) {
-                const double x0 = sJx[(2 * k) * 6 + cc], x1 = sJx[(2 * k + 1) * 6 + cc];
-                w0 = sV[(2 * k) * 4 + 0] * x0 + sV[(2 * k + 1) * 4 + 0] * x1;
-                w1 = sV[(2 * k) * 4 + 1] * x0 + sV[(2 * k + 1) * 4 + 1] * x1;
-                w2 = sV[(2 * k) * 4 + 2] * x0 + sV[(2 * k + 1) * 4 + 2] * x1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a0[c] = Hf[c]; a1[c] = Hf[3 + c]; }
+            sOC[t] = ci;
+            sC2O[ci] = t;
+        }
+
+        // ---- C: Householder QR of H_f (2M x 3), LAPACK dgeqr2 convention ------------------
+        const int g0 = 2 * t, g1 = 2 * t + 1;
+        double v0[3], v1[3], beta[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double s = 0.0;
+            if (g0 > q) s += a0[q] * a0[q];
+            if (g1 > q) s += a1[q] * a1[q];
+            const double nrm2 = wave_sum(s);
+            const double alpha = __shfl((q & 1) ? a1[q] : a0[q], q >> 1);
+            double bq = 0.0, sc = 0.0;
+            if (nrm2 != 0.0) {
+                const double nu = sqrt(alpha * alpha + nrm2);
+                const double bk = (alpha >= 0.0) ? -nu : nu;
+                bq = (bk - alpha) / bk;
+                sc = 1.0 / (alpha - bk);
+            }
+            beta[q] = bq;
+            v0[q] = (g0 > q) ? a0[q] * sc : ((g0 == q) ? 1.0 : 0.0);
+            v1[q] = (g1 > q) ? a1[q] * sc : ((g1 == q) ? 1.0 : 0.0);
+#pragma unroll
+            for (int c = q + 1; c < 3; ++c) {
+                const double w = wave_sum(v0[q] * a0[c] + v1[q] * a1[c]) * bq;
+                a0[c] -= w * v0[q];
+                a1[c] -= w * v1[q];
             }
         }
-        const double y0 = beta[0] * w0;
-        const double y1 = beta[1] * (w1 - g10 * y0);
-        const double y2 = beta[2] * (w2 - g20 * y0 - g21 * y1);
-        yq[ps][0] = y0; yq[ps][1] = y1; yq[ps][2] = y2;
-        if (a == NA) { sYr[0] = y0; sYr[1] = y1; sYr[2] = y2; }
+        if (t < M) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { sV[g0 * 4 + q] = v0[q]; sV[g1 * 4 + q] = v1[q]; }
+            sV[g0 * 4 + 3] = 0.0;
+            sV[g1 * 4 + 3] = 0.0;
+        }
+        const double g10 = wave_sum(v0[1] * v0[0] + v1[1] * v1[0]);
+        const double g20 = wave_sum(v0[2] * v0[0] + v1[2] * v1[0]);
+        const double g21 = wave_sum(v0[2] * v0[1] + v1[2] * v1[1]);
+        if (t == 0) { sQ[0] = beta[0]; sQ[1] = beta[1]; sQ[2] = beta[2]; sQ[3] = g10; sQ[4] = g20; sQ[5] = g21; }
+        wave_sync();
+        // right-hand sides of the gate, row t: [r | Q1],  Q = H0 H1 H2,  Q e_q = e_q - V z,
+        // z2 = b2 w2, z1 = b1 (w1 - g21 z2), z0 = b0 (w0 - g10 z1 - g20 z2),  w = V^T e_q = row q of V
+        {
+            double b4[4] = {0, 0, 0, 0};
+            if (t < M2) {
+                b4[0] = sR[t];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double w0 = sV[q * 4 + 0], w1 = sV[q * 4 + 1], w2 = sV[q * 4 + 2];
+                    const double z2 = beta[2] * w2;
+                    const double z1 = beta[1] * (w1 - g21 * z2);
+                    const double z0 = beta[0] * (w0 - g10 * z1 - g20 * z2);
+                    b4[1 + q] = ((t == q) ? 1.0 : 0.0) - (sV[t * 4 + 0] * z0 + sV[t * 4 + 1] * z1 + sV[t * 4 + 2] * z2);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sB[t * 4 + q] = b4[q];
+        }
     }
-    wave_sync();
+    __syncthreads();
 
-    // row-lane data: lane t <-> row t of the 2M-row block
-    const bool rowlane = t < M2;
-    double je[7], jx[6], vr[3];
-    int ja0 = 0;
-#pragma unroll
-    for (int e = 0; e < 7; ++e) je[e] = rowlane ? sJe[t * 7 + e] : 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) jx[c] = rowlane ? sJx[t * 6 + c] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) vr[q] = rowlane ? sV[t * 4 + q] : 0.0;
-    if (rowlane) ja0 = cb0 + 6 * sOC[t >> 1];
-    double rp = 0.0;   // projected residual of this row
-    if (rowlane) rp = sR[t] - (vr[0] * sYr[0] + vr[1] * sYr[1] + vr[2] * sYr[2]);
-
-    // ---- E: E = J P_aa J^T via u_l = (J_l P_aa) with coalesced P row loads ------------
-    double pe[NPASS][7];
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        const int a = t + 64 * ps;
-#pragma unroll
-        for (int e = 0; e < 7; ++e) pe[ps][e] = p.P[(size_t)(15 + e) * n + 15 + (a < NA ? a : NA - 1)];
-    }
-    // With estimate_extrin = estimate_td = 0 (every shipped config) the extrinsic / td rows and columns of P are
-    // exactly zero (src/orcvio.cpp:213-221): those 7 of the 13 terms then vanish identically and are skipped.
-    bool pe_nz = false;
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-        for (int e = 0; e < 7; ++e) pe_nz |= (pe[ps][e] != 0.0);
-    const bool ext_live = __any(pe_nz);   // wave-uniform
-    // P rows of the clone of observation l are prefetched one iteration ahead (18 coalesced loads in
-    // flight while the previous observation is being consumed)
-    double pcur[NPASS][6], pnxt[NPASS][6];
+    // ---- D: compact-WY coefficients y_q[a] of Q^T [J | r] for the columns this thread owns
+    double yq[NP4][3];
     {
-        const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[0]) * n + 15;
+        const double be0 = sQ[0], be1 = sQ[1], be2 = sQ[2], g10 = sQ[3], g20 = sQ[4], g21 = sQ[5];
+#pragma unroll
+        for (int ps = 0; ps < NP4; ++ps) {
+            const int a = tid + 256 * ps;
+            double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+            if (a < 7 || a == NA) {
+                for (int i = 0; i < M2; ++i) {
+                    const double val = (a < 7) ? sJe[i * 7 + a] : sR[i];
+                    w0 += sV[i * 4 + 0] * val;
+                    w1 += sV[i * 4 + 1] * val;
+                    w2 += sV[i * 4 + 2] * val;
+                }
+            } else if (a >= cb0 && a < NA) {
+                const int cl = (a - cb0) / 6, cc = (a - cb0) - 6 * cl;
+                const int k = sC2O[cl];
+                if (k >= 0) {
+                    const double x0 = sJx[(2 * k) * 6 + cc], x1 = sJx[(2 * k + 1) * 6 + cc];
+                    w0 = sV[(2 * k) * 4 + 0] * x0 + sV[(2 * k + 1) * 4 + 0] * x1;
+                    w1 = sV[(2 * k) * 4 + 1] * x0 + sV[(2 * k + 1) * 4 + 1] * x1;
+                    w2 = sV[(2 * k) * 4 + 2] * x0 + sV[(2 * k + 1) * 4 + 2] * x1;
+                }
+            }
+            const double y0 = be0 * w0;
+            const double y1 = be1 * (w1 - g10 * y0);
+            const double y2 = be2 * (w2 - g20 * y0 - g21 * y1);
+            yq[ps][0] = y0; yq[ps][1] = y1; yq[ps][2] = y2;
+        }
+    }
+
+    // ---- E: E = J P_aa J^T, observation l on wave l % 4 ---------------------------------
+    {
+        double* sU = sUall + (size_t)wave * 2 * NAP;
+        // row-lane data: lane t <-> row t of the 2M-row block
+        const bool rowlane = t < M2;
+        double je[7], jx[6];
+        int ja0 = 0;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) je[e] = rowlane ? sJe[t * 7 + e] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) jx[c] = rowlane ? sJx[t * 6 + c] : 0.0;
+        if (rowlane) ja0 = cb0 + 6 * sOC[t >> 1];
+        double pe[NPASS][7];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int a = t + 64 * ps;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) pcur[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
+            for (int e = 0; e < 7; ++e) pe[ps][e] = p.P[(size_t)(15 + e) * n + 15 + (a < NA ? a : NA - 1)];
         }
-    }
-    for (int l = 0; l < ((p.ablate & 1) ? 0 : M); ++l) {
-        if (l + 1 < M) {
-            const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[l + 1]) * n + 15;
+        // With estimate_extrin = estimate_td = 0 (every shipped config) the extrinsic / td rows and columns of P are
+        // exactly zero (src/orcvio.cpp:213-221): those 7 of the 13 terms then vanish identically and are skipped.
+        bool pe_nz = false;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int e = 0; e < 7; ++e) pe_nz |= (pe[ps][e] != 0.0);
+        const bool ext_live = __any(pe_nz);   // wave-uniform (and the same on every wave: same loads)
+        const int lend = (p.ablate & 1) ? 0 : M;
+        double pcur[NPASS][6], pnxt[NPASS][6];
+        if (wave < lend) {
+            const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[wave]) * n + 15;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int a = t + 64 * ps;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) pnxt[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
+                for (int c = 0; c < 6; ++c) pcur[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
             }
         }
-        double jl0e[7], jl1e[7], jl0x[6], jl1x[6];
+        for (int l = wave; l < lend; l += 4) {
+            if (l + 4 < lend) {
+                const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[l + 4]) * n + 15;
 #pragma unroll
-        for (int e = 0; e < 7; ++e) { jl0e[e] = sJe[(2 * l) * 7 + e]; jl1e[e] = sJe[(2 * l + 1) * 7 + e]; }
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int a = t + 64 * ps;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) { jl0x[c] = sJx[(2 * l) * 6 + c]; jl1x[c] = sJx[(2 * l + 1) * 6 + c]; }
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int a = t + 64 * ps;
-            if (a < NA) {
-                double u0 = 0.0, u1 = 0.0;
-                if (ext_live) {
-#pragma unroll
-                    for (int e = 0; e < 7; ++e) { u0 += jl0e[e] * pe[ps][e]; u1 += jl1e[e] * pe[ps][e]; }
+                    for (int c = 0; c < 6; ++c) pnxt[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
                 }
+            }
+            double jl0e[7], jl1e[7], jl0x[6], jl1x[6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    u0 += jl0x[c] * pcur[ps][c];
-                    u1 += jl1x[c] * pcur[ps][c];
+            for (int e = 0; e < 7; ++e) { jl0e[e] = sJe[(2 * l) * 7 + e]; jl1e[e] = sJe[(2 * l + 1) * 7 + e]; }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { jl0x[c] = sJx[(2 * l) * 6 + c]; jl1x[c] = sJx[(2 * l + 1) * 6 + c]; }
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int a = t + 64 * ps;
+                if (a < NA) {
+                    double u0 = 0.0, u1 = 0.0;
+                    if (ext_live) {
+#pragma unroll
+                        for (int e = 0; e < 7; ++e) { u0 += jl0e[e] * pe[ps][e]; u1 += jl1e[e] * pe[ps][e]; }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        u0 += jl0x[c] * pcur[ps][c];
+                        u1 += jl1x[c] * pcur[ps][c];
+                    }
+                    sU[2 * a] = u0;
+                    sU[2 * a + 1] = u1;
                 }
-                sU[2 * a] = u0;
-                sU[2 * a + 1] = u1;
             }
-        }
-        wave_sync();
-        if (rowlane) {
-            double e0 = 0.0, e1 = 0.0;
-            if (ext_live) {   // P symmetric: zero rows <=> zero columns, so u at the ext columns is zero too
-#pragma unroll
-                for (int e = 0; e < 7; ++e) { e0 += je[e] * sU[2 * e]; e1 += je[e] * sU[2 * e + 1]; }
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { e0 += jx[c] * sU[2 * (ja0 + c)]; e1 += jx[c] * sU[2 * (ja0 + c) + 1]; }
-            sE[t * LDE + 2 * l] = e0;
-            sE[t * LDE + 2 * l + 1] = e1;
-        }
-        wave_sync();
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) pcur[ps][c] = pnxt[ps][c];
-    }
-
-    // row of E into registers (static indexing: full unroll)
-    double row[64];
-#pragma unroll
-    for (int c = 0; c < 64; ++c) row[c] = (rowlane && c < M2) ? sE[t * LDE + c] : 0.0;
-
-    // ---- F: E' = Q^T E Q through the compact-WY form ----------------------------------
-    if (!(p.ablate & 2)) {
-        double W0 = 0.0, W1 = 0.0, W2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            if (c < M2) {
-                W0 += row[c] * sV[c * 4 + 0];
-                W1 += row[c] * sV[c * 4 + 1];
-                W2 += row[c] * sV[c * 4 + 2];
-            }
-        }
-        const double c00 = wave_sum(vr[0] * W0), c01 = wave_sum(vr[0] * W1), c02 = wave_sum(vr[0] * W2);
-        const double c11 = wave_sum(vr[1] * W1), c12 = wave_sum(vr[1] * W2), c22 = wave_sum(vr[2] * W2);
-        const double T00 = beta[0], T11 = beta[1], T22 = beta[2];
-        const double T01 = -beta[0] * g10 * beta[1];
-        const double T02 = -beta[2] * (T00 * g20 + T01 * g21);
-        const double T12 = -beta[2] * T11 * g21;
-        // X = W T
-        const double X0 = W0 * T00;
-        const double X1 = W0 * T01 + W1 * T11;
-        const double X2 = W0 * T02 + W1 * T12 + W2 * T22;
-        // Mid = T^T C3 T  (C3 symmetric)
-        const double d00 = c00 * T00, d01 = c00 * T01 + c01 * T11, d02 = c00 * T02 + c01 * T12 + c02 * T22;
-        const double d10 = c01 * T00, d11 = c01 * T01 + c11 * T11, d12 = c01 * T02 + c11 * T12 + c12 * T22;
-        const double d20 = c02 * T00, d21 = c02 * T01 + c12 * T11, d22 = c02 * T02 + c12 * T12 + c22 * T22;
-        const double m00 = T00 * d00, m01 = T00 * d01, m02 = T00 * d02;
-        const double m11 = T01 * d01 + T11 * d11, m12 = T01 * d02 + T11 * d12;
-        const double m22 = T02 * d02 + T12 * d12 + T22 * d22;
-        (void)d10; (void)d20; (void)d21;
-        const double xt0 = X0 - 0.5 * (vr[0] * m00 + vr[1] * m01 + vr[2] * m02);
-        const double xt1 = X1 - 0.5 * (vr[0] * m01 + vr[1] * m11 + vr[2] * m12);
-        const double xt2 = X2 - 0.5 * (vr[0] * m02 + vr[1] * m12 + vr[2] * m22);
-        if (rowlane) { sX[t * 4 + 0] = xt0; sX[t * 4 + 1] = xt1; sX[t * 4 + 2] = xt2; sX[t * 4 + 3] = 0.0; }
-        sZ[t] = rp;
-        wave_sync();
-#pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            if (c < M2) {
-                row[c] -= vr[0] * sX[c * 4 + 0] + vr[1] * sX[c * 4 + 1] + vr[2] * sX[c * 4 + 2] +
-                          xt0 * sV[c * 4 + 0] + xt1 * sV[c * 4 + 1] + xt2 * sV[c * 4 + 2];
-            }
-        }
-        // lane 0 becomes the augmented right-hand-side row (rows 0..2 are the discarded part)
-#pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            if (c < M2) {
-                const double rc = sZ[c];
-                if (t == 0) row[c] = rc;
-            }
-        }
-    }
-
-    // ---- G: gamma = r'^T (E'[3:,3:] + sigma2 I)^-1 r' by a right-looking Cholesky with the
-    //         matrix rows in registers and the pivot column broadcast through LDS -------------
-    double gam = 0.0;
-    bool fail = false;
-#pragma unroll
-    for (int jc = 3; jc < 64; ++jc) {
-        if (jc < M2 && !(p.ablate & 4)) {
-            const double d = bcast_lane(row[jc], jc) + p.sigma2;
-            if (!(d > 0.0)) fail = true;
-            const double inv = rsqrt_nr(d);
-            const double lr = row[jc] * inv;
-            double* col = sCol + 64 * (jc & 1);
-            col[t] = lr;
             wave_sync();
-            if (t == 0) gam += lr * lr;
+            if (rowlane) {
+                double e0 = 0.0, e1 = 0.0;
+                if (ext_live) {   // P symmetric: zero rows <=> zero columns, so u at the ext columns is zero too
 #pragma unroll
-            for (int c = jc + 1; c < 64; ++c) row[c] -= lr * col[c];
+                    for (int e = 0; e < 7; ++e) { e0 += je[e] * sU[2 * e]; e1 += je[e] * sU[2 * e + 1]; }
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { e0 += jx[c] * sU[2 * (ja0 + c)]; e1 += jx[c] * sU[2 * (ja0 + c) + 1]; }
+                sE[t * LDE + 2 * l] = e0;
+                sE[t * LDE + 2 * l + 1] = e1;
+            }
+            wave_sync();
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) pcur[ps][c] = pnxt[ps][c];
         }
     }
-    gam = __shfl(gam, 0);
-    const int dof = M2 - 3;
-    const bool ok = (!fail) && (gam < p.chi2[dof]);
-    if (t == 0) {
-        p.gamma[j] = fail ? NAN : gam;
-        p.accept[j] = ok ? 1 : 0;
+    __syncthreads();
+
+    // ---- G: the gate (wave 0) ---------------------------------------------------------------
+    if (wave == 0) {
+        const int kk = t >> 4, cc = t & 15;
+        const int nbk = (M2 + 15) >> 4;
+        d4 S[4][4], Bt[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * a + kk + 4 * r;
+                Bt[a][r] = (i < M2 && cc < 4) ? sB[i * 4 + (cc & 3)] : 0.0;
+            }
+#pragma unroll
+            for (int b = a; b < 4; ++b) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * a + kk + 4 * r, c = 16 * b + cc;
+                    const bool in = i < M2 && c < M2;
+                    const double ev = sE[(in ? i : 0) * LDE + (in ? c : 0)];
+                    S[a][b][r] = in ? (ev + ((i == c) ? p.sigma2 : 0.0)) : 0.0;
+                }
+            }
+        }
+        int nzero = 0, nneg = 0;
+        if (!(p.ablate & 4)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < nbk) {
+                    // diagonal tile: accumulator layout -> rows in lanes, factor + invert in one DPP sweep
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sD[(kk + 4 * r) * 16 + cc] = S[k][k][r];
+                    wave_sync();
+                    double v[16], y[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const double av = sD[cc * 16 + c];
+                        v[c] = (c <= cc) ? av : 0.0;
+                        y[c] = (c == cc) ? 1.0 : 0.0;
+                    }
+                    DiagStep<0>::run(v, y, 0.0, M2 - 16 * k, nzero, nneg);
+                    if (t < 16) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) sDi[c * 16 + t] = y[c];   // Linv[c][t]
+                    }
+                    wave_sync();
+                    double li[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) li[s4] = sDi[cc * 16 + kk + 4 * s4];
+                    wave_sync();
+                    // panel: row block k of the factor (transposed) and of the right-hand sides
+#pragma unroll
+                    for (int b = k + 1; b < 4; ++b) {
+                        if (b < nbk) {
+                            d4 x = {0, 0, 0, 0};
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], S[k][b][s4], x);
+                            S[k][b] = x;
+                        }
+                    }
+                    {
+                        d4 x = {0, 0, 0, 0};
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], Bt[k][s4], x);
+                        Bt[k] = x;
+                    }
+                    // trailing tiles
+#pragma unroll
+                    for (int a = k + 1; a < 4; ++a) {
+                        if (a < nbk) {
+#pragma unroll
+                            for (int b = a; b < 4; ++b) {
+                                if (b < nbk) {
+#pragma unroll
+                                    for (int s4 = 0; s4 < 4; ++s4) S[a][b] = mfma_f64(-S[k][a][s4], S[k][b][s4], S[a][b]);
+                                }
+                            }
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) Bt[a] = mfma_f64(-S[k][a][s4], Bt[k][s4], Bt[a]);
+                        }
+                    }
+                }
+            }
+        }
+        // y = L^-1 r (column 0), Y = L^-1 Q1 (columns 1..3): every lane gathers its 16 rows of all four columns, then
+        // modified Gram-Schmidt (redundantly on every lane; sums over the four 16-lane rows by two butterflies)
+        double c0[16], c1[16], c2[16], c3[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = Bt[k][r];
+                c0[4 * k + r] = dpp_row_bcast<0>(v);
+                c1[4 * k + r] = dpp_row_bcast<1>(v);
+                c2[4 * k + r] = dpp_row_bcast<2>(v);
+                c3[4 * k + r] = dpp_row_bcast<3>(v);
+            }
+        }
+        auto red = [&](double x) -> double {
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            return x;
+        };
+        auto dot = [&](const double (&a)[16], const double (&b)[16]) -> double {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) { s0 += a[i] * b[i]; s1 += a[i + 1] * b[i + 1]; }
+            return s0 + s1;
+        };
+        auto axpy = [&](double (&y)[16], double al, const double (&x)[16]) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i] -= al * x[i];
+        };
+        {
+            const double n1 = red(dot(c1, c1)), d12 = red(dot(c1, c2)), d13 = red(dot(c1, c3)), d1y = red(dot(c1, c0));
+            const double i1 = (n1 > 0.0) ? 1.0 / n1 : 0.0;
+            axpy(c2, d12 * i1, c1); axpy(c3, d13 * i1, c1); axpy(c0, d1y * i1, c1);
+            const double n2 = red(dot(c2, c2)), d23 = red(dot(c2, c3)), d2y = red(dot(c2, c0));
+            const double i2 = (n2 > 0.0) ? 1.0 / n2 : 0.0;
+            axpy(c3, d23 * i2, c2); axpy(c0, d2y * i2, c2);
+            const double n3 = red(dot(c3, c3)), d3y = red(dot(c3, c0));
+            const double i3 = (n3 > 0.0) ? 1.0 / n3 : 0.0;
+            axpy(c0, d3y * i3, c3);
+        }
+        const double gam = red(dot(c0, c0));
+        const bool fail = (nzero + nneg) > 0 || !(gam == gam);
+        const int dof = M2 - 3;
+        const bool ok = (!fail) && (gam < p.chi2[dof]);
+        if (t == 0) {
+            p.gamma[j] = fail ? NAN : gam;
+            p.accept[j] = ok ? 1 : 0;
+            sFlag[0] = ok ? 1 : 0;
+        }
     }
+    __syncthreads();
+    const bool ok = sFlag[0] != 0;
 
     // ---- I: outputs -------------------------------------------------------------------------
     // The compression needs only  H'^T H' = X^T X - T3^T T3  (X = [J | r] un-projected, T3 = rows 0..2 of
@@ -471,8 +561,8 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
     // itself is materialised only on request (p.Hs != nullptr; tests and callers that want H').
     if (p.ablate & 8) return;
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        const int a = t + 64 * ps;
+    for (int ps = 0; ps < NP4; ++ps) {
+        const int a = tid + 256 * ps;
         if (a < NAP) {
             int kobs = -1, cc = 0;
             if (a >= cb0 && a < NA) {
@@ -510,7 +600,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatArgs p) {
     }
     // un-projected rows of this track: [H_e(6) td | H_x(6) | r | 0 0], 16 doubles per row, stored at the
     // observation's position in the clone-sorted order (so that k_gram reads every clone contiguously)
-    for (int e = t; e < 16 * M2; e += 64) {
+    for (int e = tid; e < 16 * M2; e += 256) {
         const int row = e >> 4, c = e & 15;
         double v = 0.0;
         if (ok && c < 14) v = (c < 7) ? sJe[row * 7 + c] : ((c < 13) ? sJx[row * 6 + (c - 7)] : sR[row]);
