@@ -475,11 +475,12 @@ static int launch_potrf(orcvio_msckf_handle* h, hipStream_t s, const double* X, 
     const int NP = h->NP;
     if (h->reg_path) {
         const int nb = (nn + 15) / 16, noff = nb * (nb - 1) / 2;
-        const int need = (noff + 6) / 7;   // wave 0 keeps the diagonal tiles in LDS, waves 1..7 the rest in registers
+        const int need = potrf_slots_needed(nb);   // wave 0 keeps the diagonal tiles in LDS, the workers the rest in registers
+        (void)noff;
         if (need <= 4) hipLaunchKernelGGL(k_potrf_reg<4>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
         else if (need <= 8) hipLaunchKernelGGL(k_potrf_reg<8>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
         else if (need <= 12) hipLaunchKernelGGL(k_potrf_reg<12>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
-        else hipLaunchKernelGGL(k_potrf_reg<14>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
+        else hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
     } else {
         HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * NP, X, sizeof(double) * ldx, sizeof(double) * nn, nn, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, out, nn, NP, tol_rel, Dinv, info);
@@ -538,7 +539,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
             return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, n, n, NA, 1.0, sigma2, 1, h->d_M, NP, 1, h->d_flag);
         case ST_POTRF_M:
             if (fused_solve_active(h)) {   // chol(M) + Z = L_M^-1 [Lf^T | g] in one launch (solver workgroups trail the factorisation)
-                const int nbm = (n + 15) / 16, noff = nbm * (nbm - 1) / 2, need = (noff + 6) / 7;
+                const int nbm = (n + 15) / 16, need = potrf_slots_needed(nbm);
                 const int ncb = (n + 1 + 15) / 16;
                 const dim3 grid(1 + (ncb + SOLVE_WPB - 1) / SOLVE_WPB), block(512);
                 const double* g = h->d_U + (size_t)NA * NP;
@@ -547,7 +548,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
                 if (need <= 4) LAUNCH_PS(4);
                 else if (need <= 8) LAUNCH_PS(8);
                 else if (need <= 12) LAUNCH_PS(12);
-                else LAUNCH_PS(14);
+                else LAUNCH_PS(16);
 #undef LAUNCH_PS
                 HIPCHK(hipGetLastError());
                 return ORCVIO_OK;
@@ -901,7 +902,7 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     }
     // F_o = Hf^T Hf (lower tiles of the bottom-right block) -> R_F ; Y_o = L_F^-1 C_o
     {
-        const int nbf = NOP / 16, need = (nbf * (nbf - 1) / 2 + 6) / 7;
+        const int nbf = NOP / 16, need = potrf_slots_needed(nbf);
         const double* F0 = h->d_Gobj + (size_t)NAP * W + NAP;
         const double tolF = (double)no_max * 2.220446049250313e-16;
         if (need <= 4)
@@ -1273,11 +1274,11 @@ int32_t orcvio_msckf_debug_potrf_ablate(orcvio_msckf_handle* h, int32_t ablate, 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep)
-        hipLaunchKernelGGL(k_potrf_reg<12>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
+        hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
                            h->d_info + 6, (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, ablate);
     HIPCHK(hipEventRecord(e0, h->stream));
     for (int rep = 0; rep < reps; ++rep)
-        hipLaunchKernelGGL(k_potrf_reg<12>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
+        hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
                            h->d_info + 6, (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, ablate);
     HIPCHK(hipEventRecord(e1, h->stream));
     HIPCHK(hipEventSynchronize(e1));
@@ -1286,6 +1287,23 @@ int32_t orcvio_msckf_debug_potrf_ablate(orcvio_msckf_handle* h, int32_t ablate, 
     *us_out = 1e3 * ms / reps;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return ORCVIO_OK;
+}
+
+// Diagnostic: core-clock stamps of one k_potrf_reg<12> run on the handle's current P (256 values; layout in potrf_reg_body)
+int32_t orcvio_msckf_debug_potrf_stamps(orcvio_msckf_handle* h, unsigned long long* out256) {
+    if (!h || !h->uploaded || !h->reg_path || !out256) return ORCVIO_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 256));
+    HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 256));
+    const int n = h->n, NP = h->NP;
+    for (int rep = 0; rep < 4; ++rep)
+        hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
+                           h->d_info + 6, d, (size_t)0, (size_t)0, (size_t)0, 0, 0);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out256, d, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
     return ORCVIO_OK;
 }
 

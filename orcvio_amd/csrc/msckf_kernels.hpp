@@ -74,47 +74,100 @@ template <int C>
 __device__ __forceinline__ void dpp_fnmac(double& acc, double a, double b) {   // acc -= a[lane C of the row] * b
     asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(C));
 }
-template <int J, int C>
-struct DiagUpd {
-    static __device__ __forceinline__ void run(double (&v)[16], double (&y)[16], double m, double x) {
-        dpp_fnmac<C>(v[C], m, m);   // A[r][C] -= L[C][J] * L[r][J]
-        dpp_fnmac<C>(y[C], m, x);   // Linv[C][r] -= L[C][J] * Linv[J][r]
-        DiagUpd<J, C + 1>::run(v, y, m, x);
-    }
-};
-template <int J>
-struct DiagUpd<J, 16> {
-    static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double, double) {}
-};
 // right-looking Cholesky + inverse of a 16x16 tile: lane (l & 15) holds row r of the tile in v[] and
 // column r of the inverse in y[]; the four 16-lane rows of the wavefront work redundantly.
-template <int J>
-struct DiagStep {
-    static __device__ __forceinline__ void run(double (&v)[16], double (&y)[16], double tol, int nlive, int& nzero, int& nneg) {
-        const double d = dpp_row_bcast<J>(v[J]);
+//
+// The sweep is a chain of 16 dependent pivots (broadcast, rsqrt, two Newton steps, scale) with 2 (15-J) independent
+// rank-1 updates hanging off each.  A wavefront issues in order, so the schedule is written out by hand: pivot J
+// first updates column J+1 only, the reciprocal square root of pivot J+1 is started at once, and the remaining
+// updates of pivot J are issued between its Newton steps.  Every arithmetic instruction is volatile inline asm to
+// pin that order (the compiler would otherwise sink the independent updates behind the dependent chain).
+__device__ __forceinline__ double asm_mul(double a, double b) {
+    double d;
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double asm_fnma(double a, double b, double c) {   // c - a*b
+    double d;
+    asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double asm_rsq(double a) {
+    double d;
+    asm volatile("v_rsq_f64 %0, %1" : "=v"(d) : "v"(a));
+    return d;
+}
+template <int J, int C>
+__device__ __forceinline__ void diag_fill(double (&v)[16], double (&y)[16], double m, double x) {
+    if constexpr (C < 16) {
+        dpp_fnmac<C>(v[C], m, m);   // A[r][C] -= L[C][J] * L[r][J]
+        dpp_fnmac<C>(y[C], m, x);   // Linv[C][r] -= L[C][J] * Linv[J][r]
+    }
+}
+struct PivotScale {   // 1/sqrt(d) of a pivot, 0 for a dropped one; counters of dropped / negative pivots
+    template <int J>
+    static __device__ __forceinline__ bool classify(double d, double tol, int nlive, int& nzero, int& nneg) {
         const bool live = J < nlive;
         const bool ok = live && (d > tol);
         nzero += (live && !ok) ? 1 : 0;
         nneg += (live && d < -tol) ? 1 : 0;
-        double inv = __builtin_amdgcn_rsq(ok ? d : 1.0);
-        const double h = 0.5 * d;
-        inv = inv * (1.5 - h * inv * inv);
-        inv = inv * (1.5 - h * inv * inv);
-        inv = ok ? inv : 0.0;
-        const double m = v[J] * inv;
-        const double x = y[J] * inv;
-        v[J] = m;
-        y[J] = x;
-        asm volatile("s_nop 1" ::"v"(m), "v"(x));
-        DiagUpd<J, J + 1>::run(v, y, m, x);
-        DiagStep<J + 1>::run(v, y, tol, nlive, nzero, nneg);
+        return ok;
     }
 };
-template <>
-struct DiagStep<16> {
-    static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double, int, int&, int&) {}
+template <int J>
+struct DiagStep {
+    // inv: scale of pivot J (already masked)
+    static __device__ __forceinline__ void step(double (&v)[16], double (&y)[16], double inv, double c15, double tol, int nlive,
+                                                int& nzero, int& nneg) {
+        const double m = asm_mul(v[J], inv);
+        const double x = asm_mul(y[J], inv);
+        v[J] = m;
+        y[J] = x;
+        if constexpr (J + 1 < 16) {
+            asm volatile("s_nop 1" ::"v"(m), "v"(x));
+            dpp_fnmac<J + 1>(v[J + 1], m, m);
+            const double d = dpp_row_bcast<J + 1>(v[J + 1]);   // (leading s_nop 1 inside)
+            const bool ok = PivotScale::classify<J + 1>(d, tol, nlive, nzero, nneg);
+            const double r0 = asm_rsq(ok ? d : 1.0);
+            const double h = asm_mul(d, 0.5);
+            dpp_fnmac<J + 1>(y[J + 1], m, x);
+            diag_fill<J, J + 2>(v, y, m, x);
+            const double t1 = asm_mul(r0, r0);
+            diag_fill<J, J + 3>(v, y, m, x);
+            const double t2 = asm_fnma(h, t1, c15);
+            diag_fill<J, J + 4>(v, y, m, x);
+            const double r1 = asm_mul(r0, t2);
+            diag_fill<J, J + 5>(v, y, m, x);
+            const double t3 = asm_mul(r1, r1);
+            diag_fill<J, J + 6>(v, y, m, x);
+            const double t4 = asm_fnma(h, t3, c15);
+            diag_fill<J, J + 7>(v, y, m, x);
+            const double r2 = asm_mul(r1, t4);
+            diag_fill<J, J + 8>(v, y, m, x);
+            diag_fill<J, J + 9>(v, y, m, x);
+            diag_fill<J, J + 10>(v, y, m, x);
+            diag_fill<J, J + 11>(v, y, m, x);
+            diag_fill<J, J + 12>(v, y, m, x);
+            diag_fill<J, J + 13>(v, y, m, x);
+            diag_fill<J, J + 14>(v, y, m, x);
+            diag_fill<J, J + 15>(v, y, m, x);
+            DiagStep<J + 1>::step(v, y, ok ? r2 : 0.0, c15, tol, nlive, nzero, nneg);
+        }
+    }
+    static __device__ __forceinline__ void run(double (&v)[16], double (&y)[16], double tol, int nlive, int& nzero, int& nneg) {
+        static_assert(J == 0, "the sweep starts at pivot 0");
+        double c15 = 1.5;
+        asm volatile("" : "+v"(c15));   // keep 1.5 in a register pair (not an inline constant)
+        const double d = dpp_row_bcast<0>(v[0]);
+        const bool ok = PivotScale::classify<0>(d, tol, nlive, nzero, nneg);
+        const double r0 = asm_rsq(ok ? d : 1.0);
+        const double h = asm_mul(d, 0.5);
+        asm volatile("s_nop 1" ::"v"(r0));
+        const double r1 = asm_mul(r0, asm_fnma(h, asm_mul(r0, r0), c15));
+        const double r2 = asm_mul(r1, asm_fnma(h, asm_mul(r1, r1), c15));
+        step(v, y, ok ? r2 : 0.0, c15, tol, nlive, nzero, nneg);
+    }
 };
-
 __device__ __forceinline__ void wave_sync() {
     // single-wave workgroups: LDS operations of one wave execute in order; this only
     // stops the compiler from moving LDS accesses across the point.
@@ -1082,16 +1135,22 @@ __global__ __launch_bounds__(64) void k_trsm(const double* __restrict__ L, int l
 // construction.  Factors are stored as UPPER triangles R (X = R^T R, row-major), so that
 // both operands of every trailing update are MFMA accumulator tiles as they stand.
 
-// k_potrf_reg: one workgroup of 8 wavefronts; every 16x16 tile of the upper triangle lives
-// in the registers of one wavefront (slot s of wave w <-> tile index 8 s + w) from the
-// first load to the last store.  Per block step: the owner of the diagonal tile factors it
-// (rows in lanes, pivots broadcast with v_readlane) and publishes inv(L11) through LDS;
-// panel tiles become inv(L11) * tile with 4 MFMAs and are published through LDS in the
-// accumulator layout; trailing tiles subtract panel_a^T panel_b with 4 MFMAs.
+// k_potrf_reg: one workgroup of 8 wavefronts.
+//   wave 0 ("chain")   owns every diagonal tile (in LDS) and does nothing but: bring the next diagonal tile up to
+//                      date, factor + invert it in one DPP sweep (rows in lanes), publish inv(L11).
+//   POTRF_NW workers   hold the off-diagonal tiles of the upper triangle in registers from the first load to the last
+//                      store (tiles enumerated row by row and dealt round-robin, so the slots of a worker ascend in the
+//                      block row: the panel tiles of a step are a contiguous slot range, the trailing tiles the rest).
+//                      Panel tiles become inv(L11) * tile with 4 MFMAs and are published through LDS in the
+//                      accumulator layout; trailing tiles subtract panel_a^T panel_b with 4 MFMAs.
 //   X  : symmetric input (full diagonal tiles + upper tiles are read), n x n, ldx
-//   R  : output upper factor, row-major ldr (lower parts of diagonal tiles written as 0)
+//   R  : output upper factor, row-major ldr, FULL 16x16 tiles are stored: R must hold 16*ceil(n/16) rows and columns
+//        (lower parts of diagonal tiles and the mirrored tiles are written as 0)
 //   Dinv[nb][16][16] : inv(L11) of every diagonal block (generalised inverse on zero pivots)
 //   info[0] += pivots <= tol (dropped), info[1] += pivots < -tol (matrix not PSD)
+#define POTRF_NW 6
+__host__ __device__ inline int potrf_slots_needed(int nb) { return (nb * (nb - 1) / 2 + POTRF_NW - 1) / POTRF_NW; }
+
 // LDS-only workgroup barrier: orders LDS traffic (lgkmcnt) but does not wait for global stores in flight
 // (a __syncthreads() would also drain vmcnt, i.e. stall ~1 us per step on the stores of finished tiles).
 __device__ __forceinline__ void lds_barrier() {
@@ -1112,61 +1171,75 @@ __device__ __forceinline__ double ld_pub(const double* p) {
 __device__ __forceinline__ void lds_barrier_drain() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// uniform base (SGPR pair) + 32-bit lane offset in bytes: the saddr form of global_store, no 64-bit VALU address math
+template <bool PUB>
+__device__ __forceinline__ void st_tile(double* ubase, unsigned lane_bytes, double v) {
+    st_pub<PUB>(reinterpret_cast<double*>(reinterpret_cast<char*>(ubase) + lane_bytes), v);
+}
 
-// PUB: every byte of R (full tiles, padding included: R must be allocated 16 nb x ldr) and of Dinv is stored sc1, and
-// flag[0] = number of block steps whose row block of R and inv(L11) are complete in memory (monotonic, set by one
-// lane behind a workgroup barrier that every storing wave reaches after draining its stores).
+// PUB: every byte of R and of Dinv is stored sc1, and flag[0] = number of block steps whose row block of R and
+// inv(L11) are complete in memory (monotonic, set by one lane behind a workgroup barrier that every storing wave
+// reaches after draining its stores).
 template <int NSLOT, bool PUB>
 __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int ldx, int n, double tol_rel,
                                                double* __restrict__ R, int ldr, double* __restrict__ Dinv,
-                                               int* __restrict__ info, int from_lower, int ablate, int* __restrict__ flag) {
+                                               int* __restrict__ info, int from_lower, int ablate, int* __restrict__ flag,
+                                               unsigned long long* __restrict__ stamps = nullptr) {
     // ablate (diagnostic only, scripts/gpu_ablate.py): 1 skip the diagonal sweep, 2 skip trailing MFMAs, 4 skip panel
     // MFMAs, 8 skip the later-diagonal updates.  Results are garbage when non-zero.
+    // stamps (diagnostic, scripts/gpu_potrf_stamps.py): core-clock time stamps of wave 0 ([0..63]) and wave 1 ([64..127])
+#define POTRF_STAMP(w, idx) do { if (stamps && l == 0 && (w) < 3) stamps[(w) * 64 + (idx)] = clock64(); } while (0)
     __shared__ __attribute__((aligned(16))) double sD[16][16];       // diagonal tile being factored (row view)
-    __shared__ __attribute__((aligned(16))) double sDi[16][16];      // inv(L11) of the current block step
+    __shared__ __attribute__((aligned(16))) double sDi[2][16][16];   // inv(L11) of block step kb in sDi[kb & 1]
+    __shared__ int sCnt[16];                                        // waves that have published their panel tiles of step kb
     __shared__ __attribute__((aligned(16))) double sPan[14][4][64];  // published panel tiles, accumulator layout
     __shared__ __attribute__((aligned(16))) double sDg[14][4][64];   // the diagonal tiles (owned by wave 0)
-    __shared__ double sred[8];
+    __shared__ __attribute__((aligned(16))) double sStage[14][4][64];   // block row kb of the trailing matrix, up to date
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nb = (n + 15) >> 4;
-
-    // largest diagonal entry -> pivot tolerance
-    double tol = 0.0;
-    if (tol_rel > 0.0) {   // uniform; chol(M) passes 0 (M >= s2 I) and skips this dependent pass over the diagonal
-        double mx = 0.0;
-        for (int i = tid; i < n; i += 512) mx = fmax(mx, X[(size_t)i * ldx + i]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-        if (l == 0) sred[wave] = mx;
-        __syncthreads();
-        mx = 0.0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) mx = fmax(mx, sred[w]);
-        tol = tol_rel * mx;
-    }
+    POTRF_STAMP(wave == 0 ? 0 : (wave == 1 ? 1 : 3), 0);
+    if (stamps && tid == 0) stamps[192] = wall_clock64();
+    if (tid < 16) sCnt[tid] = 0;   // first use is behind barrier A of step 0
 
     if (wave == 0) {
         // =====================================================================================
-        // Role 1 -- the critical chain.  Wave 0 owns every diagonal tile (kept in LDS: dynamic index, no
-        // register array) and does nothing but: update the next diagonal tile, factor + invert it in one
-        // DPP sweep, publish inv(L11), then bring the later diagonal tiles up to date.
+        // Role 1 -- the critical chain
         // =====================================================================================
         int nzero = 0, nneg = 0;
-        for (int k = 0; k < nb; ++k) {
+        double mx = 0.0;   // largest diagonal entry -> pivot tolerance (taken from the tiles as they are loaded)
+        {   // all 56 loads in flight before the first LDS write (a rolled loop waits for every tile in turn)
+            double dg[14][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * k + kk + 4 * r, j = 16 * k + cc;
-                const bool in = i < n && j < n;
-                const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
-                sDg[k][r][l] = in ? xv : 0.0;
+            for (int k = 0; k < 14; ++k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * k + kk + 4 * r, j = 16 * k + cc;
+                    const bool in = k < nb && i < n && j < n;
+                    const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
+                    dg[k][r] = in ? xv : 0.0;
+                    if (in && i == j) mx = fmax(mx, xv);
+                }
             }
+#pragma unroll
+            for (int k = 0; k < 14; ++k) {
+                if (k < nb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sDg[k][r][l] = dg[k][r];
+                }
+            }
+        }
+        double tol = 0.0;
+        if (tol_rel > 0.0) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+            tol = tol_rel * mx;
         }
         auto factor_diag = [&](int kb) {
             int z = 0;
             asm volatile("" : "+v"(z));   // opaque zero: keeps LDS address arithmetic out of loop-invariant hoisting
             double* pD = &sD[0][0] + z;
-            double* pDi = &sDi[0][0] + z;
+            double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
             double* pG = &sDg[0][0][0] + z + kb * 256 + l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pD[(kk + 4 * r) * 16 + cc] = pG[r * 64];
@@ -1178,7 +1251,9 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                 v[c] = (c <= cc) ? a : 0.0;
                 y[c] = (c == cc) ? 1.0 : 0.0;
             }
+            POTRF_STAMP(2, 3 * kb);
             if (!(ablate & 1)) DiagStep<0>::run(v, y, tol, n - 16 * kb, nzero, nneg);
+            POTRF_STAMP(2, 3 * kb + 1);
             if (l < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) pDi[c * 16 + l] = y[c];   // Linv[c][l]
@@ -1192,28 +1267,49 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                 pG[r * 64] = (kk + 4 * r <= cc) ? xs : 0.0;
             }
         };
-        __builtin_amdgcn_s_setprio(3);   // win VALU arbitration against the co-resident wave of this SIMD
+        __builtin_amdgcn_s_setprio(3);
+        POTRF_STAMP(0, 1);
         if (!(ablate & 64)) factor_diag(0);
+        POTRF_STAMP(0, 2);
+        const unsigned lane_b0 = (unsigned)((kk * ldr + cc) * 8);
         for (int kb = 0; kb < nb; ++kb) {
-            lds_barrier();   // A: inv(L11) of step kb visible
-            lds_barrier();   // B: panel of step kb published
+            // A: the workers have finished the trailing update of step kb-1 (block row kb staged, later diagonal tiles
+            // up to date) and see inv(L11) of step kb.  It is the only point where the chain waits for anybody.
+            if (PUB) lds_barrier_drain(); else lds_barrier();
+            POTRF_STAMP(0, 3 + 4 * kb);
             const int kn = kb + 1;
-            if (kn < nb && !(ablate & 16)) {
+            if (kn < nb) {
                 int z = 0;
                 asm volatile("" : "+v"(z));
-                const double* pPan = &sPan[0][0][0] + z + l;
+                // the chain computes the one panel tile its next diagonal tile needs, (kb, kb+1), itself: no hand-off
+                const double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
+                const double* st = &sStage[0][0][0] + z + kn * 256 + l;
+                d4 x = {0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(pDi[cc * 16 + kk + 4 * s4], st[s4 * 64], x);
+                double* pPan = &sPan[0][0][0] + z + kn * 256 + l;
+                double* ub = R + (size_t)(16 * kb) * ldr + 16 * kn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pPan[r * 64] = x[r];
+                    st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b0, x[r]);
+                }
+                if (l == 0) __hip_atomic_fetch_add(&sCnt[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                POTRF_STAMP(0, 4 + 4 * kb);
                 double* pG = &sDg[0][0][0] + z + l;
-                {   // next diagonal tile: -= panel^T panel, then factor
+                {   // next diagonal tile: -= panel^T panel (operands straight from the accumulator registers), then factor
                     d4 t;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) t[r] = pG[kn * 256 + r * 64];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) { const double q = pPan[kn * 256 + s4 * 64]; t = mfma_f64(-q, q, t); }
+                    for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-x[s4], x[s4], t);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pG[kn * 256 + r * 64] = t[r];
                 }
+                POTRF_STAMP(0, 5 + 4 * kb);
                 factor_diag(kn);
-                // the later diagonal tiles (k > kn) are brought up to date by waves 1..7 (they live in LDS)
+                POTRF_STAMP(0, 6 + 4 * kb);
+                // the later diagonal tiles (k > kn) are brought up to date by the workers (they live in LDS)
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1221,25 +1317,42 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             if (nzero) atomicAdd(&info[0], nzero);
             if (nneg) atomicAdd(&info[1], nneg);
         }
+    } else if (wave == 4) {
+        // =====================================================================================
+        // Role 3 -- wave 4 shares SIMD 0 with the chain wave (waves are dealt to the four SIMDs round-robin): no MFMA
+        // work here, it only writes inv(L11) and R11 of every step from LDS to memory.
+        // =====================================================================================
+        const unsigned lane_b = (unsigned)((kk * ldr + cc) * 8);
+        for (int kb = 0; kb < nb; ++kb) {
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            if (PUB) lds_barrier_drain(); else lds_barrier();   // A
+            const double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
+            const double* g = &sDg[0][0][0] + z + kb * 256 + l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_pub<PUB>(Dinv + (size_t)kb * 256 + l + 64 * r, pDi[l + 64 * r]);
+            double* ub = R + (size_t)(16 * kb) * ldr + 16 * kb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, g[r * 64]);
+        }
     } else {
         // =====================================================================================
-        // Role 2 -- waves 1..7 hold the off-diagonal tiles in registers.  Tiles are enumerated row by row,
-        // t = T(a) + (b - a - 1) with T(a) = a nb - a(a+1)/2, and dealt round-robin (wave 1 + t % 7, slot
-        // t / 7): within a wave the slots ascend in a, so at step kb the panel tiles (a == kb) are the slot
-        // range [s_lo, s_hi) and the trailing tiles (a > kb) exactly the slots >= s_hi.
+        // Role 2 -- workers (waves 1,2,3,5,6,7).  Tile t = T(a) + (b - a - 1), T(a) = a nb - a(a+1)/2, of worker t % NW, slot t / NW.
         // =====================================================================================
+        const int wi = (wave < 4) ? wave - 1 : wave - 2;   // 0 .. POTRF_NW-1
         d4 acc[NSLOT];
         int tab[NSLOT];   // packed a | b << 8 (wave-uniform), -1 if the slot is empty
         const int noff = nb * (nb - 1) / 2;
+        const unsigned lane_b = (unsigned)((kk * ldr + cc) * 8);   // lane part of every R address, bytes
+        int dec_a = 0, dec_base = 0;   // running (block row, first tile index of that row): t grows with s
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             int a = -1, b = -1;
-            const int t = s * 7 + (wave - 1);
+            const int t = s * POTRF_NW + wi;
             if (t < noff) {
-                int aa = 0, base = 0;
-                while (base + (nb - 1 - aa) <= t) { base += nb - 1 - aa; ++aa; }
-                a = aa;
-                b = aa + 1 + (t - base);
+                while (dec_base + (nb - 1 - dec_a) <= t) { dec_base += nb - 1 - dec_a; ++dec_a; }
+                a = dec_a;
+                b = dec_a + 1 + (t - dec_base);
             }
             tab[s] = __builtin_amdgcn_readfirstlane(a < 0 ? -1 : (a | (b << 8)));
 #pragma unroll
@@ -1249,81 +1362,105 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                 const int ic = in ? i : 0, jc = in ? j : 0;   // clamped address + select: keeps the loads unpredicated
                 const double xv = from_lower ? X[(size_t)jc * ldx + ic] : X[(size_t)ic * ldx + jc];
                 acc[s][r] = in ? xv : 0.0;
-                if (a >= 0) {   // the mirrored (strictly lower) tile of the output is never touched again: zero it
-                    const int i2 = 16 * b + kk + 4 * r, j2 = 16 * a + cc;
-                    if (i2 < n && j2 < n) R[(size_t)i2 * ldr + j2] = 0.0;
+            }
+            if (tab[s] >= 0) {   // the mirrored (strictly lower) tile of the output is never touched again: zero it
+                double* ub = R + (size_t)(16 * (tab[s] >> 8)) * ldr + 16 * (tab[s] & 255);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_tile<false>(ub + (size_t)(4 * r) * ldr, lane_b, 0.0);
+                if ((tab[s] & 255) == 0) {   // block row 0 is the first panel
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sStage[tab[s] >> 8][r][l] = acc[s][r];
                 }
             }
         }
-        auto slots_below = [&](int x) -> int {   // slots of this wave whose tile index is < x
-            const int v = x - (wave - 1);
-            return v <= 0 ? 0 : (v + 6) / 7;
+        auto slots_below = [&](int x) -> int {   // slots of this worker whose tile index is < x
+            const int v = x - wi;
+            return v <= 0 ? 0 : (v + POTRF_NW - 1) / POTRF_NW;
         };
         for (int kb = 0; kb < nb; ++kb) {
             int z = 0;
             asm volatile("" : "+v"(z));
-            double* pDi = &sDi[0][0] + z;
+            double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
             double* pPan = &sPan[0][0][0] + z;
+            POTRF_STAMP(wave == 1 ? 1 : 3, 2 + 4 * kb);
             if (PUB) {
                 lds_barrier_drain();   // A (+ the stores of step kb-1 of this wave have landed)
                 if (wave == 1 && l == 0 && kb > 0) __hip_atomic_store(flag, kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 lds_barrier();   // A
             }
+            POTRF_STAMP(wave == 1 ? 1 : 3, 3 + 4 * kb);
             // ---- panel tiles (a == kb < b): tile <- inv(L11) * tile, published and stored ---------------
             const int Tkb = kb * nb - kb * (kb + 1) / 2;
             const int s_lo = slots_below(Tkb), s_hi = slots_below(Tkb + (nb - 1 - kb));
-            if (wave == 1 + (Tkb + (nb - 1 - kb)) % 7) {   // helper: inv(L11) and R11 of this step, LDS -> memory
-                const double* g = &sDg[0][0][0] + z + kb * 256 + l;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st_pub<PUB>(Dinv + (size_t)kb * 256 + l + 64 * r, pDi[l + 64 * r]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * kb + kk + 4 * r, j = 16 * kb + cc;
-                    if (PUB || (i < n && j < n)) st_pub<PUB>(R + (size_t)i * ldr + j, g[r * 64]);
-                }
-            }
-            if (s_hi > s_lo && !(ablate & 32)) {
+            // The panel row was staged in LDS by the trailing update of the previous step (sStage), so the panel is a
+            // rolled loop that any worker can run on any tile: tile kb+2+wi, +NW, ...
+            (void)s_lo;
+            if (kb + 2 + wi < nb && !(ablate & 32)) {   // tile (kb, kb+1) is the chain's
                 double li[4];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) li[s4] = pDi[cc * 16 + kk + 4 * s4];   // A operand: Linv[m = cc][k = kk + 4 s4]
+                double* urow = R + (size_t)(16 * kb) * ldr;
+#pragma unroll 1
+                for (int b = kb + 2 + wi; b < nb; b += POTRF_NW) {
+                    const double* st = &sStage[0][0][0] + z + b * 256 + l;
+                    d4 x = {0, 0, 0, 0};
+                    if (!(ablate & 4)) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], st[s4 * 64], x);
+                    }
+                    double* dst = pPan + b * 256 + l;
+                    double* ub = urow + 16 * b;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dst[r * 64] = x[r];
+                        st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, x[r]);   // final: row block kb of R
+                    }
+                }
+            }
+            POTRF_STAMP(wave == 1 ? 1 : 3, 4 + 4 * kb);
+            // B: every panel tile of step kb is in LDS -- a counter, not a barrier: the chain only adds to it
+            if (l == 0) __hip_atomic_fetch_add(&sCnt[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            {
+                const int target = POTRF_NW + ((kb + 1 < nb) ? 1 : 0);
+                while (__hip_atomic_load(&sCnt[kb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+            }
+            POTRF_STAMP(wave == 1 ? 1 : 3, 5 + 4 * kb);
+            // ---- trailing tiles (a > kb): tile -= panel_a^T panel_b.  The FP64 MFMA issues once per 64 cycles, which is
+            // also its latency, so one dependent chain per tile runs at the full rate of the pipe; the operands of the
+            // next live slot are fetched from LDS while the MFMAs of the current one execute.  Tiles of block row
+            // kb+1 (the next panel) are also staged in LDS.
+            if (!(ablate & 2)) {
+                double q[2][8];
+                auto fetch = [&](double (&dst)[8], int tb) {
+                    const double* qa = pPan + (tb & 255) * 256 + l;
+                    const double* qb = pPan + (tb >> 8) * 256 + l;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) { dst[s4] = qa[s4 * 64]; dst[4 + s4] = qb[s4 * 64]; }
+                };
 #pragma unroll
                 for (int s = 0; s < NSLOT; ++s) {
-                    if (s >= s_lo && s < s_hi) {
-                        d4 x = {0, 0, 0, 0};
-                        if (!(ablate & 4)) {
-#pragma unroll
-                            for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], acc[s][s4], x);
+                    if (s >= s_hi && tab[s] >= 0) {
+                        if (s == s_hi) fetch(q[s & 1], tab[s]);
+                        if (s + 1 < NSLOT) {
+                            if (tab[(s + 1 < NSLOT) ? s + 1 : s] >= 0) fetch(q[(s + 1) & 1], tab[(s + 1 < NSLOT) ? s + 1 : s]);
                         }
-                        acc[s] = x;
-                        const int b = tab[s] >> 8;
-                        double* dst = pPan + b * 256 + l;
+                        d4 x = acc[s];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            dst[r * 64] = x[r];
-                            const int i = 16 * kb + kk + 4 * r, j = 16 * b + cc;
-                            if (PUB || (i < n && j < n)) st_pub<PUB>(R + (size_t)i * ldr + j, x[r]);   // final: row block kb of R
+                        for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(-q[s & 1][s4], q[s & 1][4 + s4], x);
+                        acc[s] = x;
+                        if ((tab[s] & 255) == kb + 1) {
+                            double* st = &sStage[0][0][0] + z + (tab[s] >> 8) * 256 + l;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) st[r * 64] = x[r];
                         }
                     }
                 }
             }
-            lds_barrier();   // B
-            // ---- trailing tiles (a > kb): tile -= panel_a^T panel_b ---------------------------------------
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                if (s >= s_hi && tab[s] >= 0 && !(ablate & 2)) {
-                    const double* qa = pPan + (tab[s] & 255) * 256 + l;
-                    const double* qb = pPan + (tab[s] >> 8) * 256 + l;
-                    d4 x = acc[s];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(-qa[s4 * 64], qb[s4 * 64], x);
-                    acc[s] = x;
-                }
-            }
-            // later diagonal tiles k > kb+1 live in LDS and are off the critical chain: wave 1 + k % 7 updates them
+            // later diagonal tiles k > kb+1 live in LDS and are off the critical chain: worker k % NW updates them
             if (!(ablate & 8)) {
                 for (int k = kb + 2; k < nb; ++k) {
-                    if ((k % 7) != wave - 1) continue;
+                    if ((k % POTRF_NW) != wi) continue;
                     const double* q = pPan + k * 256 + l;
                     double* g = &sDg[0][0][0] + z + k * 256 + l;
                     d4 t;
@@ -1337,11 +1474,14 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             }
         }
     }
+    POTRF_STAMP(wave == 0 ? 0 : (wave == 1 ? 1 : 3), 63);
+    if (stamps && tid == 0) stamps[193] = wall_clock64();
     if (PUB) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (wave == 1 && l == 0) __hip_atomic_store(flag, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#undef POTRF_STAMP
 }
 
 template <int NSLOT>
@@ -1352,9 +1492,8 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
                                                    int from_lower = 0, int ablate = 0) {
     // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
     // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
-    (void)stamps;
     potrf_reg_body<NSLOT, false>(X + (size_t)blockIdx.x * strideX, ldx, n, tol_rel, R + (size_t)blockIdx.x * strideR, ldr,
-                                 Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr);
+                                 Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr, stamps);
 }
 
 // generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j] [+ Cin(i,j)]; tiles with
