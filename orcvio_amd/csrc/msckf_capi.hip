@@ -544,7 +544,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
                 const dim3 grid(1 + (ncb + SOLVE_WPB - 1) / SOLVE_WPB), block(512);
                 const double* g = h->d_U + (size_t)NA * NP;
 #define LAUNCH_PS(NS) hipLaunchKernelGGL(k_potrf_solve<NS>, grid, block, 0, s, h->d_M, NP, n, 0.0, h->d_RM, NP, h->d_DinvM, h->d_info + 2, \
-                                         h->d_flag, h->d_RP, sLj, sLi, n, g, 1L, h->d_Z, ldz)
+                                         h->d_flag, h->d_info + 8, h->d_RP, sLj, sLi, n, g, 1L, h->d_Z, ldz)
                 if (need <= 4) LAUNCH_PS(4);
                 else if (need <= 8) LAUNCH_PS(8);
                 else if (need <= 12) LAUNCH_PS(12);
@@ -572,8 +572,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
 static int launch_prior_fork(orcvio_msckf_handle* h, hipStream_t s) {
     HIPCHK(hipEventRecord(h->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int) * 8, h->side));
-    int rc = launch_solve_stage(h, h->side, ST_POTRF_P);
+    int rc = launch_solve_stage(h, h->side, ST_POTRF_P);   // writes d_info[0..1] itself
     if (rc != ORCVIO_OK) return rc;
     HIPCHK(hipEventRecord(h->ev_side, h->side));
     return ORCVIO_OK;
@@ -730,8 +729,13 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
     if (res->P_out) HIPCHK(hipMemcpy(res->P_out, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
     if (res->accept && F > 0) std::memcpy(res->accept, acc.data(), sizeof(int) * F);
     if (res->gamma && F > 0) HIPCHK(hipMemcpy(res->gamma, h->d_gamma, sizeof(double) * F, hipMemcpyDeviceToHost));
-    int info[8] = {0};
-    HIPCHK(hipMemcpy(info, h->d_info, sizeof(int) * 8, hipMemcpyDeviceToHost));
+    int info[9] = {0};
+    HIPCHK(hipMemcpy(info, h->d_info, sizeof(int) * 9, hipMemcpyDeviceToHost));
+    if (info[8] != 0) {   // a solver wavefront of k_potrf_solve gave up waiting for the factorisation (never on a healthy device)
+        HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
+        g_last_error = "k_potrf_solve: hand-off from the factorisation timed out";
+        return ORCVIO_ERR_NOT_SPD;
+    }
     int stacked = 0, nacc = 0;
     for (int j = 0; j < F; ++j)
         if (acc[j]) { stacked += h->h_row_ptr[j + 1] - h->h_row_ptr[j]; ++nacc; }
@@ -903,6 +907,7 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     // F_o = Hf^T Hf (lower tiles of the bottom-right block) -> R_F ; Y_o = L_F^-1 C_o
     {
         const int nbf = NOP / 16, need = potrf_slots_needed(nbf);
+        HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));   // the batched factorisation ADDS its pivot counters
         const double* F0 = h->d_Gobj + (size_t)NAP * W + NAP;
         const double tolF = (double)no_max * 2.220446049250313e-16;
         if (need <= 4)

@@ -114,35 +114,52 @@ struct PivotScale {   // 1/sqrt(d) of a pivot, 0 for a dropped one; counters of 
         return ok;
     }
 };
+#ifndef ORCVIO_DIAG_NEWTON
+#define ORCVIO_DIAG_NEWTON 1
+#endif
 template <int J>
 struct DiagStep {
-    // inv: scale of pivot J (already masked)
-    static __device__ __forceinline__ void step(double (&v)[16], double (&y)[16], double inv, double c15, double tol, int nlive,
-                                                int& nzero, int& nneg) {
-        const double m = asm_mul(v[J], inv);
-        const double x = asm_mul(y[J], inv);
-        v[J] = m;
-        y[J] = x;
+    // inv: scale 1/sqrt(d_J) of pivot J (0 for a dropped pivot).  u, a1: entries (J+1, J) and (J+1, J+1) of the tile as
+    // they stand before this step, already broadcast to every lane, so that the next pivot d_{J+1} = a1 - (u inv)^2 and
+    // its reciprocal square root hang off `inv` through a chain of dependent operations that is as short as possible
+    // (a dependent FP64 operation costs ~25-40 cycles here whatever is issued in between).
+    static __device__ __forceinline__ void step(double (&v)[16], double (&y)[16], double inv, double u, double a1, double c15,
+                                                double tol, int nlive, int& nzero, int& nneg) {
         if constexpr (J + 1 < 16) {
+            const double w = asm_mul(u, inv);
+            const double d = asm_fnma(w, w, a1);
+            const double r0 = asm_rsq(d);
+            const double m = asm_mul(v[J], inv);
+            const double x = asm_mul(y[J], inv);
+            v[J] = m;
+            y[J] = x;
+            const double h = asm_mul(d, 0.5);
+            const bool ok = PivotScale::classify<J + 1>(d, tol, nlive, nzero, nneg);
             asm volatile("s_nop 1" ::"v"(m), "v"(x));
             dpp_fnmac<J + 1>(v[J + 1], m, m);
-            const double d = dpp_row_bcast<J + 1>(v[J + 1]);   // (leading s_nop 1 inside)
-            const bool ok = PivotScale::classify<J + 1>(d, tol, nlive, nzero, nneg);
-            const double r0 = asm_rsq(ok ? d : 1.0);
-            const double h = asm_mul(d, 0.5);
             dpp_fnmac<J + 1>(y[J + 1], m, x);
-            diag_fill<J, J + 2>(v, y, m, x);
             const double t1 = asm_mul(r0, r0);
-            diag_fill<J, J + 3>(v, y, m, x);
+            diag_fill<J, J + 2>(v, y, m, x);
+            double un = 0.0, an = 0.0;
+            if constexpr (J + 2 < 16) {
+                un = dpp_row_bcast<J + 2>(v[J + 1]);   // (leading s_nop 1 inside)
+                an = dpp_row_bcast<J + 2>(v[J + 2]);
+            }
             const double t2 = asm_fnma(h, t1, c15);
+            diag_fill<J, J + 3>(v, y, m, x);
+            double r = asm_mul(r0, t2);
             diag_fill<J, J + 4>(v, y, m, x);
-            const double r1 = asm_mul(r0, t2);
-            diag_fill<J, J + 5>(v, y, m, x);
-            const double t3 = asm_mul(r1, r1);
-            diag_fill<J, J + 6>(v, y, m, x);
-            const double t4 = asm_fnma(h, t3, c15);
+            if constexpr (ORCVIO_DIAG_NEWTON >= 2) {
+                const double t3 = asm_mul(r, r);
+                diag_fill<J, J + 5>(v, y, m, x);
+                const double t4 = asm_fnma(h, t3, c15);
+                diag_fill<J, J + 6>(v, y, m, x);
+                r = asm_mul(r, t4);
+            } else {
+                diag_fill<J, J + 5>(v, y, m, x);
+                diag_fill<J, J + 6>(v, y, m, x);
+            }
             diag_fill<J, J + 7>(v, y, m, x);
-            const double r2 = asm_mul(r1, t4);
             diag_fill<J, J + 8>(v, y, m, x);
             diag_fill<J, J + 9>(v, y, m, x);
             diag_fill<J, J + 10>(v, y, m, x);
@@ -151,7 +168,10 @@ struct DiagStep {
             diag_fill<J, J + 13>(v, y, m, x);
             diag_fill<J, J + 14>(v, y, m, x);
             diag_fill<J, J + 15>(v, y, m, x);
-            DiagStep<J + 1>::step(v, y, ok ? r2 : 0.0, c15, tol, nlive, nzero, nneg);
+            DiagStep<J + 1>::step(v, y, ok ? r : 0.0, un, an, c15, tol, nlive, nzero, nneg);
+        } else {
+            v[J] = asm_mul(v[J], inv);
+            y[J] = asm_mul(y[J], inv);
         }
     }
     static __device__ __forceinline__ void run(double (&v)[16], double (&y)[16], double tol, int nlive, int& nzero, int& nneg) {
@@ -159,13 +179,15 @@ struct DiagStep {
         double c15 = 1.5;
         asm volatile("" : "+v"(c15));   // keep 1.5 in a register pair (not an inline constant)
         const double d = dpp_row_bcast<0>(v[0]);
+        const double u = dpp_row_bcast<1>(v[0]);
+        const double a1 = dpp_row_bcast<1>(v[1]);
         const bool ok = PivotScale::classify<0>(d, tol, nlive, nzero, nneg);
-        const double r0 = asm_rsq(ok ? d : 1.0);
+        const double r0 = asm_rsq(d);
         const double h = asm_mul(d, 0.5);
         asm volatile("s_nop 1" ::"v"(r0));
         const double r1 = asm_mul(r0, asm_fnma(h, asm_mul(r0, r0), c15));
         const double r2 = asm_mul(r1, asm_fnma(h, asm_mul(r1, r1), c15));
-        step(v, y, ok ? r2 : 0.0, c15, tol, nlive, nzero, nneg);
+        step(v, y, ok ? r2 : 0.0, u, a1, c15, tol, nlive, nzero, nneg);
     }
 };
 __device__ __forceinline__ void wave_sync() {
@@ -226,7 +248,7 @@ __host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
 //   I     (all)      outputs: T3 (three dense rows), the un-projected sparse rows Xobs, optionally H'.
 template <int NPASS>
 __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
-    constexpr int NP4 = (NPASS + 3) / 4;   // passes of 256 threads over the NAP columns
+    constexpr int NPD = (NPASS + 2) / 3;   // passes of the 192 threads of waves 1..3 over the NAP columns
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int j = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, t = tid & 63;
@@ -256,14 +278,15 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
     double* sE = sDi + 256;           // [R2][LDE]
     int* sC2O = (int*)(sE + (size_t)R2 * LDE);   // [N]
     int* sOC = sC2O + p.N;                        // [Mmax]
-    int* sFlag = sOC + p.Mmax;                    // [4]
+    int* sFlag = sOC + p.Mmax;                    // [4]  [0] gate verdict, [1] next observation of phase E
 
     for (int i = tid; i < p.N; i += 256) sC2O[i] = -1;
+    if (tid == 0) sFlag[1] = 0;
     __syncthreads();
 
+    // ---- B: per-observation Jacobians (wave 0, lane t <-> observation t) -----------------
+    double a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};   // rows 2t, 2t+1 of H_f
     if (wave == 0) {
-        // ---- B: per-observation Jacobians (lane t <-> observation t) ---------------------
-        double a0[3] = {0, 0, 0}, a1[3] = {0, 0, 0};   // rows 2t, 2t+1 of H_f
         if (t < M) {
             const int o = lo + t;
             const int ci = p.obs_clone[o];
@@ -287,7 +310,10 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
             sOC[t] = ci;
             sC2O[ci] = t;
         }
+    }
+    __syncthreads();   // the Jacobians are all phase E needs: waves 1..3 start on it while wave 0 does the QR
 
+    if (wave == 0) {
         // ---- C: Householder QR of H_f (2M x 3), LAPACK dgeqr2 convention ------------------
         const int g0 = 2 * t, g1 = 2 * t + 1;
         double v0[3], v1[3], beta[3];
@@ -345,41 +371,9 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
             for (int q = 0; q < 4; ++q) sB[t * 4 + q] = b4[q];
         }
     }
-    __syncthreads();
 
-    // ---- D: compact-WY coefficients y_q[a] of Q^T [J | r] for the columns this thread owns
-    double yq[NP4][3];
-    {
-        const double be0 = sQ[0], be1 = sQ[1], be2 = sQ[2], g10 = sQ[3], g20 = sQ[4], g21 = sQ[5];
-#pragma unroll
-        for (int ps = 0; ps < NP4; ++ps) {
-            const int a = tid + 256 * ps;
-            double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-            if (a < 7 || a == NA) {
-                for (int i = 0; i < M2; ++i) {
-                    const double val = (a < 7) ? sJe[i * 7 + a] : sR[i];
-                    w0 += sV[i * 4 + 0] * val;
-                    w1 += sV[i * 4 + 1] * val;
-                    w2 += sV[i * 4 + 2] * val;
-                }
-            } else if (a >= cb0 && a < NA) {
-                const int cl = (a - cb0) / 6, cc = (a - cb0) - 6 * cl;
-                const int k = sC2O[cl];
-                if (k >= 0) {
-                    const double x0 = sJx[(2 * k) * 6 + cc], x1 = sJx[(2 * k + 1) * 6 + cc];
-                    w0 = sV[(2 * k) * 4 + 0] * x0 + sV[(2 * k + 1) * 4 + 0] * x1;
-                    w1 = sV[(2 * k) * 4 + 1] * x0 + sV[(2 * k + 1) * 4 + 1] * x1;
-                    w2 = sV[(2 * k) * 4 + 2] * x0 + sV[(2 * k + 1) * 4 + 2] * x1;
-                }
-            }
-            const double y0 = be0 * w0;
-            const double y1 = be1 * (w1 - g10 * y0);
-            const double y2 = be2 * (w2 - g20 * y0 - g21 * y1);
-            yq[ps][0] = y0; yq[ps][1] = y1; yq[ps][2] = y2;
-        }
-    }
-
-    // ---- E: E = J P_aa J^T, observation l on wave l % 4 ---------------------------------
+    // ---- E: E = J P_aa J^T.  Observations are handed out through an LDS counter (wave 0 joins when its QR is done);
+    //         every wave keeps one observation in hand and the P rows of the next one in flight -----------------
     {
         double* sU = sUall + (size_t)wave * 2 * NAP;
         // row-lane data: lane t <-> row t of the 2M-row block
@@ -407,9 +401,15 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
             for (int e = 0; e < 7; ++e) pe_nz |= (pe[ps][e] != 0.0);
         const bool ext_live = __any(pe_nz);   // wave-uniform (and the same on every wave: same loads)
         const int lend = (p.ablate & 1) ? 0 : M;
+        auto grab = [&]() -> int {
+            int v = 0;
+            if (t == 0) v = atomicAdd(&sFlag[1], 1);
+            return __builtin_amdgcn_readfirstlane(v);
+        };
         double pcur[NPASS][6], pnxt[NPASS][6];
-        if (wave < lend) {
-            const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[wave]) * n + 15;
+        int l = grab();
+        if (l < lend) {
+            const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[l]) * n + 15;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int a = t + 64 * ps;
@@ -417,9 +417,10 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
                 for (int c = 0; c < 6; ++c) pcur[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
             }
         }
-        for (int l = wave; l < lend; l += 4) {
-            if (l + 4 < lend) {
-                const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[l + 4]) * n + 15;
+        while (l < lend) {
+            const int lnext = grab();
+            if (lnext < lend) {
+                const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[lnext]) * n + 15;
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int a = t + 64 * ps;
@@ -467,9 +468,44 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
             for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) pcur[ps][c] = pnxt[ps][c];
+            l = lnext;
         }
     }
     __syncthreads();
+
+    // ---- D (waves 1..3, while wave 0 runs the gate): compact-WY coefficients y_q[a] of Q^T [J | r] for the
+    //      columns a = (tid - 64) + 192 ps this thread owns; only the outputs need them
+    double yq[NPD][3];
+    if (wave > 0) {
+        const int td = tid - 64;
+        const double be0 = sQ[0], be1 = sQ[1], be2 = sQ[2], g10 = sQ[3], g20 = sQ[4], g21 = sQ[5];
+#pragma unroll
+        for (int ps = 0; ps < NPD; ++ps) {
+            const int a = td + 192 * ps;
+            double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+            if (a < 7 || a == NA) {
+                for (int i = 0; i < M2; ++i) {
+                    const double val = (a < 7) ? sJe[i * 7 + a] : sR[i];
+                    w0 += sV[i * 4 + 0] * val;
+                    w1 += sV[i * 4 + 1] * val;
+                    w2 += sV[i * 4 + 2] * val;
+                }
+            } else if (a >= cb0 && a < NA) {
+                const int cl = (a - cb0) / 6, cc = (a - cb0) - 6 * cl;
+                const int k = sC2O[cl];
+                if (k >= 0) {
+                    const double x0 = sJx[(2 * k) * 6 + cc], x1 = sJx[(2 * k + 1) * 6 + cc];
+                    w0 = sV[(2 * k) * 4 + 0] * x0 + sV[(2 * k + 1) * 4 + 0] * x1;
+                    w1 = sV[(2 * k) * 4 + 1] * x0 + sV[(2 * k + 1) * 4 + 1] * x1;
+                    w2 = sV[(2 * k) * 4 + 2] * x0 + sV[(2 * k + 1) * 4 + 2] * x1;
+                }
+            }
+            const double y0 = be0 * w0;
+            const double y1 = be1 * (w1 - g10 * y0);
+            const double y2 = be2 * (w2 - g20 * y0 - g21 * y1);
+            yq[ps][0] = y0; yq[ps][1] = y1; yq[ps][2] = y2;
+        }
+    }
 
     // ---- G: the gate (wave 0) ---------------------------------------------------------------
     if (wave == 0) {
@@ -614,9 +650,9 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
     // itself is materialised only on request (p.Hs != nullptr; tests and callers that want H').
     if (p.ablate & 8) return;
 #pragma unroll
-    for (int ps = 0; ps < NP4; ++ps) {
-        const int a = tid + 256 * ps;
-        if (a < NAP) {
+    for (int ps = 0; ps < NPD; ++ps) {
+        const int a = (tid - 64) + 192 * ps;
+        if (wave > 0 && a < NAP) {
             int kobs = -1, cc = 0;
             if (a >= cb0 && a < NA) {
                 const int cl = (a - cb0) / 6;
@@ -1184,7 +1220,8 @@ template <int NSLOT, bool PUB>
 __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int ldx, int n, double tol_rel,
                                                double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                int* __restrict__ info, int from_lower, int ablate, int* __restrict__ flag,
-                                               unsigned long long* __restrict__ stamps = nullptr) {
+                                               unsigned long long* __restrict__ stamps = nullptr, int info_store = 0) {
+    // info_store: single-workgroup launches WRITE their two counters (no zeroing launch needed); batched launches add
     // ablate (diagnostic only, scripts/gpu_ablate.py): 1 skip the diagonal sweep, 2 skip trailing MFMAs, 4 skip panel
     // MFMAs, 8 skip the later-diagonal updates.  Results are garbage when non-zero.
     // stamps (diagnostic, scripts/gpu_potrf_stamps.py): core-clock time stamps of wave 0 ([0..63]) and wave 1 ([64..127])
@@ -1314,8 +1351,11 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
         }
         __builtin_amdgcn_s_setprio(0);
         if (l == 0) {
-            if (nzero) atomicAdd(&info[0], nzero);
-            if (nneg) atomicAdd(&info[1], nneg);
+            if (info_store) { info[0] = nzero; info[1] = nneg; }
+            else {
+                if (nzero) atomicAdd(&info[0], nzero);
+                if (nneg) atomicAdd(&info[1], nneg);
+            }
         }
     } else if (wave == 4) {
         // =====================================================================================
@@ -1493,7 +1533,8 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
     // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
     // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
     potrf_reg_body<NSLOT, false>(X + (size_t)blockIdx.x * strideX, ldx, n, tol_rel, R + (size_t)blockIdx.x * strideR, ldr,
-                                 Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr, stamps);
+                                 Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr, stamps,
+                                 gridDim.x == 1 ? 1 : 0);
 }
 
 // generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j] [+ Cin(i,j)]; tiles with
@@ -1713,11 +1754,11 @@ __global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, 
 template <int NSLOT>
 __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ X, int ldx, int n, double tol_rel,
                                                      double* __restrict__ R, int ldr, double* __restrict__ Dinv,
-                                                     int* __restrict__ info, int* __restrict__ flag,
+                                                     int* __restrict__ info, int* __restrict__ flag, int* __restrict__ lost_flag,
                                                      const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
                                                      const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz) {
     if (blockIdx.x == 0) {
-        potrf_reg_body<NSLOT, true>(X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag);
+        potrf_reg_body<NSLOT, true>(X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag, nullptr, 1);
         return;
     }
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -1803,7 +1844,7 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
             }
         }
     }
-    if (lost && l == 0) atomicAdd(&info[0], 1 << 20);   // reported as ORCVIO_ERR_NOT_SPD by the host
+    if (lost && l == 0) atomicAdd(lost_flag, 1);   // reported as an error by the host
 }
 
 // P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (n x (n+1), ldz).  One workgroup per lower

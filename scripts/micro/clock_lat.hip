@@ -52,6 +52,52 @@ __global__ void k_chain(double* out, int iters, int mode, unsigned long long* st
         x = c[0] + c[1] + c[2] + c[3];
     } else if (mode == 8) {   // __syncthreads chain
         for (int i = 0; i < iters; ++i) { __syncthreads(); x = x * y; }
+    } else if (mode == 9) {   // 8 independent DPP fnmacs (row_newbcast) per iteration
+        double a[8];
+        for (int k = 0; k < 8; ++k) a[k] = x + k;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(a[k]) : "v"(y), "v"(y));
+        }
+        for (int k = 0; k < 8; ++k) x += a[k];
+    } else if (mode == 10) {   // 8 independent asm v_fma_f64 per iteration
+        double a[8];
+        for (int k = 0; k < 8; ++k) a[k] = x + k;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("v_fma_f64 %0, -%1, %2, %0" : "+v"(a[k]) : "v"(y), "v"(y));
+        }
+        for (int k = 0; k < 8; ++k) x += a[k];
+    } else if (mode == 11) {   // 4 independent f64 MFMAs per iteration
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 c0 = {x, x, x, x}, c1 = c0, c2 = c0, c3 = c0;
+        for (int i = 0; i < iters; ++i) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, 1e-3, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, 1e-3, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, 1e-3, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, 1e-3, c3, 0, 0, 0);
+        }
+        x = c0[0] + c1[1] + c2[2] + c3[3];
+    } else if (mode == 12) {   // 8 independent f64 FMAs with a scalar (SGPR) multiplier
+        double a[8];
+        for (int k = 0; k < 8; ++k) a[k] = x + k;
+        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(y)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(y));
+        const double ys = __hiloint2double(hi, lo);
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("v_fma_f64 %0, -%1, %2, %0" : "+v"(a[k]) : "s"(ys), "v"(y));
+        }
+        for (int k = 0; k < 8; ++k) x += a[k];
+    } else if (mode == 13) {   // 8 independent f32 FMAs
+        float a[8];
+        for (int k = 0; k < 8; ++k) a[k] = (float)x + k;
+        const float yf = (float)y;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[k]) : "v"(yf), "v"(yf));
+        }
+        for (int k = 0; k < 8; ++k) x += a[k];
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -59,12 +105,14 @@ __global__ void k_chain(double* out, int iters, int mode, unsigned long long* st
     if (threadIdx.x == 0 && blockIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
 }
 
+void run_dpp_check();
 int main() {
+    run_dpp_check();
     double* d; unsigned long long* st;
     hipMalloc(&d, 1 << 20); hipMalloc(&st, 64);
-    const char* names[] = {"dep fma f64", "rsq+2 newton", "1/sqrt libm", "readlane bcast+fma", "shfl bcast+fma", "lds write->read", "8 indep fma f64 (per 8)", "dep mfma f64 16x16x4", "__syncthreads (512 thr)"};
+    const char* names[] = {"dep fma f64", "rsq+2 newton", "1/sqrt libm", "readlane bcast+fma", "shfl bcast+fma", "lds write->read", "8 indep fma f64 (per 8)", "dep mfma f64 16x16x4", "__syncthreads (512 thr)", "8 indep fnmac_dpp f64", "8 indep asm fma f64", "4 indep mfma f64", "8 indep fma f64 sgpr mult", "8 indep fma f32"};
     for (int grid : {1, 256}) {
-        for (int mode = 0; mode < 9; ++mode) {
+        for (int mode = 0; mode < 14; ++mode) {
             const int iters = 20000;
             const int threads = (mode == 8) ? 512 : 64;
             for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k_chain, dim3(grid), dim3(threads), 0, 0, d, iters, mode, st);
@@ -105,4 +153,6 @@ struct DppCheck {
         }
         printf("DPP row_newbcast f64 semantics: %s  (lane 20: mov %.1f fmac %.1f)\n", ok ? "OK" : "MISMATCH", h[20], h[84]);
     }
-} dpp_check_instance;
+};
+
+void run_dpp_check() { DppCheck c; (void)c; }

@@ -17,13 +17,11 @@ __global__ void k_diag(const double* X, double* out, unsigned long long* st, int
         for (int c = 0; c < 16; ++c) { v[c] = v0[c] + rep * 1e-12; y[c] = y0[c]; }
         if (MODE == 0) DiagStep<0>::run(v, y, 1e-300, 16, nz, nn);
         if (MODE == 1) {   // updates only (no pivot math): issue cost of the 240 DPP FMAs
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { }
-            DiagUpd<0, 1>::run(v, y, v[0], y[0]); DiagUpd<1, 2>::run(v, y, v[1], y[1]); DiagUpd<2, 3>::run(v, y, v[2], y[2]);
-            DiagUpd<3, 4>::run(v, y, v[3], y[3]); DiagUpd<4, 5>::run(v, y, v[4], y[4]); DiagUpd<5, 6>::run(v, y, v[5], y[5]);
-            DiagUpd<6, 7>::run(v, y, v[6], y[6]); DiagUpd<7, 8>::run(v, y, v[7], y[7]); DiagUpd<8, 9>::run(v, y, v[8], y[8]);
-            DiagUpd<9, 10>::run(v, y, v[9], y[9]); DiagUpd<10, 11>::run(v, y, v[10], y[10]); DiagUpd<11, 12>::run(v, y, v[11], y[11]);
-            DiagUpd<12, 13>::run(v, y, v[12], y[12]); DiagUpd<13, 14>::run(v, y, v[13], y[13]); DiagUpd<14, 15>::run(v, y, v[14], y[14]);
+            double m = v[0], x = y[0];
+            diag_fill<0, 1>(v, y, m, x); diag_fill<0, 2>(v, y, m, x); diag_fill<0, 3>(v, y, m, x); diag_fill<0, 4>(v, y, m, x);
+            diag_fill<0, 5>(v, y, m, x); diag_fill<0, 6>(v, y, m, x); diag_fill<0, 7>(v, y, m, x); diag_fill<0, 8>(v, y, m, x);
+            diag_fill<0, 9>(v, y, m, x); diag_fill<0, 10>(v, y, m, x); diag_fill<0, 11>(v, y, m, x); diag_fill<0, 12>(v, y, m, x);
+            diag_fill<0, 13>(v, y, m, x); diag_fill<0, 14>(v, y, m, x); diag_fill<0, 15>(v, y, m, x);
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc += v[c] + y[c];
@@ -47,7 +45,7 @@ int main() {
             hipDeviceSynchronize();
         }
         unsigned long long s; hipMemcpy(&s, dS, 8, hipMemcpyDeviceToHost);
-        printf("mode %d: %.0f cycles per 16x16 tile\n", mode, (double)s / reps);
+        printf("mode %d: %.0f cycles per 16x16 tile (mode 1 = 30 DPP fnmacs only)\n", mode, (double)s / reps);
     }
     return 0;
 }
