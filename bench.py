@@ -141,8 +141,10 @@ def main():
         # committed profile of this round, bytes per launch; null if that profile does not list the kernel
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r1b_pmc_traffic.json')))['kernels']
-            key = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<12>', 'k_potrf_solve(M)': 'k_potrf_solve<12>', 'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt'}.get(dom)
+            import glob
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]))['kernels']
+            key = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<16>', 'k_potrf_solve(M)': 'k_potrf_solve<16>',
+                   'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt', 'k_gram': 'k_gram_pair', 'k_assemble': 'k_assemble_A'}.get(dom)
             if key in pm and N == 30 and F == 400:
                 traffic = 1024.0 * (pm[key]['FETCH_SIZE_KB_median'] + pm[key]['WRITE_SIZE_KB_median'])
         except Exception:
@@ -152,6 +154,19 @@ def main():
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},
                         kernel_tflops={k: round(kflops[k] / (prof[k] * 1e-3) / 1e12, 4) for k in prof},
                         whole_update_tflops=W['total'] / (ms * 1e-3) / 1e12)
+        # the same update with host buffers in and (dx, P+, gamma, accept) out through the one-shot C-ABI call: reported
+        # beside `value`, never as `value` (PCIe + four synchronous copies per update)
+        host_inclusive = None
+        if world == 1:
+            for _ in range(5):
+                upd.update_features(win)
+            th = time.perf_counter()
+            reps_h = 50
+            for _ in range(reps_h):
+                upd.update_features(win)
+            th = (time.perf_counter() - th) / reps_h
+            host_inclusive = dict(updates_per_s=1.0 / th, ms_per_update=th * 1e3,
+                                  what='orcvio_msckf_update_features: host tracks + P in, dx, P+, gamma, accept out')
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as orc   # checker used as the reported CPU baseline ("port")
@@ -169,7 +184,7 @@ def main():
                                         'per GPU (22 800 stacked rows x 202 columns), LARVIO Jacobians',
                                clones=N, features_per_gpu=F, observations_per_feature=N,
                                parallelism=f'features sharded over {world} GPU(s), all-gather of compressed blocks'),
-                   roofline=roofline, cpu_baseline=cpu)
+                   roofline=roofline, cpu_baseline=cpu, host_inclusive=host_inclusive)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -106,6 +106,31 @@ __global__ void k_chain(double* out, int iters, int mode, unsigned long long* st
 }
 
 void run_dpp_check();
+__global__ void k_pair(double* out, int iters, int partner, int kind, unsigned long long* stamps) {
+    const int wave = threadIdx.x >> 6;
+    if (wave != 0 && wave != partner) return;
+    double y = 0.999999, x = 1.0 + threadIdx.x * 1e-9;
+    double a[8];
+    for (int k = 0; k < 8; ++k) a[k] = x + k;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (kind == 0 || wave == 0) {
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(a[k]) : "v"(y), "v"(y));
+        }
+    } else {   // partner runs dependent f64 MFMAs
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 c = {x, x, x, x};
+        for (int i = 0; i < iters; ++i) c = __builtin_amdgcn_mfma_f64_16x16x4f64(y, 1e-3, c, 0, 0, 0);
+        a[0] = c[0] + c[1];
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < 8; ++k) x += a[k];
+    out[threadIdx.x] = x;
+    if (threadIdx.x == 0) stamps[0] = t1 - t0;
+    if (threadIdx.x == 64 * partner) stamps[1] = t1 - t0;
+}
 int main() {
     run_dpp_check();
     double* d; unsigned long long* st;
@@ -128,6 +153,15 @@ int main() {
                    h[1] * 10.0 / iters, (double)h[0] / iters, clk, ms);
         }
     }
+    for (int kind = 0; kind < 2; ++kind)
+        for (int partner : {9, 4, 1}) {   // 9 = nobody (block has 8 waves)
+            const int iters = 20000;
+            hipLaunchKernelGGL(k_pair, dim3(1), dim3(512), 0, 0, d, iters, partner, kind, st);
+            hipDeviceSynchronize();
+            unsigned long long h[2]; hipMemcpy(h, st, 16, hipMemcpyDeviceToHost);
+            printf("pair kind %d (0 = both DPP fnmac streams, 1 = partner runs dependent MFMAs) partner wave %d: wave0 %.1f cyc/iter(8 fnmac), partner %.1f cyc/iter\n",
+                   kind, partner, (double)h[0] / iters, partner < 8 ? (double)h[1] / iters : 0.0);
+        }
     return 0;
 }
 // ---- DPP row_newbcast semantics check for 64-bit ops -------------------------------------------

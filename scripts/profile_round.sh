@@ -1,0 +1,15 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel trace + two PMC passes of bench.py; raw outputs under gpurun_out/<tag>_*.
+# usage: bash scripts/profile_round.sh r1d
+set -u
+TAG=${1:-rX}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $ROOT/bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o p -- python3 $ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_$C.log 2>&1
+done
+find $OUT/${TAG}_trace $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*.csv" | head -20

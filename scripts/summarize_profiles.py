@@ -1,0 +1,65 @@
+"""Turn the raw rocprofv3 outputs of scripts/profile_round.sh (gpurun_out/<tag>_*) into the committed summaries under
+profiles/: <tag>_kernel_stats.csv (per-kernel duration statistics), <tag>_pmc_traffic.json (FETCH_SIZE / WRITE_SIZE per
+dispatch, median, KB), <tag>_bench.json."""
+import csv, glob, json, os, shutil, statistics, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, 'gpurun_out')
+dst = os.path.join(ROOT, 'profiles')
+
+
+def find(pattern):
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.replace('void orcvio_amd::', '').replace('orcvio_amd::', '')
+    return name.split('(')[0]
+
+
+stats = find(f'{tag}_trace/**/*kernel_stats.csv')
+if stats:
+    shutil.copy(stats, os.path.join(dst, f'{tag}_kernel_stats.csv'))
+    print('kernel stats ->', f'profiles/{tag}_kernel_stats.csv')
+else:   # no --stats table: build it from the kernel trace
+    trace = find(f'{tag}_trace/**/*kernel_trace.csv')
+    if trace:
+        dur = {}
+        for row in csv.DictReader(open(trace)):
+            dur.setdefault(row['Kernel_Name'], []).append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
+        tot = sum(sum(v) for v in dur.values())
+        with open(os.path.join(dst, f'{tag}_kernel_stats.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
+            for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+                w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / tot, 2), min(v), max(v),
+                            round(statistics.pstdev(v), 1)])
+        print('kernel stats (from trace) ->', f'profiles/{tag}_kernel_stats.csv')
+
+traffic = {}
+for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    f = find(f'{tag}_pmc_{counter}/**/*counter_collection.csv')
+    if not f:
+        continue
+    per = {}
+    for row in csv.DictReader(open(f)):
+        if row['Counter_Name'] != counter:
+            continue
+        per.setdefault(short(row['Kernel_Name']), []).append(float(row['Counter_Value']))
+    for k, v in per.items():
+        if k.startswith('__amd'):
+            continue
+        traffic.setdefault(k, {})[f'{counter}_KB_median'] = statistics.median(v)
+        traffic[k]['dispatches'] = len(v)
+if traffic:
+    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no trace domains) around bench.py --steps 20; '
+                       'KB per dispatch, median over the dispatches of each kernel. gfx950 caveat (MI355X_MICROARCH.md): '
+                       'FETCH_SIZE under-reports wide coalesced reads by 2x; these kernels read 8 B per lane.',
+               'kernels': traffic}, open(os.path.join(dst, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
+    print('pmc traffic ->', f'profiles/{tag}_pmc_traffic.json')
+b = os.path.join(src, f'{tag}_bench.json')
+if os.path.exists(b) and os.path.getsize(b) > 10:
+    shutil.copy(b, os.path.join(dst, f'{tag}_bench.json'))
+    print('bench ->', f'profiles/{tag}_bench.json')
