@@ -240,6 +240,44 @@ typedef struct orcvio_msckf_state {
 int32_t orcvio_msckf_increment_state(const orcvio_msckf_flags* flags, const double* dx,
                                      orcvio_msckf_state* state);
 
+/* ---- Feature triangulation --------------------------------------
+ * Replaces, for every listed track, Feature::checkMotion followed by Feature::initializePosition
+ * (include/orcvio/feat/feature.hpp:354-449; the Levenberg-Marquardt of ::triangulate_position, :583-719, with
+ * ::generateInitialGuess :332-352, ::cost :270-290, ::jacobian :292-330) as called from
+ * OrcVIO::removeLostFeatures (src/orcvio.cpp:2258-2270).  The tracks list the observations to use, in the order of
+ * the reference's std::map (ascending clone); the caller has already dropped the current frame (curr_id).
+ * The camera poses are the cached orientation_cam / position_cam of src/orcvio.cpp:954-961, formed from the window. */
+typedef struct orcvio_triangulation_config { /* Feature::OptimizationConfig, feature.hpp:41-63 */
+    double translation_threshold;     /* 0.2      */
+    double huber_epsilon;             /* 0.01     */
+    double estimation_precision;      /* 5e-7     */
+    double initial_damping;           /* 1e-3     */
+    int32_t outer_loop_max_iteration; /* 10       */
+    int32_t inner_loop_max_iteration; /* 10       */
+    double cost_threshold;            /* 4.7673e-4 */
+    double init_final_dist_threshold; /* 5        */
+} orcvio_triangulation_config;
+void orcvio_msckf_triangulation_config_default(orcvio_triangulation_config* cfg);
+
+enum { ORCVIO_TRI_NO_MOTION = 1, ORCVIO_TRI_NEG_DEPTH = 2, ORCVIO_TRI_BIG_PROJ = 4 };
+typedef struct orcvio_triangulation_result { /* every pointer may be NULL */
+    int32_t* valid;    /* [F] is_valid_solution */
+    double* p_w;       /* [F][3] Feature::position (NaN where invalid and not initialised before) */
+    double* inv_param; /* [F][3] Feature::invParam = (alpha, beta, rho) in the anchor (last listed) camera frame */
+    int32_t* flags;    /* [F] ORCVIO_TRI_* bits: why a track is invalid (failed_by_neg_dpth, failed_by_big_proj) */
+    double* cost;      /* [F] total squared reprojection error at the solution */
+} orcvio_triangulation_result;
+/* is_initialized: NULL, or [F]; where non-zero the track starts from tracks->p_w (feature.hpp:604-606) and the motion
+ * check is skipped.  tracks->p_w may be NULL when is_initialized is NULL. */
+int32_t orcvio_msckf_triangulate(orcvio_msckf_handle* h, const orcvio_triangulation_config* cfg,
+                                 const orcvio_msckf_window* window, const orcvio_msckf_tracks* tracks,
+                                 const int32_t* is_initialized, orcvio_triangulation_result* result);
+/* The same on the tracks of the last orcvio_msckf_upload, in place on the device: valid tracks get their triangulated
+ * position, the others are marked and take no part in the following orcvio_msckf_run_update (as the reference drops them
+ * into invalid_feature_ids, src/orcvio.cpp:2262-2268).  Inputs never leave HBM between the two calls. */
+int32_t orcvio_msckf_triangulate_uploaded(orcvio_msckf_handle* h, const orcvio_triangulation_config* cfg,
+                                          const int32_t* is_initialized, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,8 @@ EXPORTS = [
     'orcvio_msckf_block_ptr', 'orcvio_msckf_run_finish', 'orcvio_msckf_run_update',
     'orcvio_msckf_sync', 'orcvio_msckf_download', 'orcvio_msckf_profile_update',
     'orcvio_msckf_increment_state', 'orcvio_msckf_set_option', 'orcvio_msckf_run_local_to',
-    'orcvio_msckf_object_rows_eval',
+    'orcvio_msckf_object_rows_eval', 'orcvio_msckf_triangulation_config_default', 'orcvio_msckf_triangulate',
+    'orcvio_msckf_triangulate_uploaded',
 ]
 
 
@@ -67,6 +68,17 @@ class ObjectTrackC(C.Structure):
 class MsckfResult(C.Structure):
     _fields_ = [('dx', _dp), ('P_out', _dp), ('accept', _ip), ('gamma', _dp), ('H_thin', _dp), ('r_thin', _dp),
                 ('K', _dp), ('G', _dp), ('stats', C.c_int32 * 8)]
+
+
+class TriangulationConfig(C.Structure):
+    _fields_ = [('translation_threshold', C.c_double), ('huber_epsilon', C.c_double), ('estimation_precision', C.c_double),
+                ('initial_damping', C.c_double), ('outer_loop_max_iteration', C.c_int32),
+                ('inner_loop_max_iteration', C.c_int32), ('cost_threshold', C.c_double),
+                ('init_final_dist_threshold', C.c_double)]
+
+
+class TriangulationResult(C.Structure):
+    _fields_ = [('valid', _ip), ('p_w', _dp), ('inv_param', _dp), ('flags', _ip), ('cost', _dp)]
 
 
 class MsckfState(C.Structure):
@@ -117,6 +129,11 @@ def load():
     lib.orcvio_msckf_increment_state.argtypes = [C.POINTER(MsckfFlags), _dp, C.POINTER(MsckfState)]
     lib.orcvio_msckf_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.orcvio_msckf_run_local_to.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orcvio_msckf_triangulation_config_default.argtypes = [C.POINTER(TriangulationConfig)]
+    lib.orcvio_msckf_triangulation_config_default.restype = None
+    lib.orcvio_msckf_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangulationConfig), C.POINTER(MsckfWindow),
+                                             C.POINTER(MsckfTracks), _ip, C.POINTER(TriangulationResult)]
+    lib.orcvio_msckf_triangulate_uploaded.argtypes = [C.c_void_p, C.POINTER(TriangulationConfig), _ip, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -286,12 +303,52 @@ class MsckfUpdater:
         return dict(row_clone=row_clone[:m].copy(), Hx6=Hx6[:m].copy(), Hf=Hf[:m].copy(), res=res[:m].copy())
 
     # -- staged, device-resident form -----------------------------------------------------
-    def upload(self, win):
+    def upload(self, win, without_positions=False):
+        """without_positions: p_w is not sent (NULL); triangulate_uploaded() must run before the update."""
         fl, w, t, arrs = self._structs(win)
+        if without_positions:
+            t.p_w = None
         rc = self.lib.orcvio_msckf_upload(self.h, C.byref(fl), C.byref(w), C.byref(t), _d(arrs['P']))
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_upload')
         self.n, self.F = win.n, win.F
+
+    # -- feature triangulation (Feature::checkMotion + ::initializePosition) ---------------------
+    def _tri_config(self, cfg=None):
+        c = TriangulationConfig()
+        self.lib.orcvio_msckf_triangulation_config_default(C.byref(c))
+        if cfg is not None:   # any object / dict with the reference's OptimizationConfig field names
+            get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+            for k, _ in TriangulationConfig._fields_:
+                try:
+                    setattr(c, k, get(k))
+                except (KeyError, AttributeError):
+                    pass
+        return c
+
+    def triangulate(self, win, cfg=None, is_initialized=None):
+        """Host-buffer call: returns dict(valid, p_w, solution, flags, cost) over the tracks of ``win``."""
+        _, w, t, arrs = self._structs(win)
+        c = self._tri_config(cfg)
+        F = win.F
+        ini = None if is_initialized is None else np.ascontiguousarray(is_initialized, dtype=np.int32)
+        if ini is None:
+            t.p_w = None
+        out = dict(valid=np.zeros(max(F, 1), np.int32), p_w=np.zeros((max(F, 1), 3)), solution=np.zeros((max(F, 1), 3)),
+                   flags=np.zeros(max(F, 1), np.int32), cost=np.zeros(max(F, 1)))
+        res = TriangulationResult(_i(out['valid']), _d(out['p_w']), _d(out['solution']), _i(out['flags']), _d(out['cost']))
+        rc = self.lib.orcvio_msckf_triangulate(self.h, C.byref(c), C.byref(w), C.byref(t), _i(ini), C.byref(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_triangulate')
+        return {k: v[:F] for k, v in out.items()}
+
+    def triangulate_uploaded(self, cfg=None, is_initialized=None, stream=None):
+        """Triangulates the uploaded tracks in place on the device; invalid ones are excluded from the update."""
+        c = self._tri_config(cfg)
+        ini = None if is_initialized is None else np.ascontiguousarray(is_initialized, dtype=np.int32)
+        rc = self.lib.orcvio_msckf_triangulate_uploaded(self.h, C.byref(c), _i(ini), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_triangulate_uploaded')
 
     def run_update(self, stream=None):
         rc = self.lib.orcvio_msckf_run_update(self.h, C.c_void_p(stream) if stream else None)

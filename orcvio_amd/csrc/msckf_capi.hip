@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "msckf_kernels.hpp"
+#include "triangulate.hpp"
 #include "object_rows.hpp"
 
 using namespace orcvio_amd;
@@ -44,6 +45,11 @@ struct orcvio_msckf_handle {
     bool uploaded = false, ran = false;
     bool reg_path = true;               // register-resident Cholesky (n <= 224), else the LDS-panel kernel
     bool fused_solve = true;            // chol(M) and the triangular solve in one launch (k_potrf_solve), reg path only
+    int* d_skip = nullptr;              // [maxF] tracks dropped by triangulate_uploaded (nullptr semantics: skip_active)
+    bool skip_active = false;
+    bool pw_missing = false;            // uploaded without positions: triangulate_uploaded must run before the update
+    int *d_tri_valid = nullptr, *d_tri_flags = nullptr, *d_tri_init = nullptr;
+    double *d_tri_sol = nullptr, *d_tri_cost = nullptr;
     int* d_flag = nullptr;              // step counter of that launch (inside the d_info allocation, own 128-byte line)
     // device buffers
     double *d_poses = nullptr, *d_pw = nullptr, *d_obs_z = nullptr, *d_obs_zvel = nullptr, *d_P = nullptr;
@@ -160,7 +166,8 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_accept, h->d_info, h->d_chi2, h->d_Hs, h->d_gamma, h->d_Gpart, h->d_Ab, h->d_A, h->d_RP,
                     h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_Pout, h->d_dx, h->d_La, h->d_DinvA,
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
-                    h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_ptr, h->d_clone_obs};
+                    h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_ptr, h->d_clone_obs,
+                    h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -222,6 +229,12 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_obs_clone, sizeof(int) * max_observations));
         HIPCHK(hipMalloc(&h->d_row_ptr, sizeof(int) * (max_features + 1)));
         HIPCHK(hipMalloc(&h->d_accept, sizeof(int) * max_features));
+        HIPCHK(hipMalloc(&h->d_skip, sizeof(int) * max_features));
+        HIPCHK(hipMalloc(&h->d_tri_valid, sizeof(int) * max_features));
+        HIPCHK(hipMalloc(&h->d_tri_flags, sizeof(int) * max_features));
+        HIPCHK(hipMalloc(&h->d_tri_init, sizeof(int) * max_features));
+        HIPCHK(hipMalloc(&h->d_tri_sol, sizeof(double) * 3 * max_features));
+        HIPCHK(hipMalloc(&h->d_tri_cost, sizeof(double) * max_features));
         HIPCHK(hipMalloc(&h->d_info, sizeof(int) * 64));
         h->d_flag = h->d_info + 32;
         HIPCHK(hipMalloc(&h->d_chi2, sizeof(double) * ORCVIO_CHI2_TABLE));
@@ -313,7 +326,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     if (N > h->maxN || F > h->maxF) { g_last_error = "orcvio_msckf_upload: exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
     const int nobs = F > 0 ? tr->obs_ptr[F] : 0;
     if (nobs > h->maxObs) { g_last_error = "orcvio_msckf_upload: too many observations"; return ORCVIO_ERR_CAPACITY; }
-    if (F > 0 && (!tr->p_w || !tr->obs_clone || !tr->obs_z)) { g_last_error = "orcvio_msckf_upload: null track arrays"; return ORCVIO_ERR_INVALID; }
+    if (F > 0 && (!tr->obs_clone || !tr->obs_z)) { g_last_error = "orcvio_msckf_upload: null track arrays"; return ORCVIO_ERR_INVALID; }
     if (flags->estimate_td && F > 0 && !tr->obs_zvel) { g_last_error = "orcvio_msckf_upload: obs_zvel required with estimate_td"; return ORCVIO_ERR_INVALID; }
     // row offsets, track-length limits, index validation
     h->h_row_ptr.assign(F + 1, 0);
@@ -363,7 +376,8 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     HIPCHK(hipMemcpyAsync(h->d_obs_ptr, tr->obs_ptr, sizeof(int) * (F + 1), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->d_row_ptr, h->h_row_ptr.data(), sizeof(int) * (F + 1), hipMemcpyHostToDevice, s));
     if (F > 0) {
-        HIPCHK(hipMemcpyAsync(h->d_pw, tr->p_w, sizeof(double) * 3 * F, hipMemcpyHostToDevice, s));
+        if (tr->p_w) HIPCHK(hipMemcpyAsync(h->d_pw, tr->p_w, sizeof(double) * 3 * F, hipMemcpyHostToDevice, s));
+        else HIPCHK(hipMemsetAsync(h->d_pw, 0, sizeof(double) * 3 * F, s));   // positions come from orcvio_msckf_triangulate_uploaded
         if (nobs > 0) {
             HIPCHK(hipMemcpyAsync(h->d_obs_clone, tr->obs_clone, sizeof(int) * nobs, hipMemcpyHostToDevice, s));
             HIPCHK(hipMemcpyAsync(h->d_obs_z, tr->obs_z, sizeof(double) * 2 * nobs, hipMemcpyHostToDevice, s));
@@ -406,6 +420,8 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->uploaded = true;
     h->ran = false;
     h->graph_valid = false;
+    h->skip_active = false;
+    h->pw_missing = (F > 0 && !tr->p_w);
     return ORCVIO_OK;
 }
 
@@ -415,6 +431,7 @@ static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
     FeatArgs a;
     a.poses = h->d_poses; a.p_w = h->d_pw; a.obs_ptr = h->d_obs_ptr; a.obs_clone = h->d_obs_clone;
     a.obs_z = h->d_obs_z; a.obs_zvel = h->d_obs_zvel; a.P = h->d_P; a.row_ptr = h->d_row_ptr; a.chi2 = h->d_chi2;
+    a.skip = h->skip_active ? h->d_skip : nullptr;
     a.Hs = h->materialize ? h->d_Hs : nullptr; a.T3 = h->d_T3; a.Xobs = h->d_Xobs; a.obs_pos = h->d_clone_obs; a.gamma = h->d_gamma; a.accept = h->d_accept;
     a.sigma2 = h->flags.noise_feature * h->flags.noise_feature;
     a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP; a.Mmax = h->Mmax; a.F = h->F;
@@ -588,7 +605,7 @@ static int launch_solve_tail(orcvio_msckf_handle* h, hipStream_t s) {
 static hipStream_t pick_stream(orcvio_msckf_handle* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
 
 int32_t orcvio_msckf_run_local(orcvio_msckf_handle* h, void* stream) {
-    if (!h || !h->uploaded) { g_last_error = "run_local: nothing uploaded"; return ORCVIO_ERR_INVALID; }
+    if (!h || !h->uploaded || h->pw_missing) { g_last_error = "run_local: nothing uploaded (or positions missing)"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
     int rc = launch_prior_fork(h, s);
@@ -599,7 +616,7 @@ int32_t orcvio_msckf_run_local(orcvio_msckf_handle* h, void* stream) {
 }
 
 int32_t orcvio_msckf_run_local_to(orcvio_msckf_handle* h, double* d_dst, void* stream) {
-    if (!h || !h->uploaded || !d_dst) { g_last_error = "run_local_to: invalid"; return ORCVIO_ERR_INVALID; }
+    if (!h || !h->uploaded || !d_dst || h->pw_missing) { g_last_error = "run_local_to: invalid"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
     int rc = launch_prior_fork(h, s);
@@ -637,6 +654,7 @@ static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
 
 int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     if (!h || !h->uploaded) { g_last_error = "run_update: nothing uploaded"; return ORCVIO_ERR_INVALID; }
+    if (h->pw_missing) { g_last_error = "run_update: tracks were uploaded without positions and have not been triangulated"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
     // The eleven launches (and the side-stream fork/join) are captured once per upload into a hipGraph and
@@ -1089,6 +1107,104 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int) * 8, s));
     HIPCHK(hipStreamSynchronize(s));
     h->ran = true;
+    return ORCVIO_OK;
+}
+
+// ---- feature triangulation --------------------------------------------------
+void orcvio_msckf_triangulation_config_default(orcvio_triangulation_config* c) {
+    if (!c) return;
+    c->translation_threshold = 0.2; c->huber_epsilon = 0.01; c->estimation_precision = 5e-7; c->initial_damping = 1e-3;
+    c->outer_loop_max_iteration = 10; c->inner_loop_max_iteration = 10; c->cost_threshold = 4.7673e-04;
+    c->init_final_dist_threshold = 5.0;
+}
+
+static int launch_triangulate(orcvio_msckf_handle* h, const orcvio_triangulation_config* cfg, bool have_init, bool mark_skip, hipStream_t s) {
+    if (h->F == 0) return ORCVIO_OK;
+    TriArgs a;
+    a.poses = h->d_poses; a.obs_ptr = h->d_obs_ptr; a.obs_clone = h->d_obs_clone; a.obs_z = h->d_obs_z;
+    a.is_init = have_init ? h->d_tri_init : nullptr;
+    a.p_w = h->d_pw; a.valid = h->d_tri_valid; a.flags = h->d_tri_flags; a.solution = h->d_tri_sol; a.cost = h->d_tri_cost;
+    a.skip = mark_skip ? h->d_skip : nullptr;
+    a.translation_threshold = cfg->translation_threshold; a.huber_epsilon = cfg->huber_epsilon;
+    a.estimation_precision = cfg->estimation_precision; a.initial_damping = cfg->initial_damping;
+    a.cost_threshold = cfg->cost_threshold; a.init_final_dist_threshold = cfg->init_final_dist_threshold;
+    a.outer_max = cfg->outer_loop_max_iteration; a.inner_max = cfg->inner_loop_max_iteration;
+    a.F = h->F;
+    hipLaunchKernelGGL(k_triangulate, dim3(h->F), dim3(64), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_triangulate_uploaded(orcvio_msckf_handle* h, const orcvio_triangulation_config* cfg,
+                                          const int32_t* is_initialized, void* stream) {
+    if (!h || !cfg || !h->uploaded || h->objects_mode) { g_last_error = "triangulate_uploaded: no uploaded tracks"; return ORCVIO_ERR_INVALID; }
+    if (h->pw_missing && is_initialized) { g_last_error = "triangulate_uploaded: is_initialized needs uploaded positions"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    if (is_initialized && h->F > 0) HIPCHK(hipMemcpyAsync(h->d_tri_init, is_initialized, sizeof(int) * h->F, hipMemcpyHostToDevice, s));
+    int rc = launch_triangulate(h, cfg, is_initialized != nullptr, true, s);
+    if (rc != ORCVIO_OK) return rc;
+    h->skip_active = true;
+    h->pw_missing = false;
+    h->graph_valid = false;   // k_feature now takes the skip mask
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_triangulate(orcvio_msckf_handle* h, const orcvio_triangulation_config* cfg, const orcvio_msckf_window* w,
+                                 const orcvio_msckf_tracks* tr, const int32_t* is_initialized, orcvio_triangulation_result* res) {
+    if (!h || !cfg || !w || !tr || !res || !w->R_b2w || !w->t_b_w || !w->R_b2c || !w->t_c_b || !tr->obs_ptr) {
+        g_last_error = "orcvio_msckf_triangulate: null argument";
+        return ORCVIO_ERR_INVALID;
+    }
+    const int N = w->n_clones, F = tr->n_features;
+    if (N < 1 || F < 0) { g_last_error = "orcvio_msckf_triangulate: bad sizes"; return ORCVIO_ERR_INVALID; }
+    if (N > h->maxN || F > h->maxF) { g_last_error = "orcvio_msckf_triangulate: exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
+    const int nobs = F > 0 ? tr->obs_ptr[F] : 0;
+    if (nobs > h->maxObs) { g_last_error = "orcvio_msckf_triangulate: too many observations"; return ORCVIO_ERR_CAPACITY; }
+    if (F > 0 && (!tr->obs_clone || !tr->obs_z)) { g_last_error = "orcvio_msckf_triangulate: null track arrays"; return ORCVIO_ERR_INVALID; }
+    if (is_initialized && !tr->p_w) { g_last_error = "orcvio_msckf_triangulate: is_initialized needs tracks->p_w"; return ORCVIO_ERR_INVALID; }
+    for (int j = 0; j < F; ++j) {
+        const int M = tr->obs_ptr[j + 1] - tr->obs_ptr[j];
+        if (M < 0) { g_last_error = "orcvio_msckf_triangulate: obs_ptr not monotone"; return ORCVIO_ERR_INVALID; }
+        if (M > 64) { g_last_error = "orcvio_msckf_triangulate: track longer than 64 observations"; return ORCVIO_ERR_TRACK_TOO_LONG; }
+    }
+    for (int o = 0; o < nobs; ++o)
+        if (tr->obs_clone[o] < 0 || tr->obs_clone[o] >= N) { g_last_error = "orcvio_msckf_triangulate: obs_clone out of range"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // this call owns the track buffers: whatever was uploaded for an update is gone
+    h->uploaded = false; h->ran = false; h->graph_valid = false; h->skip_active = false; h->objects_mode = false;
+    h->N = N; h->F = F; h->nobs = nobs;
+    h->h_poses.assign((size_t)POSE_STRIDE * N, 0.0);
+    const double* tfej = w->t_fej ? w->t_fej : w->t_b_w;
+    for (int i = 0; i < N; ++i) {
+        double* r = &h->h_poses[(size_t)POSE_STRIDE * i];
+        std::memcpy(r + POSE_R_B2W, w->R_b2w + 9 * i, 9 * sizeof(double));
+        std::memcpy(r + POSE_T_B_W, w->t_b_w + 3 * i, 3 * sizeof(double));
+        std::memcpy(r + POSE_T_FEJ, tfej + 3 * i, 3 * sizeof(double));
+        std::memcpy(r + POSE_R_B2C, w->R_b2c + 9 * i, 9 * sizeof(double));
+        std::memcpy(r + POSE_T_C_B, w->t_c_b + 3 * i, 3 * sizeof(double));
+    }
+    HIPCHK(hipMemcpyAsync(h->d_poses, h->h_poses.data(), sizeof(double) * POSE_STRIDE * N, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_obs_ptr, tr->obs_ptr, sizeof(int) * (F + 1), hipMemcpyHostToDevice, s));
+    if (F > 0) {
+        if (tr->p_w) HIPCHK(hipMemcpyAsync(h->d_pw, tr->p_w, sizeof(double) * 3 * F, hipMemcpyHostToDevice, s));
+        if (is_initialized) HIPCHK(hipMemcpyAsync(h->d_tri_init, is_initialized, sizeof(int) * F, hipMemcpyHostToDevice, s));
+        if (nobs > 0) {
+            HIPCHK(hipMemcpyAsync(h->d_obs_clone, tr->obs_clone, sizeof(int) * nobs, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(h->d_obs_z, tr->obs_z, sizeof(double) * 2 * nobs, hipMemcpyHostToDevice, s));
+        }
+    }
+    int rc = launch_triangulate(h, cfg, is_initialized != nullptr, false, s);
+    if (rc != ORCVIO_OK) return rc;
+    if (F > 0) {
+        if (res->valid) HIPCHK(hipMemcpyAsync(res->valid, h->d_tri_valid, sizeof(int) * F, hipMemcpyDeviceToHost, s));
+        if (res->flags) HIPCHK(hipMemcpyAsync(res->flags, h->d_tri_flags, sizeof(int) * F, hipMemcpyDeviceToHost, s));
+        if (res->p_w) HIPCHK(hipMemcpyAsync(res->p_w, h->d_pw, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+        if (res->inv_param) HIPCHK(hipMemcpyAsync(res->inv_param, h->d_tri_sol, sizeof(double) * 3 * F, hipMemcpyDeviceToHost, s));
+        if (res->cost) HIPCHK(hipMemcpyAsync(res->cost, h->d_tri_cost, sizeof(double) * F, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
     return ORCVIO_OK;
 }
 

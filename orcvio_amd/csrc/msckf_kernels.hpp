@@ -210,6 +210,7 @@ struct FeatArgs {
     const double* obs_zvel;
     const double* P;
     const int* row_ptr;   // [F+1] row offsets into Hs (rho_j = 2M_j-3, 0 if M_j < 2)
+    const int* skip;      // [F] or nullptr: tracks that failed triangulation on the device take no part (k_triangulate)
     const double* chi2;   // [ORCVIO_CHI2_TABLE]
     double* Hs;           // optional: stacked projected blocks (nullptr = not materialised)
     double* T3;           // [3F][NAP]  first three rows of Q^T [J | r] of every track (zero if rejected)
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
     const int tid = threadIdx.x, wave = tid >> 6, t = tid & 63;
     const int lo = p.obs_ptr[j];
     const int M = p.obs_ptr[j + 1] - lo;
-    if (M < 2) {   // whole workgroup
+    if (M < 2 || (p.skip && p.skip[j])) {   // whole workgroup
         if (tid == 0) { p.gamma[j] = NAN; p.accept[j] = 0; }
         for (int e = tid; e < 3 * p.NAP; e += 256) p.T3[(size_t)3 * j * p.NAP + e] = 0.0;
         for (int e = tid; e < 32 * M; e += 256) p.Xobs[(size_t)32 * p.obs_pos[lo + (e >> 5)] + (e & 31)] = 0.0;
