@@ -67,6 +67,12 @@ struct Feature {
     std::map<StateIDType, Vec2> observations;
     std::map<StateIDType, Vec2> observations_vel;
     bool is_initialized = false;
+    // set by MsckfBackend::initializePositions (Feature::initializePosition, include/orcvio/feat/feature.hpp:430-443)
+    double position_FEJ[3] = {0, 0, 0};
+    double invParam[3] = {0, 0, 0};   // (alpha, beta, rho) in the anchor camera frame
+    StateIDType id_anchor = -1;
+    double invDepth = 0;
+    bool failed_by_neg_dpth = false, failed_by_big_proj = false;
 };
 typedef std::map<FeatureIDType, Feature> MapServer;
 
@@ -168,6 +174,67 @@ class MsckfBackend {
             out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
         }
         return out;
+    }
+
+    // ---- triangulation ------------------------------------------------------------------------------
+    // For every listed feature: Feature::checkMotion, then Feature::initializePosition(imu_states_augment, curr_id)
+    // (include/orcvio/feat/feature.hpp:354-449; called from OrcVIO::removeLostFeatures, src/orcvio.cpp:2258-2270), on the
+    // device.  Observations of `curr_id` and of clones outside the window are skipped as the reference skips them
+    // (:408-412).  Returns, per listed feature, whether it now has a valid position; the reference erases the others
+    // from the map (invalid_feature_ids).
+    orcvio_triangulation_config optimization_config = default_triangulation_config();
+    static orcvio_triangulation_config default_triangulation_config() {
+        orcvio_triangulation_config c;
+        orcvio_msckf_triangulation_config_default(&c);
+        return c;
+    }
+    std::vector<bool> initializePositions(const StateServer& ss, MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                                          StateIDType curr_id, int* status = nullptr) {
+        std::vector<bool> ok(ids.size(), false);
+        if (status) *status = ORCVIO_OK;
+        if (ids.empty()) return ok;
+        std::vector<double> R_b2w, t_b_w, t_fej, R_b2c, t_c_b, p_w, obs_z;
+        std::vector<int32_t> obs_ptr(1, 0), obs_clone, is_init;
+        std::vector<StateIDType> anchor(ids.size(), -1);
+        std::map<StateIDType, int> index_of;
+        flattenWindow(ss, R_b2w, t_b_w, t_fej, R_b2c, t_c_b, index_of);
+        for (size_t k = 0; k < ids.size(); ++k) {
+            const Feature& f = map_server.at(ids[k]);
+            p_w.insert(p_w.end(), f.position, f.position + 3);
+            is_init.push_back(f.is_initialized ? 1 : 0);
+            for (const auto& ob : f.observations) {
+                if (ob.first == curr_id) continue;
+                auto it = index_of.find(ob.first);
+                if (it == index_of.end()) continue;
+                obs_clone.push_back(it->second);
+                obs_z.push_back(ob.second.x); obs_z.push_back(ob.second.y);
+                anchor[k] = ob.first;   // the last listed camera
+            }
+            obs_ptr.push_back((int32_t)obs_clone.size());
+        }
+        const int N = (int)index_of.size();
+        orcvio_msckf_window w{N, R_b2w.data(), t_b_w.data(), t_fej.data(), R_b2c.data(), t_c_b.data()};
+        orcvio_msckf_tracks t{(int32_t)ids.size(), p_w.data(), obs_ptr.data(), obs_clone.data(), obs_z.data(), nullptr};
+        std::vector<int32_t> valid(ids.size()), flg(ids.size());
+        std::vector<double> pos(3 * ids.size()), inv(3 * ids.size());
+        orcvio_triangulation_result r{valid.data(), pos.data(), inv.data(), flg.data(), nullptr};
+        const int rc = orcvio_msckf_triangulate(h_, &optimization_config, &w, &t, is_init.data(), &r);
+        if (status) *status = rc;
+        if (rc != ORCVIO_OK) return ok;
+        for (size_t k = 0; k < ids.size(); ++k) {
+            Feature& f = map_server.at(ids[k]);
+            f.failed_by_neg_dpth = (flg[k] & ORCVIO_TRI_NEG_DEPTH) != 0;
+            f.failed_by_big_proj = (flg[k] & ORCVIO_TRI_BIG_PROJ) != 0;
+            if (!valid[k]) continue;
+            if (!f.is_initialized) std::memcpy(f.position_FEJ, f.position, sizeof(f.position));   // :431-432
+            f.is_initialized = true;
+            std::memcpy(f.position, &pos[3 * k], sizeof(f.position));
+            std::memcpy(f.invParam, &inv[3 * k], sizeof(f.invParam));
+            f.id_anchor = anchor[k];
+            f.invDepth = inv[3 * k + 2];   // 1 / final_position(2) = rho
+            ok[k] = true;
+        }
+        return ok;
     }
 
     // ---- objects --------------------------------------------------------------------------------
