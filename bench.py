@@ -191,6 +191,11 @@ def main():
     upd.close()
     if rank == 0:
         sys.stdout.flush()
+        try:   # RCCL writes its version banner through C stdio: flush that buffer first so that the JSON line comes last
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)   # the one JSON line, last thing on stdout
 
 

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include <functional>
 #include "msckf_kernels.hpp"
 #include "triangulate.hpp"
 #include "object_rows.hpp"
@@ -55,7 +56,12 @@ struct orcvio_msckf_handle {
     size_t meta_bytes = 0, outs_bytes = 0;
     size_t so_meta = 0, so_pw = 0, so_oclone = 0, so_cobs = 0, so_z = 0, so_zvel = 0, so_P = 0, so_outs = 0, so_Pout = 0, stage_bytes = 0;
     // graph policy: a launch graph is captured only when the same launch signature is seen twice in a row
-    unsigned long long sig_graph = 0, sig_last = 0;
+    struct GraphSlot {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        unsigned long long sig = 0, last = 0;
+    };
+    GraphSlot g_update, g_local, g_finish;
     hipStream_t last_stream = nullptr;   // stream of the last run_update / run_finish (download waits for it)
     bool pw_missing = false;            // uploaded without positions: triangulate_uploaded must run before the update
     int *d_tri_valid = nullptr, *d_tri_flags = nullptr, *d_tri_init = nullptr;
@@ -82,10 +88,7 @@ struct orcvio_msckf_handle {
     bool materialize = false;
     int feat_ablate = 0;
     // captured launch graph of run_update (valid for the current upload and launch stream)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    hipStream_t graph_stream = nullptr;
-    bool graph_valid = false;
+    bool graph_valid = false;   // (kept for the option setters: any change of option drops the captured graphs)
     bool use_graph = true;
     size_t hs_rows_cap = 0;
     int gram_chunks_cap = 64;
@@ -183,8 +186,10 @@ static void free_all(orcvio_msckf_handle* h) {
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    if (h->graph) (void)hipGraphDestroy(h->graph);
+    for (auto* g : {&h->g_update, &h->g_local, &h->g_finish}) {
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->side) (void)hipStreamDestroy(h->side);
 }
@@ -657,26 +662,81 @@ static int launch_solve_tail(orcvio_msckf_handle* h, hipStream_t s) {
 
 static hipStream_t pick_stream(orcvio_msckf_handle* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
 
+// ---- launch graphs ------------------------------------------------------------------------------------
+// A sequence of launches can be replayed from a captured hipGraph: same kernels, same arguments, fewer host calls and
+// tighter dispatch.  Capturing costs several hundred microseconds, so a slot captures only when the same launch
+// signature (sizes, flags, options, pointers, stream) shows up twice in a row -- a caller that replays one shape (the
+// benchmark, a fixed-size window) gets the graph, a caller whose track count changes every frame gets plain launches.
+static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStream_t s, const void* p0, long extra) {
+    unsigned long long sig = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
+    mix(h->N); mix(h->F); mix(h->nobs); mix(h->Mmax); mix(h->chunks); mix(h->s_chunks); mix(h->rows_per_chunk);
+    mix(h->flags.leg_dim); mix(h->flags.use_larvio); mix(h->flags.use_left_perturbation); mix(h->flags.if_fej);
+    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->feat_ablate);
+    unsigned long long bits;
+    double sg = h->flags.noise_feature;
+    std::memcpy(&bits, &sg, 8); mix(bits);
+    mix((unsigned long long)(size_t)s); mix((unsigned long long)(size_t)p0); mix((unsigned long long)extra);
+    return sig;
+}
+
+static int run_with_graph(orcvio_msckf_handle* h, orcvio_msckf_handle::GraphSlot& slot, unsigned long long sig, hipStream_t s,
+                          const std::function<int(bool)>& enqueue) {
+    if (h->use_graph && s != nullptr) {
+        if (!(slot.exec && slot.sig == sig) && sig == slot.last) {
+            if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+            if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                const int rc_c = enqueue(true);
+                hipGraph_t g = nullptr;
+                const hipError_t e_end = hipStreamEndCapture(s, &g);
+                if (rc_c == ORCVIO_OK && e_end == hipSuccess && g && hipGraphInstantiate(&slot.exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                    slot.graph = g;
+                    slot.sig = sig;
+                } else {
+                    if (g) (void)hipGraphDestroy(g);
+                    slot.exec = nullptr;
+                    (void)hipGetLastError();
+                    h->use_graph = false;   // capture is not available here: plain launches from now on
+                }
+            } else {
+                (void)hipGetLastError();
+                h->use_graph = false;
+            }
+        }
+        slot.last = sig;
+        if (slot.exec && slot.sig == sig) {
+            HIPCHK(hipGraphLaunch(slot.exec, s));
+            return ORCVIO_OK;
+        }
+    }
+    return enqueue(false);
+}
+
+// this rank's part of a sharded update: the Cholesky of the prior goes to the side stream with plain launches (it is
+// joined by run_finish, so it overlaps the feature kernels AND the collective), the rest replays from a graph
+static int run_local_impl(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
+    h->last_stream = s;
+    int rc = launch_prior_fork(h, s);
+    if (rc != ORCVIO_OK) return rc;
+    return run_with_graph(h, h->g_local, launch_signature(h, s, dst, 0), s, [&](bool) {
+        int r = launch_feature(h, s);
+        if (r == ORCVIO_OK) r = launch_gram(h, s);
+        if (r == ORCVIO_OK) r = launch_assemble(h, s, dst);
+        return r;
+    });
+}
+
 int32_t orcvio_msckf_run_local(orcvio_msckf_handle* h, void* stream) {
     if (!h || !h->uploaded || h->pw_missing) { g_last_error = "run_local: nothing uploaded (or positions missing)"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = pick_stream(h, stream);
-    int rc = launch_prior_fork(h, s);
-    if (rc == ORCVIO_OK) rc = launch_feature(h, s);
-    if (rc == ORCVIO_OK) rc = launch_gram(h, s);
-    if (rc == ORCVIO_OK) rc = launch_assemble(h, s, h->d_Ab);
-    return rc;
+    return run_local_impl(h, pick_stream(h, stream), h->d_Ab);
 }
 
 int32_t orcvio_msckf_run_local_to(orcvio_msckf_handle* h, double* d_dst, void* stream) {
     if (!h || !h->uploaded || !d_dst || h->pw_missing) { g_last_error = "run_local_to: invalid"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = pick_stream(h, stream);
-    int rc = launch_prior_fork(h, s);
-    if (rc == ORCVIO_OK) rc = launch_feature(h, s);
-    if (rc == ORCVIO_OK) rc = launch_gram(h, s);
-    if (rc == ORCVIO_OK) rc = launch_assemble(h, s, d_dst);
-    return rc;
+    return run_local_impl(h, pick_stream(h, stream), d_dst);
 }
 
 int32_t orcvio_msckf_block_ptr(orcvio_msckf_handle* h, double** d_block, int64_t* n_elems) {
@@ -690,8 +750,14 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
     if (!h || !h->uploaded || !d_blocks || n_blocks < 1) { g_last_error = "run_finish: invalid"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
-    int rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);   // rank-ordered sum of the gathered blocks
-    if (rc == ORCVIO_OK) rc = launch_solve_tail(h, s);
+    h->last_stream = s;
+    // the Cholesky of the prior was forked by run_local: join it here (outside the captured part)
+    HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
+    int rc = run_with_graph(h, h->g_finish, launch_signature(h, s, d_blocks, n_blocks), s, [&](bool) {
+        int r = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);   // rank-ordered sum of the gathered blocks
+        for (int st = ST_FORM_U; st < ST_COUNT && r == ORCVIO_OK; ++st) r = launch_solve_stage(h, s, st);
+        return r;
+    });
     if (rc == ORCVIO_OK) h->ran = true;
     return rc;
 }
@@ -711,55 +777,7 @@ int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
     h->last_stream = s;
-    // The launches (and the side-stream fork/join) can be replayed from a captured hipGraph: same kernels, same
-    // arguments, fewer host calls and tighter dispatch.  Capturing costs several hundred microseconds, so it is done only
-    // when the same launch signature (sizes, flags, options, stream) shows up twice in a row -- a caller that replays
-    // one shape (the benchmark, a fixed-size window) gets the graph, a caller whose track count changes every frame
-    // gets plain launches.
-    unsigned long long sig = 1469598103934665603ull;
-    {
-        auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
-        mix(h->N); mix(h->F); mix(h->nobs); mix(h->Mmax); mix(h->chunks); mix(h->s_chunks); mix(h->rows_per_chunk);
-        mix(h->flags.leg_dim); mix(h->flags.use_larvio); mix(h->flags.use_left_perturbation); mix(h->flags.if_fej);
-        mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->feat_ablate);
-        unsigned long long bits;
-        double sg = h->flags.noise_feature;
-        std::memcpy(&bits, &sg, 8); mix(bits);
-        mix((unsigned long long)(size_t)s);
-    }
-    if (h->use_graph && s != nullptr) {
-        if (h->graph_exec && h->sig_graph == sig) h->graph_valid = true;   // an upload of the same shape keeps the graph
-        if (!h->graph_valid && sig == h->sig_last) {
-            if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-            if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
-            if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                const int rc_c = enqueue_update(h, s);
-                hipGraph_t g = nullptr;
-                const hipError_t e_end = hipStreamEndCapture(s, &g);
-                if (rc_c == ORCVIO_OK && e_end == hipSuccess && g &&
-                    hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
-                    h->graph = g;
-                    h->graph_stream = s;
-                    h->graph_valid = true;
-                    h->sig_graph = sig;
-                } else {
-                    if (g) (void)hipGraphDestroy(g);
-                    (void)hipGetLastError();
-                    h->use_graph = false;   // capture is not available here: plain launches from now on
-                }
-            } else {
-                (void)hipGetLastError();
-                h->use_graph = false;
-            }
-        }
-        h->sig_last = sig;
-        if (h->graph_valid && h->sig_graph == sig) {
-            HIPCHK(hipGraphLaunch(h->graph_exec, s));
-            h->ran = true;
-            return ORCVIO_OK;
-        }
-    }
-    int rc = enqueue_update(h, s);
+    int rc = run_with_graph(h, h->g_update, launch_signature(h, s, nullptr, 0), s, [&](bool) { return enqueue_update(h, s); });
     if (rc == ORCVIO_OK) h->ran = true;
     return rc;
 }
