@@ -611,7 +611,8 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
         case ST_FORM_U:    // U[(NA+1) x n] = [A; b^T] * L_a
             return launch_gemm(s, h->d_A, NAP, 1, La, sLi, sLj, NA + 1, n, NA, 1.0, 0.0, 0, h->d_U, NP, 1);
         case ST_FORM_M:    // M = s2 I + L_a^T U[0:NA]   (upper tiles)
-            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, n, n, NA, 1.0, sigma2, 1, h->d_M, NP, 1, h->d_flag);
+            // (the register-resident Cholesky reads the upper tiles only; the LDS-panel fallback factors the lower triangle in place)
+            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, n, n, NA, 1.0, sigma2, h->reg_path ? 1 : 0, h->d_M, NP, 1, h->d_flag);
         case ST_POTRF_M:
             if (fused_solve_active(h)) {   // chol(M) + Z = L_M^-1 [Lf^T | g] in one launch (solver workgroups trail the factorisation)
                 const int nbm = (n + 15) / 16, need = potrf_slots_needed(nbm);

@@ -1,29 +1,26 @@
-// msckf_kernels.hpp -- hand-written gfx950 (CDNA4) kernels of the MSCKF update path.
+// msckf_kernels.hpp -- hand-written gfx950 (CDNA4) kernels of the MSCKF update path (DESIGN.md section 3).
 //
-// Data layout in HBM (all FP64):
+// Data layout in HBM (all FP64; DESIGN.md section 4):
 //   poses  [N][28]        clone pose records (msckf_math.hpp)
 //   P      [n][n]         prior covariance (symmetric)
-//   Hs     [m][NAP]       stacked projected blocks [H' | r' | 0-pad], row-major;
-//                         column a <-> state column 15+a (a < NA = n-15), column NA = r'
-//   Gpart  [C][NAP][NAP]  per-row-chunk partial Gram matrices (lower tiles only)
-//   Ab     [NAP][NAP]     Gram block [A b; b^T c] of this rank (lower, row-major)
-//   La     [NAP][NAP]     lower Cholesky factor of the summed Gram block (R = La^T)
-//   T      [NA][ldt]      R * P[15:n, :]
-//   S      [NA][NAP]      R P_aa R^T + sigma^2 I, then its lower Cholesky factor
-//   Z      [NA][ldt]      L_S^-1 [T | r_thin]
+//   T3     [3F][NAP]      first three rows of Q^T [J | r] of every track; column a <-> state column 15+a (a < NA = n-15),
+//                         column NA = residual
+//   Xobs   [2 nobs][16]   un-projected rows [H_e 6, td, H_x 6, r, 0, 0], grouped by clone
+//   S, Gpart              partial Gram tiles of Xobs (per clone chunk) and of T3 (per row chunk)
+//   Ab / A [NAP][NAP]     Gram block [A b; b^T c] of this rank / summed over ranks
+//   R_P, R_M [NP][NP]     upper Cholesky factors (X = R^T R) of P and of M = s2 I + L_a^T A L_a
+//   U, M, Z               solve intermediates
 //
 // Kernels (one wavefront = 64 lanes everywhere):
-//   k_feature     one wavefront per feature track: Jacobians (reference
-//                 src/orcvio.cpp:1071-1226), Householder nullspace projection
-//                 (math_utils.hpp:287-312), chi-square gate (:1953-1976), coalesced
-//                 write of the projected block into Hs.
-//   k_gram        FP64-MFMA (v_mfma_f64_16x16x4_f64) tall-skinny Gram of Hs -- the
-//                 compression step of :2532-2552 in CholeskyQR form.
-//   k_gram_reduce sums partial Gram blocks (chunks of this rank, or the blocks of all
-//                 ranks after the RCCL all-gather).
-//   k_potrf       single-workgroup blocked Cholesky with MFMA trailing updates.
-//   k_gemm_*      small FP64-MFMA products of the Kalman solve (:1682-1753).
-//   k_trsm        blocked forward substitution, accumulators fed back as MFMA operands.
+//   k_feature      four wavefronts per track: Jacobians (reference src/orcvio.cpp:1071-1226), Householder QR of H_f
+//                  (math_utils.hpp:287-312), E = J P J^T, chi-square gate (:1953-1976) by tile Cholesky, outputs
+//   k_gram_pair    FP64-MFMA (v_mfma_f64_16x16x4_f64) Grams of Xobs and T3 -- the compression of :2532-2552 in
+//                  Gram form; k_gram (one of the two), k_gram_reduce (sum of the ranks' blocks)
+//   k_assemble_A   A = scatter(sum S) - sum Gpart
+//   k_potrf_reg    register-resident single-workgroup Cholesky; k_potrf_solve: the same + the triangular solve
+//                  in one launch; k_potrf (LDS panels) and k_trsm_rl / k_trsm_lds for large windows and batches
+//   k_gemm, k_finish_sqrt   split-K MFMA products of the Kalman solve (:1682-1753)
+//   k_obj_*        object blocks (:2154-2193)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -1036,126 +1033,7 @@ __device__ __forceinline__ d4 tile_product(const double* __restrict__ A, long sA
     return acc;
 }
 
-// T[NA][ldt] = La^T[NA x NA] * P[15:n, 0:n] ; column n of T <- r_thin = La[NA][0:NA]
-__global__ __launch_bounds__(256) void k_form_T(const double* __restrict__ La, int NAP, const double* __restrict__ P, int n,
-                                                int NA, double* __restrict__ T, int ldt) {
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int ntj = (n + 1 + 15) >> 4;
-    const int tile = blockIdx.x * 4 + wave;
-    const int nti = (NA + 15) >> 4;
-    if (tile >= nti * ntj) return;
-    const int bi = tile / ntj, bj = tile - bi * ntj;
-    // A(i,k) = La[k][i]  (R = La^T), B(k,j) = P[15+k][j]
-    d4 acc = tile_product(La, 1, NAP, P + (size_t)15 * n, n, 1, NA, n, NA, 16 * bi, 16 * bj, l);
-    const int kk = l >> 4, cc = l & 15;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
-        if (i < NA) {
-            if (jj < n) T[(size_t)i * ldt + jj] = acc[r];
-            else if (jj == n) T[(size_t)i * ldt + n] = La[(size_t)NA * NAP + i];   // r_thin
-        }
-    }
-}
-
-// S[NA][lds] (lower tiles) = T[:, 15:n] * La + sigma2 I
-__global__ __launch_bounds__(256) void k_form_S(const double* __restrict__ T, int ldt, const double* __restrict__ La, int NAP,
-                                                int NA, double sigma2, double* __restrict__ S, int lds) {
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nb = (NA + 15) >> 4;
-    const int ntiles = nb * (nb + 1) / 2;
-    const int tl = blockIdx.x * 4 + wave;
-    if (tl >= ntiles) return;
-    int bi, bj;
-    tile_from_linear(tl, bi, bj);
-    // A(i,k) = T[i][15+k], B(k,j) = La[k][j]
-    d4 acc = tile_product(T + 15, ldt, 1, La, NAP, 1, NA, NA, NA, 16 * bi, 16 * bj, l);
-    const int kk = l >> 4, cc = l & 15;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
-        if (i < NA && jj < NA) S[(size_t)i * lds + jj] = acc[r] + ((i == jj) ? sigma2 : 0.0);
-    }
-}
-
-// P_out = sym(P) - Zn^T Zn (lower tiles mirrored), dx = Zn^T z  with Z = [Zn | z] (NA x (n+1))
-__global__ __launch_bounds__(256) void k_finish(const double* __restrict__ Z, int ldz, int NA, const double* __restrict__ P, int n,
-                                                double* __restrict__ P_out, double* __restrict__ dx) {
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nb = (n + 1 + 15) >> 4;
-    const int ntiles = nb * (nb + 1) / 2;
-    const int tl = blockIdx.x * 4 + wave;
-    if (tl >= ntiles) return;
-    int bi, bj;
-    tile_from_linear(tl, bi, bj);
-    // A(i,k) = Z[k][i], B(k,j) = Z[k][j]
-    d4 acc = tile_product(Z, 1, ldz, Z, ldz, 1, n + 1, n + 1, NA, 16 * bi, 16 * bj, l);
-    const int kk = l >> 4, cc = l & 15;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
-        if (i < n && jj < n && jj <= i) {
-            const double pv = 0.5 * (P[(size_t)i * n + jj] + P[(size_t)jj * n + i]) - acc[r];
-            P_out[(size_t)i * n + jj] = pv;
-            P_out[(size_t)jj * n + i] = pv;
-        } else if (i == n && jj < n) {
-            dx[jj] = acc[r];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// k_trsm: Z = L^-1 B for a lower-triangular L (NA x NA, ldl) with precomputed inverses of
-// its 16x16 diagonal blocks.  One wavefront per 16 right-hand-side columns; the solved
-// tiles stay in registers in the MFMA C layout, which is also the B-operand layout.
-// ---------------------------------------------------------------------------------------
-#define TRSM_MAXBLK 26
-__global__ __launch_bounds__(64) void k_trsm(const double* __restrict__ L, int ldl, const double* __restrict__ Dinv, int NA,
-                                             const double* __restrict__ B, int ldb, int nrhs, double* __restrict__ Z, int ldz) {
-    const int l = threadIdx.x;
-    const int j0 = blockIdx.x * 16;
-    const int kk = l >> 4, cc = l & 15;
-    const int nblk = (NA + 15) >> 4;
-    const bool jin = (j0 + cc) < nrhs;
-    d4 X[TRSM_MAXBLK];
-#pragma unroll
-    for (int kb = 0; kb < TRSM_MAXBLK; ++kb) {
-        if (kb < nblk) {
-            d4 acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * kb + kk + 4 * r;
-                acc[r] = (jin && i < NA) ? B[(size_t)i * ldb + j0 + cc] : 0.0;
-            }
-            // acc -= L[kb][jb] * X[jb]
-#pragma unroll
-            for (int jb = 0; jb < TRSM_MAXBLK; ++jb) {
-                if (jb < kb) {
-                    const int ia = 16 * kb + cc;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const double a = (ia < NA) ? -L[(size_t)ia * ldl + 16 * jb + kk + 4 * s] : 0.0;
-                        acc = mfma_f64(a, X[jb][s], acc);
-                    }
-                }
-            }
-            // X[kb] = Dinv[kb] * acc
-            d4 x = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double a = Dinv[(size_t)kb * 256 + cc * 16 + kk + 4 * s];
-                x = mfma_f64(a, acc[s], x);
-            }
-            X[kb] = x;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * kb + kk + 4 * r;
-                if (jin && i < NA) Z[(size_t)i * ldz + j0 + cc] = x[r];
-            }
-        }
-    }
-}
-
+#define TRSM_MAXBLK 26   // block rows the fallback solve k_trsm_rl keeps in registers (n <= 416)
 
 // =======================================================================================
 // Register-resident Cholesky and the square-root form of the Kalman solve

@@ -237,3 +237,21 @@ def test_fused_solve_equals_two_launch_solve(upd, cfg):
         assert np.array_equal(got['accept'], ref['accept'])
         assert rel(got['dx'], ref['dx']) < 1e-12
         assert rel(got['P_new'], ref['P_new']) < 1e-12
+
+
+def test_large_window_takes_the_lds_panel_path(upd):
+    """N = 38 clones: n = 250 > 224, so both factorisations use the LDS-panel kernel (k_potrf) and the solve k_trsm_rl
+    instead of the register-resident / fused kernels."""
+    w = synth.make_window(N=38, F=60, seed=21, track_len=(3, 12))
+    assert w.n > 224
+    _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
+
+
+def test_maximum_window_of_60_clones(built):
+    """ORCVIO_MAX_CLONES: n = 382, six 64-column passes in k_feature, 24 block steps in the LDS-panel factorisation."""
+    u = capi.MsckfUpdater(device=0, max_clones=60, max_features=256, max_observations=8192)
+    try:
+        w = synth.make_window(N=60, F=40, seed=5, track_len=(3, 20))
+        _compare(u.update_features(w, want_G=True), oracle.msckf_update(w), w)
+    finally:
+        u.close()
