@@ -240,6 +240,20 @@ typedef struct orcvio_msckf_state {
 int32_t orcvio_msckf_increment_state(const orcvio_msckf_flags* flags, const double* dx,
                                      orcvio_msckf_state* state);
 
+/* ---- Object update in two halves (the multi-GPU form of orcvio_msckf_update_objects) -----------------
+ * Objects are dealt across the ranks; P and the window are replicated.  objects_local leaves this rank's compressed
+ * block [A' b'; b'^T c'] (NAP x NAP doubles, NAP = 16*ceil((6*n_clones + leg_dim - 14)/16)) in d_dst (device memory;
+ * NULL = the handle's own block, orcvio_msckf_block_ptr) and reports the degrees of freedom of its usable objects;
+ * the caller all-gathers the blocks and sums the dofs; objects_finish sums the blocks in rank order, solves, gates
+ * jointly with dof_total (src/orcvio.cpp:2172-2176) and applies or discards the update; objects_download returns
+ * accept[0], gamma[0], dx, P_out (and G on request). */
+int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
+                                   const orcvio_msckf_object_rows* objects, int32_t n_objects, const double* P,
+                                   double* d_dst, int32_t* dof_out, void* stream);
+int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks,
+                                    int32_t dof_total, void* stream);
+int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_result* result);
+
 /* ---- Feature triangulation --------------------------------------
  * Replaces, for every listed track, Feature::checkMotion followed by Feature::initializePosition
  * (include/orcvio/feat/feature.hpp:354-449; the Levenberg-Marquardt of ::triangulate_position, :583-719, with

@@ -30,7 +30,8 @@ EXPORTS = [
     'orcvio_msckf_sync', 'orcvio_msckf_download', 'orcvio_msckf_profile_update',
     'orcvio_msckf_increment_state', 'orcvio_msckf_set_option', 'orcvio_msckf_run_local_to',
     'orcvio_msckf_object_rows_eval', 'orcvio_msckf_triangulation_config_default', 'orcvio_msckf_triangulate',
-    'orcvio_msckf_triangulate_uploaded',
+    'orcvio_msckf_triangulate_uploaded', 'orcvio_msckf_objects_local', 'orcvio_msckf_objects_finish',
+    'orcvio_msckf_objects_download',
 ]
 
 
@@ -134,6 +135,10 @@ def load():
     lib.orcvio_msckf_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangulationConfig), C.POINTER(MsckfWindow),
                                              C.POINTER(MsckfTracks), _ip, C.POINTER(TriangulationResult)]
     lib.orcvio_msckf_triangulate_uploaded.argtypes = [C.c_void_p, C.POINTER(TriangulationConfig), _ip, C.c_void_p]
+    lib.orcvio_msckf_objects_local.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.c_int32, C.POINTER(MsckfObjectRows),
+                                               C.c_int32, _dp, C.c_void_p, _ip, C.c_void_p]
+    lib.orcvio_msckf_objects_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.orcvio_msckf_objects_download.argtypes = [C.c_void_p, C.POINTER(MsckfResult)]
     _LIB = lib
     return lib
 
@@ -265,6 +270,48 @@ class MsckfUpdater:
         rc = self.lib.orcvio_msckf_update_objects(self.h, C.byref(fl), n_clones, arr, len(blocks), _d(Pc), C.byref(res))
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_update_objects')
+        out = self._finish(out, res, 1)
+        out['gamma'] = float(out['gamma'][0])
+        out['accept'] = int(out['accept'][0])
+        return out
+
+    def _object_blocks(self, blocks):
+        keep = []
+        arr = (MsckfObjectRows * max(len(blocks), 1))()
+        for k, b in enumerate(blocks):
+            rc_ = np.ascontiguousarray(b['row_clone'], dtype=np.int32)
+            hx = np.ascontiguousarray(b['Hx6'], dtype=np.float64)
+            hf = np.ascontiguousarray(b['Hf'], dtype=np.float64)
+            rs = np.ascontiguousarray(b['res'], dtype=np.float64)
+            keep += [rc_, hx, hf, rs]
+            arr[k] = MsckfObjectRows(len(rs), hf.shape[1] if hf.ndim == 2 else 0, _i(rc_), _d(hx), _d(hf), _d(rs))
+        return arr, keep
+
+    def objects_local(self, flags, n_clones, blocks, P, d_dst=None, stream=None):
+        """This rank's objects -> its compressed block (in d_dst or the handle's own block); returns the local dof."""
+        fl = make_flags(flags)
+        arr, keep = self._object_blocks(blocks)
+        Pc = np.ascontiguousarray(P, dtype=np.float64)
+        dof = C.c_int32(0)
+        rc = self.lib.orcvio_msckf_objects_local(self.h, C.byref(fl), n_clones, arr, len(blocks), _d(Pc),
+                                                 C.c_void_p(d_dst) if d_dst else None, C.byref(dof),
+                                                 C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_objects_local')
+        self.n = flags.leg_dim + 6 * n_clones
+        return int(dof.value)
+
+    def objects_finish(self, d_blocks, n_blocks, dof_total, stream=None):
+        rc = self.lib.orcvio_msckf_objects_finish(self.h, C.c_void_p(d_blocks), n_blocks, int(dof_total),
+                                                  C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_objects_finish')
+
+    def objects_download(self, want_G=False):
+        out, res = self._result(self.n, 1, False, want_G, False)
+        rc = self.lib.orcvio_msckf_objects_download(self.h, C.byref(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_objects_download')
         out = self._finish(out, res, 1)
         out['gamma'] = float(out['gamma'][0])
         out['accept'] = int(out['accept'][0])

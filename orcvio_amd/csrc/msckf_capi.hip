@@ -912,12 +912,14 @@ int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_
 // onto the left nullspace of its own Hf (SURVEY.md note N3: equal to the reference whenever one object
 // arrives per call); the blocks are stacked, gated jointly with dof = sum(rows - cols) and applied in one
 // update.  Objects with rows <= cols cannot be projected (math_utils.hpp:292) and are skipped.
-int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
-                                    const orcvio_msckf_object_rows* objs, int32_t n_objects, const double* P,
-                                    orcvio_msckf_result* res) {
-    if (!h || !flags || !P || !res || n_objects < 0 || (n_objects > 0 && !objs)) { g_last_error = "update_objects: null argument"; return ORCVIO_ERR_INVALID; }
-    if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = "update_objects: leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
-    if (n_clones < 1 || n_clones > h->maxN) { g_last_error = "update_objects: window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
+// Local part of an object update: this rank's objects -> its compressed block [A' b'; b'^T c'] (NAP x NAP) in d_dst
+// (the handle's own block if NULL), Cholesky of P forked on the side stream.
+int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
+                                   const orcvio_msckf_object_rows* objs, int32_t n_objects, const double* P, double* d_dst,
+                                   int32_t* dof_out, void* stream) {
+    if (!h || !flags || !P || n_objects < 0 || (n_objects > 0 && !objs)) { g_last_error = "objects_local: null argument"; return ORCVIO_ERR_INVALID; }
+    if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = "objects_local: leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
+    if (n_clones < 1 || n_clones > h->maxN) { g_last_error = "objects_local: window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
     const int N = n_clones;
     h->flags = *flags;
@@ -936,11 +938,11 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     int no_max = 0, rows_tot = 0, dof = 0;
     for (int o = 0; o < n_objects; ++o) {
         const orcvio_msckf_object_rows& ob = objs[o];
-        if (ob.n_rows < 0 || ob.n_obj_cols < 1 || ob.n_obj_cols > 112) { g_last_error = "update_objects: bad block shape (object state columns must be 1..112)"; return ORCVIO_ERR_INVALID; }
-        if (ob.n_rows > 0 && (!ob.row_clone || !ob.Hx6 || !ob.Hf || !ob.res)) { g_last_error = "update_objects: null block arrays"; return ORCVIO_ERR_INVALID; }
+        if (ob.n_rows < 0 || ob.n_obj_cols < 1 || ob.n_obj_cols > 112) { g_last_error = "objects_local: bad block shape (object state columns must be 1..112)"; return ORCVIO_ERR_INVALID; }
+        if (ob.n_rows > 0 && (!ob.row_clone || !ob.Hx6 || !ob.Hf || !ob.res)) { g_last_error = "objects_local: null block arrays"; return ORCVIO_ERR_INVALID; }
         if (ob.n_rows <= ob.n_obj_cols) continue;   // nullspace_project_inplace_svd returns false
         for (int r = 0; r < ob.n_rows; ++r)
-            if (ob.row_clone[r] < 0 || ob.row_clone[r] >= N) { g_last_error = "update_objects: row_clone out of range"; return ORCVIO_ERR_INVALID; }
+            if (ob.row_clone[r] < 0 || ob.row_clone[r] >= N) { g_last_error = "objects_local: row_clone out of range"; return ORCVIO_ERR_INVALID; }
         use.push_back(o);
         rows_tot += ob.n_rows;
         chunk_ptr.push_back(rows_tot);
@@ -948,23 +950,19 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
         if (ob.n_obj_cols > no_max) no_max = ob.n_obj_cols;
     }
     const int nobj = (int)use.size();
-    hipStream_t s = h->stream;
+    hipStream_t s = pick_stream(h, stream);
+    h->last_stream = s;
+    double* dst = d_dst ? d_dst : h->d_Ab;
+    if (dof_out) *dof_out = dof;
     HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
     h->uploaded = true;
     h->objects_mode = true;
     h->obj_dof = dof; h->obj_rows = rows_tot; h->obj_count = nobj;
     int rc = ORCVIO_OK;
     if (!h->d_obj_accept) { HIPCHK(hipMalloc(&h->d_obj_accept, sizeof(int) * 4)); HIPCHK(hipMalloc(&h->d_obj_gamma, sizeof(double) * 4)); }
-    const double sigma2 = flags->noise_feature * flags->noise_feature;
-    if (nobj == 0) {   // nothing usable: P unchanged, dx = 0
-        HIPCHK(hipStreamSynchronize(s));
-        if (res->dx) std::memset(res->dx, 0, sizeof(double) * n);
-        if (res->P_out) std::memcpy(res->P_out, P, sizeof(double) * (size_t)n * n);
-        if (res->accept) res->accept[0] = 0;
-        if (res->gamma) res->gamma[0] = NAN;
-        std::memset(res->stats, 0, sizeof(res->stats));
-        h->objects_mode = false;
-        return ORCVIO_OK;
+    if (nobj == 0) {   // nothing usable on this rank: a zero block
+        HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)NAP * NAP, s));
+        return launch_prior_fork(h, s);
     }
     const int NOP = round_up(no_max, 16), W = NAP + NOP;
     // host staging of the compact rows (one contiguous upload per array)
@@ -1037,20 +1035,46 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     // A' = sum_o B_o - Y^T Y  (Y = all Y_o stacked; padded rows are zero)
     hipLaunchKernelGGL(k_obj_sum_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, h->d_Gobj, nobj, W, NAP, h->d_Ab);
     hipLaunchKernelGGL(k_gemm, dim3((NAP / 16) * (NAP / 16)), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
-                       NAP, NAP, nobj * NOP, -1.0, 0.0, 0, h->d_A, (long)NAP, 1L, h->d_Ab);
+                       NAP, NAP, nobj * NOP, -1.0, 0.0, 0, dst, (long)NAP, 1L, h->d_Ab);
     HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+// Second part: rank-ordered sum of the gathered blocks, replicated solve, joint chi-square gate with the TOTAL degrees
+// of freedom of all ranks' objects, gated write-back.
+int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks, int32_t dof_total, void* stream) {
+    if (!h || !h->uploaded || !h->objects_mode || !d_blocks || n_blocks < 1) { g_last_error = "objects_finish: no local object block"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    h->last_stream = s;
+    const int n = h->n, NA = h->NA, NAP = h->NAP;
+    const double sigma2 = h->flags.noise_feature * h->flags.noise_feature;
+    h->obj_dof = dof_total;
+    int rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);
+    if (rc != ORCVIO_OK) return rc;
     // Kalman solve in square-root form, gate, gated write-back
     HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
     for (int st = ST_FORM_U; st <= ST_TRSM && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
     if (rc != ORCVIO_OK) return rc;
-    const double thr = orcvio_msckf_chi2_quantile(dof, flags->chi2_prob);   // table value below 500 dof, on the fly above (:1962-1968)
+    // table value below 500 dof, on the fly above (:1962-1968); dof 0 (no usable object anywhere) can never pass
+    const double thr = dof_total > 0 ? orcvio_msckf_chi2_quantile(dof_total, h->flags.chi2_prob) : -1.0;
     hipLaunchKernelGGL(k_obj_gate, dim3(1), dim3(64), 0, s, h->d_A, NAP, NA, h->d_Z, h->ldz, n, sigma2, thr, h->d_obj_gamma, h->d_obj_accept);
     HIPCHK(hipGetLastError());
     rc = launch_solve_stage(h, s, ST_FINISH);
-    if (rc != ORCVIO_OK) return rc;
-    HIPCHK(hipStreamSynchronize(s));
+    if (rc == ORCVIO_OK) h->ran = true;
+    return rc;
+}
+
+// Results of an object update (after orcvio_msckf_objects_finish): accept[0], gamma[0], dx, P_out, stats, optional G.
+int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) {
+    if (!h || !res || !h->ran || !h->objects_mode) { g_last_error = "objects_download: no finished object update"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    if (h->last_stream) HIPCHK(hipStreamSynchronize(h->last_stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipStreamSynchronize(h->side));
-    h->ran = true;
+    const int n = h->n, NA = h->NA, dof = h->obj_dof, nobj = h->obj_count;
+    const orcvio_msckf_flags* flags = &h->flags;
+    int rc = ORCVIO_OK;
     // results
     int acc = 0;
     double gam = NAN;
@@ -1060,6 +1084,7 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     HIPCHK(hipMemcpy(dx.data(), h->d_dx, sizeof(double) * n, hipMemcpyDeviceToHost));
     if (res->dx) std::memcpy(res->dx, dx.data(), sizeof(double) * n);
     if (res->P_out) HIPCHK(hipMemcpy(res->P_out, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+    if (dof == 0) gam = NAN;   // no usable object on any rank (the reference returns before the gate, :2157)
     if (res->accept) res->accept[0] = acc;
     if (res->gamma) res->gamma[0] = gam;
     int info[8] = {0};
@@ -1090,8 +1115,21 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
             std::memset(res->G, 0, sizeof(double) * (size_t)n * n);
         }
     }
-    h->objects_mode = false;
     return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
+                                    const orcvio_msckf_object_rows* objs, int32_t n_objects, const double* P,
+                                    orcvio_msckf_result* res) {
+    if (!res) { g_last_error = "update_objects: null argument"; return ORCVIO_ERR_INVALID; }
+    int32_t dof = 0;
+    int rc = orcvio_msckf_objects_local(h, flags, n_clones, objs, n_objects, P, nullptr, &dof, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    rc = orcvio_msckf_objects_finish(h, h->d_Ab, 1, dof, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    rc = orcvio_msckf_objects_download(h, res);
+    h->objects_mode = false;
+    return rc;
 }
 
 // ---- object residual rows ------------------------------------------------------

@@ -96,3 +96,77 @@ def test_dealing_is_balanced_and_complete():
         rho = np.where(M >= 2, 2 * M - 3, 0)
         loads = np.array([rho[p].sum() for p in parts])
         assert loads.max() - loads.min() <= rho.max()
+
+
+def _object_worker(rank, world, port, q):
+    """Objects dealt round-robin over the ranks: each rank projects ITS objects against their own H_f and forms its
+    block; all-gather, rank-ordered sum, joint gate with the summed dof, replicated solve."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch
+    import torch.distributed as dist
+    from orcvio_amd import synth, sharding
+    from oracle import mirror, mirror_objects as mo
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    flags = synth.Flags(use_larvio=0)
+    win = synth.make_window(N=10, F=4, seed=2, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=5, seed=9, sigma_kp=0.004)
+    NA = win.n - 15
+    A = np.zeros((NA + 1, NA + 1))
+    dof = 0
+    for ob in objs[rank::world]:
+        res, Hf, Jc, counts = mo.object_rows(ob.wTo, ob.shape, ob.kps, ob.frames, True, False)
+        Hx, Hf2, r, rc, hx6 = mo.construct_object_residual_jacobians(Jc, [fr['clone'] for fr in ob.frames], Hf, res, counts,
+                                                                      [fr['wTc'] for fr in ob.frames], win.R_b2c[0], win.t_c_b[0], 0,
+                                                                      flags.leg_dim, win.N)
+        ok, H1, r1 = mirror.nullspace_project_svd(Hf2, Hx, r)
+        X = np.hstack([H1[:, 15:], r1[:, None]])
+        A += X.T @ X
+        dof += H1.shape[0]
+    local = torch.from_numpy(np.ascontiguousarray(A))
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    d = torch.tensor([dof])
+    dist.all_reduce(d)
+    total = sharding.sum_blocks(gathered).numpy()
+    dx, Pn = _finish(total, win.P, flags.noise_feature ** 2)
+    q.put((rank, int(d.item()), total, dx, Pn))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_object_update_equals_single_update(built):
+    import torch.multiprocessing as mp
+    from orcvio_amd import synth
+    from oracle import mirror, mirror_objects as mo
+    from helpers import rel
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_object_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    flags = synth.Flags(use_larvio=0)
+    win = synth.make_window(N=10, F=4, seed=2, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=5, seed=9, sigma_kp=0.004)
+    Hs, rs = [], []
+    for ob in objs:
+        r0, Hf, Jc, counts = mo.object_rows(ob.wTo, ob.shape, ob.kps, ob.frames, True, False)
+        Hx, Hf2, r, rc, hx6 = mo.construct_object_residual_jacobians(Jc, [fr['clone'] for fr in ob.frames], Hf, r0, counts,
+                                                                      [fr['wTc'] for fr in ob.frames], win.R_b2c[0], win.t_c_b[0], 0,
+                                                                      flags.leg_dim, win.N)
+        ok, H1, r1 = mirror.nullspace_project_svd(Hf2, Hx, r)
+        Hs.append(H1); rs.append(r1)
+    H = np.vstack(Hs); r = np.concatenate(rs)
+    Ht, rt = mirror.qr_compress(H, r)
+    dx, K, Pn = mirror.measurement_update(Ht, rt, win.P, flags.noise_feature ** 2)
+    (_, d0, A0, dx0, P0), (_, d1, A1, dx1, P1) = res
+    assert d0 == d1 == H.shape[0]
+    assert np.array_equal(A0, A1) and np.array_equal(dx0, dx1) and np.array_equal(P0, P1)
+    assert rel(dx0, dx) < 1e-8 and rel(P0, Pn) < 1e-9

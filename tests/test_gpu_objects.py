@@ -163,3 +163,38 @@ def test_object_rows_eval_no_frame_in_window(upd):
     for fr in obj.frames:
         fr['clone'] = -1
     assert upd.object_rows_eval(obj, win.R_b2c[0], win.t_c_b[0], True, False, 0) is None
+
+
+def test_sharded_objects_equal_one_shot(upd):
+    """objects_local on two shards (as two ranks would), the two compressed blocks gathered, objects_finish with the
+    summed dof: equal to orcvio_msckf_update_objects on all objects (objects dealt across GPUs)."""
+    import ctypes as C
+    import torch
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=30, F=4, seed=0, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=7, seed=3, sigma_kp=0.004)
+    blocks = []
+    for ob in objs:
+        Hx, Hf, r, rc, hx6 = _rows_for(win, ob, True, False, 0)
+        blocks.append(dict(row_clone=rc, Hx6=hx6, Hf=Hf, res=r))
+    one = upd.update_objects(flags, win.N, blocks, win.P)
+    assert one['accept'] == 1
+    hip = C.CDLL('libamdhip64.so')
+    parts, dof = [], 0
+    for rank in range(2):
+        dof += upd.objects_local(flags, win.N, blocks[rank::2], win.P)
+        upd.sync()
+        ptr, ne = upd.block_ptr()
+        t = torch.empty(ne, dtype=torch.float64, device='cuda:0')
+        assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(ne * 8), 3) == 0
+        parts.append(t)
+    gathered = torch.cat(parts)
+    torch.cuda.synchronize()
+    upd.objects_finish(gathered.data_ptr(), 2, dof)
+    got = upd.objects_download()
+    assert got['accept'] == 1 and got['stats'][0] == one['stats'][0]
+    assert abs(got['gamma'] - one['gamma']) < 1e-9 * abs(one['gamma'])
+    assert rel(got['dx'], one['dx']) < 1e-9 and rel(got['P_new'], one['P_new']) < 1e-10
+    # a rank without objects contributes a zero block and dof 0
+    d0 = upd.objects_local(flags, win.N, [], win.P)
+    assert d0 == 0
