@@ -292,6 +292,25 @@ int32_t orcvio_msckf_triangulate(orcvio_msckf_handle* h, const orcvio_triangulat
 int32_t orcvio_msckf_triangulate_uploaded(orcvio_msckf_handle* h, const orcvio_triangulation_config* cfg,
                                           const int32_t* is_initialized, void* stream);
 
+/* ---- Device-resident covariance ------------------------------------------
+ * The three places besides the update where the reference touches state_cov, on a copy of P that stays in HBM, so that
+ * P does not cross PCIe every frame.  n = leg_dim + 6 * (clones in the window); no EKF-SLAM / nuisance states.
+ *   cov_set / cov_get     host <-> resident P (n x n, row-major)
+ *   cov_propagate         OrcVIO::processModel, src/orcvio.cpp:800-816: P_LL <- Phi P_LL Phi^T + Q (leg x leg blocks,
+ *                         row-major), cross terms, symmetrised
+ *   cov_augment           OrcVIO::stateAugmentation, :962-1010: n -> n + 6, the new clone copies the IMU (theta, p) covariance
+ *   cov_remove_clones     OrcVIO::pruneImuStateBuffer, :2935-2951 (non-Schmidt branch): rows/cols of the listed window
+ *                         indices (ascending rank in the window) are deleted
+ *   cov_commit            resident P <- P+ of the update that has just run (features: always defined; objects: P if rejected)
+ * orcvio_msckf_upload / orcvio_msckf_update_features / orcvio_msckf_objects_local accept P == NULL: the resident P is
+ * used (its dimension must match the window). */
+int32_t orcvio_msckf_cov_set(orcvio_msckf_handle* h, int32_t n, const double* P);
+int32_t orcvio_msckf_cov_get(orcvio_msckf_handle* h, int32_t* n_out, double* P_out /* may be NULL */);
+int32_t orcvio_msckf_cov_propagate(orcvio_msckf_handle* h, int32_t leg_dim, const double* Phi, const double* Q);
+int32_t orcvio_msckf_cov_augment(orcvio_msckf_handle* h);
+int32_t orcvio_msckf_cov_remove_clones(orcvio_msckf_handle* h, int32_t leg_dim, const int32_t* clone_indices, int32_t count);
+int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h);
+
 #ifdef __cplusplus
 }
 #endif

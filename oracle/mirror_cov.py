@@ -1,0 +1,41 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the covariance bookkeeping around the update.
+
+  propagate       OrcVIO::processModel, src/orcvio.cpp:800-816   P_LL <- Phi P_LL Phi^T + Q, cross terms, symmetrise
+  augment         OrcVIO::stateAugmentation, :962-1010 (no EKF-SLAM / nuisance states: rest_rows = 0)
+                  J = [I3 at cols 0:3 ; I3 at cols 6:9] -> the new clone copies the IMU (theta, p) covariance
+  remove_clones   OrcVIO::pruneImuStateBuffer, :2935-2951 (the non-Schmidt branch): rows/cols of the pruned clones deleted
+Parity unpinned (no reference test touches these lines).  Nothing under orcvio_amd/ may import this module.
+"""
+import numpy as np
+
+
+def propagate(P, Phi, Q):
+    leg = Phi.shape[0]
+    P = P.copy()
+    P[:leg, :leg] = Phi @ P[:leg, :leg] @ Phi.T + Q
+    if P.shape[0] > leg:
+        P[:leg, leg:] = Phi @ P[:leg, leg:]
+        P[leg:, :leg] = P[leg:, :leg] @ Phi.T
+    return 0.5 * (P + P.T)
+
+
+def augment(P):
+    n = P.shape[0]
+    J = np.zeros((6, n))
+    J[0:3, 0:3] = np.eye(3)
+    J[3:6, 6:9] = np.eye(3)
+    P12 = J @ P
+    P11 = P12 @ J.T
+    out = np.zeros((n + 6, n + 6))
+    out[:n, :n] = P
+    out[n:, :n] = P12
+    out[:n, n:] = P12.T
+    out[n:, n:] = P11
+    return 0.5 * (out + out.T)
+
+
+def remove_clones(P, leg, clone_indices):
+    keep = np.ones(P.shape[0], bool)
+    for c in clone_indices:
+        keep[leg + 6 * c: leg + 6 * c + 6] = False
+    return P[np.ix_(keep, keep)].copy()

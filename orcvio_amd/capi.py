@@ -31,7 +31,8 @@ EXPORTS = [
     'orcvio_msckf_increment_state', 'orcvio_msckf_set_option', 'orcvio_msckf_run_local_to',
     'orcvio_msckf_object_rows_eval', 'orcvio_msckf_triangulation_config_default', 'orcvio_msckf_triangulate',
     'orcvio_msckf_triangulate_uploaded', 'orcvio_msckf_objects_local', 'orcvio_msckf_objects_finish',
-    'orcvio_msckf_objects_download',
+    'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
+    'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
 ]
 
 
@@ -139,6 +140,12 @@ def load():
                                                C.c_int32, _dp, C.c_void_p, _ip, C.c_void_p]
     lib.orcvio_msckf_objects_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.orcvio_msckf_objects_download.argtypes = [C.c_void_p, C.POINTER(MsckfResult)]
+    lib.orcvio_msckf_cov_set.argtypes = [C.c_void_p, C.c_int32, _dp]
+    lib.orcvio_msckf_cov_get.argtypes = [C.c_void_p, _ip, _dp]
+    lib.orcvio_msckf_cov_propagate.argtypes = [C.c_void_p, C.c_int32, _dp, _dp]
+    lib.orcvio_msckf_cov_augment.argtypes = [C.c_void_p]
+    lib.orcvio_msckf_cov_remove_clones.argtypes = [C.c_void_p, C.c_int32, _ip, C.c_int32]
+    lib.orcvio_msckf_cov_commit.argtypes = [C.c_void_p]
     _LIB = lib
     return lib
 
@@ -350,15 +357,47 @@ class MsckfUpdater:
         return dict(row_clone=row_clone[:m].copy(), Hx6=Hx6[:m].copy(), Hf=Hf[:m].copy(), res=res[:m].copy())
 
     # -- staged, device-resident form -----------------------------------------------------
-    def upload(self, win, without_positions=False):
-        """without_positions: p_w is not sent (NULL); triangulate_uploaded() must run before the update."""
+    def upload(self, win, without_positions=False, resident_cov=False):
+        """without_positions: p_w is not sent (NULL); triangulate_uploaded() must run before the update.
+        resident_cov: P is not sent (NULL): the device-resident covariance (cov_*) is the prior."""
         fl, w, t, arrs = self._structs(win)
         if without_positions:
             t.p_w = None
-        rc = self.lib.orcvio_msckf_upload(self.h, C.byref(fl), C.byref(w), C.byref(t), _d(arrs['P']))
+        rc = self.lib.orcvio_msckf_upload(self.h, C.byref(fl), C.byref(w), C.byref(t), None if resident_cov else _d(arrs['P']))
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_upload')
         self.n, self.F = win.n, win.F
+
+    # -- device-resident covariance ------------------------------------------------------------------
+    def _chk(self, rc, where):
+        if rc != 0:
+            raise MsckfError(rc, where)
+
+    def cov_set(self, P):
+        Pc = np.ascontiguousarray(P, dtype=np.float64)
+        self._chk(self.lib.orcvio_msckf_cov_set(self.h, Pc.shape[0], _d(Pc)), 'orcvio_msckf_cov_set')
+
+    def cov_get(self):
+        n = C.c_int32(0)
+        self._chk(self.lib.orcvio_msckf_cov_get(self.h, C.byref(n), None), 'orcvio_msckf_cov_get')
+        P = np.zeros((n.value, n.value))
+        self._chk(self.lib.orcvio_msckf_cov_get(self.h, C.byref(n), _d(P)), 'orcvio_msckf_cov_get')
+        return P
+
+    def cov_propagate(self, Phi, Q):
+        Ph = np.ascontiguousarray(Phi, dtype=np.float64)
+        Qc = np.ascontiguousarray(Q, dtype=np.float64)
+        self._chk(self.lib.orcvio_msckf_cov_propagate(self.h, Ph.shape[0], _d(Ph), _d(Qc)), 'orcvio_msckf_cov_propagate')
+
+    def cov_augment(self):
+        self._chk(self.lib.orcvio_msckf_cov_augment(self.h), 'orcvio_msckf_cov_augment')
+
+    def cov_remove_clones(self, leg_dim, indices):
+        ix = np.ascontiguousarray(indices, dtype=np.int32)
+        self._chk(self.lib.orcvio_msckf_cov_remove_clones(self.h, leg_dim, _i(ix), len(ix)), 'orcvio_msckf_cov_remove_clones')
+
+    def cov_commit(self):
+        self._chk(self.lib.orcvio_msckf_cov_commit(self.h), 'orcvio_msckf_cov_commit')
 
     # -- feature triangulation (Feature::checkMotion + ::initializePosition) ---------------------
     def _tri_config(self, cfg=None):

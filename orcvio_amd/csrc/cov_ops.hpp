@@ -1,0 +1,67 @@
+// cov_ops.hpp -- covariance bookkeeping on a device-resident P: the three places
+// besides the update where the reference touches state_cov, so that P never has to cross PCIe between updates.
+//   k_cov_propagate_*  OrcVIO::processModel      (src/orcvio.cpp:800-816)
+//   k_cov_augment      OrcVIO::stateAugmentation (:962-1010, no EKF-SLAM / nuisance states)
+//   k_cov_remove       OrcVIO::pruneImuStateBuffer (:2935-2951, non-Schmidt branch)
+// All three are HBM-bound element kernels over an n x n matrix (n <= 406): coalesced row-major reads and writes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace orcvio_amd {
+
+// T[i][j] = sum_k Phi[i][k] P[k][j],  i < leg, j < n   (the first leg rows of Phi * P)
+__global__ __launch_bounds__(256) void k_cov_propagate_rows(const double* __restrict__ P, int n, const double* __restrict__ Phi, int leg,
+                                                            double* __restrict__ T) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= leg * n) return;
+    const int i = idx / n, j = idx - i * n;
+    double s = 0.0;
+    for (int k = 0; k < leg; ++k) s += Phi[i * leg + k] * P[(size_t)k * n + j];
+    T[idx] = s;
+}
+// out = P with  P_LL <- sym(T[:, :leg] Phi^T + Q),  P_LC <- T[:, leg:],  P_CL <- its transpose,  P_CC unchanged
+__global__ __launch_bounds__(256) void k_cov_propagate_finish(const double* __restrict__ P, int n, const double* __restrict__ Phi,
+                                                              const double* __restrict__ Q, int leg, const double* __restrict__ T,
+                                                              double* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    double v;
+    if (i < leg && j < leg) {
+        double a = Q[i * leg + j], b = Q[j * leg + i];
+        for (int k = 0; k < leg; ++k) { a += T[(size_t)i * n + k] * Phi[j * leg + k]; b += T[(size_t)j * n + k] * Phi[i * leg + k]; }
+        v = 0.5 * (a + b);
+    } else if (i < leg) {
+        v = T[(size_t)i * n + j];
+    } else if (j < leg) {
+        v = T[(size_t)j * n + i];
+    } else {
+        v = P[idx];
+    }
+    out[idx] = v;
+}
+// out (n+6)^2: the new clone copies rows/cols (0:3, 6:9) of P
+__global__ __launch_bounds__(256) void k_cov_augment(const double* __restrict__ P, int n, double* __restrict__ out) {
+    const int m = n + 6;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= m * m) return;
+    const int i = idx / m, j = idx - i * m;
+    const int si = i < n ? i : (i - n < 3 ? i - n : i - n + 3);   // source row: 0..2 -> theta, 3..5 -> p (cols 6:9)
+    const int sj = j < n ? j : (j - n < 3 ? j - n : j - n + 3);
+    // [[P, P12^T], [P12, P11]] then (X + X^T)/2 as :1008-1010: the off-diagonal blocks are transposes of each other already
+    double v;
+    if ((i < n) == (j < n)) v = 0.5 * (P[(size_t)si * n + sj] + P[(size_t)sj * n + si]);
+    else if (i >= n) v = P[(size_t)si * n + j];
+    else v = P[(size_t)sj * n + i];
+    out[idx] = v;
+}
+// out m^2 = P without the rows/cols flagged in drop[] (drop[k] = 1: state k is removed); map[k'] = k precomputed
+__global__ __launch_bounds__(256) void k_cov_remove(const double* __restrict__ P, int n, const int* __restrict__ map, int m,
+                                                    double* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= m * m) return;
+    const int i = idx / m, j = idx - i * m;
+    out[idx] = P[(size_t)map[i] * n + map[j]];
+}
+
+}  // namespace orcvio_amd

@@ -15,6 +15,7 @@
 #include <functional>
 #include "msckf_kernels.hpp"
 #include "triangulate.hpp"
+#include "cov_ops.hpp"
 #include "object_rows.hpp"
 
 using namespace orcvio_amd;
@@ -63,6 +64,9 @@ struct orcvio_msckf_handle {
     };
     GraphSlot g_update, g_local, g_finish;
     hipStream_t last_stream = nullptr;   // stream of the last run_update / run_finish (download waits for it)
+    double *d_Pres = nullptr, *d_Ptmp = nullptr, *d_covT = nullptr;   // resident covariance, scratch, Phi*P rows
+    int* d_covmap = nullptr;
+    int res_n = 0;                      // dimension of the resident covariance (0 = none)
     bool pw_missing = false;            // uploaded without positions: triangulate_uploaded must run before the update
     int *d_tri_valid = nullptr, *d_tri_flags = nullptr, *d_tri_init = nullptr;
     double *d_tri_sol = nullptr, *d_tri_cost = nullptr;
@@ -180,7 +184,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_Pout, h->d_La, h->d_DinvA,
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_obs,
-                    h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost};
+                    h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -274,6 +278,10 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_P, sizeof(double) * nn));
         HIPCHK(hipMalloc(&h->d_obs_clone, sizeof(int) * max_observations));
         HIPCHK(hipMalloc(&h->d_skip, sizeof(int) * max_features));
+        HIPCHK(hipMalloc(&h->d_Pres, sizeof(double) * nn));
+        HIPCHK(hipMalloc(&h->d_Ptmp, sizeof(double) * nn));
+        HIPCHK(hipMalloc(&h->d_covT, sizeof(double) * 46 * h->n_max));
+        HIPCHK(hipMalloc(&h->d_covmap, sizeof(int) * h->n_max));
         HIPCHK(hipMalloc(&h->d_tri_valid, sizeof(int) * max_features));
         HIPCHK(hipMalloc(&h->d_tri_flags, sizeof(int) * max_features));
         HIPCHK(hipMalloc(&h->d_tri_init, sizeof(int) * max_features));
@@ -353,7 +361,7 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
 // ---- upload --------------------------------------------------------------------------------
 int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
                             const orcvio_msckf_tracks* tr, const double* P) {
-    if (!h || !flags || !w || !tr || !P || !w->R_b2w || !w->t_b_w || !w->R_b2c || !w->t_c_b || !tr->obs_ptr) {
+    if (!h || !flags || !w || !tr || !w->R_b2w || !w->t_b_w || !w->R_b2c || !w->t_c_b || !tr->obs_ptr) {
         g_last_error = "orcvio_msckf_upload: null argument";
         return ORCVIO_ERR_INVALID;
     }
@@ -442,8 +450,13 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
         h->s_chunks = nch;
     }
     HIPCHK(hipMemcpyAsync(h->d_meta, st + h->so_meta, h->meta_bytes, hipMemcpyHostToDevice, s));
-    std::memcpy(st + h->so_P, P, sizeof(double) * (size_t)h->n * h->n);
-    HIPCHK(hipMemcpyAsync(h->d_P, st + h->so_P, sizeof(double) * (size_t)h->n * h->n, hipMemcpyHostToDevice, s));
+    if (P) {
+        std::memcpy(st + h->so_P, P, sizeof(double) * (size_t)h->n * h->n);
+        HIPCHK(hipMemcpyAsync(h->d_P, st + h->so_P, sizeof(double) * (size_t)h->n * h->n, hipMemcpyHostToDevice, s));
+    } else {   // the device-resident covariance (orcvio_msckf_cov_*)
+        if (h->res_n != h->n) { g_last_error = "orcvio_msckf_upload: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
+        HIPCHK(hipMemcpyAsync(h->d_P, h->d_Pres, sizeof(double) * (size_t)h->n * h->n, hipMemcpyDeviceToDevice, s));
+    }
     if (F > 0) {
         if (tr->p_w) {
             std::memcpy(st + h->so_pw, tr->p_w, sizeof(double) * 3 * F);
@@ -917,7 +930,7 @@ int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_
 int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
                                    const orcvio_msckf_object_rows* objs, int32_t n_objects, const double* P, double* d_dst,
                                    int32_t* dof_out, void* stream) {
-    if (!h || !flags || !P || n_objects < 0 || (n_objects > 0 && !objs)) { g_last_error = "objects_local: null argument"; return ORCVIO_ERR_INVALID; }
+    if (!h || !flags || n_objects < 0 || (n_objects > 0 && !objs)) { g_last_error = "objects_local: null argument"; return ORCVIO_ERR_INVALID; }
     if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = "objects_local: leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
     if (n_clones < 1 || n_clones > h->maxN) { g_last_error = "objects_local: window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
@@ -954,7 +967,12 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     h->last_stream = s;
     double* dst = d_dst ? d_dst : h->d_Ab;
     if (dof_out) *dof_out = dof;
-    HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
+    if (P) {
+        HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
+    } else {
+        if (h->res_n != n) { g_last_error = "objects_local: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
+        HIPCHK(hipMemcpyAsync(h->d_P, h->d_Pres, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
+    }
     h->uploaded = true;
     h->objects_mode = true;
     h->obj_dof = dof; h->obj_rows = rows_tot; h->obj_count = nobj;
@@ -1240,6 +1258,89 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int) * 8, s));
     HIPCHK(hipStreamSynchronize(s));
     h->ran = true;
+    return ORCVIO_OK;
+}
+
+// ---- device-resident covariance --------------------------------------------------
+int32_t orcvio_msckf_cov_set(orcvio_msckf_handle* h, int32_t n, const double* P) {
+    if (!h || !P || n < 1 || n > h->n_max) { g_last_error = "cov_set: invalid"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(h->d_Pres, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    h->res_n = n;
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_cov_get(orcvio_msckf_handle* h, int32_t* n_out, double* P_out) {
+    if (!h || h->res_n == 0) { g_last_error = "cov_get: no resident covariance"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    if (n_out) *n_out = h->res_n;
+    if (P_out) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(P_out, h->d_Pres, sizeof(double) * (size_t)h->res_n * h->res_n, hipMemcpyDeviceToHost));
+    }
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_cov_propagate(orcvio_msckf_handle* h, int32_t leg, const double* Phi, const double* Q) {
+    if (!h || !Phi || !Q || (leg != 22 && leg != 46) || h->res_n < leg) { g_last_error = "cov_propagate: invalid"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int n = h->res_n;
+    double* dPhi = h->d_covT + (size_t)46 * h->n_max - 2 * 46 * 46;   // tail of the scratch holds Phi and Q
+    if ((size_t)leg * n + 2 * 46 * 46 > (size_t)46 * h->n_max) { g_last_error = "cov_propagate: scratch too small"; return ORCVIO_ERR_CAPACITY; }
+    double* dQ = dPhi + 46 * 46;
+    HIPCHK(hipMemcpyAsync(dPhi, Phi, sizeof(double) * leg * leg, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dQ, Q, sizeof(double) * leg * leg, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_cov_propagate_rows, dim3((leg * n + 255) / 256), dim3(256), 0, s, h->d_Pres, n, dPhi, leg, h->d_covT);
+    hipLaunchKernelGGL(k_cov_propagate_finish, dim3((n * n + 255) / 256), dim3(256), 0, s, h->d_Pres, n, dPhi, dQ, leg, h->d_covT, h->d_Ptmp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));   // Phi and Q are caller memory
+    std::swap(h->d_Pres, h->d_Ptmp);
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_cov_augment(orcvio_msckf_handle* h) {
+    if (!h || h->res_n < 9 || h->res_n + 6 > h->n_max) { g_last_error = "cov_augment: no resident covariance, or window full"; return ORCVIO_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->res_n, m = n + 6;
+    hipLaunchKernelGGL(k_cov_augment, dim3((m * m + 255) / 256), dim3(256), 0, h->stream, h->d_Pres, n, h->d_Ptmp);
+    HIPCHK(hipGetLastError());
+    std::swap(h->d_Pres, h->d_Ptmp);
+    h->res_n = m;
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_cov_remove_clones(orcvio_msckf_handle* h, int32_t leg, const int32_t* idx, int32_t count) {
+    if (!h || (count > 0 && !idx) || count < 0 || (leg != 22 && leg != 46) || h->res_n < leg) { g_last_error = "cov_remove_clones: invalid"; return ORCVIO_ERR_INVALID; }
+    if (count == 0) return ORCVIO_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->res_n, N = (n - leg) / 6;
+    std::vector<char> drop(n, 0);
+    for (int k = 0; k < count; ++k) {
+        if (idx[k] < 0 || idx[k] >= N) { g_last_error = "cov_remove_clones: index out of the window"; return ORCVIO_ERR_INVALID; }
+        for (int c = 0; c < 6; ++c) drop[leg + 6 * idx[k] + c] = 1;
+    }
+    std::vector<int> map;
+    for (int i = 0; i < n; ++i)
+        if (!drop[i]) map.push_back(i);
+    const int m = (int)map.size();
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_covmap, map.data(), sizeof(int) * m, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_cov_remove, dim3((m * m + 255) / 256), dim3(256), 0, s, h->d_Pres, n, h->d_covmap, m, h->d_Ptmp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));   // map is a local
+    std::swap(h->d_Pres, h->d_Ptmp);
+    h->res_n = m;
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h) {
+    if (!h || !h->ran) { g_last_error = "cov_commit: no finished update"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->last_stream ? h->last_stream : h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_Pres, h->d_Pout, sizeof(double) * (size_t)h->n * h->n, hipMemcpyDeviceToDevice, s));
+    if (s != h->stream) HIPCHK(hipStreamSynchronize(s));   // the other cov_* calls run on the handle's own stream
+    h->res_n = h->n;
     return ORCVIO_OK;
 }
 

@@ -1,0 +1,97 @@
+"""GPU tests of the device-resident covariance against oracle/mirror_cov.py, and of a small
+filter loop that keeps P in HBM across propagate / augment / update / marginalise."""
+import numpy as np
+import pytest
+
+from orcvio_amd import capi, synth
+from oracle import mirror_cov as mc, oracle
+from helpers import rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def upd(built):
+    u = capi.MsckfUpdater(device=0, max_clones=40, max_features=512, max_observations=16384)
+    yield u
+    u.close()
+
+
+def _spd(n, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    return A @ A.T * 1e-3 + np.diag(rng.uniform(1e-4, 1e-2, n))
+
+
+@pytest.mark.parametrize('leg,N', [(22, 0), (22, 7), (46, 5), (22, 30)])
+def test_propagate(upd, leg, N):
+    n = leg + 6 * N
+    rng = np.random.default_rng(n)
+    P = _spd(n, n)
+    Phi = np.eye(leg) + 0.05 * rng.standard_normal((leg, leg))
+    G = rng.standard_normal((leg, 12))
+    Q = 1e-5 * G @ G.T
+    upd.cov_set(P)
+    upd.cov_propagate(Phi, Q)
+    got = upd.cov_get()
+    ref = mc.propagate(P, Phi, Q)
+    assert got.shape == ref.shape and rel(got, ref) < 1e-14
+    assert np.array_equal(got, got.T)
+
+
+def test_augment_and_remove_are_exact(upd):
+    P = _spd(22 + 6 * 5, 3)
+    upd.cov_set(P)
+    upd.cov_augment()
+    got = upd.cov_get()
+    assert np.array_equal(got, mc.augment(P))
+    upd.cov_remove_clones(22, [1, 4])
+    got2 = upd.cov_get()
+    assert np.array_equal(got2, mc.remove_clones(mc.augment(P), 22, [1, 4]))
+    # removing the clone that was just added gives the old matrix back
+    upd.cov_set(P)
+    upd.cov_augment()
+    upd.cov_remove_clones(22, [5])
+    assert np.array_equal(upd.cov_get(), 0.5 * (P + P.T))
+
+
+def test_limits(upd):
+    with pytest.raises(capi.MsckfError):
+        upd.cov_remove_clones(22, [99])
+    upd.cov_set(_spd(46 + 6 * 40, 1))   # capacity: leg_dim 46 and max_clones = 40 states
+    with pytest.raises(capi.MsckfError):
+        upd.cov_augment()
+
+
+def test_filter_loop_keeps_the_covariance_on_the_device(upd):
+    """Three frames of propagate -> augment -> update (prior = resident P) -> commit -> marginalise, with P never sent
+    after the first frame; every step equals the same loop run with the oracle on the host."""
+    rng = np.random.default_rng(5)
+    N0 = 6
+    w0 = synth.make_window(N=N0, F=30, seed=40, track_len=(3, 6))
+    P = w0.P.copy()
+    upd.cov_set(P)
+    for frame in range(3):
+        leg = 22
+        Phi = np.eye(leg) + 0.01 * rng.standard_normal((leg, leg))
+        G = rng.standard_normal((leg, 12))
+        Q = 1e-6 * G @ G.T
+        upd.cov_propagate(Phi, Q)
+        P = mc.propagate(P, Phi, Q)
+        upd.cov_augment()
+        P = mc.augment(P)
+        N = (P.shape[0] - leg) // 6
+        w = synth.make_window(N=N, F=30, seed=41 + frame, track_len=(3, N))
+        w.P[:] = P
+        ref = oracle.msckf_update(w)
+        upd.upload(w, resident_cov=True)
+        upd.run_update()
+        upd.sync()
+        got = upd.download()
+        assert np.array_equal(got['accept'], ref['accept'])
+        assert rel(got['dx'], ref['dx']) < 1e-6 and rel(got['P_new'], ref['P_new']) < 1e-6
+        upd.cov_commit()
+        P = ref['P_new']
+        upd.cov_remove_clones(leg, [0])
+        P = mc.remove_clones(P, leg, [0])
+        assert rel(upd.cov_get(), P) < 1e-6
