@@ -255,3 +255,23 @@ def test_maximum_window_of_60_clones(built):
         _compare(u.update_features(w, want_G=True), oracle.msckf_update(w), w)
     finally:
         u.close()
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_shapes_and_flags(upd, seed):
+    """Randomised sweep over window size, track raggedness, Jacobian variant, FEJ, td, leg_dim, noise and outlier
+    rate: every combination must agree with the oracle (catches shape-dependent launch and indexing errors)."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(2, 40))
+    F = int(rng.integers(1, 120))
+    lo = int(rng.integers(2, min(N, 6) + 1))
+    hi = int(rng.integers(lo, min(N, 32) + 1))
+    variant = int(rng.integers(0, 3))
+    flags = synth.Flags(use_larvio=int(variant == 0), use_left_perturbation=int(variant == 1), if_fej=int(rng.integers(0, 2)),
+                        estimate_td=int(rng.integers(0, 2)), leg_dim=int(rng.choice([22, 22, 46])),
+                        noise_feature=float(rng.choice([0.008, 0.05, 1.0])))
+    w = synth.make_window(N=N, F=F, seed=seed, track_len=(lo, hi), flags=flags, outlier_frac=float(rng.choice([0.0, 0.3])),
+                          sigma_px=0.008)
+    ref = oracle.msckf_update(w)
+    got = upd.update_features(w, want_G=True)
+    _compare(got, ref, w)
