@@ -53,10 +53,20 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             continue
         traffic.setdefault(k, {})[f'{counter}_KB_median'] = statistics.median(v)
         traffic[k]['dispatches'] = len(v)
+f = find(f'{tag}_pmc_MFMA/**/*counter_collection.csv')
+if f:
+    per = {}
+    for row in csv.DictReader(open(f)):
+        per.setdefault((short(row['Kernel_Name']), row['Counter_Name']), []).append(float(row['Counter_Value']))
+    for (k, c), v in per.items():
+        if k.startswith('__amd'):
+            continue
+        traffic.setdefault(k, {})[f'{c}_median'] = statistics.median(v)
 if traffic:
     json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no trace domains) around bench.py --steps 20; '
                        'KB per dispatch, median over the dispatches of each kernel. gfx950 caveat (MI355X_MICROARCH.md): '
-                       'FETCH_SIZE under-reports wide coalesced reads by 2x; these kernels read 8 B per lane.',
+                       'FETCH_SIZE under-reports wide coalesced reads by 2x; these kernels read 8 B per lane. SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 = '
+                       'FP64 flops executed on the matrix cores per dispatch; SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs.',
                'kernels': traffic}, open(os.path.join(dst, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
     print('pmc traffic ->', f'profiles/{tag}_pmc_traffic.json')
 b = os.path.join(src, f'{tag}_bench.json')
