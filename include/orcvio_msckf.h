@@ -254,6 +254,20 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
                                     int32_t dof_total, void* stream);
 int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_result* result);
 
+/* The object update straight from object TRACKS (state at the LM optimum + observations; the structs of
+ * orcvio_msckf_object_rows_eval): the residual rows and Jacobians of CameraLM::Error{Feature,BBox}Quadric /
+ * ObjectLM::df and constructObjectResidualJacobians are evaluated on the device into the compact row arrays, so only
+ * the tracks cross PCIe (a 12-keypoint car seen in 30 frames is 9 KB of input against 360 KB of rows).
+ * objects_local_tracks is the sharded first half (followed by orcvio_msckf_objects_finish / _objects_download). */
+int32_t orcvio_msckf_update_object_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
+                                          const orcvio_object_eval_flags* eval_flags, int32_t n_clones,
+                                          const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
+                                          orcvio_msckf_result* result);
+int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
+                                          const orcvio_object_eval_flags* eval_flags, int32_t n_clones,
+                                          const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
+                                          double* d_dst, int32_t* dof_out, void* stream);
+
 /* ---- Feature triangulation --------------------------------------
  * Replaces, for every listed track, Feature::checkMotion followed by Feature::initializePosition
  * (include/orcvio/feat/feature.hpp:354-449; the Levenberg-Marquardt of ::triangulate_position, :583-719, with

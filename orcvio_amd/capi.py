@@ -33,6 +33,7 @@ EXPORTS = [
     'orcvio_msckf_triangulate_uploaded', 'orcvio_msckf_objects_local', 'orcvio_msckf_objects_finish',
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
+    'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
 ]
 
 
@@ -146,6 +147,10 @@ def load():
     lib.orcvio_msckf_cov_augment.argtypes = [C.c_void_p]
     lib.orcvio_msckf_cov_remove_clones.argtypes = [C.c_void_p, C.c_int32, _ip, C.c_int32]
     lib.orcvio_msckf_cov_commit.argtypes = [C.c_void_p]
+    lib.orcvio_msckf_update_object_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.c_int32,
+                                                      C.POINTER(ObjectTrackC), C.c_int32, _dp, C.POINTER(MsckfResult)]
+    lib.orcvio_msckf_objects_local_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.c_int32,
+                                                      C.POINTER(ObjectTrackC), C.c_int32, _dp, C.c_void_p, _ip, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -355,6 +360,39 @@ class MsckfUpdater:
         if m == 0:
             return None
         return dict(row_clone=row_clone[:m].copy(), Hx6=Hx6[:m].copy(), Hf=Hf[:m].copy(), res=res[:m].copy())
+
+    def _object_tracks(self, objs, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D):
+        fl = ObjectEvalFlags(int(obj_left), int(new_bbox), int(vio_left), int(fix_D))
+        fl.R_b2c[:] = list(np.asarray(R_b2c, dtype=np.float64).ravel())
+        fl.t_c_b[:] = list(np.asarray(t_c_b, dtype=np.float64).ravel())
+        arr = (ObjectTrackC * max(len(objs), 1))()
+        keep = []
+        for k, obj in enumerate(objs):
+            wTo = np.ascontiguousarray(obj.wTo, dtype=np.float64)
+            shape = np.ascontiguousarray(obj.shape, dtype=np.float64)
+            kps = np.ascontiguousarray(obj.kps, dtype=np.float64)
+            wTc = np.ascontiguousarray(np.stack([fr['wTc'] for fr in obj.frames]), dtype=np.float64)
+            zs = np.ascontiguousarray(np.stack([fr['zs'] for fr in obj.frames]), dtype=np.float64)
+            bb = np.ascontiguousarray(np.stack([fr['bbox'] for fr in obj.frames]), dtype=np.float64)
+            cl = np.ascontiguousarray([fr['clone'] for fr in obj.frames], dtype=np.int32)
+            keep += [wTo, shape, kps, wTc, zs, bb, cl]
+            arr[k] = ObjectTrackC(kps.shape[0], len(obj.frames), _d(wTo), _d(shape), _d(kps), _d(wTc), _d(zs), _d(bb), _i(cl))
+        return fl, arr, keep
+
+    def update_object_tracks(self, flags, n_clones, objs, P, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D=False, want_G=False):
+        """removeLostObjects straight from object tracks (synth.ObjectTrack-shaped): rows evaluated on the device."""
+        fl = make_flags(flags)
+        ef, arr, keep = self._object_tracks(objs, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D)
+        n = flags.leg_dim + 6 * n_clones
+        Pc = None if P is None else np.ascontiguousarray(P, dtype=np.float64)
+        out, res = self._result(n, 1, False, want_G, False)
+        rc = self.lib.orcvio_msckf_update_object_tracks(self.h, C.byref(fl), C.byref(ef), n_clones, arr, len(objs), _d(Pc), C.byref(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_update_object_tracks')
+        out = self._finish(out, res, 1)
+        out['gamma'] = float(out['gamma'][0])
+        out['accept'] = int(out['accept'][0])
+        return out
 
     # -- staged, device-resident form -----------------------------------------------------
     def upload(self, win, without_positions=False, resident_cov=False):

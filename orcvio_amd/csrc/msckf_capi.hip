@@ -925,6 +925,73 @@ int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_
 // onto the left nullspace of its own Hf (SURVEY.md note N3: equal to the reference whenever one object
 // arrives per call); the blocks are stacked, gated jointly with dof = sum(rows - cols) and applied in one
 // update.  Objects with rows <= cols cannot be projected (math_utils.hpp:292) and are skipped.
+// Device scratch of an object update: compact rows [row_clone | row_cols | chunk_ptr] and [Hx6 | Hf (ld no_max) | res],
+// followed by `extra_d` doubles / `extra_i` ints for the callers' own inputs.
+struct ObjScratch {
+    int *d_clone, *d_cols, *d_chunk, *d_extra_i;
+    double *d_hx, *d_hf, *d_res, *d_extra_d;
+};
+static int objects_scratch(orcvio_msckf_handle* h, int nobj, int rows_tot, int no_max, size_t extra_d, ObjScratch* sc, size_t extra_i = 0) {
+    const int NAP = h->NAP, NOP = round_up(no_max, 16), W = NAP + NOP;
+    int rc;
+    if ((rc = grow(&h->d_obj_i, &h->cap_obj_i, (size_t)2 * rows_tot + nobj + 1 + extra_i)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_objH, &h->cap_objH, (size_t)rows_tot * (6 + no_max + 1) + extra_d)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Xaug, &h->cap_Xaug, (size_t)rows_tot * W)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, (size_t)nobj * W * W)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_RF, &h->cap_RF, (size_t)nobj * (NOP * NOP + 7 * 256))) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Yobj, &h->cap_Yobj, (size_t)nobj * NOP * NAP)) != ORCVIO_OK) return rc;
+    sc->d_clone = h->d_obj_i;
+    sc->d_cols = h->d_obj_i + rows_tot;
+    sc->d_chunk = h->d_obj_i + 2 * rows_tot;
+    sc->d_extra_i = sc->d_chunk + nobj + 1;
+    sc->d_hx = h->d_objH;
+    sc->d_hf = sc->d_hx + (size_t)rows_tot * 6;
+    sc->d_res = sc->d_hf + (size_t)rows_tot * no_max;
+    sc->d_extra_d = sc->d_res + rows_tot;
+    return ORCVIO_OK;
+}
+
+// From the compact rows in device memory to this rank's block in dst (P already in d_P; forks the Cholesky of P).
+static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, int nobj, int rows_tot, int no_max, const ObjScratch& sc) {
+    const int NA = h->NA, NAP = h->NAP, NOP = round_up(no_max, 16), W = NAP + NOP;
+    double* d_RF = h->d_RF;
+    double* d_DinvF = h->d_RF + (size_t)nobj * NOP * NOP;
+    HIPCHK(hipMemsetAsync(h->d_Yobj, 0, sizeof(double) * (size_t)nobj * NOP * NAP, s));
+    HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
+    int rc = launch_prior_fork(h, s);   // Cholesky of P on the side stream
+    if (rc != ORCVIO_OK) return rc;
+    // augmented stack and its per-object Gram
+    hipLaunchKernelGGL(k_obj_build, dim3(rows_tot), dim3(256), 0, s, sc.d_clone, sc.d_hx, sc.d_hf, sc.d_res, sc.d_cols, rows_tot, no_max,
+                       h->flags.leg_dim, NA, NAP, W, h->d_Xaug);
+    {
+        const int nbw = W / 16, ntiles = nbw * (nbw + 1) / 2;
+        hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, nobj), dim3(256), 0, s, h->d_Xaug, rows_tot, W, 0, h->d_Gobj, sc.d_chunk);
+    }
+    // F_o = Hf^T Hf (lower tiles of the bottom-right block) -> R_F ; Y_o = L_F^-1 C_o
+    {
+        const int nbf = NOP / 16, need = potrf_slots_needed(nbf);
+        HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));   // the batched factorisation ADDS its pivot counters
+        const double* F0 = h->d_Gobj + (size_t)NAP * W + NAP;
+        const double tolF = (double)no_max * 2.220446049250313e-16;
+        if (need <= 4)
+            hipLaunchKernelGGL(k_potrf_reg<4>, dim3(nobj), dim3(512), 0, s, F0, W, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
+                               (unsigned long long*)nullptr, (size_t)W * W, (size_t)NOP * NOP, (size_t)7 * 256, 1);
+        else
+            hipLaunchKernelGGL(k_potrf_reg<8>, dim3(nobj), dim3(512), 0, s, F0, W, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
+                               (unsigned long long*)nullptr, (size_t)W * W, (size_t)NOP * NOP, (size_t)7 * 256, 1);
+        const int nwave = (NA + 1 + 15) / 16;
+        hipLaunchKernelGGL(k_trsm_lds, dim3((nwave + 3) / 4, nobj), dim3(256), 0, s, d_RF, NOP, d_DinvF, no_max,
+                           h->d_Gobj + (size_t)NAP * W, (long)W, 1L, NA + 1, (const double*)nullptr, 0L, h->d_Yobj, NAP,
+                           (size_t)NOP * NOP, (size_t)7 * 256, (size_t)W * W, (size_t)NOP * NAP);
+    }
+    // A' = sum_o B_o - Y^T Y  (Y = all Y_o stacked; padded rows are zero)
+    hipLaunchKernelGGL(k_obj_sum_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, h->d_Gobj, nobj, W, NAP, h->d_Ab);
+    hipLaunchKernelGGL(k_gemm, dim3((NAP / 16) * (NAP / 16)), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
+                       NAP, NAP, nobj * NOP, -1.0, 0.0, 0, dst, (long)NAP, 1L, h->d_Ab);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
 // Local part of an object update: this rank's objects -> its compressed block [A' b'; b'^T c'] (NAP x NAP) in d_dst
 // (the handle's own block if NULL), Cholesky of P forked on the side stream.
 int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
@@ -1000,61 +1067,123 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
             r0 += ob.n_rows;
         }
     }
-    const size_t need_i = (size_t)2 * rows_tot + nobj + 1;
-    const size_t need_h = (size_t)rows_tot * (6 + no_max + 1);
-    if ((rc = grow(&h->d_obj_i, &h->cap_obj_i, need_i)) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_objH, &h->cap_objH, need_h)) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_Xaug, &h->cap_Xaug, (size_t)rows_tot * W)) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, (size_t)nobj * W * W)) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_RF, &h->cap_RF, (size_t)nobj * (NOP * NOP + 7 * 256))) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_Yobj, &h->cap_Yobj, (size_t)nobj * NOP * NAP)) != ORCVIO_OK) return rc;
-    int* d_clone = h->d_obj_i;
-    int* d_cols = h->d_obj_i + rows_tot;
-    int* d_chunk = h->d_obj_i + 2 * rows_tot;
-    double* d_hx = h->d_objH;
-    double* d_hf = d_hx + (size_t)rows_tot * 6;
-    double* d_res = d_hf + (size_t)rows_tot * no_max;
-    double* d_RF = h->d_RF;
-    double* d_DinvF = h->d_RF + (size_t)nobj * NOP * NOP;
-    HIPCHK(hipMemcpyAsync(d_clone, h_clone.data(), sizeof(int) * rows_tot, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_cols, h_cols.data(), sizeof(int) * rows_tot, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_chunk, chunk_ptr.data(), sizeof(int) * (nobj + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_hx, h_hx.data(), sizeof(double) * h_hx.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_hf, h_hf.data(), sizeof(double) * h_hf.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_res, h_res.data(), sizeof(double) * rows_tot, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(h->d_Yobj, 0, sizeof(double) * (size_t)nobj * NOP * NAP, s));
-    HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
-    rc = launch_prior_fork(h, s);   // Cholesky of P on the side stream
+    ObjScratch sc;
+    if ((rc = objects_scratch(h, nobj, rows_tot, no_max, 0, &sc)) != ORCVIO_OK) return rc;
+    HIPCHK(hipMemcpyAsync(sc.d_clone, h_clone.data(), sizeof(int) * rows_tot, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sc.d_cols, h_cols.data(), sizeof(int) * rows_tot, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sc.d_chunk, chunk_ptr.data(), sizeof(int) * (nobj + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sc.d_hx, h_hx.data(), sizeof(double) * h_hx.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sc.d_hf, h_hf.data(), sizeof(double) * h_hf.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sc.d_res, h_res.data(), sizeof(double) * rows_tot, hipMemcpyHostToDevice, s));
+    return objects_pipeline(h, s, dst, nobj, rows_tot, no_max, sc);
+}
+
+// The same from object TRACKS (state at the LM optimum + observations): the residual rows and Jacobians of SURVEY 8a rows
+// 12-16 are evaluated on the device (k_object_rows) straight into the compact row arrays -- nothing but the tracks
+// crosses PCIe.  Tracks whose in-window rows do not exceed their state columns are skipped (math_utils.hpp:292).
+int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_object_eval_flags* fl,
+                                          int32_t n_clones, const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
+                                          double* d_dst, int32_t* dof_out, void* stream) {
+    if (!h || !flags || !fl || n_tracks < 0 || (n_tracks > 0 && !tracks)) { g_last_error = "objects_local_tracks: null argument"; return ORCVIO_ERR_INVALID; }
+    if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = "objects_local_tracks: leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
+    if (n_clones < 1 || n_clones > h->maxN) { g_last_error = "objects_local_tracks: window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    const int N = n_clones;
+    h->flags = *flags;
+    h->N = N; h->F = 0; h->nobs = 0;
+    h->n = flags->leg_dim + 6 * N;
+    h->NA = h->n - 15;
+    h->NAP = round_up(h->NA + 1, 16);
+    h->NP = round_up(h->n, 16);
+    h->ldz = round_up(h->n + 1, 16);
+    h->reg_path = (h->NP / 16) <= 14;
+    h->m_tot = 0; h->Mmax = 2; h->chunks = 1; h->rows_per_chunk = 8;
+    h->h_row_ptr.assign(1, 0);
+    const int n = h->n, NAP = h->NAP;
+    struct Use { int t, row0, rows, ncol; size_t off_d, off_i; };
+    std::vector<Use> use;
+    std::vector<int> chunk_ptr(1, 0);
+    std::vector<double> hin;
+    std::vector<int> hi;
+    int rows_tot = 0, dof = 0, no_max = 0;
+    for (int t = 0; t < n_tracks; ++t) {
+        const orcvio_object_track& ob = tracks[t];
+        if (!ob.wTo || !ob.shape || !ob.kps || !ob.frame_wTc || !ob.frame_zs || !ob.frame_bbox || !ob.frame_clone) { g_last_error = "objects_local_tracks: null track arrays"; return ORCVIO_ERR_INVALID; }
+        const int K = ob.n_keypoints, F = ob.n_frames, ncol = 9 + 3 * K;
+        if (K < 1 || K > 34 || F < 1) { g_last_error = "objects_local_tracks: 1..34 keypoints (object state <= 112 columns), >= 1 frame"; return ORCVIO_ERR_INVALID; }
+        std::vector<int> row0(F, 0);
+        int rows = 0;
+        for (int f = 0; f < F; ++f) {
+            if (ob.frame_clone[f] >= N) { g_last_error = "objects_local_tracks: frame_clone out of the window"; return ORCVIO_ERR_INVALID; }
+            if (ob.frame_clone[f] < 0) continue;
+            int nv = 0;
+            for (int k = 0; k < K; ++k) {
+                const double a = ob.frame_zs[((size_t)f * K + k) * 2], b = ob.frame_zs[((size_t)f * K + k) * 2 + 1];
+                if (std::isfinite(a) && std::isfinite(b)) ++nv;   // row finite test, ObjectLM.cpp:171-198
+            }
+            row0[f] = rows_tot + rows;
+            rows += 2 * nv + 4;
+        }
+        if (rows <= ncol) continue;   // nullspace_project_inplace_svd returns false
+        Use u{t, rows_tot, rows, ncol, hin.size(), hi.size()};
+        use.push_back(u);
+        hin.insert(hin.end(), ob.wTo, ob.wTo + 16);
+        hin.insert(hin.end(), ob.shape, ob.shape + 3);
+        hin.insert(hin.end(), ob.kps, ob.kps + (size_t)3 * K);
+        hin.insert(hin.end(), ob.frame_wTc, ob.frame_wTc + (size_t)16 * F);
+        hin.insert(hin.end(), ob.frame_zs, ob.frame_zs + (size_t)2 * K * F);
+        hin.insert(hin.end(), ob.frame_bbox, ob.frame_bbox + (size_t)4 * F);
+        hi.insert(hi.end(), ob.frame_clone, ob.frame_clone + F);
+        hi.insert(hi.end(), row0.begin(), row0.end());
+        rows_tot += rows;
+        chunk_ptr.push_back(rows_tot);
+        dof += rows - ncol;
+        if (ncol > no_max) no_max = ncol;
+    }
+    const int nobj = (int)use.size();
+    hipStream_t s = pick_stream(h, stream);
+    h->last_stream = s;
+    double* dst = d_dst ? d_dst : h->d_Ab;
+    if (dof_out) *dof_out = dof;
+    if (P) {
+        HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
+    } else {
+        if (h->res_n != n) { g_last_error = "objects_local_tracks: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
+        HIPCHK(hipMemcpyAsync(h->d_P, h->d_Pres, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
+    }
+    h->uploaded = true;
+    h->objects_mode = true;
+    h->obj_dof = dof; h->obj_rows = rows_tot; h->obj_count = nobj;
+    if (!h->d_obj_accept) { HIPCHK(hipMalloc(&h->d_obj_accept, sizeof(int) * 4)); HIPCHK(hipMalloc(&h->d_obj_gamma, sizeof(double) * 4)); }
+    if (nobj == 0) {
+        HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)NAP * NAP, s));
+        return launch_prior_fork(h, s);
+    }
+    ObjScratch sc;
+    int rc = objects_scratch(h, nobj, rows_tot, no_max, hin.size(), &sc, hi.size());
     if (rc != ORCVIO_OK) return rc;
-    // augmented stack and its per-object Gram
-    hipLaunchKernelGGL(k_obj_build, dim3(rows_tot), dim3(256), 0, s, d_clone, d_hx, d_hf, d_res, d_cols, rows_tot, no_max,
-                       flags->leg_dim, NA, NAP, W, h->d_Xaug);
-    {
-        const int nbw = W / 16, ntiles = nbw * (nbw + 1) / 2;
-        hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, nobj), dim3(256), 0, s, h->d_Xaug, rows_tot, W, 0, h->d_Gobj, d_chunk);
+    HIPCHK(hipMemcpyAsync(sc.d_extra_d, hin.data(), sizeof(double) * hin.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sc.d_extra_i, hi.data(), sizeof(int) * hi.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sc.d_chunk, chunk_ptr.data(), sizeof(int) * (nobj + 1), hipMemcpyHostToDevice, s));
+    for (const Use& u : use) {
+        const orcvio_object_track& ob = tracks[u.t];
+        const int K = ob.n_keypoints, F = ob.n_frames;
+        ObjEvalArgs a;
+        a.wTo = sc.d_extra_d + u.off_d; a.shape = a.wTo + 16; a.kps = a.shape + 3; a.frame_wTc = a.kps + 3 * K;
+        a.frame_zs = a.frame_wTc + (size_t)16 * F; a.frame_bbox = a.frame_zs + (size_t)2 * K * F;
+        a.frame_clone = sc.d_extra_i + u.off_i; a.frame_row0 = a.frame_clone + F;
+        a.K = K; a.F = F; a.ncol = u.ncol; a.ldhf = no_max; a.row_cols = sc.d_cols;
+        a.obj_left = fl->use_left_perturbation; a.new_bbox = fl->use_new_bbox_residual; a.vio_left = fl->vio_use_left_perturbation;
+        a.fix_D = fl->fix_dcampose_dimupose_to_identity;
+        std::memcpy(a.R_b2c, fl->R_b2c, sizeof(a.R_b2c));
+        std::memcpy(a.t_c_b, fl->t_c_b, sizeof(a.t_c_b));
+        a.Hx6 = sc.d_hx; a.Hf = sc.d_hf; a.res = sc.d_res; a.row_clone = sc.d_clone;
+        hipLaunchKernelGGL(k_object_rows, dim3(F), dim3(64), 0, s, a);
     }
-    // F_o = Hf^T Hf (lower tiles of the bottom-right block) -> R_F ; Y_o = L_F^-1 C_o
-    {
-        const int nbf = NOP / 16, need = potrf_slots_needed(nbf);
-        HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));   // the batched factorisation ADDS its pivot counters
-        const double* F0 = h->d_Gobj + (size_t)NAP * W + NAP;
-        const double tolF = (double)no_max * 2.220446049250313e-16;
-        if (need <= 4)
-            hipLaunchKernelGGL(k_potrf_reg<4>, dim3(nobj), dim3(512), 0, s, F0, W, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
-                               (unsigned long long*)nullptr, (size_t)W * W, (size_t)NOP * NOP, (size_t)7 * 256, 1);
-        else
-            hipLaunchKernelGGL(k_potrf_reg<8>, dim3(nobj), dim3(512), 0, s, F0, W, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
-                               (unsigned long long*)nullptr, (size_t)W * W, (size_t)NOP * NOP, (size_t)7 * 256, 1);
-        const int nwave = (NA + 1 + 15) / 16;
-        hipLaunchKernelGGL(k_trsm_lds, dim3((nwave + 3) / 4, nobj), dim3(256), 0, s, d_RF, NOP, d_DinvF, no_max,
-                           h->d_Gobj + (size_t)NAP * W, (long)W, 1L, NA + 1, (const double*)nullptr, 0L, h->d_Yobj, NAP,
-                           (size_t)NOP * NOP, (size_t)7 * 256, (size_t)W * W, (size_t)NOP * NAP);
-    }
-    // A' = sum_o B_o - Y^T Y  (Y = all Y_o stacked; padded rows are zero)
-    hipLaunchKernelGGL(k_obj_sum_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, h->d_Gobj, nobj, W, NAP, h->d_Ab);
-    hipLaunchKernelGGL(k_gemm, dim3((NAP / 16) * (NAP / 16)), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
-                       NAP, NAP, nobj * NOP, -1.0, 0.0, 0, dst, (long)NAP, 1L, h->d_Ab);
     HIPCHK(hipGetLastError());
+    rc = objects_pipeline(h, s, dst, nobj, rows_tot, no_max, sc);
+    if (rc != ORCVIO_OK) return rc;
+    HIPCHK(hipStreamSynchronize(s));   // hin / hi / chunk_ptr are locals
     return ORCVIO_OK;
 }
 
@@ -1150,6 +1279,21 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     return rc;
 }
 
+int32_t orcvio_msckf_update_object_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_object_eval_flags* fl,
+                                          int32_t n_clones, const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
+                                          orcvio_msckf_result* res) {
+    if (!res) { g_last_error = "update_object_tracks: null argument"; return ORCVIO_ERR_INVALID; }
+    int32_t dof = 0;
+    int rc = orcvio_msckf_objects_local_tracks(h, flags, fl, n_clones, tracks, n_tracks, P, nullptr, &dof, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    rc = orcvio_msckf_objects_finish(h, h->d_Ab, 1, dof, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    rc = orcvio_msckf_objects_download(h, res);
+    h->objects_mode = false;
+    return rc;
+}
+
+
 // ---- object residual rows ------------------------------------------------------
 int32_t orcvio_msckf_object_rows_eval(orcvio_msckf_handle* h, const orcvio_object_eval_flags* fl, const orcvio_object_track* ob,
                                       int32_t cap_rows, int32_t* n_rows, int32_t* row_clone, double* Hx6, double* Hf, double* res) {
@@ -1198,7 +1342,7 @@ int32_t orcvio_msckf_object_rows_eval(orcvio_msckf_handle* h, const orcvio_objec
     a.wTo = h->d_objH; a.shape = a.wTo + 16; a.kps = a.shape + 3; a.frame_wTc = a.kps + 3 * K;
     a.frame_zs = a.frame_wTc + (size_t)16 * F; a.frame_bbox = a.frame_zs + (size_t)2 * K * F;
     a.frame_clone = h->d_obj_i; a.frame_row0 = h->d_obj_i + F;
-    a.K = K; a.F = F; a.ncol = ncol;
+    a.K = K; a.F = F; a.ncol = ncol; a.ldhf = ncol; a.row_cols = nullptr;
     a.obj_left = fl->use_left_perturbation; a.new_bbox = fl->use_new_bbox_residual; a.vio_left = fl->vio_use_left_perturbation;
     a.fix_D = fl->fix_dcampose_dimupose_to_identity;
     std::memcpy(a.R_b2c, fl->R_b2c, sizeof(a.R_b2c));

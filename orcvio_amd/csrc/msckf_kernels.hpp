@@ -256,6 +256,10 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
         if (tid == 0) { p.gamma[j] = NAN; p.accept[j] = 0; }
         for (int e = tid; e < 3 * p.NAP; e += 256) p.T3[(size_t)3 * j * p.NAP + e] = 0.0;
         for (int e = tid; e < 32 * M; e += 256) p.Xobs[(size_t)32 * p.obs_pos[lo + (e >> 5)] + (e & 31)] = 0.0;
+        if (p.Hs) {   // a track dropped by the triangulation still owns rows of the materialised stack: zero them
+            const size_t r0 = (size_t)p.row_ptr[j], r1 = (size_t)p.row_ptr[j + 1];
+            for (size_t e = r0 * p.NAP + tid; e < r1 * p.NAP; e += 256) p.Hs[e] = 0.0;
+        }
         return;
     }
     const int M2 = 2 * M;

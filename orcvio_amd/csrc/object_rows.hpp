@@ -23,6 +23,8 @@ struct ObjEvalArgs {
     const int* frame_clone;   // [F] (-1: not in the window)
     const int* frame_row0;    // [F] first output row of the frame (only for in-window frames)
     int K, F, ncol;           // ncol = 9 + 3K
+    int ldhf;                 // leading dimension of Hf (>= ncol; the columns beyond ncol are written as 0)
+    int* row_cols;            // optional: ncol of the object is written per row (k_obj_build's row_obj_cols)
     int obj_left, new_bbox, vio_left, fix_D;
     double R_b2c[9], t_c_b[3];
     int* row_clone;
@@ -109,8 +111,9 @@ __global__ __launch_bounds__(64) void k_object_rows(ObjEvalArgs p) {
             for (int k = 0; k < 6; ++k) s += jc[k] * D[k * 6 + c];
             p.Hx6[(size_t)row * 6 + c] = s;
         }
-        double* hf = p.Hf + (size_t)row * ncol;
-        for (int c = 0; c < ncol; ++c) hf[c] = 0.0;
+        double* hf = p.Hf + (size_t)row * p.ldhf;
+        for (int c = 0; c < p.ldhf; ++c) hf[c] = 0.0;
+        if (p.row_cols) p.row_cols[row] = ncol;
         for (int c = 0; c < 6; ++c) hf[c] = hpose[c];
         if (hshape) for (int c = 0; c < 3; ++c) hf[6 + c] = hshape[c];
         if (hkp) for (int c = 0; c < 3; ++c) hf[9 + 3 * kpid + c] = hkp[c];

@@ -40,13 +40,32 @@ for ob in objs:
     Hx, Hf2, r, rc, hx6 = mo.construct_object_residual_jacobians(Jc, [fr['clone'] for fr in ob.frames], Hf, res, counts,
                                                                   [fr['wTc'] for fr in ob.frames], win.R_b2c[0], win.t_c_b[0], 0, 22, win.N)
     blocks.append(dict(row_clone=rc, Hx6=hx6, Hf=Hf2, res=r))
-for _ in range(3):
-    upd.update_objects(flags, win.N, blocks, win.P)
-t0 = time.perf_counter()
-for _ in range(20):
-    g = upd.update_objects(flags, win.N, blocks, win.P)
-out['config3_objects'] = dict(objects=20, rows=int(sum(len(b['res']) for b in blocks)), host_inclusive_ms=round((time.perf_counter() - t0) / 20 * 1e3, 4),
-                              accept=int(g['accept']))
+import ctypes as C
+fl = capi.make_flags(flags)
+Pc = np.ascontiguousarray(win.P)
+n = win.n
+arr_rows, keep1 = upd._object_blocks(blocks)
+ef, arr_tr, keep2 = upd._object_tracks(objs, win.R_b2c[0], win.t_c_b[0], True, False, 0, False)
+def call_rows():
+    out, res = upd._result(n, 1)
+    rc = upd.lib.orcvio_msckf_update_objects(upd.h, C.byref(fl), win.N, arr_rows, len(blocks), capi._d(Pc), C.byref(res))
+    assert rc == 0
+    return int(out['accept'][0])
+def call_tracks():
+    out, res = upd._result(n, 1)
+    rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(fl), C.byref(ef), win.N, arr_tr, len(objs), capi._d(Pc), C.byref(res))
+    assert rc == 0
+    return int(out['accept'][0])
+res3 = {}
+for name, fn in (('from_rows', call_rows), ('from_tracks', call_tracks)):
+    for _ in range(10):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        acc = fn()
+    res3[name + '_host_inclusive_ms'] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+    res3[name + '_accept'] = acc
+out['config3_objects'] = dict(objects=20, rows=int(sum(len(b['res']) for b in blocks)), **res3)
 # triangulation
 w = synth.config_window(2)
 for _ in range(3):

@@ -198,3 +198,36 @@ def test_sharded_objects_equal_one_shot(upd):
     # a rank without objects contributes a zero block and dof 0
     d0 = upd.objects_local(flags, win.N, [], win.P)
     assert d0 == 0
+
+
+@pytest.mark.parametrize('new_bbox', [False, True])
+def test_update_from_object_tracks_equals_update_from_rows(upd, new_bbox):
+    """orcvio_msckf_update_object_tracks (rows evaluated on the device, straight into the update) against the two-step
+    form object_rows_eval -> update_objects, and against the mirror's rows; with a track that has too few in-window rows,
+    one with frames outside the window, and a mixed number of keypoints."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=30, F=4, seed=0, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=6, seed=11, sigma_kp=0.004)
+    # object 1: only two frames in the window -> rows <= columns -> skipped; object 2: half of the frames outside
+    for k, fr in enumerate(objs[1].frames):
+        if k >= 1:
+            fr['clone'] = -1
+    for k, fr in enumerate(objs[2].frames):
+        if k % 2:
+            fr['clone'] = -1
+    # object 3 carries fewer keypoints (narrower object state than the others)
+    objs[3].kps = objs[3].kps[:8].copy()
+    for fr in objs[3].frames:
+        fr['zs'] = fr['zs'][:8].copy()
+    blocks = []
+    for ob in objs:
+        b = upd.object_rows_eval(ob, win.R_b2c[0], win.t_c_b[0], True, new_bbox, 0)
+        if b is not None:
+            blocks.append(b)
+    ref = upd.update_objects(flags, win.N, blocks, win.P, want_G=True)
+    got = upd.update_object_tracks(flags, win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], True, new_bbox, 0, want_G=True)
+    assert got['accept'] == ref['accept'] and got['stats'][0] == ref['stats'][0]
+    assert abs(got['gamma'] - ref['gamma']) < 1e-9 * abs(ref['gamma'])
+    assert rel(got['dx'], ref['dx']) < 1e-9 or (not got['dx'].any() and not ref['dx'].any())
+    assert rel(got['P_new'], ref['P_new']) < 1e-10
+    assert rel(got['G'], ref['G']) < 1e-8 or (not got['G'].any() and not ref['G'].any())
