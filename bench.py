@@ -167,6 +167,37 @@ def main():
             th = (time.perf_counter() - th) / reps_h
             host_inclusive = dict(updates_per_s=1.0 / th, ms_per_update=th * 1e3,
                                   what='orcvio_msckf_update_features: host tracks + P in, dx, P+, gamma, accept out')
+        # config 3 adds 20 objects x 12 keypoints to the same window: the object update (a second EKF update per frame in
+        # the reference, src/orcvio.cpp:2154-2193) from object tracks, host buffers in and out; reported beside the metric
+        objects = None
+        if world == 1 and N == 30:
+            try:
+                oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+                owin = synth.make_window(N=N, F=4, seed=0, flags=oflags, track_len=4)
+                objs = synth.make_objects(owin, n_objects=20, seed=1, sigma_kp=0.004)
+                import ctypes as C
+                ofl = capi.make_flags(oflags)
+                ef, arr, keep = upd._object_tracks(objs, owin.R_b2c[0], owin.t_c_b[0], True, False, 0, False)   # marshalled once
+                Pc = np.ascontiguousarray(owin.P)
+
+                def call():
+                    out, res = upd._result(owin.n, 1)
+                    rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs),
+                                                                   capi._d(Pc), C.byref(res))
+                    assert rc == 0
+                    return int(out['accept'][0]), int(res.stats[0])
+                for _ in range(5):
+                    g = call()
+                to = time.perf_counter()
+                for _ in range(20):
+                    g = call()
+                to = (time.perf_counter() - to) / 20
+                objects = dict(ms_per_update=to * 1e3, objects=20, accepted=g[0], dof=g[1],
+                               what='orcvio_msckf_update_object_tracks: 20 cars x 12 keypoints x 30 frames, rows evaluated on the '
+                                    'device, host buffers in, dx and P+ out')
+                upd.upload(win)   # the feature tracks again for what follows
+            except Exception as e:   # never let the side measurement break the metric line
+                objects = dict(error=str(e))
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as orc   # checker used as the reported CPU baseline ("port")
@@ -184,7 +215,7 @@ def main():
                                         'per GPU (22 800 stacked rows x 202 columns), LARVIO Jacobians',
                                clones=N, features_per_gpu=F, observations_per_feature=N,
                                parallelism=f'features sharded over {world} GPU(s), all-gather of compressed blocks'),
-                   roofline=roofline, cpu_baseline=cpu, host_inclusive=host_inclusive)
+                   roofline=roofline, cpu_baseline=cpu, host_inclusive=host_inclusive, objects_update=objects)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
