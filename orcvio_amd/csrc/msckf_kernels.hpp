@@ -1155,16 +1155,14 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
             tol = tol_rel * mx;
         }
-        auto factor_diag = [&](int kb) {
+        double v[16];   // rows of the most recent L11 (lane (l & 15) = row), kept until its R11 tile has been written
+        // factor + invert the tile that sits in sD (row view): v <- L11, inv(L11) -> sDi[kb & 1]
+        auto sweep_tile = [&](int kb) {
             int z = 0;
             asm volatile("" : "+v"(z));   // opaque zero: keeps LDS address arithmetic out of loop-invariant hoisting
-            double* pD = &sD[0][0] + z;
+            const double* pD = &sD[0][0] + z;
             double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
-            double* pG = &sDg[0][0][0] + z + kb * 256 + l;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pD[(kk + 4 * r) * 16 + cc] = pG[r * 64];
-            wave_sync();
-            double v[16], y[16];
+            double y[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const double a = pD[cc * 16 + c];
@@ -1178,8 +1176,13 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
 #pragma unroll
                 for (int c = 0; c < 16; ++c) pDi[c * 16 + l] = y[c];   // Linv[c][l]
             }
-            // R11[kk+4r][cc] = L11[cc][kk+4r] = v[kk+4r] of this very lane (every 16-lane row holds all rows);
-            // inv(L11) and R11 go to memory from LDS by a helper wave of role 2 (no global stores on this chain)
+        };
+        // R11[kk+4r][cc] = L11[cc][kk+4r] = v[kk+4r] of this very lane (every 16-lane row holds all rows) -> sDg[kb];
+        // wave 4 takes inv(L11) and R11 from LDS to memory (no global stores of them on this chain)
+        auto write_R11 = [&](int kb) {
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            double* pG = &sDg[0][0][0] + z + kb * 256 + l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double x0 = v[4 * r], x1 = v[4 * r + 1], x2 = v[4 * r + 2], x3 = v[4 * r + 3];
@@ -1189,7 +1192,14 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
         };
         __builtin_amdgcn_s_setprio(3);
         POTRF_STAMP(0, 1);
-        if (!(ablate & 64)) factor_diag(0);
+        {   // tile 0 goes from sDg to the row view as it is
+            int z = 0;
+            asm volatile("" : "+v"(z));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 16 + cc] = (&sDg[0][0][0] + z + l)[r * 64];
+            wave_sync();
+            sweep_tile(0);
+        }
         POTRF_STAMP(0, 2);
         const unsigned lane_b0 = (unsigned)((kk * ldr + cc) * 8);
         for (int kb = 0; kb < nb; ++kb) {
@@ -1204,9 +1214,17 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                 // the chain computes the one panel tile its next diagonal tile needs, (kb, kb+1), itself: no hand-off
                 const double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
                 const double* st = &sStage[0][0][0] + z + kn * 256 + l;
-                d4 x = {0, 0, 0, 0};
+                const double* pGn = &sDg[0][0][0] + z + kn * 256 + l;
+                double li[4], sv[4];
+                d4 t;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(pDi[cc * 16 + kk + 4 * s4], st[s4 * 64], x);
+                for (int s4 = 0; s4 < 4; ++s4) { li[s4] = pDi[cc * 16 + kk + 4 * s4]; sv[s4] = st[s4 * 64]; t[s4] = pGn[s4 * 64]; }
+                d4 x = {0, 0, 0, 0};
+                x = mfma_f64(li[0], sv[0], x);
+                write_R11(kb);   // (independent LDS writes: they issue in the shadow of the dependent MFMAs)
+                x = mfma_f64(li[1], sv[1], x);
+                x = mfma_f64(li[2], sv[2], x);
+                x = mfma_f64(li[3], sv[3], x);
                 double* pPan = &sPan[0][0][0] + z + kn * 256 + l;
                 double* ub = R + (size_t)(16 * kb) * ldr + 16 * kn;
 #pragma unroll
@@ -1216,20 +1234,20 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                 }
                 if (l == 0) __hip_atomic_fetch_add(&sCnt[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 POTRF_STAMP(0, 4 + 4 * kb);
-                double* pG = &sDg[0][0][0] + z + l;
-                {   // next diagonal tile: -= panel^T panel (operands straight from the accumulator registers), then factor
-                    d4 t;
+                // next diagonal tile: -= panel^T panel (operands straight from the accumulator registers), straight into
+                // the row view for its sweep
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] = pG[kn * 256 + r * 64];
+                for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-x[s4], x[s4], t);
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-x[s4], x[s4], t);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pG[kn * 256 + r * 64] = t[r];
-                }
+                for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 16 + cc] = t[r];
+                wave_sync();
                 POTRF_STAMP(0, 5 + 4 * kb);
-                factor_diag(kn);
+                sweep_tile(kn);
                 POTRF_STAMP(0, 6 + 4 * kb);
                 // the later diagonal tiles (k > kn) are brought up to date by the workers (they live in LDS)
+            } else {
+                write_R11(kb);
+                if (l == 0) __hip_atomic_fetch_add(&sCnt[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1254,6 +1272,8 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             const double* g = &sDg[0][0][0] + z + kb * 256 + l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) st_pub<PUB>(Dinv + (size_t)kb * 256 + l + 64 * r, pDi[l + 64 * r]);
+            // R11 is written by the chain after this barrier, before it adds to the step counter
+            while (__hip_atomic_load(&sCnt[kb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < POTRF_NW + 1) __builtin_amdgcn_s_sleep(2);
             double* ub = R + (size_t)(16 * kb) * ldr + 16 * kb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, g[r * 64]);
@@ -1345,7 +1365,7 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             // B: every panel tile of step kb is in LDS -- a counter, not a barrier: the chain only adds to it
             if (l == 0) __hip_atomic_fetch_add(&sCnt[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             {
-                const int target = POTRF_NW + ((kb + 1 < nb) ? 1 : 0);
+                const int target = POTRF_NW + 1;   // the workers and the chain (which also writes R11 of this step before it adds)
                 while (__hip_atomic_load(&sCnt[kb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
             }
             POTRF_STAMP(wave == 1 ? 1 : 3, 5 + 4 * kb);
