@@ -1086,6 +1086,14 @@ __device__ __forceinline__ void st_pub(double* p, double v) {
 __device__ __forceinline__ double ld_pub(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// "my LDS writes of this step are done": the LDS executes one wavefront's operations in order, so the counter bump only
+// has to stay behind them in program order -- a release fence here would also drain the wave's GLOBAL stores (the
+// finished tiles on their way to memory), i.e. stall ~1.5 k cycles on every step.
+__device__ __forceinline__ void lds_publish_count(int* cnt, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
 // workgroup barrier that also drains this wave's global stores (publishing waves, one block step after issuing them)
 __device__ __forceinline__ void lds_barrier_drain() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1109,8 +1117,10 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
     // MFMAs, 8 skip the later-diagonal updates.  Results are garbage when non-zero.
     // stamps (diagnostic, scripts/gpu_potrf_stamps.py): core-clock time stamps of wave 0 ([0..63]) and wave 1 ([64..127])
 #define POTRF_STAMP(w, idx) do { if (stamps && l == 0 && (w) < 3) stamps[(w) * 64 + (idx)] = clock64(); } while (0)
-    __shared__ __attribute__((aligned(16))) double sD[16][16];       // diagonal tile being factored (row view)
-    __shared__ __attribute__((aligned(16))) double sDi[2][16][16];   // inv(L11) of block step kb in sDi[kb & 1]
+    // rows of 17 doubles: the row view is read one ROW per lane and inv(L11) one COLUMN block per lane; a stride of 16
+    // doubles would put every lane of a 16-lane row on the same two banks
+    __shared__ __attribute__((aligned(16))) double sD[16][17];       // diagonal tile being factored (row view)
+    __shared__ __attribute__((aligned(16))) double sDi[2][16][17];   // inv(L11) of block step kb in sDi[kb & 1]
     __shared__ int sCnt[16];                                        // waves that have published their panel tiles of step kb
     __shared__ __attribute__((aligned(16))) double sPan[14][4][64];  // published panel tiles, accumulator layout
     __shared__ __attribute__((aligned(16))) double sDg[14][4][64];   // the diagonal tiles (owned by wave 0)
@@ -1161,11 +1171,11 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             int z = 0;
             asm volatile("" : "+v"(z));   // opaque zero: keeps LDS address arithmetic out of loop-invariant hoisting
             const double* pD = &sD[0][0] + z;
-            double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
+            double* pDi = &sDi[0][0][0] + z + (kb & 1) * 272;
             double y[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const double a = pD[cc * 16 + c];
+                const double a = pD[cc * 17 + c];
                 v[c] = (c <= cc) ? a : 0.0;
                 y[c] = (c == cc) ? 1.0 : 0.0;
             }
@@ -1174,7 +1184,7 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             POTRF_STAMP(2, 3 * kb + 1);
             if (l < 16) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) pDi[c * 16 + l] = y[c];   // Linv[c][l]
+                for (int c = 0; c < 16; ++c) pDi[c * 17 + l] = y[c];   // Linv[c][l]
             }
         };
         // R11[kk+4r][cc] = L11[cc][kk+4r] = v[kk+4r] of this very lane (every 16-lane row holds all rows) -> sDg[kb];
@@ -1196,7 +1206,7 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             int z = 0;
             asm volatile("" : "+v"(z));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 16 + cc] = (&sDg[0][0][0] + z + l)[r * 64];
+            for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 17 + cc] = (&sDg[0][0][0] + z + l)[r * 64];
             wave_sync();
             sweep_tile(0);
         }
@@ -1212,13 +1222,13 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                 int z = 0;
                 asm volatile("" : "+v"(z));
                 // the chain computes the one panel tile its next diagonal tile needs, (kb, kb+1), itself: no hand-off
-                const double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
+                const double* pDi = &sDi[0][0][0] + z + (kb & 1) * 272;
                 const double* st = &sStage[0][0][0] + z + kn * 256 + l;
                 const double* pGn = &sDg[0][0][0] + z + kn * 256 + l;
                 double li[4], sv[4];
                 d4 t;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) { li[s4] = pDi[cc * 16 + kk + 4 * s4]; sv[s4] = st[s4 * 64]; t[s4] = pGn[s4 * 64]; }
+                for (int s4 = 0; s4 < 4; ++s4) { li[s4] = pDi[cc * 17 + kk + 4 * s4]; sv[s4] = st[s4 * 64]; t[s4] = pGn[s4 * 64]; }
                 d4 x = {0, 0, 0, 0};
                 x = mfma_f64(li[0], sv[0], x);
                 write_R11(kb);   // (independent LDS writes: they issue in the shadow of the dependent MFMAs)
@@ -1232,14 +1242,14 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                     pPan[r * 64] = x[r];
                     st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b0, x[r]);
                 }
-                if (l == 0) __hip_atomic_fetch_add(&sCnt[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_publish_count(&sCnt[kb], l);
                 POTRF_STAMP(0, 4 + 4 * kb);
                 // next diagonal tile: -= panel^T panel (operands straight from the accumulator registers), straight into
                 // the row view for its sweep
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-x[s4], x[s4], t);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 16 + cc] = t[r];
+                for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 17 + cc] = t[r];
                 wave_sync();
                 POTRF_STAMP(0, 5 + 4 * kb);
                 sweep_tile(kn);
@@ -1247,7 +1257,7 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                 // the later diagonal tiles (k > kn) are brought up to date by the workers (they live in LDS)
             } else {
                 write_R11(kb);
-                if (l == 0) __hip_atomic_fetch_add(&sCnt[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_publish_count(&sCnt[kb], l);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1268,10 +1278,10 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             int z = 0;
             asm volatile("" : "+v"(z));
             if (PUB) lds_barrier_drain(); else lds_barrier();   // A
-            const double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
+            const double* pDi = &sDi[0][0][0] + z + (kb & 1) * 272;
             const double* g = &sDg[0][0][0] + z + kb * 256 + l;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st_pub<PUB>(Dinv + (size_t)kb * 256 + l + 64 * r, pDi[l + 64 * r]);
+            for (int r = 0; r < 4; ++r) st_pub<PUB>(Dinv + (size_t)kb * 256 + l + 64 * r, pDi[(kk + 4 * r) * 17 + cc]);   // element l + 64 r = (row kk + 4r, column cc)
             // R11 is written by the chain after this barrier, before it adds to the step counter
             while (__hip_atomic_load(&sCnt[kb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < POTRF_NW + 1) __builtin_amdgcn_s_sleep(2);
             double* ub = R + (size_t)(16 * kb) * ldr + 16 * kb;
@@ -1323,7 +1333,7 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
         for (int kb = 0; kb < nb; ++kb) {
             int z = 0;
             asm volatile("" : "+v"(z));
-            double* pDi = &sDi[0][0][0] + z + (kb & 1) * 256;
+            double* pDi = &sDi[0][0][0] + z + (kb & 1) * 272;
             double* pPan = &sPan[0][0][0] + z;
             POTRF_STAMP(wave == 1 ? 1 : 3, 2 + 4 * kb);
             if (PUB) {
@@ -1342,7 +1352,7 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             if (kb + 2 + wi < nb && !(ablate & 32)) {   // tile (kb, kb+1) is the chain's
                 double li[4];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) li[s4] = pDi[cc * 16 + kk + 4 * s4];   // A operand: Linv[m = cc][k = kk + 4 s4]
+                for (int s4 = 0; s4 < 4; ++s4) li[s4] = pDi[cc * 17 + kk + 4 * s4];   // A operand: Linv[m = cc][k = kk + 4 s4]
                 double* urow = R + (size_t)(16 * kb) * ldr;
 #pragma unroll 1
                 for (int b = kb + 2 + wi; b < nb; b += POTRF_NW) {
@@ -1363,7 +1373,7 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             }
             POTRF_STAMP(wave == 1 ? 1 : 3, 4 + 4 * kb);
             // B: every panel tile of step kb is in LDS -- a counter, not a barrier: the chain only adds to it
-            if (l == 0) __hip_atomic_fetch_add(&sCnt[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_publish_count(&sCnt[kb], l);
             {
                 const int target = POTRF_NW + 1;   // the workers and the chain (which also writes R11 of this step before it adds)
                 while (__hip_atomic_load(&sCnt[kb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
