@@ -75,6 +75,7 @@ struct orcvio_msckf_handle {
     double *d_poses = nullptr, *d_pw = nullptr, *d_obs_z = nullptr, *d_obs_zvel = nullptr, *d_P = nullptr;
     int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_info = nullptr;
     double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_A = nullptr;
+    int clean_NP = -1, clean_path = -1;   // layout for which the strictly-lower tiles of d_RP / d_RM are known to be zero
     double *d_RP = nullptr, *d_DinvP = nullptr, *d_U = nullptr, *d_M = nullptr, *d_RM = nullptr, *d_DinvM = nullptr;
     double *d_Z = nullptr, *d_Pout = nullptr, *d_dx = nullptr;
     double *d_La = nullptr, *d_DinvA = nullptr, *d_W = nullptr, *d_Y = nullptr, *d_KG = nullptr;   // optional outputs
@@ -358,6 +359,8 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
     return ORCVIO_ERR_INVALID;
 }
 
+static int factor_layout_clean(orcvio_msckf_handle* h);
+
 // ---- upload --------------------------------------------------------------------------------
 int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
                             const orcvio_msckf_tracks* tr, const double* P) {
@@ -399,6 +402,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->NP = round_up(h->n, 16);
     h->ldz = round_up(h->n + 1, 16);
     h->reg_path = (h->NP / 16) <= 14;
+    { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
     h->m_tot = h->h_row_ptr[F];
     h->Mmax = Mmax;
     // chi-square table (src/orcvio.cpp:481-494)
@@ -556,6 +560,21 @@ static int launch_reduce(orcvio_msckf_handle* h, hipStream_t s, const double* pa
     return ORCVIO_OK;
 }
 
+// k_potrf_reg / k_potrf_solve write the upper tiles of d_RP / d_RM only and rely on the strictly-lower tiles being zero
+// (the consumers read the factors as dense matrices).  They are: zeroed at creation, and again whenever the leading
+// dimension or the factorisation path changes -- a change of window size, not a per-update event.
+static int factor_layout_clean(orcvio_msckf_handle* h) {
+    if (h->NP == h->clean_NP && (int)h->reg_path == h->clean_path) return ORCVIO_OK;
+    HIPCHK(hipDeviceSynchronize());   // an earlier update may still be reading the factors
+    const size_t bytes = sizeof(double) * (size_t)h->NP_max * h->NP_max;
+    HIPCHK(hipMemset(h->d_RP, 0, bytes));
+    HIPCHK(hipMemset(h->d_RM, 0, bytes));
+    HIPCHK(hipDeviceSynchronize());
+    h->clean_NP = h->NP;
+    h->clean_path = (int)h->reg_path;
+    return ORCVIO_OK;
+}
+
 // Cholesky X = L L^T.  reg path: upper factor R (L = R^T) written to `out` (ld = NP), L(i,j) = out[j*NP + i];
 // LDS-panel path: X copied to `out`, factored in place (lower), L(i,j) = out[i*NP + j].
 static int launch_potrf(orcvio_msckf_handle* h, hipStream_t s, const double* X, int ldx, int nn, double tol_rel, double* out,
@@ -565,10 +584,14 @@ static int launch_potrf(orcvio_msckf_handle* h, hipStream_t s, const double* X, 
         const int nb = (nn + 15) / 16, noff = nb * (nb - 1) / 2;
         const int need = potrf_slots_needed(nb);   // wave 0 keeps the diagonal tiles in LDS, the workers the rest in registers
         (void)noff;
-        if (need <= 4) hipLaunchKernelGGL(k_potrf_reg<4>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
-        else if (need <= 8) hipLaunchKernelGGL(k_potrf_reg<8>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
-        else if (need <= 12) hipLaunchKernelGGL(k_potrf_reg<12>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
-        else hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info);
+        // zero_lower = 0: `out` is d_RP / d_RM, whose strictly-lower tiles factor_layout_clean() keeps zero
+#define LAUNCH_PR(NS) hipLaunchKernelGGL(k_potrf_reg<NS>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info, \
+                                         (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, 0, 0)
+        if (need <= 4) LAUNCH_PR(4);
+        else if (need <= 8) LAUNCH_PR(8);
+        else if (need <= 12) LAUNCH_PR(12);
+        else LAUNCH_PR(16);
+#undef LAUNCH_PR
     } else {
         HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * NP, X, sizeof(double) * ldx, sizeof(double) * nn, nn, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_potrf, dim3(1), dim3(1024), 0, s, out, nn, NP, tol_rel, Dinv, info);
@@ -1010,6 +1033,7 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     h->NP = round_up(h->n, 16);
     h->ldz = round_up(h->n + 1, 16);
     h->reg_path = (h->NP / 16) <= 14;
+    { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
     h->m_tot = 0; h->Mmax = 2; h->chunks = 1; h->rows_per_chunk = 8;
     h->h_row_ptr.assign(1, 0);
     const int n = h->n, NA = h->NA, NAP = h->NAP;
@@ -1097,6 +1121,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     h->NP = round_up(h->n, 16);
     h->ldz = round_up(h->n + 1, 16);
     h->reg_path = (h->NP / 16) <= 14;
+    { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
     h->m_tot = 0; h->Mmax = 2; h->chunks = 1; h->rows_per_chunk = 8;
     h->h_row_ptr.assign(1, 0);
     const int n = h->n, NAP = h->NAP;
@@ -1715,6 +1740,7 @@ int32_t orcvio_msckf_debug_potrf(orcvio_msckf_handle* h, const double* X, int32_
     const int NP = h->NP;
     HIPCHK(hipMemcpy(h->d_M, X, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 8));
+    HIPCHK(hipMemset(h->d_RM, 0, sizeof(double) * (size_t)h->NP_max * h->NP_max));   // lower tiles: zero for any layout
     int rc = launch_potrf(h, h->stream, h->d_M, n, n, tol_rel, h->d_RM, h->d_DinvM, h->d_info);
     if (rc == ORCVIO_OK) {
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1747,6 +1773,7 @@ int32_t orcvio_msckf_debug_trsm(orcvio_msckf_handle* h, const double* X, int32_t
     const int NP = h->NP;
     HIPCHK(hipMemcpy(h->d_M, X, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_U, B, sizeof(double) * (size_t)n * nrhs, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(h->d_RM, 0, sizeof(double) * (size_t)h->NP_max * h->NP_max));
     int rc = launch_potrf(h, h->stream, h->d_M, n, n, 0.0, h->d_RM, h->d_DinvM, h->d_info);
     if (rc == ORCVIO_OK) rc = launch_trsm(h, h->stream, h->d_RM, h->d_DinvM, n, h->d_U, nrhs, 1, nrhs, nullptr, 0, h->d_Z, h->NP_max);
     if (rc == ORCVIO_OK) {
@@ -1797,9 +1824,11 @@ int32_t orcvio_msckf_debug_potrf_stamps(orcvio_msckf_handle* h, unsigned long lo
     HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 256));
     HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 256));
     const int n = h->n, NP = h->NP;
+    const char* ab = getenv("ORCVIO_POTRF_ABLATE");   // diagnostic only: phases switched off (results are garbage)
+    const int ablate = ab ? atoi(ab) : 0;
     for (int rep = 0; rep < 4; ++rep)
         hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
-                           h->d_info + 6, d, (size_t)0, (size_t)0, (size_t)0, 0, 0);
+                           h->d_info + 6, d, (size_t)0, (size_t)0, (size_t)0, 0, ablate);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out256, d, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost));
     (void)hipFree(d);

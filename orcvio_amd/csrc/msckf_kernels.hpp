@@ -224,7 +224,7 @@ struct FeatArgs {
 __host__ __device__ inline int feat_lde(int Mmax) { return 2 * Mmax + 1; }
 __host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
     const int R2 = 2 * Mmax;
-    size_t dbl = (size_t)R2 * 7 + (size_t)R2 * 6 + R2 + (size_t)R2 * 4 + 64 * 4 + 16 + 4 + 8 * (size_t)NAP + 256 + 256 +
+    size_t dbl = (size_t)R2 * 7 + (size_t)R2 * 6 + R2 + (size_t)R2 * 4 + 64 * 4 + 16 + 4 + 8 * (size_t)NAP + 272 + 272 +
                  (size_t)R2 * feat_lde(Mmax);
     size_t bytes = dbl * 8 + (size_t)(N + Mmax + 4) * 4;
     return (bytes + 15) & ~(size_t)15;
@@ -275,9 +275,9 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
     double* sQ = sB + 256;            // [16]     beta(3), g10, g20, g21
     double* sYr = sQ + 16;            // [4]
     double* sUall = sYr + 4;          // [4 waves][NAP][2]
-    double* sD = sUall + 8 * NAP;     // [16][16] diagonal tile, row view
-    double* sDi = sD + 256;           // [16][16] its inverse factor
-    double* sE = sDi + 256;           // [R2][LDE]
+    double* sD = sUall + 8 * NAP;     // [16][17] diagonal tile, row view (17: one row per lane without bank conflicts)
+    double* sDi = sD + 272;           // [16][17] its inverse factor
+    double* sE = sDi + 272;           // [R2][LDE]
     int* sC2O = (int*)(sE + (size_t)R2 * LDE);   // [N]
     int* sOC = sC2O + p.N;                        // [Mmax]
     int* sFlag = sOC + p.Mmax;                    // [4]  [0] gate verdict, [1] next observation of phase E
@@ -539,24 +539,24 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
                 if (k < nbk) {
                     // diagonal tile: accumulator layout -> rows in lanes, factor + invert in one DPP sweep
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sD[(kk + 4 * r) * 16 + cc] = S[k][k][r];
+                    for (int r = 0; r < 4; ++r) sD[(kk + 4 * r) * 17 + cc] = S[k][k][r];
                     wave_sync();
                     double v[16], y[16];
 #pragma unroll
                     for (int c = 0; c < 16; ++c) {
-                        const double av = sD[cc * 16 + c];
+                        const double av = sD[cc * 17 + c];
                         v[c] = (c <= cc) ? av : 0.0;
                         y[c] = (c == cc) ? 1.0 : 0.0;
                     }
                     DiagStep<0>::run(v, y, 0.0, M2 - 16 * k, nzero, nneg);
                     if (t < 16) {
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) sDi[c * 16 + t] = y[c];   // Linv[c][t]
+                        for (int c = 0; c < 16; ++c) sDi[c * 17 + t] = y[c];   // Linv[c][t]
                     }
                     wave_sync();
                     double li[4];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) li[s4] = sDi[cc * 16 + kk + 4 * s4];
+                    for (int s4 = 0; s4 < 4; ++s4) li[s4] = sDi[cc * 17 + kk + 4 * s4];
                     wave_sync();
                     // panel: row block k of the factor (transposed) and of the right-hand sides
 #pragma unroll
@@ -1111,7 +1111,10 @@ template <int NSLOT, bool PUB>
 __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int ldx, int n, double tol_rel,
                                                double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                int* __restrict__ info, int from_lower, int ablate, int* __restrict__ flag,
-                                               unsigned long long* __restrict__ stamps = nullptr, int info_store = 0) {
+                                               unsigned long long* __restrict__ stamps = nullptr, int info_store = 0,
+                                               int zero_lower = 1) {
+    // zero_lower: write zeros to the strictly-lower tiles of R.  0 when the caller keeps them zero itself (the handle's
+    // factors: zeroed when the leading dimension changes, never written otherwise).
     // info_store: single-workgroup launches WRITE their two counters (no zeroing launch needed); batched launches add
     // ablate (diagnostic only, scripts/gpu_ablate.py): 1 skip the diagonal sweep, 2 skip trailing MFMAs, 4 skip panel
     // MFMAs, 8 skip the later-diagonal updates.  Results are garbage when non-zero.
@@ -1125,7 +1128,7 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
     __shared__ __attribute__((aligned(16))) double sPan[14][4][64];  // published panel tiles, accumulator layout
     __shared__ __attribute__((aligned(16))) double sDg[14][4][64];   // the diagonal tiles (owned by wave 0)
     __shared__ __attribute__((aligned(16))) double sStage[14][4][64];   // block row kb of the trailing matrix, up to date
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nb = (n + 15) >> 4;
     POTRF_STAMP(wave == 0 ? 0 : (wave == 1 ? 1 : 3), 0);
@@ -1137,27 +1140,27 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
         // Role 1 -- the critical chain
         // =====================================================================================
         int nzero = 0, nneg = 0;
-        double mx = 0.0;   // largest diagonal entry -> pivot tolerance (taken from the tiles as they are loaded)
-        {   // all 56 loads in flight before the first LDS write (a rolled loop waits for every tile in turn)
-            double dg[14][4];
+        double mx = 0.0;   // largest diagonal entry -> pivot tolerance
+        // Only tile 0 and the n diagonal entries (one gather) stand between the launch and the first sweep: eight loads
+        // in flight, one memory latency.  Wave 4 brings the other diagonal tiles into LDS meanwhile.
+        {
+            double d0[4], dd[4];
 #pragma unroll
-            for (int k = 0; k < 14; ++k) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * k + kk + 4 * r, j = 16 * k + cc;
-                    const bool in = k < nb && i < n && j < n;
-                    const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
-                    dg[k][r] = in ? xv : 0.0;
-                    if (in && i == j) mx = fmax(mx, xv);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = kk + 4 * r, j = cc;
+                const bool in = i < n && j < n;
+                const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
+                d0[r] = in ? xv : 0.0;
+                const int e = l + 64 * r;
+                const double dv = X[(size_t)(e < n ? e : 0) * (ldx + 1)];
+                dd[r] = (e < n) ? dv : 0.0;
             }
+            int z = 0;
+            asm volatile("" : "+v"(z));
 #pragma unroll
-            for (int k = 0; k < 14; ++k) {
-                if (k < nb) {
+            for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 17 + cc] = d0[r];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sDg[k][r][l] = dg[k][r];
-                }
-            }
+            for (int r = 0; r < 4; ++r) mx = fmax(mx, dd[r]);
         }
         double tol = 0.0;
         if (tol_rel > 0.0) {
@@ -1202,14 +1205,8 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
         };
         __builtin_amdgcn_s_setprio(3);
         POTRF_STAMP(0, 1);
-        {   // tile 0 goes from sDg to the row view as it is
-            int z = 0;
-            asm volatile("" : "+v"(z));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 17 + cc] = (&sDg[0][0][0] + z + l)[r * 64];
-            wave_sync();
-            sweep_tile(0);
-        }
+        wave_sync();
+        sweep_tile(0);
         POTRF_STAMP(0, 2);
         const unsigned lane_b0 = (unsigned)((kk * ldr + cc) * 8);
         for (int kb = 0; kb < nb; ++kb) {
@@ -1274,6 +1271,26 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
         // work here, it only writes inv(L11) and R11 of every step from LDS to memory.
         // =====================================================================================
         const unsigned lane_b = (unsigned)((kk * ldr + cc) * 8);
+        {   // diagonal tiles 1.. -> sDg (first needed behind barrier A of step 0); all loads in flight before the first write
+            double dg[13][4];
+#pragma unroll
+            for (int k = 1; k < 14; ++k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * k + kk + 4 * r, j = 16 * k + cc;
+                    const bool in = k < nb && i < n && j < n;
+                    const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
+                    dg[k - 1][r] = in ? xv : 0.0;
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < 14; ++k) {
+                if (k < nb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sDg[k][r][l] = dg[k - 1][r];
+                }
+            }
+        }
         for (int kb = 0; kb < nb; ++kb) {
             int z = 0;
             asm volatile("" : "+v"(z));
@@ -1292,37 +1309,57 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
         // =====================================================================================
         // Role 2 -- workers (waves 1,2,3,5,6,7).  Tile t = T(a) + (b - a - 1), T(a) = a nb - a(a+1)/2, of worker t % NW, slot t / NW.
         // =====================================================================================
-        const int wi = (wave < 4) ? wave - 1 : wave - 2;   // 0 .. POTRF_NW-1
+        const int wi = (wave < 4) ? wave - 1 : wave - 2;   // 0 .. POTRF_NW-1 (wave-uniform, in an SGPR)
         d4 acc[NSLOT];
         int tab[NSLOT];   // packed a | b << 8 (wave-uniform), -1 if the slot is empty
-        const int noff = nb * (nb - 1) / 2;
         const unsigned lane_b = (unsigned)((kk * ldr + cc) * 8);   // lane part of every R address, bytes
-        int dec_a = 0, dec_base = 0;   // running (block row, first tile index of that row): t grows with s
+        // Loads: uniform tile base (SGPRs) + one 32-bit lane offset, so a slot costs a handful of instructions and all
+        // loads of the wave are in flight within a few hundred cycles.  Only the last block column can reach past n
+        // (rows of an off-diagonal tile never do: a <= nb - 2): its lanes use a clamped column and select 0.
+        const int ce = n - 1 - 16 * (nb - 1);   // last valid column inside block column nb - 1
+        const bool cin = cc <= ce;
+        const int ccE = cin ? cc : ce;
+        const unsigned loN = (unsigned)(from_lower ? (cc * ldx + kk) : (kk * ldx + cc)) * 8u;
+        const unsigned loE = (unsigned)(from_lower ? (ccE * ldx + kk) : (kk * ldx + ccE)) * 8u;
+        const size_t rstep = from_lower ? (size_t)32 : (size_t)32 * ldx;   // bytes between accumulator rows r -> r + 1
+        int ta = 0, tb = 1 + wi;   // tile index t = s NW + wi as (block row, block column), advanced by NW per slot
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            int a = -1, b = -1;
-            const int t = s * POTRF_NW + wi;
-            if (t < noff) {
-                while (dec_base + (nb - 1 - dec_a) <= t) { dec_base += nb - 1 - dec_a; ++dec_a; }
-                a = dec_a;
-                b = dec_a + 1 + (t - dec_base);
+            while (ta < nb - 1 && tb > nb - 1) { const int over = tb - nb; ++ta; tb = ta + 1 + over; }
+            const bool live = ta < nb - 1;
+            tab[s] = live ? (ta | (tb << 8)) : -1;
+            const bool edge = tb == nb - 1;
+            // (an empty slot reads element 0: no branch, and the select below comes after every load has been issued)
+            const char* ub = reinterpret_cast<const char*>(X) +
+                             (!live ? (size_t)0 : (from_lower ? ((size_t)(16 * tb) * ldx + 16 * ta) : ((size_t)(16 * ta) * ldx + 16 * tb)) * 8);
+            const unsigned lo = !live ? 0u : (edge ? loE : loN);
+            const size_t rs = live ? rstep : (size_t)0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s][r] = *reinterpret_cast<const double*>(ub + r * rs + lo);
+            tb += POTRF_NW;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const bool dead = tab[s] < 0, edge = (tab[s] >> 8) == nb - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s][r] = (dead || (edge && !cin)) ? 0.0 : acc[s][r];
+        }
+        // every load of this wave is in flight before the first use (loads and stores share one in-order counter)
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (tab[s] >= 0 && (tab[s] & 255) == 0) {   // block row 0 is the first panel
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sStage[tab[s] >> 8][r][l] = acc[s][r];
             }
-            tab[s] = __builtin_amdgcn_readfirstlane(a < 0 ? -1 : (a | (b << 8)));
+        }
+        if (zero_lower) {   // the mirrored (strictly lower) tile of the output is never touched again
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * a + kk + 4 * r, j = 16 * b + cc;
-                const bool in = a >= 0 && i < n && j < n;
-                const int ic = in ? i : 0, jc = in ? j : 0;   // clamped address + select: keeps the loads unpredicated
-                const double xv = from_lower ? X[(size_t)jc * ldx + ic] : X[(size_t)ic * ldx + jc];
-                acc[s][r] = in ? xv : 0.0;
-            }
-            if (tab[s] >= 0) {   // the mirrored (strictly lower) tile of the output is never touched again: zero it
-                double* ub = R + (size_t)(16 * (tab[s] >> 8)) * ldr + 16 * (tab[s] & 255);
+            for (int s = 0; s < NSLOT; ++s) {
+                if (tab[s] >= 0) {
+                    double* ub = R + (size_t)(16 * (tab[s] >> 8)) * ldr + 16 * (tab[s] & 255);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st_tile<false>(ub + (size_t)(4 * r) * ldr, lane_b, 0.0);
-                if ((tab[s] & 255) == 0) {   // block row 0 is the first panel
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sStage[tab[s] >> 8][r][l] = acc[s][r];
+                    for (int r = 0; r < 4; ++r) st_tile<false>(ub + (size_t)(4 * r) * ldr, lane_b, 0.0);
                 }
             }
         }
@@ -1350,24 +1387,43 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             // rolled loop that any worker can run on any tile: tile kb+2+wi, +NW, ...
             (void)s_lo;
             if (kb + 2 + wi < nb && !(ablate & 32)) {   // tile (kb, kb+1) is the chain's
-                double li[4];
+                // at most two tiles per worker (nb <= 14): both operand sets are fetched before the first MFMA
+                const int b0 = kb + 2 + wi;
+                const bool two = b0 + POTRF_NW < nb;
+                const int b1 = two ? b0 + POTRF_NW : b0;
+                double li[4], sa[4], sb[4];
+                const double* st0 = &sStage[0][0][0] + z + b0 * 256 + l;
+                const double* st1 = &sStage[0][0][0] + z + b1 * 256 + l;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) li[s4] = pDi[cc * 17 + kk + 4 * s4];   // A operand: Linv[m = cc][k = kk + 4 s4]
+                for (int s4 = 0; s4 < 4; ++s4) { li[s4] = pDi[cc * 17 + kk + 4 * s4]; sa[s4] = st0[s4 * 64]; }   // A operand: Linv[m = cc][k = kk + 4 s4]
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) sb[s4] = st1[s4 * 64];
                 double* urow = R + (size_t)(16 * kb) * ldr;
-#pragma unroll 1
-                for (int b = kb + 2 + wi; b < nb; b += POTRF_NW) {
-                    const double* st = &sStage[0][0][0] + z + b * 256 + l;
-                    d4 x = {0, 0, 0, 0};
-                    if (!(ablate & 4)) {
+                d4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+                if (!(ablate & 4)) {
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], st[s4 * 64], x);
+                    for (int s4 = 0; s4 < 4; ++s4) x0 = mfma_f64(li[s4], sa[s4], x0);
+                    if (two) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) x1 = mfma_f64(li[s4], sb[s4], x1);
                     }
-                    double* dst = pPan + b * 256 + l;
-                    double* ub = urow + 16 * b;
+                }
+                {
+                    double* dst = pPan + b0 * 256 + l;
+                    double* ub = urow + 16 * b0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        dst[r * 64] = x[r];
-                        st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, x[r]);   // final: row block kb of R
+                        dst[r * 64] = x0[r];
+                        st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, x0[r]);   // final: row block kb of R
+                    }
+                }
+                if (two) {
+                    double* dst = pPan + b1 * 256 + l;
+                    double* ub = urow + 16 * b1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dst[r * 64] = x1[r];
+                        st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, x1[r]);
                     }
                 }
             }
@@ -1383,6 +1439,39 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
             // also its latency, so one dependent chain per tile runs at the full rate of the pipe; the operands of the
             // next live slot are fetched from LDS while the MFMAs of the current one execute.  Tiles of block row
             // kb+1 (the next panel) are also staged in LDS.
+            // later diagonal tiles k > kb+1 live in LDS and are off the critical chain: worker k % NW updates them (at
+            // most two per worker); operands of both are fetched before the first MFMA
+            if (!(ablate & 8)) {
+                int d0 = (wi - (kb + 2)) % POTRF_NW;
+                if (d0 < 0) d0 += POTRF_NW;
+                const int k0 = kb + 2 + d0;
+                if (k0 < nb) {
+                    const bool two = k0 + POTRF_NW < nb;
+                    const int k1 = two ? k0 + POTRF_NW : k0;
+                    const double* qp0 = pPan + k0 * 256 + l;
+                    const double* qp1 = pPan + k1 * 256 + l;
+                    double* g0 = &sDg[0][0][0] + z + k0 * 256 + l;
+                    double* g1 = &sDg[0][0][0] + z + k1 * 256 + l;
+                    double qa[4], qb[4];
+                    d4 t0, t1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qa[r] = qp0[r * 64]; t0[r] = g0[r * 64]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qb[r] = qp1[r * 64]; t1[r] = g1[r * 64]; }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) t0 = mfma_f64(-qa[s4], qa[s4], t0);
+                    if (two) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) t1 = mfma_f64(-qb[s4], qb[s4], t1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g0[r * 64] = t0[r];
+                    if (two) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g1[r * 64] = t1[r];
+                    }
+                }
+            }
             if (!(ablate & 2)) {
                 double q[2][8];
                 auto fetch = [&](double (&dst)[8], int tb) {
@@ -1395,9 +1484,10 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                 for (int s = 0; s < NSLOT; ++s) {
                     if (s >= s_hi && tab[s] >= 0) {
                         if (s == s_hi) fetch(q[s & 1], tab[s]);
-                        if (s + 1 < NSLOT) {
-                            if (tab[(s + 1 < NSLOT) ? s + 1 : s] >= 0) fetch(q[(s + 1) & 1], tab[(s + 1 < NSLOT) ? s + 1 : s]);
-                        }
+                        // the fetch of the next slot is unconditional (an empty slot reads tile 0): the wait in front of
+                        // the MFMAs can then count it, and leaves it in flight
+                        if (s + 1 < NSLOT) { const int tn = tab[(s + 1 < NSLOT) ? s + 1 : s]; fetch(q[(s + 1) & 1], tn >= 0 ? tn : 0); }
+                        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the fetch below the MFMAs)
                         d4 x = acc[s];
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(-q[s & 1][s4], q[s & 1][4 + s4], x);
@@ -1408,21 +1498,6 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
                             for (int r = 0; r < 4; ++r) st[r * 64] = x[r];
                         }
                     }
-                }
-            }
-            // later diagonal tiles k > kb+1 live in LDS and are off the critical chain: worker k % NW updates them
-            if (!(ablate & 8)) {
-                for (int k = kb + 2; k < nb; ++k) {
-                    if ((k % POTRF_NW) != wi) continue;
-                    const double* q = pPan + k * 256 + l;
-                    double* g = &sDg[0][0][0] + z + k * 256 + l;
-                    d4 t;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] = g[r * 64];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) { const double qv = q[s4 * 64]; t = mfma_f64(-qv, qv, t); }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) g[r * 64] = t[r];
                 }
             }
         }
@@ -1442,12 +1517,12 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
                                                    double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                    int* __restrict__ info, unsigned long long* __restrict__ stamps = nullptr,
                                                    size_t strideX = 0, size_t strideR = 0, size_t strideD = 0,
-                                                   int from_lower = 0, int ablate = 0) {
+                                                   int from_lower = 0, int ablate = 0, int zero_lower = 1) {
     // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
     // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
     potrf_reg_body<NSLOT, false>(X + (size_t)blockIdx.x * strideX, ldx, n, tol_rel, R + (size_t)blockIdx.x * strideR, ldr,
                                  Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr, stamps,
-                                 gridDim.x == 1 ? 1 : 0);
+                                 gridDim.x == 1 ? 1 : 0, zero_lower);
 }
 
 // generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j] [+ Cin(i,j)]; tiles with
@@ -1671,7 +1746,7 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
                                                      const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
                                                      const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz) {
     if (blockIdx.x == 0) {
-        potrf_reg_body<NSLOT, true>(X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag, nullptr, 1);
+        potrf_reg_body<NSLOT, true>(X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag, nullptr, 1, 0);   // lower tiles: kept zero by the handle
         return;
     }
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;

@@ -131,6 +131,20 @@ __global__ void k_pair(double* out, int iters, int partner, int kind, unsigned l
     if (threadIdx.x == 0) stamps[0] = t1 - t0;
     if (threadIdx.x == 64 * partner) stamps[1] = t1 - t0;
 }
+// how does the FP64 MFMA rate scale with the number of wavefronts of one workgroup (one CU) issuing them?
+__global__ void k_mfma_scale(double* out, int iters, int nactive, unsigned long long* stamps) {
+    const int wave = threadIdx.x >> 6;
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    double y = 0.999999, x = 1.0 + threadIdx.x * 1e-9;
+    d4 c = {x, x, x, x};
+    __syncthreads();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (wave < nactive)
+        for (int i = 0; i < iters; ++i) c = __builtin_amdgcn_mfma_f64_16x16x4f64(y, 1e-3, c, 0, 0, 0);
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[threadIdx.x] = c[0] + c[1];
+    if ((threadIdx.x & 63) == 0) stamps[wave] = t1 - t0;
+}
 int main() {
     run_dpp_check();
     double* d; unsigned long long* st;
@@ -152,6 +166,15 @@ int main() {
             printf("grid %3d  %-26s  %8.1f ns/iter  %7.1f cyc/iter  clock %.0f MHz  (event %.3f ms)\n", grid, names[mode],
                    h[1] * 10.0 / iters, (double)h[0] / iters, clk, ms);
         }
+    }
+    for (int na : {1, 2, 4, 6, 8}) {
+        const int iters = 20000;
+        hipLaunchKernelGGL(k_mfma_scale, dim3(1), dim3(512), 0, 0, d, iters, na, st);
+        hipDeviceSynchronize();
+        unsigned long long h[8]; hipMemcpy(h, st, 64, hipMemcpyDeviceToHost);
+        printf("mfma f64 chains on %d waves of one workgroup: cycles per MFMA per wave:", na);
+        for (int w = 0; w < na; ++w) printf(" %.1f", (double)h[w] / iters);
+        printf("\n");
     }
     for (int kind = 0; kind < 2; ++kind)
         for (int partner : {9, 4, 1}) {   // 9 = nobody (block has 8 waves)
