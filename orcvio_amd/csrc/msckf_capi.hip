@@ -87,7 +87,7 @@ struct orcvio_msckf_handle {
     bool objects_mode = false;
     int obj_dof = 0, obj_rows = 0, obj_count = 0;
     double *d_T3 = nullptr, *d_Xobs = nullptr, *d_S = nullptr;
-    int *d_clone_ptr = nullptr, *d_clone_obs = nullptr;   // d_clone_ptr: [0..N] chunk_of_clone, then row chunk_ptr; d_clone_obs: obs_pos
+    int *d_clone_ptr = nullptr, *d_clone_obs = nullptr;   // d_clone_ptr: [0..N] first sparse row of every clone; d_clone_obs: obs_pos
     std::vector<int> h_clone_ptr, h_clone_obs;
     int s_chunks = 0;
     bool materialize = false;
@@ -431,8 +431,8 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
         std::memcpy(st + h->so_meta + ((char*)h->d_obs_ptr - h->d_meta), tr->obs_ptr, sizeof(int) * (F + 1));
         std::memcpy(st + h->so_meta + ((char*)h->d_row_ptr - h->d_meta), h->h_row_ptr.data(), sizeof(int) * (F + 1));
     }
-    // observations grouped by clone: position of every observation in the clone-sorted order, and row chunks
-    // (<= 256 rows, never across clones) for the sparse part of the compression
+    // observations grouped by clone: position of every observation in the clone-sorted order, and the row range of
+    // every clone (two rows per observation) for the sparse part of the compression
     {
         std::vector<int> cnt(N + 1, 0);
         for (int o = 0; o < nobs; ++o) cnt[tr->obs_clone[o] + 1]++;
@@ -440,18 +440,9 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
         int* clone_obs = reinterpret_cast<int*>(st + h->so_cobs);
         std::vector<int> fill(cnt.begin(), cnt.end() - 1);
         for (int o = 0; o < nobs; ++o) clone_obs[o] = fill[tr->obs_clone[o]]++;
-        // layout of the clone table: [0..N] chunk_of_clone, then chunk_ptr[0..nchunks] (row offsets)
-        int* cptr = reinterpret_cast<int*>(st + h->so_meta + ((char*)h->d_clone_ptr - h->d_meta));
-        int nch = 0;
-        cptr[0] = 0;
-        int* chunk_ptr = cptr + N + 1;
-        chunk_ptr[0] = 0;
-        for (int i = 0; i < N; ++i) {
-            const int r0 = 2 * cnt[i], r1 = 2 * cnt[i + 1];
-            for (int r = r0; r < r1; r += 256) chunk_ptr[++nch] = r + 256 < r1 ? r + 256 : r1;
-            cptr[i + 1] = nch;
-        }
-        h->s_chunks = nch;
+        int* cptr = reinterpret_cast<int*>(st + h->so_meta + ((char*)h->d_clone_ptr - h->d_meta));   // [0..N] row offsets
+        for (int i = 0; i <= N; ++i) cptr[i] = 2 * cnt[i];
+        h->s_chunks = N;
     }
     HIPCHK(hipMemcpyAsync(h->d_meta, st + h->so_meta, h->meta_bytes, hipMemcpyHostToDevice, s));
     if (P) {
@@ -482,9 +473,9 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     }
     // (no synchronisation: the staging buffer is rewritten only by the next upload, which the caller issues after the
     // download / sync of this update; the kernels are ordered behind the copies on the same stream)
-    // Gram chunking: enough (chunk, tile) wavefronts to fill 256 CUs
-    const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
-    int chunks = (640 + ntiles - 1) / ntiles;   // >= 640 (chunk, tile) wavefronts; few chunks keep the partials small
+    // Gram chunking: a workgroup of 16 wavefronts per (tile, chunk); up to 1024 rows per chunk keeps every wavefront
+    // at one batch of loads (64 rows) and the number of partial Grams small
+    int chunks = (3 * F + 1023) / 1024;
     if (chunks > h->gram_chunks_cap) chunks = h->gram_chunks_cap;
     if (chunks < 1) chunks = 1;
     const int t3rows = 3 * F;   // the dense part of the compression: three rows per track
@@ -537,18 +528,19 @@ static int launch_gram(orcvio_msckf_handle* h, hipStream_t s) {
         HIPCHK(hipMemsetAsync(h->d_Gpart, 0, sizeof(double) * (size_t)h->NAP * h->NAP, s));
         return ORCVIO_OK;
     }
-    // sparse rows: one 16x16 tile per row chunk (wave 0 of each workgroup), chunks never span two clones
-    dim3 grid((ntiles + 3) / 4, h->chunks + h->s_chunks), block(256);
+    // grid.y < chunks: T3 tiles; grid.y == chunks: one workgroup per clone for the sparse rows
+    dim3 grid(ntiles > h->N ? ntiles : h->N, h->chunks + 1), block(1024);
     hipLaunchKernelGGL(k_gram_pair, grid, block, 0, s, h->d_T3, 3 * h->F, h->NAP, h->rows_per_chunk, h->chunks, h->d_Gpart, h->d_Xobs,
-                       2 * h->nobs, h->d_S, (const int*)(h->d_clone_ptr + h->N + 1));
+                       h->d_S, (const int*)h->d_clone_ptr, h->N);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
 
 static int launch_assemble(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
     const int total = h->NAP * h->NAP;
-    hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->d_clone_ptr, h->F > 0 ? h->N : 0,
-                       h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->chunks, (size_t)total, dst);
+    hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->F > 0 ? h->N : 0,
+                       h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->chunks, (size_t)total, dst,
+                       getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }

@@ -709,9 +709,12 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
 // partial Grams of T3 (lower tiles valid).  Column map of a sparse-row entry e: 0..6 -> a = e (ext, td),
 // 7..12 -> clone block, 13 -> a = NA (right-hand side).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ Sp, const int* __restrict__ chunk_of_clone, int N,
+__global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ Sp, int N,
                                                     int cb0, int NA, int NAP, const double* __restrict__ parts, int nparts,
-                                                    size_t part_stride, double* __restrict__ dst) {
+                                                    size_t part_stride, double* __restrict__ dst, int dbg = 0) {
+    // Sp: one 16x16 tile per clone (k_gram_pair).  An entry of a clone block or of the arrow reads one tile; the
+    // shared (ext|r) x (ext|r) entries sum all N -- sixteen loads in flight (clamped index + select: no serial tail),
+    // fixed summation order.
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= NAP * NAP) return;
     const int i = idx / NAP, j = idx - i * NAP;
@@ -719,34 +722,39 @@ __global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ S
     if (i < 7) ei = i; else if (i == NA) ei = 13; else if (i >= cb0 && i < NA) { ci = (i - cb0) / 6; ei = 7 + (i - cb0) - 6 * ci; }
     if (j < 7) ej = j; else if (j == NA) ej = 13; else if (j >= cb0 && j < NA) { cj = (j - cb0) / 6; ej = 7 + (j - cb0) - 6 * cj; }
     double s = 0.0;
-    if (ei >= 0 && ej >= 0) {
-        // the 16x16 tiles hold both triangles (diagonal tile of k_gram): read [max][min]
+    if (ei >= 0 && ej >= 0 && N > 0 && !(dbg & 1)) {
+        // the 16x16 tiles hold both triangles: read [max][min]
         const int e = (ei >= ej) ? ei * 16 + ej : ej * 16 + ei;
         int c0 = 0, c1 = 0;
-        if (ci < 0 && cj < 0) { c0 = 0; c1 = chunk_of_clone[N]; }
-        else if (ci >= 0 && cj >= 0) { if (ci == cj) { c0 = chunk_of_clone[ci]; c1 = chunk_of_clone[ci + 1]; } }
-        else { const int c = ci >= 0 ? ci : cj; c0 = chunk_of_clone[c]; c1 = chunk_of_clone[c + 1]; }
-        // fixed summation order (deterministic); eight loads in flight: the shared (ext|r) entries sum every chunk
-        double sa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int c = c0;
-        for (; c + 8 <= c1; c += 8) {
+        if (ci < 0 && cj < 0) { c0 = 0; c1 = N; }
+        else if (ci >= 0 && cj >= 0) { if (ci == cj) { c0 = ci; c1 = ci + 1; } }
+        else { c0 = ci >= 0 ? ci : cj; c1 = c0 + 1; }
+        if (c1 - c0 == 1) {
+            s = Sp[(size_t)c0 * 256 + e];
+        } else if (c1 > c0) {
+            double sa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = c0; c < c1; c += 16) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) sa[u] += Sp[(size_t)(c + u) * 256 + e];
+                for (int u = 0; u < 16; ++u) {
+                    const int cu = c + u;
+                    const double v = Sp[(size_t)(cu < c1 ? cu : c1 - 1) * 256 + e];
+                    sa[u & 7] += cu < c1 ? v : 0.0;
+                }
+            }
+            s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
         }
-        for (; c < c1; ++c) sa[0] += Sp[(size_t)c * 256 + e];
-        s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
     }
     const int src = ((i >> 4) >= (j >> 4)) ? idx : j * NAP + i;
-    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
-    int c = 0;
-    for (; c + 4 <= nparts; c += 4) {
-        g0 += parts[(size_t)c * part_stride + src];
-        g1 += parts[(size_t)(c + 1) * part_stride + src];
-        g2 += parts[(size_t)(c + 2) * part_stride + src];
-        g3 += parts[(size_t)(c + 3) * part_stride + src];
+    double g[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < ((dbg & 2) ? 0 : nparts); c += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cu = c + u;
+            const double v = parts[(size_t)(cu < nparts ? cu : nparts - 1) * part_stride + src];
+            g[u] += cu < nparts ? v : 0.0;
+        }
     }
-    for (; c < nparts; ++c) g0 += parts[(size_t)c * part_stride + src];
-    dst[idx] = s - ((g0 + g1) + (g2 + g3));
+    dst[idx] = s - ((g[0] + g[1]) + (g[2] + g[3]));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -808,13 +816,68 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int 
                                               double* __restrict__ Gpart, const int* __restrict__ chunk_ptr = nullptr) {
     gram_body(X, m, NAP, rows_per_chunk, Gpart, chunk_ptr, blockIdx.x, blockIdx.y);
 }
-// both Grams of the compression in one launch: blockIdx.y < chunks -> dense rows T3 (width NAP, uniform chunks),
-// the rest -> the sparse rows Xobs (width 16, one tile, clone-aligned ragged chunks)
-__global__ __launch_bounds__(256) void k_gram_pair(const double* __restrict__ T3, int m3, int NAP, int rows_per_chunk, int chunks,
-                                                   double* __restrict__ Gpart, const double* __restrict__ Xobs, int mx,
-                                                   double* __restrict__ S, const int* __restrict__ chunk_ptr) {
-    if ((int)blockIdx.y < chunks) gram_body(T3, m3, NAP, rows_per_chunk, Gpart, nullptr, blockIdx.x, blockIdx.y);
-    else if (blockIdx.x == 0) gram_body(Xobs, mx, 16, 0, S, chunk_ptr, 0, (int)blockIdx.y - chunks);
+// Both Grams of the compression in one launch, 1024-thread workgroups: the sixteen wavefronts of a workgroup split
+// the rows of ONE output tile between them (one batch of loads in flight per wavefront: a single memory round
+// trip), the sixteen partial tiles are summed through LDS in a fixed order.
+//   blockIdx.y <  chunks : dense rows T3 (width NAP), lower tile blockIdx.x, row chunk blockIdx.y  -> Gpart[chunk]
+//   blockIdx.y == chunks : sparse rows Xobs (width 16, grouped by clone), clone blockIdx.x          -> S[clone]
+__device__ __forceinline__ void gram16_body(const double* __restrict__ X, int ld, int r0, int r1, int bi, int bj,
+                                            double* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) double sT[16][256];
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int kk = l >> 4, cc = l & 15;
+    int rw = (r1 - r0 + 15) / 16;
+    rw = (rw + 3) & ~3;   // rows per wavefront, whole k-steps
+    const int k0 = r0 + wave * rw;
+    const int k1 = (k0 + rw < r1) ? k0 + rw : r1;
+    const double* pa = X + 16 * bi + cc;
+    const double* pb = X + 16 * bj + cc;
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    constexpr int GB = 16;   // k-steps (of 4 rows) whose operands are in flight together
+    for (int k = k0; k < k1; k += 4 * GB) {
+        double a[GB], b[GB];
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {   // clamped address + select (no branch, no vmcnt(0) per load)
+            const int rq = k + 4 * q + kk;
+            const int rc = rq < k1 ? rq : k1 - 1;
+            const double av = pa[(size_t)rc * ld], bv = pb[(size_t)rc * ld];
+            a[q] = rq < k1 ? av : 0.0;
+            b[q] = rq < k1 ? bv : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < GB; q += 2) {
+            acc0 = mfma_f64(a[q], b[q], acc0);
+            acc1 = mfma_f64(a[q + 1], b[q + 1], acc1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sT[wave][r * 64 + l] = acc0[r] + acc1[r];
+    __syncthreads();
+    if (tid < 256) {
+        double t[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t[w] = sT[w][tid];
+        const double v = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                         (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+        const int r = tid >> 6, lk = (tid & 63) >> 4, lc = tid & 15;   // accumulator element (row lk + 4 r, column lc)
+        out[(size_t)(16 * bi + lk + 4 * r) * ldo + 16 * bj + lc] = v;
+    }
+}
+__global__ __launch_bounds__(1024) void k_gram_pair(const double* __restrict__ T3, int m3, int NAP, int rows_per_chunk, int chunks,
+                                                    double* __restrict__ Gpart, const double* __restrict__ Xobs,
+                                                    double* __restrict__ S, const int* __restrict__ clone_rows, int N) {
+    const int nb = NAP >> 4;
+    if ((int)blockIdx.y < chunks) {
+        if ((int)blockIdx.x >= nb * (nb + 1) / 2) return;
+        int bi, bj;
+        tile_from_linear(blockIdx.x, bi, bj);
+        const int r0 = blockIdx.y * rows_per_chunk;
+        const int r1 = (r0 + rows_per_chunk < m3) ? r0 + rows_per_chunk : m3;
+        gram16_body(T3, NAP, r0, r1 > r0 ? r1 : r0, bi, bj, Gpart + (size_t)blockIdx.y * NAP * NAP, NAP);
+    } else {
+        if ((int)blockIdx.x >= N) return;
+        gram16_body(Xobs, 16, clone_rows[blockIdx.x], clone_rows[blockIdx.x + 1], 0, 0, S + (size_t)blockIdx.x * 256, 16);
+    }
 }
 
 // Sums `nparts` blocks into dst (full symmetric result); used for the chunk partials of one
