@@ -792,6 +792,7 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
 }
 
 static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
+    // (the other way round -- prior on the origin stream, feature branch forked -- measured 15 us slower)
     int rc = launch_prior_fork(h, s);
     if (rc == ORCVIO_OK) rc = launch_feature(h, s);
     if (rc == ORCVIO_OK) rc = launch_gram(h, s);
