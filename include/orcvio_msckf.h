@@ -136,7 +136,10 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * update itself never needs them; tests and callers that want H' switch it on. */
 /* ORCVIO_OPT_FUSED_SOLVE (default 1): factor M and solve for Z in one launch (solver workgroups trail the
  * factorisation block step by block step); 0 = two launches (k_potrf_reg, k_trsm_lds).  Same arithmetic. */
-enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2 };
+/* ORCVIO_OPT_FUSED_FRONT (default 1): the Cholesky of the prior runs as workgroup 0 of the feature launch (k_front)
+ * whenever the whole front end is co-resident (n <= 224, 1 + ceil(F/2) workgroups <= compute units); 0 = always fork
+ * it to the handle's side stream around k_feature.  Same kernels' bodies, same arithmetic. */
+enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* Feature update: replaces the loop + compression + update of

@@ -200,6 +200,12 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_set_option')
 
+    def set_fused_front(self, on: bool):
+        """ORCVIO_OPT_FUSED_FRONT: chol(P) as workgroup 0 of the feature launch (default) or forked to a side stream."""
+        rc = self.lib.orcvio_msckf_set_option(self.h, 3, int(bool(on)))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_set_option')
+
     def close(self):
         if self.h:
             self.lib.orcvio_msckf_destroy(self.h)

@@ -75,6 +75,8 @@ struct orcvio_msckf_handle {
     double *d_poses = nullptr, *d_pw = nullptr, *d_obs_z = nullptr, *d_obs_zvel = nullptr, *d_P = nullptr;
     int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_info = nullptr;
     double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_A = nullptr;
+    int front_fused = 1;                // ORCVIO_OPT_FUSED_FRONT
+    int n_cus = 0;                      // compute units of the device
     int clean_NP = -1, clean_path = -1;   // layout for which the strictly-lower tiles of d_RP / d_RM are known to be zero
     double *d_RP = nullptr, *d_DinvP = nullptr, *d_U = nullptr, *d_M = nullptr, *d_RM = nullptr, *d_DinvM = nullptr;
     double *d_Z = nullptr, *d_Pout = nullptr, *d_dx = nullptr;
@@ -221,6 +223,7 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
     }
     auto* h = new orcvio_msckf_handle();
     h->device = device;
+    h->n_cus = prop.multiProcessorCount;
     h->maxN = max_clones;
     h->maxF = max_features;
     h->maxObs = max_observations;
@@ -352,6 +355,11 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
     }
     if (option == ORCVIO_OPT_FUSED_SOLVE) {
         h->fused_solve = value != 0;
+        h->graph_valid = false;
+        return ORCVIO_OK;
+    }
+    if (option == ORCVIO_OPT_FUSED_FRONT) {
+        h->front_fused = value != 0;
         h->graph_valid = false;
         return ORCVIO_OK;
     }
@@ -492,8 +500,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
 }
 
 // ---- launches --------------------------------------------------------------------------------
-static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
-    if (h->F == 0) return ORCVIO_OK;
+static FeatArgs feature_args(const orcvio_msckf_handle* h) {
     FeatArgs a;
     a.poses = h->d_poses; a.p_w = h->d_pw; a.obs_ptr = h->d_obs_ptr; a.obs_clone = h->d_obs_clone;
     a.obs_z = h->d_obs_z; a.obs_zvel = h->d_obs_zvel; a.P = h->d_P; a.row_ptr = h->d_row_ptr; a.chi2 = h->d_chi2;
@@ -504,6 +511,12 @@ static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
     a.use_larvio = h->flags.use_larvio; a.use_left = h->flags.use_left_perturbation; a.if_fej = h->flags.if_fej;
     a.estimate_td = h->flags.estimate_td;
     a.ablate = h->feat_ablate;
+    return a;
+}
+
+static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
+    if (h->F == 0) return ORCVIO_OK;
+    const FeatArgs a = feature_args(h);
     const size_t lds = feat_lds_bytes(h->Mmax, h->NAP, h->N);
     const int npass = (h->NAP + 63) / 64;
     dim3 grid(h->F), block(256);
@@ -517,6 +530,48 @@ static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
         case 7: hipLaunchKernelGGL(k_feature<7>, grid, block, lds, s, a); break;
         default: g_last_error = "window too wide for k_feature"; return ORCVIO_ERR_CAPACITY;
     }
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+// The Cholesky of the prior and the feature tracks in one launch (k_front) when everything is co-resident: register
+// path (n <= 224), 1 + ceil(F/2) workgroups on the device's CUs, two feature teams + the factorisation's LDS within one
+// CU's 160 KB.  Otherwise the caller forks the factorisation to the side stream and launches k_feature.
+static bool front_fused_active(const orcvio_msckf_handle* h) {
+    if (!h->front_fused || !h->reg_path || h->F < 1) return false;
+    if (1 + (h->F + 1) / 2 > h->n_cus) return false;
+    const size_t team = feat_lds_bytes(h->Mmax, h->NAP, h->N);
+    const size_t lds = 2 * team > sizeof(double) * POTRF_LDS_DOUBLES ? 2 * team : sizeof(double) * POTRF_LDS_DOUBLES;
+    return lds <= (size_t)160 * 1024 && (h->NAP + 63) / 64 <= 4;
+}
+
+static int launch_front(orcvio_msckf_handle* h, hipStream_t s) {
+    const FeatArgs a = feature_args(h);
+    const double eps = 2.220446049250313e-16;
+    FrontPotrfArgs q{h->d_P, h->n, h->n, 8.0 * eps, h->d_RP, h->NP, h->d_DinvP, h->d_info};
+    const size_t team = feat_lds_bytes(h->Mmax, h->NAP, h->N);
+    const size_t lds = 2 * team > sizeof(double) * POTRF_LDS_DOUBLES ? 2 * team : sizeof(double) * POTRF_LDS_DOUBLES;
+    const int team_doubles = (int)(team / sizeof(double));
+    dim3 grid(1 + (h->F + 1) / 2), block(512);
+    // the window width fixes both template arguments: NPASS = ceil(NAP/64) column passes, and enough register slots
+    // for the widest matrix of that class (n <= 79 / 143 / 207 / 224)
+#define LAUNCH_FRONT(NPS, NSL)                                                                                                  \
+    do {                                                                                                                        \
+        static size_t attr_set = 0;                                                                                             \
+        if (lds > attr_set) {                                                                                                   \
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<NPS, NSL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024))); \
+            attr_set = (size_t)160 * 1024;                                                                                      \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((k_front<NPS, NSL>), grid, block, lds, s, a, q, team_doubles);                                       \
+    } while (0)
+    switch ((h->NAP + 63) / 64) {
+        case 1: LAUNCH_FRONT(1, 4); break;
+        case 2: LAUNCH_FRONT(2, 8); break;
+        case 3: LAUNCH_FRONT(3, 16); break;
+        case 4: LAUNCH_FRONT(4, 16); break;
+        default: g_last_error = "launch_front: window too wide"; return ORCVIO_ERR_CAPACITY;
+    }
+#undef LAUNCH_FRONT
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -701,7 +756,7 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
     mix(h->N); mix(h->F); mix(h->nobs); mix(h->Mmax); mix(h->chunks); mix(h->s_chunks); mix(h->rows_per_chunk);
     mix(h->flags.leg_dim); mix(h->flags.use_larvio); mix(h->flags.use_left_perturbation); mix(h->flags.if_fej);
-    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->feat_ablate);
+    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->front_fused); mix(h->feat_ablate);
     unsigned long long bits;
     double sg = h->flags.noise_feature;
     std::memcpy(&bits, &sg, 8); mix(bits);
@@ -793,6 +848,13 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
 
 static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
     // (the other way round -- prior on the origin stream, feature branch forked -- measured 15 us slower)
+    if (front_fused_active(h)) {   // one stream, no fork: the prior is factored by workgroup 0 of the feature launch
+        int rc = launch_front(h, s);
+        if (rc == ORCVIO_OK) rc = launch_gram(h, s);
+        if (rc == ORCVIO_OK) rc = launch_assemble(h, s, h->d_A);
+        for (int st = ST_FORM_U; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
+        return rc;
+    }
     int rc = launch_prior_fork(h, s);
     if (rc == ORCVIO_OK) rc = launch_feature(h, s);
     if (rc == ORCVIO_OK) rc = launch_gram(h, s);

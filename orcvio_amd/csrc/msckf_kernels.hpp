@@ -244,12 +244,13 @@ __host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
 //                    trailing tiles by MFMA on accumulator-layout operands), the four right-hand sides
 //                    [r | Q1] ride along as one more tile column, the projection is modified Gram-Schmidt.
 //   I     (all)      outputs: T3 (three dense rows), the un-projected sparse rows Xobs, optionally H'.
+// feature_body: track j on the 256 threads `tid` = 0..255 of one four-wavefront team with its own LDS block; the
+// team is a whole workgroup (k_feature) or half of one (k_front).  Its four workgroup barriers are unconditional for a
+// live track, so two teams of one workgroup stay in step.
 template <int NPASS>
-__global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
+__device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, const int tid, double* __restrict__ smem) {
     constexpr int NPD = (NPASS + 2) / 3;   // passes of the 192 threads of waves 1..3 over the NAP columns
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int j = blockIdx.x;
-    const int tid = threadIdx.x, wave = tid >> 6, t = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
     const int lo = p.obs_ptr[j];
     const int M = p.obs_ptr[j + 1] - lo;
     if (M < 2 || (p.skip && p.skip[j])) {   // whole workgroup
@@ -697,6 +698,12 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
         if (ok && c < 14) v = (c < 7) ? sJe[row * 7 + c] : ((c < 13) ? sJx[row * 6 + (c - 7)] : sR[row]);
         p.Xobs[(size_t)32 * p.obs_pos[lo + (row >> 1)] + 16 * (row & 1) + c] = v;
     }
+}
+
+template <int NPASS>
+__global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    feature_body<NPASS>(p, blockIdx.x, threadIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1171,7 +1178,8 @@ __device__ __forceinline__ void st_tile(double* ubase, unsigned lane_bytes, doub
 // inv(L11) are complete in memory (monotonic, set by one lane behind a workgroup barrier that every storing wave
 // reaches after draining its stores).
 template <int NSLOT, bool PUB>
-__device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int ldx, int n, double tol_rel,
+#define POTRF_LDS_DOUBLES (816 + 3 * 3584 + 8)
+__device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const double* __restrict__ X, int ldx, int n, double tol_rel,
                                                double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                int* __restrict__ info, int from_lower, int ablate, int* __restrict__ flag,
                                                unsigned long long* __restrict__ stamps = nullptr, int info_store = 0,
@@ -1185,12 +1193,14 @@ __device__ __forceinline__ void potrf_reg_body(const double* __restrict__ X, int
 #define POTRF_STAMP(w, idx) do { if (stamps && l == 0 && (w) < 3) stamps[(w) * 64 + (idx)] = clock64(); } while (0)
     // rows of 17 doubles: the row view is read one ROW per lane and inv(L11) one COLUMN block per lane; a stride of 16
     // doubles would put every lane of a 16-lane row on the same two banks
-    __shared__ __attribute__((aligned(16))) double sD[16][17];       // diagonal tile being factored (row view)
-    __shared__ __attribute__((aligned(16))) double sDi[2][16][17];   // inv(L11) of block step kb in sDi[kb & 1]
-    __shared__ int sCnt[16];                                        // waves that have published their panel tiles of step kb
-    __shared__ __attribute__((aligned(16))) double sPan[14][4][64];  // published panel tiles, accumulator layout
-    __shared__ __attribute__((aligned(16))) double sDg[14][4][64];   // the diagonal tiles (owned by wave 0)
-    __shared__ __attribute__((aligned(16))) double sStage[14][4][64];   // block row kb of the trailing matrix, up to date
+    // LDS (POTRF_LDS_DOUBLES doubles at `lds`: the caller's static buffer, or dynamic LDS when the factorisation
+    // shares a launch with other workgroups -- k_front):
+    double (*sD)[17] = reinterpret_cast<double (*)[17]>(lds);                         // diagonal tile being factored (row view)
+    double (*sDi)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + 272);          // inv(L11) of block step kb in sDi[kb & 1]
+    double (*sPan)[4][64] = reinterpret_cast<double (*)[4][64]>(lds + 816);           // published panel tiles, accumulator layout
+    double (*sDg)[4][64] = reinterpret_cast<double (*)[4][64]>(lds + 816 + 3584);     // the diagonal tiles (owned by wave 0)
+    double (*sStage)[4][64] = reinterpret_cast<double (*)[4][64]>(lds + 816 + 7168);  // block row kb of the trailing matrix, up to date
+    int* sCnt = reinterpret_cast<int*>(lds + 816 + 10752);                            // [16] waves that have published their panel tiles of step kb
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nb = (n + 15) >> 4;
@@ -1583,9 +1593,35 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
                                                    int from_lower = 0, int ablate = 0, int zero_lower = 1) {
     // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
     // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
-    potrf_reg_body<NSLOT, false>(X + (size_t)blockIdx.x * strideX, ldx, n, tol_rel, R + (size_t)blockIdx.x * strideR, ldr,
+    __shared__ __attribute__((aligned(16))) double sPotrf[POTRF_LDS_DOUBLES];
+    potrf_reg_body<NSLOT, false>(sPotrf, X + (size_t)blockIdx.x * strideX, ldx, n, tol_rel, R + (size_t)blockIdx.x * strideR, ldr,
                                  Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr, stamps,
                                  gridDim.x == 1 ? 1 : 0, zero_lower);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_front: the two independent front ends of the update in ONE launch -- workgroup 0 factors the prior
+// (potrf_reg_body, depends on P only), every other workgroup runs two feature tracks (feature_body, one
+// four-wavefront team each).  Replaces a cross-stream fork / join around k_potrf_reg (8 + 10 us of dependency
+// latency in the replayed graph) by plain co-residency: 1 + ceil(F/2) workgroups of 512 threads, all resident
+// at once for F <= 510.  The second team takes its roles two wavefronts on, so that the two chain-like
+// wavefronts of a workgroup (QR + gate) sit on different SIMDs.
+// ---------------------------------------------------------------------------------------
+struct FrontPotrfArgs {
+    const double* X; int ldx; int n; double tol_rel; double* R; int ldr; double* Dinv; int* info;
+};
+template <int NPASS, int NSLOT>
+__global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int team_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (blockIdx.x == 0) {
+        potrf_reg_body<NSLOT, false>(smem, q.X, q.ldx, q.n, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, 0, 0, nullptr, nullptr, 1, 0);
+        return;
+    }
+    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    const int j = 2 * ((int)blockIdx.x - 1) + team;
+    if (j >= p.F) return;   // (an odd track count: the last workgroup has one team)
+    const int local = threadIdx.x & 255;
+    feature_body<NPASS>(p, j, team ? ((local + 128) & 255) : local, smem + (size_t)team * team_doubles);
 }
 
 // generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j] [+ Cin(i,j)]; tiles with
@@ -1809,7 +1845,8 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
                                                      const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
                                                      const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz) {
     if (blockIdx.x == 0) {
-        potrf_reg_body<NSLOT, true>(X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag, nullptr, 1, 0);   // lower tiles: kept zero by the handle
+        __shared__ __attribute__((aligned(16))) double sPotrf[POTRF_LDS_DOUBLES];
+        potrf_reg_body<NSLOT, true>(sPotrf, X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag, nullptr, 1, 0);   // lower tiles: kept zero by the handle
         return;
     }
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
