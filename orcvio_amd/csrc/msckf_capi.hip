@@ -76,6 +76,7 @@ struct orcvio_msckf_handle {
     int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_info = nullptr;
     double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_A = nullptr;
     int front_fused = 1;                // ORCVIO_OPT_FUSED_FRONT
+    int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     int n_cus = 0;                      // compute units of the device
     int clean_NP = -1, clean_path = -1;   // layout for which the strictly-lower tiles of d_RP / d_RM are known to be zero
     double *d_RP = nullptr, *d_DinvP = nullptr, *d_U = nullptr, *d_M = nullptr, *d_RM = nullptr, *d_DinvM = nullptr;
@@ -187,7 +188,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_Pout, h->d_La, h->d_DinvA,
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_obs,
-                    h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost};
+                    h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -315,6 +316,8 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_KG, sizeof(double) * np2));
         HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 64));   // (inside the outputs arena)
         HIPCHK(hipMemset(h->d_obs_zvel, 0, sizeof(double) * 2 * max_observations));
+        HIPCHK(hipMalloc(&h->d_sync, 256));
+        HIPCHK(hipMemset(h->d_sync, 0, 256));
         HIPCHK(hipMemset(h->d_RP, 0, sizeof(double) * np2));   // strictly-lower tiles of the upper factors stay 0
         HIPCHK(hipMemset(h->d_RM, 0, sizeof(double) * np2));
         // opt in to large dynamic LDS for the feature kernel instantiations
@@ -545,24 +548,34 @@ static bool front_fused_active(const orcvio_msckf_handle* h) {
     return lds <= (size_t)160 * 1024 && (h->NAP + 63) / 64 <= 4;
 }
 
-static int launch_front(orcvio_msckf_handle* h, hipStream_t s) {
+// compress_dst != nullptr: the compression (Grams + assembly of A into compress_dst) runs inside the same launch
+static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_dst) {
     const FeatArgs a = feature_args(h);
     const double eps = 2.220446049250313e-16;
     FrontPotrfArgs q{h->d_P, h->n, h->n, 8.0 * eps, h->d_RP, h->NP, h->d_DinvP, h->d_info};
     const size_t team = feat_lds_bytes(h->Mmax, h->NAP, h->N);
     const size_t lds = 2 * team > sizeof(double) * POTRF_LDS_DOUBLES ? 2 * team : sizeof(double) * POTRF_LDS_DOUBLES;
     const int team_doubles = (int)(team / sizeof(double));
+    FrontGramArgs g{};
+    g.enabled = compress_dst != nullptr;
+    const int t3rows = 3 * h->F;
+    g.chunks = (t3rows + 639) / 640;   // eight wavefronts x 80 rows: one batch of loads each
+    if (g.chunks < 1) g.chunks = 1;
+    g.rows_per_chunk = round_up((t3rows + g.chunks - 1) / g.chunks, 4);
+    g.Gpart = h->d_Gpart; g.S = h->d_S; g.clone_rows = h->d_clone_ptr; g.counter = h->d_sync;
+    g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15;
+    if (g.enabled && g.chunks > h->gram_chunks_cap) { g_last_error = "launch_front: too many row chunks"; return ORCVIO_ERR_CAPACITY; }
     dim3 grid(1 + (h->F + 1) / 2), block(512);
     // the window width fixes both template arguments: NPASS = ceil(NAP/64) column passes, and enough register slots
     // for the widest matrix of that class (n <= 79 / 143 / 207 / 224)
 #define LAUNCH_FRONT(NPS, NSL)                                                                                                  \
     do {                                                                                                                        \
-        static size_t attr_set = 0;                                                                                             \
-        if (lds > attr_set) {                                                                                                   \
+        static bool attr_set = false;                                                                                           \
+        if (!attr_set) {                                                                                                        \
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front<NPS, NSL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024))); \
-            attr_set = (size_t)160 * 1024;                                                                                      \
+            attr_set = true;                                                                                                    \
         }                                                                                                                       \
-        hipLaunchKernelGGL((k_front<NPS, NSL>), grid, block, lds, s, a, q, team_doubles);                                       \
+        hipLaunchKernelGGL((k_front<NPS, NSL>), grid, block, lds, s, a, q, team_doubles, g);                                    \
     } while (0)
     switch ((h->NAP + 63) / 64) {
         case 1: LAUNCH_FRONT(1, 4); break;
@@ -849,9 +862,7 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
 static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
     // (the other way round -- prior on the origin stream, feature branch forked -- measured 15 us slower)
     if (front_fused_active(h)) {   // one stream, no fork: the prior is factored by workgroup 0 of the feature launch
-        int rc = launch_front(h, s);
-        if (rc == ORCVIO_OK) rc = launch_gram(h, s);
-        if (rc == ORCVIO_OK) rc = launch_assemble(h, s, h->d_A);
+        int rc = launch_front(h, s, h->d_A);   // ... and the compression behind the tracks, under the factorisation
         for (int st = ST_FORM_U; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
         return rc;
     }
@@ -1769,6 +1780,7 @@ int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst
         case 5: src = h->d_RM; bytes = np2; break;
         case 6: src = h->d_Z; bytes = (size_t)h->n * h->ldz * sizeof(double); break;
         case 8: src = h->d_U; bytes = np2; break;
+        case 9: src = h->d_sync; bytes = 256; break;   // k_front: counter + diagnostic time stamps
         case 7: {
             int32_t dims[8] = {h->n, h->NA, h->NAP, h->NP, h->m_tot, h->Mmax, h->ldz, h->reg_path ? 1 : 0};
             if ((size_t)max_bytes < sizeof(dims)) return ORCVIO_ERR_INVALID;

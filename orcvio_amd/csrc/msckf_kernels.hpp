@@ -30,6 +30,21 @@ namespace orcvio_amd {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Stores / loads of bytes that another workgroup of the SAME launch consumes (k_potrf_solve, k_front): agent-scope relaxed
+// atomics = global_store/load ... sc1 (write-through, L1-bypassing); MI355X_MICROARCH.md "inter-workgroup visibility".
+template <bool PUB>
+__device__ __forceinline__ void st_pub(double* p, double v) {
+    if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ double ld_pub(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool PUB>
+__device__ __forceinline__ double ld_sel(const double* p) {
+    if (PUB) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     // D(16x16) += A(16x4) * B(4x16).  lane l: a = A[l&15][l>>4], b = B[l>>4][l&15],
     // c[r] = C[(l>>4) + 4r][l&15]   (cdna_hip_programming.md section 3, f64 layout)
@@ -247,7 +262,7 @@ __host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
 // feature_body: track j on the 256 threads `tid` = 0..255 of one four-wavefront team with its own LDS block; the
 // team is a whole workgroup (k_feature) or half of one (k_front).  Its four workgroup barriers are unconditional for a
 // live track, so two teams of one workgroup stay in step.
-template <int NPASS>
+template <int NPASS, bool PAD_BARRIERS = false>
 __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, const int tid, double* __restrict__ smem) {
     constexpr int NPD = (NPASS + 2) / 3;   // passes of the 192 threads of waves 1..3 over the NAP columns
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
@@ -255,11 +270,14 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
     const int M = p.obs_ptr[j + 1] - lo;
     if (M < 2 || (p.skip && p.skip[j])) {   // whole workgroup
         if (tid == 0) { p.gamma[j] = NAN; p.accept[j] = 0; }
-        for (int e = tid; e < 3 * p.NAP; e += 256) p.T3[(size_t)3 * j * p.NAP + e] = 0.0;
-        for (int e = tid; e < 32 * M; e += 256) p.Xobs[(size_t)32 * p.obs_pos[lo + (e >> 5)] + (e & 31)] = 0.0;
+        for (int e = tid; e < 3 * p.NAP; e += 256) st_pub<PAD_BARRIERS>(&p.T3[(size_t)3 * j * p.NAP + e], 0.0);
+        for (int e = tid; e < 32 * M; e += 256) st_pub<PAD_BARRIERS>(&p.Xobs[(size_t)32 * p.obs_pos[lo + (e >> 5)] + (e & 31)], 0.0);
         if (p.Hs) {   // a track dropped by the triangulation still owns rows of the materialised stack: zero them
             const size_t r0 = (size_t)p.row_ptr[j], r1 = (size_t)p.row_ptr[j + 1];
             for (size_t e = r0 * p.NAP + tid; e < r1 * p.NAP; e += 256) p.Hs[e] = 0.0;
+        }
+        if (PAD_BARRIERS) {   // the other team of the workgroup runs a live track: keep its four barriers company
+            __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
         }
         return;
     }
@@ -672,7 +690,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                     else if (kobs == (i >> 1)) jv = sJx[i * 6 + cc];
                     val = jv - (sV[i * 4 + 0] * yq[ps][0] + sV[i * 4 + 1] * yq[ps][1] + sV[i * 4 + 2] * yq[ps][2]);
                 }
-                p.T3[((size_t)3 * j + i) * NAP + a] = val;
+                st_pub<PAD_BARRIERS>(&p.T3[((size_t)3 * j + i) * NAP + a], val);   // (k_front: consumed inside the launch)
             }
             if (p.Hs) {
                 const size_t row0 = (size_t)p.row_ptr[j];
@@ -696,7 +714,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
         const int row = e >> 4, c = e & 15;
         double v = 0.0;
         if (ok && c < 14) v = (c < 7) ? sJe[row * 7 + c] : ((c < 13) ? sJx[row * 6 + (c - 7)] : sR[row]);
-        p.Xobs[(size_t)32 * p.obs_pos[lo + (row >> 1)] + 16 * (row & 1) + c] = v;
+        st_pub<PAD_BARRIERS>(&p.Xobs[(size_t)32 * p.obs_pos[lo + (row >> 1)] + 16 * (row & 1) + c], v);
     }
 }
 
@@ -716,14 +734,13 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
 // partial Grams of T3 (lower tiles valid).  Column map of a sparse-row entry e: 0..6 -> a = e (ext, td),
 // 7..12 -> clone block, 13 -> a = NA (right-hand side).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ Sp, int N,
-                                                    int cb0, int NA, int NAP, const double* __restrict__ parts, int nparts,
-                                                    size_t part_stride, double* __restrict__ dst, int dbg = 0) {
+template <bool PUB = false>
+__device__ __forceinline__ void assemble_entry(const int idx, const double* __restrict__ Sp, int N, int cb0, int NA, int NAP,
+                                               const double* __restrict__ parts, int nparts, size_t part_stride,
+                                               double* __restrict__ dst, int dbg) {
     // Sp: one 16x16 tile per clone (k_gram_pair).  An entry of a clone block or of the arrow reads one tile; the
     // shared (ext|r) x (ext|r) entries sum all N -- sixteen loads in flight (clamped index + select: no serial tail),
     // fixed summation order.
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= NAP * NAP) return;
     const int i = idx / NAP, j = idx - i * NAP;
     int ei = -1, ci = -1, ej = -1, cj = -1;
     if (i < 7) ei = i; else if (i == NA) ei = 13; else if (i >= cb0 && i < NA) { ci = (i - cb0) / 6; ei = 7 + (i - cb0) - 6 * ci; }
@@ -737,14 +754,14 @@ __global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ S
         else if (ci >= 0 && cj >= 0) { if (ci == cj) { c0 = ci; c1 = ci + 1; } }
         else { c0 = ci >= 0 ? ci : cj; c1 = c0 + 1; }
         if (c1 - c0 == 1) {
-            s = Sp[(size_t)c0 * 256 + e];
+            s = ld_sel<PUB>(Sp + (size_t)c0 * 256 + e);
         } else if (c1 > c0) {
             double sa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int c = c0; c < c1; c += 16) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int cu = c + u;
-                    const double v = Sp[(size_t)(cu < c1 ? cu : c1 - 1) * 256 + e];
+                    const double v = ld_sel<PUB>(Sp + (size_t)(cu < c1 ? cu : c1 - 1) * 256 + e);
                     sa[u & 7] += cu < c1 ? v : 0.0;
                 }
             }
@@ -757,11 +774,18 @@ __global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ S
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cu = c + u;
-            const double v = parts[(size_t)(cu < nparts ? cu : nparts - 1) * part_stride + src];
+            const double v = ld_sel<PUB>(parts + (size_t)(cu < nparts ? cu : nparts - 1) * part_stride + src);
             g[u] += cu < nparts ? v : 0.0;
         }
     }
     dst[idx] = s - ((g[0] + g[1]) + (g[2] + g[3]));
+}
+__global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ Sp, int N,
+                                                    int cb0, int NA, int NAP, const double* __restrict__ parts, int nparts,
+                                                    size_t part_stride, double* __restrict__ dst, int dbg = 0) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NAP * NAP) return;
+    assemble_entry(idx, Sp, N, cb0, NA, NAP, parts, nparts, part_stride, dst, dbg);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -828,26 +852,26 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int 
 // trip), the sixteen partial tiles are summed through LDS in a fixed order.
 //   blockIdx.y <  chunks : dense rows T3 (width NAP), lower tile blockIdx.x, row chunk blockIdx.y  -> Gpart[chunk]
 //   blockIdx.y == chunks : sparse rows Xobs (width 16, grouped by clone), clone blockIdx.x          -> S[clone]
-__device__ __forceinline__ void gram16_body(const double* __restrict__ X, int ld, int r0, int r1, int bi, int bj,
-                                            double* __restrict__ out, int ldo) {
-    __shared__ __attribute__((aligned(16))) double sT[16][256];
+template <int NWAVES, int GB, bool PUB = false>
+__device__ __forceinline__ void gramw_body(double* __restrict__ sT /* [NWAVES][256] LDS */, const double* __restrict__ X, int ld,
+                                           int r0, int r1, int bi, int bj, double* __restrict__ out, int ldo) {
+    // GB: k-steps (of 4 rows) whose operands are in flight together
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
-    int rw = (r1 - r0 + 15) / 16;
+    int rw = (r1 - r0 + NWAVES - 1) / NWAVES;
     rw = (rw + 3) & ~3;   // rows per wavefront, whole k-steps
     const int k0 = r0 + wave * rw;
     const int k1 = (k0 + rw < r1) ? k0 + rw : r1;
     const double* pa = X + 16 * bi + cc;
     const double* pb = X + 16 * bj + cc;
     d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    constexpr int GB = 16;   // k-steps (of 4 rows) whose operands are in flight together
     for (int k = k0; k < k1; k += 4 * GB) {
         double a[GB], b[GB];
 #pragma unroll
         for (int q = 0; q < GB; ++q) {   // clamped address + select (no branch, no vmcnt(0) per load)
             const int rq = k + 4 * q + kk;
             const int rc = rq < k1 ? rq : k1 - 1;
-            const double av = pa[(size_t)rc * ld], bv = pb[(size_t)rc * ld];
+            const double av = ld_sel<PUB>(pa + (size_t)rc * ld), bv = ld_sel<PUB>(pb + (size_t)rc * ld);
             a[q] = rq < k1 ? av : 0.0;
             b[q] = rq < k1 ? bv : 0.0;
         }
@@ -858,17 +882,24 @@ __device__ __forceinline__ void gram16_body(const double* __restrict__ X, int ld
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sT[wave][r * 64 + l] = acc0[r] + acc1[r];
+    for (int r = 0; r < 4; ++r) sT[wave * 256 + r * 64 + l] = acc0[r] + acc1[r];
     __syncthreads();
     if (tid < 256) {
-        double t[16];
+        double t[NWAVES];
 #pragma unroll
-        for (int w = 0; w < 16; ++w) t[w] = sT[w][tid];
-        const double v = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
-                         (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+        for (int w = 0; w < NWAVES; ++w) t[w] = sT[w * 256 + tid];
+#pragma unroll
+        for (int st = 1; st < NWAVES; st *= 2)   // fixed pairwise order
+#pragma unroll
+            for (int w = 0; w + st < NWAVES; w += 2 * st) t[w] += t[w + st];
         const int r = tid >> 6, lk = (tid & 63) >> 4, lc = tid & 15;   // accumulator element (row lk + 4 r, column lc)
-        out[(size_t)(16 * bi + lk + 4 * r) * ldo + 16 * bj + lc] = v;
+        st_pub<PUB>(out + (size_t)(16 * bi + lk + 4 * r) * ldo + 16 * bj + lc, t[0]);
     }
+}
+__device__ __forceinline__ void gram16_body(const double* __restrict__ X, int ld, int r0, int r1, int bi, int bj,
+                                            double* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) double sT[16 * 256];
+    gramw_body<16, 16>(sT, X, ld, r0, r1, bi, bj, out, ldo);
 }
 __global__ __launch_bounds__(1024) void k_gram_pair(const double* __restrict__ T3, int m3, int NAP, int rows_per_chunk, int chunks,
                                                     double* __restrict__ Gpart, const double* __restrict__ Xobs,
@@ -1146,16 +1177,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Stores / loads of bytes that another workgroup of the SAME launch consumes (k_potrf_solve): agent-scope relaxed
-// atomics = global_store/load ... sc1 (write-through, L1-bypassing); MI355X_MICROARCH.md "inter-workgroup visibility".
-template <bool PUB>
-__device__ __forceinline__ void st_pub(double* p, double v) {
-    if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-__device__ __forceinline__ double ld_pub(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // "my LDS writes of this step are done": the LDS executes one wavefront's operations in order, so the counter bump only
 // has to stay behind them in program order -- a release fence here would also drain the wave's GLOBAL stores (the
 // finished tiles on their way to memory), i.e. stall ~1.5 k cycles on every step.
@@ -1610,18 +1631,94 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
 struct FrontPotrfArgs {
     const double* X; int ldx; int n; double tol_rel; double* R; int ldr; double* Dinv; int* info;
 };
+// The compression (both Grams, then the assembly of A) can run in the same launch: the feature workgroups meet at a
+// device-wide counter (they are all resident: the launch has at most as many workgroups as the device has CUs, one
+// per CU by its LDS size), take (tile, chunk) / clone work items, meet again and assemble.  The factorisation in
+// workgroup 0 takes no part; it outlasts all of this, so the compression is free.
+struct FrontGramArgs {
+    int enabled;
+    int chunks, rows_per_chunk;   // T3 row chunks of this launch (<= 8 x 80 rows each: one batch of loads per wavefront)
+    double* Gpart; double* S; const int* clone_rows;
+    int* counter;                 // zero between launches (the last workgroup through resets it)
+    double* A_dst; int cb0;
+};
+__device__ __forceinline__ void front_grid_barrier(int* counter, int target, unsigned long long* dbg = nullptr) {
+    // Everything that crosses this barrier is written with write-through (sc1) stores and read with sc1 loads
+    // (st_pub / ld_sel<true>), so no cache write-back or invalidate is needed: every wavefront waits for its own stores
+    // to be acknowledged, one thread bumps the counter and polls it.  (A release/acquire fence pair per workgroup --
+    // L2 write-back and invalidate -- made each barrier 11-14 us.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (dbg) dbg[0] = wall_clock64();
+        // the arrivals are read-modify-writes on one line; the waiting is done on ANOTHER line with plain loads, so the
+        // polls of 200 workgroups do not queue up with the arrivals: the last one in raises the flag (monotonic phase)
+        int* flag = counter + 32;
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == target - 1) __hip_atomic_store(flag, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+}
 template <int NPASS, int NSLOT>
-__global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int team_doubles) {
+__global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int team_doubles, FrontGramArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (blockIdx.x == 0) {
+        if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[0] = wall_clock64();
         potrf_reg_body<NSLOT, false>(smem, q.X, q.ldx, q.n, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, 0, 0, nullptr, nullptr, 1, 0);
+        if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[6] = wall_clock64();
         return;
     }
     const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
     const int j = 2 * ((int)blockIdx.x - 1) + team;
-    if (j >= p.F) return;   // (an odd track count: the last workgroup has one team)
     const int local = threadIdx.x & 255;
-    feature_body<NPASS>(p, j, team ? ((local + 128) & 255) : local, smem + (size_t)team * team_doubles);
+    if (j < p.F) {
+        feature_body<NPASS, true>(p, j, team ? ((local + 128) & 255) : local, smem + (size_t)team * team_doubles);
+    } else {   // (an odd track count: the last workgroup has one team)
+        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+    }
+    if (!g.enabled) return;
+    const int nfb = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
+    unsigned long long* stamp = reinterpret_cast<unsigned long long*>(g.counter) + 8;   // diagnostic (bytes 64..): 100 MHz clock
+#define FRONT_STAMP(i) do { if (me == 0 && threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
+    FRONT_STAMP(1);
+    front_grid_barrier(g.counter, nfb);
+    FRONT_STAMP(2);
+    // ---- Grams: (lower tile, chunk) items of T3, then one item per clone of the sparse rows -----------------
+    const int nb = p.NAP >> 4, ntiles = nb * (nb + 1) / 2;
+    const int nitems = ntiles * g.chunks + p.N;
+    const int m3 = 3 * p.F;
+    for (int it = me; it < nitems; it += nfb) {
+        if (it < ntiles * g.chunks) {
+            const int ch = it / ntiles, tl = it - ch * ntiles;
+            int bi, bj;
+            tile_from_linear(tl, bi, bj);
+            const int r0 = ch * g.rows_per_chunk;
+            int r1 = r0 + g.rows_per_chunk;
+            if (r1 > m3) r1 = m3;
+            gramw_body<8, 20, true>(smem, p.T3, p.NAP, r0, r1 > r0 ? r1 : r0, bi, bj, g.Gpart + (size_t)ch * p.NAP * p.NAP, p.NAP);
+        } else {
+            const int c = it - ntiles * g.chunks;
+            gramw_body<8, 20, true>(smem, p.Xobs, 16, g.clone_rows[c], g.clone_rows[c + 1], 0, 0, g.S + (size_t)c * 256, 16);
+        }
+        __syncthreads();   // the reduction buffer is reused by the next item
+    }
+    FRONT_STAMP(3);
+    front_grid_barrier(g.counter, 2 * nfb, me == 0 ? stamp + 7 : nullptr);
+    FRONT_STAMP(4);
+    // ---- A = scatter(S) - sum of the partial Grams ------------------------------------------------------------
+    for (int idx = me * 512 + (int)threadIdx.x; idx < p.NAP * p.NAP; idx += nfb * 512)
+        assemble_entry<true>(idx, g.S, p.N, g.cb0, p.NA, p.NAP, g.Gpart, g.chunks, (size_t)p.NAP * p.NAP, g.A_dst, 0);
+    FRONT_STAMP(5);
+#undef FRONT_STAMP
+    // the last workgroup through puts the counter back to zero for the next launch
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(g.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 3 * nfb - 1) {
+            __hip_atomic_store(g.counter + 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // generic strided product C(i,j) = alpha * sum_k A(i,k) B(k,j) [+ diag_add on i == j] [+ Cin(i,j)]; tiles with
