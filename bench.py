@@ -133,6 +133,8 @@ def main():
             'k_potrf_solve(M)': n ** 3 / 3.0 + 1.0 * n * n * (n + 1),   # factorisation + trailing solve, one launch
             'k_finish': 1.0 * n * (n + 1) * (n + 1),
         }
+        # k_front = the tracks, the compression and chol(P) in one launch (the default whenever they are co-resident)
+        kflops['k_front'] = kflops['k_feature'] + kflops['k_gram'] + kflops['k_potrf(P)']
         # k_potrf(P) runs on a side stream, overlapped with k_feature/k_gram: not on the critical path
         crit = {k: v for k, v in prof.items() if k != 'k_potrf(P)'}
         dom = max(crit, key=crit.get)
@@ -140,17 +142,25 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes) of the
         # committed profile of this round, bytes per launch; null if that profile does not list the kernel
         traffic = None
+        executed = None
         try:
             import glob
             pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]))['kernels']
             key = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<16>', 'k_potrf_solve(M)': 'k_potrf_solve<16>',
-                   'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt', 'k_gram': 'k_gram_pair', 'k_assemble': 'k_assemble_A'}.get(dom)
+                   'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt', 'k_gram': 'k_gram_pair', 'k_assemble': 'k_assemble_A',
+                   'k_front': 'k_front<3, 16>'}.get(dom)
             if key in pm and N == 30 and F == 400:
                 traffic = 1024.0 * (pm[key]['FETCH_SIZE_KB_median'] + pm[key]['WRITE_SIZE_KB_median'])
+                if 'SQ_INSTS_VALU_MFMA_MOPS_F64_median' in pm[key]:   # flops the matrix cores actually executed
+                    executed = 512.0 * pm[key]['SQ_INSTS_VALU_MFMA_MOPS_F64_median'] / (prof[dom] * 1e-3) / 1e12
         except Exception:
             traffic = None
         roofline = dict(bound='mfma', kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic,
+                        executed_mfma_tflops=executed,
+                        note='achieved = algorithmic FP64 work of the reference algorithm (SURVEY 8d dense minimum) / kernel '
+                             'time; the kernel reaches the same result with far fewer executed flops (structured gate, fused '
+                             'compression), see executed_mfma_tflops and DESIGN.md 6: the path is latency-bound, not MFMA-bound',
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},
                         kernel_tflops={k: round(kflops[k] / (prof[k] * 1e-3) / 1e12, 4) for k in prof},
                         whole_update_tflops=W['total'] / (ms * 1e-3) / 1e12)

@@ -814,6 +814,7 @@ static int run_with_graph(orcvio_msckf_handle* h, orcvio_msckf_handle::GraphSlot
 // joined by run_finish, so it overlaps the feature kernels AND the collective), the rest replays from a graph
 static int run_local_impl(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
     h->last_stream = s;
+    if (front_fused_active(h)) return launch_front(h, s, dst);   // one launch: tracks, compression, and the prior's factor
     int rc = launch_prior_fork(h, s);
     if (rc != ORCVIO_OK) return rc;
     return run_with_graph(h, h->g_local, launch_signature(h, s, dst, 0), s, [&](bool) {
@@ -1463,12 +1464,14 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
+    const bool front = front_fused_active(h);   // k_front = tracks + compression + chol(P) in one launch: reported as entry 0
     for (int k = 0; k < nk; ++k) ms[k] = 0.0;
     for (int r = 0; r < reps; ++r) {
         for (int k = 0; k < nk; ++k) {
+            if (front && k >= 1 && k <= 3) continue;
             HIPCHK(hipEventRecord(e0, s));
             int rc = ORCVIO_OK;
-            if (k == 0) rc = launch_feature(h, s);
+            if (k == 0) rc = front ? launch_front(h, s, h->d_A) : launch_feature(h, s);
             else if (k == 1) rc = launch_gram(h, s);
             else if (k == 2) rc = launch_assemble(h, s, h->d_A);
             else rc = launch_solve_stage(h, s, k - 3);
@@ -1483,8 +1486,9 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
     int no = 0;
     for (int k = 0; k < nk; ++k) {
         if (k == 3 + ST_TRSM && fused_solve_active(h)) continue;   // nothing launched: part of k_potrf_solve(M)
+        if (front && k >= 1 && k <= 3) continue;                   // part of k_front
         ms[no] = ms[k] / reps;
-        names[no] = (k == 3 + ST_POTRF_M && fused_solve_active(h)) ? "k_potrf_solve(M)" : kn[k];
+        names[no] = (k == 3 + ST_POTRF_M && fused_solve_active(h)) ? "k_potrf_solve(M)" : ((front && k == 0) ? "k_front" : kn[k]);
         ++no;
     }
     *count = no;

@@ -239,6 +239,33 @@ def test_fused_solve_equals_two_launch_solve(upd, cfg):
         assert rel(got['P_new'], ref['P_new']) < 1e-12
 
 
+@pytest.mark.parametrize('cfg', [1, 2])
+def test_fused_front_equals_forked_front(upd, cfg):
+    """ORCVIO_OPT_FUSED_FRONT: the tracks, the compression and chol(P) in one launch (k_front: two feature teams per
+    workgroup, device-wide counters between the phases) against the forked form (k_potrf_reg on the side stream,
+    k_feature, k_gram_pair, k_assemble_A).  The Gram row chunks differ, so the sums agree to rounding, not bit for bit;
+    repeated to catch a stale counter or a missed hand-off."""
+    w = synth.config_window(cfg)
+    upd.set_fused_front(False)
+    ref = upd.update_features(w, want_G=True)
+    upd.set_fused_front(True)
+    for _ in range(20):
+        got = upd.update_features(w, want_G=True)
+        assert np.array_equal(got['accept'], ref['accept'])
+        assert np.allclose(got['gamma'], ref['gamma'], rtol=1e-12, atol=0, equal_nan=True)
+        assert rel(got['dx'], ref['dx']) < 1e-11
+        assert rel(got['P_new'], ref['P_new']) < 1e-12
+        assert rel(got['G'], ref['G']) < 1e-11
+
+
+@pytest.mark.parametrize('F', [1, 2, 3, 255, 509, 510, 511, 700])
+def test_fused_front_track_counts(upd, F):
+    """One team idle (odd F), a single workgroup, the co-residency limit (1 + ceil(F/2) workgroups <= 256 CUs: 510
+    tracks) and beyond it (falls back to the forked front): all against the oracle."""
+    w = synth.make_window(N=12, F=F, seed=300 + F, track_len=(2, 9))
+    _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
+
+
 def test_large_window_takes_the_lds_panel_path(upd):
     """N = 38 clones: n = 250 > 224, so both factorisations use the LDS-panel kernel (k_potrf) and the solve k_trsm_rl
     instead of the register-resident / fused kernels."""
