@@ -745,6 +745,12 @@ __device__ __forceinline__ void assemble_entry(const int idx, const double* __re
     int ei = -1, ci = -1, ej = -1, cj = -1;
     if (i < 7) ei = i; else if (i == NA) ei = 13; else if (i >= cb0 && i < NA) { ci = (i - cb0) / 6; ei = 7 + (i - cb0) - 6 * ci; }
     if (j < 7) ej = j; else if (j == NA) ej = 13; else if (j >= cb0 && j < NA) { cj = (j - cb0) / 6; ej = 7 + (j - cb0) - 6 * cj; }
+    const int src = ((i >> 4) >= (j >> 4)) ? idx : j * NAP + i;
+    // (the partial Grams first: their loads are unconditional and stay in flight under the S branch)
+    double gv[4];
+    const int np0 = (dbg & 2) ? 0 : nparts;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gv[u] = ld_sel<PUB>(parts + (size_t)(u < nparts ? u : nparts - 1) * part_stride + src);
     double s = 0.0;
     if (ei >= 0 && ej >= 0 && N > 0 && !(dbg & 1)) {
         // the 16x16 tiles hold both triangles: read [max][min]
@@ -768,9 +774,10 @@ __device__ __forceinline__ void assemble_entry(const int idx, const double* __re
             s = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
         }
     }
-    const int src = ((i >> 4) >= (j >> 4)) ? idx : j * NAP + i;
-    double g[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int c = 0; c < ((dbg & 2) ? 0 : nparts); c += 4) {
+    double g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[u] = u < np0 ? gv[u] : 0.0;
+    for (int c = 4; c < np0; c += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cu = c + u;
@@ -1199,7 +1206,7 @@ __device__ __forceinline__ void st_tile(double* ubase, unsigned lane_bytes, doub
 // inv(L11) are complete in memory (monotonic, set by one lane behind a workgroup barrier that every storing wave
 // reaches after draining its stores).
 template <int NSLOT, bool PUB>
-#define POTRF_LDS_DOUBLES (816 + 3 * 3584 + 8)
+#define POTRF_LDS_DOUBLES (816 + 3 * 3584 + 8 + 544)
 __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const double* __restrict__ X, int ldx, int n, double tol_rel,
                                                double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                int* __restrict__ info, int from_lower, int ablate, int* __restrict__ flag,
@@ -1222,6 +1229,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
     double (*sDg)[4][64] = reinterpret_cast<double (*)[4][64]>(lds + 816 + 3584);     // the diagonal tiles (owned by wave 0)
     double (*sStage)[4][64] = reinterpret_cast<double (*)[4][64]>(lds + 816 + 7168);  // block row kb of the trailing matrix, up to date
     int* sCnt = reinterpret_cast<int*>(lds + 816 + 10752);                            // [16] waves that have published their panel tiles of step kb
+    double (*sL)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + 816 + 10752 + 8);   // L11 of block step kb (rows) in sL[kb & 1]: wave 4 stores R11 from it
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nb = (n + 15) >> 4;
@@ -1280,23 +1288,15 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             if (!(ablate & 1)) DiagStep<0>::run(v, y, tol, n - 16 * kb, nzero, nneg);
             POTRF_STAMP(2, 3 * kb + 1);
             if (l < 16) {
+                double* pL = &sL[0][0][0] + z + (kb & 1) * 272;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) pDi[c * 17 + l] = y[c];   // Linv[c][l]
-            }
-        };
-        // R11[kk+4r][cc] = L11[cc][kk+4r] = v[kk+4r] of this very lane (every 16-lane row holds all rows) -> sDg[kb];
-        // wave 4 takes inv(L11) and R11 from LDS to memory (no global stores of them on this chain)
-        auto write_R11 = [&](int kb) {
-            int z = 0;
-            asm volatile("" : "+v"(z));
-            double* pG = &sDg[0][0][0] + z + kb * 256 + l;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double x0 = v[4 * r], x1 = v[4 * r + 1], x2 = v[4 * r + 2], x3 = v[4 * r + 3];
-                const double xs = (kk == 0) ? x0 : ((kk == 1) ? x1 : ((kk == 2) ? x2 : x3));
-                pG[r * 64] = (kk + 4 * r <= cc) ? xs : 0.0;
+                for (int c = 0; c < 16; ++c) pL[l * 17 + c] = v[c];    // L11[l][c] (zero above the diagonal)
             }
         };
+        // wave 4 takes inv(L11) and L11 (as R11) of every step from LDS to memory: no global stores of them, and no
+        // transposition, on this chain
         __builtin_amdgcn_s_setprio(3);
         POTRF_STAMP(0, 1);
         wave_sync();
@@ -1321,11 +1321,14 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) { li[s4] = pDi[cc * 17 + kk + 4 * s4]; sv[s4] = st[s4 * 64]; t[s4] = pGn[s4 * 64]; }
                 d4 x = {0, 0, 0, 0};
-                x = mfma_f64(li[0], sv[0], x);
-                write_R11(kb);   // (independent LDS writes: they issue in the shadow of the dependent MFMAs)
-                x = mfma_f64(li[1], sv[1], x);
-                x = mfma_f64(li[2], sv[2], x);
-                x = mfma_f64(li[3], sv[3], x);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], sv[s4], x);
+                // next diagonal tile: -= panel^T panel (operands straight from the accumulator registers), straight into
+                // the row view for its sweep.  Eight dependent MFMAs back to back; everything else of the step is issued
+                // while they run: the panel tile to LDS / memory, the step counter.
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-x[s4], x[s4], t);
+                __builtin_amdgcn_sched_barrier(0);
                 double* pPan = &sPan[0][0][0] + z + kn * 256 + l;
                 double* ub = R + (size_t)(16 * kb) * ldr + 16 * kn;
 #pragma unroll
@@ -1335,10 +1338,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                 }
                 lds_publish_count(&sCnt[kb], l);
                 POTRF_STAMP(0, 4 + 4 * kb);
-                // next diagonal tile: -= panel^T panel (operands straight from the accumulator registers), straight into
-                // the row view for its sweep
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) t = mfma_f64(-x[s4], x[s4], t);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) (&sD[0][0] + z)[(kk + 4 * r) * 17 + cc] = t[r];
                 wave_sync();
@@ -1347,7 +1347,6 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                 POTRF_STAMP(0, 6 + 4 * kb);
                 // the later diagonal tiles (k > kn) are brought up to date by the workers (they live in LDS)
             } else {
-                write_R11(kb);
                 lds_publish_count(&sCnt[kb], l);
             }
         }
@@ -1393,11 +1392,11 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             const double* g = &sDg[0][0][0] + z + kb * 256 + l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) st_pub<PUB>(Dinv + (size_t)kb * 256 + l + 64 * r, pDi[(kk + 4 * r) * 17 + cc]);   // element l + 64 r = (row kk + 4r, column cc)
-            // R11 is written by the chain after this barrier, before it adds to the step counter
-            while (__hip_atomic_load(&sCnt[kb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < POTRF_NW + 1) __builtin_amdgcn_s_sleep(2);
+            // R11 = L11^T from the row copy the sweep left in sL[kb & 1] (written before this barrier)
+            const double* pL = &sL[0][0][0] + z + (kb & 1) * 272;
             double* ub = R + (size_t)(16 * kb) * ldr + 16 * kb;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, g[r * 64]);
+            for (int r = 0; r < 4; ++r) st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, (kk + 4 * r <= cc) ? pL[cc * 17 + kk + 4 * r] : 0.0);
         }
     } else {
         // =====================================================================================
