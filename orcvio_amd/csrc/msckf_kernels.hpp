@@ -1233,6 +1233,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nb = (n + 15) >> 4;
+    const int ksw = (ablate & 16) ? 0 : (nb > 5 ? (nb - 5) / 2 : 0);   // steps whose later-diagonal updates wave 4 takes over
     POTRF_STAMP(wave == 0 ? 0 : (wave == 1 ? 1 : 3), 0);
     if (stamps && tid == 0) stamps[192] = wall_clock64();
     if (tid < 16) sCnt[tid] = 0;   // first use is behind barrier A of step 0
@@ -1397,6 +1398,35 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             double* ub = R + (size_t)(16 * kb) * ldr + 16 * kb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, (kk + 4 * r <= cc) ? pL[cc * 17 + kk + 4 * r] : 0.0);
+            if (kb < ksw && !(ablate & 8)) {
+                // the later diagonal tiles of the early steps (the workers are the bottleneck there): -= panel^T panel once
+                // the panel tiles of this step are all in LDS; two tiles in flight
+                while (__hip_atomic_load(&sCnt[kb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < POTRF_NW + 1) __builtin_amdgcn_s_sleep(2);
+                const double* pPan = &sPan[0][0][0] + z + l;
+                double* pG = &sDg[0][0][0] + z + l;
+#pragma unroll 1
+                for (int k = kb + 2; k < nb; k += 2) {
+                    const bool two = k + 1 < nb;
+                    const int k1 = two ? k + 1 : k;
+                    double qa[4], qb[4];
+                    d4 t0, t1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qa[r] = pPan[k * 256 + r * 64]; t0[r] = pG[k * 256 + r * 64]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qb[r] = pPan[k1 * 256 + r * 64]; t1[r] = pG[k1 * 256 + r * 64]; }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        t0 = mfma_f64(-qa[s4], qa[s4], t0);
+                        t1 = mfma_f64(-qb[s4], qb[s4], t1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pG[k * 256 + r * 64] = t0[r];
+                    if (two) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pG[k1 * 256 + r * 64] = t1[r];
+                    }
+                }
+            }
         }
     } else {
         // =====================================================================================
@@ -1533,8 +1563,9 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             // next live slot are fetched from LDS while the MFMAs of the current one execute.  Tiles of block row
             // kb+1 (the next panel) are also staged in LDS.
             // later diagonal tiles k > kb+1 live in LDS and are off the critical chain: worker k % NW updates them (at
-            // most two per worker); operands of both are fetched before the first MFMA
-            if (!(ablate & 8)) {
+            // most two per worker); operands of both are fetched before the first MFMA.  In the first ksw steps the
+            // workers are the bottleneck and the chain's SIMD has time to spare: wave 4 does these updates there.
+            if (!(ablate & 8) && kb >= ksw) {
                 int d0 = (wi - (kb + 2)) % POTRF_NW;
                 if (d0 < 0) d0 += POTRF_NW;
                 const int k0 = kb + 2 + d0;
