@@ -77,6 +77,8 @@ struct orcvio_msckf_handle {
     double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_A = nullptr;
     int front_fused = 1;                // ORCVIO_OPT_FUSED_FRONT
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
+    bool A_deferred = false;            // the last run left S / Gpart only: d_A is assembled on demand (assemble_deferred)
+    int front_chunks = 1;               // T3 row chunks of the last k_front launch
     int n_cus = 0;                      // compute units of the device
     int clean_NP = -1, clean_path = -1;   // layout for which the strictly-lower tiles of d_RP / d_RM are known to be zero
     double *d_RP = nullptr, *d_DinvP = nullptr, *d_U = nullptr, *d_M = nullptr, *d_RM = nullptr, *d_DinvM = nullptr;
@@ -548,8 +550,17 @@ static bool front_fused_active(const orcvio_msckf_handle* h) {
     return lds <= (size_t)160 * 1024 && (h->NAP + 63) / 64 <= 4;
 }
 
-// compress_dst != nullptr: the compression (Grams + assembly of A into compress_dst) runs inside the same launch
-static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_dst) {
+static int front_row_chunks(const orcvio_msckf_handle* h) {
+    const int c = (3 * h->F + 639) / 640;   // eight wavefronts x 80 rows: one batch of loads each
+    return c < 1 ? 1 : c;
+}
+// U = [A; b^T] L_a can assemble A on the fly (k_gemm_asmA) when there are at most four partial Grams: k_front then stops
+// after the Grams (one device-wide barrier instead of two, no assembly pass)
+static bool front_defers_assembly(const orcvio_msckf_handle* h) { return front_fused_active(h) && front_row_chunks(h) <= 4 && h->NA <= 192; }
+
+// compress_dst != nullptr: the compression (Grams + assembly of A into compress_dst) runs inside the same launch;
+// grams_only: ... without the assembly (the caller's next kernel is k_gemm_asmA)
+static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_dst, bool grams_only = false) {
     const FeatArgs a = feature_args(h);
     const double eps = 2.220446049250313e-16;
     FrontPotrfArgs q{h->d_P, h->n, h->n, 8.0 * eps, h->d_RP, h->NP, h->d_DinvP, h->d_info};
@@ -557,10 +568,10 @@ static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_
     const size_t lds = 2 * team > sizeof(double) * POTRF_LDS_DOUBLES ? 2 * team : sizeof(double) * POTRF_LDS_DOUBLES;
     const int team_doubles = (int)(team / sizeof(double));
     FrontGramArgs g{};
-    g.enabled = compress_dst != nullptr;
+    g.enabled = compress_dst != nullptr ? (grams_only ? 2 : 1) : 0;
     const int t3rows = 3 * h->F;
-    g.chunks = (t3rows + 639) / 640;   // eight wavefronts x 80 rows: one batch of loads each
-    if (g.chunks < 1) g.chunks = 1;
+    g.chunks = front_row_chunks(h);
+    h->front_chunks = g.chunks;
     g.rows_per_chunk = round_up((t3rows + g.chunks - 1) / g.chunks, 4);
     g.Gpart = h->d_Gpart; g.S = h->d_S; g.clone_rows = h->d_clone_ptr; g.counter = h->d_sync;
     g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15;
@@ -610,6 +621,17 @@ static int launch_assemble(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
                        h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->chunks, (size_t)total, dst,
                        getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0);
     HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+// d_A on demand (optional outputs, tests) after an update whose k_front left the Grams only
+static int assemble_deferred(orcvio_msckf_handle* h, hipStream_t s) {
+    if (!h->A_deferred) return ORCVIO_OK;
+    const int total = h->NAP * h->NAP;
+    hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->F > 0 ? h->N : 0,
+                       h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->front_chunks, (size_t)total, h->d_A, 0);
+    HIPCHK(hipGetLastError());
+    h->A_deferred = false;
     return ORCVIO_OK;
 }
 
@@ -705,6 +727,13 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
         case ST_POTRF_P:   // P = Lf Lf^T
             return launch_potrf(h, s, h->d_P, n, n, 8.0 * eps, h->d_RP, h->d_DinvP, h->d_info);
         case ST_FORM_U:    // U[(NA+1) x n] = [A; b^T] * L_a
+            if (h->A_deferred) {   // A = scatter(S) - sum Gpart assembled inside the product (k_front left the Grams only)
+                AsmArgs aa{h->d_S, h->N, h->flags.leg_dim - 15, NA, NAP, h->d_Gpart, h->front_chunks, (size_t)NAP * NAP, getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0};
+                const int tiles = ((NA + 1 + 15) / 16) * ((n + 15) / 16);
+                hipLaunchKernelGGL(k_gemm_asmA, dim3(tiles), dim3(256), 0, s, aa, La, sLi, sLj, NA + 1, n, NA, h->d_U, (long)NP, 1L, (int*)nullptr);
+                HIPCHK(hipGetLastError());
+                return ORCVIO_OK;
+            }
             return launch_gemm(s, h->d_A, NAP, 1, La, sLi, sLj, NA + 1, n, NA, 1.0, 0.0, 0, h->d_U, NP, 1);
         case ST_FORM_M:    // M = s2 I + L_a^T U[0:NA]   (upper tiles)
             // (the register-resident Cholesky reads the upper tiles only; the LDS-panel fallback factors the lower triangle in place)
@@ -851,6 +880,7 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
     h->last_stream = s;
     // the Cholesky of the prior was forked by run_local: join it here (outside the captured part)
     HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
+    h->A_deferred = false;   // d_A is the sum of the gathered blocks
     int rc = run_with_graph(h, h->g_finish, launch_signature(h, s, d_blocks, n_blocks), s, [&](bool) {
         int r = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);   // rank-ordered sum of the gathered blocks
         for (int st = ST_FORM_U; st < ST_COUNT && r == ORCVIO_OK; ++st) r = launch_solve_stage(h, s, st);
@@ -862,8 +892,10 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
 
 static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
     // (the other way round -- prior on the origin stream, feature branch forked -- measured 15 us slower)
+    h->A_deferred = front_defers_assembly(h);
     if (front_fused_active(h)) {   // one stream, no fork: the prior is factored by workgroup 0 of the feature launch
-        int rc = launch_front(h, s, h->d_A);   // ... and the compression behind the tracks, under the factorisation
+        // ... and the compression behind the tracks, under the factorisation
+        int rc = launch_front(h, s, h->d_A, h->A_deferred);
         for (int st = ST_FORM_U; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
         return rc;
     }
@@ -882,6 +914,7 @@ int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     hipStream_t s = pick_stream(h, stream);
     h->last_stream = s;
     int rc = run_with_graph(h, h->g_update, launch_signature(h, s, nullptr, 0), s, [&](bool) { return enqueue_update(h, s); });
+    h->A_deferred = front_defers_assembly(h);   // (a replayed graph does not pass through enqueue_update)
     if (rc == ORCVIO_OK) h->ran = true;
     return rc;
 }
@@ -904,6 +937,7 @@ static int compute_optional(orcvio_msckf_handle* h, bool want_thin_or_K, bool wa
     long sLi, sLj;
     factor_strides(h, sLi, sLj);
     const double* La_P = h->d_RP + 15 * sLi;
+    { const int ra = assemble_deferred(h, s); if (ra != ORCVIO_OK) return ra; }
     if (want_thin_or_K) {   // lower Cholesky factor of the Gram block with the LDS-panel kernel
         HIPCHK(hipMemcpyAsync(h->d_La, h->d_A, sizeof(double) * (size_t)NAP * NAP, hipMemcpyDeviceToDevice, s));
         // the Gram block is singular in every update (gauge freedom): factor A + 1e-11 max(diag) I, which needs no
@@ -1289,6 +1323,7 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
     const int n = h->n, NA = h->NA, NAP = h->NAP;
     const double sigma2 = h->flags.noise_feature * h->flags.noise_feature;
     h->obj_dof = dof_total;
+    h->A_deferred = false;
     int rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);
     if (rc != ORCVIO_OK) return rc;
     // Kalman solve in square-root form, gate, gated write-back
@@ -1465,13 +1500,15 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     const bool front = front_fused_active(h);   // k_front = tracks + compression + chol(P) in one launch: reported as entry 0
+    const bool defer = front_defers_assembly(h);
     for (int k = 0; k < nk; ++k) ms[k] = 0.0;
     for (int r = 0; r < reps; ++r) {
         for (int k = 0; k < nk; ++k) {
             if (front && k >= 1 && k <= 3) continue;
             HIPCHK(hipEventRecord(e0, s));
             int rc = ORCVIO_OK;
-            if (k == 0) rc = front ? launch_front(h, s, h->d_A) : launch_feature(h, s);
+            h->A_deferred = defer;
+            if (k == 0) rc = front ? launch_front(h, s, h->d_A, defer) : launch_feature(h, s);
             else if (k == 1) rc = launch_gram(h, s);
             else if (k == 2) rc = launch_assemble(h, s, h->d_A);
             else rc = launch_solve_stage(h, s, k - 3);
@@ -1778,7 +1815,12 @@ int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst
             if (!h->materialize) { g_last_error = "debug_read: stack not materialised (ORCVIO_OPT_MATERIALIZE_STACK)"; return ORCVIO_ERR_INVALID; }
             src = h->d_Hs; bytes = (size_t)h->m_tot * h->NAP * sizeof(double); break;
         case 1: src = h->d_Ab; bytes = pp; break;
-        case 2: src = h->d_A; bytes = pp; break;
+        case 2: {
+            const int ra = assemble_deferred(h, h->stream);
+            if (ra != ORCVIO_OK) return ra;
+            HIPCHK(hipDeviceSynchronize());
+            src = h->d_A; bytes = pp; break;
+        }
         case 3: src = h->d_RP; bytes = np2; break;
         case 4: src = h->d_M; bytes = np2; break;
         case 5: src = h->d_RM; bytes = np2; break;

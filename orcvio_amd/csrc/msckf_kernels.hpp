@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int 
 // trip), the sixteen partial tiles are summed through LDS in a fixed order.
 //   blockIdx.y <  chunks : dense rows T3 (width NAP), lower tile blockIdx.x, row chunk blockIdx.y  -> Gpart[chunk]
 //   blockIdx.y == chunks : sparse rows Xobs (width 16, grouped by clone), clone blockIdx.x          -> S[clone]
-template <int NWAVES, int GB, bool PUB = false>
+template <int NWAVES, int GB, bool PUB = false, bool MIRROR = false>
 __device__ __forceinline__ void gramw_body(double* __restrict__ sT /* [NWAVES][256] LDS */, const double* __restrict__ X, int ld,
                                            int r0, int r1, int bi, int bj, double* __restrict__ out, int ldo) {
     // GB: k-steps (of 4 rows) whose operands are in flight together
@@ -901,6 +901,7 @@ __device__ __forceinline__ void gramw_body(double* __restrict__ sT /* [NWAVES][2
             for (int w = 0; w + st < NWAVES; w += 2 * st) t[w] += t[w + st];
         const int r = tid >> 6, lk = (tid & 63) >> 4, lc = tid & 15;   // accumulator element (row lk + 4 r, column lc)
         st_pub<PUB>(out + (size_t)(16 * bi + lk + 4 * r) * ldo + 16 * bj + lc, t[0]);
+        if (MIRROR && bi != bj) st_pub<PUB>(out + (size_t)(16 * bj + lc) * ldo + 16 * bi + lk + 4 * r, t[0]);   // the other triangle
     }
 }
 __device__ __forceinline__ void gram16_body(const double* __restrict__ X, int ld, int r0, int r1, int bi, int bj,
@@ -1726,7 +1727,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
             const int r0 = ch * g.rows_per_chunk;
             int r1 = r0 + g.rows_per_chunk;
             if (r1 > m3) r1 = m3;
-            gramw_body<8, 20, true>(smem, p.T3, p.NAP, r0, r1 > r0 ? r1 : r0, bi, bj, g.Gpart + (size_t)ch * p.NAP * p.NAP, p.NAP);
+            gramw_body<8, 20, true, true>(smem, p.T3, p.NAP, r0, r1 > r0 ? r1 : r0, bi, bj, g.Gpart + (size_t)ch * p.NAP * p.NAP, p.NAP);
         } else {
             const int c = it - ntiles * g.chunks;
             gramw_body<8, 20, true>(smem, p.Xobs, 16, g.clone_rows[c], g.clone_rows[c + 1], 0, 0, g.S + (size_t)c * 256, 16);
@@ -1734,17 +1735,21 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
         __syncthreads();   // the reduction buffer is reused by the next item
     }
     FRONT_STAMP(3);
-    front_grid_barrier(g.counter, 2 * nfb, me == 0 ? stamp + 7 : nullptr);
-    FRONT_STAMP(4);
-    // ---- A = scatter(S) - sum of the partial Grams ------------------------------------------------------------
-    for (int idx = me * 512 + (int)threadIdx.x; idx < p.NAP * p.NAP; idx += nfb * 512)
-        assemble_entry<true>(idx, g.S, p.N, g.cb0, p.NA, p.NAP, g.Gpart, g.chunks, (size_t)p.NAP * p.NAP, g.A_dst, 0);
-    FRONT_STAMP(5);
+    int phases = 2;
+    if (g.enabled == 1) {   // (enabled == 2: the consumer, k_gemm_asmA, assembles A on the fly)
+        front_grid_barrier(g.counter, 2 * nfb, me == 0 ? stamp + 7 : nullptr);
+        FRONT_STAMP(4);
+        // ---- A = scatter(S) - sum of the partial Grams --------------------------------------------------------
+        for (int idx = me * 512 + (int)threadIdx.x; idx < p.NAP * p.NAP; idx += nfb * 512)
+            assemble_entry<true>(idx, g.S, p.N, g.cb0, p.NA, p.NAP, g.Gpart, g.chunks, (size_t)p.NAP * p.NAP, g.A_dst, 0);
+        FRONT_STAMP(5);
+        phases = 3;
+    }
 #undef FRONT_STAMP
-    // the last workgroup through puts the counter back to zero for the next launch
+    // the last workgroup through puts the counter (and the flag) back to zero for the next launch
     if (threadIdx.x == 0) {
         const int old = __hip_atomic_fetch_add(g.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 3 * nfb - 1) {
+        if (old == phases * nfb - 1) {
             __hip_atomic_store(g.counter + 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1784,6 +1789,156 @@ __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long
         const int i = 16 * bi + kk + 4 * r, j = 16 * bj + cc;
         if (i < M && j < N)
             C[(long)i * sCi + (long)j * sCj] = alpha * v + ((i == j) ? diag_add : 0.0) + (Cin ? Cin[(long)i * sCi + (long)j * sCj] : 0.0);
+    }
+}
+
+// k_gemm_asmA: C (M x Nc) = A (M x K) * B (K x Nc) where A is NOT in memory: entry (i,k) of the compressed block is
+// assembled on the fly as k_assemble_A would, scatter(S)(i,k) - sum_c Gpart[c](i,k).  Used for U = [A; b^T] L_a right
+// behind k_front, whose in-launch compression then ends with the Grams (no second device-wide barrier, no assembly
+// pass).  Same tiling as k_gemm: one workgroup per 16x16 tile of C, split-K over its four wavefronts; every load of a
+// batch (one S tile entry, <= 4 partial-Gram entries and one B entry per k-step) is issued before the first use.
+struct AsmArgs {
+    const double* S; int N, cb0, NA, NAP; const double* parts; int nparts; size_t stride; int dbg;
+};
+__global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __restrict__ B, long sBk, long sBj, int M, int Nc, int K,
+                                                   double* __restrict__ C, long sCi, long sCj, int* __restrict__ clear) {
+    // The 16 x K strip of A this tile needs is assembled into LDS first, with the k index along the lanes (coalesced
+    // reads of the partial Grams, whose two triangles are both written by k_front), then read back as MFMA operands.
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr int KMAX = 192, LDA = KMAX + 1;   // (193: one row per lane group without bank conflicts)
+    __shared__ double sA[16 * LDA];
+    __shared__ double sPart[3][4][64];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    const int kk = l >> 4, cc = l & 15;
+    const int ntj = (Nc + 15) >> 4;
+    const int bi = (int)blockIdx.x / ntj, bj = (int)blockIdx.x - bi * ntj;
+    const int KS = ((K + 15) >> 4) << 2;   // k-slice per wavefront, a multiple of the MFMA depth (<= 48 for K <= 192)
+    const int kbeg = wave * KS;
+    const int kend = (kbeg + KS < K) ? kbeg + KS : K;
+    // B operands of this wavefront's slice: in flight while the strip is assembled
+    constexpr int GB = 12;
+    const int jc = 16 * bj + cc;
+    const bool jb = jc < Nc;
+    const double* pb = B + (long)(jb ? jc : Nc - 1) * sBj;
+    double bv[GB];
+#pragma unroll
+    for (int q = 0; q < GB; ++q) {
+        const int k = kbeg + 4 * q + kk;
+        bv[q] = pb[(long)(k < kend ? k : (kend > 0 ? kend - 1 : 0)) * sBk];
+    }
+    // ---- the (ext|r) x (ext|r) entries sum EVERY clone tile: once per workgroup that owns such rows, 64 entries x N
+    //      tiles over the 256 threads (clone c on thread group c % 4, then a fixed-order sum of the four partials)
+    __shared__ double sShared[4][64];
+    const bool has_shared = (bi == 0 || bi == (aa.NA >> 4)) && aa.N > 0 && !(aa.dbg & 1);   // rows 0..6 or row NA
+    if (has_shared) {
+        const int g4 = tid >> 6, en = tid & 63;
+        const int ea = en >> 3, eb = en & 7;                      // entry classes 0..6 -> e = 0..6, 7 -> e = 13
+        const int e0 = ea == 7 ? 13 : ea, e1 = eb == 7 ? 13 : eb;
+        const int e16 = (e0 >= e1) ? e0 * 16 + e1 : e1 * 16 + e0;
+        double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = g4; c < aa.N; c += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cu = c + 4 * u;
+                const double v = aa.S[(size_t)(cu < aa.N ? cu : aa.N - 1) * 256 + e16];
+                acc8[u] += cu < aa.N ? v : 0.0;
+            }
+        }
+        sShared[g4][en] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+    }
+    // ---- strip: thread (wave w, lane l) owns rows w, w+4, w+8, w+12 and columns l, l+64, l+128 -----------------------
+    double sv[4][3], gv[4][3][4];
+    int cls[4][3];   // 0: no S contribution, 1: one clone tile (sv), 2: shared entry (index in cls >> 2)
+    int ekj[3], ckj[3];   // column classes: three per thread, shared by its four rows
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = l + 64 * j;
+        const int kc = k < K ? k : 0;
+        ekj[j] = -1; ckj[j] = -1;
+        if (kc < 7) ekj[j] = kc; else if (kc >= aa.cb0 && kc < aa.NA) { ckj[j] = (kc - aa.cb0) / 6; ekj[j] = 7 + (kc - aa.cb0) - 6 * ckj[j]; }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave + 4 * rr;
+        const int i = 16 * bi + r;          // (wave-uniform)
+        const int ic = i < M ? i : 0;
+        int ei = -1, ci = -1;
+        if (ic < 7) ei = ic; else if (ic == aa.NA) ei = 13; else if (ic >= aa.cb0 && ic < aa.NA) { ci = (ic - aa.cb0) / 6; ei = 7 + (ic - aa.cb0) - 6 * ci; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = l + 64 * j;
+            const bool in = i < M && k < K;
+            const int kc = k < K ? k : 0;
+            const int ek = ekj[j], ck = ckj[j];
+            int c0 = 0, n1 = 0;   // clone tile and number of clone tiles that contribute (0, 1, or all N)
+            if (ei >= 0 && ek >= 0) {
+                if (ci < 0 && ck < 0) n1 = 2;
+                else if (ci >= 0 && ck >= 0) { if (ci == ck) { c0 = ci; n1 = 1; } }
+                else { c0 = ci >= 0 ? ci : ck; n1 = 1; }
+            }
+            if (!in || aa.N == 0 || (aa.dbg & 4)) n1 = 0;
+            if ((aa.dbg & 1) && n1 > 1) n1 = 1;
+            const int e16 = (ei >= ek) ? ei * 16 + ek : ek * 16 + ei;   // the S tiles hold both triangles: [max][min]
+            const int ea = ei == 13 ? 7 : ei, eb = ek == 13 ? 7 : ek;   // (shared entries: both below 8)
+            cls[rr][j] = n1 == 2 ? (2 | ((ea * 8 + eb) << 2)) : n1;
+            sv[rr][j] = aa.S[(size_t)(n1 == 1 ? c0 : 0) * 256 + (n1 == 1 ? e16 : 0)];
+            const size_t src = (size_t)ic * aa.NAP + kc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < aa.nparts && !(aa.dbg & 2)) gv[rr][j][u] = aa.parts[(size_t)u * aa.stride + src];   // (wave-uniform count)
+        }
+    }
+    if (has_shared) __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave + 4 * rr;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = l + 64 * j;
+            double sS = cls[rr][j] == 1 ? sv[rr][j] : 0.0;
+            if (has_shared && (cls[rr][j] & 3) == 2) {
+                const int en = cls[rr][j] >> 2;
+                sS = (sShared[0][en] + sShared[1][en]) + (sShared[2][en] + sShared[3][en]);
+            }
+            double g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = u < aa.nparts ? gv[rr][j][u] : 0.0;
+            const bool in = 16 * bi + r < M && k < K;
+            sA[r * LDA + k] = in ? sS - ((g[0] + g[1]) + (g[2] + g[3])) : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- split-K product from the strip ---------------------------------------------------------------------------
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    {
+        double a[GB];
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+            const int k = kbeg + 4 * q + kk;
+            const bool kin = k < kend;
+            a[q] = kin ? sA[cc * LDA + (kin ? k : 0)] : 0.0;
+            bv[q] = (jb && kin) ? bv[q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < GB; q += 2) {
+            acc0 = mfma_f64(a[q], bv[q], acc0);
+            acc1 = mfma_f64(a[q + 1], bv[q + 1], acc1);
+        }
+    }
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPart[wave - 1][r][l] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = ((acc[r] + sPart[0][r][l]) + sPart[1][r][l]) + sPart[2][r][l];
+        const int io = 16 * bi + kk + 4 * r, jo = 16 * bj + cc;
+        if (io < M && jo < Nc) C[(long)io * sCi + (long)jo * sCj] = v;
     }
 }
 
