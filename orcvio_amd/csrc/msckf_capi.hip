@@ -573,7 +573,7 @@ static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_
     g.chunks = front_row_chunks(h);
     h->front_chunks = g.chunks;
     g.rows_per_chunk = round_up((t3rows + g.chunks - 1) / g.chunks, 4);
-    g.Gpart = h->d_Gpart; g.S = h->d_S; g.clone_rows = h->d_clone_ptr; g.counter = h->d_sync;
+    g.Gpart = h->d_Gpart; g.S = h->d_S; g.clone_rows = h->d_clone_ptr; g.counter = h->d_sync; g.lost = h->d_info + 8;
     g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15;
     if (g.enabled && g.chunks > h->gram_chunks_cap) { g_last_error = "launch_front: too many row chunks"; return ORCVIO_ERR_CAPACITY; }
     dim3 grid(1 + (h->F + 1) / 2), block(512);
@@ -981,9 +981,10 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
     if (res->gamma && F > 0) std::memcpy(res->gamma, gam, sizeof(double) * F);
     int info[9] = {0};
     std::memcpy(info, st + h->so_outs + ((char*)h->d_info - h->d_outs), sizeof(int) * 9);
-    if (info[8] != 0) {   // a solver wavefront of k_potrf_solve gave up waiting for the factorisation (never on a healthy device)
+    if (info[8] != 0) {   // a wait inside a launch gave up (a solver wavefront of k_potrf_solve, or a workgroup of k_front at its device-wide counter): never on a healthy device
         HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
-        g_last_error = "k_potrf_solve: hand-off from the factorisation timed out";
+        HIPCHK(hipMemset(h->d_sync, 0, 256));
+        g_last_error = "k_potrf_solve / k_front: an in-launch hand-off timed out";
         return ORCVIO_ERR_NOT_SPD;
     }
     int stacked = 0, nacc = 0;

@@ -1445,23 +1445,43 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
         const int ccE = cin ? cc : ce;
         const unsigned loN = (unsigned)(from_lower ? (cc * ldx + kk) : (kk * ldx + cc)) * 8u;
         const unsigned loE = (unsigned)(from_lower ? (ccE * ldx + kk) : (kk * ldx + ccE)) * 8u;
-        const size_t rstep = from_lower ? (size_t)32 : (size_t)32 * ldx;   // bytes between accumulator rows r -> r + 1
-        int ta = 0, tb = 1 + wi;   // tile index t = s NW + wi as (block row, block column), advanced by NW per slot
+        const unsigned rstep = from_lower ? 32u : 32u * (unsigned)ldx;   // bytes between accumulator rows r -> r + 1
+        // The (block row, block column) of every slot is decoded by ONE lane each (lane s <-> slot s, tile index
+        // t = s NW + wi: row a is the largest a with T(a) <= t, T(a) = a (nb-1) - a (a-1)/2) and read back with
+        // v_readlane: a per-slot scalar search loop plus 64-bit address arithmetic was ~5 k cycles of issue per wavefront.
+        int mytab = -1;
+        {
+            const int t = l * POTRF_NW + wi;
+            if (l < NSLOT && t < nb * (nb - 1) / 2) {
+                const float bq = 2.0f * nb - 1.0f;
+                int a = (int)((bq - __builtin_sqrtf(bq * bq - 8.0f * t)) * 0.5f);
+                a = a < 0 ? 0 : (a > nb - 2 ? nb - 2 : a);
+                while (a > 0 && a * (nb - 1) - a * (a - 1) / 2 > t) --a;
+                while ((a + 1) * (nb - 1) - (a + 1) * a / 2 <= t) ++a;
+                mytab = a | ((a + 1 + (t - (a * (nb - 1) - a * (a - 1) / 2))) << 8);
+            }
+        }
+        unsigned loNr[4], loEr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { loNr[r] = loN + r * rstep; loEr[r] = loE + r * rstep; }
+        const char* Xb = reinterpret_cast<const char*>(X);
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            while (ta < nb - 1 && tb > nb - 1) { const int over = tb - nb; ++ta; tb = ta + 1 + over; }
-            const bool live = ta < nb - 1;
-            tab[s] = live ? (ta | (tb << 8)) : -1;
-            const bool edge = tb == nb - 1;
-            // (an empty slot reads element 0: no branch, and the select below comes after every load has been issued)
-            const char* ub = reinterpret_cast<const char*>(X) +
-                             (!live ? (size_t)0 : (from_lower ? ((size_t)(16 * tb) * ldx + 16 * ta) : ((size_t)(16 * ta) * ldx + 16 * tb)) * 8);
-            const unsigned lo = !live ? 0u : (edge ? loE : loN);
-            const size_t rs = live ? rstep : (size_t)0;
+            tab[s] = __builtin_amdgcn_readlane(mytab, s);
+            acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+            if (tab[s] >= 0) {   // (wave-uniform)
+                const int ta = tab[s] & 255, tb = tab[s] >> 8;
+                const unsigned off = (unsigned)(from_lower ? (16 * tb) * ldx + 16 * ta : (16 * ta) * ldx + 16 * tb) * 8u;
+                if (tb == nb - 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[s][r] = *reinterpret_cast<const double*>(ub + r * rs + lo);
-            tb += POTRF_NW;
+                    for (int r = 0; r < 4; ++r) acc[s][r] = *reinterpret_cast<const double*>(Xb + (size_t)(off + loEr[r]));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[s][r] = *reinterpret_cast<const double*>(Xb + (size_t)(off + loNr[r]));
+                }
+            }
         }
+        POTRF_STAMP(wave == 1 ? 1 : 3, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
@@ -1671,9 +1691,10 @@ struct FrontGramArgs {
     int chunks, rows_per_chunk;   // T3 row chunks of this launch (<= 8 x 80 rows each: one batch of loads per wavefront)
     double* Gpart; double* S; const int* clone_rows;
     int* counter;                 // zero between launches (the last workgroup through resets it)
+    int* lost;                    // incremented if a wait gives up (reported as an error by the host)
     double* A_dst; int cb0;
 };
-__device__ __forceinline__ void front_grid_barrier(int* counter, int target, unsigned long long* dbg = nullptr) {
+__device__ __forceinline__ void front_grid_barrier(int* counter, int target, int* lost, unsigned long long* dbg = nullptr) {
     // Everything that crosses this barrier is written with write-through (sc1) stores and read with sc1 loads
     // (st_pub / ld_sel<true>), so no cache write-back or invalidate is needed: every wavefront waits for its own stores
     // to be acknowledged, one thread bumps the counter and polls it.  (A release/acquire fence pair per workgroup --
@@ -1687,7 +1708,11 @@ __device__ __forceinline__ void front_grid_barrier(int* counter, int target, uns
         int* flag = counter + 32;
         const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == target - 1) __hip_atomic_store(flag, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
+        else {   // bounded (~0.5 s): a workgroup that never arrives must not hang the GPU; the update is then flagged
+            int it = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && it < (1 << 22)) { __builtin_amdgcn_s_sleep(4); ++it; }
+            if (it >= (1 << 22) && lost) atomicAdd(lost, 1);
+        }
     }
     __syncthreads();
 }
@@ -1713,7 +1738,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     unsigned long long* stamp = reinterpret_cast<unsigned long long*>(g.counter) + 8;   // diagnostic (bytes 64..): 100 MHz clock
 #define FRONT_STAMP(i) do { if (me == 0 && threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
     FRONT_STAMP(1);
-    front_grid_barrier(g.counter, nfb);
+    front_grid_barrier(g.counter, nfb, g.lost);
     FRONT_STAMP(2);
     // ---- Grams: (lower tile, chunk) items of T3, then one item per clone of the sparse rows -----------------
     const int nb = p.NAP >> 4, ntiles = nb * (nb + 1) / 2;
@@ -1737,7 +1762,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     FRONT_STAMP(3);
     int phases = 2;
     if (g.enabled == 1) {   // (enabled == 2: the consumer, k_gemm_asmA, assembles A on the fly)
-        front_grid_barrier(g.counter, 2 * nfb, me == 0 ? stamp + 7 : nullptr);
+        front_grid_barrier(g.counter, 2 * nfb, g.lost, me == 0 ? stamp + 7 : nullptr);
         FRONT_STAMP(4);
         // ---- A = scatter(S) - sum of the partial Grams --------------------------------------------------------
         for (int idx = me * 512 + (int)threadIdx.x; idx < p.NAP * p.NAP; idx += nfb * 512)
