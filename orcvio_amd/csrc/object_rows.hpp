@@ -48,8 +48,7 @@ __device__ __forceinline__ void mat4_vec(const double* T, const double* x, doubl
     for (int i = 0; i < 4; ++i) y[i] = T[i * 4] * x[0] + T[i * 4 + 1] * x[1] + T[i * 4 + 2] * x[2] + T[i * 4 + 3] * x[3];
 }
 
-__global__ __launch_bounds__(64) void k_object_rows(ObjEvalArgs p) {
-    const int f = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int f, const int t) {
     const int clone = p.frame_clone[f];
     if (clone < 0) return;
     const int K = p.K;
@@ -222,6 +221,16 @@ __global__ __launch_bounds__(64) void k_object_rows(ObjEvalArgs p) {
         }
         emit(row0 + 2 * nvalid + j, r, jc, hp, hs, 0, nullptr);
     }
+}
+
+// one object per launch (grid = its frames) ...
+__global__ __launch_bounds__(64) void k_object_rows(ObjEvalArgs p) { object_rows_body(p, blockIdx.x, threadIdx.x); }
+// ... or every object of an update in one launch: grid (most frames of any object, objects), the arguments of object
+// blockIdx.y from a device array (wave-uniform: scalar loads)
+__global__ __launch_bounds__(64) void k_object_rows_batch(const ObjEvalArgs* __restrict__ args) {
+    const ObjEvalArgs p = args[blockIdx.y];
+    if ((int)blockIdx.x >= p.F) return;
+    object_rows_body(p, blockIdx.x, threadIdx.x);
 }
 
 }  // namespace orcvio_amd
