@@ -500,6 +500,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->ran = false;
     h->graph_valid = false;
     h->skip_active = false;
+    h->objects_mode = false;   // (a staged object update may have left it set)
     h->pw_missing = (F > 0 && !tr->p_w);
     return ORCVIO_OK;
 }
