@@ -227,6 +227,8 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
     auto* h = new orcvio_msckf_handle();
     h->device = device;
     h->n_cus = prop.multiProcessorCount;
+    if (const char* e = getenv("ORCVIO_FUSED_SOLVE")) h->fused_solve = atoi(e);   // diagnostics: defaults of the options
+    if (const char* e = getenv("ORCVIO_FUSED_FRONT")) h->front_fused = atoi(e);
     h->maxN = max_clones;
     h->maxF = max_features;
     h->maxObs = max_observations;
