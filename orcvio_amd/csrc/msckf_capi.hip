@@ -1094,7 +1094,9 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
                        h->flags.leg_dim, NA, NAP, W, h->d_Xaug);
     {
         const int nbw = W / 16, ntiles = nbw * (nbw + 1) / 2;
-        hipLaunchKernelGGL(k_gram_chunks16, dim3(ntiles, nobj), dim3(1024), 0, s, h->d_Xaug, W, (const int*)sc.d_chunk, h->d_Gobj);
+        // (one wavefront per (tile, object): this Gram re-reads both operand column blocks for every tile and is bound by
+        // that L2 traffic, not by latency -- 16 wavefronts per tile, as in k_gram_pair, measured 50 us against 45)
+        hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, nobj), dim3(256), 0, s, h->d_Xaug, rows_tot, W, 0, h->d_Gobj, sc.d_chunk);
     }
     // F_o = Hf^T Hf (lower tiles of the bottom-right block) -> R_F ; Y_o = L_F^-1 C_o
     {

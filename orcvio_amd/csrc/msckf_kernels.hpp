@@ -926,15 +926,6 @@ __global__ __launch_bounds__(1024) void k_gram_pair(const double* __restrict__ T
     }
 }
 
-// one Gram per ragged row chunk (one chunk per object: the object update), 1024-thread workgroups as k_gram_pair:
-// workgroup (lower tile, chunk), the sixteen wavefronts split the rows of the chunk
-__global__ __launch_bounds__(1024) void k_gram_chunks16(const double* __restrict__ X, int ld, const int* __restrict__ chunk_ptr,
-                                                        double* __restrict__ Gpart) {
-    int bi, bj;
-    tile_from_linear(blockIdx.x, bi, bj);
-    gram16_body(X, ld, chunk_ptr[blockIdx.y], chunk_ptr[blockIdx.y + 1], bi, bj, Gpart + (size_t)blockIdx.y * ld * ld, ld);
-}
-
 // Sums `nparts` blocks into dst (full symmetric result); used for the chunk partials of one
 // rank (lower tiles valid) and for the all-gathered blocks of all ranks.
 __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ parts, int nparts, size_t part_stride,
