@@ -266,6 +266,15 @@ def test_fused_front_track_counts(upd, F):
     _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
 
 
+@pytest.mark.parametrize('N,leg', [(31, 22), (33, 22), (26, 46), (29, 46)])
+def test_fused_front_wide_windows(upd, N, leg):
+    """The widest windows of the register path (n up to 224): four 64-column passes in the feature teams, NA > 192 so
+    the assembly stays inside k_front (k_gemm_asmA needs NA <= 192), and the 46-dimensional legacy block."""
+    w = synth.make_window(N=N, F=90, seed=400 + N, track_len=(3, min(N, 20)), flags=synth.Flags(use_larvio=1, leg_dim=leg))
+    assert w.n <= 224
+    _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
+
+
 def test_large_window_takes_the_lds_panel_path(upd):
     """N = 38 clones: n = 250 > 224, so both factorisations use the LDS-panel kernel (k_potrf) and the solve k_trsm_rl
     instead of the register-resident / fused kernels."""
