@@ -139,7 +139,12 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
 /* ORCVIO_OPT_FUSED_FRONT (default 1): the Cholesky of the prior runs as workgroup 0 of the feature launch (k_front)
  * whenever the whole front end is co-resident (n <= 224, 1 + ceil(F/2) workgroups <= compute units); 0 = always fork
  * it to the handle's side stream around k_feature.  Same kernels' bodies, same arithmetic. */
-enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3 };
+/* ORCVIO_OPT_EXTRA_STATES (default 0): number of state columns BEHIND the clones that no row of the update touches --
+ * the EKF-SLAM feature states (and Schmidt nuisance states) the reference keeps at the end of state_cov when
+ * max_features_in_one_grid > 0 (src/orcvio.cpp:1495-1510): its H_msckf then has zero columns there
+ * (featureJacobian_msckf builds its rows state_cov.cols() wide, :1191-1192) and the update still moves those states and
+ * their covariance through the cross terms.  With value k, P / P_out are (LEG + 6N + k)^2 and dx has that length. */
+enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* Feature update: replaces the loop + compression + update of

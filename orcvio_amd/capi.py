@@ -187,6 +187,7 @@ class MsckfUpdater:
         self._keep = None
         self.n = None
         self.F = None
+        self.n_extra = 0
 
     def set_materialize_stack(self, on: bool):
         """ORCVIO_OPT_MATERIALIZE_STACK: also write the stacked projected blocks [H' | r'] (debug_read 'Hs')."""
@@ -205,6 +206,13 @@ class MsckfUpdater:
         rc = self.lib.orcvio_msckf_set_option(self.h, 3, int(bool(on)))
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_set_option')
+
+    def set_extra_states(self, k: int):
+        """ORCVIO_OPT_EXTRA_STATES: k state columns behind the clones (EKF-SLAM feature states) untouched by the rows."""
+        rc = self.lib.orcvio_msckf_set_option(self.h, 4, int(k))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_set_option')
+        self.n_extra = int(k)
 
     def close(self):
         if self.h:
@@ -273,7 +281,7 @@ class MsckfUpdater:
     def update_objects(self, flags, n_clones, blocks, P, want_G=False):
         """blocks: list of dict(row_clone [rows] int32, Hx6 [rows,6], Hf [rows,no], res [rows])."""
         fl = make_flags(flags)
-        n = flags.leg_dim + 6 * n_clones
+        n = flags.leg_dim + 6 * n_clones + self.n_extra
         keep = []
         arr = (MsckfObjectRows * max(len(blocks), 1))()
         for k, b in enumerate(blocks):
@@ -316,7 +324,7 @@ class MsckfUpdater:
                                                  C.c_void_p(stream) if stream else None)
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_objects_local')
-        self.n = flags.leg_dim + 6 * n_clones
+        self.n = flags.leg_dim + 6 * n_clones + self.n_extra
         return int(dof.value)
 
     def objects_finish(self, d_blocks, n_blocks, dof_total, stream=None):
@@ -389,7 +397,7 @@ class MsckfUpdater:
         """removeLostObjects straight from object tracks (synth.ObjectTrack-shaped): rows evaluated on the device."""
         fl = make_flags(flags)
         ef, arr, keep = self._object_tracks(objs, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D)
-        n = flags.leg_dim + 6 * n_clones
+        n = flags.leg_dim + 6 * n_clones + self.n_extra
         Pc = None if P is None else np.ascontiguousarray(P, dtype=np.float64)
         out, res = self._result(n, 1, False, want_G, False)
         rc = self.lib.orcvio_msckf_update_object_tracks(self.h, C.byref(fl), C.byref(ef), n_clones, arr, len(objs), _d(Pc), C.byref(res))

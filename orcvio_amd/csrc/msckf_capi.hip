@@ -77,6 +77,7 @@ struct orcvio_msckf_handle {
     int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_info = nullptr;
     double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_A = nullptr;
     int front_fused = 1;                // ORCVIO_OPT_FUSED_FRONT
+    int n_extra = 0;                    // ORCVIO_OPT_EXTRA_STATES
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     bool A_deferred = false;            // the last run left S / Gpart only: d_A is assembled on demand (assemble_deferred)
     int front_chunks = 1;               // T3 row chunks of the last k_front launch
@@ -371,6 +372,12 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
         h->graph_valid = false;
         return ORCVIO_OK;
     }
+    if (option == ORCVIO_OPT_EXTRA_STATES) {
+        if (value < 0 || 22 + 6 + value > h->n_max) { g_last_error = "orcvio_msckf_set_option: extra states out of range"; return ORCVIO_ERR_INVALID; }
+        h->n_extra = value;   // takes effect with the next upload / update call
+        h->graph_valid = false;
+        return ORCVIO_OK;
+    }
     g_last_error = "orcvio_msckf_set_option: unknown option";
     return ORCVIO_ERR_INVALID;
 }
@@ -412,8 +419,9 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     HIPCHK(hipSetDevice(h->device));
     h->flags = *flags;
     h->N = N; h->F = F; h->nobs = nobs;
-    h->n = flags->leg_dim + 6 * N;
-    h->NA = h->n - 15;
+    h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
+    h->NA = flags->leg_dim + 6 * N - 15;
+    if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);
     h->ldz = round_up(h->n + 1, 16);
@@ -1135,8 +1143,9 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     const int N = n_clones;
     h->flags = *flags;
     h->N = N; h->F = 0; h->nobs = 0;
-    h->n = flags->leg_dim + 6 * N;
-    h->NA = h->n - 15;
+    h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
+    h->NA = flags->leg_dim + 6 * N - 15;
+    if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);
     h->ldz = round_up(h->n + 1, 16);
@@ -1223,8 +1232,9 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     const int N = n_clones;
     h->flags = *flags;
     h->N = N; h->F = 0; h->nobs = 0;
-    h->n = flags->leg_dim + 6 * N;
-    h->NA = h->n - 15;
+    h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
+    h->NA = flags->leg_dim + 6 * N - 15;
+    if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);
     h->ldz = round_up(h->n + 1, 16);

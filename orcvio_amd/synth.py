@@ -69,6 +69,7 @@ class Window:
     obs_zvel: np.ndarray   # [nobs,2]
     P: np.ndarray          # [n,n] symmetric
     flags: Flags
+    n_extra: int = 0       # state columns behind the clones that no row touches (EKF-SLAM feature states)
 
     @property
     def N(self):
@@ -80,7 +81,7 @@ class Window:
 
     @property
     def n(self):
-        return self.flags.leg_dim + 6 * self.N
+        return self.flags.leg_dim + 6 * self.N + self.n_extra
 
 
 def make_prior_cov(N: int, rng: np.random.Generator, leg_dim: int = LEG_DIM,
@@ -110,6 +111,23 @@ def make_prior_cov(N: int, rng: np.random.Generator, leg_dim: int = LEG_DIM,
     if leg_dim > 22:
         pass  # IMU-intrinsic block keeps its generic SPD values
     return 0.5 * (P + P.T)
+
+
+def with_extra_states(win: "Window", k: int, seed: int = 0) -> "Window":
+    """The same window with k more states behind the clones (inverse-depth feature states of the hybrid filter,
+    src/orcvio.cpp:1495-1510): a new SPD prior of the larger size whose clone / IMU block keeps the structure of
+    make_prior_cov (zero rows for the states that are not estimated) and whose cross terms are dense."""
+    rng = np.random.default_rng(10_000 + seed)
+    n0 = win.n - win.n_extra
+    n = n0 + k
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    P = 1e-4 * (A @ A.T)
+    P[:n0, :n0] += np.diag(np.diag(win.P))
+    P[n0:, n0:] += np.diag(np.full(k, 2.5e-3))   # ~ (0.05 1/m)^2 inverse-depth variance
+    zero = np.where(np.diag(win.P) == 0.0)[0]
+    P[zero, :] = 0.0
+    P[:, zero] = 0.0
+    return dataclasses.replace(win, P=np.ascontiguousarray(0.5 * (P + P.T)), n_extra=k)
 
 
 def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,

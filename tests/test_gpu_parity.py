@@ -275,6 +275,25 @@ def test_fused_front_wide_windows(upd, N, leg):
     _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
 
 
+@pytest.mark.parametrize('k', [1, 3, 9, 24])
+def test_extra_states_behind_the_clones(upd, k):
+    """ORCVIO_OPT_EXTRA_STATES: the covariance carries k more states behind the clones (the EKF-SLAM feature states of
+    the hybrid filter); the reference's featureJacobian_msckf builds its rows state_cov.cols() wide with zeros there
+    (src/orcvio.cpp:1191-1192) and the update moves those states through the cross-covariances.  Oracle: the literal
+    numpy restatement on the wider state."""
+    from oracle import mirror
+    w = synth.with_extra_states(synth.make_window(N=9, F=40, seed=70 + k, track_len=(3, 9)), k, seed=k)
+    assert w.P.shape[0] == 22 + 54 + k
+    upd.set_extra_states(k)
+    try:
+        got = upd.update_features(w, want_G=True)
+    finally:
+        upd.set_extra_states(0)
+    ref = mirror.msckf_update(w)
+    _compare(got, ref, w)
+    assert np.linalg.norm(ref['dx'][-k:]) > 0   # the extra states do move
+
+
 def test_large_window_takes_the_lds_panel_path(upd):
     """N = 38 clones: n = 250 > 224, so both factorisations use the LDS-panel kernel (k_potrf) and the solve k_trsm_rl
     instead of the register-resident / fused kernels."""
