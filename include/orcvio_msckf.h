@@ -144,8 +144,36 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * max_features_in_one_grid > 0 (src/orcvio.cpp:1495-1510): its H_msckf then has zero columns there
  * (featureJacobian_msckf builds its rows state_cov.cols() wide, :1191-1192) and the update still moves those states and
  * their covariance through the cross terms.  With value k, P / P_out are (LEG + 6N + k)^2 and dx has that length. */
-enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4 };
+/* ORCVIO_OPT_EKF_ROWS (default 0): the next uploads may be followed by orcvio_msckf_upload_ekf_rows -- the extra states
+ * are then active columns of the compressed block (the rows of the SLAM features reach into them). */
+enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
+       ORCVIO_OPT_EKF_ROWS = 5 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
+
+/* EKF-SLAM rows of the hybrid filter (existing SLAM features).  For every SLAM feature the current
+ * state observes, the reference evaluates featureJacobian_ekf (src/orcvio.cpp:1575-1651: measurementJacobian_ekf_3didp
+ * :1229-1353 or _1didp :1356-1478), gates the row pair with 2 degrees of freedom (:2457) and stacks what passed under
+ * the MSCKF rows for ONE update (measurementUpdate_hybrid, :1766-1950).  The rows come in the compact form of those
+ * functions' outputs; gate and stacking happen on the device.  Call order: set_option(ORCVIO_OPT_EXTRA_STATES, k),
+ * set_option(ORCVIO_OPT_EKF_ROWS, 1), upload(...) [P is (LEG+6N+k)^2], upload_ekf_rows, run_update, download,
+ * download_ekf.  The rows belong to the upload they follow.  New features (the H_1 / H_2 initialisation) stay with the
+ * caller. */
+typedef struct orcvio_msckf_ekf_rows {
+    int32_t n_features;
+    int32_t idp_dim;         /* feature_idp_dim: 3 (invParam) or 1 (invDepth)                               */
+    const int32_t* anchor;   /* [F] anchor clone (index in the window, Feature::id_anchor)                  */
+    const int32_t* state;    /* [F] observing clone (state_server.imu_state.id)                             */
+    const int32_t* slot;     /* [F] position in feature_states: columns LEG + 6N + idp_dim*slot ...         */
+    const double* H_e;       /* [F][2][6]  -> columns 15..20 (:1641)                                        */
+    const double* H_a;       /* [F][2][6]  -> the anchor clone (:1639)                                      */
+    const double* H_x;       /* [F][2][6]  -> the observing clone (:1640)                                   */
+    const double* H_f;       /* [F][2][idp_dim] -> the feature's own columns (:1630, :1636)                 */
+    const double* z_vel;     /* [F][2] observations_vel -> column 21 under estimate_td (:1642), else unused  */
+    const double* r;         /* [F][2]                                                                      */
+} orcvio_msckf_ekf_rows;
+int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_ekf_rows* rows);
+/* gamma[F], accept[F] of the SLAM features of the last update (either may be NULL) */
+int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept);
 
 /* Feature update: replaces the loop + compression + update of
  * OrcVIO::removeLostFeatures (src/orcvio.cpp:2497-2560) and of

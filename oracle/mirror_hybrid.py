@@ -1,0 +1,151 @@
+"""TEST INFRASTRUCTURE ONLY -- literal numpy restatement of the EKF-SLAM rows of the reference's hybrid filter and of
+the joint update with them (existing SLAM features; the H_1 / H_2 initialisation of new ones is not restated here).
+
+Follows src/orcvio.cpp:
+  measurementJacobian_ekf_3didp   :1229-1353
+  measurementJacobian_ekf_1didp   :1356-1478
+  featureJacobian_ekf             :1575-1651  (one observation, the current IMU state; anchor inside the window)
+  removeLostFeatures, EKF part    :2444-2464  (gatingTestFeature(H_xj, r_j, 2) per SLAM feature, then stacking)
+  measurementUpdate_hybrid        :1766-1950  (case sz_new == 0: H_o = [H_msckf; H_ekf], K, dx, (I - K H) P)
+State layout: [legacy LEG | clones 6N | feature states d each] (:1495-1510 without Schmidt nuisance states).
+Parity unpinned: the reference has no test of these functions; anchored on its text and on central differences
+(tests/test_oracle_hybrid.py).  Nothing under orcvio_amd/ may import this module.
+"""
+import dataclasses
+
+import numpy as np
+
+from . import mirror
+from .mirror import skew
+
+
+@dataclasses.dataclass
+class SlamFeature:
+    """One EKF-SLAM feature as Feature holds it (include/orcvio/feat/feature.hpp): anchor clone, inverse-depth
+    parametrisation in the anchor CAMERA frame, world position, and its observation in the current state."""
+    anchor: int            # index of the anchor clone in the window (id_anchor)
+    state: int             # index of the observing clone (state_server.imu_state.id: the newest clone)
+    inv_param: np.ndarray  # [3] (x/z, y/z, 1/z) in the anchor camera frame            (3-d idp: invParam)
+    obs_anchor: np.ndarray # [3] (u, v, 1) corrected observation in the anchor frame    (1-d idp: obs_anchor)
+    inv_depth: float       #                                                             (1-d idp: invDepth)
+    p_w: np.ndarray        # [3] Feature::position
+    z: np.ndarray          # [2] observation in the current state
+    z_vel: np.ndarray      # [2] observations_vel (used under estimate_td)
+    p_fej: np.ndarray = None   # position_FEJ (if_FEJ)
+
+
+def _poses(win, k, a):
+    R_b2c, t_c_b = win.R_b2c[k], win.t_c_b[k]
+    R_w2bk = win.R_b2w[k].T
+    t_bk_w = win.t_b_w[k]
+    R_w2ck = R_b2c @ R_w2bk
+    t_ck_w = t_bk_w + win.R_b2w[k] @ t_c_b
+    R_w2ba = win.R_b2w[a].T
+    t_ba_w = win.t_b_w[a]
+    R_w2ca = R_b2c @ R_w2ba
+    return R_b2c, t_c_b, R_w2bk, t_bk_w, R_w2ck, t_ck_w, R_w2ba, t_ba_w, R_w2ca
+
+
+def measurement_jacobian_ekf(win, ft: SlamFeature, idp_dim: int):
+    """(H_f [2,d], H_a [2,6], H_x [2,6], H_e [2,6], r [2]) -- :1229-1353 (d = 3) / :1356-1478 (d = 1)."""
+    f = win.flags
+    k, a = ft.state, ft.anchor
+    R_b2c, t_c_b, R_w2bk, t_bk_w, R_w2ck, t_ck_w, R_w2ba, t_ba_w, R_w2ca = _poses(win, k, a)
+    fej = bool(f.if_fej)
+    p_fej = ft.p_fej if ft.p_fej is not None else ft.p_w
+    if fej:                                                     # :1281-1282 / :1410-1411
+        p_ca = R_b2c @ (R_w2ba @ (p_fej - win.t_fej[a]) - t_c_b)
+    elif idp_dim == 3:
+        p_ca = np.array([ft.inv_param[0] / ft.inv_param[2], ft.inv_param[1] / ft.inv_param[2], 1.0 / ft.inv_param[2]])
+    else:
+        p_ca = np.array([ft.obs_anchor[0] / ft.inv_depth, ft.obs_anchor[1] / ft.inv_depth, 1.0 / ft.inv_depth])
+    p_ck = R_w2ck @ (ft.p_w - t_ck_w)                           # :1295-1296
+    r = ft.z - np.array([p_ck[0] / p_ck[2], p_ck[1] / p_ck[2]])   # :1299
+    d = idp_dim
+    if k == a:                                                  # :1302-1310 / :1432-1440
+        H_f = np.zeros((2, d))
+        if d == 3:
+            H_f[0, 0] = 1.0
+            H_f[1, 1] = 1.0
+        else:
+            r = np.zeros(2)
+        return H_f, np.zeros((2, 6)), np.zeros((2, 6)), np.zeros((2, 6)), r
+    J_k = np.zeros((2, 3))                                      # :1312-1316
+    J_k[0, 0] = 1 / p_ck[2]
+    J_k[1, 1] = 1 / p_ck[2]
+    J_k[0, 2] = -p_ck[0] / (p_ck[2] * p_ck[2])
+    J_k[1, 2] = -p_ck[1] / (p_ck[2] * p_ck[2])
+    p_baf_w = (p_fej - win.t_fej[a]) if fej else (ft.p_w - t_ba_w)   # :1320-1323
+    p_bkf_w = (p_fej - win.t_fej[k]) if fej else (ft.p_w - t_bk_w)
+    J_xa = np.zeros((3, 6))                                     # :1325-1327
+    J_xa[:, :3] = -R_w2ck @ skew(p_baf_w)
+    J_xa[:, 3:] = R_w2ck
+    J_xk = np.zeros((3, 6))                                     # :1329-1331
+    J_xk[:, :3] = R_w2ck @ skew(p_bkf_w)
+    J_xk[:, 3:] = -R_w2ck
+    J_e = np.zeros((3, 6))                                      # :1333-1337
+    SkewMx = skew(R_w2bk @ p_bkf_w - t_c_b)
+    Mx = R_w2bk @ R_w2ba.T @ skew(R_b2c.T @ p_ca)
+    J_e[:, :3] = R_b2c @ (SkewMx - Mx)
+    J_e[:, 3:] = R_b2c @ (R_w2bk @ R_w2ba.T - np.eye(3))
+    if d == 3:                                                  # :1318, :1339-1345
+        J_p = R_w2ck @ R_w2ca.T
+        fc = ft.inv_param
+        J_f = np.eye(3)
+        J_f[0, 2] = -fc[0] / fc[2]
+        J_f[1, 2] = -fc[1] / fc[2]
+        J_f[2, 2] = -1 / fc[2]
+        J_f = J_f / fc[2]
+        H_f = J_k @ J_p @ J_f
+    else:                                                       # :1447, :1469-1471
+        J_d = R_w2ck @ R_w2ca.T @ ft.obs_anchor
+        J_rho = -1 / (ft.inv_depth * ft.inv_depth)
+        H_f = (J_k @ J_d * J_rho).reshape(2, 1)
+    return H_f, J_k @ J_xa, J_k @ J_xk, J_k @ J_e, r
+
+
+def feature_jacobian_ekf(win, ft: SlamFeature, idx: int, idp_dim: int):
+    """:1575-1651 -- the two rows of SLAM feature number idx over the whole state (width win.n)."""
+    f = win.flags
+    H = np.zeros((2, win.n))
+    H_f, H_a, H_x, H_e, r = measurement_jacobian_ekf(win, ft, idp_dim)
+    fi = f.leg_dim + 6 * win.N + idp_dim * idx                  # :1612
+    H[:, fi:fi + idp_dim] = H_f                                 # :1630 / :1636
+    H[:, f.leg_dim + 6 * ft.anchor: f.leg_dim + 6 * ft.anchor + 6] = H_a   # :1639 (assignment order as the reference:
+    H[:, f.leg_dim + 6 * ft.state: f.leg_dim + 6 * ft.state + 6] = H_x     # :1640  a later block overwrites an earlier one)
+    H[:, 15:21] = H_e                                           # :1641
+    if f.estimate_td:
+        H[:, 21] = ft.z_vel                                     # :1642-1643
+    return H, r
+
+
+def hybrid_update(win, slam, idp_dim: int, table=None):
+    """removeLostFeatures with SLAM features in the state and none being initialised (:2444-2560): the MSCKF blocks as
+    mirror.msckf_update builds and gates them, the SLAM rows gated one feature at a time with 2 degrees of freedom,
+    one update with everything that passed."""
+    f = win.flags
+    sigma2 = f.noise_feature ** 2
+    table = mirror.chi2_table(f.chi2_prob) if table is None else table
+    base = mirror.msckf_update(win, table=table)
+    acc_blocks = [b for b, a in zip(base['blocks'], base['accept']) if a]
+    acc_rs = [b for b, a in zip(base['rs'], base['accept']) if a]
+    eg, ea, erows = [], [], []
+    for idx, ft in enumerate(slam):
+        H, r = feature_jacobian_ekf(win, ft, idx, idp_dim)
+        g = mirror.gating_gamma(H, r, win.P, sigma2)            # :2457 gatingTestFeature(H_xj, r_j, 2)
+        ok = g < mirror.chi2_threshold(2, f.chi2_prob, table)
+        eg.append(g); ea.append(int(ok)); erows.append((H, r))
+        if ok:
+            acc_blocks.append(H); acc_rs.append(r)
+    out = dict(gamma=base['gamma'], accept=base['accept'], ekf_gamma=np.array(eg), ekf_accept=np.array(ea, dtype=np.int32),
+               ekf_rows=erows)
+    n = win.n
+    if not acc_blocks:
+        out.update(dx=np.zeros(n), P_new=win.P.copy(), G=np.zeros((n, n)))
+        return out
+    H = np.vstack(acc_blocks)
+    r = np.concatenate(acc_rs)
+    H_thin, r_thin = mirror.qr_compress(H, r)
+    dx, K, Pn = mirror.measurement_update(H_thin, r_thin, win.P, sigma2)
+    out.update(dx=dx, P_new=Pn, G=K @ H_thin)
+    return out

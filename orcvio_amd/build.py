@@ -9,7 +9,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB = os.path.join(LIB_DIR, 'liborcvio_msckf.so')
 SOURCES = ['msckf_capi.hip']
-DEPS = ['msckf_capi.hip', 'msckf_kernels.hpp', 'msckf_math.hpp', 'object_rows.hpp', 'triangulate.hpp', 'cov_ops.hpp',
+DEPS = ['msckf_capi.hip', 'msckf_kernels.hpp', 'msckf_math.hpp', 'object_rows.hpp', 'triangulate.hpp', 'cov_ops.hpp', 'ekf_rows.hpp',
         os.path.join('..', '..', 'include', 'orcvio_msckf.h')]
 
 

@@ -34,6 +34,7 @@ EXPORTS = [
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
+    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf',
 ]
 
 
@@ -170,6 +171,14 @@ def _i(a):
     return None if a is None else a.ctypes.data_as(_ip)
 
 
+class EkfRows(C.Structure):
+    """orcvio_msckf_ekf_rows (include/orcvio_msckf.h)."""
+    _fields_ = [('n_features', C.c_int32), ('idp_dim', C.c_int32),
+                ('anchor', C.POINTER(C.c_int32)), ('state', C.POINTER(C.c_int32)), ('slot', C.POINTER(C.c_int32)),
+                ('H_e', C.POINTER(C.c_double)), ('H_a', C.POINTER(C.c_double)), ('H_x', C.POINTER(C.c_double)),
+                ('H_f', C.POINTER(C.c_double)), ('z_vel', C.POINTER(C.c_double)), ('r', C.POINTER(C.c_double))]
+
+
 def make_flags(f) -> MsckfFlags:
     return MsckfFlags(int(f.leg_dim), int(f.use_larvio), int(f.use_left_perturbation), int(f.if_fej),
                       int(f.estimate_td), int(f.discard_large_update), float(f.noise_feature), float(f.chi2_prob))
@@ -206,6 +215,34 @@ class MsckfUpdater:
         rc = self.lib.orcvio_msckf_set_option(self.h, 3, int(bool(on)))
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_set_option')
+
+    def set_ekf_rows_mode(self, on: bool):
+        """ORCVIO_OPT_EKF_ROWS: the extra states become active columns (upload_ekf_rows may follow an upload)."""
+        rc = self.lib.orcvio_msckf_set_option(self.h, 5, int(bool(on)))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_set_option')
+
+    def upload_ekf_rows(self, idp_dim, anchor, state, slot, H_e, H_a, H_x, H_f, r, z_vel=None):
+        """Row pairs of the SLAM features the current state observes, as featureJacobian_ekf produces them."""
+        F = len(anchor)
+        ia = [np.ascontiguousarray(a, dtype=np.int32) for a in (anchor, state, slot)]
+        da = [np.ascontiguousarray(a, dtype=np.float64) for a in (H_e, H_a, H_x, H_f, r)]
+        zv = None if z_vel is None else np.ascontiguousarray(z_vel, dtype=np.float64)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        rows = EkfRows(F, int(idp_dim), ip(ia[0]), ip(ia[1]), ip(ia[2]), _d(da[0]), _d(da[1]), _d(da[2]), _d(da[3]), _d(zv), _d(da[4]))
+        rc = self.lib.orcvio_msckf_upload_ekf_rows(self.h, C.byref(rows))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_upload_ekf_rows')
+        self._ekf_F = F
+
+    def download_ekf(self):
+        F = getattr(self, '_ekf_F', 0)
+        gamma = np.zeros(F)
+        accept = np.zeros(F, dtype=np.int32)
+        rc = self.lib.orcvio_msckf_download_ekf(self.h, _d(gamma), accept.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_download_ekf')
+        return gamma, accept
 
     def set_extra_states(self, k: int):
         """ORCVIO_OPT_EXTRA_STATES: k state columns behind the clones (EKF-SLAM feature states) untouched by the rows."""

@@ -17,6 +17,7 @@
 #include "msckf_kernels.hpp"
 #include "triangulate.hpp"
 #include "cov_ops.hpp"
+#include "ekf_rows.hpp"
 #include "object_rows.hpp"
 
 using namespace orcvio_amd;
@@ -78,6 +79,14 @@ struct orcvio_msckf_handle {
     double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_A = nullptr;
     int front_fused = 1;                // ORCVIO_OPT_FUSED_FRONT
     int n_extra = 0;                    // ORCVIO_OPT_EXTRA_STATES
+    int ekf_mode = 0;                   // ORCVIO_OPT_EKF_ROWS: the extra states are active columns (EKF-SLAM rows may follow an upload)
+    int ekf_F = 0, ekf_idp = 3;         // SLAM features of the current upload (orcvio_msckf_upload_ekf_rows)
+    int ekf_cap = 0;
+    int* d_ekf_i = nullptr;             // [3 cap] anchor | state | slot
+    double* d_ekf_d = nullptr;          // [46 cap] H_e 12 | H_a 12 | H_x 12 | H_f 6 | z_vel 2 | r 2
+    double* d_ekf_E = nullptr;          // [2 cap][NAP_max] dense accepted rows [H | r]
+    double* d_Gekf = nullptr;           // [NAP_max^2] their Gram (lower tiles)
+    double* d_ekf_gamma = nullptr; int* d_ekf_accept = nullptr;
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     bool A_deferred = false;            // the last run left S / Gpart only: d_A is assembled on demand (assemble_deferred)
     int front_chunks = 1;               // T3 row chunks of the last k_front launch
@@ -192,7 +201,8 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_Pout, h->d_La, h->d_DinvA,
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_obs,
-                    h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync};
+                    h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
+                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -372,6 +382,11 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
         h->graph_valid = false;
         return ORCVIO_OK;
     }
+    if (option == ORCVIO_OPT_EKF_ROWS) {
+        h->ekf_mode = value != 0;   // takes effect with the next upload
+        h->graph_valid = false;
+        return ORCVIO_OK;
+    }
     if (option == ORCVIO_OPT_EXTRA_STATES) {
         if (value < 0 || 22 + 6 + value > h->n_max) { g_last_error = "orcvio_msckf_set_option: extra states out of range"; return ORCVIO_ERR_INVALID; }
         h->n_extra = value;   // takes effect with the next upload / update call
@@ -383,6 +398,7 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
 }
 
 static int factor_layout_clean(orcvio_msckf_handle* h);
+static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s);
 
 // ---- upload --------------------------------------------------------------------------------
 int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
@@ -420,7 +436,8 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->flags = *flags;
     h->N = N; h->F = F; h->nobs = nobs;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
-    h->NA = flags->leg_dim + 6 * N - 15;
+    h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
+    h->ekf_F = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);
@@ -586,7 +603,7 @@ static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_
     h->front_chunks = g.chunks;
     g.rows_per_chunk = round_up((t3rows + g.chunks - 1) / g.chunks, 4);
     g.Gpart = h->d_Gpart; g.S = h->d_S; g.clone_rows = h->d_clone_ptr; g.counter = h->d_sync; g.lost = h->d_info + 8;
-    g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15;
+    g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15; g.plus = h->ekf_F > 0 ? h->d_Gekf : nullptr;
     if (g.enabled && g.chunks > h->gram_chunks_cap) { g_last_error = "launch_front: too many row chunks"; return ORCVIO_ERR_CAPACITY; }
     dim3 grid(1 + (h->F + 1) / 2), block(512);
     // the window width fixes both template arguments: NPASS = ceil(NAP/64) column passes, and enough register slots
@@ -631,7 +648,7 @@ static int launch_assemble(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
     const int total = h->NAP * h->NAP;
     hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->F > 0 ? h->N : 0,
                        h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->chunks, (size_t)total, dst,
-                       getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0);
+                       getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0, h->ekf_F > 0 ? h->d_Gekf : (const double*)nullptr);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -641,7 +658,8 @@ static int assemble_deferred(orcvio_msckf_handle* h, hipStream_t s) {
     if (!h->A_deferred) return ORCVIO_OK;
     const int total = h->NAP * h->NAP;
     hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->F > 0 ? h->N : 0,
-                       h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->front_chunks, (size_t)total, h->d_A, 0);
+                       h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->front_chunks, (size_t)total, h->d_A, 0,
+                       h->ekf_F > 0 ? h->d_Gekf : (const double*)nullptr);
     HIPCHK(hipGetLastError());
     h->A_deferred = false;
     return ORCVIO_OK;
@@ -740,7 +758,8 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
             return launch_potrf(h, s, h->d_P, n, n, 8.0 * eps, h->d_RP, h->d_DinvP, h->d_info);
         case ST_FORM_U:    // U[(NA+1) x n] = [A; b^T] * L_a
             if (h->A_deferred) {   // A = scatter(S) - sum Gpart assembled inside the product (k_front left the Grams only)
-                AsmArgs aa{h->d_S, h->N, h->flags.leg_dim - 15, NA, NAP, h->d_Gpart, h->front_chunks, (size_t)NAP * NAP, getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0};
+                AsmArgs aa{h->d_S, h->N, h->flags.leg_dim - 15, NA, NAP, h->d_Gpart, h->front_chunks, (size_t)NAP * NAP, getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0,
+                           h->ekf_F > 0 ? h->d_Gekf : nullptr};
                 const int tiles = ((NA + 1 + 15) / 16) * ((n + 15) / 16);
                 hipLaunchKernelGGL(k_gemm_asmA, dim3(tiles), dim3(256), 0, s, aa, La, sLi, sLj, NA + 1, n, NA, h->d_U, (long)NP, 1L, (int*)nullptr);
                 HIPCHK(hipGetLastError());
@@ -810,7 +829,7 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
     mix(h->N); mix(h->F); mix(h->nobs); mix(h->Mmax); mix(h->chunks); mix(h->s_chunks); mix(h->rows_per_chunk);
     mix(h->flags.leg_dim); mix(h->flags.use_larvio); mix(h->flags.use_left_perturbation); mix(h->flags.if_fej);
-    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->front_fused); mix(h->feat_ablate);
+    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->front_fused); mix(h->feat_ablate); mix(h->ekf_F); mix(h->ekf_mode); mix(h->n_extra);
     unsigned long long bits;
     double sg = h->flags.noise_feature;
     std::memcpy(&bits, &sg, 8); mix(bits);
@@ -855,6 +874,7 @@ static int run_with_graph(orcvio_msckf_handle* h, orcvio_msckf_handle::GraphSlot
 // joined by run_finish, so it overlaps the feature kernels AND the collective), the rest replays from a graph
 static int run_local_impl(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
     h->last_stream = s;
+    { const int re = launch_ekf(h, s); if (re != ORCVIO_OK) return re; }
     if (front_fused_active(h)) return launch_front(h, s, dst);   // one launch: tracks, compression, and the prior's factor
     int rc = launch_prior_fork(h, s);
     if (rc != ORCVIO_OK) return rc;
@@ -902,7 +922,31 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
     return rc;
 }
 
+// EKF-SLAM rows of this upload: gate every feature against the prior (2 degrees of freedom), accepted rows -> dense
+// [H | r] rows -> their Gram, which assembly adds to the compressed block (ekf_rows.hpp)
+static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s) {
+    if (h->ekf_F <= 0) return ORCVIO_OK;
+    const int F = h->ekf_F, cap = h->ekf_cap;
+    HIPCHK(hipMemsetAsync(h->d_ekf_E, 0, sizeof(double) * (size_t)2 * F * h->NAP, s));
+    EkfGateArgs a;
+    a.F = F; a.idp_dim = h->ekf_idp; a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP;
+    a.estimate_td = h->flags.estimate_td;
+    a.anchor = h->d_ekf_i; a.state = h->d_ekf_i + cap; a.slot = h->d_ekf_i + 2 * cap;
+    a.He = h->d_ekf_d; a.Ha = a.He + (size_t)12 * cap; a.Hx = a.Ha + (size_t)12 * cap; a.Hf = a.Hx + (size_t)12 * cap;
+    a.zvel = a.Hf + (size_t)6 * cap; a.r = a.zvel + (size_t)2 * cap;
+    a.P = h->d_P; a.sigma2 = h->flags.noise_feature * h->flags.noise_feature;
+    a.threshold = orcvio_msckf_chi2_quantile(2, h->flags.chi2_prob);
+    a.E = h->d_ekf_E; a.gamma = h->d_ekf_gamma; a.accept = h->d_ekf_accept;
+    hipLaunchKernelGGL(k_ekf_gate, dim3(F), dim3(64), 0, s, a);
+    const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
+    hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, 1), dim3(256), 0, s, (const double*)h->d_ekf_E, 2 * F, h->NAP, round_up(2 * F, 8),
+                       h->d_Gekf, (const int*)nullptr);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
 static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
+    { const int re = launch_ekf(h, s); if (re != ORCVIO_OK) return re; }
     // (the other way round -- prior on the origin stream, feature branch forked -- measured 15 us slower)
     h->A_deferred = front_defers_assembly(h);
     if (front_fused_active(h)) {   // one stream, no fork: the prior is factored by workgroup 0 of the feature launch
@@ -917,6 +961,62 @@ static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
     if (rc == ORCVIO_OK) rc = launch_assemble(h, s, h->d_A);
     if (rc == ORCVIO_OK) rc = launch_solve_tail(h, s);
     return rc;
+}
+
+// ---- EKF-SLAM rows ---------------------------------------------------------------------
+int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_ekf_rows* rows) {
+    if (!h || !rows || !h->uploaded) { g_last_error = "upload_ekf_rows: upload the window first"; return ORCVIO_ERR_INVALID; }
+    if (!h->ekf_mode) { g_last_error = "upload_ekf_rows: set ORCVIO_OPT_EKF_ROWS before the upload"; return ORCVIO_ERR_INVALID; }
+    const int F = rows->n_features, d = rows->idp_dim;
+    if (F < 0 || (d != 1 && d != 3)) { g_last_error = "upload_ekf_rows: idp_dim must be 1 or 3"; return ORCVIO_ERR_INVALID; }
+    if (F > 0 && (!rows->anchor || !rows->state || !rows->slot || !rows->H_e || !rows->H_a || !rows->H_x || !rows->H_f || !rows->r ||
+                  (h->flags.estimate_td && !rows->z_vel))) { g_last_error = "upload_ekf_rows: null array"; return ORCVIO_ERR_INVALID; }
+    for (int f = 0; f < F; ++f) {
+        if (rows->anchor[f] < 0 || rows->anchor[f] >= h->N || rows->state[f] < 0 || rows->state[f] >= h->N) { g_last_error = "upload_ekf_rows: clone index outside the window"; return ORCVIO_ERR_INVALID; }
+        if (rows->slot[f] < 0 || d * (rows->slot[f] + 1) > h->n_extra) { g_last_error = "upload_ekf_rows: feature slot outside the extra states"; return ORCVIO_ERR_INVALID; }
+    }
+    HIPCHK(hipSetDevice(h->device));
+    if (F > h->ekf_cap) {
+        HIPCHK(hipDeviceSynchronize());
+        void* old[] = {h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_ekf_gamma, h->d_ekf_accept};
+        for (void* q : old) if (q) (void)hipFree(q);
+        const int cap = round_up(F, 32);
+        HIPCHK(hipMalloc(&h->d_ekf_i, sizeof(int) * 3 * cap));
+        HIPCHK(hipMalloc(&h->d_ekf_d, sizeof(double) * 46 * cap));
+        HIPCHK(hipMalloc(&h->d_ekf_E, sizeof(double) * (size_t)2 * cap * h->NAP_max));
+        HIPCHK(hipMalloc(&h->d_ekf_gamma, sizeof(double) * cap));
+        HIPCHK(hipMalloc(&h->d_ekf_accept, sizeof(int) * cap));
+        if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)h->NAP_max * h->NAP_max));
+        h->ekf_cap = cap;
+    }
+    h->ekf_F = F; h->ekf_idp = d;
+    h->graph_valid = false;
+    if (F == 0) return ORCVIO_OK;
+    const int cap = h->ekf_cap;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_ekf_i, rows->anchor, sizeof(int) * F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ekf_i + cap, rows->state, sizeof(int) * F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ekf_i + 2 * cap, rows->slot, sizeof(int) * F, hipMemcpyHostToDevice));
+    double* q = h->d_ekf_d;
+    HIPCHK(hipMemcpy(q, rows->H_e, sizeof(double) * 12 * F, hipMemcpyHostToDevice)); q += (size_t)12 * cap;
+    HIPCHK(hipMemcpy(q, rows->H_a, sizeof(double) * 12 * F, hipMemcpyHostToDevice)); q += (size_t)12 * cap;
+    HIPCHK(hipMemcpy(q, rows->H_x, sizeof(double) * 12 * F, hipMemcpyHostToDevice)); q += (size_t)12 * cap;
+    HIPCHK(hipMemcpy(q, rows->H_f, sizeof(double) * 2 * d * F, hipMemcpyHostToDevice)); q += (size_t)6 * cap;
+    if (rows->z_vel) HIPCHK(hipMemcpy(q, rows->z_vel, sizeof(double) * 2 * F, hipMemcpyHostToDevice));
+    q += (size_t)2 * cap;
+    HIPCHK(hipMemcpy(q, rows->r, sizeof(double) * 2 * F, hipMemcpyHostToDevice));
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept) {
+    if (!h || !h->ran) { g_last_error = "download_ekf: no finished update"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->last_stream ? h->last_stream : h->stream));
+    if (h->ekf_F > 0) {
+        if (gamma) HIPCHK(hipMemcpy(gamma, h->d_ekf_gamma, sizeof(double) * h->ekf_F, hipMemcpyDeviceToHost));
+        if (accept) HIPCHK(hipMemcpy(accept, h->d_ekf_accept, sizeof(int) * h->ekf_F, hipMemcpyDeviceToHost));
+    }
+    return ORCVIO_OK;
 }
 
 int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
@@ -1144,7 +1244,8 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     h->flags = *flags;
     h->N = N; h->F = 0; h->nobs = 0;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
-    h->NA = flags->leg_dim + 6 * N - 15;
+    h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
+    h->ekf_F = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);
@@ -1233,7 +1334,8 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     h->flags = *flags;
     h->N = N; h->F = 0; h->nobs = 0;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
-    h->NA = flags->leg_dim + 6 * N - 15;
+    h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
+    h->ekf_F = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);

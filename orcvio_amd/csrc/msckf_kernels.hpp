@@ -286,6 +286,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
     const int LDE = feat_lde(p.Mmax);
     const int NA = p.NA, NAP = p.NAP, n = p.n;
     const int cb0 = p.leg - 15;   // active index of the first clone column
+    const int NAc = cb0 + 6 * p.N;   // end of the clone columns (NA is larger when SLAM feature states follow the clones: their columns are zero here)
     double* sJe = smem;               // [R2][7]  ext(6)+td
     double* sJx = sJe + R2 * 7;       // [R2][6]
     double* sR = sJx + R2 * 6;        // [R2]
@@ -511,7 +512,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                     w1 += sV[i * 4 + 1] * val;
                     w2 += sV[i * 4 + 2] * val;
                 }
-            } else if (a >= cb0 && a < NA) {
+            } else if (a >= cb0 && a < NAc) {
                 const int cl = (a - cb0) / 6, cc = (a - cb0) - 6 * cl;
                 const int k = sC2O[cl];
                 if (k >= 0) {
@@ -675,7 +676,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
         const int a = (tid - 64) + 192 * ps;
         if (wave > 0 && a < NAP) {
             int kobs = -1, cc = 0;
-            if (a >= cb0 && a < NA) {
+            if (a >= cb0 && a < NAc) {
                 const int cl = (a - cb0) / 6;
                 cc = (a - cb0) - 6 * cl;
                 kobs = sC2O[cl];
@@ -737,14 +738,17 @@ __global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
 template <bool PUB = false>
 __device__ __forceinline__ void assemble_entry(const int idx, const double* __restrict__ Sp, int N, int cb0, int NA, int NAP,
                                                const double* __restrict__ parts, int nparts, size_t part_stride,
-                                               double* __restrict__ dst, int dbg) {
+                                               double* __restrict__ dst, int dbg, const double* __restrict__ plus = nullptr) {
+    // plus: a Gram that is ADDED (lower tiles valid): the EKF-SLAM rows of the hybrid filter (ekf_rows.hpp).  The clone
+    // columns end at cb0 + 6N; with SLAM feature states behind them NA is larger and those columns get no S term.
     // Sp: one 16x16 tile per clone (k_gram_pair).  An entry of a clone block or of the arrow reads one tile; the
     // shared (ext|r) x (ext|r) entries sum all N -- sixteen loads in flight (clamped index + select: no serial tail),
     // fixed summation order.
     const int i = idx / NAP, j = idx - i * NAP;
     int ei = -1, ci = -1, ej = -1, cj = -1;
-    if (i < 7) ei = i; else if (i == NA) ei = 13; else if (i >= cb0 && i < NA) { ci = (i - cb0) / 6; ei = 7 + (i - cb0) - 6 * ci; }
-    if (j < 7) ej = j; else if (j == NA) ej = 13; else if (j >= cb0 && j < NA) { cj = (j - cb0) / 6; ej = 7 + (j - cb0) - 6 * cj; }
+    const int NAc = cb0 + 6 * N;   // end of the clone columns
+    if (i < 7) ei = i; else if (i == NA) ei = 13; else if (i >= cb0 && i < NAc) { ci = (i - cb0) / 6; ei = 7 + (i - cb0) - 6 * ci; }
+    if (j < 7) ej = j; else if (j == NA) ej = 13; else if (j >= cb0 && j < NAc) { cj = (j - cb0) / 6; ej = 7 + (j - cb0) - 6 * cj; }
     const int src = ((i >> 4) >= (j >> 4)) ? idx : j * NAP + i;
     // (the partial Grams first: their loads are unconditional and stay in flight under the S branch)
     double gv[4];
@@ -785,14 +789,15 @@ __device__ __forceinline__ void assemble_entry(const int idx, const double* __re
             g[u] += cu < nparts ? v : 0.0;
         }
     }
-    dst[idx] = s - ((g[0] + g[1]) + (g[2] + g[3]));
+    dst[idx] = s - ((g[0] + g[1]) + (g[2] + g[3])) + (plus ? plus[src] : 0.0);
 }
 __global__ __launch_bounds__(256) void k_assemble_A(const double* __restrict__ Sp, int N,
                                                     int cb0, int NA, int NAP, const double* __restrict__ parts, int nparts,
-                                                    size_t part_stride, double* __restrict__ dst, int dbg = 0) {
+                                                    size_t part_stride, double* __restrict__ dst, int dbg = 0,
+                                                    const double* __restrict__ plus = nullptr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= NAP * NAP) return;
-    assemble_entry(idx, Sp, N, cb0, NA, NAP, parts, nparts, part_stride, dst, dbg);
+    assemble_entry(idx, Sp, N, cb0, NA, NAP, parts, nparts, part_stride, dst, dbg, plus);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1693,6 +1698,7 @@ struct FrontGramArgs {
     int* counter;                 // zero between launches (the last workgroup through resets it)
     int* lost;                    // incremented if a wait gives up (reported as an error by the host)
     double* A_dst; int cb0;
+    const double* plus;           // optional Gram added to A (EKF-SLAM rows), lower tiles valid
 };
 __device__ __forceinline__ void front_grid_barrier(int* counter, int target, int* lost, unsigned long long* dbg = nullptr) {
     // Everything that crosses this barrier is written with write-through (sc1) stores and read with sc1 loads
@@ -1766,7 +1772,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
         FRONT_STAMP(4);
         // ---- A = scatter(S) - sum of the partial Grams --------------------------------------------------------
         for (int idx = me * 512 + (int)threadIdx.x; idx < p.NAP * p.NAP; idx += nfb * 512)
-            assemble_entry<true>(idx, g.S, p.N, g.cb0, p.NA, p.NAP, g.Gpart, g.chunks, (size_t)p.NAP * p.NAP, g.A_dst, 0);
+            assemble_entry<true>(idx, g.S, p.N, g.cb0, p.NA, p.NAP, g.Gpart, g.chunks, (size_t)p.NAP * p.NAP, g.A_dst, 0, g.plus);
         FRONT_STAMP(5);
         phases = 3;
     }
@@ -1824,6 +1830,7 @@ __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long
 // batch (one S tile entry, <= 4 partial-Gram entries and one B entry per k-step) is issued before the first use.
 struct AsmArgs {
     const double* S; int N, cb0, NA, NAP; const double* parts; int nparts; size_t stride; int dbg;
+    const double* plus;   // optional Gram added to A (EKF-SLAM rows), lower tiles valid
 };
 __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __restrict__ B, long sBk, long sBj, int M, int Nc, int K,
                                                    double* __restrict__ C, long sCi, long sCj, int* __restrict__ clear) {
@@ -1872,7 +1879,7 @@ __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __r
         sShared[g4][en] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
     }
     // ---- strip: thread (wave w, lane l) owns rows w, w+4, w+8, w+12 and columns l, l+64, l+128 -----------------------
-    double sv[4][3], gv[4][3][4];
+    double sv[4][3], gv[4][3][4], pv[4][3];
     int cls[4][3];   // 0: no S contribution, 1: one clone tile (sv), 2: shared entry (index in cls >> 2)
     int ekj[3], ckj[3];   // column classes: three per thread, shared by its four rows
 #pragma unroll
@@ -1880,7 +1887,7 @@ __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __r
         const int k = l + 64 * j;
         const int kc = k < K ? k : 0;
         ekj[j] = -1; ckj[j] = -1;
-        if (kc < 7) ekj[j] = kc; else if (kc >= aa.cb0 && kc < aa.NA) { ckj[j] = (kc - aa.cb0) / 6; ekj[j] = 7 + (kc - aa.cb0) - 6 * ckj[j]; }
+        if (kc < 7) ekj[j] = kc; else if (kc >= aa.cb0 && kc < aa.cb0 + 6 * aa.N) { ckj[j] = (kc - aa.cb0) / 6; ekj[j] = 7 + (kc - aa.cb0) - 6 * ckj[j]; }
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -1888,7 +1895,7 @@ __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __r
         const int i = 16 * bi + r;          // (wave-uniform)
         const int ic = i < M ? i : 0;
         int ei = -1, ci = -1;
-        if (ic < 7) ei = ic; else if (ic == aa.NA) ei = 13; else if (ic >= aa.cb0 && ic < aa.NA) { ci = (ic - aa.cb0) / 6; ei = 7 + (ic - aa.cb0) - 6 * ci; }
+        if (ic < 7) ei = ic; else if (ic == aa.NA) ei = 13; else if (ic >= aa.cb0 && ic < aa.cb0 + 6 * aa.N) { ci = (ic - aa.cb0) / 6; ei = 7 + (ic - aa.cb0) - 6 * ci; }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int k = l + 64 * j;
@@ -1911,6 +1918,7 @@ __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __r
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (u < aa.nparts && !(aa.dbg & 2)) gv[rr][j][u] = aa.parts[(size_t)u * aa.stride + src];   // (wave-uniform count)
+            pv[rr][j] = aa.plus ? aa.plus[((ic >> 4) >= (kc >> 4)) ? src : (size_t)kc * aa.NAP + ic] : 0.0;
         }
     }
     if (has_shared) __syncthreads();
@@ -1929,7 +1937,7 @@ __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __r
 #pragma unroll
             for (int u = 0; u < 4; ++u) g[u] = u < aa.nparts ? gv[rr][j][u] : 0.0;
             const bool in = 16 * bi + r < M && k < K;
-            sA[r * LDA + k] = in ? sS - ((g[0] + g[1]) + (g[2] + g[3])) : 0.0;
+            sA[r * LDA + k] = in ? sS - ((g[0] + g[1]) + (g[2] + g[3])) + pv[rr][j] : 0.0;
         }
     }
     __syncthreads();

@@ -130,6 +130,46 @@ def with_extra_states(win: "Window", k: int, seed: int = 0) -> "Window":
     return dataclasses.replace(win, P=np.ascontiguousarray(0.5 * (P + P.T)), n_extra=k)
 
 
+@dataclasses.dataclass
+class SlamFeature:
+    """One EKF-SLAM feature of the hybrid filter as the reference's Feature holds it (anchor clone, inverse-depth
+    parametrisation in the anchor camera frame, world position) and its observation in the current state."""
+    anchor: int
+    state: int
+    inv_param: np.ndarray
+    obs_anchor: np.ndarray
+    inv_depth: float
+    p_w: np.ndarray
+    z: np.ndarray
+    z_vel: np.ndarray
+    p_fej: np.ndarray = None
+
+
+def make_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_frac: float = 0.0):
+    """n_feat SLAM features anchored at random earlier clones and observed by the newest one (+ pixel noise; a
+    fraction with gross errors that the 2-dof gate rejects)."""
+    rng = np.random.default_rng(20_000 + seed)
+    k = win.N - 1
+    sig = win.flags.noise_feature
+    out = []
+    for _ in range(n_feat):
+        a = int(rng.integers(0, win.N - 1))
+        R_c2w = win.R_b2w[a] @ win.R_b2c[a].T
+        t_c_w = win.t_b_w[a] + win.R_b2w[a] @ win.t_c_b[a]
+        pc = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(4.0, 12.0)])
+        pw = R_c2w @ pc + t_c_w
+        inv = np.array([pc[0] / pc[2], pc[1] / pc[2], 1.0 / pc[2]])
+        Rk = win.R_b2c[k] @ win.R_b2w[k].T
+        tk = win.t_b_w[k] + win.R_b2w[k] @ win.t_c_b[k]
+        pk = Rk @ (pw - tk)
+        noise = sig * (40.0 if rng.random() < outlier_frac else 1.0)
+        z = pk[:2] / pk[2] + noise * rng.standard_normal(2)
+        out.append(SlamFeature(anchor=a, state=k, inv_param=inv, obs_anchor=np.array([inv[0], inv[1], 1.0]),
+                               inv_depth=float(inv[2]), p_w=pw + 0.01 * rng.standard_normal(3), z=z,
+                               z_vel=0.05 * rng.standard_normal(2), p_fej=pw + 0.01 * rng.standard_normal(3)))
+    return out
+
+
 def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,
                 flags: Flags | None = None, estimate_extrin: bool = False,
                 sigma_px: float | None = None, outlier_frac: float = 0.0) -> Window:

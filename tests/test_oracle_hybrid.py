@@ -1,0 +1,99 @@
+"""oracle/mirror_hybrid.py (EKF-SLAM rows of the hybrid filter) against central differences of the measurement model and
+against the structure of the joint update.  CPU only."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from orcvio_amd import synth
+from oracle import mirror, mirror_hybrid as mh
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def _project(win, ft, idp, d_anchor, d_state, d_ext, d_feat):
+    """pi(p_ck) with error-state increments applied: clones [dtheta, dp] with the LARVIO (left) convention of the
+    feature rows (tests/test_oracle.py::_project), extrinsics [dtheta_e, dt_e], feature parameters additive.  The
+    world point is rebuilt from the anchor camera and the inverse-depth parameters, as measurementUpdate_hybrid does
+    after the update (src/orcvio.cpp:1857-1885)."""
+    def clone(i, d):
+        return mirror.so3_exp(d[:3]) @ win.R_b2w[i], win.t_b_w[i] + d[3:]
+    q = mirror.small_angle_quaternion(d_ext[:3])
+    R_b2c = win.R_b2c[0] @ mirror.quat_to_rot_hamilton(q).T
+    t_c_b = win.t_c_b[0] + d_ext[3:]
+    Ra, ta = clone(ft.anchor, d_anchor)
+    Rk, tk = clone(ft.state, d_state)
+    if idp == 3:
+        fc = ft.inv_param + d_feat
+        p_ca = np.array([fc[0] / fc[2], fc[1] / fc[2], 1.0 / fc[2]])
+    else:
+        rho = ft.inv_depth + d_feat[0]
+        p_ca = np.array([ft.obs_anchor[0] / rho, ft.obs_anchor[1] / rho, 1.0 / rho])
+    p_w = Ra @ (R_b2c.T @ p_ca + t_c_b) + ta
+    pc = R_b2c @ (Rk.T @ (p_w - tk) - t_c_b)
+    return pc[:2] / pc[2]
+
+
+@pytest.mark.parametrize('idp', [3, 1])
+def test_ekf_rows_against_central_differences(idp):
+    """H_a, H_x, H_e, H_f of measurementJacobian_ekf_{3,1}didp are d pi / d(error state) when the feature's world position
+    is the one its anchor camera and inverse-depth parameters define."""
+    w = synth.make_window(N=6, F=2, seed=3, track_len=6, flags=synth.Flags(use_larvio=1))
+    slam = synth.make_slam_features(w, 8, seed=4)
+    eps = 1e-6
+    for ft in slam:
+        # make the stored world position exactly consistent with the parametrisation (the Jacobians assume it)
+        R_c2w = w.R_b2w[ft.anchor] @ w.R_b2c[ft.anchor].T
+        t_c_w = w.t_b_w[ft.anchor] + w.R_b2w[ft.anchor] @ w.t_c_b[ft.anchor]
+        pc = np.array([ft.inv_param[0] / ft.inv_param[2], ft.inv_param[1] / ft.inv_param[2], 1 / ft.inv_param[2]])
+        ft = dataclasses.replace(ft, p_w=R_c2w @ pc + t_c_w)
+        H_f, H_a, H_x, H_e, r = mh.measurement_jacobian_ekf(w, ft, idp)
+        assert np.allclose(r, ft.z - _project(w, ft, idp, np.zeros(6), np.zeros(6), np.zeros(6), np.zeros(3)), atol=1e-12)
+        num = np.zeros((2, 21))
+        for c in range(18 + idp):
+            d = np.zeros(21)
+            d[c] = eps
+            zp = _project(w, ft, idp, d[0:6], d[6:12], d[12:18], d[18:21])
+            zm = _project(w, ft, idp, -d[0:6], -d[6:12], -d[12:18], -d[18:21])
+            num[:, c] = (zp - zm) / (2 * eps)
+        assert np.allclose(H_a, num[:, 0:6], atol=5e-8)
+        assert np.allclose(H_x, num[:, 6:12], atol=5e-8)
+        assert np.allclose(H_e, num[:, 12:18], atol=5e-8)
+        assert np.allclose(H_f, num[:, 18:18 + idp], atol=5e-8)
+
+
+def test_anchor_frame_observation_3didp():
+    """state == anchor (:1302-1310): the row pair observes the first two inverse-depth parameters directly."""
+    w = synth.make_window(N=5, F=2, seed=1, track_len=5)
+    ft = synth.make_slam_features(w, 1, seed=0)[0]
+    ft = dataclasses.replace(ft, anchor=ft.state)
+    H_f, H_a, H_x, H_e, _ = mh.measurement_jacobian_ekf(w, ft, 3)
+    assert np.array_equal(H_f, np.array([[1.0, 0, 0], [0, 1.0, 0]]))
+    assert not H_a.any() and not H_x.any() and not H_e.any()
+
+
+@pytest.mark.parametrize('idp', [3, 1])
+def test_joint_update_is_the_sequential_update(idp):
+    """One update with [H_msckf; H_ekf] (measurementUpdate_hybrid) equals the MSCKF update followed by the update with
+    the SLAM rows linearised at the SAME prior: information adds.  Also: rejected SLAM features change nothing."""
+    w0 = synth.make_window(N=7, F=25, seed=11, track_len=(3, 7))
+    slam = synth.make_slam_features(w0, 7, seed=2, outlier_frac=0.3)
+    w = synth.with_extra_states(w0, idp * len(slam), seed=3)
+    joint = mh.hybrid_update(w, slam, idp)
+    assert 0 < joint['ekf_accept'].sum() < len(slam)
+    s2 = w.flags.noise_feature ** 2
+    first = mirror.msckf_update(w)
+    H2 = np.vstack([H for (H, _), a in zip(joint['ekf_rows'], joint['ekf_accept']) if a])
+    r2 = np.concatenate([r for (_, r), a in zip(joint['ekf_rows'], joint['ekf_accept']) if a])
+    P1 = first['P_new']
+    S = H2 @ P1 @ H2.T + s2 * np.eye(H2.shape[0])
+    K2 = np.linalg.solve(S, H2 @ P1).T
+    dx = first['dx'] + K2 @ (r2 - H2 @ first['dx'])
+    P2 = (np.eye(w.n) - K2 @ H2) @ P1
+    assert rel(dx, joint['dx']) < 1e-8
+    assert rel(0.5 * (P2 + P2.T), joint['P_new']) < 1e-9
+    # gate values are those of the individual row pairs against the prior
+    for (H, r), g in zip(joint['ekf_rows'], joint['ekf_gamma']):
+        assert abs(g - r @ np.linalg.solve(H @ w.P @ H.T + s2 * np.eye(2), r)) <= 1e-12 * max(1.0, g)
