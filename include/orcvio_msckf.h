@@ -172,6 +172,23 @@ typedef struct orcvio_msckf_ekf_rows {
     const double* r;         /* [F][2]                                                                      */
 } orcvio_msckf_ekf_rows;
 int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_ekf_rows* rows);
+/* ... or the SLAM features themselves: the four blocks are then evaluated on the device (measurementJacobian_ekf_3didp,
+ * src/orcvio.cpp:1229-1353, / _1didp, :1356-1478) from the window poses already uploaded -- observations in, delta_x out.
+ * Same call order, this call instead of orcvio_msckf_upload_ekf_rows. */
+typedef struct orcvio_msckf_slam_features {
+    int32_t n_features;
+    int32_t idp_dim;          /* feature_idp_dim: 3 or 1                                                     */
+    const int32_t* anchor;    /* [F] Feature::id_anchor as a window index                                    */
+    const int32_t* state;     /* [F] the observing clone (state_server.imu_state.id)                         */
+    const int32_t* slot;      /* [F] position in feature_states                                              */
+    const double* param;      /* [F][3] idp 3: Feature::invParam; idp 1: Feature::obs_anchor                 */
+    const double* inv_depth;  /* [F]    idp 1: Feature::invDepth (NULL for idp 3)                            */
+    const double* p_w;        /* [F][3] Feature::position                                                    */
+    const double* p_fej;      /* [F][3] Feature::position_FEJ, read under if_fej (may be NULL otherwise)      */
+    const double* z;          /* [F][2] observations[imu_state.id]                                           */
+    const double* z_vel;      /* [F][2] observations_vel[imu_state.id], read under estimate_td               */
+} orcvio_msckf_slam_features;
+int32_t orcvio_msckf_upload_slam_features(orcvio_msckf_handle* h, const orcvio_msckf_slam_features* feats);
 /* gamma[F], accept[F] of the SLAM features of the last update (either may be NULL) */
 int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept);
 

@@ -34,7 +34,7 @@ EXPORTS = [
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
-    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf',
+    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features',
 ]
 
 
@@ -179,6 +179,14 @@ class EkfRows(C.Structure):
                 ('H_f', C.POINTER(C.c_double)), ('z_vel', C.POINTER(C.c_double)), ('r', C.POINTER(C.c_double))]
 
 
+class SlamFeatures(C.Structure):
+    """orcvio_msckf_slam_features (include/orcvio_msckf.h)."""
+    _fields_ = [('n_features', C.c_int32), ('idp_dim', C.c_int32),
+                ('anchor', C.POINTER(C.c_int32)), ('state', C.POINTER(C.c_int32)), ('slot', C.POINTER(C.c_int32)),
+                ('param', C.POINTER(C.c_double)), ('inv_depth', C.POINTER(C.c_double)), ('p_w', C.POINTER(C.c_double)),
+                ('p_fej', C.POINTER(C.c_double)), ('z', C.POINTER(C.c_double)), ('z_vel', C.POINTER(C.c_double))]
+
+
 def make_flags(f) -> MsckfFlags:
     return MsckfFlags(int(f.leg_dim), int(f.use_larvio), int(f.use_left_perturbation), int(f.if_fej),
                       int(f.estimate_td), int(f.discard_large_update), float(f.noise_feature), float(f.chi2_prob))
@@ -233,6 +241,24 @@ class MsckfUpdater:
         rc = self.lib.orcvio_msckf_upload_ekf_rows(self.h, C.byref(rows))
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_upload_ekf_rows')
+        self._ekf_F = F
+
+    def upload_slam_features(self, idp_dim, slam, slots=None):
+        """SLAM features (synth.SlamFeature-shaped) observed by the current state: rows evaluated on the device."""
+        F = len(slam)
+        ia = [np.ascontiguousarray(a, dtype=np.int32) for a in ([f.anchor for f in slam], [f.state for f in slam],
+                                                                 list(range(F)) if slots is None else slots)]
+        param = np.ascontiguousarray([f.inv_param if idp_dim == 3 else f.obs_anchor for f in slam], dtype=np.float64).reshape(F, 3)
+        rho = np.ascontiguousarray([f.inv_depth for f in slam], dtype=np.float64)
+        pw = np.ascontiguousarray([f.p_w for f in slam], dtype=np.float64).reshape(F, 3)
+        pf = np.ascontiguousarray([f.p_fej if f.p_fej is not None else f.p_w for f in slam], dtype=np.float64).reshape(F, 3)
+        z = np.ascontiguousarray([f.z for f in slam], dtype=np.float64).reshape(F, 2)
+        zv = np.ascontiguousarray([f.z_vel for f in slam], dtype=np.float64).reshape(F, 2)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        st = SlamFeatures(F, int(idp_dim), ip(ia[0]), ip(ia[1]), ip(ia[2]), _d(param), _d(rho), _d(pw), _d(pf), _d(z), _d(zv))
+        rc = self.lib.orcvio_msckf_upload_slam_features(self.h, C.byref(st))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_upload_slam_features')
         self._ekf_F = F
 
     def download_ekf(self):

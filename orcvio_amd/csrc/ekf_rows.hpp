@@ -8,6 +8,7 @@
 // (A = X^T X - T3^T T3 + E^T E): the joint update with the stacked rows, in the Gram form the solve already uses.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "msckf_math.hpp"
 
 namespace orcvio_amd {
 
@@ -72,6 +73,139 @@ __global__ __launch_bounds__(64) void k_ekf_gate(EkfGateArgs p) {
         p.E[(size_t)(2 * f) * p.NAP + p.NA] = r0;
         p.E[(size_t)(2 * f + 1) * p.NAP + p.NA] = r1;
     }
+}
+
+
+// ---- the four blocks themselves, from the SLAM features (measurementJacobian_ekf_3didp :1229-1353, _1didp :1356-1478) ----
+struct EkfEvalArgs {
+    int F, idp_dim, if_fej;
+    const double* poses;     // [N][POSE_STRIDE]
+    const int* anchor; const int* state;
+    const double* param;     // [F][3]  3-d: invParam (x/z, y/z, 1/z in the anchor camera); 1-d: obs_anchor (u, v, 1)
+    const double* inv_depth; // [F]     1-d: invDepth
+    const double* p_w;       // [F][3]  Feature::position
+    const double* p_fej;     // [F][3]  Feature::position_FEJ (if_fej)
+    const double* z;         // [F][2]  the observation in the current state
+    double* He; double* Ha; double* Hx; double* Hf; double* r;   // outputs, compact (as orcvio_msckf_ekf_rows)
+};
+
+namespace ekfm {
+__device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C) {   // C = A B
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_mul_bt(const double* A, const double* B, double* C) {   // C = A B^T
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+}
+__device__ __forceinline__ void mat3_tmul_vec(const double* A, const double* x, double* y) {   // y = A^T x
+    for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
+}
+__device__ __forceinline__ void mat3_vec(const double* A, const double* x, double* y) {   // y = A x
+    for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * x[0] + A[i * 3 + 1] * x[1] + A[i * 3 + 2] * x[2];
+}
+__device__ __forceinline__ void skew(const double* w, double* S) {
+    S[0] = 0; S[1] = -w[2]; S[2] = w[1]; S[3] = w[2]; S[4] = 0; S[5] = -w[0]; S[6] = -w[1]; S[7] = w[0]; S[8] = 0;
+}
+// out (2 x 3) = J_k (2 x 3) M (3 x 3)
+__device__ __forceinline__ void jk_mul(const double* Jk, const double* M, double* out) {
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) out[i * 3 + j] = Jk[i * 3] * M[j] + Jk[i * 3 + 1] * M[3 + j] + Jk[i * 3 + 2] * M[6 + j];
+}
+}  // namespace ekfm
+
+// one thread per SLAM feature (a handful to a few dozen per frame)
+__global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
+    using namespace ekfm;
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= p.F) return;
+    const int d = p.idp_dim, a = p.anchor[f], k = p.state[f];
+    const double* Pk = p.poses + (size_t)k * POSE_STRIDE;
+    const double* Pa = p.poses + (size_t)a * POSE_STRIDE;
+    const double* R_b2c = Pk + POSE_R_B2C;
+    const double* t_c_b = Pk + POSE_T_C_B;
+    const double* R_bk2w = Pk + POSE_R_B2W;
+    const double* R_ba2w = Pa + POSE_R_B2W;
+    double R_w2ck[9], R_w2ca[9];
+    mat3_mul_bt(R_b2c, R_bk2w, R_w2ck);     // R_b2c R_w2bk   (:1264)
+    mat3_mul_bt(R_b2c, R_ba2w, R_w2ca);     // (:1278)
+    double t_ck_w[3], tmp[3];
+    mat3_vec(R_bk2w, t_c_b, tmp);
+    for (int i = 0; i < 3; ++i) t_ck_w[i] = Pk[POSE_T_B_W + i] + tmp[i];
+    const double* pw = p.p_w + (size_t)3 * f;
+    const double* pf = p.if_fej ? p.p_fej + (size_t)3 * f : pw;
+    const double* prm = p.param + (size_t)3 * f;
+    const double rho = d == 3 ? prm[2] : p.inv_depth[f];
+    double p_ca[3];
+    if (p.if_fej) {                          // :1281-1282
+        double dv[3], q[3];
+        for (int i = 0; i < 3; ++i) dv[i] = pf[i] - Pa[POSE_T_FEJ + i];
+        mat3_tmul_vec(R_ba2w, dv, q);
+        for (int i = 0; i < 3; ++i) q[i] -= t_c_b[i];
+        mat3_vec(R_b2c, q, p_ca);
+    } else {
+        p_ca[0] = prm[0] / rho; p_ca[1] = prm[1] / rho; p_ca[2] = 1.0 / rho;
+    }
+    double dv[3], p_ck[3];
+    for (int i = 0; i < 3; ++i) dv[i] = pw[i] - t_ck_w[i];
+    mat3_vec(R_w2ck, dv, p_ck);
+    double r0 = p.z[2 * f] - p_ck[0] / p_ck[2], r1 = p.z[2 * f + 1] - p_ck[1] / p_ck[2];   // :1299
+    double He[12] = {0}, Ha[12] = {0}, Hx[12] = {0}, Hf[6] = {0};
+    if (k == a) {                            // :1302-1310 / :1432-1440
+        if (d == 3) { Hf[0] = 1.0; Hf[d + 1] = 1.0; }
+        else { r0 = 0.0; r1 = 0.0; }
+    } else {
+        double Jk[6] = {1.0 / p_ck[2], 0.0, -p_ck[0] / (p_ck[2] * p_ck[2]), 0.0, 1.0 / p_ck[2], -p_ck[1] / (p_ck[2] * p_ck[2])};
+        double p_baf[3], p_bkf[3];
+        for (int i = 0; i < 3; ++i) {
+            p_baf[i] = p.if_fej ? pf[i] - Pa[POSE_T_FEJ + i] : pw[i] - Pa[POSE_T_B_W + i];   // :1320-1323
+            p_bkf[i] = p.if_fej ? pf[i] - Pk[POSE_T_FEJ + i] : pw[i] - Pk[POSE_T_B_W + i];
+        }
+        double S[9], M[9], J[6];
+        skew(p_baf, S); mat3_mul(R_w2ck, S, M);
+        jk_mul(Jk, M, J);
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Ha[i * 6 + j] = -J[i * 3 + j];       // -R_w2ck [p_baf]x
+        jk_mul(Jk, R_w2ck, J);
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) { Ha[i * 6 + 3 + j] = J[i * 3 + j]; Hx[i * 6 + 3 + j] = -J[i * 3 + j]; }
+        skew(p_bkf, S); mat3_mul(R_w2ck, S, M);
+        jk_mul(Jk, M, J);
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Hx[i * 6 + j] = J[i * 3 + j];        //  R_w2ck [p_bkf]x
+        // J_e (:1333-1337)
+        double q[3], u[3], Rka[9], SkM[9], Mx[9], T[9];
+        mat3_tmul_vec(R_bk2w, p_bkf, q);
+        for (int i = 0; i < 3; ++i) q[i] -= t_c_b[i];
+        skew(q, SkM);
+        mat3_tmul_vec(R_b2c, p_ca, u);
+        skew(u, S);
+        for (int i = 0; i < 3; ++i)          // Rka = R_w2bk R_ba2w = R_bk2w^T R_ba2w
+            for (int j = 0; j < 3; ++j) Rka[i * 3 + j] = R_bk2w[i] * R_ba2w[j] + R_bk2w[3 + i] * R_ba2w[3 + j] + R_bk2w[6 + i] * R_ba2w[6 + j];
+        mat3_mul(Rka, S, Mx);
+        for (int i = 0; i < 9; ++i) T[i] = SkM[i] - Mx[i];
+        mat3_mul(R_b2c, T, M);
+        jk_mul(Jk, M, J);
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) He[i * 6 + j] = J[i * 3 + j];
+        for (int i = 0; i < 9; ++i) T[i] = Rka[i] - ((i % 4 == 0) ? 1.0 : 0.0);
+        mat3_mul(R_b2c, T, M);
+        jk_mul(Jk, M, J);
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) He[i * 6 + 3 + j] = J[i * 3 + j];
+        // H_f
+        double Jp[9];
+        mat3_mul_bt(R_w2ck, R_w2ca, Jp);     // :1318
+        if (d == 3) {                        // :1339-1345
+            const double Jf[9] = {1.0 / rho, 0.0, -prm[0] / rho / rho, 0.0, 1.0 / rho, -prm[1] / rho / rho, 0.0, 0.0, -1.0 / rho / rho};
+            mat3_mul(Jp, Jf, M);
+            jk_mul(Jk, M, J);
+            for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) Hf[i * 3 + j] = J[i * 3 + j];
+        } else {                             // :1447, :1469-1471
+            double Jd[3];
+            mat3_vec(Jp, prm, Jd);
+            const double Jrho = -1.0 / (rho * rho);
+            for (int i = 0; i < 2; ++i) Hf[i] = (Jk[i * 3] * Jd[0] + Jk[i * 3 + 1] * Jd[1] + Jk[i * 3 + 2] * Jd[2]) * Jrho;
+        }
+    }
+    for (int i = 0; i < 12; ++i) { p.He[(size_t)f * 12 + i] = He[i]; p.Ha[(size_t)f * 12 + i] = Ha[i]; p.Hx[(size_t)f * 12 + i] = Hx[i]; }
+    for (int i = 0; i < 2 * d; ++i) p.Hf[(size_t)f * 2 * d + i] = Hf[i];
+    p.r[2 * f] = r0; p.r[2 * f + 1] = r1;
 }
 
 }  // namespace orcvio_amd

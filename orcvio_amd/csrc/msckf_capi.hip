@@ -87,6 +87,8 @@ struct orcvio_msckf_handle {
     double* d_ekf_E = nullptr;          // [2 cap][NAP_max] dense accepted rows [H | r]
     double* d_Gekf = nullptr;           // [NAP_max^2] their Gram (lower tiles)
     double* d_ekf_gamma = nullptr; int* d_ekf_accept = nullptr;
+    bool ekf_eval = false;              // the four blocks are evaluated on the device from the SLAM features (k_ekf_eval)
+    double* d_slam = nullptr;           // [12 cap] param 3 | inv_depth 1 | p_w 3 | p_fej 3 | z 2
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     bool A_deferred = false;            // the last run left S / Gpart only: d_A is assembled on demand (assemble_deferred)
     int front_chunks = 1;               // T3 row chunks of the last k_front launch
@@ -202,7 +204,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_obs,
                     h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
-                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept};
+                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -928,6 +930,16 @@ static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s) {
     if (h->ekf_F <= 0) return ORCVIO_OK;
     const int F = h->ekf_F, cap = h->ekf_cap;
     HIPCHK(hipMemsetAsync(h->d_ekf_E, 0, sizeof(double) * (size_t)2 * F * h->NAP, s));
+    if (h->ekf_eval) {   // measurementJacobian_ekf_{3,1}didp on the device: the compact row blocks from the SLAM features
+        EkfEvalArgs e;
+        e.F = F; e.idp_dim = h->ekf_idp; e.if_fej = h->flags.if_fej; e.poses = h->d_poses;
+        e.anchor = h->d_ekf_i; e.state = h->d_ekf_i + cap;
+        e.param = h->d_slam; e.inv_depth = e.param + (size_t)3 * cap; e.p_w = e.inv_depth + cap; e.p_fej = e.p_w + (size_t)3 * cap;
+        e.z = e.p_fej + (size_t)3 * cap;
+        e.He = h->d_ekf_d; e.Ha = e.He + (size_t)12 * cap; e.Hx = e.Ha + (size_t)12 * cap; e.Hf = e.Hx + (size_t)12 * cap;
+        e.r = e.Hf + (size_t)6 * cap + (size_t)2 * cap;
+        hipLaunchKernelGGL(k_ekf_eval, dim3((F + 63) / 64), dim3(64), 0, s, e);
+    }
     EkfGateArgs a;
     a.F = F; a.idp_dim = h->ekf_idp; a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP;
     a.estimate_td = h->flags.estimate_td;
@@ -964,6 +976,56 @@ static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
 }
 
 // ---- EKF-SLAM rows ---------------------------------------------------------------------
+static int ekf_reserve(orcvio_msckf_handle* h, int F) {
+    if (F <= h->ekf_cap) return ORCVIO_OK;
+    HIPCHK(hipDeviceSynchronize());
+    void* old[] = {h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam};
+    for (void* q : old) if (q) (void)hipFree(q);
+    const int cap = round_up(F, 32);
+    HIPCHK(hipMalloc(&h->d_ekf_i, sizeof(int) * 3 * cap));
+    HIPCHK(hipMalloc(&h->d_ekf_d, sizeof(double) * 46 * cap));
+    HIPCHK(hipMalloc(&h->d_ekf_E, sizeof(double) * (size_t)2 * cap * h->NAP_max));
+    HIPCHK(hipMalloc(&h->d_ekf_gamma, sizeof(double) * cap));
+    HIPCHK(hipMalloc(&h->d_ekf_accept, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&h->d_slam, sizeof(double) * 12 * cap));
+    if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)h->NAP_max * h->NAP_max));
+    h->ekf_cap = cap;
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_upload_slam_features(orcvio_msckf_handle* h, const orcvio_msckf_slam_features* ft) {
+    if (!h || !ft || !h->uploaded) { g_last_error = "upload_slam_features: upload the window first"; return ORCVIO_ERR_INVALID; }
+    if (!h->ekf_mode) { g_last_error = "upload_slam_features: set ORCVIO_OPT_EKF_ROWS before the upload"; return ORCVIO_ERR_INVALID; }
+    const int F = ft->n_features, d = ft->idp_dim;
+    if (F < 0 || (d != 1 && d != 3)) { g_last_error = "upload_slam_features: idp_dim must be 1 or 3"; return ORCVIO_ERR_INVALID; }
+    if (F > 0 && (!ft->anchor || !ft->state || !ft->slot || !ft->param || !ft->p_w || !ft->z || (d == 1 && !ft->inv_depth) ||
+                  (h->flags.if_fej && !ft->p_fej) || (h->flags.estimate_td && !ft->z_vel))) { g_last_error = "upload_slam_features: null array"; return ORCVIO_ERR_INVALID; }
+    for (int f = 0; f < F; ++f) {
+        if (ft->anchor[f] < 0 || ft->anchor[f] >= h->N || ft->state[f] < 0 || ft->state[f] >= h->N) { g_last_error = "upload_slam_features: clone index outside the window"; return ORCVIO_ERR_INVALID; }
+        if (ft->slot[f] < 0 || d * (ft->slot[f] + 1) > h->n_extra) { g_last_error = "upload_slam_features: feature slot outside the extra states"; return ORCVIO_ERR_INVALID; }
+    }
+    HIPCHK(hipSetDevice(h->device));
+    { const int rc = ekf_reserve(h, F); if (rc != ORCVIO_OK) return rc; }
+    h->ekf_F = F; h->ekf_idp = d; h->ekf_eval = true;
+    h->graph_valid = false;
+    if (F == 0) return ORCVIO_OK;
+    const int cap = h->ekf_cap;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_ekf_i, ft->anchor, sizeof(int) * F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ekf_i + cap, ft->state, sizeof(int) * F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ekf_i + 2 * cap, ft->slot, sizeof(int) * F, hipMemcpyHostToDevice));
+    double* q = h->d_slam;
+    HIPCHK(hipMemcpy(q, ft->param, sizeof(double) * 3 * F, hipMemcpyHostToDevice)); q += (size_t)3 * cap;
+    if (ft->inv_depth) HIPCHK(hipMemcpy(q, ft->inv_depth, sizeof(double) * F, hipMemcpyHostToDevice));
+    q += cap;
+    HIPCHK(hipMemcpy(q, ft->p_w, sizeof(double) * 3 * F, hipMemcpyHostToDevice)); q += (size_t)3 * cap;
+    if (ft->p_fej) HIPCHK(hipMemcpy(q, ft->p_fej, sizeof(double) * 3 * F, hipMemcpyHostToDevice));
+    q += (size_t)3 * cap;
+    HIPCHK(hipMemcpy(q, ft->z, sizeof(double) * 2 * F, hipMemcpyHostToDevice));
+    if (ft->z_vel) HIPCHK(hipMemcpy(h->d_ekf_d + (size_t)42 * cap, ft->z_vel, sizeof(double) * 2 * F, hipMemcpyHostToDevice));   // (the gate's z_vel slot)
+    return ORCVIO_OK;
+}
+
 int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_ekf_rows* rows) {
     if (!h || !rows || !h->uploaded) { g_last_error = "upload_ekf_rows: upload the window first"; return ORCVIO_ERR_INVALID; }
     if (!h->ekf_mode) { g_last_error = "upload_ekf_rows: set ORCVIO_OPT_EKF_ROWS before the upload"; return ORCVIO_ERR_INVALID; }
@@ -976,20 +1038,8 @@ int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_
         if (rows->slot[f] < 0 || d * (rows->slot[f] + 1) > h->n_extra) { g_last_error = "upload_ekf_rows: feature slot outside the extra states"; return ORCVIO_ERR_INVALID; }
     }
     HIPCHK(hipSetDevice(h->device));
-    if (F > h->ekf_cap) {
-        HIPCHK(hipDeviceSynchronize());
-        void* old[] = {h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_ekf_gamma, h->d_ekf_accept};
-        for (void* q : old) if (q) (void)hipFree(q);
-        const int cap = round_up(F, 32);
-        HIPCHK(hipMalloc(&h->d_ekf_i, sizeof(int) * 3 * cap));
-        HIPCHK(hipMalloc(&h->d_ekf_d, sizeof(double) * 46 * cap));
-        HIPCHK(hipMalloc(&h->d_ekf_E, sizeof(double) * (size_t)2 * cap * h->NAP_max));
-        HIPCHK(hipMalloc(&h->d_ekf_gamma, sizeof(double) * cap));
-        HIPCHK(hipMalloc(&h->d_ekf_accept, sizeof(int) * cap));
-        if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)h->NAP_max * h->NAP_max));
-        h->ekf_cap = cap;
-    }
-    h->ekf_F = F; h->ekf_idp = d;
+    { const int rc = ekf_reserve(h, F); if (rc != ORCVIO_OK) return rc; }
+    h->ekf_F = F; h->ekf_idp = d; h->ekf_eval = false;
     h->graph_valid = false;
     if (F == 0) return ORCVIO_OK;
     const int cap = h->ekf_cap;

@@ -30,14 +30,17 @@ def compact_rows(win, slam, idp):
     return (np.array(He), np.array(Ha), np.array(Hx), np.array(Hf).reshape(len(slam), 2, idp), np.array(r))
 
 
-def run(upd, win, slam, idp):
-    He, Ha, Hx, Hf, r = compact_rows(win, slam, idp)
+def run(upd, win, slam, idp, on_device=False):
     upd.set_extra_states(win.n_extra)
     upd.set_ekf_rows_mode(True)
     try:
         upd.upload(win)
-        upd.upload_ekf_rows(idp, [f.anchor for f in slam], [f.state for f in slam], list(range(len(slam))), He, Ha, Hx, Hf, r,
-                            z_vel=np.array([f.z_vel for f in slam]))
+        if on_device:   # the SLAM features themselves: measurementJacobian_ekf_* evaluated by k_ekf_eval
+            upd.upload_slam_features(idp, slam)
+        else:
+            He, Ha, Hx, Hf, r = compact_rows(win, slam, idp)
+            upd.upload_ekf_rows(idp, [f.anchor for f in slam], [f.state for f in slam], list(range(len(slam))), He, Ha, Hx, Hf, r,
+                                z_vel=np.array([f.z_vel for f in slam]))
         upd.run_update()
         upd.sync()
         got = upd.download(want_G=True)
@@ -48,17 +51,19 @@ def run(upd, win, slam, idp):
     return got
 
 
+@pytest.mark.parametrize('on_device', [False, True], ids=['rows', 'features'])
 @pytest.mark.parametrize('idp', [3, 1])
 @pytest.mark.parametrize('case', [dict(N=9, F=40, nf=6, flags={}), dict(N=14, F=90, nf=20, flags=dict(estimate_td=1)),
-                                  dict(N=30, F=400, nf=12, flags={}), dict(N=8, F=0, nf=5, flags=dict(if_fej=1))])
-def test_joint_update_with_slam_rows(upd, idp, case):
+                                  dict(N=30, F=400, nf=12, flags={}), dict(N=8, F=0, nf=5, flags=dict(if_fej=1)),
+                                  dict(N=11, F=30, nf=9, flags=dict(if_fej=1, estimate_td=1))])
+def test_joint_update_with_slam_rows(upd, idp, case, on_device):
     fl = synth.Flags(use_larvio=1, **case['flags'])
     w0 = synth.make_window(N=case['N'], F=case['F'], seed=31 + case['nf'], track_len=None if case['F'] == 400 else (3, min(case['N'], 9)),
                            flags=fl)
     slam = synth.make_slam_features(w0, case['nf'], seed=idp, outlier_frac=0.25)
     w = synth.with_extra_states(w0, idp * len(slam), seed=7)
     ref = mh.hybrid_update(w, slam, idp)
-    got = run(upd, w, slam, idp)
+    got = run(upd, w, slam, idp, on_device)
     assert np.array_equal(got['ekf_accept'], ref['ekf_accept'])
     assert 0 < ref['ekf_accept'].sum() < len(slam) or case['nf'] < 8   # the gate does both
     assert rel(got['ekf_gamma'], ref['ekf_gamma']) < 1e-9
@@ -68,3 +73,19 @@ def test_joint_update_with_slam_rows(upd, idp, case):
     assert rel(got['P_new'] - w.P, ref['P_new'] - w.P) < TOL
     assert rel(got['G'], ref['G']) < TOL
     assert np.array_equal(got['P_new'], got['P_new'].T)
+
+
+def test_anchor_equal_to_the_observing_state(upd):
+    """state == anchor (src/orcvio.cpp:1302-1310): the 3-d row pair observes the first two parameters directly; on the
+    device and through the restatement."""
+    import dataclasses
+    w0 = synth.make_window(N=6, F=20, seed=2, track_len=(3, 6))
+    slam = synth.make_slam_features(w0, 4, seed=9)
+    slam[1] = dataclasses.replace(slam[1], anchor=slam[1].state)
+    w = synth.with_extra_states(w0, 3 * len(slam), seed=1)
+    ref = mh.hybrid_update(w, slam, 3)
+    got = run(upd, w, slam, 3, on_device=True)
+    assert np.array_equal(got['ekf_accept'], ref['ekf_accept'])
+    assert rel(got['ekf_gamma'], ref['ekf_gamma']) < 1e-9
+    assert rel(got['dx'], ref['dx']) < TOL
+    assert rel(got['P_new'], ref['P_new']) < TOL
