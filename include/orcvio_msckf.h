@@ -189,6 +189,13 @@ typedef struct orcvio_msckf_slam_features {
     const double* z_vel;      /* [F][2] observations_vel[imu_state.id], read under estimate_td               */
 } orcvio_msckf_slam_features;
 int32_t orcvio_msckf_upload_slam_features(orcvio_msckf_handle* h, const orcvio_msckf_slam_features* feats);
+/* Rows the caller has projected and gated itself, stacked under everything else as they are: H [n_rows][n] over the
+ * WHOLE state (n = LEG + 6N + extra states; the first 15 columns must be zero, as for every feature row), r [n_rows].
+ * This is how a frame that initialises NEW SLAM features keeps the heavy update on the device: the caller evaluates
+ * featureJacobian_ekf_new and the W = [V | U] split of src/orcvio.cpp:2337-2436 (a few features, small), hands the
+ * V-part rows (zero in the new features' columns) over here, and applies the reference's own H_1 / H_2 algebra
+ * (:1811-1947) to the downloaded delta_x and covariance.  The rows belong to the upload they follow. */
+int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, const double* H, const double* r);
 /* gamma[F], accept[F] of the SLAM features of the last update (either may be NULL) */
 int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept);
 

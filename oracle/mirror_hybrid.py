@@ -149,3 +149,133 @@ def hybrid_update(win, slam, idp_dim: int, table=None):
     dx, K, Pn = mirror.measurement_update(H_thin, r_thin, win.P, sigma2)
     out.update(dx=dx, P_new=Pn, G=K @ H_thin)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# New SLAM features: featureJacobian_ekf_new (:1481-1572), the W = [V | U] split (:2337-2436) and the H_1 / H_2 part of
+# measurementUpdate_hybrid (:1766-1947).  Without Schmidt nuisance states.
+# ----------------------------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class NewSlamFeature:
+    """A feature about to enter the state: anchor, parametrisation, position and ALL its observations."""
+    anchor: int
+    inv_param: np.ndarray
+    obs_anchor: np.ndarray
+    inv_depth: float
+    p_w: np.ndarray
+    obs: list               # [(clone index, z [2], z_vel [2])], ascending clone index
+    p_fej: np.ndarray = None
+
+
+def feature_jacobian_ekf_new(win, ft: NewSlamFeature, idx_new: int, n_new: int, idp_dim: int):
+    """:1481-1572 -- rows of every listed observation over [state (win.n) | new feature states (d n_new)]."""
+    f = win.flags
+    d = idp_dim
+    obs = [(k, z, zv) for (k, z, zv) in ft.obs if not (d == 1 and k == ft.anchor)]   # :1494-1496
+    H = np.zeros((2 * len(obs), win.n + d * n_new))
+    r = np.zeros(2 * len(obs))
+    fi = win.n + d * idx_new                                                          # :1533 (no nuisance states)
+    for c, (k, z, zv) in enumerate(obs):
+        one = SlamFeature(anchor=ft.anchor, state=k, inv_param=ft.inv_param, obs_anchor=ft.obs_anchor, inv_depth=ft.inv_depth,
+                          p_w=ft.p_w, z=z, z_vel=zv, p_fej=ft.p_fej)
+        H_f, H_a, H_x, H_e, rr = measurement_jacobian_ekf(win, one, d)
+        H[2 * c:2 * c + 2, fi:fi + d] = H_f                                           # :1550 / :1557
+        H[2 * c:2 * c + 2, f.leg_dim + 6 * ft.anchor: f.leg_dim + 6 * ft.anchor + 6] = H_a   # :1561
+        H[2 * c:2 * c + 2, f.leg_dim + 6 * k: f.leg_dim + 6 * k + 6] = H_x            # :1562
+        H[2 * c:2 * c + 2, 15:21] = H_e                                               # :1563
+        if f.estimate_td:
+            H[2 * c:2 * c + 2, 21] = zv                                               # :1564-1565
+        r[2 * c:2 * c + 2] = rr
+    return H, r
+
+
+def msckf_gate_of_feature(win, ft: NewSlamFeature, table=None):
+    """:2361-2367 -- the new feature is judged by the MSCKF test of its track: featureJacobian_msckf over all its
+    observations, gatingTestFeature with 2M - 3 degrees of freedom."""
+    f = win.flags
+    table = mirror.chi2_table(f.chi2_prob) if table is None else table
+    M = len(ft.obs)
+    Hx = np.zeros((2 * M, win.n)); Hf = np.zeros((2 * M, 3)); r = np.zeros(2 * M)
+    for c, (k, z, zv) in enumerate(ft.obs):
+        H_x, H_e, H_f, rr = mirror.measurement_jacobian_msckf(win, k, ft.p_w, z)
+        Hx[2 * c:2 * c + 2, f.leg_dim + 6 * k: f.leg_dim + 6 * k + 6] = H_x
+        Hx[2 * c:2 * c + 2, 15:21] = H_e
+        if f.estimate_td:
+            Hx[2 * c:2 * c + 2, 21] = zv
+        Hf[2 * c:2 * c + 2] = H_f
+        r[2 * c:2 * c + 2] = rr
+    _, Hp, rp = mirror.nullspace_project_svd(Hf, Hx, r)
+    g = mirror.gating_gamma(Hp, rp, win.P, f.noise_feature ** 2)
+    return g, bool(g < mirror.chi2_threshold(2 * M - 3, f.chi2_prob, table))
+
+
+def split_new_rows(win, new_feats, idp_dim: int, table=None):
+    """:2337-2436 -- stack the rows of the new features that pass, then rotate them with W = [V | U] (V: left null space
+    of the new-feature columns, U: their column space): returns (accepted indices, H_top [rows - sz, n], r_top, H_1 [sz, n],
+    H_2 [sz, sz], r_1)."""
+    d = idp_dim
+    acc = [i for i, ft in enumerate(new_feats) if msckf_gate_of_feature(win, ft, table)[1]]
+    n_new = len(acc)
+    if n_new == 0:
+        z = np.zeros
+        return acc, z((0, win.n)), z(0), z((0, win.n)), z((0, 0)), z(0)
+    Hs, rs = [], []
+    for j, i in enumerate(acc):
+        H, r = feature_jacobian_ekf_new(win, new_feats[i], j, n_new, d)
+        Hs.append(H); rs.append(r)
+    H = np.vstack(Hs); r = np.concatenate(rs)
+    sz = d * n_new
+    Q, _ = np.linalg.qr(H[:, win.n:], mode='complete')       # U = first sz columns, V = the rest (any orthonormal bases
+    W = np.hstack([Q[:, sz:], Q[:, :sz]])                    #  of the two subspaces give the same update)
+    Hn = W.T @ H; rn = W.T @ r
+    m = H.shape[0]
+    return acc, Hn[:m - sz, :win.n], rn[:m - sz], Hn[m - sz:, :win.n], Hn[m - sz:, win.n:], rn[m - sz:]
+
+
+def augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2):
+    """:1811-1821 and :1904-1947 (no nuisance states): the new states' correction and the augmented covariance from the
+    UPDATED legacy covariance.  This part stays with the caller in the integration."""
+    n = P_upd.shape[0]
+    sz = H_2.shape[0]
+    if sz == 0:
+        return dx_leg.copy(), P_upd.copy()
+    HH = np.linalg.solve(H_2, H_1)
+    dx_new = -HH @ dx_leg + np.linalg.solve(H_2, r_1)
+    nHHP = -HH @ P_upd
+    P22 = -nHHP @ HH.T + sigma2 * np.linalg.inv(H_2.T @ H_2)
+    P = np.zeros((n + sz, n + sz))
+    P[:n, :n] = P_upd
+    P[n:, :n] = nHHP
+    P[:n, n:] = nHHP.T
+    P[n:, n:] = P22
+    return np.concatenate([dx_leg, dx_new]), 0.5 * (P + P.T)
+
+
+def hybrid_update_full(win, slam, new_feats, idp_dim: int, table=None):
+    """removeLostFeatures + measurementUpdate_hybrid with MSCKF tracks, existing SLAM features and new ones."""
+    f = win.flags
+    sigma2 = f.noise_feature ** 2
+    table = mirror.chi2_table(f.chi2_prob) if table is None else table
+    base = mirror.msckf_update(win, table=table)
+    blocks = [b for b, a in zip(base['blocks'], base['accept']) if a]
+    rs = [b for b, a in zip(base['rs'], base['accept']) if a]
+    ea = []
+    for idx, ft in enumerate(slam):
+        H, r = feature_jacobian_ekf(win, ft, idx, idp_dim)
+        ok = mirror.gating_gamma(H, r, win.P, sigma2) < mirror.chi2_threshold(2, f.chi2_prob, table)
+        ea.append(int(ok))
+        if ok:
+            blocks.append(H); rs.append(r)
+    acc, H_top, r_top, H_1, H_2, r_1 = split_new_rows(win, new_feats, idp_dim, table)
+    if H_top.shape[0]:
+        blocks.append(H_top); rs.append(r_top)
+    H_o = np.vstack(blocks); r_o = np.concatenate(rs)
+    P = win.P
+    S = H_o @ P @ H_o.T + sigma2 * np.eye(H_o.shape[0])                  # :1811-1815
+    K = np.linalg.solve(S, H_o @ P).T
+    dx_leg = K @ r_o
+    P_upd = (np.eye(win.n) - K @ H_o) @ P                                # :1889-1902
+    P_upd = 0.5 * (P_upd + P_upd.T)
+    dx, P_full = augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2)
+    return dict(dx=dx, P_new=P_full, accept=base['accept'], ekf_accept=np.array(ea, dtype=np.int32), new_accept=acc,
+                dx_leg=dx_leg, P_upd=P_upd)

@@ -34,7 +34,7 @@ EXPORTS = [
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
-    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features',
+    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows',
 ]
 
 
@@ -260,6 +260,14 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_upload_slam_features')
         self._ekf_F = F
+
+    def upload_dense_rows(self, H, r):
+        """Caller-projected dense rows over the whole state, stacked as they are (no gate)."""
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        rc = self.lib.orcvio_msckf_upload_dense_rows(self.h, H.shape[0], _d(H), _d(r))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_upload_dense_rows')
 
     def download_ekf(self):
         F = getattr(self, '_ekf_F', 0)

@@ -208,4 +208,9 @@ __global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
     p.r[2 * f] = r0; p.r[2 * f + 1] = r1;
 }
 
+__global__ __launch_bounds__(256) void k_add_inplace(double* __restrict__ dst, const double* __restrict__ src, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 }  // namespace orcvio_amd

@@ -87,6 +87,8 @@ struct orcvio_msckf_handle {
     double* d_ekf_E = nullptr;          // [2 cap][NAP_max] dense accepted rows [H | r]
     double* d_Gekf = nullptr;           // [NAP_max^2] their Gram (lower tiles)
     double* d_ekf_gamma = nullptr; int* d_ekf_accept = nullptr;
+    int dense_rows = 0, dense_cap = 0;  // caller-projected dense rows [H | r] stacked as they are (orcvio_msckf_upload_dense_rows)
+    double* d_dense = nullptr;          // [dense_cap][NAP_max]
     bool ekf_eval = false;              // the four blocks are evaluated on the device from the SLAM features (k_ekf_eval)
     double* d_slam = nullptr;           // [12 cap] param 3 | inv_depth 1 | p_w 3 | p_fej 3 | z 2
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
@@ -204,7 +206,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_obs,
                     h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
-                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam};
+                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -401,6 +403,8 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
 
 static int factor_layout_clean(orcvio_msckf_handle* h);
 static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s);
+// Gram of the rows stacked under the MSCKF rows (EKF-SLAM rows that passed their gate, caller-projected dense rows)
+static inline const double* extra_gram(const orcvio_msckf_handle* h) { return (h->ekf_F > 0 || h->dense_rows > 0) ? h->d_Gekf : nullptr; }
 
 // ---- upload --------------------------------------------------------------------------------
 int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
@@ -439,7 +443,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->N = N; h->F = F; h->nobs = nobs;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
     h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
-    h->ekf_F = 0;
+    h->ekf_F = 0; h->dense_rows = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);
@@ -605,7 +609,7 @@ static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_
     h->front_chunks = g.chunks;
     g.rows_per_chunk = round_up((t3rows + g.chunks - 1) / g.chunks, 4);
     g.Gpart = h->d_Gpart; g.S = h->d_S; g.clone_rows = h->d_clone_ptr; g.counter = h->d_sync; g.lost = h->d_info + 8;
-    g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15; g.plus = h->ekf_F > 0 ? h->d_Gekf : nullptr;
+    g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15; g.plus = extra_gram(h);
     if (g.enabled && g.chunks > h->gram_chunks_cap) { g_last_error = "launch_front: too many row chunks"; return ORCVIO_ERR_CAPACITY; }
     dim3 grid(1 + (h->F + 1) / 2), block(512);
     // the window width fixes both template arguments: NPASS = ceil(NAP/64) column passes, and enough register slots
@@ -650,7 +654,7 @@ static int launch_assemble(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
     const int total = h->NAP * h->NAP;
     hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->F > 0 ? h->N : 0,
                        h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->chunks, (size_t)total, dst,
-                       getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0, h->ekf_F > 0 ? h->d_Gekf : (const double*)nullptr);
+                       getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0, extra_gram(h));
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -661,7 +665,7 @@ static int assemble_deferred(orcvio_msckf_handle* h, hipStream_t s) {
     const int total = h->NAP * h->NAP;
     hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->F > 0 ? h->N : 0,
                        h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->front_chunks, (size_t)total, h->d_A, 0,
-                       h->ekf_F > 0 ? h->d_Gekf : (const double*)nullptr);
+                       extra_gram(h));
     HIPCHK(hipGetLastError());
     h->A_deferred = false;
     return ORCVIO_OK;
@@ -761,7 +765,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
         case ST_FORM_U:    // U[(NA+1) x n] = [A; b^T] * L_a
             if (h->A_deferred) {   // A = scatter(S) - sum Gpart assembled inside the product (k_front left the Grams only)
                 AsmArgs aa{h->d_S, h->N, h->flags.leg_dim - 15, NA, NAP, h->d_Gpart, h->front_chunks, (size_t)NAP * NAP, getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0,
-                           h->ekf_F > 0 ? h->d_Gekf : nullptr};
+                           extra_gram(h)};
                 const int tiles = ((NA + 1 + 15) / 16) * ((n + 15) / 16);
                 hipLaunchKernelGGL(k_gemm_asmA, dim3(tiles), dim3(256), 0, s, aa, La, sLi, sLj, NA + 1, n, NA, h->d_U, (long)NP, 1L, (int*)nullptr);
                 HIPCHK(hipGetLastError());
@@ -831,7 +835,7 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
     mix(h->N); mix(h->F); mix(h->nobs); mix(h->Mmax); mix(h->chunks); mix(h->s_chunks); mix(h->rows_per_chunk);
     mix(h->flags.leg_dim); mix(h->flags.use_larvio); mix(h->flags.use_left_perturbation); mix(h->flags.if_fej);
-    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->front_fused); mix(h->feat_ablate); mix(h->ekf_F); mix(h->ekf_mode); mix(h->n_extra);
+    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->front_fused); mix(h->feat_ablate); mix(h->ekf_F); mix(h->ekf_mode); mix(h->n_extra); mix(h->dense_rows);
     unsigned long long bits;
     double sg = h->flags.noise_feature;
     std::memcpy(&bits, &sg, 8); mix(bits);
@@ -927,32 +931,43 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
 // EKF-SLAM rows of this upload: gate every feature against the prior (2 degrees of freedom), accepted rows -> dense
 // [H | r] rows -> their Gram, which assembly adds to the compressed block (ekf_rows.hpp)
 static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s) {
-    if (h->ekf_F <= 0) return ORCVIO_OK;
+    if (h->ekf_F <= 0 && h->dense_rows <= 0) return ORCVIO_OK;
     const int F = h->ekf_F, cap = h->ekf_cap;
-    HIPCHK(hipMemsetAsync(h->d_ekf_E, 0, sizeof(double) * (size_t)2 * F * h->NAP, s));
-    if (h->ekf_eval) {   // measurementJacobian_ekf_{3,1}didp on the device: the compact row blocks from the SLAM features
-        EkfEvalArgs e;
-        e.F = F; e.idp_dim = h->ekf_idp; e.if_fej = h->flags.if_fej; e.poses = h->d_poses;
-        e.anchor = h->d_ekf_i; e.state = h->d_ekf_i + cap;
-        e.param = h->d_slam; e.inv_depth = e.param + (size_t)3 * cap; e.p_w = e.inv_depth + cap; e.p_fej = e.p_w + (size_t)3 * cap;
-        e.z = e.p_fej + (size_t)3 * cap;
-        e.He = h->d_ekf_d; e.Ha = e.He + (size_t)12 * cap; e.Hx = e.Ha + (size_t)12 * cap; e.Hf = e.Hx + (size_t)12 * cap;
-        e.r = e.Hf + (size_t)6 * cap + (size_t)2 * cap;
-        hipLaunchKernelGGL(k_ekf_eval, dim3((F + 63) / 64), dim3(64), 0, s, e);
-    }
-    EkfGateArgs a;
-    a.F = F; a.idp_dim = h->ekf_idp; a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP;
-    a.estimate_td = h->flags.estimate_td;
-    a.anchor = h->d_ekf_i; a.state = h->d_ekf_i + cap; a.slot = h->d_ekf_i + 2 * cap;
-    a.He = h->d_ekf_d; a.Ha = a.He + (size_t)12 * cap; a.Hx = a.Ha + (size_t)12 * cap; a.Hf = a.Hx + (size_t)12 * cap;
-    a.zvel = a.Hf + (size_t)6 * cap; a.r = a.zvel + (size_t)2 * cap;
-    a.P = h->d_P; a.sigma2 = h->flags.noise_feature * h->flags.noise_feature;
-    a.threshold = orcvio_msckf_chi2_quantile(2, h->flags.chi2_prob);
-    a.E = h->d_ekf_E; a.gamma = h->d_ekf_gamma; a.accept = h->d_ekf_accept;
-    hipLaunchKernelGGL(k_ekf_gate, dim3(F), dim3(64), 0, s, a);
     const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
-    hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, 1), dim3(256), 0, s, (const double*)h->d_ekf_E, 2 * F, h->NAP, round_up(2 * F, 8),
-                       h->d_Gekf, (const int*)nullptr);
+    if (F > 0) {
+        HIPCHK(hipMemsetAsync(h->d_ekf_E, 0, sizeof(double) * (size_t)2 * F * h->NAP, s));
+        if (h->ekf_eval) {   // measurementJacobian_ekf_{3,1}didp on the device: the compact row blocks from the SLAM features
+            EkfEvalArgs e;
+            e.F = F; e.idp_dim = h->ekf_idp; e.if_fej = h->flags.if_fej; e.poses = h->d_poses;
+            e.anchor = h->d_ekf_i; e.state = h->d_ekf_i + cap;
+            e.param = h->d_slam; e.inv_depth = e.param + (size_t)3 * cap; e.p_w = e.inv_depth + cap; e.p_fej = e.p_w + (size_t)3 * cap;
+            e.z = e.p_fej + (size_t)3 * cap;
+            e.He = h->d_ekf_d; e.Ha = e.He + (size_t)12 * cap; e.Hx = e.Ha + (size_t)12 * cap; e.Hf = e.Hx + (size_t)12 * cap;
+            e.r = e.Hf + (size_t)6 * cap + (size_t)2 * cap;
+            hipLaunchKernelGGL(k_ekf_eval, dim3((F + 63) / 64), dim3(64), 0, s, e);
+        }
+        EkfGateArgs a;
+        a.F = F; a.idp_dim = h->ekf_idp; a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP;
+        a.estimate_td = h->flags.estimate_td;
+        a.anchor = h->d_ekf_i; a.state = h->d_ekf_i + cap; a.slot = h->d_ekf_i + 2 * cap;
+        a.He = h->d_ekf_d; a.Ha = a.He + (size_t)12 * cap; a.Hx = a.Ha + (size_t)12 * cap; a.Hf = a.Hx + (size_t)12 * cap;
+        a.zvel = a.Hf + (size_t)6 * cap; a.r = a.zvel + (size_t)2 * cap;
+        a.P = h->d_P; a.sigma2 = h->flags.noise_feature * h->flags.noise_feature;
+        a.threshold = orcvio_msckf_chi2_quantile(2, h->flags.chi2_prob);
+        a.E = h->d_ekf_E; a.gamma = h->d_ekf_gamma; a.accept = h->d_ekf_accept;
+        hipLaunchKernelGGL(k_ekf_gate, dim3(F), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, 1), dim3(256), 0, s, (const double*)h->d_ekf_E, 2 * F, h->NAP, round_up(2 * F, 8),
+                           h->d_Gekf, (const int*)nullptr);
+    }
+    if (h->dense_rows > 0) {   // their Gram into the scratch behind d_Gekf, then summed (fixed order)
+        double* G2 = h->d_Gekf + (size_t)h->NAP_max * h->NAP_max;
+        hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, 1), dim3(256), 0, s, (const double*)h->d_dense, h->dense_rows, h->NAP,
+                           round_up(h->dense_rows, 8), F > 0 ? G2 : h->d_Gekf, (const int*)nullptr);
+        if (F > 0) {
+            const int total = h->NAP * h->NAP;
+            hipLaunchKernelGGL(k_add_inplace, dim3((total + 255) / 256), dim3(256), 0, s, h->d_Gekf, (const double*)G2, total);
+        }
+    }
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -979,7 +994,7 @@ static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
 static int ekf_reserve(orcvio_msckf_handle* h, int F) {
     if (F <= h->ekf_cap) return ORCVIO_OK;
     HIPCHK(hipDeviceSynchronize());
-    void* old[] = {h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam};
+    void* old[] = {h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense};
     for (void* q : old) if (q) (void)hipFree(q);
     const int cap = round_up(F, 32);
     HIPCHK(hipMalloc(&h->d_ekf_i, sizeof(int) * 3 * cap));
@@ -988,7 +1003,7 @@ static int ekf_reserve(orcvio_msckf_handle* h, int F) {
     HIPCHK(hipMalloc(&h->d_ekf_gamma, sizeof(double) * cap));
     HIPCHK(hipMalloc(&h->d_ekf_accept, sizeof(int) * cap));
     HIPCHK(hipMalloc(&h->d_slam, sizeof(double) * 12 * cap));
-    if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)h->NAP_max * h->NAP_max));
+    if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)2 * h->NAP_max * h->NAP_max));
     h->ekf_cap = cap;
     return ORCVIO_OK;
 }
@@ -1055,6 +1070,34 @@ int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_
     if (rows->z_vel) HIPCHK(hipMemcpy(q, rows->z_vel, sizeof(double) * 2 * F, hipMemcpyHostToDevice));
     q += (size_t)2 * cap;
     HIPCHK(hipMemcpy(q, rows->r, sizeof(double) * 2 * F, hipMemcpyHostToDevice));
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, const double* H, const double* r) {
+    if (!h || !h->uploaded || n_rows < 0 || (n_rows > 0 && (!H || !r))) { g_last_error = "upload_dense_rows: upload the window first"; return ORCVIO_ERR_INVALID; }
+    if (h->n_extra > 0 && !h->ekf_mode) { g_last_error = "upload_dense_rows: with extra states set ORCVIO_OPT_EKF_ROWS before the upload"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    if (n_rows > h->dense_cap) {
+        HIPCHK(hipDeviceSynchronize());
+        if (h->d_dense) (void)hipFree(h->d_dense);
+        h->dense_cap = round_up(n_rows, 64);
+        HIPCHK(hipMalloc(&h->d_dense, sizeof(double) * (size_t)h->dense_cap * h->NAP_max));
+    }
+    if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)2 * h->NAP_max * h->NAP_max));
+    h->dense_rows = n_rows;
+    h->graph_valid = false;
+    if (n_rows == 0) return ORCVIO_OK;
+    const int n = h->n, NA = h->NA, NAP = h->NAP;
+    for (int i = 0; i < n_rows; ++i)
+        for (int c = 0; c < 15; ++c)
+            if (H[(size_t)i * n + c] != 0.0) { g_last_error = "upload_dense_rows: the first 15 columns (IMU state) must be zero"; return ORCVIO_ERR_INVALID; }
+    std::vector<double> st((size_t)n_rows * NAP, 0.0);   // [H(:, 15:15+NA) | r | 0]
+    for (int i = 0; i < n_rows; ++i) {
+        std::memcpy(&st[(size_t)i * NAP], H + (size_t)i * n + 15, sizeof(double) * NA);
+        st[(size_t)i * NAP + NA] = r[i];
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_dense, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
     return ORCVIO_OK;
 }
 
@@ -1295,7 +1338,7 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     h->N = N; h->F = 0; h->nobs = 0;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
     h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
-    h->ekf_F = 0;
+    h->ekf_F = 0; h->dense_rows = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);
@@ -1385,7 +1428,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     h->N = N; h->F = 0; h->nobs = 0;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
     h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
-    h->ekf_F = 0;
+    h->ekf_F = 0; h->dense_rows = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     h->NP = round_up(h->n, 16);

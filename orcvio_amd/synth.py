@@ -170,6 +170,33 @@ def make_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_frac: 
     return out
 
 
+def make_new_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_frac: float = 0.0):
+    """Features about to ENTER the state of the hybrid filter: anchored at the first clone of a contiguous run of 3..7
+    observations (oracle.mirror_hybrid.NewSlamFeature-shaped dicts: anchor, inv_param, obs_anchor, inv_depth, p_w, obs)."""
+    rng = np.random.default_rng(30_000 + seed)
+    sig = win.flags.noise_feature
+    out = []
+    for _ in range(n_feat):
+        M = int(rng.integers(3, min(win.N, 7) + 1))
+        start = int(rng.integers(0, win.N - M + 1))
+        a = start
+        R_c2w = win.R_b2w[a] @ win.R_b2c[a].T
+        t_c_w = win.t_b_w[a] + win.R_b2w[a] @ win.t_c_b[a]
+        pc = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(4.0, 12.0)])
+        pw = R_c2w @ pc + t_c_w
+        inv = np.array([pc[0] / pc[2], pc[1] / pc[2], 1.0 / pc[2]])
+        noise = sig * (12.0 if rng.random() < outlier_frac else 1.0)
+        obs = []
+        for k in range(start, start + M):
+            Rk = win.R_b2c[k] @ win.R_b2w[k].T
+            tk = win.t_b_w[k] + win.R_b2w[k] @ win.t_c_b[k]
+            pk = Rk @ (pw - tk)
+            obs.append((k, pk[:2] / pk[2] + noise * rng.standard_normal(2), 0.05 * rng.standard_normal(2)))
+        out.append(dict(anchor=a, inv_param=inv, obs_anchor=np.array([inv[0], inv[1], 1.0]), inv_depth=float(inv[2]),
+                        p_w=pw + 0.01 * rng.standard_normal(3), obs=obs))
+    return out
+
+
 def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,
                 flags: Flags | None = None, estimate_extrin: bool = False,
                 sigma_px: float | None = None, outlier_frac: float = 0.0) -> Window:

@@ -89,3 +89,66 @@ def test_anchor_equal_to_the_observing_state(upd):
     assert rel(got['ekf_gamma'], ref['ekf_gamma']) < 1e-9
     assert rel(got['dx'], ref['dx']) < TOL
     assert rel(got['P_new'], ref['P_new']) < TOL
+
+
+@pytest.mark.parametrize('idp', [3, 1])
+def test_frame_with_new_slam_features(upd, idp):
+    """The integration recipe of INTEGRATION.md 7b for a frame in which NEW SLAM features enter the state: the caller's
+    own small host code (featureJacobian_ekf_new, the MSCKF gate of the new features, the W = [V | U] split; here the
+    restatement stands in for it) produces the V-part rows, which go to the device as dense rows under the MSCKF tracks
+    and the rows of the existing SLAM features; the H_1 / H_2 augmentation (src/orcvio.cpp:1811-1947) is applied to the
+    downloaded delta_x and covariance.  Result: the reference's full hybrid update (oracle.hybrid_update_full)."""
+    w0 = synth.make_window(N=10, F=60, seed=17, track_len=(3, 10), flags=synth.Flags(use_larvio=1, estimate_td=1))
+    slam = synth.make_slam_features(w0, 7, seed=5, outlier_frac=0.25)
+    w = synth.with_extra_states(w0, idp * len(slam), seed=4)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 5, seed=9, outlier_frac=0.5)]
+    ref = mh.hybrid_update_full(w, slam, new, idp)
+    assert 0 < len(ref['new_accept']) < len(new)
+    # --- caller side (CPU): rows of the new features
+    acc, H_top, r_top, H_1, H_2, r_1 = mh.split_new_rows(w, new, idp)
+    assert acc == ref['new_accept']
+    # --- device: one joint update with everything that has no column in the new states
+    upd.set_extra_states(w.n_extra)
+    upd.set_ekf_rows_mode(True)
+    try:
+        upd.upload(w)
+        upd.upload_slam_features(idp, slam)
+        upd.upload_dense_rows(H_top, r_top)
+        upd.run_update()
+        upd.sync()
+        got = upd.download()
+        _, ekf_accept = upd.download_ekf()
+    finally:
+        upd.set_ekf_rows_mode(False)
+        upd.set_extra_states(0)
+    assert np.array_equal(ekf_accept, ref['ekf_accept'])
+    assert np.array_equal(got['accept'], ref['accept'])
+    assert rel(got['dx'], ref['dx_leg']) < TOL
+    assert rel(got['P_new'], ref['P_upd']) < TOL
+    # --- caller side again: the new states and the augmented covariance
+    dx, P = mh.augment_after_update(got['P_new'], got['dx'], H_1, H_2, r_1, w.flags.noise_feature ** 2)
+    assert dx.shape[0] == w.n + idp * len(acc)
+    assert rel(dx, ref['dx']) < TOL
+    assert rel(P, ref['P_new']) < TOL
+
+
+def test_dense_rows_alone(upd):
+    """orcvio_msckf_upload_dense_rows without SLAM features or extra states: arbitrary caller-projected rows stacked
+    under the MSCKF blocks."""
+    from oracle import mirror
+    w = synth.make_window(N=7, F=30, seed=8, track_len=(3, 7))
+    rng = np.random.default_rng(0)
+    H = np.zeros((11, w.n))
+    H[:, 15:] = 0.3 * rng.standard_normal((11, w.n - 15)) * (rng.random((11, w.n - 15)) < 0.3)
+    r = 0.01 * rng.standard_normal(11)
+    base = mirror.msckf_update(w)
+    Hs = np.vstack([b for b, a in zip(base['blocks'], base['accept']) if a] + [H])
+    rs = np.concatenate([b for b, a in zip(base['rs'], base['accept']) if a] + [r])
+    dx, _, Pn = mirror.measurement_update(*mirror.qr_compress(Hs, rs), w.P, w.flags.noise_feature ** 2)
+    upd.upload(w)
+    upd.upload_dense_rows(H, r)
+    upd.run_update()
+    upd.sync()
+    got = upd.download()
+    assert rel(got['dx'], dx) < TOL
+    assert rel(got['P_new'], Pn) < TOL

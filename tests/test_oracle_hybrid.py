@@ -97,3 +97,35 @@ def test_joint_update_is_the_sequential_update(idp):
     # gate values are those of the individual row pairs against the prior
     for (H, r), g in zip(joint['ekf_rows'], joint['ekf_gamma']):
         assert abs(g - r @ np.linalg.solve(H @ w.P @ H.T + s2 * np.eye(2), r)) <= 1e-12 * max(1.0, g)
+
+
+@pytest.mark.parametrize('idp', [3, 1])
+def test_new_feature_update_does_not_depend_on_the_bases(idp):
+    """The reference takes V from a full-U SVD and U from SPQR's Q (src/orcvio.cpp:2420-2431); the restatement takes both
+    from one complete QR.  The update only depends on the two SUBSPACES: rotating either basis changes nothing; and the
+    augmented covariance stays symmetric positive semi-definite."""
+    w0 = synth.make_window(N=9, F=30, seed=5, track_len=(3, 9))
+    slam = synth.make_slam_features(w0, 5, seed=1)
+    w = synth.with_extra_states(w0, idp * len(slam), seed=2)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 4, seed=3)]
+    ref = mh.hybrid_update_full(w, slam, new, idp)
+    acc, H_top, r_top, H_1, H_2, r_1 = mh.split_new_rows(w, new, idp)
+    rng = np.random.default_rng(0)
+    Qv, _ = np.linalg.qr(rng.standard_normal((H_top.shape[0], H_top.shape[0])))
+    Qu, _ = np.linalg.qr(rng.standard_normal((H_2.shape[0], H_2.shape[0])))
+    s2 = w.flags.noise_feature ** 2
+    base = mirror.msckf_update(w)
+    blocks = [b for b, a in zip(base['blocks'], base['accept']) if a]
+    rs = [b for b, a in zip(base['rs'], base['accept']) if a]
+    for idx, ft in enumerate(slam):
+        H, r = mh.feature_jacobian_ekf(w, ft, idx, idp)
+        if ref['ekf_accept'][idx]:
+            blocks.append(H); rs.append(r)
+    blocks.append(Qv.T @ H_top); rs.append(Qv.T @ r_top)
+    H_o = np.vstack(blocks); r_o = np.concatenate(rs)
+    dx_leg, _, P_upd = mirror.measurement_update(H_o, r_o, w.P, s2)
+    dx, P = mh.augment_after_update(P_upd, dx_leg, Qu.T @ H_1, Qu.T @ H_2, Qu.T @ r_1, s2)
+    assert rel(dx, ref['dx']) < 1e-9
+    assert rel(P, ref['P_new']) < 1e-9
+    assert np.linalg.eigvalsh(ref['P_new']).min() > -1e-12
+    assert ref['P_new'].shape[0] == w.n + idp * len(acc)
