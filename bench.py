@@ -7,6 +7,7 @@ N=1: config 2 (30 clones x 400 features x 30 observations).  N>1 (weak scaling):
 holds its own shard of 400 features of one joint update; per step the ranks all-gather their
 compressed blocks over RCCL and each performs the (replicated) Kalman solve.
 """
+import gc
 import argparse
 import json
 import os
@@ -170,11 +171,14 @@ def main():
         if world == 1:
             for _ in range(5):
                 upd.update_features(win)
+            gc.collect()
+            gc.disable()   # (a collection of the interpreter in the middle of a call costs tens of ms: not the library's)
             th = time.perf_counter()
             reps_h = 50
             for _ in range(reps_h):
                 upd.update_features(win)
             th = (time.perf_counter() - th) / reps_h
+            gc.enable()
             host_inclusive = dict(updates_per_s=1.0 / th, ms_per_update=th * 1e3,
                                   what='orcvio_msckf_update_features: host tracks + P in, dx, P+, gamma, accept out')
         # config 3 adds 20 objects x 12 keypoints to the same window: the object update (a second EKF update per frame in
@@ -198,10 +202,13 @@ def main():
                     return int(out['accept'][0]), int(res.stats[0])
                 for _ in range(5):
                     g = call()
+                gc.collect()
+                gc.disable()
                 to = time.perf_counter()
                 for _ in range(20):
                     g = call()
                 to = (time.perf_counter() - to) / 20
+                gc.enable()
                 objects = dict(ms_per_update=to * 1e3, objects=20, accepted=g[0], dof=g[1],
                                what='orcvio_msckf_update_object_tracks: 20 cars x 12 keypoints x 30 frames, rows evaluated on the '
                                     'device, host buffers in, dx and P+ out')

@@ -1242,13 +1242,26 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
 
 int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* window,
                                      const orcvio_msckf_tracks* tracks, const double* P, orcvio_msckf_result* result) {
+    static const bool timing = getenv("ORCVIO_TIMING") != nullptr;   // diagnostics: calls slower than 2 ms are broken down
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = orcvio_msckf_upload(h, flags, window, tracks, P);
     if (rc != ORCVIO_OK) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_run_update(h, nullptr);
     if (rc != ORCVIO_OK) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_sync(h, nullptr);
     if (rc != ORCVIO_OK) return rc;
-    return orcvio_msckf_download(h, result);
+    const auto t3 = std::chrono::steady_clock::now();
+    rc = orcvio_msckf_download(h, result);
+    const auto t4 = std::chrono::steady_clock::now();
+    if (timing) {
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        if (us(t0, t4) > 2000.0)
+            fprintf(stderr, "update_features: upload %.0f us, run (enqueue) %.0f us, sync %.0f us, download %.0f us\n", us(t0, t1), us(t1, t2),
+                    us(t2, t3), us(t3, t4));
+    }
+    return rc;
 }
 
 // Object update: OrcVIO::removeLostObjects (src/orcvio.cpp:2154-2193).  Every object block is projected

@@ -25,10 +25,13 @@ for cfg in (1, 2, 4, 5):
     # host-inclusive
     for _ in range(10):   # the first calls at a new shape pay one-off costs (code load, graph capture): several ms
         upd.update_features(w)
+    import gc
+    gc.collect(); gc.disable()   # (an interpreter collection inside a call costs tens of ms: not the library's)
     t0 = time.perf_counter()
     for _ in range(20):
         upd.update_features(w)
     out[f'config{cfg}']['host_inclusive_ms'] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+    gc.enable()
 # config 3: 20 objects
 from oracle import mirror_objects as mo
 flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
