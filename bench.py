@@ -96,6 +96,8 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()   # the timed region is tens of ms: an interpreter collection in the middle of it would be most of it
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -107,6 +109,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
