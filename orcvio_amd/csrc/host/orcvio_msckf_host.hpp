@@ -57,6 +57,9 @@ struct StateServer {
     double td = 0;
     double imu_intrinsics[24] = {0};
     std::vector<double> state_cov;   // n x n, symmetric
+    // hybrid filter: ids of the EKF-SLAM features in the state, in state order (StateServer::feature_states,
+    // include/orcvio/state.h; their columns follow the clones, src/orcvio.cpp:1495-1510)
+    std::vector<FeatureIDType> feature_states;
     int dim() const { return (int)std::lround(std::sqrt((double)state_cov.size())); }
 };
 
@@ -72,6 +75,7 @@ struct Feature {
     double invParam[3] = {0, 0, 0};   // (alpha, beta, rho) in the anchor camera frame
     StateIDType id_anchor = -1;
     double invDepth = 0;
+    double obs_anchor[3] = {0, 0, 1};   // corrected observation in the anchor frame (1-d inverse depth, feature.hpp)
     bool failed_by_neg_dpth = false, failed_by_big_proj = false;
 };
 typedef std::map<FeatureIDType, Feature> MapServer;
@@ -83,6 +87,8 @@ struct UpdateOutcome {
     std::vector<int> accepted;     // per listed feature
     std::vector<double> gamma;
     std::vector<double> delta_x;
+    std::vector<int> ekf_accepted;   // hybridUpdate: per listed SLAM feature
+    std::vector<double> ekf_gamma;
 };
 
 class MsckfBackend {
@@ -172,6 +178,95 @@ class MsckfBackend {
         if (out.updated) {
             ss.state_cov.swap(P_new);                       // P is updated even when delta_x is discarded (:4479-4494)
             out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
+        }
+        return out;
+    }
+
+    // ---- hybrid filter: the same call site with EKF-SLAM features in the state (and none being initialised) --------
+    // removeLostFeatures, src/orcvio.cpp:2444-2560: the MSCKF loop as above, featureJacobian_ekf + gatingTestFeature(.., 2)
+    // for every SLAM feature of `ekf_ids` the current state observes, ONE update with everything that passed
+    // (measurementUpdate_hybrid, :1766-1950, sz_new == 0), incrementState_IMUCam, and the write-back of the feature states
+    // (:1836-1887).  state_cov is (LEG + 6N + d |feature_states|)^2.
+    int feature_idp_dim = 3;
+    UpdateOutcome hybridUpdate(StateServer& ss, MapServer& map_server, const std::vector<FeatureIDType>& msckf_ids,
+                               const std::vector<FeatureIDType>& ekf_ids) {
+        UpdateOutcome out;
+        const int d = feature_idp_dim;
+        std::vector<double> R_b2w, t_b_w, t_fej, R_b2c, t_c_b, p_w, obs_z, obs_zvel;
+        std::vector<int32_t> obs_ptr, obs_clone;
+        std::map<StateIDType, int> index_of;
+        flattenWindow(ss, R_b2w, t_b_w, t_fej, R_b2c, t_c_b, index_of);
+        flattenTracks(map_server, msckf_ids, index_of, {}, p_w, obs_ptr, obs_clone, obs_z, obs_zvel);
+        const int N = (int)index_of.size(), nf = (int)ss.feature_states.size();
+        const int base = flags.leg_dim + 6 * N, n = base + d * nf;
+        if (ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        const StateIDType imu_id = ss.imu_state.id;
+        if (!index_of.count(imu_id)) { out.status = ORCVIO_ERR_INVALID; return out; }
+        // the SLAM features as Feature holds them
+        std::vector<int32_t> anchor, state, slot;
+        std::vector<double> param, rho, pw, pfej, z, zvel;
+        for (FeatureIDType fid : ekf_ids) {
+            const Feature& f = map_server.at(fid);
+            auto it = std::find(ss.feature_states.begin(), ss.feature_states.end(), fid);
+            auto ob = f.observations.find(imu_id);
+            if (it == ss.feature_states.end() || ob == f.observations.end() || !index_of.count(f.id_anchor)) { out.status = ORCVIO_ERR_INVALID; return out; }
+            anchor.push_back(index_of.at(f.id_anchor));
+            state.push_back(index_of.at(imu_id));
+            slot.push_back((int32_t)(it - ss.feature_states.begin()));
+            const double* prm = d == 3 ? f.invParam : f.obs_anchor;
+            param.insert(param.end(), prm, prm + 3);
+            rho.push_back(f.invDepth);
+            pw.insert(pw.end(), f.position, f.position + 3);
+            pfej.insert(pfej.end(), f.position_FEJ, f.position_FEJ + 3);
+            z.push_back(ob->second.x); z.push_back(ob->second.y);
+            auto v = f.observations_vel.find(imu_id);
+            zvel.push_back(v == f.observations_vel.end() ? 0.0 : v->second.x);
+            zvel.push_back(v == f.observations_vel.end() ? 0.0 : v->second.y);
+        }
+        orcvio_msckf_window w{N, R_b2w.data(), t_b_w.data(), t_fej.data(), R_b2c.data(), t_c_b.data()};
+        orcvio_msckf_tracks t{(int32_t)msckf_ids.size(), p_w.data(), obs_ptr.data(), obs_clone.data(), obs_z.data(), obs_zvel.data()};
+        orcvio_msckf_slam_features sf{(int32_t)ekf_ids.size(), d, anchor.data(), state.data(), slot.data(), param.data(), rho.data(),
+                                      pw.data(), pfej.data(), z.data(), zvel.data()};
+        out.accepted.assign(msckf_ids.size(), 0);
+        out.gamma.assign(msckf_ids.size(), 0.0);
+        out.ekf_accepted.assign(ekf_ids.size(), 0);
+        out.ekf_gamma.assign(ekf_ids.size(), 0.0);
+        out.delta_x.assign(n, 0.0);
+        std::vector<double> P_new((size_t)n * n);
+        orcvio_msckf_result r{};
+        r.dx = out.delta_x.data(); r.P_out = P_new.data(); r.accept = out.accepted.data(); r.gamma = out.gamma.data();
+        auto step = [&](int rc) { if (out.status == ORCVIO_OK) out.status = rc; };
+        step(orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, d * nf));
+        step(orcvio_msckf_set_option(h_, ORCVIO_OPT_EKF_ROWS, 1));
+        if (out.status == ORCVIO_OK) step(orcvio_msckf_upload(h_, &flags, &w, &t, ss.state_cov.data()));
+        if (out.status == ORCVIO_OK) step(orcvio_msckf_upload_slam_features(h_, &sf));
+        if (out.status == ORCVIO_OK) step(orcvio_msckf_run_update(h_, nullptr));
+        if (out.status == ORCVIO_OK) step(orcvio_msckf_download(h_, &r));
+        if (out.status == ORCVIO_OK) step(orcvio_msckf_download_ekf(h_, out.ekf_gamma.data(), out.ekf_accepted.data()));
+        (void)orcvio_msckf_set_option(h_, ORCVIO_OPT_EKF_ROWS, 0);
+        (void)orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, 0);
+        if (out.status != ORCVIO_OK) return out;
+        int nacc = 0;
+        for (int a : out.ekf_accepted) nacc += a;
+        out.updated = r.stats[3] != 0 || nacc > 0;
+        if (!out.updated) return out;
+        ss.state_cov.swap(P_new);
+        std::vector<double> dx_leg(out.delta_x.begin(), out.delta_x.begin() + base);
+        out.state_incremented = incrementState_IMUCam(ss, dx_leg);   // (:1833)
+        if (!out.state_incremented) return out;
+        for (int i = 0; i < nf; ++i) {                                // (:1836-1887)
+            Feature& f = map_server.at(ss.feature_states[i]);
+            const IMUState_Aug& a = ss.imu_states_augment.at(f.id_anchor);
+            double p_c[3];
+            if (d == 3) {
+                for (int k = 0; k < 3; ++k) f.invParam[k] += out.delta_x[base + 3 * i + k];
+                p_c[0] = f.invParam[0] / f.invParam[2]; p_c[1] = f.invParam[1] / f.invParam[2]; p_c[2] = 1.0 / f.invParam[2];
+            } else {
+                f.invDepth += out.delta_x[base + i];
+                p_c[0] = f.obs_anchor[0] / f.invDepth; p_c[1] = f.obs_anchor[1] / f.invDepth; p_c[2] = 1.0 / f.invDepth;
+            }
+            for (int k = 0; k < 3; ++k)
+                f.position[k] = a.orientation_cam[3 * k] * p_c[0] + a.orientation_cam[3 * k + 1] * p_c[1] + a.orientation_cam[3 * k + 2] * p_c[2] + a.position_cam[k];
         }
         return out;
     }
