@@ -192,8 +192,12 @@ def make_new_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_fr
             tk = win.t_b_w[k] + win.R_b2w[k] @ win.t_c_b[k]
             pk = Rk @ (pw - tk)
             obs.append((k, pk[:2] / pk[2] + noise * rng.standard_normal(2), 0.05 * rng.standard_normal(2)))
-        out.append(dict(anchor=a, inv_param=inv, obs_anchor=np.array([inv[0], inv[1], 1.0]), inv_depth=float(inv[2]),
-                        p_w=pw + 0.01 * rng.standard_normal(3), obs=obs))
+        # the estimate the filter would hold after triangulation: perturbed in the anchor camera frame, world position
+        # and inverse-depth parameters consistent with each other (Feature::initializePosition sets both from one solution)
+        pce = pc + 0.01 * rng.standard_normal(3)
+        inve = np.array([pce[0] / pce[2], pce[1] / pce[2], 1.0 / pce[2]])
+        out.append(dict(anchor=a, inv_param=inve, obs_anchor=np.array([inve[0], inve[1], 1.0]), inv_depth=float(inve[2]),
+                        p_w=R_c2w @ pce + t_c_w, obs=obs))
     return out
 
 

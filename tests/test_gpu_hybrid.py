@@ -152,3 +152,46 @@ def test_dense_rows_alone(upd):
     got = upd.download()
     assert rel(got['dx'], dx) < TOL
     assert rel(got['P_new'], Pn) < TOL
+
+
+def test_new_3d_features_are_msckf_tracks_in_the_joint_update(upd):
+    """For the 3-parameter inverse-depth form, the V part of a NEW feature's rows (src/orcvio.cpp:2416-2436) is its
+    MSCKF block: H_f(idp) = H_f(xyz) J with J invertible (same column space, same left null space), and
+    featureJacobian_ekf_new differs from featureJacobian_msckf only by terms H_f(xyz) X with X common to all rows
+    (anchor-pose and extrinsic dependence of the world point) -- which V^T removes.  The reference even gates the new
+    feature with the MSCKF test (:2361-2367).  So the joint update needs no special input for them: list them as
+    tracks.  (Not so for the 1-parameter form, which fixes the bearing in the anchor frame.)"""
+    w0 = synth.make_window(N=10, F=60, seed=17, track_len=(3, 10), flags=synth.Flags(use_larvio=1, estimate_td=1))
+    slam = synth.make_slam_features(w0, 7, seed=5, outlier_frac=0.25)
+    w = synth.with_extra_states(w0, 3 * len(slam), seed=4)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 5, seed=9, outlier_frac=0.5)]
+    ref = mh.hybrid_update_full(w, slam, new, 3)
+    assert 0 < len(ref['new_accept']) < len(new)
+    # the window again, with the new features appended as ordinary tracks
+    import dataclasses
+    obs_ptr = list(w.obs_ptr)
+    obs_clone, obs_z, obs_zvel = list(w.obs_clone), list(w.obs_z), list(w.obs_zvel)
+    p_w = list(w.p_w)
+    for ft in new:
+        p_w.append(ft.p_w)
+        for (k, z, zv) in ft.obs:
+            obs_clone.append(k); obs_z.append(z); obs_zvel.append(zv)
+        obs_ptr.append(len(obs_clone))
+    w2 = dataclasses.replace(w, p_w=np.ascontiguousarray(p_w), obs_ptr=np.asarray(obs_ptr, dtype=np.int32),
+                             obs_clone=np.asarray(obs_clone, dtype=np.int32), obs_z=np.ascontiguousarray(obs_z).reshape(-1, 2),
+                             obs_zvel=np.ascontiguousarray(obs_zvel).reshape(-1, 2))
+    upd.set_extra_states(w2.n_extra)
+    upd.set_ekf_rows_mode(True)
+    try:
+        upd.upload(w2)
+        upd.upload_slam_features(3, slam)
+        upd.run_update()
+        upd.sync()
+        got = upd.download()
+    finally:
+        upd.set_ekf_rows_mode(False)
+        upd.set_extra_states(0)
+    acc_new = [i for i in range(len(new)) if got['accept'][w.F + i]]
+    assert acc_new == ref['new_accept']          # the device gate of the track IS the reference's gate of the new feature
+    assert rel(got['dx'], ref['dx_leg']) < TOL
+    assert rel(got['P_new'], ref['P_upd']) < TOL
