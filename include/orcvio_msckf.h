@@ -196,6 +196,17 @@ int32_t orcvio_msckf_upload_slam_features(orcvio_msckf_handle* h, const orcvio_m
  * V-part rows (zero in the new features' columns) over here, and applies the reference's own H_1 / H_2 algebra
  * (:1811-1947) to the downloaded delta_x and covariance.  The rows belong to the upload they follow. */
 int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, const double* H, const double* r);
+/* New SLAM features in the 3-parameter form need no special rows: list them among the tracks (the V part of their rows is
+ * their MSCKF block).  After the update, this call returns their correction and the augmented
+ * covariance -- measurementUpdate_hybrid, src/orcvio.cpp:1811-1821 and :1904-1947, without nuisance states -- from what the
+ * feature kernel left on the device for those tracks (host arithmetic on a few 3 x n blocks):
+ *   track[j]      index of new feature j among the tracks of the last upload (it must have been accepted)
+ *   anchor[j]     its anchor clone (window index);  inv_param [j][3] = Feature::invParam
+ *   dx, P_upd     delta_x [n] and covariance [n][n] of the update just downloaded
+ *   dx_new [3 n_new];  P_aug [(n + 3 n_new)^2] = [[P_upd, (-HH P)^T], [-HH P, P22]] */
+int32_t orcvio_msckf_augment_new_features(orcvio_msckf_handle* h, const orcvio_msckf_window* window, int32_t n_new,
+                                          const int32_t* track, const int32_t* anchor, const double* inv_param,
+                                          const double* dx, const double* P_upd, double* dx_new, double* P_aug);
 /* gamma[F], accept[F] of the SLAM features of the last update (either may be NULL) */
 int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept);
 

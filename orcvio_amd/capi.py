@@ -34,7 +34,7 @@ EXPORTS = [
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
-    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows',
+    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features',
 ]
 
 
@@ -268,6 +268,24 @@ class MsckfUpdater:
         rc = self.lib.orcvio_msckf_upload_dense_rows(self.h, H.shape[0], _d(H), _d(r))
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_upload_dense_rows')
+
+    def augment_new_features(self, win, track, anchor, inv_param, dx, P_upd):
+        """New 3-d SLAM features that were listed as tracks: (dx_new [3k], P_aug [(n+3k)^2]) after the update."""
+        fl, wn, tr, keep = self._structs(win)
+        k = len(track)
+        n = P_upd.shape[0]
+        ti = np.ascontiguousarray(track, dtype=np.int32)
+        ai = np.ascontiguousarray(anchor, dtype=np.int32)
+        ip = np.ascontiguousarray(inv_param, dtype=np.float64).reshape(k, 3)
+        dxc = np.ascontiguousarray(dx, dtype=np.float64)
+        Pc = np.ascontiguousarray(P_upd, dtype=np.float64)
+        dx_new = np.zeros(3 * k)
+        P_aug = np.zeros((n + 3 * k, n + 3 * k))
+        rc = self.lib.orcvio_msckf_augment_new_features(self.h, C.byref(wn), k, ti.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                        ai.ctypes.data_as(C.POINTER(C.c_int32)), _d(ip), _d(dxc), _d(Pc), _d(dx_new), _d(P_aug))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_augment_new_features')
+        return dx_new, P_aug
 
     def download_ekf(self):
         F = getattr(self, '_ekf_F', 0)

@@ -91,6 +91,7 @@ struct orcvio_msckf_handle {
     double* d_dense = nullptr;          // [dense_cap][NAP_max]
     bool ekf_eval = false;              // the four blocks are evaluated on the device from the SLAM features (k_ekf_eval)
     double* d_slam = nullptr;           // [12 cap] param 3 | inv_depth 1 | p_w 3 | p_fej 3 | z 2
+    double* d_Rf = nullptr;             // [maxF][6] R factor of every track's H_f (k_feature), for orcvio_msckf_augment_new_features
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     bool A_deferred = false;            // the last run left S / Gpart only: d_A is assembled on demand (assemble_deferred)
     int front_chunks = 1;               // T3 row chunks of the last k_front launch
@@ -206,7 +207,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_obs,
                     h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
-                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense};
+                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense, h->d_Rf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -315,6 +316,7 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         h->d_flag = h->d_info + 32;
         HIPCHK(hipMalloc(&h->d_chi2, sizeof(double) * ORCVIO_CHI2_TABLE));
         HIPCHK(hipMalloc(&h->d_T3, sizeof(double) * (size_t)3 * max_features * h->NAP_max));
+        HIPCHK(hipMalloc(&h->d_Rf, sizeof(double) * (size_t)6 * max_features));
         HIPCHK(hipMalloc(&h->d_Xobs, sizeof(double) * (size_t)32 * max_observations));
         HIPCHK(hipMalloc(&h->d_S, sizeof(double) * (size_t)256 * (2 * max_observations / 256 + max_clones + 2)));
         HIPCHK(hipMalloc(&h->d_clone_obs, sizeof(int) * max_observations));
@@ -545,7 +547,7 @@ static FeatArgs feature_args(const orcvio_msckf_handle* h) {
     a.poses = h->d_poses; a.p_w = h->d_pw; a.obs_ptr = h->d_obs_ptr; a.obs_clone = h->d_obs_clone;
     a.obs_z = h->d_obs_z; a.obs_zvel = h->d_obs_zvel; a.P = h->d_P; a.row_ptr = h->d_row_ptr; a.chi2 = h->d_chi2;
     a.skip = h->skip_active ? h->d_skip : nullptr;
-    a.Hs = h->materialize ? h->d_Hs : nullptr; a.T3 = h->d_T3; a.Xobs = h->d_Xobs; a.obs_pos = h->d_clone_obs; a.gamma = h->d_gamma; a.accept = h->d_accept;
+    a.Hs = h->materialize ? h->d_Hs : nullptr; a.T3 = h->d_T3; a.Xobs = h->d_Xobs; a.obs_pos = h->d_clone_obs; a.gamma = h->d_gamma; a.accept = h->d_accept; a.Rf = h->d_Rf;
     a.sigma2 = h->flags.noise_feature * h->flags.noise_feature;
     a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP; a.Mmax = h->Mmax; a.F = h->F;
     a.use_larvio = h->flags.use_larvio; a.use_left = h->flags.use_left_perturbation; a.if_fej = h->flags.if_fej;
@@ -994,7 +996,7 @@ static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
 static int ekf_reserve(orcvio_msckf_handle* h, int F) {
     if (F <= h->ekf_cap) return ORCVIO_OK;
     HIPCHK(hipDeviceSynchronize());
-    void* old[] = {h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense};
+    void* old[] = {h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam};
     for (void* q : old) if (q) (void)hipFree(q);
     const int cap = round_up(F, 32);
     HIPCHK(hipMalloc(&h->d_ekf_i, sizeof(int) * 3 * cap));
@@ -1098,6 +1100,126 @@ int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, c
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->d_dense, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
+    return ORCVIO_OK;
+}
+
+// New SLAM features, 3-parameter form, listed among the tracks of the last update: their correction and the augmented
+// covariance (measurementUpdate_hybrid, src/orcvio.cpp:1811-1821 and :1904-1947, without nuisance states).  Host
+// arithmetic on a few 3 x n blocks.  For a track, k_feature left T3 = Q1^T [J_msckf | r] and R = Q1^T H_f(xyz); the rows
+// of featureJacobian_ekf_new differ from the MSCKF rows by H_f(xyz) X, X = d p_w / d(state) at fixed inverse-depth
+// parameters (anchor pose, extrinsics), and H_f(idp) = H_f(xyz) J_pf, J_pf = R_ca2w J_f, so that
+//   H_1 = T3_J + R X,   H_2 = R J_pf,   r_1 = T3_r        (:2433-2436 with U = Q1).
+int32_t orcvio_msckf_augment_new_features(orcvio_msckf_handle* h, const orcvio_msckf_window* win, int32_t n_new,
+                                          const int32_t* track, const int32_t* anchor, const double* inv_param,
+                                          const double* dx, const double* P_upd, double* dx_new, double* P_aug) {
+    if (!h || !win || !h->ran || n_new < 0 || (n_new > 0 && (!track || !anchor || !inv_param)) || !dx || !P_upd || !dx_new || !P_aug) {
+        g_last_error = "augment_new_features: null argument or no finished update"; return ORCVIO_ERR_INVALID;
+    }
+    if (h->flags.if_fej) { g_last_error = "augment_new_features: if_FEJ is not supported here (the anchor terms use the current estimates)"; return ORCVIO_ERR_INVALID; }
+    const int n = h->n, NA = h->NA, NAP = h->NAP, leg = h->flags.leg_dim, N = h->N, k3 = 3 * n_new, nt = n + k3;
+    for (int j = 0; j < n_new; ++j)
+        if (track[j] < 0 || track[j] >= h->F || anchor[j] < 0 || anchor[j] >= N) { g_last_error = "augment_new_features: index out of range"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->last_stream ? h->last_stream : h->stream));
+    std::vector<double> T3((size_t)3 * NAP), Rf(6), H1((size_t)k3 * n, 0.0), H2i((size_t)n_new * 9), HtH_i((size_t)n_new * 9), r1s(k3);
+    const double s2 = h->flags.noise_feature * h->flags.noise_feature;
+    auto inv3 = [](const double* A, double* B) {   // B = A^-1 (3 x 3)
+        const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+        const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+        B[0] = c00 / det; B[1] = (A[2] * A[7] - A[1] * A[8]) / det; B[2] = (A[1] * A[5] - A[2] * A[4]) / det;
+        B[3] = c01 / det; B[4] = (A[0] * A[8] - A[2] * A[6]) / det; B[5] = (A[2] * A[3] - A[0] * A[5]) / det;
+        B[6] = c02 / det; B[7] = (A[1] * A[6] - A[0] * A[7]) / det; B[8] = (A[0] * A[4] - A[1] * A[3]) / det;
+    };
+    for (int j = 0; j < n_new; ++j) {
+        HIPCHK(hipMemcpy(T3.data(), h->d_T3 + (size_t)3 * track[j] * NAP, sizeof(double) * 3 * NAP, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(Rf.data(), h->d_Rf + (size_t)6 * track[j], sizeof(double) * 6, hipMemcpyDeviceToHost));
+        const double R[9] = {Rf[0], Rf[1], Rf[2], 0.0, Rf[3], Rf[4], 0.0, 0.0, Rf[5]};
+        const int a = anchor[j];
+        const double* Ra = win->R_b2w + 9 * a;      // R_ba2w
+        const double* ta = win->t_b_w + 3 * a;
+        const double* Rbc = win->R_b2c + 9 * a;
+        const double* tcb = win->t_c_b + 3 * a;
+        const double* f = inv_param + 3 * j;
+        const double p_ca[3] = {f[0] / f[2], f[1] / f[2], 1.0 / f[2]};
+        double q[3], pb[3], pw_rel[3];            // q = R_b2c^T p_ca ; pb = q + t_c_b ; pw_rel = R_ba2w pb = p_w - t_ba
+        for (int i = 0; i < 3; ++i) q[i] = Rbc[i] * p_ca[0] + Rbc[3 + i] * p_ca[1] + Rbc[6 + i] * p_ca[2];
+        for (int i = 0; i < 3; ++i) pb[i] = q[i] + tcb[i];
+        for (int i = 0; i < 3; ++i) pw_rel[i] = Ra[3 * i] * pb[0] + Ra[3 * i + 1] * pb[1] + Ra[3 * i + 2] * pb[2];
+        // X (3 x n): anchor clone [-skew(p_w - t_ba), I]; extrinsics [-R_ba2w skew(q), R_ba2w]
+        std::vector<double> X((size_t)3 * n, 0.0);
+        const double S[9] = {0, -pw_rel[2], pw_rel[1], pw_rel[2], 0, -pw_rel[0], -pw_rel[1], pw_rel[0], 0};
+        const double Sq[9] = {0, -q[2], q[1], q[2], 0, -q[0], -q[1], q[0], 0};
+        for (int i = 0; i < 3; ++i)
+            for (int c = 0; c < 3; ++c) {
+                X[(size_t)i * n + leg + 6 * a + c] = -S[3 * i + c];
+                X[(size_t)i * n + leg + 6 * a + 3 + c] = (i == c) ? 1.0 : 0.0;
+                double m = 0.0;
+                for (int k = 0; k < 3; ++k) m += Ra[3 * i + k] * Sq[3 * k + c];
+                X[(size_t)i * n + 15 + c] = -m;
+                X[(size_t)i * n + 18 + c] = Ra[3 * i + c];
+            }
+        // H_1 = T3_J (active columns 15 .. 15+NA) + R X
+        for (int i = 0; i < 3; ++i) {
+            double* row = &H1[(size_t)(3 * j + i) * n];
+            for (int c = 0; c < NA; ++c) row[15 + c] = T3[(size_t)i * NAP + c];
+            for (int c = 0; c < n; ++c) {
+                double m = 0.0;
+                for (int k = i; k < 3; ++k) m += R[3 * i + k] * X[(size_t)k * n + c];
+                row[c] += m;
+            }
+            r1s[3 * j + i] = T3[(size_t)i * NAP + NA];
+        }
+        // H_2 = R R_ca2w J_f,  R_ca2w = R_ba2w R_b2c^T,  J_f = d p_ca / d(alpha, beta, rho)
+        double Rca[9], Jf[9] = {1.0 / f[2], 0.0, -f[0] / (f[2] * f[2]), 0.0, 1.0 / f[2], -f[1] / (f[2] * f[2]), 0.0, 0.0, -1.0 / (f[2] * f[2])};
+        for (int i = 0; i < 3; ++i)
+            for (int c = 0; c < 3; ++c) Rca[3 * i + c] = Ra[3 * i] * Rbc[3 * c] + Ra[3 * i + 1] * Rbc[3 * c + 1] + Ra[3 * i + 2] * Rbc[3 * c + 2];
+        double M1[9], H2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int c = 0; c < 3; ++c) M1[3 * i + c] = Rca[3 * i] * Jf[c] + Rca[3 * i + 1] * Jf[3 + c] + Rca[3 * i + 2] * Jf[6 + c];
+        for (int i = 0; i < 3; ++i)
+            for (int c = 0; c < 3; ++c) H2[3 * i + c] = R[3 * i] * M1[c] + R[3 * i + 1] * M1[3 + c] + R[3 * i + 2] * M1[6 + c];
+        inv3(H2, &H2i[9 * j]);
+        double HtH[9];
+        for (int i = 0; i < 3; ++i)
+            for (int c = 0; c < 3; ++c) HtH[3 * i + c] = H2[i] * H2[c] + H2[3 + i] * H2[3 + c] + H2[6 + i] * H2[6 + c];
+        inv3(HtH, &HtH_i[9 * j]);
+    }
+    // HH = H_2^-1 H_1 (block rows), dx_new = -HH dx + H_2^-1 r_1, nHHP = -HH P, P22 = HH P HH^T + s2 (H_2^T H_2)^-1
+    std::vector<double> HH((size_t)k3 * n, 0.0), nHHP((size_t)k3 * n, 0.0);
+    for (int j = 0; j < n_new; ++j)
+        for (int i = 0; i < 3; ++i)
+            for (int c = 0; c < n; ++c) {
+                double m = 0.0;
+                for (int k = 0; k < 3; ++k) m += H2i[9 * j + 3 * i + k] * H1[(size_t)(3 * j + k) * n + c];
+                HH[(size_t)(3 * j + i) * n + c] = m;
+            }
+    for (int j = 0; j < n_new; ++j)
+        for (int i = 0; i < 3; ++i) {
+            double m = 0.0;
+            for (int k = 0; k < 3; ++k) m += H2i[9 * j + 3 * i + k] * r1s[3 * j + k];
+            for (int c = 0; c < n; ++c) m -= HH[(size_t)(3 * j + i) * n + c] * dx[c];
+            dx_new[3 * j + i] = m;
+        }
+    for (int r = 0; r < k3; ++r)
+        for (int k = 0; k < n; ++k) {
+            const double hv = HH[(size_t)r * n + k];
+            if (hv == 0.0) continue;
+            const double* prow = P_upd + (size_t)k * n;
+            double* o = &nHHP[(size_t)r * n];
+            for (int c = 0; c < n; ++c) o[c] -= hv * prow[c];
+        }
+    for (int r = 0; r < n; ++r) std::memcpy(P_aug + (size_t)r * nt, P_upd + (size_t)r * n, sizeof(double) * n);
+    for (int r = 0; r < k3; ++r)
+        for (int c = 0; c < n; ++c) { P_aug[(size_t)(n + r) * nt + c] = nHHP[(size_t)r * n + c]; P_aug[(size_t)c * nt + n + r] = nHHP[(size_t)r * n + c]; }
+    for (int r = 0; r < k3; ++r)
+        for (int c = 0; c < k3; ++c) {
+            double m = 0.0;
+            for (int k = 0; k < n; ++k) m -= nHHP[(size_t)r * n + k] * HH[(size_t)c * n + k];
+            if (r / 3 == c / 3) m += s2 * HtH_i[9 * (r / 3) + 3 * (r % 3) + (c % 3)];
+            P_aug[(size_t)(n + r) * nt + n + c] = m;
+        }
+    for (int r = 0; r < nt; ++r)   // (:1946) symmetrise
+        for (int c = r + 1; c < nt; ++c) { const double m = 0.5 * (P_aug[(size_t)r * nt + c] + P_aug[(size_t)c * nt + r]); P_aug[(size_t)r * nt + c] = m; P_aug[(size_t)c * nt + r] = m; }
     return ORCVIO_OK;
 }
 

@@ -230,6 +230,7 @@ struct FeatArgs {
     const int* obs_pos;   // [nobs] position of every observation in the clone-sorted order
     double* gamma;
     int* accept;
+    double* Rf;           // optional [F][6]: upper triangle (r00 r01 r02 r11 r12 r22) of the R factor of H_f = Q R (same Q as T3)
     double sigma2;
     int n, leg, N, NA, NAP, Mmax, F;
     int use_larvio, use_left, if_fej, estimate_td;
@@ -338,7 +339,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
     if (wave == 0) {
         // ---- C: Householder QR of H_f (2M x 3), LAPACK dgeqr2 convention ------------------
         const int g0 = 2 * t, g1 = 2 * t + 1;
-        double v0[3], v1[3], beta[3];
+        double v0[3], v1[3], beta[3], rdiag[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             double s = 0.0;
@@ -347,11 +348,13 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
             const double nrm2 = wave_sum(s);
             const double alpha = __shfl((q & 1) ? a1[q] : a0[q], q >> 1);
             double bq = 0.0, sc = 0.0;
+            rdiag[q] = alpha;
             if (nrm2 != 0.0) {
                 const double nu = sqrt(alpha * alpha + nrm2);
                 const double bk = (alpha >= 0.0) ? -nu : nu;
                 bq = (bk - alpha) / bk;
                 sc = 1.0 / (alpha - bk);
+                rdiag[q] = bk;
             }
             beta[q] = bq;
             v0[q] = (g0 > q) ? a0[q] * sc : ((g0 == q) ? 1.0 : 0.0);
@@ -373,6 +376,10 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
         const double g20 = wave_sum(v0[2] * v0[0] + v1[2] * v1[0]);
         const double g21 = wave_sum(v0[2] * v0[1] + v1[2] * v1[1]);
         if (t == 0) { sQ[0] = beta[0]; sQ[1] = beta[1]; sQ[2] = beta[2]; sQ[3] = g10; sQ[4] = g20; sQ[5] = g21; }
+        if (p.Rf && t == 0) {   // rows 0 and 1 of the reduced H_f sit in lane 0 (a0, a1): R = Q^T H_f, upper triangle
+            double* rf = p.Rf + (size_t)6 * j;
+            rf[0] = rdiag[0]; rf[1] = a0[1]; rf[2] = a0[2]; rf[3] = rdiag[1]; rf[4] = a1[2]; rf[5] = rdiag[2];
+        }
         wave_sync();
         // right-hand sides of the gate, row t: [r | Q1],  Q = H0 H1 H2,  Q e_q = e_q - V z,
         // z2 = b2 w2, z1 = b1 (w1 - g21 z2), z0 = b0 (w0 - g10 z1 - g20 z2),  w = V^T e_q = row q of V

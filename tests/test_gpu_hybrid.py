@@ -188,10 +188,17 @@ def test_new_3d_features_are_msckf_tracks_in_the_joint_update(upd):
         upd.run_update()
         upd.sync()
         got = upd.download()
+        acc_new = [i for i in range(len(new)) if got['accept'][w.F + i]]
+        # ... and the augmentation from what the feature kernel left for those tracks (T3 and the R factor of H_f):
+        # measurementUpdate_hybrid's tail (:1811-1821, :1904-1947) without any Jacobian code on the caller's side
+        dx_new, P_aug = upd.augment_new_features(w2, [w.F + i for i in acc_new], [new[i].anchor for i in acc_new],
+                                                 [new[i].inv_param for i in acc_new], got['dx'], got['P_new'])
     finally:
         upd.set_ekf_rows_mode(False)
         upd.set_extra_states(0)
-    acc_new = [i for i in range(len(new)) if got['accept'][w.F + i]]
     assert acc_new == ref['new_accept']          # the device gate of the track IS the reference's gate of the new feature
     assert rel(got['dx'], ref['dx_leg']) < TOL
     assert rel(got['P_new'], ref['P_upd']) < TOL
+    assert rel(np.concatenate([got['dx'], dx_new]), ref['dx']) < TOL
+    assert rel(P_aug, ref['P_new']) < TOL
+    assert rel(P_aug[w.n:, :], ref['P_new'][w.n:, :]) < TOL   # the new rows on their own (cross terms and P22)
