@@ -188,10 +188,18 @@ class MsckfBackend {
     // (measurementUpdate_hybrid, :1766-1950, sz_new == 0), incrementState_IMUCam, and the write-back of the feature states
     // (:1836-1887).  state_cov is (LEG + 6N + d |feature_states|)^2.
     int feature_idp_dim = 3;
-    UpdateOutcome hybridUpdate(StateServer& ss, MapServer& map_server, const std::vector<FeatureIDType>& msckf_ids,
-                               const std::vector<FeatureIDType>& ekf_ids) {
+    // `new_ids` (3-parameter form only): features that ENTER the state in this update (ekf_new_feature_ids, :2337-2442).
+    // They ride among the MSCKF tracks -- the V part of their rows is their MSCKF block and the reference gates them with
+    // the MSCKF test (:2361-2367) --; the accepted ones are appended to feature_states with their correction and the
+    // augmented covariance (orcvio_msckf_augment_new_features: :1811-1821, :1904-1947).  `new_accepted` reports which.
+    UpdateOutcome hybridUpdate(StateServer& ss, MapServer& map_server, const std::vector<FeatureIDType>& msckf_ids_in,
+                               const std::vector<FeatureIDType>& ekf_ids, const std::vector<FeatureIDType>& new_ids = {},
+                               std::vector<int>* new_accepted = nullptr) {
         UpdateOutcome out;
         const int d = feature_idp_dim;
+        if (!new_ids.empty() && d != 3) { out.status = ORCVIO_ERR_INVALID; return out; }
+        std::vector<FeatureIDType> msckf_ids(msckf_ids_in);
+        msckf_ids.insert(msckf_ids.end(), new_ids.begin(), new_ids.end());
         std::vector<double> R_b2w, t_b_w, t_fej, R_b2c, t_c_b, p_w, obs_z, obs_zvel;
         std::vector<int32_t> obs_ptr, obs_clone;
         std::map<StateIDType, int> index_of;
@@ -250,11 +258,37 @@ class MsckfBackend {
         for (int a : out.ekf_accepted) nacc += a;
         out.updated = r.stats[3] != 0 || nacc > 0;
         if (!out.updated) return out;
+        // new SLAM features that passed: their states behind the existing ones
+        std::vector<int32_t> ntrack, nanchor;
+        std::vector<double> nparam;
+        std::vector<FeatureIDType> entering;
+        if (new_accepted) new_accepted->assign(new_ids.size(), 0);
+        for (size_t k = 0; k < new_ids.size(); ++k) {
+            const int tr = (int)(msckf_ids_in.size() + k);
+            if (!out.accepted[tr]) continue;
+            const Feature& f = map_server.at(new_ids[k]);
+            if (!index_of.count(f.id_anchor)) { out.status = ORCVIO_ERR_INVALID; return out; }
+            ntrack.push_back(tr); nanchor.push_back(index_of.at(f.id_anchor));
+            nparam.insert(nparam.end(), f.invParam, f.invParam + 3);
+            entering.push_back(new_ids[k]);
+            if (new_accepted) (*new_accepted)[k] = 1;
+        }
+        if (!entering.empty()) {
+            const int k3 = 3 * (int)entering.size();
+            std::vector<double> dx_new(k3), P_aug((size_t)(n + k3) * (n + k3));
+            out.status = orcvio_msckf_augment_new_features(h_, &w, (int32_t)entering.size(), ntrack.data(), nanchor.data(), nparam.data(),
+                                                           out.delta_x.data(), P_new.data(), dx_new.data(), P_aug.data());
+            if (out.status != ORCVIO_OK) return out;
+            out.delta_x.insert(out.delta_x.end(), dx_new.begin(), dx_new.end());
+            P_new.swap(P_aug);
+            for (FeatureIDType id : entering) ss.feature_states.push_back(id);   // (:2339-2341)
+        }
+        const int nf_all = (int)ss.feature_states.size();
         ss.state_cov.swap(P_new);
         std::vector<double> dx_leg(out.delta_x.begin(), out.delta_x.begin() + base);
         out.state_incremented = incrementState_IMUCam(ss, dx_leg);   // (:1833)
         if (!out.state_incremented) return out;
-        for (int i = 0; i < nf; ++i) {                                // (:1836-1887)
+        for (int i = 0; i < nf_all; ++i) {                            // (:1836-1887)
             Feature& f = map_server.at(ss.feature_states[i]);
             const IMUState_Aug& a = ss.imu_states_augment.at(f.id_anchor);
             double p_c[3];

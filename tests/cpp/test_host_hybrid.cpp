@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     D.resize(bytes / 8);
     if (fread(D.data(), 8, D.size(), f) != D.size()) return 4;
     fclose(f);
-    const int N = (int)rd(), F = (int)rd(), nf = (int)rd(), d = (int)rd(), estimate_td = (int)rd(), if_fej = (int)rd();
+    const int N = (int)rd(), F = (int)rd(), nf = (int)rd(), d = (int)rd(), estimate_td = (int)rd(), if_fej = (int)rd(), nnew = (int)rd();
     StateServer ss;
     MapServer map;
     std::vector<StateIDType> ids(N);
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     std::memcpy(ss.imu_state.position, ss.imu_states_augment[ids[N - 1]].position, 24);
     std::memcpy(ss.imu_state.R_imu_cam0, ss.imu_states_augment[ids[0]].R_imu_cam0, 72);
     std::memcpy(ss.imu_state.t_cam0_imu, ss.imu_states_augment[ids[0]].t_cam0_imu, 24);
-    std::vector<FeatureIDType> msckf_ids, ekf_ids;
+    std::vector<FeatureIDType> msckf_ids, ekf_ids, new_ids;
     for (int j = 0; j < F; ++j) {
         Feature ft; ft.id = 1000 + j;
         rdv(ft.position, 3);
@@ -71,6 +71,18 @@ int main(int argc, char** argv) {
         ft.observations[ss.imu_state.id] = z; ft.observations_vel[ss.imu_state.id] = zv;
         map[ft.id] = ft; ekf_ids.push_back(ft.id); ss.feature_states.push_back(ft.id);
     }
+    for (int j = 0; j < nnew; ++j) {   // features about to enter the state: anchor, parameters, position, all observations
+        Feature ft; ft.id = 9000 + j;
+        ft.id_anchor = ids[(int)rd()];
+        rdv(ft.invParam, 3); rdv(ft.position, 3);
+        const int M = (int)rd();
+        for (int k = 0; k < M; ++k) {
+            const int c = (int)rd();
+            Vec2 z, zv; z.x = rd(); z.y = rd(); zv.x = rd(); zv.y = rd();
+            ft.observations[ids[c]] = z; ft.observations_vel[ids[c]] = zv;
+        }
+        map[ft.id] = ft; new_ids.push_back(ft.id);
+    }
     const int n = 22 + 6 * N + d * nf;
     ss.state_cov.resize((size_t)n * n);
     rdv(ss.state_cov.data(), n * n);
@@ -79,15 +91,18 @@ int main(int argc, char** argv) {
     MsckfBackend be(0, 32, 2048, 65536);
     be.flags.estimate_td = estimate_td; be.flags.if_fej = if_fej;
     be.feature_idp_dim = d;
-    UpdateOutcome o = be.hybridUpdate(ss, map, msckf_ids, ekf_ids);
+    std::vector<int> new_acc;
+    UpdateOutcome o = be.hybridUpdate(ss, map, msckf_ids, ekf_ids, new_ids, &new_acc);
     if (o.status != ORCVIO_OK) { printf("hybridUpdate: %d %s\n", o.status, orcvio_msckf_last_error()); return 6; }
     if (!o.updated || !o.state_incremented) { printf("no update applied\n"); return 7; }
 
     std::vector<double> out;
     out.insert(out.end(), o.delta_x.begin(), o.delta_x.end());
     out.insert(out.end(), ss.state_cov.begin(), ss.state_cov.end());
-    for (int a : o.accepted) out.push_back(a);
+    out.insert(out.begin(), (double)o.delta_x.size());   // size of the state after the update first
+    for (int j = 0; j < F; ++j) out.push_back(o.accepted[j]);
     for (int a : o.ekf_accepted) out.push_back(a);
+    for (int a : new_acc) out.push_back(a);
     for (FeatureIDType id : ss.feature_states) {
         const Feature& ft = map.at(id);
         out.insert(out.end(), ft.invParam, ft.invParam + 3);

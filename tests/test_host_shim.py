@@ -36,11 +36,11 @@ def test_host_backend_end_to_end(built, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('idp', [3, 1])
-def test_host_backend_hybrid_update(built, tmp_path, idp):
+@pytest.mark.parametrize('idp,with_new', [(3, False), (1, False), (3, True)])
+def test_host_backend_hybrid_update(built, tmp_path, idp, with_new):
     """MsckfBackend::hybridUpdate (std::map containers, SLAM features as Feature holds them -> C-ABI -> write-back of the
-    feature states) against the literal restatement: oracle.mirror_hybrid.hybrid_update, mirror.increment_state and the
-    feature write-back of src/orcvio.cpp:1836-1887."""
+    feature states; with_new: features entering the state in the same update) against the literal restatement:
+    oracle.mirror_hybrid.hybrid_update(_full), mirror.increment_state and the feature write-back of src/orcvio.cpp:1836-1887."""
     import numpy as np
     from orcvio_amd import synth
     from oracle import mirror, mirror_hybrid as mh
@@ -48,8 +48,9 @@ def test_host_backend_hybrid_update(built, tmp_path, idp):
     w0 = synth.make_window(N=9, F=50, seed=41, track_len=(3, 9), flags=fl)
     slam = synth.make_slam_features(w0, 8, seed=3, outlier_frac=0.25)
     w = synth.with_extra_states(w0, idp * len(slam), seed=6)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 5, seed=9, outlier_frac=0.5)] if with_new else []
     # ---- case file
-    v = [w.N, w.F, len(slam), idp, fl.estimate_td, fl.if_fej]
+    v = [w.N, w.F, len(slam), idp, fl.estimate_td, fl.if_fej, len(new)]
     for i in range(w.N):
         v += list(w.R_b2w[i].ravel()) + list(w.t_b_w[i]) + list(w.t_fej[i]) + list(w.R_b2c[i].ravel()) + list(w.t_c_b[i])
     for j in range(w.F):
@@ -59,6 +60,10 @@ def test_host_backend_hybrid_update(built, tmp_path, idp):
             v += [int(w.obs_clone[o])] + list(w.obs_z[o]) + list(w.obs_zvel[o])
     for ft in slam:
         v += [ft.anchor] + list(ft.inv_param) + list(ft.obs_anchor) + [ft.inv_depth] + list(ft.p_w) + list(ft.p_fej) + list(ft.z) + list(ft.z_vel)
+    for ft in new:
+        v += [ft.anchor] + list(ft.inv_param) + list(ft.p_w) + [len(ft.obs)]
+        for (k, z, zv) in ft.obs:
+            v += [k] + list(z) + list(zv)
     v += list(w.P.ravel())
     case, outp = str(tmp_path / 'case.bin'), str(tmp_path / 'out.bin')
     np.asarray(v, dtype=np.float64).tofile(case)
@@ -68,15 +73,17 @@ def test_host_backend_hybrid_update(built, tmp_path, idp):
     assert run.returncode == 0, run.stdout + run.stderr
     got = np.fromfile(outp, dtype=np.float64)
     # ---- restatement
-    ref = mh.hybrid_update(w, slam, idp)
-    n, nf = w.n, len(slam)
+    ref = mh.hybrid_update_full(w, slam, new, idp) if with_new else mh.hybrid_update(w, slam, idp)
+    acc_new = ref['new_accept'] if with_new else []
+    feats_all = list(slam) + [new[i] for i in acc_new]
+    n, nf = w.n + idp * len(acc_new), len(feats_all)
     state = dict(R_b2w_imu=w.R_b2w[-1], v=np.zeros(3), p=w.t_b_w[-1], bg=np.zeros(3), ba=np.zeros(3), R_b2c=w.R_b2c[0], t_c_b=w.t_c_b[0],
                  td=0.0, R_b2w=w.R_b2w.copy(), t_b_w=w.t_b_w.copy())
     st, applied = mirror.increment_state(state, ref['dx'], fl)
     assert applied
     base = fl.leg_dim + 6 * w.N
     feats = []
-    for i, ft in enumerate(slam):
+    for i, ft in enumerate(feats_all):
         R_c2w, t_c_w = st['R_c2w'][ft.anchor], st['t_c_w'][ft.anchor]
         if idp == 3:
             ip = ft.inv_param + ref['dx'][base + 3 * i: base + 3 * i + 3]
@@ -89,18 +96,22 @@ def test_host_backend_hybrid_update(built, tmp_path, idp):
         feats.append((ip, rho, R_c2w @ pc + t_c_w))
     # ---- compare
     rel = lambda a, b: np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
-    k = 0
+    assert int(got[0]) == n
+    k = 1
     assert rel(got[k:k + n], ref['dx']) < 1e-6; k += n
     assert rel(got[k:k + n * n], ref['P_new'].ravel()) < 1e-6; k += n * n
     assert np.array_equal(got[k:k + w.F].astype(int), ref['accept']); k += w.F
-    assert np.array_equal(got[k:k + nf].astype(int), ref['ekf_accept']); k += nf
-    assert 0 < ref['ekf_accept'].sum() < nf
+    assert np.array_equal(got[k:k + len(slam)].astype(int), ref['ekf_accept']); k += len(slam)
+    assert 0 < ref['ekf_accept'].sum() < len(slam)
+    if with_new:
+        assert [i for i in range(len(new)) if got[k + i]] == acc_new and 0 < len(acc_new) < len(new)
+    k += len(new)
     for ip, rho, pw in feats:
         if idp == 3:
-            assert rel(got[k:k + 3], ip) < 1e-9
+            assert rel(got[k:k + 3], ip) < 1e-8
         else:
             assert abs(got[k + 3] - rho) < 1e-9 * abs(rho)
-        assert rel(got[k + 4:k + 7], pw) < 1e-9
+        assert rel(got[k + 4:k + 7], pw) < 1e-8
         k += 7
     for i in range(w.N):
         assert rel(got[k:k + 9], st['R_b2w'][i].ravel()) < 1e-9
