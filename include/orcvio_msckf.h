@@ -189,6 +189,12 @@ typedef struct orcvio_msckf_slam_features {
     const double* z_vel;      /* [F][2] observations_vel[imu_state.id], read under estimate_td               */
 } orcvio_msckf_slam_features;
 int32_t orcvio_msckf_upload_slam_features(orcvio_msckf_handle* h, const orcvio_msckf_slam_features* feats);
+/* The gate alone, no update: gatingTestFeature (src/orcvio.cpp:1953-1976) of featureJacobian_msckf for every listed
+ * track against the prior P -- the test the reference applies to a feature before it may enter the state as a SLAM
+ * feature (:2361-2367).  gamma [F], accept [F]. */
+int32_t orcvio_msckf_gate_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* window,
+                                 const orcvio_msckf_tracks* tracks, const double* P, double* gamma, int32_t* accept);
+
 /* Rows the caller has projected and gated itself, stacked under everything else as they are: H [n_rows][n] over the
  * WHOLE state (n = LEG + 6N + extra states; the first 15 columns must be zero, as for every feature row), r [n_rows].
  * This is how a frame that initialises NEW SLAM features keeps the heavy update on the device: the caller evaluates

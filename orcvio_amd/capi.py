@@ -34,7 +34,7 @@ EXPORTS = [
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
-    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features',
+    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks',
 ]
 
 
@@ -286,6 +286,17 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_augment_new_features')
         return dx_new, P_aug
+
+    def gate_tracks(self, win):
+        """gatingTestFeature of every track of `win` against win.P, no update: (gamma [F], accept [F])."""
+        fl, wn, tr, keep = self._structs(win)
+        gamma = np.zeros(win.F)
+        accept = np.zeros(win.F, dtype=np.int32)
+        rc = self.lib.orcvio_msckf_gate_tracks(self.h, C.byref(fl), C.byref(wn), C.byref(tr), _d(keep['P']), _d(gamma),
+                                               accept.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_gate_tracks')
+        return gamma, accept
 
     def download_ekf(self):
         F = getattr(self, '_ekf_F', 0)

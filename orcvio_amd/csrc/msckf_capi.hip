@@ -1386,6 +1386,26 @@ int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_
     return rc;
 }
 
+// The gate alone: gatingTestFeature (src/orcvio.cpp:1953-1976) of featureJacobian_msckf for every listed track, against the
+// prior -- what the reference asks of a feature before it lets it ENTER the state as a SLAM feature (:2361-2367) -- without
+// an update.  gamma[F], accept[F].
+int32_t orcvio_msckf_gate_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* window,
+                                 const orcvio_msckf_tracks* tracks, const double* P, double* gamma, int32_t* accept) {
+    if (!gamma || !accept) { g_last_error = "gate_tracks: null output"; return ORCVIO_ERR_INVALID; }
+    int rc = orcvio_msckf_upload(h, flags, window, tracks, P);
+    if (rc != ORCVIO_OK) return rc;
+    if (h->pw_missing) { g_last_error = "gate_tracks: tracks without positions"; return ORCVIO_ERR_INVALID; }
+    const int F = h->F;
+    if (F == 0) return ORCVIO_OK;
+    rc = launch_feature(h, h->stream);
+    if (rc != ORCVIO_OK) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(gamma, h->d_gamma, sizeof(double) * F, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(accept, h->d_accept, sizeof(int) * F, hipMemcpyDeviceToHost));
+    h->uploaded = false;   // nothing here is an update: the next update call uploads its own tracks
+    return ORCVIO_OK;
+}
+
 // Object update: OrcVIO::removeLostObjects (src/orcvio.cpp:2154-2193).  Every object block is projected
 // onto the left nullspace of its own Hf (SURVEY.md note N3: equal to the reference whenever one object
 // arrives per call); the blocks are stacked, gated jointly with dof = sum(rows - cols) and applied in one

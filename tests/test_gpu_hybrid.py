@@ -104,6 +104,24 @@ def test_frame_with_new_slam_features(upd, idp):
     new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 5, seed=9, outlier_frac=0.5)]
     ref = mh.hybrid_update_full(w, slam, new, idp)
     assert 0 < len(ref['new_accept']) < len(new)
+    # --- the MSCKF gate of the features that want to enter (:2361-2367), on the device: their tracks against the prior
+    import dataclasses
+    ptr, cl, zz, zv = [0], [], [], []
+    for ft in new:
+        for (k, z, v) in ft.obs:
+            cl.append(k); zz.append(z); zv.append(v)
+        ptr.append(len(cl))
+    wg = dataclasses.replace(w, p_w=np.ascontiguousarray([ft.p_w for ft in new]), obs_ptr=np.asarray(ptr, dtype=np.int32),
+                             obs_clone=np.asarray(cl, dtype=np.int32), obs_z=np.ascontiguousarray(zz).reshape(-1, 2),
+                             obs_zvel=np.ascontiguousarray(zv).reshape(-1, 2))
+    upd.set_extra_states(w.n_extra)
+    try:
+        g_gamma, g_accept = upd.gate_tracks(wg)
+    finally:
+        upd.set_extra_states(0)
+    assert [i for i in range(len(new)) if g_accept[i]] == ref['new_accept']
+    for i, ft in enumerate(new):
+        assert abs(g_gamma[i] - mh.msckf_gate_of_feature(w, ft)[0]) < 1e-9 * max(1.0, g_gamma[i])
     # --- caller side (CPU): rows of the new features
     acc, H_top, r_top, H_1, H_2, r_1 = mh.split_new_rows(w, new, idp)
     assert acc == ref['new_accept']
