@@ -213,6 +213,21 @@ int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, c
 int32_t orcvio_msckf_augment_new_features(orcvio_msckf_handle* h, const orcvio_msckf_window* window, int32_t n_new,
                                           const int32_t* track, const int32_t* anchor, const double* inv_param,
                                           const double* dx, const double* P_upd, double* dx_new, double* P_aug);
+/* Host arithmetic for features entering the state, either parametrisation (no device involved):
+ * orcvio_msckf_new_feature_rows -- featureJacobian_ekf_new (src/orcvio.cpp:1481-1572) for the listed features (CSR of ALL
+ *   their observations; the 1-parameter form drops the anchor's own, :1494-1496) and the rotation by W = [V | U]
+ *   (:2416-2436), one small Householder QR per feature.  H_top [*rows_top][n_cols], r_top: the V parts, for
+ *   orcvio_msckf_upload_dense_rows (capacity: 2 x observations rows).  H_1 [d n_new][n_cols], H_2 [n_new][d][d], r_1.
+ *   param: invParam (d = 3) or obs_anchor (d = 1); inv_depth: d = 1 only.  n_cols = state_cov.cols() before the update.
+ * orcvio_msckf_augment_state -- the tail of measurementUpdate_hybrid (:1818-1821, :1904-1947, no nuisance states) from
+ *   the delta_x [n] and covariance [n][n] of the update: dx_new [d n_new], P_aug [(n + d n_new)^2]. */
+int32_t orcvio_msckf_new_feature_rows(const orcvio_msckf_flags* flags, const orcvio_msckf_window* window, int32_t idp_dim, int32_t n_cols,
+                                      int32_t n_new, const int32_t* anchor, const double* param, const double* inv_depth,
+                                      const double* p_w, const double* p_fej, const int32_t* obs_ptr, const int32_t* obs_clone,
+                                      const double* obs_z, const double* obs_zvel, int32_t* rows_top, double* H_top, double* r_top,
+                                      double* H_1, double* H_2, double* r_1);
+int32_t orcvio_msckf_augment_state(int32_t n, int32_t n_new, int32_t idp_dim, const double* H_1, const double* H_2, const double* r_1,
+                                   double sigma2, const double* dx, const double* P_upd, double* dx_new, double* P_aug);
 /* gamma[F], accept[F] of the SLAM features of the last update (either may be NULL) */
 int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept);
 

@@ -34,7 +34,7 @@ EXPORTS = [
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
-    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks',
+    'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks', 'orcvio_msckf_new_feature_rows', 'orcvio_msckf_augment_state',
 ]
 
 
@@ -638,6 +638,58 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_profile_update')
         return {names[i].decode(): ms[i] for i in range(cnt.value)}
+
+
+def new_feature_rows(win, idp_dim, feats):
+    """Host arithmetic (no device): featureJacobian_ekf_new + the W = [V | U] split for features entering the state.
+    feats: objects with anchor, inv_param / obs_anchor / inv_depth, p_w, p_fej (optional), obs = [(clone, z, z_vel)].
+    Returns (H_top [rows, n], r_top, H_1 [d k, n], H_2 [k, d, d], r_1)."""
+    lib = load()
+    fl = make_flags(win.flags)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (win.R_b2w, win.t_b_w, win.t_fej, win.R_b2c, win.t_c_b)]
+    wn = MsckfWindow(win.N, *[_d(a) for a in arrs])
+    k, d, n = len(feats), int(idp_dim), win.n
+    ptr, cl, zz, zv = [0], [], [], []
+    for ft in feats:
+        for (c, z, v) in ft.obs:
+            cl.append(c); zz.append(z); zv.append(v)
+        ptr.append(len(cl))
+    ia = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    da = lambda a, shape: np.ascontiguousarray(a, dtype=np.float64).reshape(shape)
+    anchor, obs_ptr, obs_clone = ia([f.anchor for f in feats]), ia(ptr), ia(cl)
+    param = da([f.inv_param if d == 3 else f.obs_anchor for f in feats], (k, 3))
+    rho = da([f.inv_depth for f in feats], (k,))
+    pw = da([f.p_w for f in feats], (k, 3))
+    pf = da([f.p_fej if f.p_fej is not None else f.p_w for f in feats], (k, 3))
+    oz, ozv = da(zz, (-1, 2)), da(zv, (-1, 2))
+    cap = 2 * len(cl)
+    H_top, r_top = np.zeros((cap, n)), np.zeros(cap)
+    H_1, H_2, r_1 = np.zeros((d * k, n)), np.zeros((k, d, d)), np.zeros(d * k)
+    rows = C.c_int32(0)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = lib.orcvio_msckf_new_feature_rows(C.byref(fl), C.byref(wn), d, n, k, ip(anchor), _d(param), _d(rho), _d(pw), _d(pf), ip(obs_ptr),
+                                           ip(obs_clone), _d(oz), _d(ozv), C.byref(rows), _d(H_top), _d(r_top), _d(H_1), _d(H_2), _d(r_1))
+    if rc != 0:
+        raise MsckfError(rc, 'orcvio_msckf_new_feature_rows')
+    return H_top[:rows.value].copy(), r_top[:rows.value].copy(), H_1, H_2, r_1
+
+
+def augment_state(idp_dim, H_1, H_2, r_1, sigma2, dx, P_upd):
+    """Host arithmetic (no device): dx_new and the augmented covariance of measurementUpdate_hybrid's tail."""
+    lib = load()
+    lib.orcvio_msckf_augment_state.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    d = int(idp_dim)
+    k = H_2.shape[0]
+    n = P_upd.shape[0]
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (H_1, H_2, r_1, dx, P_upd)]
+    dx_new = np.zeros(d * k)
+    P_aug = np.zeros((n + d * k, n + d * k))
+    rc = lib.orcvio_msckf_augment_state(n, k, d, _d(a[0]), _d(a[1]), _d(a[2]), float(sigma2), _d(a[3]), _d(a[4]), _d(dx_new), _d(P_aug))
+    if rc != 0:
+        raise MsckfError(rc, 'orcvio_msckf_augment_state')
+    return dx_new, P_aug
 
 
 def chi2_quantile(dof, prob=0.95):

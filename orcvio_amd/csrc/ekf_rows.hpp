@@ -90,38 +90,37 @@ struct EkfEvalArgs {
 };
 
 namespace ekfm {
-__device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C) {   // C = A B
+ORC_HD void mat3_mul(const double* A, const double* B, double* C) {   // C = A B
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
 }
-__device__ __forceinline__ void mat3_mul_bt(const double* A, const double* B, double* C) {   // C = A B^T
+ORC_HD void mat3_mul_bt(const double* A, const double* B, double* C) {   // C = A B^T
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
 }
-__device__ __forceinline__ void mat3_tmul_vec(const double* A, const double* x, double* y) {   // y = A^T x
+ORC_HD void mat3_tmul_vec(const double* A, const double* x, double* y) {   // y = A^T x
     for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
 }
-__device__ __forceinline__ void mat3_vec(const double* A, const double* x, double* y) {   // y = A x
+ORC_HD void mat3_vec(const double* A, const double* x, double* y) {   // y = A x
     for (int i = 0; i < 3; ++i) y[i] = A[i * 3] * x[0] + A[i * 3 + 1] * x[1] + A[i * 3 + 2] * x[2];
 }
-__device__ __forceinline__ void skew(const double* w, double* S) {
+ORC_HD void skew(const double* w, double* S) {
     S[0] = 0; S[1] = -w[2]; S[2] = w[1]; S[3] = w[2]; S[4] = 0; S[5] = -w[0]; S[6] = -w[1]; S[7] = w[0]; S[8] = 0;
 }
 // out (2 x 3) = J_k (2 x 3) M (3 x 3)
-__device__ __forceinline__ void jk_mul(const double* Jk, const double* M, double* out) {
+ORC_HD void jk_mul(const double* Jk, const double* M, double* out) {
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 3; ++j) out[i * 3 + j] = Jk[i * 3] * M[j] + Jk[i * 3 + 1] * M[3 + j] + Jk[i * 3 + 2] * M[6 + j];
 }
 }  // namespace ekfm
 
-// one thread per SLAM feature (a handful to a few dozen per frame)
-__global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
+// measurementJacobian_ekf_3didp (:1229-1353) / _1didp (:1356-1478) for ONE (feature, observing state) pair: the four blocks
+// and the residual.  Pk / Pa: pose records of the observing and of the anchor clone; same = (state == anchor).
+ORC_HD void ekf_row_blocks(const double* Pk, const double* Pa, bool same, int d, int if_fej, const double* prm, double inv_depth,
+                           const double* pw, const double* pfej, const double* z, double* He, double* Ha, double* Hx, double* Hf,
+                           double* r) {
     using namespace ekfm;
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= p.F) return;
-    const int d = p.idp_dim, a = p.anchor[f], k = p.state[f];
-    const double* Pk = p.poses + (size_t)k * POSE_STRIDE;
-    const double* Pa = p.poses + (size_t)a * POSE_STRIDE;
+    const int k = same ? 0 : 1, a = 0;   // (only their equality matters below)
     const double* R_b2c = Pk + POSE_R_B2C;
     const double* t_c_b = Pk + POSE_T_C_B;
     const double* R_bk2w = Pk + POSE_R_B2W;
@@ -132,12 +131,10 @@ __global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
     double t_ck_w[3], tmp[3];
     mat3_vec(R_bk2w, t_c_b, tmp);
     for (int i = 0; i < 3; ++i) t_ck_w[i] = Pk[POSE_T_B_W + i] + tmp[i];
-    const double* pw = p.p_w + (size_t)3 * f;
-    const double* pf = p.if_fej ? p.p_fej + (size_t)3 * f : pw;
-    const double* prm = p.param + (size_t)3 * f;
-    const double rho = d == 3 ? prm[2] : p.inv_depth[f];
+    const double* pf = if_fej ? pfej : pw;
+    const double rho = d == 3 ? prm[2] : inv_depth;
     double p_ca[3];
-    if (p.if_fej) {                          // :1281-1282
+    if (if_fej) {                          // :1281-1282
         double dv[3], q[3];
         for (int i = 0; i < 3; ++i) dv[i] = pf[i] - Pa[POSE_T_FEJ + i];
         mat3_tmul_vec(R_ba2w, dv, q);
@@ -149,8 +146,9 @@ __global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
     double dv[3], p_ck[3];
     for (int i = 0; i < 3; ++i) dv[i] = pw[i] - t_ck_w[i];
     mat3_vec(R_w2ck, dv, p_ck);
-    double r0 = p.z[2 * f] - p_ck[0] / p_ck[2], r1 = p.z[2 * f + 1] - p_ck[1] / p_ck[2];   // :1299
-    double He[12] = {0}, Ha[12] = {0}, Hx[12] = {0}, Hf[6] = {0};
+    double r0 = z[0] - p_ck[0] / p_ck[2], r1 = z[1] - p_ck[1] / p_ck[2];   // :1299
+    for (int i = 0; i < 12; ++i) { He[i] = 0.0; Ha[i] = 0.0; Hx[i] = 0.0; }
+    for (int i = 0; i < 6; ++i) Hf[i] = 0.0;
     if (k == a) {                            // :1302-1310 / :1432-1440
         if (d == 3) { Hf[0] = 1.0; Hf[d + 1] = 1.0; }
         else { r0 = 0.0; r1 = 0.0; }
@@ -158,8 +156,8 @@ __global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
         double Jk[6] = {1.0 / p_ck[2], 0.0, -p_ck[0] / (p_ck[2] * p_ck[2]), 0.0, 1.0 / p_ck[2], -p_ck[1] / (p_ck[2] * p_ck[2])};
         double p_baf[3], p_bkf[3];
         for (int i = 0; i < 3; ++i) {
-            p_baf[i] = p.if_fej ? pf[i] - Pa[POSE_T_FEJ + i] : pw[i] - Pa[POSE_T_B_W + i];   // :1320-1323
-            p_bkf[i] = p.if_fej ? pf[i] - Pk[POSE_T_FEJ + i] : pw[i] - Pk[POSE_T_B_W + i];
+            p_baf[i] = if_fej ? pf[i] - Pa[POSE_T_FEJ + i] : pw[i] - Pa[POSE_T_B_W + i];   // :1320-1323
+            p_bkf[i] = if_fej ? pf[i] - Pk[POSE_T_FEJ + i] : pw[i] - Pk[POSE_T_B_W + i];
         }
         double S[9], M[9], J[6];
         skew(p_baf, S); mat3_mul(R_w2ck, S, M);
@@ -203,9 +201,21 @@ __global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
             for (int i = 0; i < 2; ++i) Hf[i] = (Jk[i * 3] * Jd[0] + Jk[i * 3 + 1] * Jd[1] + Jk[i * 3 + 2] * Jd[2]) * Jrho;
         }
     }
+    r[0] = r0; r[1] = r1;
+}
+
+// one thread per SLAM feature (a handful to a few dozen per frame)
+__global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= p.F) return;
+    const int d = p.idp_dim, a = p.anchor[f], k = p.state[f];
+    double He[12], Ha[12], Hx[12], Hf[6], r[2];
+    ekf_row_blocks(p.poses + (size_t)k * POSE_STRIDE, p.poses + (size_t)a * POSE_STRIDE, k == a, d, p.if_fej, p.param + (size_t)3 * f,
+                   d == 1 ? p.inv_depth[f] : 0.0, p.p_w + (size_t)3 * f, p.p_fej ? p.p_fej + (size_t)3 * f : nullptr, p.z + (size_t)2 * f,
+                   He, Ha, Hx, Hf, r);
     for (int i = 0; i < 12; ++i) { p.He[(size_t)f * 12 + i] = He[i]; p.Ha[(size_t)f * 12 + i] = Ha[i]; p.Hx[(size_t)f * 12 + i] = Hx[i]; }
     for (int i = 0; i < 2 * d; ++i) p.Hf[(size_t)f * 2 * d + i] = Hf[i];
-    p.r[2 * f] = r0; p.r[2 * f + 1] = r1;
+    p.r[2 * f] = r[0]; p.r[2 * f + 1] = r[1];
 }
 
 __global__ __launch_bounds__(256) void k_add_inplace(double* __restrict__ dst, const double* __restrict__ src, int n) {

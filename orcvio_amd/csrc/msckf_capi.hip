@@ -1223,6 +1223,163 @@ int32_t orcvio_msckf_augment_new_features(orcvio_msckf_handle* h, const orcvio_m
     return ORCVIO_OK;
 }
 
+// ---- host arithmetic for features entering the state, either parametrisation (no device, no handle) -----------------
+// Rows of featureJacobian_ekf_new (src/orcvio.cpp:1481-1572) for every listed feature and their rotation by W = [V | U]
+// (:2416-2436): H_f of different features share no column, so the split is one small Householder QR per feature
+// (U = the first d columns of Q, V the rest; only the two subspaces matter).
+//   out: H_top [*rows_top][n_cols], r_top  -- the V parts, zero in the new columns: to orcvio_msckf_upload_dense_rows
+//        H_1 [d n_new][n_cols], H_2 [n_new][d][d] (upper triangular blocks), r_1 [d n_new]  -- the U parts
+int32_t orcvio_msckf_new_feature_rows(const orcvio_msckf_flags* flags, const orcvio_msckf_window* win, int32_t idp_dim, int32_t n_cols,
+                                      int32_t n_new, const int32_t* anchor, const double* param, const double* inv_depth,
+                                      const double* p_w, const double* p_fej, const int32_t* obs_ptr, const int32_t* obs_clone,
+                                      const double* obs_z, const double* obs_zvel, int32_t* rows_top, double* H_top, double* r_top,
+                                      double* H_1, double* H_2, double* r_1) {
+    if (!flags || !win || n_new < 0 || (idp_dim != 1 && idp_dim != 3) || !rows_top || (n_new > 0 && (!anchor || !param || !p_w || !obs_ptr ||
+        !obs_clone || !obs_z || !H_top || !r_top || !H_1 || !H_2 || !r_1 || (idp_dim == 1 && !inv_depth) || (flags->if_fej && !p_fej) ||
+        (flags->estimate_td && !obs_zvel)))) { g_last_error = "new_feature_rows: null argument"; return ORCVIO_ERR_INVALID; }
+    const int d = idp_dim, N = win->n_clones, leg = flags->leg_dim;
+    if (n_cols < leg + 6 * N) { g_last_error = "new_feature_rows: n_cols smaller than the window"; return ORCVIO_ERR_INVALID; }
+    auto pose = [&](int i, double* rec) {
+        std::memcpy(rec + POSE_R_B2W, win->R_b2w + 9 * i, 72); std::memcpy(rec + POSE_T_B_W, win->t_b_w + 3 * i, 24);
+        std::memcpy(rec + POSE_T_FEJ, (win->t_fej ? win->t_fej : win->t_b_w) + 3 * i, 24);
+        std::memcpy(rec + POSE_R_B2C, win->R_b2c + 9 * i, 72); std::memcpy(rec + POSE_T_C_B, win->t_c_b + 3 * i, 24);
+    };
+    int top = 0;
+    for (int j = 0; j < n_new; ++j) {
+        const int a = anchor[j];
+        if (a < 0 || a >= N) { g_last_error = "new_feature_rows: anchor outside the window"; return ORCVIO_ERR_INVALID; }
+        std::vector<int> obs;
+        for (int o = obs_ptr[j]; o < obs_ptr[j + 1]; ++o) {
+            if (obs_clone[o] < 0 || obs_clone[o] >= N) { g_last_error = "new_feature_rows: obs_clone outside the window"; return ORCVIO_ERR_INVALID; }
+            if (d == 1 && obs_clone[o] == a) continue;   // :1494-1496
+            obs.push_back(o);
+        }
+        const int m = 2 * (int)obs.size();
+        if (m <= d) { g_last_error = "new_feature_rows: a feature with too few observations"; return ORCVIO_ERR_INVALID; }
+        std::vector<double> Hx((size_t)m * n_cols, 0.0), Hf((size_t)m * d, 0.0), r(m, 0.0);
+        double Pa[POSE_STRIDE], Pk[POSE_STRIDE];
+        pose(a, Pa);
+        for (size_t c = 0; c < obs.size(); ++c) {
+            const int o = obs[c], k = obs_clone[o];
+            pose(k, Pk);
+            double He[12], Ha[12], Hxk[12], Hfk[6], rr[2];
+            ekf_row_blocks(Pk, Pa, k == a, d, flags->if_fej, param + 3 * j, d == 1 ? inv_depth[j] : 0.0, p_w + 3 * j,
+                           p_fej ? p_fej + 3 * j : nullptr, obs_z + 2 * o, He, Ha, Hxk, Hfk, rr);
+            for (int b = 0; b < 2; ++b) {
+                double* row = &Hx[(size_t)(2 * c + b) * n_cols];
+                for (int e = 0; e < 6; ++e) row[leg + 6 * a + e] = Ha[6 * b + e];            // :1561
+                for (int e = 0; e < 6; ++e) row[leg + 6 * k + e] = Hxk[6 * b + e];           // :1562 (overwrites if k == a)
+                for (int e = 0; e < 6; ++e) row[15 + e] = He[6 * b + e];                     // :1563
+                if (flags->estimate_td) row[21] = obs_zvel[2 * o + b];                       // :1564-1565
+                for (int e = 0; e < d; ++e) Hf[(size_t)(2 * c + b) * d + e] = Hfk[b * d + e];
+                r[2 * c + b] = rr[b];
+            }
+        }
+        // Householder QR of H_f (m x d), applied to [H_x | r]
+        for (int q = 0; q < d; ++q) {
+            double nrm2 = 0.0;
+            for (int i = q + 1; i < m; ++i) nrm2 += Hf[(size_t)i * d + q] * Hf[(size_t)i * d + q];
+            const double alpha = Hf[(size_t)q * d + q];
+            if (nrm2 == 0.0) continue;
+            const double nu = std::sqrt(alpha * alpha + nrm2), bk = alpha >= 0.0 ? -nu : nu;
+            const double beta = (bk - alpha) / bk, sc = 1.0 / (alpha - bk);
+            std::vector<double> v(m, 0.0);
+            v[q] = 1.0;
+            for (int i = q + 1; i < m; ++i) v[i] = Hf[(size_t)i * d + q] * sc;
+            auto apply = [&](double* M, int ld, int c0, int c1) {
+                for (int c = c0; c < c1; ++c) {
+                    double w = 0.0;
+                    for (int i = q; i < m; ++i) w += v[i] * M[(size_t)i * ld + c];
+                    w *= beta;
+                    for (int i = q; i < m; ++i) M[(size_t)i * ld + c] -= w * v[i];
+                }
+            };
+            apply(Hf.data(), d, q, d);
+            apply(Hx.data(), n_cols, 0, n_cols);
+            apply(r.data(), 1, 0, 1);
+        }
+        for (int i = 0; i < d; ++i) {   // U part
+            std::memcpy(H_1 + (size_t)(d * j + i) * n_cols, &Hx[(size_t)i * n_cols], sizeof(double) * n_cols);
+            for (int e = 0; e < d; ++e) H_2[(size_t)j * d * d + i * d + e] = e >= i ? Hf[(size_t)i * d + e] : 0.0;
+            r_1[d * j + i] = r[i];
+        }
+        for (int i = d; i < m; ++i) {   // V part
+            std::memcpy(H_top + (size_t)top * n_cols, &Hx[(size_t)i * n_cols], sizeof(double) * n_cols);
+            r_top[top++] = r[i];
+        }
+    }
+    *rows_top = top;
+    return ORCVIO_OK;
+}
+
+// measurementUpdate_hybrid, the part behind the update of the legacy state (src/orcvio.cpp:1818-1821, :1904-1947, no
+// nuisance states): dx_new = H_2^-1 (r_1 - H_1 dx), P_aug = [[P, (-HH P)^T], [-HH P, HH P HH^T + s2 (H_2^T H_2)^-1]],
+// HH = H_2^-1 H_1, with H_2 block diagonal (one upper-triangular d x d block per feature).
+// (The reference writes H_2.ldlt().solve(.), which for d = 3 reads only the lower triangle of an upper-triangular H_2;
+// the triangular system is solved here.  For the 1-parameter form of the shipped configurations H_2 is diagonal and the
+// two coincide.)
+int32_t orcvio_msckf_augment_state(int32_t n, int32_t n_new, int32_t idp_dim, const double* H_1, const double* H_2, const double* r_1,
+                                   double sigma2, const double* dx, const double* P_upd, double* dx_new, double* P_aug) {
+    if (n < 1 || n_new < 0 || (idp_dim != 1 && idp_dim != 3) || !dx || !P_upd || !dx_new || !P_aug || (n_new > 0 && (!H_1 || !H_2 || !r_1))) {
+        g_last_error = "augment_state: invalid argument"; return ORCVIO_ERR_INVALID;
+    }
+    const int d = idp_dim, sz = d * n_new, nt = n + sz;
+    std::vector<double> HH((size_t)sz * n, 0.0), nHHP((size_t)sz * n, 0.0), W((size_t)n_new * d * d, 0.0);
+    for (int j = 0; j < n_new; ++j) {
+        const double* R = H_2 + (size_t)j * d * d;
+        for (int i = 0; i < d; ++i)
+            if (R[i * d + i] == 0.0) { g_last_error = "augment_state: singular H_2"; return ORCVIO_ERR_NOT_SPD; }
+        // back substitution on the block: HH_j = R^-1 H_1_j, x_j = R^-1 r_1_j
+        for (int c = 0; c <= n; ++c)
+            for (int i = d - 1; i >= 0; --i) {
+                double m = c < n ? H_1[(size_t)(d * j + i) * n + c] : r_1[d * j + i];
+                for (int k = i + 1; k < d; ++k) m -= R[i * d + k] * (c < n ? HH[(size_t)(d * j + k) * n + c] : dx_new[d * j + k]);
+                m /= R[i * d + i];
+                if (c < n) HH[(size_t)(d * j + i) * n + c] = m; else dx_new[d * j + i] = m;
+            }
+        // (R^T R)^-1 = R^-1 R^-T
+        double Ri[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < d; ++c)
+            for (int i = d - 1; i >= 0; --i) {
+                double m = i == c ? 1.0 : 0.0;
+                for (int k = i + 1; k < d; ++k) m -= R[i * d + k] * Ri[k * d + c];
+                Ri[i * d + c] = m / R[i * d + i];
+            }
+        for (int i = 0; i < d; ++i)
+            for (int c = 0; c < d; ++c) {
+                double m = 0.0;
+                for (int k = 0; k < d; ++k) m += Ri[i * d + k] * Ri[c * d + k];
+                W[(size_t)j * d * d + i * d + c] = m;
+            }
+    }
+    for (int r = 0; r < sz; ++r) {
+        double m = 0.0;
+        for (int c = 0; c < n; ++c) m += HH[(size_t)r * n + c] * dx[c];
+        dx_new[r] -= m;
+    }
+    for (int r = 0; r < sz; ++r)
+        for (int k = 0; k < n; ++k) {
+            const double hv = HH[(size_t)r * n + k];
+            if (hv == 0.0) continue;
+            const double* prow = P_upd + (size_t)k * n;
+            double* o = &nHHP[(size_t)r * n];
+            for (int c = 0; c < n; ++c) o[c] -= hv * prow[c];
+        }
+    for (int r = 0; r < n; ++r) std::memcpy(P_aug + (size_t)r * nt, P_upd + (size_t)r * n, sizeof(double) * n);
+    for (int r = 0; r < sz; ++r)
+        for (int c = 0; c < n; ++c) { P_aug[(size_t)(n + r) * nt + c] = nHHP[(size_t)r * n + c]; P_aug[(size_t)c * nt + n + r] = nHHP[(size_t)r * n + c]; }
+    for (int r = 0; r < sz; ++r)
+        for (int c = 0; c < sz; ++c) {
+            double m = 0.0;
+            for (int k = 0; k < n; ++k) m -= nHHP[(size_t)r * n + k] * HH[(size_t)c * n + k];
+            if (r / d == c / d) m += sigma2 * W[(size_t)(r / d) * d * d + (r % d) * d + (c % d)];
+            P_aug[(size_t)(n + r) * nt + n + c] = m;
+        }
+    for (int r = 0; r < nt; ++r)   // (:1946)
+        for (int c = r + 1; c < nt; ++c) { const double m = 0.5 * (P_aug[(size_t)r * nt + c] + P_aug[(size_t)c * nt + r]); P_aug[(size_t)r * nt + c] = m; P_aug[(size_t)c * nt + r] = m; }
+    return ORCVIO_OK;
+}
+
 int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept) {
     if (!h || !h->ran) { g_last_error = "download_ekf: no finished update"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));

@@ -75,6 +75,7 @@ int main(int argc, char** argv) {
         Feature ft; ft.id = 9000 + j;
         ft.id_anchor = ids[(int)rd()];
         rdv(ft.invParam, 3); rdv(ft.position, 3);
+        ft.obs_anchor[0] = ft.invParam[0]; ft.obs_anchor[1] = ft.invParam[1]; ft.obs_anchor[2] = 1.0; ft.invDepth = ft.invParam[2];
         const int M = (int)rd();
         for (int k = 0; k < M; ++k) {
             const int c = (int)rd();

@@ -93,11 +93,11 @@ def test_anchor_equal_to_the_observing_state(upd):
 
 @pytest.mark.parametrize('idp', [3, 1])
 def test_frame_with_new_slam_features(upd, idp):
-    """The integration recipe of INTEGRATION.md 7b for a frame in which NEW SLAM features enter the state: the caller's
-    own small host code (featureJacobian_ekf_new, the MSCKF gate of the new features, the W = [V | U] split; here the
-    restatement stands in for it) produces the V-part rows, which go to the device as dense rows under the MSCKF tracks
-    and the rows of the existing SLAM features; the H_1 / H_2 augmentation (src/orcvio.cpp:1811-1947) is applied to the
-    downloaded delta_x and covariance.  Result: the reference's full hybrid update (oracle.hybrid_update_full)."""
+    """A frame in which NEW SLAM features enter the state, either parametrisation, through library calls only
+    (INTEGRATION.md 7b): orcvio_msckf_gate_tracks (their MSCKF gate on the device), orcvio_msckf_new_feature_rows
+    (featureJacobian_ekf_new and the W = [V | U] split, host arithmetic), the V-part rows as dense rows under the MSCKF
+    tracks and the rows of the existing SLAM features in ONE device update, orcvio_msckf_augment_state for the H_1 / H_2
+    tail (src/orcvio.cpp:1811-1947).  Result: the reference's full hybrid update (oracle.hybrid_update_full)."""
     w0 = synth.make_window(N=10, F=60, seed=17, track_len=(3, 10), flags=synth.Flags(use_larvio=1, estimate_td=1))
     slam = synth.make_slam_features(w0, 7, seed=5, outlier_frac=0.25)
     w = synth.with_extra_states(w0, idp * len(slam), seed=4)
@@ -122,9 +122,10 @@ def test_frame_with_new_slam_features(upd, idp):
     assert [i for i in range(len(new)) if g_accept[i]] == ref['new_accept']
     for i, ft in enumerate(new):
         assert abs(g_gamma[i] - mh.msckf_gate_of_feature(w, ft)[0]) < 1e-9 * max(1.0, g_gamma[i])
-    # --- caller side (CPU): rows of the new features
-    acc, H_top, r_top, H_1, H_2, r_1 = mh.split_new_rows(w, new, idp)
-    assert acc == ref['new_accept']
+    # --- rows of the features that passed and their W split: host arithmetic of the library (the restatement's own
+    #     split is compared with it in tests/test_oracle_hybrid.py)
+    acc = [i for i in range(len(new)) if g_accept[i]]
+    H_top, r_top, H_1, H_2, r_1 = capi.new_feature_rows(w, idp, [new[i] for i in acc])
     # --- device: one joint update with everything that has no column in the new states
     upd.set_extra_states(w.n_extra)
     upd.set_ekf_rows_mode(True)
@@ -143,8 +144,9 @@ def test_frame_with_new_slam_features(upd, idp):
     assert np.array_equal(got['accept'], ref['accept'])
     assert rel(got['dx'], ref['dx_leg']) < TOL
     assert rel(got['P_new'], ref['P_upd']) < TOL
-    # --- caller side again: the new states and the augmented covariance
-    dx, P = mh.augment_after_update(got['P_new'], got['dx'], H_1, H_2, r_1, w.flags.noise_feature ** 2)
+    # --- the new states and the augmented covariance (host arithmetic of the library again)
+    dx_new, P = capi.augment_state(idp, H_1, H_2, r_1, w.flags.noise_feature ** 2, got['dx'], got['P_new'])
+    dx = np.concatenate([got['dx'], dx_new])
     assert dx.shape[0] == w.n + idp * len(acc)
     assert rel(dx, ref['dx']) < TOL
     assert rel(P, ref['P_new']) < TOL

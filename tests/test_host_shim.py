@@ -36,7 +36,7 @@ def test_host_backend_end_to_end(built, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('idp,with_new', [(3, False), (1, False), (3, True)])
+@pytest.mark.parametrize('idp,with_new', [(3, False), (1, False), (3, True), (1, True)])
 def test_host_backend_hybrid_update(built, tmp_path, idp, with_new):
     """MsckfBackend::hybridUpdate (std::map containers, SLAM features as Feature holds them -> C-ABI -> write-back of the
     feature states; with_new: features entering the state in the same update) against the literal restatement:

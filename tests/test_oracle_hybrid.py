@@ -129,3 +129,34 @@ def test_new_feature_update_does_not_depend_on_the_bases(idp):
     assert rel(P, ref['P_new']) < 1e-9
     assert np.linalg.eigvalsh(ref['P_new']).min() > -1e-12
     assert ref['P_new'].shape[0] == w.n + idp * len(acc)
+
+
+@pytest.mark.parametrize('idp', [3, 1])
+def test_library_host_arithmetic_for_entering_features(built, idp):
+    """orcvio_msckf_new_feature_rows / orcvio_msckf_augment_state (host arithmetic inside the library, no device) against
+    the restatement: bases differ (one Householder QR per feature there, one complete QR of the stacked H_f here), so the
+    comparison is on what the update depends on -- the Gram data of the V part, H_2^-1 H_1, H_2^-1 r_1, (H_2^T H_2)^-1 --
+    and on the augmented state itself."""
+    from orcvio_amd import capi
+    from scipy.linalg import block_diag
+    w0 = synth.make_window(N=9, F=30, seed=5, track_len=(3, 9), flags=synth.Flags(use_larvio=1, estimate_td=1))
+    slam = synth.make_slam_features(w0, 5, seed=1)
+    w = synth.with_extra_states(w0, idp * len(slam), seed=2)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 4, seed=3)]
+    acc, H_top, r_top, H_1, H_2, r_1 = mh.split_new_rows(w, new, idp)
+    feats = [new[i] for i in acc]
+    gH_top, gr_top, gH_1, gH_2, gr_1 = capi.new_feature_rows(w, idp, feats)
+    assert gH_top.shape == H_top.shape
+    assert rel(gH_top.T @ gH_top, H_top.T @ H_top) < 1e-10
+    assert rel(gH_top.T @ gr_top, H_top.T @ r_top) < 1e-9
+    assert abs(gr_top @ gr_top - r_top @ r_top) < 1e-10 * max(1.0, r_top @ r_top)
+    G2 = block_diag(*gH_2)
+    assert np.allclose(G2, np.triu(G2))
+    assert rel(np.linalg.solve(G2, gH_1), np.linalg.solve(H_2, H_1)) < 1e-9
+    assert rel(np.linalg.solve(G2, gr_1), np.linalg.solve(H_2, r_1)) < 1e-9
+    assert rel(np.linalg.inv(G2.T @ G2), np.linalg.inv(H_2.T @ H_2)) < 1e-9
+    # the augmentation, from the restatement's update of the legacy state
+    ref = mh.hybrid_update_full(w, slam, new, idp)
+    dx_new, P_aug = capi.augment_state(idp, gH_1, gH_2, gr_1, w.flags.noise_feature ** 2, ref['dx_leg'], ref['P_upd'])
+    assert rel(np.concatenate([ref['dx_leg'], dx_new]), ref['dx']) < 1e-9
+    assert rel(P_aug, ref['P_new']) < 1e-9
