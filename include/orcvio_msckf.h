@@ -202,8 +202,9 @@ int32_t orcvio_msckf_gate_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flag
  * V-part rows (zero in the new features' columns) over here, and applies the reference's own H_1 / H_2 algebra
  * (:1811-1947) to the downloaded delta_x and covariance.  The rows belong to the upload they follow. */
 int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, const double* H, const double* r);
-/* New SLAM features in the 3-parameter form need no special rows: list them among the tracks (the V part of their rows is
- * their MSCKF block).  After the update, this call returns their correction and the augmented
+/* New SLAM features in the 3-parameter form need no special rows when the MSCKF rows are LARVIO's (use_larvio = 1: the SLAM
+ * rows' own error-state convention) and if_FEJ = 0: list them among the tracks (the V part of their rows is their MSCKF
+ * block).  After the update, this call returns their correction and the augmented
  * covariance -- measurementUpdate_hybrid, src/orcvio.cpp:1811-1821 and :1904-1947, without nuisance states -- from what the
  * feature kernel left on the device for those tracks (host arithmetic on a few 3 x n blocks):
  *   track[j]      index of new feature j among the tracks of the last upload (it must have been accepted)

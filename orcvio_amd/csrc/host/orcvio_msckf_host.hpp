@@ -197,20 +197,24 @@ class MsckfBackend {
                                std::vector<int>* new_accepted = nullptr) {
         UpdateOutcome out;
         const int d = feature_idp_dim;
+        // Shortcut for the 3-parameter form when the MSCKF rows are LARVIO's (the same error-state convention as the SLAM
+        // rows) and FEJ is off: the V part of an entering feature IS its MSCKF block.  Otherwise its rows
+        // are restated literally on the host and ride as dense rows.
+        const bool shortcut = d == 3 && flags.use_larvio && !flags.if_fej;
         std::vector<FeatureIDType> msckf_ids(msckf_ids_in);
-        if (d == 3) msckf_ids.insert(msckf_ids.end(), new_ids.begin(), new_ids.end());   // (their V part is their MSCKF block)
+        if (shortcut) msckf_ids.insert(msckf_ids.end(), new_ids.begin(), new_ids.end());
         std::vector<double> R_b2w, t_b_w, t_fej, R_b2c, t_c_b, p_w, obs_z, obs_zvel;
         std::vector<int32_t> obs_ptr, obs_clone;
         std::map<StateIDType, int> index_of;
         flattenWindow(ss, R_b2w, t_b_w, t_fej, R_b2c, t_c_b, index_of);
-        // 1-parameter form: the entering features are gated as tracks on the device first (:2361-2367), the rows of those
+        // general path: the entering features are gated as tracks on the device first (:2361-2367), the rows of those
         // that pass are rotated on the host (featureJacobian_ekf_new + W split) and their V part rides as dense rows
         std::vector<FeatureIDType> entering1;
         std::vector<double> H_top, r_top, H1_1, H2_1, r1_1;
         int rows_top = 0;
         if (new_accepted) new_accepted->assign(new_ids.size(), 0);
-        if (d == 1 && !new_ids.empty()) {
-            const int Nw = (int)index_of.size(), ncols = flags.leg_dim + 6 * Nw + (int)ss.feature_states.size();
+        if (!shortcut && !new_ids.empty()) {
+            const int Nw = (int)index_of.size(), ncols = flags.leg_dim + 6 * Nw + d * (int)ss.feature_states.size();
             if (ss.dim() != ncols) { out.status = ORCVIO_ERR_INVALID; return out; }
             std::vector<double> gp, gz, gzv;
             std::vector<int32_t> gptr, gcl;
@@ -219,7 +223,7 @@ class MsckfBackend {
             orcvio_msckf_tracks gt{(int32_t)new_ids.size(), gp.data(), gptr.data(), gcl.data(), gz.data(), gzv.data()};
             std::vector<double> gg(new_ids.size());
             std::vector<int32_t> ga(new_ids.size());
-            out.status = orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, (int)ss.feature_states.size());
+            out.status = orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, d * (int)ss.feature_states.size());
             if (out.status == ORCVIO_OK) out.status = orcvio_msckf_gate_tracks(h_, &flags, &gw, &gt, ss.state_cov.data(), gg.data(), ga.data());
             (void)orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, 0);
             if (out.status != ORCVIO_OK) return out;
@@ -232,7 +236,8 @@ class MsckfBackend {
                 entering1.push_back(new_ids[k]);
                 if (new_accepted) (*new_accepted)[k] = 1;
                 anc.push_back(index_of.at(f.id_anchor));
-                prm.insert(prm.end(), f.obs_anchor, f.obs_anchor + 3); rho.push_back(f.invDepth);
+                const double* pp = d == 3 ? f.invParam : f.obs_anchor;
+                prm.insert(prm.end(), pp, pp + 3); rho.push_back(f.invDepth);
                 pw.insert(pw.end(), f.position, f.position + 3); pfj.insert(pfj.end(), f.position_FEJ, f.position_FEJ + 3);
                 for (int o = gptr[k]; o < gptr[k + 1]; ++o) {
                     ocl.push_back(gcl[o]); oz.push_back(gz[2 * o]); oz.push_back(gz[2 * o + 1]); ozv.push_back(gzv[2 * o]); ozv.push_back(gzv[2 * o + 1]);
@@ -242,8 +247,8 @@ class MsckfBackend {
             if (!entering1.empty()) {
                 const int k1 = (int)entering1.size();
                 H_top.assign((size_t)2 * ocl.size() * ncols, 0.0); r_top.assign(2 * ocl.size(), 0.0);
-                H1_1.assign((size_t)k1 * ncols, 0.0); H2_1.assign(k1, 0.0); r1_1.assign(k1, 0.0);
-                out.status = orcvio_msckf_new_feature_rows(&flags, &gw, 1, ncols, k1, anc.data(), prm.data(), rho.data(), pw.data(), pfj.data(),
+                H1_1.assign((size_t)d * k1 * ncols, 0.0); H2_1.assign((size_t)k1 * d * d, 0.0); r1_1.assign((size_t)d * k1, 0.0);
+                out.status = orcvio_msckf_new_feature_rows(&flags, &gw, d, ncols, k1, anc.data(), prm.data(), rho.data(), pw.data(), pfj.data(),
                                                            optr.data(), ocl.data(), oz.data(), ozv.data(), &rows_top, H_top.data(), r_top.data(),
                                                            H1_1.data(), H2_1.data(), r1_1.data());
                 if (out.status != ORCVIO_OK) return out;
@@ -308,7 +313,7 @@ class MsckfBackend {
         std::vector<int32_t> ntrack, nanchor;
         std::vector<double> nparam;
         std::vector<FeatureIDType> entering;
-        for (size_t k = 0; d == 3 && k < new_ids.size(); ++k) {
+        for (size_t k = 0; shortcut && k < new_ids.size(); ++k) {
             const int tr = (int)(msckf_ids_in.size() + k);
             if (!out.accepted[tr]) continue;
             const Feature& f = map_server.at(new_ids[k]);
@@ -328,10 +333,10 @@ class MsckfBackend {
             P_new.swap(P_aug);
             for (FeatureIDType id : entering) ss.feature_states.push_back(id);   // (:2339-2341)
         }
-        if (!entering1.empty()) {   // 1-parameter form: the tail of measurementUpdate_hybrid from the rotated rows
-            const int k1 = (int)entering1.size();
-            std::vector<double> dx_new(k1), P_aug((size_t)(n + k1) * (n + k1));
-            out.status = orcvio_msckf_augment_state(n, k1, 1, H1_1.data(), H2_1.data(), r1_1.data(), flags.noise_feature * flags.noise_feature,
+        if (!entering1.empty()) {   // general path: the tail of measurementUpdate_hybrid from the rotated rows
+            const int k1 = (int)entering1.size(), sz1 = d * k1;
+            std::vector<double> dx_new(sz1), P_aug((size_t)(n + sz1) * (n + sz1));
+            out.status = orcvio_msckf_augment_state(n, k1, d, H1_1.data(), H2_1.data(), r1_1.data(), flags.noise_feature * flags.noise_feature,
                                                     out.delta_x.data(), P_new.data(), dx_new.data(), P_aug.data());
             if (out.status != ORCVIO_OK) return out;
             out.delta_x.insert(out.delta_x.end(), dx_new.begin(), dx_new.end());

@@ -1115,7 +1115,11 @@ int32_t orcvio_msckf_augment_new_features(orcvio_msckf_handle* h, const orcvio_m
     if (!h || !win || !h->ran || n_new < 0 || (n_new > 0 && (!track || !anchor || !inv_param)) || !dx || !P_upd || !dx_new || !P_aug) {
         g_last_error = "augment_new_features: null argument or no finished update"; return ORCVIO_ERR_INVALID;
     }
-    if (h->flags.if_fej) { g_last_error = "augment_new_features: if_FEJ is not supported here (the anchor terms use the current estimates)"; return ORCVIO_ERR_INVALID; }
+    if (h->flags.if_fej || !h->flags.use_larvio) {
+        // the equivalence "V part = MSCKF block" needs the MSCKF rows in the SLAM rows' own error-state convention
+        g_last_error = "augment_new_features: needs use_larvio = 1 and if_FEJ = 0 (use orcvio_msckf_new_feature_rows / _augment_state otherwise)";
+        return ORCVIO_ERR_INVALID;
+    }
     const int n = h->n, NA = h->NA, NAP = h->NAP, leg = h->flags.leg_dim, N = h->N, k3 = 3 * n_new, nt = n + k3;
     for (int j = 0; j < n_new; ++j)
         if (track[j] < 0 || track[j] >= h->F || anchor[j] < 0 || anchor[j] >= N) { g_last_error = "augment_new_features: index out of range"; return ORCVIO_ERR_INVALID; }

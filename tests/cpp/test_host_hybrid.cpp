@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     D.resize(bytes / 8);
     if (fread(D.data(), 8, D.size(), f) != D.size()) return 4;
     fclose(f);
-    const int N = (int)rd(), F = (int)rd(), nf = (int)rd(), d = (int)rd(), estimate_td = (int)rd(), if_fej = (int)rd(), nnew = (int)rd();
+    const int N = (int)rd(), F = (int)rd(), nf = (int)rd(), d = (int)rd(), estimate_td = (int)rd(), if_fej = (int)rd(), nnew = (int)rd(), use_larvio = (int)rd();
     StateServer ss;
     MapServer map;
     std::vector<StateIDType> ids(N);
@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
     if (pos != D.size()) { printf("case file: %zu of %zu doubles read\n", pos, D.size()); return 5; }
 
     MsckfBackend be(0, 32, 2048, 65536);
-    be.flags.estimate_td = estimate_td; be.flags.if_fej = if_fej;
+    be.flags.estimate_td = estimate_td; be.flags.if_fej = if_fej; be.flags.use_larvio = use_larvio;
     be.feature_idp_dim = d;
     std::vector<int> new_acc;
     UpdateOutcome o = be.hybridUpdate(ss, map, msckf_ids, ekf_ids, new_ids, &new_acc);

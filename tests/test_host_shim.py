@@ -36,21 +36,21 @@ def test_host_backend_end_to_end(built, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('idp,with_new', [(3, False), (1, False), (3, True), (1, True)])
-def test_host_backend_hybrid_update(built, tmp_path, idp, with_new):
+@pytest.mark.parametrize('idp,with_new,larvio', [(3, False, 1), (1, False, 1), (3, True, 1), (1, True, 1), (3, True, 0)])
+def test_host_backend_hybrid_update(built, tmp_path, idp, with_new, larvio):
     """MsckfBackend::hybridUpdate (std::map containers, SLAM features as Feature holds them -> C-ABI -> write-back of the
     feature states; with_new: features entering the state in the same update) against the literal restatement:
     oracle.mirror_hybrid.hybrid_update(_full), mirror.increment_state and the feature write-back of src/orcvio.cpp:1836-1887."""
     import numpy as np
     from orcvio_amd import synth
     from oracle import mirror, mirror_hybrid as mh
-    fl = synth.Flags(use_larvio=1, estimate_td=1, if_fej=0)
+    fl = synth.Flags(use_larvio=larvio, estimate_td=1, if_fej=0)   # (larvio = 0: the entering 3-d features take the rows path)
     w0 = synth.make_window(N=9, F=50, seed=41, track_len=(3, 9), flags=fl)
     slam = synth.make_slam_features(w0, 8, seed=3, outlier_frac=0.25)
     w = synth.with_extra_states(w0, idp * len(slam), seed=6)
     new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 5, seed=9, outlier_frac=0.5)] if with_new else []
     # ---- case file
-    v = [w.N, w.F, len(slam), idp, fl.estimate_td, fl.if_fej, len(new)]
+    v = [w.N, w.F, len(slam), idp, fl.estimate_td, fl.if_fej, len(new), fl.use_larvio]
     for i in range(w.N):
         v += list(w.R_b2w[i].ravel()) + list(w.t_b_w[i]) + list(w.t_fej[i]) + list(w.R_b2c[i].ravel()) + list(w.t_c_b[i])
     for j in range(w.F):
