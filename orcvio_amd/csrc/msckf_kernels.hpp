@@ -1868,7 +1868,7 @@ __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __r
     // ---- the (ext|r) x (ext|r) entries sum EVERY clone tile: once per workgroup that owns such rows, 64 entries x N
     //      tiles over the 256 threads (clone c on thread group c % 4, then a fixed-order sum of the four partials)
     __shared__ double sShared[4][64];
-    const bool has_shared = (bi == 0 || bi == (aa.NA >> 4)) && aa.N > 0 && !(aa.dbg & 1);   // rows 0..6 or row NA
+    const bool has_shared = (bi == 0 || bi == (aa.NA >> 4)) && aa.N > 0;   // rows 0..6 or row NA
     if (has_shared) {
         const int g4 = tid >> 6, en = tid & 63;
         const int ea = en >> 3, eb = en & 7;                      // entry classes 0..6 -> e = 0..6, 7 -> e = 13
@@ -1896,36 +1896,38 @@ __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __r
         ekj[j] = -1; ckj[j] = -1;
         if (kc < 7) ekj[j] = kc; else if (kc >= aa.cb0 && kc < aa.cb0 + 6 * aa.N) { ckj[j] = (kc - aa.cb0) / 6; ekj[j] = 7 + (kc - aa.cb0) - 6 * ckj[j]; }
     }
+    // (32-bit element offsets from wave-uniform bases: the loads take the SGPR-base form, and the row part of every
+    //  index is scalar -- the per-element code is a dozen instructions, not a hundred)
+    const bool use_S = aa.N > 0;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int r = wave + 4 * rr;
         const int i = 16 * bi + r;          // (wave-uniform)
-        const int ic = i < M ? i : 0;
+        const bool rin = i < M;
+        const int ic = rin ? i : 0;
         int ei = -1, ci = -1;
         if (ic < 7) ei = ic; else if (ic == aa.NA) ei = 13; else if (ic >= aa.cb0 && ic < aa.cb0 + 6 * aa.N) { ci = (ic - aa.cb0) / 6; ei = 7 + (ic - aa.cb0) - 6 * ci; }
+        const unsigned rowoff = (unsigned)(ic * aa.NAP);
+        const int ea = ei == 13 ? 7 : ei;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int k = l + 64 * j;
-            const bool in = i < M && k < K;
-            const int kc = k < K ? k : 0;
+            const bool in = rin && k < K;
+            const unsigned kc = k < K ? (unsigned)k : 0u;
             const int ek = ekj[j], ck = ckj[j];
-            int c0 = 0, n1 = 0;   // clone tile and number of clone tiles that contribute (0, 1, or all N)
-            if (ei >= 0 && ek >= 0) {
-                if (ci < 0 && ck < 0) n1 = 2;
-                else if (ci >= 0 && ck >= 0) { if (ci == ck) { c0 = ci; n1 = 1; } }
-                else { c0 = ci >= 0 ? ci : ck; n1 = 1; }
-            }
-            if (!in || aa.N == 0 || (aa.dbg & 4)) n1 = 0;
-            if ((aa.dbg & 1) && n1 > 1) n1 = 1;
+            // clone tile and kind of S contribution: 0 none, 1 one clone tile, 2 every clone tile (shared block)
+            int c0 = ci >= 0 ? ci : ck, n1 = 0;
+            if (ei >= 0 && ek >= 0) n1 = (ci < 0 && ck < 0) ? 2 : ((ci >= 0 && ck >= 0 && ci != ck) ? 0 : 1);
+            if (!in || !use_S) n1 = 0;
             const int e16 = (ei >= ek) ? ei * 16 + ek : ek * 16 + ei;   // the S tiles hold both triangles: [max][min]
-            const int ea = ei == 13 ? 7 : ei, eb = ek == 13 ? 7 : ek;   // (shared entries: both below 8)
-            cls[rr][j] = n1 == 2 ? (2 | ((ea * 8 + eb) << 2)) : n1;
-            sv[rr][j] = aa.S[(size_t)(n1 == 1 ? c0 : 0) * 256 + (n1 == 1 ? e16 : 0)];
-            const size_t src = (size_t)ic * aa.NAP + kc;
+            cls[rr][j] = n1 == 2 ? (2 | ((ea * 8 + (ek == 13 ? 7 : ek)) << 2)) : n1;
+            sv[rr][j] = aa.S[n1 == 1 ? (unsigned)(c0 * 256 + e16) : 0u];
+            const unsigned src = rowoff + kc;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (u < aa.nparts && !(aa.dbg & 2)) gv[rr][j][u] = aa.parts[(size_t)u * aa.stride + src];   // (wave-uniform count)
-            pv[rr][j] = aa.plus ? aa.plus[((ic >> 4) >= (kc >> 4)) ? src : (size_t)kc * aa.NAP + ic] : 0.0;
+                if (u < aa.nparts) gv[rr][j][u] = (aa.parts + (size_t)u * aa.stride)[src];   // (wave-uniform count and base)
+            pv[rr][j] = 0.0;
+            if (aa.plus) pv[rr][j] = aa.plus[((ic >> 4) >= (int)(kc >> 4)) ? src : kc * (unsigned)aa.NAP + (unsigned)ic];
         }
     }
     if (has_shared) __syncthreads();
