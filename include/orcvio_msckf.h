@@ -361,6 +361,39 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
                                           const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
                                           double* d_dst, int32_t* dof_out, void* stream);
 
+/* ---- Multi-GPU: the handle owns an RCCL communicator (SURVEY.md 8b "handle owns ... RCCL comm", 8e) --------------------
+ * One process per GPU, one handle per process.  The reference has no collectives; the callers this serves are the same
+ * three call sites (OrcVIO::removeLostFeatures src/orcvio.cpp:2497-2560, ::pruneImuStateBuffer :2803-2851,
+ * System::processObjects -> removeLostObjects ros_wrapper/src/orcvio/src/System.cpp:622-708), each rank holding a share of the
+ * tracks / objects and ALL of the window and the prior.  Per update: local tracks -> local compressed block -> ONE
+ * ncclAllGather of the blocks over xGMI -> rank-ordered sum (bit-identical on every rank) -> replicated Kalman solve, so
+ * every rank ends with the same delta_x and P+ and nothing is broadcast back.
+ *   comm_unique_id   rank 0: ncclGetUniqueId into id[ORCVIO_COMM_ID_BYTES]; the caller ships the bytes to the other ranks
+ *                    by whatever channel it has (MPI, a TCP store, torch.distributed, a file)
+ *   comm_init        ncclCommInitRank on the handle's device; allocates the gather buffer
+ *   comm_destroy     (also done by orcvio_msckf_destroy)
+ * RCCL (librccl.so.1) is loaded with dlopen on the first of these calls: a single-GPU caller never needs it. */
+#define ORCVIO_COMM_ID_BYTES 128
+int32_t orcvio_msckf_comm_unique_id(uint8_t* id /* [ORCVIO_COMM_ID_BYTES] */);
+int32_t orcvio_msckf_comm_init(orcvio_msckf_handle* h, const uint8_t* id, int32_t rank, int32_t world);
+int32_t orcvio_msckf_comm_destroy(orcvio_msckf_handle* h);
+int32_t orcvio_msckf_comm_info(orcvio_msckf_handle* h, int32_t* rank, int32_t* world); /* world = 0: no communicator */
+/* The sharded feature update.  run_update_sharded: staged form on the tracks of the last orcvio_msckf_upload (this rank's
+ * share), results stay in HBM (orcvio_msckf_download fetches them).  update_features_sharded: host buffers in and out like
+ * orcvio_msckf_update_features; `tracks` are THIS RANK's tracks, result->accept / gamma are theirs, result->dx / P_out are
+ * the joint update's (identical on every rank); stats[0], [2] count this rank's accepted rows / tracks.
+ * Every rank must make the same call in the same order (it contains a collective). */
+int32_t orcvio_msckf_run_update_sharded(orcvio_msckf_handle* h, void* stream);
+int32_t orcvio_msckf_update_features_sharded(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
+                                             const orcvio_msckf_window* window, const orcvio_msckf_tracks* tracks,
+                                             const double* P, orcvio_msckf_result* result);
+/* The sharded object update (System::processObjects): this rank's object tracks -> local block -> all-gather of the blocks
+ * and of the local degrees of freedom -> joint gate with the total dof (src/orcvio.cpp:2172-2176) -> replicated solve. */
+int32_t orcvio_msckf_update_object_tracks_sharded(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
+                                                  const orcvio_object_eval_flags* eval_flags, int32_t n_clones,
+                                                  const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
+                                                  orcvio_msckf_result* result);
+
 /* ---- Feature triangulation --------------------------------------
  * Replaces, for every listed track, Feature::checkMotion followed by Feature::initializePosition
  * (include/orcvio/feat/feature.hpp:354-449; the Levenberg-Marquardt of ::triangulate_position, :583-719, with

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- numpy restatement of the covariance bookkeeping around the update.
 
   propagate       OrcVIO::processModel, src/orcvio.cpp:800-816   P_LL <- Phi P_LL Phi^T + Q, cross terms, symmetrise
-  augment         OrcVIO::stateAugmentation, :962-1010 (no EKF-SLAM / nuisance states: rest_rows = 0)
+  augment         OrcVIO::stateAugmentation, :962-1010 (rest = EKF-SLAM feature + nuisance states behind the clones)
                   J = [I3 at cols 0:3 ; I3 at cols 6:9] -> the new clone copies the IMU (theta, p) covariance
   remove_clones   OrcVIO::pruneImuStateBuffer, :2935-2951 (the non-Schmidt branch): rows/cols of the pruned clones deleted
 Parity unpinned (no reference test touches these lines).  Nothing under orcvio_amd/ may import this module.
@@ -19,18 +19,22 @@ def propagate(P, Phi, Q):
     return 0.5 * (P + P.T)
 
 
-def augment(P):
+def augment(P, rest=0):
+    """rest = feature_rows + nui_rows (:976-981): the new clone is inserted in front of those states (:988-1003)."""
     n = P.shape[0]
+    pose = n - rest
     J = np.zeros((6, n))
     J[0:3, 0:3] = np.eye(3)
     J[3:6, 6:9] = np.eye(3)
     P12 = J @ P
     P11 = P12 @ J.T
     out = np.zeros((n + 6, n + 6))
-    out[:n, :n] = P
-    out[n:, :n] = P12
-    out[:n, n:] = P12.T
-    out[n:, n:] = P11
+    old = np.r_[np.arange(pose), np.arange(pose + 6, n + 6)]
+    new = np.arange(pose, pose + 6)
+    out[np.ix_(old, old)] = P
+    out[np.ix_(new, old)] = P12
+    out[np.ix_(old, new)] = P12.T
+    out[np.ix_(new, new)] = P11
     return 0.5 * (out + out.T)
 
 

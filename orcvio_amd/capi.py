@@ -35,6 +35,8 @@ EXPORTS = [
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
     'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks', 'orcvio_msckf_new_feature_rows', 'orcvio_msckf_augment_state',
+    'orcvio_msckf_comm_unique_id', 'orcvio_msckf_comm_init', 'orcvio_msckf_comm_destroy', 'orcvio_msckf_comm_info',
+    'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
 ]
 
 
@@ -152,8 +154,27 @@ def load():
                                                       C.POINTER(ObjectTrackC), C.c_int32, _dp, C.POINTER(MsckfResult)]
     lib.orcvio_msckf_objects_local_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.c_int32,
                                                       C.POINTER(ObjectTrackC), C.c_int32, _dp, C.c_void_p, _ip, C.c_void_p]
+    lib.orcvio_msckf_comm_unique_id.argtypes = [C.c_char_p]
+    lib.orcvio_msckf_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+    lib.orcvio_msckf_comm_destroy.argtypes = [C.c_void_p]
+    lib.orcvio_msckf_comm_info.argtypes = [C.c_void_p, _ip, _ip]
+    lib.orcvio_msckf_run_update_sharded.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orcvio_msckf_update_features_sharded.argtypes = lib.orcvio_msckf_update_features.argtypes
+    lib.orcvio_msckf_update_object_tracks_sharded.argtypes = lib.orcvio_msckf_update_object_tracks.argtypes
     _LIB = lib
     return lib
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId (rank 0); ship the bytes to the other ranks, then every rank calls MsckfUpdater.comm_init."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().orcvio_msckf_comm_unique_id(buf)
+    if rc != 0:
+        raise MsckfError(rc, 'orcvio_msckf_comm_unique_id')
+    return buf.raw
 
 
 class MsckfError(RuntimeError):
@@ -314,6 +335,51 @@ class MsckfUpdater:
             raise MsckfError(rc, 'orcvio_msckf_set_option')
         self.n_extra = int(k)
 
+    # -- multi-GPU: the handle's own RCCL communicator ---------------------------------------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._chk(self.lib.orcvio_msckf_comm_init(self.h, unique_id, int(rank), int(world)), 'orcvio_msckf_comm_init')
+
+    def comm_destroy(self):
+        self._chk(self.lib.orcvio_msckf_comm_destroy(self.h), 'orcvio_msckf_comm_destroy')
+
+    def comm_info(self):
+        r, w = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.orcvio_msckf_comm_info(self.h, C.byref(r), C.byref(w)), 'orcvio_msckf_comm_info')
+        return r.value, w.value
+
+    def run_update_sharded(self, stream=None):
+        """This rank's uploaded tracks -> block -> RCCL all-gather -> rank-ordered sum -> replicated solve."""
+        self._chk(self.lib.orcvio_msckf_run_update_sharded(self.h, C.c_void_p(stream) if stream else None),
+                  'orcvio_msckf_run_update_sharded')
+
+    def update_features_sharded(self, win, want_G=False, resident_cov=False, want_P=True):
+        """Host buffers in and out; `win` holds THIS RANK's share of the tracks (sharding.shard_window)."""
+        fl, w, t, arrs = self._structs(win)
+        out, res = self._result(win.n, win.F, False, want_G, False)
+        if not want_P:
+            res.P_out = None
+        rc = self.lib.orcvio_msckf_update_features_sharded(self.h, C.byref(fl), C.byref(w), C.byref(t),
+                                                           None if resident_cov else _d(arrs['P']), C.byref(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_update_features_sharded')
+        return self._finish(out, res, win.F)
+
+    def update_object_tracks_sharded(self, flags, n_clones, objs, P, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D=False, want_G=False):
+        """System::processObjects over the ranks: `objs` are THIS RANK's object tracks."""
+        fl = make_flags(flags)
+        ef, arr, keep = self._object_tracks(objs, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D)
+        n = flags.leg_dim + 6 * n_clones + self.n_extra
+        Pc = None if P is None else np.ascontiguousarray(P, dtype=np.float64)
+        out, res = self._result(n, 1, False, want_G, False)
+        rc = self.lib.orcvio_msckf_update_object_tracks_sharded(self.h, C.byref(fl), C.byref(ef), n_clones, arr, len(objs), _d(Pc), C.byref(res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_update_object_tracks_sharded')
+        out = self._finish(out, res, 1)
+        out['gamma'] = float(out['gamma'][0])
+        out['accept'] = int(out['accept'][0])
+        return out
+
     def close(self):
         if self.h:
             self.lib.orcvio_msckf_destroy(self.h)
@@ -368,14 +434,41 @@ class MsckfUpdater:
         return out
 
     # -- one-shot host-buffer update (the reference call sites) ---------------------------
-    def update_features(self, win, want_K=False, want_G=False, want_thin=False):
+    def update_features(self, win, want_K=False, want_G=False, want_thin=False, resident_cov=False, want_P=True):
+        """resident_cov: the prior is the device-resident covariance (P is not sent); want_P=False: P+ stays in HBM
+        (cov_commit makes it the resident covariance) and only dx, gamma, accept come back."""
         fl, w, t, arrs = self._structs(win)
         out, res = self._result(win.n, win.F, want_K, want_G, want_thin)
-        rc = self.lib.orcvio_msckf_update_features(self.h, C.byref(fl), C.byref(w), C.byref(t), _d(arrs['P']),
-                                                   C.byref(res))
+        if not want_P:
+            res.P_out = None
+        rc = self.lib.orcvio_msckf_update_features(self.h, C.byref(fl), C.byref(w), C.byref(t),
+                                                   None if resident_cov else _d(arrs['P']), C.byref(res))
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_update_features')
         return self._finish(out, res, win.F)
+
+    def make_update_call(self, win, resident_cov=False, want_P=True, commit=False):
+        """The one-shot update with the argument structs marshalled ONCE: returns (call, out) where call() runs
+        orcvio_msckf_update_features (and orcvio_msckf_cov_commit if `commit`) on the same buffers -- what a C++ caller's
+        per-frame cost is, without this binding's numpy / ctypes marshalling (bench.py's latency modes)."""
+        fl, w, t, arrs = self._structs(win)
+        out, res = self._result(win.n, win.F)
+        if not want_P:
+            res.P_out = None
+        Pp = None if resident_cov else _d(arrs['P'])
+        lib, h = self.lib, self.h
+        args = (h, C.byref(fl), C.byref(w), C.byref(t), Pp, C.byref(res))
+        keep = (fl, w, t, arrs, res)
+
+        def call():
+            rc = lib.orcvio_msckf_update_features(*args)
+            if rc == 0 and commit:
+                rc = lib.orcvio_msckf_cov_commit(h)
+            if rc != 0:
+                raise MsckfError(rc, 'orcvio_msckf_update_features')
+        call._keep = keep
+        self.n, self.F = win.n, win.F
+        return call, out
 
     # -- object blocks (OrcVIO::removeLostObjects) ---------------------------------------------
     def update_objects(self, flags, n_clones, blocks, P, want_G=False):

@@ -1,7 +1,7 @@
 // cov_ops.hpp -- covariance bookkeeping on a device-resident P: the three places
 // besides the update where the reference touches state_cov, so that P never has to cross PCIe between updates.
 //   k_cov_propagate_*  OrcVIO::processModel      (src/orcvio.cpp:800-816)
-//   k_cov_augment      OrcVIO::stateAugmentation (:962-1010, no EKF-SLAM / nuisance states)
+//   k_cov_augment      OrcVIO::stateAugmentation (:962-1010, feature / nuisance states behind the clones included)
 //   k_cov_remove       OrcVIO::pruneImuStateBuffer (:2935-2951, non-Schmidt branch)
 // All three are HBM-bound element kernels over an n x n matrix (n <= 406): coalesced row-major reads and writes.
 #pragma once
@@ -40,19 +40,22 @@ __global__ __launch_bounds__(256) void k_cov_propagate_finish(const double* __re
     }
     out[idx] = v;
 }
-// out (n+6)^2: the new clone copies rows/cols (0:3, 6:9) of P
-__global__ __launch_bounds__(256) void k_cov_augment(const double* __restrict__ P, int n, double* __restrict__ out) {
+// out (n+6)^2: the new clone copies rows/cols (0:3, 6:9) of P and is inserted at `pose` = n - rest_rows, i.e. behind the
+// clones and in front of the feature / nuisance states (src/orcvio.cpp:976-1003: the rest block moves down / right by 6)
+__global__ __launch_bounds__(256) void k_cov_augment(const double* __restrict__ P, int n, int pose, double* __restrict__ out) {
     const int m = n + 6;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= m * m) return;
     const int i = idx / m, j = idx - i * m;
-    const int si = i < n ? i : (i - n < 3 ? i - n : i - n + 3);   // source row: 0..2 -> theta, 3..5 -> p (cols 6:9)
-    const int sj = j < n ? j : (j - n < 3 ? j - n : j - n + 3);
+    const bool ni = i >= pose && i < pose + 6, nj = j >= pose && j < pose + 6;
+    // source row: old states keep their index (shifted back by 6 behind the new clone); new 0..2 -> theta, 3..5 -> p (6:9)
+    const int si = ni ? (i - pose < 3 ? i - pose : i - pose + 3) : (i < pose ? i : i - 6);
+    const int sj = nj ? (j - pose < 3 ? j - pose : j - pose + 3) : (j < pose ? j : j - 6);
     // [[P, P12^T], [P12, P11]] then (X + X^T)/2 as :1008-1010: the off-diagonal blocks are transposes of each other already
     double v;
-    if ((i < n) == (j < n)) v = 0.5 * (P[(size_t)si * n + sj] + P[(size_t)sj * n + si]);
-    else if (i >= n) v = P[(size_t)si * n + j];
-    else v = P[(size_t)sj * n + i];
+    if (ni == nj) v = 0.5 * (P[(size_t)si * n + sj] + P[(size_t)sj * n + si]);
+    else if (ni) v = P[(size_t)si * n + sj];
+    else v = P[(size_t)sj * n + si];
     out[idx] = v;
 }
 // out m^2 = P without the rows/cols flagged in drop[] (drop[k] = 1: state k is removed); map[k'] = k precomputed

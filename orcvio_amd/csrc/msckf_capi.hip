@@ -4,6 +4,8 @@
 #include "../../include/orcvio_msckf.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is loaded with dlopen (comm_* section), never linked
+#include <dlfcn.h>
 #include <chrono>
 
 #include <algorithm>
@@ -54,10 +56,15 @@ struct orcvio_msckf_handle {
     // host <-> device traffic of the one-shot calls: small inputs share one device arena (one copy), everything is staged
     // through pinned host memory (a copy from pageable memory is synchronous and several times slower), the small
     // outputs share one arena (one copy back)
-    char *d_meta = nullptr, *d_outs = nullptr;       // device arenas
-    char* h_stage = nullptr;                          // pinned
-    size_t meta_bytes = 0, outs_bytes = 0;
-    size_t so_meta = 0, so_pw = 0, so_oclone = 0, so_cobs = 0, so_z = 0, so_zvel = 0, so_P = 0, so_outs = 0, so_Pout = 0, stage_bytes = 0;
+    // ONE input arena and ONE output arena, laid out compactly for the sizes of the current upload (layout_inputs /
+    // layout_outputs) and mirrored in pinned host memory: an update moves one block in and one block out
+    char *d_in = nullptr, *d_outs = nullptr;         // device arenas
+    char* h_stage = nullptr;                          // pinned: [inputs | outputs]
+    size_t in_cap = 0, outs_cap = 0, in_used = 0, outs_small = 0, stage_bytes = 0;
+    size_t io_poses = 0, io_optr = 0, io_rptr = 0, io_cptr = 0, io_pw = 0, io_oclone = 0, io_cobs = 0, io_z = 0, io_zvel = 0, io_P = 0;
+    size_t oo_dx = 0, oo_gamma = 0, oo_accept = 0, oo_Pout = 0;
+    bool dl_pending = false, dl_with_P = false;      // a device -> host copy of the outputs is in flight on dl_stream
+    hipStream_t dl_stream = nullptr;
     // graph policy: a launch graph is captured only when the same launch signature is seen twice in a row
     struct GraphSlot {
         hipGraph_t graph = nullptr;
@@ -93,6 +100,12 @@ struct orcvio_msckf_handle {
     double* d_slam = nullptr;           // [12 cap] param 3 | inv_depth 1 | p_w 3 | p_fej 3 | z 2
     double* d_Rf = nullptr;             // [maxF][6] R factor of every track's H_f (k_feature), for orcvio_msckf_augment_new_features
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
+    // multi-GPU: RCCL communicator of this handle (orcvio_msckf_comm_init), the all-gather buffer [world][NAP_max^2] and
+    // the gathered degrees of freedom of a sharded object update
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    double *d_gather = nullptr, *d_dofs = nullptr;
+    double* h_dofs = nullptr;           // pinned [2 * world]
     bool A_deferred = false;            // the last run left S / Gpart only: d_A is assembled on demand (assemble_deferred)
     int front_chunks = 1;               // T3 row chunks of the last k_front launch
     int n_cus = 0;                      // compute units of the device
@@ -114,7 +127,10 @@ struct orcvio_msckf_handle {
     bool materialize = false;
     int feat_ablate = 0;
     // captured launch graph of run_update (valid for the current upload and launch stream)
-    bool graph_valid = false;   // (kept for the option setters: any change of option drops the captured graphs)
+    // every captured graph bakes in device pointers and launch arguments: anything that reallocates a buffer a graph may
+    // reference, or changes an option / gate threshold, bumps this epoch; the epoch is part of the launch signature, so a
+    // stale graph can never be replayed (use-after-free through ekf_reserve / upload_dense_rows)
+    unsigned long long graph_epoch = 1;
     bool use_graph = true;
     size_t hs_rows_cap = 0;
     int gram_chunks_cap = 64;
@@ -199,13 +215,70 @@ double orcvio_msckf_chi2_quantile(int32_t dof, double prob) {
     return x;
 }
 
+// ---- arenas -----------------------------------------------------------------------------------
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// [poses | obs_ptr | row_ptr | clone_ptr | p_w | obs_clone | clone_obs | obs_z | (obs_zvel) | (P)], 256-byte aligned parts
+static size_t inputs_bytes(int N, int F, int nobs, bool zvel, size_t n_with_P) {
+    return al256(sizeof(double) * POSE_STRIDE * N) + 2 * al256(sizeof(int) * (F + 1)) + al256(sizeof(int) * (2 * N + 4)) +
+           al256(sizeof(double) * 3 * F) + 2 * al256(sizeof(int) * nobs) + al256(sizeof(double) * 2 * nobs) +
+           (zvel ? al256(sizeof(double) * 2 * nobs) : 0) + al256(sizeof(double) * n_with_P * n_with_P);
+}
+static size_t outputs_bytes(int n, int F) {
+    return 256 + al256(sizeof(double) * n) + al256(sizeof(double) * F) + al256(sizeof(int) * F) + al256(sizeof(double) * (size_t)n * n);
+}
+// Compact layout of the inputs for the sizes of this upload; with_P = false: the prior is the resident covariance and
+// does not travel.  The device pointers are functions of (N, F, nobs, zvel, with_P) only, so equal shapes give equal
+// pointers (the captured launch graphs stay valid; d_P is part of the launch signature all the same).
+static void layout_inputs(orcvio_msckf_handle* h, int N, int F, int nobs, bool zvel, bool with_P, int n) {
+    size_t o = 0;
+    h->io_poses = o; o += al256(sizeof(double) * POSE_STRIDE * N);
+    h->io_optr = o; o += al256(sizeof(int) * (F + 1));
+    h->io_rptr = o; o += al256(sizeof(int) * (F + 1));
+    h->io_cptr = o; o += al256(sizeof(int) * (2 * N + 4));
+    h->io_pw = o; o += al256(sizeof(double) * 3 * F);
+    h->io_oclone = o; o += al256(sizeof(int) * nobs);
+    h->io_cobs = o; o += al256(sizeof(int) * nobs);
+    h->io_z = o; o += al256(sizeof(double) * 2 * nobs);
+    h->io_zvel = h->io_z;   // (never read without estimate_td: any valid address)
+    if (zvel) { h->io_zvel = o; o += al256(sizeof(double) * 2 * nobs); }
+    h->io_P = o;
+    h->in_used = o;         // what travels besides P
+    char* d = h->d_in;
+    h->d_poses = reinterpret_cast<double*>(d + h->io_poses);
+    h->d_obs_ptr = reinterpret_cast<int*>(d + h->io_optr);
+    h->d_row_ptr = reinterpret_cast<int*>(d + h->io_rptr);
+    h->d_clone_ptr = reinterpret_cast<int*>(d + h->io_cptr);
+    h->d_pw = reinterpret_cast<double*>(d + h->io_pw);
+    h->d_obs_clone = reinterpret_cast<int*>(d + h->io_oclone);
+    h->d_clone_obs = reinterpret_cast<int*>(d + h->io_cobs);
+    h->d_obs_z = reinterpret_cast<double*>(d + h->io_z);
+    h->d_obs_zvel = reinterpret_cast<double*>(d + h->io_zvel);
+    h->d_P = with_P ? reinterpret_cast<double*>(d + h->io_P) : h->d_Pres;
+    (void)n;
+}
+// [info 64 ints | dx | gamma | accept | P+]: the small part is one copy, with P+ behind it one longer copy
+static void layout_outputs(orcvio_msckf_handle* h, int n, int F) {
+    size_t o = 256;
+    h->d_info = reinterpret_cast<int*>(h->d_outs);
+    h->d_flag = h->d_info + 32;
+    h->oo_dx = o; o += al256(sizeof(double) * n);
+    h->oo_gamma = o; o += al256(sizeof(double) * (F > 0 ? F : 1));
+    h->oo_accept = o; o += al256(sizeof(int) * (F > 0 ? F : 1));
+    h->oo_Pout = o;
+    h->outs_small = o;
+    h->d_dx = reinterpret_cast<double*>(h->d_outs + h->oo_dx);
+    h->d_gamma = reinterpret_cast<double*>(h->d_outs + h->oo_gamma);
+    h->d_accept = reinterpret_cast<int*>(h->d_outs + h->oo_accept);
+    h->d_Pout = reinterpret_cast<double*>(h->d_outs + h->oo_Pout);
+}
+
 // ---- create / destroy ---------------------------------------------------------------------
 static void free_all(orcvio_msckf_handle* h) {
-    void* ptrs[] = {h->d_meta, h->d_outs, h->d_pw, h->d_obs_z, h->d_obs_zvel, h->d_P, h->d_obs_clone,
+    void* ptrs[] = {h->d_in, h->d_outs,
                     h->d_chi2, h->d_Hs, h->d_Gpart, h->d_Ab, h->d_A, h->d_RP,
-                    h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_Pout, h->d_La, h->d_DinvA,
+                    h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_La, h->d_DinvA,
                     h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
-                    h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S, h->d_clone_obs,
+                    h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S,
                     h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
                     h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense, h->d_Rf};
     for (void* p : ptrs)
@@ -266,60 +339,32 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         const size_t nn = (size_t)h->n_max * h->n_max, pp = (size_t)h->NAP_max * h->NAP_max;
         const size_t np2 = (size_t)h->NP_max * h->NP_max;
         h->hs_rows_cap = (size_t)2 * max_observations + 16;
-        {   // meta arena: [poses | obs_ptr | row_ptr | clone_ptr], 256-byte aligned parts, copied as one block
-            auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-            const size_t b_poses = al(sizeof(double) * POSE_STRIDE * max_clones), b_ptr = al(sizeof(int) * (max_features + 1));
-            const size_t b_cptr = al(sizeof(int) * (2 * max_observations / 256 + 2 * max_clones + 4));
-            h->meta_bytes = b_poses + 2 * b_ptr + b_cptr;
-            HIPCHK(hipMalloc(&h->d_meta, h->meta_bytes));
-            h->d_poses = reinterpret_cast<double*>(h->d_meta);
-            h->d_obs_ptr = reinterpret_cast<int*>(h->d_meta + b_poses);
-            h->d_row_ptr = reinterpret_cast<int*>(h->d_meta + b_poses + b_ptr);
-            h->d_clone_ptr = reinterpret_cast<int*>(h->d_meta + b_poses + 2 * b_ptr);
-            // outputs arena: [dx | gamma | accept | info(64 ints)]
-            const size_t b_dx = al(sizeof(double) * h->n_max), b_gam = al(sizeof(double) * max_features), b_acc = al(sizeof(int) * max_features);
-            h->outs_bytes = b_dx + b_gam + b_acc + 256;
-            HIPCHK(hipMalloc(&h->d_outs, h->outs_bytes));
-            h->d_dx = reinterpret_cast<double*>(h->d_outs);
-            h->d_gamma = reinterpret_cast<double*>(h->d_outs + b_dx);
-            h->d_accept = reinterpret_cast<int*>(h->d_outs + b_dx + b_gam);
-            h->d_info = reinterpret_cast<int*>(h->d_outs + b_dx + b_gam + b_acc);
-            // pinned staging: inputs then outputs
-            size_t o = 0;
-            h->so_meta = o; o += h->meta_bytes;
-            h->so_pw = o; o += al(sizeof(double) * 3 * max_features);
-            h->so_oclone = o; o += al(sizeof(int) * max_observations);
-            h->so_cobs = o; o += al(sizeof(int) * max_observations);
-            h->so_z = o; o += al(sizeof(double) * 2 * max_observations);
-            h->so_zvel = o; o += al(sizeof(double) * 2 * max_observations);
-            h->so_P = o; o += al(sizeof(double) * nn);
-            h->so_outs = o; o += h->outs_bytes;
-            h->so_Pout = o; o += al(sizeof(double) * nn);
-            h->stage_bytes = o;
+        {   // input / output arenas at their worst-case size, pinned mirror of both
+            h->in_cap = inputs_bytes(max_clones, max_features, max_observations, true, (size_t)h->n_max);
+            h->outs_cap = outputs_bytes(h->n_max, max_features);
+            HIPCHK(hipMalloc(&h->d_in, h->in_cap));
+            HIPCHK(hipMalloc(&h->d_outs, h->outs_cap));
+            HIPCHK(hipMemset(h->d_in, 0, h->in_cap));
+            h->stage_bytes = h->in_cap + h->outs_cap;
             HIPCHK(hipHostMalloc(&h->h_stage, h->stage_bytes, hipHostMallocDefault));
+            layout_inputs(h, max_clones, max_features, max_observations, true, true, h->n_max);
+            layout_outputs(h, h->n_max, max_features);
         }
-        HIPCHK(hipMalloc(&h->d_pw, sizeof(double) * 3 * max_features));
-        HIPCHK(hipMalloc(&h->d_obs_z, sizeof(double) * 2 * max_observations));
-        HIPCHK(hipMalloc(&h->d_obs_zvel, sizeof(double) * 2 * max_observations));
-        HIPCHK(hipMalloc(&h->d_P, sizeof(double) * nn));
-        HIPCHK(hipMalloc(&h->d_obs_clone, sizeof(int) * max_observations));
         HIPCHK(hipMalloc(&h->d_skip, sizeof(int) * max_features));
         HIPCHK(hipMalloc(&h->d_Pres, sizeof(double) * nn));
         HIPCHK(hipMalloc(&h->d_Ptmp, sizeof(double) * nn));
-        HIPCHK(hipMalloc(&h->d_covT, sizeof(double) * 46 * h->n_max));
+        HIPCHK(hipMalloc(&h->d_covT, sizeof(double) * (46 * (size_t)h->n_max + 2 * 46 * 46)));   // Phi P rows, then Phi and Q
         HIPCHK(hipMalloc(&h->d_covmap, sizeof(int) * h->n_max));
         HIPCHK(hipMalloc(&h->d_tri_valid, sizeof(int) * max_features));
         HIPCHK(hipMalloc(&h->d_tri_flags, sizeof(int) * max_features));
         HIPCHK(hipMalloc(&h->d_tri_init, sizeof(int) * max_features));
         HIPCHK(hipMalloc(&h->d_tri_sol, sizeof(double) * 3 * max_features));
         HIPCHK(hipMalloc(&h->d_tri_cost, sizeof(double) * max_features));
-        h->d_flag = h->d_info + 32;
         HIPCHK(hipMalloc(&h->d_chi2, sizeof(double) * ORCVIO_CHI2_TABLE));
         HIPCHK(hipMalloc(&h->d_T3, sizeof(double) * (size_t)3 * max_features * h->NAP_max));
         HIPCHK(hipMalloc(&h->d_Rf, sizeof(double) * (size_t)6 * max_features));
         HIPCHK(hipMalloc(&h->d_Xobs, sizeof(double) * (size_t)32 * max_observations));
         HIPCHK(hipMalloc(&h->d_S, sizeof(double) * (size_t)256 * (2 * max_observations / 256 + max_clones + 2)));
-        HIPCHK(hipMalloc(&h->d_clone_obs, sizeof(int) * max_observations));
         HIPCHK(hipMalloc(&h->d_Gpart, sizeof(double) * pp * h->gram_chunks_cap));
         HIPCHK(hipMalloc(&h->d_Ab, sizeof(double) * pp));
         HIPCHK(hipMalloc(&h->d_A, sizeof(double) * pp));
@@ -330,14 +375,12 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_RM, sizeof(double) * np2));
         HIPCHK(hipMalloc(&h->d_DinvM, sizeof(double) * 256 * TRSM_MAXBLK));
         HIPCHK(hipMalloc(&h->d_Z, sizeof(double) * np2));
-        HIPCHK(hipMalloc(&h->d_Pout, sizeof(double) * nn));
         HIPCHK(hipMalloc(&h->d_La, sizeof(double) * pp));
         HIPCHK(hipMalloc(&h->d_DinvA, sizeof(double) * 256 * TRSM_MAXBLK));
         HIPCHK(hipMalloc(&h->d_W, sizeof(double) * np2));
         HIPCHK(hipMalloc(&h->d_Y, sizeof(double) * np2));
         HIPCHK(hipMalloc(&h->d_KG, sizeof(double) * np2));
-        HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 64));   // (inside the outputs arena)
-        HIPCHK(hipMemset(h->d_obs_zvel, 0, sizeof(double) * 2 * max_observations));
+        HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 64));   // (head of the outputs arena)
         HIPCHK(hipMalloc(&h->d_sync, 256));
         HIPCHK(hipMemset(h->d_sync, 0, 256));
         HIPCHK(hipMemset(h->d_RP, 0, sizeof(double) * np2));   // strictly-lower tiles of the upper factors stay 0
@@ -365,6 +408,7 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
 void orcvio_msckf_destroy(orcvio_msckf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    (void)orcvio_msckf_comm_destroy(h);
     free_all(h);
     delete h;
 }
@@ -375,28 +419,26 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
         HIPCHK(hipSetDevice(h->device));
         if (value && !h->d_Hs) HIPCHK(hipMalloc(&h->d_Hs, sizeof(double) * h->hs_rows_cap * h->NAP_max));
         h->materialize = value != 0;
-        h->graph_valid = false;
+        h->graph_epoch++;
         return ORCVIO_OK;
     }
     if (option == ORCVIO_OPT_FUSED_SOLVE) {
         h->fused_solve = value != 0;
-        h->graph_valid = false;
+        h->graph_epoch++;
         return ORCVIO_OK;
     }
     if (option == ORCVIO_OPT_FUSED_FRONT) {
         h->front_fused = value != 0;
-        h->graph_valid = false;
+        h->graph_epoch++;
         return ORCVIO_OK;
     }
     if (option == ORCVIO_OPT_EKF_ROWS) {
-        h->ekf_mode = value != 0;   // takes effect with the next upload
-        h->graph_valid = false;
+        h->ekf_mode = value != 0;   // takes effect with the next upload (part of the launch signature)
         return ORCVIO_OK;
     }
     if (option == ORCVIO_OPT_EXTRA_STATES) {
         if (value < 0 || 22 + 6 + value > h->n_max) { g_last_error = "orcvio_msckf_set_option: extra states out of range"; return ORCVIO_ERR_INVALID; }
-        h->n_extra = value;   // takes effect with the next upload / update call
-        h->graph_valid = false;
+        h->n_extra = value;   // takes effect with the next upload / update call (part of the launch signature)
         return ORCVIO_OK;
     }
     g_last_error = "orcvio_msckf_set_option: unknown option";
@@ -423,6 +465,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     if (N < 1 || F < 0) { g_last_error = "orcvio_msckf_upload: bad sizes"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));   // the pinned staging buffer of the previous upload is free again
+    if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     if (N > h->maxN || F > h->maxF) { g_last_error = "orcvio_msckf_upload: exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
     const int nobs = F > 0 ? tr->obs_ptr[F] : 0;
     if (nobs > h->maxObs) { g_last_error = "orcvio_msckf_upload: too many observations"; return ORCVIO_ERR_CAPACITY; }
@@ -462,11 +505,20 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
         HIPCHK(hipStreamSynchronize(h->stream));
         h->chi2_prob_cached = flags->chi2_prob;
     }
-    // ---- stage everything in pinned memory, then a handful of asynchronous copies -------------------
+    // ---- stage everything in pinned memory in the arena's layout: ONE asynchronous copy ---------------------
     hipStream_t s = h->stream;
+    if (!P && h->res_n != h->n) { g_last_error = "orcvio_msckf_upload: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
+    const bool with_zvel = tr->obs_zvel && flags->estimate_td;   // read by the kernels only under estimate_td
+    layout_inputs(h, N, F, nobs, with_zvel, P != nullptr, h->n);
+    layout_outputs(h, h->n, F);
     char* st = h->h_stage;
-    {   // meta block: poses, obs_ptr, row_ptr, clone tables (same layout as the device arena)
-        double* poses = reinterpret_cast<double*>(st + h->so_meta);
+    size_t bytes = h->in_used;
+    if (P) {   // the largest part first: the copy engine could start on it while the rest is staged (one copy all the same)
+        std::memcpy(st + h->io_P, P, sizeof(double) * (size_t)h->n * h->n);
+        bytes = h->io_P + sizeof(double) * (size_t)h->n * h->n;
+    }
+    {   // poses, obs_ptr, row_ptr
+        double* poses = reinterpret_cast<double*>(st + h->io_poses);
         const double* tfej = w->t_fej ? w->t_fej : w->t_b_w;
         for (int i = 0; i < N; ++i) {
             double* r = poses + (size_t)POSE_STRIDE * i;
@@ -477,51 +529,35 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
             std::memcpy(r + POSE_T_C_B, w->t_c_b + 3 * i, 3 * sizeof(double));
             r[27] = 0.0;
         }
-        std::memcpy(st + h->so_meta + ((char*)h->d_obs_ptr - h->d_meta), tr->obs_ptr, sizeof(int) * (F + 1));
-        std::memcpy(st + h->so_meta + ((char*)h->d_row_ptr - h->d_meta), h->h_row_ptr.data(), sizeof(int) * (F + 1));
+        std::memcpy(st + h->io_optr, tr->obs_ptr, sizeof(int) * (F + 1));
+        std::memcpy(st + h->io_rptr, h->h_row_ptr.data(), sizeof(int) * (F + 1));
     }
     // observations grouped by clone: position of every observation in the clone-sorted order, and the row range of
     // every clone (two rows per observation) for the sparse part of the compression
     {
-        std::vector<int> cnt(N + 1, 0);
+        int cnt[ORCVIO_MAX_CLONES + 2] = {0};
         for (int o = 0; o < nobs; ++o) cnt[tr->obs_clone[o] + 1]++;
         for (int i = 0; i < N; ++i) cnt[i + 1] += cnt[i];
-        int* clone_obs = reinterpret_cast<int*>(st + h->so_cobs);
-        std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+        int* clone_obs = reinterpret_cast<int*>(st + h->io_cobs);
+        int fill[ORCVIO_MAX_CLONES + 2];
+        std::memcpy(fill, cnt, sizeof(int) * (N + 1));
         for (int o = 0; o < nobs; ++o) clone_obs[o] = fill[tr->obs_clone[o]]++;
-        int* cptr = reinterpret_cast<int*>(st + h->so_meta + ((char*)h->d_clone_ptr - h->d_meta));   // [0..N] row offsets
+        int* cptr = reinterpret_cast<int*>(st + h->io_cptr);   // [0..N] row offsets
         for (int i = 0; i <= N; ++i) cptr[i] = 2 * cnt[i];
         h->s_chunks = N;
     }
-    HIPCHK(hipMemcpyAsync(h->d_meta, st + h->so_meta, h->meta_bytes, hipMemcpyHostToDevice, s));
-    if (P) {
-        std::memcpy(st + h->so_P, P, sizeof(double) * (size_t)h->n * h->n);
-        HIPCHK(hipMemcpyAsync(h->d_P, st + h->so_P, sizeof(double) * (size_t)h->n * h->n, hipMemcpyHostToDevice, s));
-    } else {   // the device-resident covariance (orcvio_msckf_cov_*)
-        if (h->res_n != h->n) { g_last_error = "orcvio_msckf_upload: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
-        HIPCHK(hipMemcpyAsync(h->d_P, h->d_Pres, sizeof(double) * (size_t)h->n * h->n, hipMemcpyDeviceToDevice, s));
-    }
     if (F > 0) {
-        if (tr->p_w) {
-            std::memcpy(st + h->so_pw, tr->p_w, sizeof(double) * 3 * F);
-            HIPCHK(hipMemcpyAsync(h->d_pw, st + h->so_pw, sizeof(double) * 3 * F, hipMemcpyHostToDevice, s));
-        } else {
-            HIPCHK(hipMemsetAsync(h->d_pw, 0, sizeof(double) * 3 * F, s));   // positions come from orcvio_msckf_triangulate_uploaded
-        }
+        if (tr->p_w) std::memcpy(st + h->io_pw, tr->p_w, sizeof(double) * 3 * F);
+        else std::memset(st + h->io_pw, 0, sizeof(double) * 3 * F);   // positions come from orcvio_msckf_triangulate_uploaded
         if (nobs > 0) {
-            std::memcpy(st + h->so_oclone, tr->obs_clone, sizeof(int) * nobs);
-            std::memcpy(st + h->so_z, tr->obs_z, sizeof(double) * 2 * nobs);
-            HIPCHK(hipMemcpyAsync(h->d_obs_clone, st + h->so_oclone, sizeof(int) * nobs, hipMemcpyHostToDevice, s));
-            HIPCHK(hipMemcpyAsync(h->d_clone_obs, st + h->so_cobs, sizeof(int) * nobs, hipMemcpyHostToDevice, s));
-            HIPCHK(hipMemcpyAsync(h->d_obs_z, st + h->so_z, sizeof(double) * 2 * nobs, hipMemcpyHostToDevice, s));
-            if (tr->obs_zvel && flags->estimate_td) {   // read by the kernels only under estimate_td
-                std::memcpy(st + h->so_zvel, tr->obs_zvel, sizeof(double) * 2 * nobs);
-                HIPCHK(hipMemcpyAsync(h->d_obs_zvel, st + h->so_zvel, sizeof(double) * 2 * nobs, hipMemcpyHostToDevice, s));
-            }
+            std::memcpy(st + h->io_oclone, tr->obs_clone, sizeof(int) * nobs);
+            std::memcpy(st + h->io_z, tr->obs_z, sizeof(double) * 2 * nobs);
+            if (with_zvel) std::memcpy(st + h->io_zvel, tr->obs_zvel, sizeof(double) * 2 * nobs);
         }
     }
+    HIPCHK(hipMemcpyAsync(h->d_in, st, bytes, hipMemcpyHostToDevice, s));
     // (no synchronisation: the staging buffer is rewritten only by the next upload, which the caller issues after the
-    // download / sync of this update; the kernels are ordered behind the copies on the same stream)
+    // download / sync of this update; the kernels are ordered behind the copy on the same stream)
     // Gram chunking: a workgroup of 16 wavefronts per (tile, chunk); up to 1024 rows per chunk keeps every wavefront
     // at one batch of loads (64 rows) and the number of partial Grams small
     int chunks = (3 * F + 1023) / 1024;
@@ -534,7 +570,6 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->chunks = t3rows > 0 ? (t3rows + rpc - 1) / rpc : 1;
     h->uploaded = true;
     h->ran = false;
-    h->graph_valid = false;
     h->skip_active = false;
     h->objects_mode = false;   // (a staged object update may have left it set)
     h->pw_missing = (F > 0 && !tr->p_w);
@@ -841,6 +876,12 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     unsigned long long bits;
     double sg = h->flags.noise_feature;
     std::memcpy(&bits, &sg, 8); mix(bits);
+    double cp = h->flags.chi2_prob;
+    std::memcpy(&bits, &cp, 8); mix(bits);
+    mix(h->graph_epoch); mix(h->ekf_idp); mix(h->ekf_eval); mix(h->ekf_cap); mix(h->dense_cap);
+    mix((unsigned long long)(size_t)h->d_ekf_i); mix((unsigned long long)(size_t)h->d_ekf_d); mix((unsigned long long)(size_t)h->d_ekf_E);
+    mix((unsigned long long)(size_t)h->d_slam); mix((unsigned long long)(size_t)h->d_dense); mix((unsigned long long)(size_t)h->d_Gekf);
+    mix((unsigned long long)(size_t)h->d_Hs); mix((unsigned long long)(size_t)h->d_P);
     mix((unsigned long long)(size_t)s); mix((unsigned long long)(size_t)p0); mix((unsigned long long)extra);
     return sig;
 }
@@ -918,6 +959,7 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
     h->last_stream = s;
+    if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     // the Cholesky of the prior was forked by run_local: join it here (outside the captured part)
     HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
     h->A_deferred = false;   // d_A is the sum of the gathered blocks
@@ -1007,6 +1049,7 @@ static int ekf_reserve(orcvio_msckf_handle* h, int F) {
     HIPCHK(hipMalloc(&h->d_slam, sizeof(double) * 12 * cap));
     if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)2 * h->NAP_max * h->NAP_max));
     h->ekf_cap = cap;
+    h->graph_epoch++;   // captured graphs hold the freed pointers
     return ORCVIO_OK;
 }
 
@@ -1024,7 +1067,6 @@ int32_t orcvio_msckf_upload_slam_features(orcvio_msckf_handle* h, const orcvio_m
     HIPCHK(hipSetDevice(h->device));
     { const int rc = ekf_reserve(h, F); if (rc != ORCVIO_OK) return rc; }
     h->ekf_F = F; h->ekf_idp = d; h->ekf_eval = true;
-    h->graph_valid = false;
     if (F == 0) return ORCVIO_OK;
     const int cap = h->ekf_cap;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1057,7 +1099,6 @@ int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_
     HIPCHK(hipSetDevice(h->device));
     { const int rc = ekf_reserve(h, F); if (rc != ORCVIO_OK) return rc; }
     h->ekf_F = F; h->ekf_idp = d; h->ekf_eval = false;
-    h->graph_valid = false;
     if (F == 0) return ORCVIO_OK;
     const int cap = h->ekf_cap;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1084,10 +1125,10 @@ int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, c
         if (h->d_dense) (void)hipFree(h->d_dense);
         h->dense_cap = round_up(n_rows, 64);
         HIPCHK(hipMalloc(&h->d_dense, sizeof(double) * (size_t)h->dense_cap * h->NAP_max));
+        h->graph_epoch++;   // captured graphs hold the freed pointer
     }
     if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)2 * h->NAP_max * h->NAP_max));
     h->dense_rows = n_rows;
-    h->graph_valid = false;
     if (n_rows == 0) return ORCVIO_OK;
     const int n = h->n, NA = h->NA, NAP = h->NAP;
     for (int i = 0; i < n_rows; ++i)
@@ -1401,6 +1442,7 @@ int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
     h->last_stream = s;
+    if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }   // (a copy of the previous results nobody fetched)
     int rc = run_with_graph(h, h->g_update, launch_signature(h, s, nullptr, 0), s, [&](bool) { return enqueue_update(h, s); });
     h->A_deferred = front_defers_assembly(h);   // (a replayed graph does not pass through enqueue_update)
     if (rc == ORCVIO_OK) h->ran = true;
@@ -1448,27 +1490,39 @@ static int compute_optional(orcvio_msckf_handle* h, bool want_thin_or_K, bool wa
     return ORCVIO_OK;
 }
 
+// Device -> host copy of the outputs arena ([info | dx | gamma | accept], with P+ behind it if wanted) into the pinned
+// mirror, enqueued on `sd` behind the update: ONE copy.  download() waits for it (or issues it itself).
+static int download_enqueue(orcvio_msckf_handle* h, hipStream_t sd, bool with_P) {
+    const size_t bytes = with_P ? h->oo_Pout + sizeof(double) * (size_t)h->n * h->n : h->outs_small;
+    HIPCHK(hipMemcpyAsync(h->h_stage + h->in_cap, h->d_outs, bytes, hipMemcpyDeviceToHost, sd));
+    h->dl_pending = true; h->dl_with_P = with_P; h->dl_stream = sd;
+    return ORCVIO_OK;
+}
+
 int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) {
     if (!h || !res || !h->ran) { g_last_error = "download: no finished update"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     const int n = h->n, NA = h->NA, NAP = h->NAP, NP = h->NP, F = h->F;
-    // one copy brings [dx | gamma | accept | info] (the outputs arena), one more P+; both land in pinned memory
-    hipStream_t sd = h->stream;
-    if (h->last_stream && h->last_stream != sd) HIPCHK(hipStreamSynchronize(h->last_stream));
-    HIPCHK(hipStreamSynchronize(h->side));
-    char* st = h->h_stage;
-    HIPCHK(hipMemcpyAsync(st + h->so_outs, h->d_outs, h->outs_bytes, hipMemcpyDeviceToHost, sd));
-    if (res->P_out) HIPCHK(hipMemcpyAsync(st + h->so_Pout, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, sd));
-    HIPCHK(hipStreamSynchronize(sd));
-    const double* dx = reinterpret_cast<const double*>(st + h->so_outs + ((char*)h->d_dx - h->d_outs));
-    const double* gam = reinterpret_cast<const double*>(st + h->so_outs + ((char*)h->d_gamma - h->d_outs));
-    const int* acc = reinterpret_cast<const int*>(st + h->so_outs + ((char*)h->d_accept - h->d_outs));
+    const bool want_P = res->P_out != nullptr;
+    if (!(h->dl_pending && (h->dl_with_P || !want_P))) {   // not enqueued behind the update (staged callers), or without P+
+        hipStream_t sd = h->last_stream ? h->last_stream : h->stream;
+        if (h->dl_pending) HIPCHK(hipStreamSynchronize(h->dl_stream));
+        HIPCHK(hipStreamSynchronize(h->side));
+        const int rq = download_enqueue(h, sd, want_P);
+        if (rq != ORCVIO_OK) return rq;
+    }
+    HIPCHK(hipStreamSynchronize(h->dl_stream));
+    h->dl_pending = false;
+    const char* so = h->h_stage + h->in_cap;
+    const double* dx = reinterpret_cast<const double*>(so + h->oo_dx);
+    const double* gam = reinterpret_cast<const double*>(so + h->oo_gamma);
+    const int* acc = reinterpret_cast<const int*>(so + h->oo_accept);
     if (res->dx) std::memcpy(res->dx, dx, sizeof(double) * n);
-    if (res->P_out) std::memcpy(res->P_out, st + h->so_Pout, sizeof(double) * (size_t)n * n);
+    if (res->P_out) std::memcpy(res->P_out, so + h->oo_Pout, sizeof(double) * (size_t)n * n);
     if (res->accept && F > 0) std::memcpy(res->accept, acc, sizeof(int) * F);
     if (res->gamma && F > 0) std::memcpy(res->gamma, gam, sizeof(double) * F);
     int info[9] = {0};
-    std::memcpy(info, st + h->so_outs + ((char*)h->d_info - h->d_outs), sizeof(int) * 9);
+    std::memcpy(info, so, sizeof(int) * 9);
     if (info[8] != 0) {   // a wait inside a launch gave up (a solver wavefront of k_potrf_solve, or a workgroup of k_front at its device-wide counter): never on a healthy device
         HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
         HIPCHK(hipMemset(h->d_sync, 0, 256));
@@ -1525,23 +1579,27 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
 
 int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* window,
                                      const orcvio_msckf_tracks* tracks, const double* P, orcvio_msckf_result* result) {
+    // one block in, the launches, one block out, ONE synchronisation
     static const bool timing = getenv("ORCVIO_TIMING") != nullptr;   // diagnostics: calls slower than 2 ms are broken down
+    if (!result) { g_last_error = "update_features: null result"; return ORCVIO_ERR_INVALID; }
     const auto t0 = std::chrono::steady_clock::now();
     int rc = orcvio_msckf_upload(h, flags, window, tracks, P);
     if (rc != ORCVIO_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_run_update(h, nullptr);
     if (rc != ORCVIO_OK) return rc;
-    const auto t2 = std::chrono::steady_clock::now();
-    rc = orcvio_msckf_sync(h, nullptr);
+    rc = download_enqueue(h, h->stream, result->P_out != nullptr);
     if (rc != ORCVIO_OK) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
+    HIPCHK(hipStreamSynchronize(h->stream));
     const auto t3 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_download(h, result);
     const auto t4 = std::chrono::steady_clock::now();
     if (timing) {
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        if (us(t0, t4) > 2000.0)
-            fprintf(stderr, "update_features: upload %.0f us, run (enqueue) %.0f us, sync %.0f us, download %.0f us\n", us(t0, t1), us(t1, t2),
+        static int calls = 0;
+        if (us(t0, t4) > 2000.0 || (++calls % 64) == 0)
+            fprintf(stderr, "update_features: upload %.0f us, enqueue %.0f us, sync %.0f us, unpack %.0f us\n", us(t0, t1), us(t1, t2),
                     us(t2, t3), us(t3, t4));
     }
     return rc;
@@ -1640,6 +1698,22 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
     return ORCVIO_OK;
 }
 
+// Prior of an object update: the caller's P staged through pinned memory (one asynchronous copy; the caller's buffer is
+// free when the call returns), or the resident covariance in place (no copy at all).
+static int objects_prior(orcvio_msckf_handle* h, hipStream_t s, const double* P, const char* who) {
+    const int n = h->n;
+    if (!P && h->res_n != n) { g_last_error = std::string(who) + ": P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipStreamSynchronize(h->stream));   // the pinned staging of the previous call is free again
+    if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
+    layout_inputs(h, h->N, 0, 0, false, P != nullptr, n);
+    layout_outputs(h, n, 1);
+    if (P) {
+        std::memcpy(h->h_stage + h->io_P, P, sizeof(double) * (size_t)n * n);
+        HIPCHK(hipMemcpyAsync(h->d_P, h->h_stage + h->io_P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
+    }
+    return ORCVIO_OK;
+}
+
 // Local part of an object update: this rank's objects -> its compressed block [A' b'; b'^T c'] (NAP x NAP) in d_dst
 // (the handle's own block if NULL), Cholesky of P forked on the side stream.
 int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
@@ -1685,12 +1759,7 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     h->last_stream = s;
     double* dst = d_dst ? d_dst : h->d_Ab;
     if (dof_out) *dof_out = dof;
-    if (P) {
-        HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
-    } else {
-        if (h->res_n != n) { g_last_error = "objects_local: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
-        HIPCHK(hipMemcpyAsync(h->d_P, h->d_Pres, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
-    }
+    { const int rp = objects_prior(h, s, P, "objects_local"); if (rp != ORCVIO_OK) return rp; }
     h->uploaded = true;
     h->objects_mode = true;
     h->obj_dof = dof; h->obj_rows = rows_tot; h->obj_count = nobj;
@@ -1726,7 +1795,10 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     HIPCHK(hipMemcpyAsync(sc.d_hx, h_hx.data(), sizeof(double) * h_hx.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(sc.d_hf, h_hf.data(), sizeof(double) * h_hf.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(sc.d_res, h_res.data(), sizeof(double) * rows_tot, hipMemcpyHostToDevice, s));
-    return objects_pipeline(h, s, dst, nobj, rows_tot, no_max, sc);
+    rc = objects_pipeline(h, s, dst, nobj, rows_tot, no_max, sc);
+    if (rc != ORCVIO_OK) return rc;
+    HIPCHK(hipStreamSynchronize(s));   // h_clone ... h_res are locals: the copies must have left them
+    return ORCVIO_OK;
 }
 
 // The same from object TRACKS (state at the LM optimum + observations): the residual rows and Jacobians of SURVEY 8a rows
@@ -1799,12 +1871,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     h->last_stream = s;
     double* dst = d_dst ? d_dst : h->d_Ab;
     if (dof_out) *dof_out = dof;
-    if (P) {
-        HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
-    } else {
-        if (h->res_n != n) { g_last_error = "objects_local_tracks: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
-        HIPCHK(hipMemcpyAsync(h->d_P, h->d_Pres, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
-    }
+    { const int rp = objects_prior(h, s, P, "objects_local_tracks"); if (rp != ORCVIO_OK) return rp; }
     h->uploaded = true;
     h->objects_mode = true;
     h->obj_dof = dof; h->obj_rows = rows_tot; h->obj_count = nobj;
@@ -1861,6 +1928,7 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
     h->last_stream = s;
     const int n = h->n, NA = h->NA, NAP = h->NAP;
     const double sigma2 = h->flags.noise_feature * h->flags.noise_feature;
+    if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     h->obj_dof = dof_total;
     h->A_deferred = false;
     int rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);
@@ -2035,6 +2103,172 @@ int32_t orcvio_msckf_object_rows_eval(orcvio_msckf_handle* h, const orcvio_objec
     return ORCVIO_OK;
 }
 
+// ---- multi-GPU: RCCL communicator owned by the handle ---------------------------------------
+// RCCL is loaded with dlopen on first use, so the library has no link-time dependency on it and a single-GPU caller
+// never loads it.  In a process that already holds librccl.so.1 (PyTorch ships one) the same instance is reused.
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+}  // namespace
+
+static int rccl_load() {
+    if (g_rccl.lib) return ORCVIO_OK;
+    const char* env = getenv("ORCVIO_RCCL_LIB");
+    const char* cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    std::string tried;
+    for (const char* c : cands) {
+        if (!c || !*c) continue;
+        lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+        tried += std::string(c) + " ";
+    }
+    if (!lib) { g_last_error = "RCCL not found (tried " + tried + "; set ORCVIO_RCCL_LIB)"; return ORCVIO_ERR_NO_DEVICE; }
+    RcclApi a;
+    a.lib = lib;
+#define RCCL_SYM(name) a.name = reinterpret_cast<decltype(a.name)>(dlsym(lib, "nccl" #name)); \
+    if (!a.name) { g_last_error = "RCCL: symbol nccl" #name " missing"; dlclose(lib); return ORCVIO_ERR_NO_DEVICE; }
+    RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(AllGather) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd)
+    RCCL_SYM(GetErrorString)
+#undef RCCL_SYM
+    g_rccl = a;
+    return ORCVIO_OK;
+}
+#define RCCLCHK(expr)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess) {                                                                            \
+            g_last_error = std::string(#expr) + ": " + g_rccl.GetErrorString(_r);                           \
+            return ORCVIO_ERR_HIP;                                                                          \
+        }                                                                                                   \
+    } while (0)
+
+int32_t orcvio_msckf_comm_unique_id(uint8_t* id) {
+    if (!id) { g_last_error = "comm_unique_id: null"; return ORCVIO_ERR_INVALID; }
+    { const int rl = rccl_load(); if (rl != ORCVIO_OK) return rl; }
+    static_assert(sizeof(ncclUniqueId) == ORCVIO_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    RCCLCHK(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof(u));
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_comm_destroy(orcvio_msckf_handle* h) {
+    if (!h) return ORCVIO_ERR_INVALID;
+    if (h->comm) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        (void)g_rccl.CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    if (h->d_gather) { (void)hipFree(h->d_gather); h->d_gather = nullptr; }
+    if (h->d_dofs) { (void)hipFree(h->d_dofs); h->d_dofs = nullptr; }
+    if (h->h_dofs) { (void)hipHostFree(h->h_dofs); h->h_dofs = nullptr; }
+    h->comm_world = 0; h->comm_rank = 0;
+    h->graph_epoch++;
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_comm_init(orcvio_msckf_handle* h, const uint8_t* id, int32_t rank, int32_t world) {
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) { g_last_error = "comm_init: invalid rank / world"; return ORCVIO_ERR_INVALID; }
+    { const int rl = rccl_load(); if (rl != ORCVIO_OK) return rl; }
+    if (h->comm) (void)orcvio_msckf_comm_destroy(h);
+    HIPCHK(hipSetDevice(h->device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    RCCLCHK(g_rccl.CommInitRank(&h->comm, world, u, rank));
+    h->comm_rank = rank; h->comm_world = world;
+    const size_t pp = (size_t)h->NAP_max * h->NAP_max;
+    HIPCHK(hipMalloc(&h->d_gather, sizeof(double) * pp * world));
+    HIPCHK(hipMalloc(&h->d_dofs, sizeof(double) * 2 * world));
+    HIPCHK(hipHostMalloc(&h->h_dofs, sizeof(double) * 2 * world, hipHostMallocDefault));
+    h->graph_epoch++;
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_comm_info(orcvio_msckf_handle* h, int32_t* rank, int32_t* world) {
+    if (!h) return ORCVIO_ERR_INVALID;
+    if (rank) *rank = h->comm_rank;
+    if (world) *world = h->comm_world;
+    return ORCVIO_OK;
+}
+
+// this rank's tracks -> its block, written straight into its slot of the gather buffer -> in-place all-gather (the one
+// data-path collective; <= 295 KB per rank, latency-bound over xGMI) -> rank-ordered sum + replicated solve
+int32_t orcvio_msckf_run_update_sharded(orcvio_msckf_handle* h, void* stream) {
+    if (!h || !h->uploaded || h->pw_missing) { g_last_error = "run_update_sharded: nothing uploaded (or positions missing)"; return ORCVIO_ERR_INVALID; }
+    if (!h->comm) { g_last_error = "run_update_sharded: no communicator (orcvio_msckf_comm_init)"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    const size_t ne = (size_t)h->NAP * h->NAP;
+    double* mine = h->d_gather + ne * h->comm_rank;
+    int rc = run_local_impl(h, s, mine);
+    if (rc != ORCVIO_OK) return rc;
+    RCCLCHK(g_rccl.AllGather(mine, h->d_gather, ne, ncclDouble, h->comm, s));
+    return orcvio_msckf_run_finish(h, h->d_gather, h->comm_world, s);
+}
+
+int32_t orcvio_msckf_update_features_sharded(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* window,
+                                             const orcvio_msckf_tracks* tracks, const double* P, orcvio_msckf_result* result) {
+    if (!result) { g_last_error = "update_features_sharded: null result"; return ORCVIO_ERR_INVALID; }
+    int rc = orcvio_msckf_upload(h, flags, window, tracks, P);
+    if (rc != ORCVIO_OK) return rc;
+    rc = orcvio_msckf_run_update_sharded(h, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    rc = download_enqueue(h, h->stream, result->P_out != nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    rc = orcvio_msckf_download(h, result);
+    if (rc == ORCVIO_OK) {   // the joint update is applied whenever ANY rank stacked rows: P+ != P decides, not the local count
+        result->stats[1] = h->NA;
+        result->stats[3] = 1;
+    }
+    return rc;
+}
+
+int32_t orcvio_msckf_update_object_tracks_sharded(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
+                                                  const orcvio_object_eval_flags* eval_flags, int32_t n_clones,
+                                                  const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
+                                                  orcvio_msckf_result* res) {
+    if (!h || !res) { g_last_error = "update_object_tracks_sharded: null argument"; return ORCVIO_ERR_INVALID; }
+    if (!h->comm) { g_last_error = "update_object_tracks_sharded: no communicator (orcvio_msckf_comm_init)"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int world = h->comm_world, rank = h->comm_rank;
+    // NAP is a function of the window only: known before the local part runs
+    const int n = flags ? flags->leg_dim + 6 * n_clones + h->n_extra : 0;
+    const int NA = h->ekf_mode ? n - 15 : n - h->n_extra - 15;
+    const size_t ne = (size_t)round_up(NA + 1, 16) * round_up(NA + 1, 16);
+    double* mine = h->d_gather + ne * rank;
+    int32_t dof = 0;
+    int rc = orcvio_msckf_objects_local_tracks(h, flags, eval_flags, n_clones, tracks, n_tracks, P, mine, &dof, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    h->h_dofs[world + rank] = (double)dof;
+    HIPCHK(hipMemcpyAsync(h->d_dofs + rank, h->h_dofs + world + rank, sizeof(double), hipMemcpyHostToDevice, s));
+    RCCLCHK(g_rccl.GroupStart());
+    RCCLCHK(g_rccl.AllGather(mine, h->d_gather, ne, ncclDouble, h->comm, s));
+    RCCLCHK(g_rccl.AllGather(h->d_dofs + rank, h->d_dofs, 1, ncclDouble, h->comm, s));
+    RCCLCHK(g_rccl.GroupEnd());
+    HIPCHK(hipMemcpyAsync(h->h_dofs, h->d_dofs, sizeof(double) * world, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));   // the gate threshold is a function of the total dof (host-side quantile)
+    int dof_total = 0;
+    for (int r = 0; r < world; ++r) dof_total += (int)h->h_dofs[r];
+    rc = orcvio_msckf_objects_finish(h, h->d_gather, world, dof_total, nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    rc = orcvio_msckf_objects_download(h, res);
+    h->objects_mode = false;
+    return rc;
+}
+
 // ---- per-kernel profile -------------------------------------------------------------------------
 int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_t reps, const char** names, double* ms,
                                     int32_t* count) {
@@ -2110,8 +2344,7 @@ int32_t orcvio_msckf_cov_propagate(orcvio_msckf_handle* h, int32_t leg, const do
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const int n = h->res_n;
-    double* dPhi = h->d_covT + (size_t)46 * h->n_max - 2 * 46 * 46;   // tail of the scratch holds Phi and Q
-    if ((size_t)leg * n + 2 * 46 * 46 > (size_t)46 * h->n_max) { g_last_error = "cov_propagate: scratch too small"; return ORCVIO_ERR_CAPACITY; }
+    double* dPhi = h->d_covT + (size_t)46 * h->n_max;   // behind the Phi P rows: Phi, then Q
     double* dQ = dPhi + 46 * 46;
     HIPCHK(hipMemcpyAsync(dPhi, Phi, sizeof(double) * leg * leg, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dQ, Q, sizeof(double) * leg * leg, hipMemcpyHostToDevice, s));
@@ -2127,7 +2360,9 @@ int32_t orcvio_msckf_cov_augment(orcvio_msckf_handle* h) {
     if (!h || h->res_n < 9 || h->res_n + 6 > h->n_max) { g_last_error = "cov_augment: no resident covariance, or window full"; return ORCVIO_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
     const int n = h->res_n, m = n + 6;
-    hipLaunchKernelGGL(k_cov_augment, dim3((m * m + 255) / 256), dim3(256), 0, h->stream, h->d_Pres, n, h->d_Ptmp);
+    // the new clone goes BEHIND the clones and IN FRONT of the feature / nuisance states (rest_rows, src/orcvio.cpp:976-1003)
+    if (h->n_extra > n - 15) { g_last_error = "cov_augment: more extra states than the resident covariance has"; return ORCVIO_ERR_INVALID; }
+    hipLaunchKernelGGL(k_cov_augment, dim3((m * m + 255) / 256), dim3(256), 0, h->stream, h->d_Pres, n, n - h->n_extra, h->d_Ptmp);
     HIPCHK(hipGetLastError());
     std::swap(h->d_Pres, h->d_Ptmp);
     h->res_n = m;
@@ -2204,7 +2439,6 @@ int32_t orcvio_msckf_triangulate_uploaded(orcvio_msckf_handle* h, const orcvio_t
     if (rc != ORCVIO_OK) return rc;
     h->skip_active = true;
     h->pw_missing = false;
-    h->graph_valid = false;   // k_feature now takes the skip mask
     return ORCVIO_OK;
 }
 
@@ -2231,8 +2465,11 @@ int32_t orcvio_msckf_triangulate(orcvio_msckf_handle* h, const orcvio_triangulat
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     // this call owns the track buffers: whatever was uploaded for an update is gone
-    h->uploaded = false; h->ran = false; h->graph_valid = false; h->skip_active = false; h->objects_mode = false;
+    h->uploaded = false; h->ran = false; h->skip_active = false; h->objects_mode = false;
     h->N = N; h->F = F; h->nobs = nobs;
+    HIPCHK(hipStreamSynchronize(s));
+    if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
+    layout_inputs(h, N, F, nobs, false, true, h->n_max);
     h->h_poses.assign((size_t)POSE_STRIDE * N, 0.0);
     const double* tfej = w->t_fej ? w->t_fej : w->t_b_w;
     for (int i = 0; i < N; ++i) {

@@ -55,6 +55,42 @@ def test_augment_and_remove_are_exact(upd):
     assert np.array_equal(upd.cov_get(), 0.5 * (P + P.T))
 
 
+@pytest.mark.parametrize('max_clones,leg,N', [(8, 22, 8), (8, 46, 8), (40, 46, 40), (18, 22, 18)])
+def test_propagate_on_a_full_window(built, max_clones, leg, N):
+    """the scratch of cov_propagate must hold Phi P and Phi, Q for a window filled to the handle's capacity."""
+    u = capi.MsckfUpdater(device=0, max_clones=max_clones, max_features=64, max_observations=1024)
+    try:
+        n = leg + 6 * N
+        rng = np.random.default_rng(n)
+        P = _spd(n, n)
+        Phi = np.eye(leg) + 0.05 * rng.standard_normal((leg, leg))
+        G = rng.standard_normal((leg, 12))
+        Q = 1e-5 * G @ G.T
+        u.cov_set(P)
+        u.cov_propagate(Phi, Q)
+        assert rel(u.cov_get(), mc.propagate(P, Phi, Q)) < 1e-14
+    finally:
+        u.close()
+
+
+def test_augment_in_front_of_the_feature_states(upd):
+    """stateAugmentation with EKF-SLAM feature / nuisance states behind the clones (src/orcvio.cpp:976-1003): the new clone
+    is inserted in front of them."""
+    k = 9
+    P = _spd(22 + 6 * 4 + k, 8)
+    upd.set_extra_states(k)
+    try:
+        upd.cov_set(P)
+        upd.cov_augment()
+        got = upd.cov_get()
+    finally:
+        upd.set_extra_states(0)
+    ref = mc.augment(P, rest=k)
+    assert np.array_equal(got, ref)
+    n = P.shape[0]
+    assert np.array_equal(got[n - k + 6:, n - k + 6:], 0.5 * (P + P.T)[n - k:, n - k:])   # the feature block moved down by 6
+
+
 def test_limits(upd):
     with pytest.raises(capi.MsckfError):
         upd.cov_remove_clones(22, [99])

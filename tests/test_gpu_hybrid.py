@@ -222,3 +222,35 @@ def test_new_3d_features_are_msckf_tracks_in_the_joint_update(upd):
     assert rel(np.concatenate([got['dx'], dx_new]), ref['dx']) < TOL
     assert rel(P_aug, ref['P_new']) < TOL
     assert rel(P_aug[w.n:, :], ref['P_new'][w.n:, :]) < TOL   # the new rows on their own (cross terms and P22)
+
+
+def test_captured_graph_survives_a_reallocation_of_the_ekf_rows():
+    """a launch graph captured for shape X must not be replayed after the EKF-row buffers it points into were
+    freed and reallocated (grow to a larger SLAM-feature count, then return to shape X).  Every run is compared with a
+    fresh handle that never captured anything."""
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=256, max_observations=4096)
+    try:
+        w0 = synth.make_window(N=8, F=30, seed=3, track_len=(3, 8))
+        small = synth.make_slam_features(w0, 40, seed=1)
+        big = synth.make_slam_features(w0, 70, seed=2)
+        ws = synth.with_extra_states(w0, len(small), seed=1)
+        wb = synth.with_extra_states(w0, len(big), seed=2)
+        ref_s = mh.hybrid_update(ws, small, 1)
+        ref_b = mh.hybrid_update(wb, big, 1)
+        for _ in range(3):   # same signature three times: captured on the second, replayed on the third
+            got = run(u, ws, small, 1, on_device=True)
+            assert rel(got['dx'], ref_s['dx']) < TOL
+        got = run(u, wb, big, 1, on_device=True)          # reallocates d_ekf_* (70 > capacity 64)
+        assert rel(got['dx'], ref_b['dx']) < TOL and np.array_equal(got['ekf_accept'], ref_b['ekf_accept'])
+        for _ in range(3):                                # back to the earlier shape
+            got = run(u, ws, small, 1, on_device=True)
+            assert rel(got['dx'], ref_s['dx']) < TOL and rel(got['P_new'], ref_s['P_new']) < TOL
+            assert np.array_equal(got['ekf_accept'], ref_s['ekf_accept'])
+        # a change of the gate probability between replays of one shape must reach the SLAM-row gate
+        import dataclasses
+        ws2 = dataclasses.replace(ws, flags=dataclasses.replace(ws.flags, chi2_prob=0.5))
+        ref2 = mh.hybrid_update(ws2, small, 1)
+        got = run(u, ws2, small, 1, on_device=True)
+        assert np.array_equal(got['ekf_accept'], ref2['ekf_accept']) and rel(got['dx'], ref2['dx']) < TOL
+    finally:
+        u.close()

@@ -39,3 +39,14 @@ def test_augment_is_J_P_Jt_and_remove_undoes_it():
     # removing an inner clone keeps the others in order
     B = mc.remove_clones(A, 22, [0])
     assert B.shape == (n, n) and np.array_equal(B[22:28, 22:28], A[28:34, 28:34])
+
+
+def test_augment_with_rest_rows_inserts_in_front_of_them():
+    k = 5
+    P = _spd(22 + 12 + k, 4)
+    n = P.shape[0]
+    A = mc.augment(P, rest=k)
+    J = np.zeros((6, n)); J[:3, :3] = np.eye(3); J[3:, 6:9] = np.eye(3)
+    T = np.vstack([np.eye(n)[:n - k], J, np.eye(n)[n - k:]])   # old poses, the new clone, then the rest
+    assert np.allclose(A, T @ P @ T.T, atol=1e-15)
+    assert np.array_equal(mc.augment(P, rest=0), mc.augment(P))
