@@ -298,10 +298,14 @@ def main():
                     objects = dict(percentiles(lat_obj), objects=20, accepted=last['g'][0], dof=last['g'][1],
                                    what='orcvio_msckf_update_object_tracks: 20 cars x 12 keypoints x 30 frames, rows evaluated on the '
                                         'device, host buffers in, dx and P+ out')
-                    try:
-                        objects['stage_ms'] = upd.profile_objects()
-                    except Exception:
-                        pass
+                    # per-stage device times of the object update (HIP events between the stages, median of 20 runs)
+                    upd.set_stage_profile(True)
+                    runs = []
+                    for _ in range(20):
+                        call()
+                        runs.append(upd.profile_stages())
+                    upd.set_stage_profile(False)
+                    objects['stage_ms'] = {name: round(float(np.median([r[i][1] for r in runs])), 5) for i, (name, _) in enumerate(runs[0])}
                     upd.upload(win)   # the feature tracks again for what follows
                 except Exception as e:   # never let the side measurement break the metric line
                     objects = dict(error=str(e))

@@ -146,8 +146,11 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * their covariance through the cross terms.  With value k, P / P_out are (LEG + 6N + k)^2 and dx has that length. */
 /* ORCVIO_OPT_EKF_ROWS (default 0): the next uploads may be followed by orcvio_msckf_upload_ekf_rows -- the extra states
  * are then active columns of the compressed block (the rows of the SLAM features reach into them). */
+/* ORCVIO_OPT_STAGE_PROFILE (default 0): record HIP events between the stages of the object update (rows, compression, the
+ * batched factorisation of F, Y, A', the solve, the gate); orcvio_msckf_profile_stages returns the per-stage device times
+ * of the last object update (SURVEY.md 8d "device-only time per stage from hipEvents"). */
 enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
-       ORCVIO_OPT_EKF_ROWS = 5 };
+       ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* EKF-SLAM rows of the hybrid filter (existing SLAM features).  For every SLAM feature the current
@@ -314,6 +317,10 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* resul
  * stream.  names[i] / ms[i] for i < *count (count in: capacity, out: filled). */
 int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_t reps,
                                     const char** names, double* ms, int32_t* count);
+
+/* Per-stage device times of the last object update (ORCVIO_OPT_STAGE_PROFILE must be on): names[i] / ms[i] for
+ * i < *count (count in: capacity, out: filled). */
+int32_t orcvio_msckf_profile_stages(orcvio_msckf_handle* h, const char** names, double* ms, int32_t* count);
 
 /* State correction: replaces OrcVIO::incrementState_IMUCam (src/orcvio.cpp:4468-4567).
  * Pure host arithmetic (15 + 6N small updates); returns 1 if the correction was applied,

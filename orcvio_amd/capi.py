@@ -35,6 +35,7 @@ EXPORTS = [
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
     'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks', 'orcvio_msckf_new_feature_rows', 'orcvio_msckf_augment_state',
+    'orcvio_msckf_profile_stages',
     'orcvio_msckf_comm_unique_id', 'orcvio_msckf_comm_init', 'orcvio_msckf_comm_destroy', 'orcvio_msckf_comm_info',
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
 ]
@@ -721,6 +722,19 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_download')
         return self._finish(out, res, self.F)
+
+    def set_stage_profile(self, on: bool):
+        """ORCVIO_OPT_STAGE_PROFILE: HIP events between the stages of the object update."""
+        self._chk(self.lib.orcvio_msckf_set_option(self.h, 6, int(bool(on))), 'orcvio_msckf_set_option')
+
+    def profile_stages(self):
+        """[(stage, ms)] of the last object update run with the stage profile on."""
+        names = (C.c_char_p * 32)()
+        ms = (C.c_double * 32)()
+        cnt = C.c_int32(32)
+        self.lib.orcvio_msckf_profile_stages.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), _dp, C.POINTER(C.c_int32)]
+        self._chk(self.lib.orcvio_msckf_profile_stages(self.h, names, ms, C.byref(cnt)), 'orcvio_msckf_profile_stages')
+        return [(names[i].decode(), ms[i]) for i in range(cnt.value)]
 
     def profile(self, reps=20, stream=None):
         names = (C.c_char_p * 16)()

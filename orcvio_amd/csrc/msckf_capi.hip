@@ -9,6 +9,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -36,6 +37,8 @@ static thread_local std::string g_last_error;
     } while (0)
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct ObjUse { int t, row0, rows, ncol; size_t off_d, off_i; };   // a usable object track of the current object update
 
 struct orcvio_msckf_handle {
     int device = 0;
@@ -114,10 +117,19 @@ struct orcvio_msckf_handle {
     double *d_Z = nullptr, *d_Pout = nullptr, *d_dx = nullptr;
     double *d_La = nullptr, *d_DinvA = nullptr, *d_W = nullptr, *d_Y = nullptr, *d_KG = nullptr;   // optional outputs
     // object blocks (allocated on first use, grown on demand)
-    double *d_Xaug = nullptr, *d_Gobj = nullptr, *d_RF = nullptr, *d_DinvF = nullptr, *d_Yobj = nullptr, *d_objH = nullptr;
+    double *d_Gobj = nullptr, *d_RF = nullptr, *d_DinvF = nullptr, *d_Yobj = nullptr, *d_objH = nullptr;
     double *d_obj_gamma = nullptr;
     int *d_obj_i = nullptr, *d_obj_accept = nullptr;
-    size_t cap_Xaug = 0, cap_Gobj = 0, cap_RF = 0, cap_Yobj = 0, cap_objH = 0, cap_obj_i = 0;
+    size_t cap_Gobj = 0, cap_RF = 0, cap_Yobj = 0, cap_objH = 0, cap_obj_i = 0;
+    char *h_obj_stage = nullptr, *d_obj_in = nullptr;   // input arena of an object update: pinned mirror + device copy (grown on demand)
+    size_t obj_stage_cap = 0;
+    std::vector<ObjUse> obj_use;        // (objects_local_tracks: per-track records, kept across calls: no allocation per frame)
+    std::vector<int> obj_fnr;           // rows of every frame of the track being staged
+    // per-stage device times of the last object update (orcvio_msckf_profile_stages): events recorded between the stages
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<const char*> prof_names;
+    int prof_n = 0;
     bool objects_mode = false;
     int obj_dof = 0, obj_rows = 0, obj_count = 0;
     double *d_T3 = nullptr, *d_Xobs = nullptr, *d_S = nullptr;
@@ -277,13 +289,16 @@ static void free_all(orcvio_msckf_handle* h) {
     void* ptrs[] = {h->d_in, h->d_outs,
                     h->d_chi2, h->d_Hs, h->d_Gpart, h->d_Ab, h->d_A, h->d_RP,
                     h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_La, h->d_DinvA,
-                    h->d_W, h->d_Y, h->d_KG, h->d_Xaug, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
+                    h->d_W, h->d_Y, h->d_KG, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S,
                     h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
                     h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense, h->d_Rf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_obj_stage) (void)hipHostFree(h->h_obj_stage);
+    if (h->d_obj_in) (void)hipFree(h->d_obj_in);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     for (auto* g : {&h->g_update, &h->g_local, &h->g_finish}) {
@@ -439,6 +454,11 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
     if (option == ORCVIO_OPT_EXTRA_STATES) {
         if (value < 0 || 22 + 6 + value > h->n_max) { g_last_error = "orcvio_msckf_set_option: extra states out of range"; return ORCVIO_ERR_INVALID; }
         h->n_extra = value;   // takes effect with the next upload / update call (part of the launch signature)
+        return ORCVIO_OK;
+    }
+    if (option == ORCVIO_OPT_STAGE_PROFILE) {
+        h->prof_on = value != 0;
+        h->prof_n = 0;
         return ORCVIO_OK;
     }
     g_last_error = "orcvio_msckf_set_option: unknown option";
@@ -1629,72 +1649,115 @@ int32_t orcvio_msckf_gate_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flag
 // onto the left nullspace of its own Hf (SURVEY.md note N3: equal to the reference whenever one object
 // arrives per call); the blocks are stacked, gated jointly with dof = sum(rows - cols) and applied in one
 // update.  Objects with rows <= cols cannot be projected (math_utils.hpp:292) and are skipped.
-// Device scratch of an object update: compact rows [row_clone | row_cols | chunk_ptr] and [Hx6 | Hf (ld no_max) | res],
-// followed by `extra_d` doubles / `extra_i` ints for the callers' own inputs.
-struct ObjScratch {
-    int *d_clone, *d_cols, *d_chunk, *d_extra_i;
-    double *d_hx, *d_hf, *d_res, *d_extra_d;
+// ---- per-stage device times (HIP events between the stages of an update; off unless switched on) -------------------
+static void prof_begin(orcvio_msckf_handle* h, hipStream_t s) {
+    if (!h->prof_on) return;
+    h->prof_n = 0;
+    h->prof_names.clear();
+    if (h->prof_ev.empty()) { h->prof_ev.resize(24); for (auto& e : h->prof_ev) (void)hipEventCreate(&e); }
+    (void)hipEventRecord(h->prof_ev[0], s);
+    h->prof_n = 1;
+}
+static void prof_mark(orcvio_msckf_handle* h, hipStream_t s, const char* name) {
+    if (!h->prof_on || h->prof_n == 0 || h->prof_n >= (int)h->prof_ev.size()) return;
+    (void)hipEventRecord(h->prof_ev[h->prof_n++], s);
+    h->prof_names.push_back(name);
+}
+
+// ---- object update: device scratch and host staging ------------------------------------------------------------------
+// ONE input arena per object update, mirrored in pinned host memory (grown on demand) and copied with one asynchronous
+// copy: [doubles ... | ints ...].  Device-side scratch (row arrays written by k_object_rows_batch, Cd, Sg, Gff, factors)
+// is separate and never crosses PCIe.
+struct ObjPlan {
+    int nobj = 0, rows_tot = 0, no_max = 0, ngroups = 0;
+    int NOP = 0, ldf = 0;
+    // device pointers
+    int *d_ridx = nullptr, *d_rowptr = nullptr, *d_clone = nullptr, *d_cols = nullptr;
+    ObjGroup* d_groups = nullptr;
+    double *d_hx = nullptr, *d_hf = nullptr, *d_res = nullptr;
+    double *d_Cd = nullptr, *d_Sg = nullptr, *d_Gff = nullptr;
 };
-static int objects_scratch(orcvio_msckf_handle* h, int nobj, int rows_tot, int no_max, size_t extra_d, ObjScratch* sc, size_t extra_i = 0) {
-    const int NAP = h->NAP, NOP = round_up(no_max, 16), W = NAP + NOP;
+static int obj_stage_reserve(orcvio_msckf_handle* h, size_t bytes) {
+    if (bytes <= h->obj_stage_cap) return ORCVIO_OK;
+    HIPCHK(hipDeviceSynchronize());
+    if (h->h_obj_stage) (void)hipHostFree(h->h_obj_stage);
+    if (h->d_obj_in) (void)hipFree(h->d_obj_in);
+    h->h_obj_stage = nullptr; h->d_obj_in = nullptr; h->obj_stage_cap = 0;
+    const size_t cap = (bytes * 3 / 2 + 4095) & ~(size_t)4095;
+    HIPCHK(hipHostMalloc(&h->h_obj_stage, cap, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&h->d_obj_in, cap));
+    h->obj_stage_cap = cap;
+    return ORCVIO_OK;
+}
+// device scratch of the compression: row arrays [Hx6 | HfR (ld ldf) | res | row_clone | row_cols] and [Cd | Sg | Gff]
+static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
+    const int NAP = h->NAP, N = h->N;
+    pl->NOP = round_up(pl->no_max, 16);
+    pl->ldf = round_up(pl->no_max + 1, 16);
+    const size_t rows = (size_t)pl->rows_tot, nobj = (size_t)pl->nobj;
     int rc;
-    if ((rc = grow(&h->d_obj_i, &h->cap_obj_i, (size_t)2 * rows_tot + nobj + 1 + extra_i)) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_objH, &h->cap_objH, (size_t)rows_tot * (6 + no_max + 1) + extra_d)) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_Xaug, &h->cap_Xaug, (size_t)rows_tot * W)) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, (size_t)nobj * W * W)) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_RF, &h->cap_RF, (size_t)nobj * (NOP * NOP + 7 * 256))) != ORCVIO_OK) return rc;
-    if ((rc = grow(&h->d_Yobj, &h->cap_Yobj, (size_t)nobj * NOP * NAP)) != ORCVIO_OK) return rc;
-    sc->d_clone = h->d_obj_i;
-    sc->d_cols = h->d_obj_i + rows_tot;
-    sc->d_chunk = h->d_obj_i + 2 * rows_tot;
-    sc->d_extra_i = sc->d_chunk + nobj + 1;
-    sc->d_hx = h->d_objH;
-    sc->d_hf = sc->d_hx + (size_t)rows_tot * 6;
-    sc->d_res = sc->d_hf + (size_t)rows_tot * no_max;
-    sc->d_extra_d = sc->d_res + rows_tot;
+    if ((rc = grow(&h->d_obj_i, &h->cap_obj_i, 2 * rows + 16)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_objH, &h->cap_objH, rows * (6 + pl->ldf + 1) + 16)) != ORCVIO_OK) return rc;
+    const size_t nCd = nobj * pl->NOP * NAP, nSg = nobj * N * 64, nGff = nobj * pl->ldf * pl->ldf;
+    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, nCd + nSg + nGff)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_RF, &h->cap_RF, nobj * ((size_t)pl->NOP * pl->NOP + 7 * 256))) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Yobj, &h->cap_Yobj, nobj * pl->NOP * NAP)) != ORCVIO_OK) return rc;
+    pl->d_clone = h->d_obj_i;
+    pl->d_cols = h->d_obj_i + rows;
+    pl->d_hx = h->d_objH;
+    pl->d_hf = pl->d_hx + rows * 6;
+    pl->d_res = pl->d_hf + rows * pl->ldf;
+    pl->d_Cd = h->d_Gobj;
+    pl->d_Sg = pl->d_Cd + nCd;
+    pl->d_Gff = pl->d_Sg + nSg;
     return ORCVIO_OK;
 }
 
-// From the compact rows in device memory to this rank's block in dst (P already in d_P; forks the Cholesky of P).
-static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, int nobj, int rows_tot, int no_max, const ObjScratch& sc) {
-    const int NA = h->NA, NAP = h->NAP, NOP = round_up(no_max, 16), W = NAP + NOP;
+// From the compact rows in device memory to this rank's block in dst (P already in d_P).  The prior's Cholesky factor is
+// forked to the side stream (joined by objects_finish).
+static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, const ObjPlan& pl) {
+    const int NA = h->NA, NAP = h->NAP, N = h->N, nobj = pl.nobj, NOP = pl.NOP, ldf = pl.ldf, no_max = pl.no_max;
     double* d_RF = h->d_RF;
     double* d_DinvF = h->d_RF + (size_t)nobj * NOP * NOP;
+    // zero: Y (padded rows), R_F (strictly-lower tiles), C (clones an object does not see), the clone tiles
     HIPCHK(hipMemsetAsync(h->d_Yobj, 0, sizeof(double) * (size_t)nobj * NOP * NAP, s));
     HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
+    HIPCHK(hipMemsetAsync(pl.d_Cd, 0, sizeof(double) * ((size_t)nobj * NOP * NAP + (size_t)nobj * N * 64), s));   // Cd and Sg are adjacent
     int rc = launch_prior_fork(h, s);   // Cholesky of P on the side stream
     if (rc != ORCVIO_OK) return rc;
-    // augmented stack and its per-object Gram
-    hipLaunchKernelGGL(k_obj_build, dim3(rows_tot), dim3(256), 0, s, sc.d_clone, sc.d_hx, sc.d_hf, sc.d_res, sc.d_cols, rows_tot, no_max,
-                       h->flags.leg_dim, NA, NAP, W, h->d_Xaug);
+    prof_mark(h, s, "rows+copies");
+    hipLaunchKernelGGL(k_obj_cross, dim3((pl.ngroups + 3) / 4), dim3(256), 0, s, pl.d_groups, pl.ngroups, pl.d_ridx, pl.d_hx, pl.d_hf, ldf,
+                       no_max, h->flags.leg_dim - 15, NAP, NOP, N, pl.d_Cd, pl.d_Sg);
     {
-        const int nbw = W / 16, ntiles = nbw * (nbw + 1) / 2;
-        // (one wavefront per (tile, object): this Gram re-reads both operand column blocks for every tile and is bound by
-        // that L2 traffic, not by latency -- 16 wavefronts per tile, as in k_gram_pair, measured 50 us against 45)
-        hipLaunchKernelGGL(k_gram, dim3((ntiles + 3) / 4, nobj), dim3(256), 0, s, h->d_Xaug, rows_tot, W, 0, h->d_Gobj, sc.d_chunk);
+        const int nbf = ldf / 16;
+        hipLaunchKernelGGL(k_obj_gram_ff, dim3(nbf * (nbf + 1) / 2, nobj), dim3(1024), 0, s, pl.d_hf, ldf, pl.d_rowptr, pl.d_Gff);
     }
-    // F_o = Hf^T Hf (lower tiles of the bottom-right block) -> R_F ; Y_o = L_F^-1 C_o
+    prof_mark(h, s, "k_obj_cross+k_obj_gram_ff");
+    // F_o = Hf^T Hf (lower tiles of Gff) -> R_F ; Y_o = L_F^-1 C_o, C_o = [Cd_o | Hf^T r]
     {
         const int nbf = NOP / 16, need = potrf_slots_needed(nbf);
         HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));   // the batched factorisation ADDS its pivot counters
-        const double* F0 = h->d_Gobj + (size_t)NAP * W + NAP;
         const double tolF = (double)no_max * 2.220446049250313e-16;
         if (need <= 4)
-            hipLaunchKernelGGL(k_potrf_reg<4>, dim3(nobj), dim3(512), 0, s, F0, W, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
-                               (unsigned long long*)nullptr, (size_t)W * W, (size_t)NOP * NOP, (size_t)7 * 256, 1);
+            hipLaunchKernelGGL(k_potrf_reg<4>, dim3(nobj), dim3(512), 0, s, pl.d_Gff, ldf, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
+                               (unsigned long long*)nullptr, (size_t)ldf * ldf, (size_t)NOP * NOP, (size_t)7 * 256, 1);
         else
-            hipLaunchKernelGGL(k_potrf_reg<8>, dim3(nobj), dim3(512), 0, s, F0, W, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
-                               (unsigned long long*)nullptr, (size_t)W * W, (size_t)NOP * NOP, (size_t)7 * 256, 1);
+            hipLaunchKernelGGL(k_potrf_reg<8>, dim3(nobj), dim3(512), 0, s, pl.d_Gff, ldf, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
+                               (unsigned long long*)nullptr, (size_t)ldf * ldf, (size_t)NOP * NOP, (size_t)7 * 256, 1);
+        prof_mark(h, s, "k_potrf_reg(F) batched");
         const int nwave = (NA + 1 + 15) / 16;
         hipLaunchKernelGGL(k_trsm_lds, dim3((nwave + 3) / 4, nobj), dim3(256), 0, s, d_RF, NOP, d_DinvF, no_max,
-                           h->d_Gobj + (size_t)NAP * W, (long)W, 1L, NA + 1, (const double*)nullptr, 0L, h->d_Yobj, NAP,
-                           (size_t)NOP * NOP, (size_t)7 * 256, (size_t)W * W, (size_t)NOP * NAP);
+                           pl.d_Cd, (long)NAP, 1L, NA, pl.d_Gff + (size_t)no_max * ldf, 1L, h->d_Yobj, NAP,
+                           (size_t)NOP * NOP, (size_t)7 * 256, (size_t)NOP * NAP, (size_t)NOP * NAP, (size_t)ldf * ldf);
+        prof_mark(h, s, "k_trsm_lds(Y) batched");
     }
     // A' = sum_o B_o - Y^T Y  (Y = all Y_o stacked; padded rows are zero)
-    hipLaunchKernelGGL(k_obj_sum_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, h->d_Gobj, nobj, W, NAP, h->d_Ab);
+    hipLaunchKernelGGL(k_obj_assemble_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, pl.d_Sg, nobj, N, pl.d_Gff, ldf, no_max,
+                       h->flags.leg_dim - 15, NA, NAP, h->d_Ab);
     hipLaunchKernelGGL(k_gemm, dim3((NAP / 16) * (NAP / 16)), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
                        NAP, NAP, nobj * NOP, -1.0, 0.0, 0, dst, (long)NAP, 1L, h->d_Ab);
     HIPCHK(hipGetLastError());
+    prof_mark(h, s, "k_obj_assemble_B+k_gemm(A')");
     return ORCVIO_OK;
 }
 
@@ -1704,6 +1767,7 @@ static int objects_prior(orcvio_msckf_handle* h, hipStream_t s, const double* P,
     const int n = h->n;
     if (!P && h->res_n != n) { g_last_error = std::string(who) + ": P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipStreamSynchronize(h->stream));   // the pinned staging of the previous call is free again
+    if (s != h->stream) HIPCHK(hipStreamSynchronize(s));
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     layout_inputs(h, h->N, 0, 0, false, P != nullptr, n);
     layout_outputs(h, n, 1);
@@ -1714,16 +1778,10 @@ static int objects_prior(orcvio_msckf_handle* h, hipStream_t s, const double* P,
     return ORCVIO_OK;
 }
 
-// Local part of an object update: this rank's objects -> its compressed block [A' b'; b'^T c'] (NAP x NAP) in d_dst
-// (the handle's own block if NULL), Cholesky of P forked on the side stream.
-int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
-                                   const orcvio_msckf_object_rows* objs, int32_t n_objects, const double* P, double* d_dst,
-                                   int32_t* dof_out, void* stream) {
-    if (!h || !flags || n_objects < 0 || (n_objects > 0 && !objs)) { g_last_error = "objects_local: null argument"; return ORCVIO_ERR_INVALID; }
-    if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = "objects_local: leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
-    if (n_clones < 1 || n_clones > h->maxN) { g_last_error = "objects_local: window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
-    HIPCHK(hipSetDevice(h->device));
-    const int N = n_clones;
+// window-dependent sizes of an object update (no tracks)
+static int objects_problem(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int N, const char* who) {
+    if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = std::string(who) + ": leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
+    if (N < 1 || N > h->maxN) { g_last_error = std::string(who) + ": window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
     h->flags = *flags;
     h->N = N; h->F = 0; h->nobs = 0;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
@@ -1737,10 +1795,22 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
     h->m_tot = 0; h->Mmax = 2; h->chunks = 1; h->rows_per_chunk = 8;
     h->h_row_ptr.assign(1, 0);
-    const int n = h->n, NA = h->NA, NAP = h->NAP;
+    return ORCVIO_OK;
+}
+
+// Local part of an object update: this rank's objects -> its compressed block [A' b'; b'^T c'] (NAP x NAP) in d_dst
+// (the handle's own block if NULL), Cholesky of P forked on the side stream.
+int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
+                                   const orcvio_msckf_object_rows* objs, int32_t n_objects, const double* P, double* d_dst,
+                                   int32_t* dof_out, void* stream) {
+    if (!h || !flags || n_objects < 0 || (n_objects > 0 && !objs)) { g_last_error = "objects_local: null argument"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    { const int rp = objects_problem(h, flags, n_clones, "objects_local"); if (rp != ORCVIO_OK) return rp; }
+    const int N = n_clones, NAP = h->NAP;
     // usable objects, row offsets, widest object state
-    std::vector<int> use, chunk_ptr(1, 0);
-    int no_max = 0, rows_tot = 0, dof = 0;
+    std::vector<int> use;
+    ObjPlan pl;
+    int dof = 0;
     for (int o = 0; o < n_objects; ++o) {
         const orcvio_msckf_object_rows& ob = objs[o];
         if (ob.n_rows < 0 || ob.n_obj_cols < 1 || ob.n_obj_cols > 112) { g_last_error = "objects_local: bad block shape (object state columns must be 1..112)"; return ORCVIO_ERR_INVALID; }
@@ -1749,56 +1819,68 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
         for (int r = 0; r < ob.n_rows; ++r)
             if (ob.row_clone[r] < 0 || ob.row_clone[r] >= N) { g_last_error = "objects_local: row_clone out of range"; return ORCVIO_ERR_INVALID; }
         use.push_back(o);
-        rows_tot += ob.n_rows;
-        chunk_ptr.push_back(rows_tot);
+        pl.rows_tot += ob.n_rows;
         dof += ob.n_rows - ob.n_obj_cols;
-        if (ob.n_obj_cols > no_max) no_max = ob.n_obj_cols;
+        if (ob.n_obj_cols > pl.no_max) pl.no_max = ob.n_obj_cols;
     }
-    const int nobj = (int)use.size();
+    pl.nobj = (int)use.size();
     hipStream_t s = pick_stream(h, stream);
     h->last_stream = s;
     double* dst = d_dst ? d_dst : h->d_Ab;
     if (dof_out) *dof_out = dof;
+    prof_begin(h, s);
     { const int rp = objects_prior(h, s, P, "objects_local"); if (rp != ORCVIO_OK) return rp; }
     h->uploaded = true;
     h->objects_mode = true;
-    h->obj_dof = dof; h->obj_rows = rows_tot; h->obj_count = nobj;
-    int rc = ORCVIO_OK;
+    h->obj_dof = dof; h->obj_rows = pl.rows_tot; h->obj_count = pl.nobj;
     if (!h->d_obj_accept) { HIPCHK(hipMalloc(&h->d_obj_accept, sizeof(int) * 4)); HIPCHK(hipMalloc(&h->d_obj_gamma, sizeof(double) * 4)); }
-    if (nobj == 0) {   // nothing usable on this rank: a zero block
+    if (pl.nobj == 0) {   // nothing usable on this rank: a zero block
         HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)NAP * NAP, s));
         return launch_prior_fork(h, s);
     }
-    const int NOP = round_up(no_max, 16), W = NAP + NOP;
-    // host staging of the compact rows (one contiguous upload per array)
-    std::vector<int> h_clone(rows_tot), h_cols(rows_tot);
-    std::vector<double> h_hx((size_t)rows_tot * 6), h_hf((size_t)rows_tot * no_max, 0.0), h_res(rows_tot);
-    {
-        int r0 = 0;
-        for (int o : use) {
-            const orcvio_msckf_object_rows& ob = objs[o];
-            for (int r = 0; r < ob.n_rows; ++r) {
-                h_clone[r0 + r] = ob.row_clone[r];
-                h_cols[r0 + r] = ob.n_obj_cols;
-                std::memcpy(&h_hx[(size_t)(r0 + r) * 6], ob.Hx6 + (size_t)r * 6, 6 * sizeof(double));
-                std::memcpy(&h_hf[(size_t)(r0 + r) * no_max], ob.Hf + (size_t)r * ob.n_obj_cols, ob.n_obj_cols * sizeof(double));
-                h_res[r0 + r] = ob.res[r];
-            }
-            r0 += ob.n_rows;
-        }
-    }
-    ObjScratch sc;
-    if ((rc = objects_scratch(h, nobj, rows_tot, no_max, 0, &sc)) != ORCVIO_OK) return rc;
-    HIPCHK(hipMemcpyAsync(sc.d_clone, h_clone.data(), sizeof(int) * rows_tot, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sc.d_cols, h_cols.data(), sizeof(int) * rows_tot, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sc.d_chunk, chunk_ptr.data(), sizeof(int) * (nobj + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sc.d_hx, h_hx.data(), sizeof(double) * h_hx.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sc.d_hf, h_hf.data(), sizeof(double) * h_hf.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sc.d_res, h_res.data(), sizeof(double) * rows_tot, hipMemcpyHostToDevice, s));
-    rc = objects_pipeline(h, s, dst, nobj, rows_tot, no_max, sc);
+    int rc = objects_scratch(h, &pl);
     if (rc != ORCVIO_OK) return rc;
-    HIPCHK(hipStreamSynchronize(s));   // h_clone ... h_res are locals: the copies must have left them
-    return ORCVIO_OK;
+    // staging arena: [Hx6 rows x 6 | HfR rows x ldf] doubles, then [ridx rows | rowptr nobj+1 | groups 4 x <= nobj N] ints
+    const size_t rows = (size_t)pl.rows_tot, ldf = (size_t)pl.ldf;
+    const size_t nd = rows * 6 + rows * ldf, ni = rows + (size_t)pl.nobj + 1 + (size_t)4 * pl.nobj * N;
+    if ((rc = obj_stage_reserve(h, nd * 8 + ni * 4)) != ORCVIO_OK) return rc;
+    double* hd = reinterpret_cast<double*>(h->h_obj_stage);
+    int* hi = reinterpret_cast<int*>(h->h_obj_stage + nd * 8);
+    double* hx = hd;
+    double* hf = hd + rows * 6;
+    int* ridx = hi;
+    int* rowptr = hi + rows;
+    ObjGroup* groups = reinterpret_cast<ObjGroup*>(hi + rows + pl.nobj + 1);
+    std::memset(hf, 0, sizeof(double) * rows * ldf);
+    int r0 = 0, ng = 0;
+    rowptr[0] = 0;
+    for (size_t ui = 0; ui < use.size(); ++ui) {
+        const orcvio_msckf_object_rows& ob = objs[use[ui]];
+        int cnt[ORCVIO_MAX_CLONES + 1] = {0};
+        for (int r = 0; r < ob.n_rows; ++r) {
+            std::memcpy(hx + (size_t)(r0 + r) * 6, ob.Hx6 + (size_t)r * 6, 6 * sizeof(double));
+            double* row = hf + (size_t)(r0 + r) * ldf;
+            std::memcpy(row, ob.Hf + (size_t)r * ob.n_obj_cols, ob.n_obj_cols * sizeof(double));
+            row[pl.no_max] = ob.res[r];
+            cnt[ob.row_clone[r] + 1]++;
+        }
+        for (int c = 0; c < N; ++c) cnt[c + 1] += cnt[c];
+        for (int c = 0; c < N; ++c)
+            if (cnt[c + 1] > cnt[c]) groups[ng++] = ObjGroup{r0 + cnt[c], r0 + cnt[c + 1], c, (int)ui};
+        int fill[ORCVIO_MAX_CLONES + 1];
+        std::memcpy(fill, cnt, sizeof(int) * (N + 1));
+        for (int r = 0; r < ob.n_rows; ++r) ridx[r0 + fill[ob.row_clone[r]]++] = r0 + r;   // rows grouped by clone (stable)
+        r0 += ob.n_rows;
+        rowptr[ui + 1] = r0;
+    }
+    pl.ngroups = ng;
+    // device views of the arena
+    double* dd = reinterpret_cast<double*>(h->d_obj_in);
+    int* di = reinterpret_cast<int*>(h->d_obj_in + nd * 8);
+    pl.d_hx = dd; pl.d_hf = dd + rows * 6;
+    pl.d_ridx = di; pl.d_rowptr = di + rows; pl.d_groups = reinterpret_cast<ObjGroup*>(di + rows + pl.nobj + 1);
+    HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (rows + pl.nobj + 1 + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
+    return objects_pipeline(h, s, dst, pl);
 }
 
 // The same from object TRACKS (state at the LM optimum + observations): the residual rows and Jacobians of SURVEY 8a rows
@@ -1808,115 +1890,144 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
                                           int32_t n_clones, const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
                                           double* d_dst, int32_t* dof_out, void* stream) {
     if (!h || !flags || !fl || n_tracks < 0 || (n_tracks > 0 && !tracks)) { g_last_error = "objects_local_tracks: null argument"; return ORCVIO_ERR_INVALID; }
-    if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = "objects_local_tracks: leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
-    if (n_clones < 1 || n_clones > h->maxN) { g_last_error = "objects_local_tracks: window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
-    const int N = n_clones;
-    h->flags = *flags;
-    h->N = N; h->F = 0; h->nobs = 0;
-    h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
-    h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
-    h->ekf_F = 0; h->dense_rows = 0;
-    if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
-    h->NAP = round_up(h->NA + 1, 16);
-    h->NP = round_up(h->n, 16);
-    h->ldz = round_up(h->n + 1, 16);
-    h->reg_path = (h->NP / 16) <= 14;
-    { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
-    h->m_tot = 0; h->Mmax = 2; h->chunks = 1; h->rows_per_chunk = 8;
-    h->h_row_ptr.assign(1, 0);
-    const int n = h->n, NAP = h->NAP;
-    struct Use { int t, row0, rows, ncol; size_t off_d, off_i; };
-    std::vector<Use> use;
-    std::vector<int> chunk_ptr(1, 0);
-    std::vector<double> hin;
-    std::vector<int> hi;
-    int rows_tot = 0, dof = 0, no_max = 0;
+    { const int rp = objects_problem(h, flags, n_clones, "objects_local_tracks"); if (rp != ORCVIO_OK) return rp; }
+    const int N = n_clones, NAP = h->NAP;
+    typedef ObjUse Use;
+    std::vector<Use>& use = h->obj_use;
+    use.clear();
+    ObjPlan pl;
+    int dof = 0, Fmax = 1;
+    size_t nd = 0, ni = 0;   // staged doubles / ints
+    // pass 1: which tracks are usable, sizes
     for (int t = 0; t < n_tracks; ++t) {
         const orcvio_object_track& ob = tracks[t];
         if (!ob.wTo || !ob.shape || !ob.kps || !ob.frame_wTc || !ob.frame_zs || !ob.frame_bbox || !ob.frame_clone) { g_last_error = "objects_local_tracks: null track arrays"; return ORCVIO_ERR_INVALID; }
         const int K = ob.n_keypoints, F = ob.n_frames, ncol = 9 + 3 * K;
         if (K < 1 || K > 34 || F < 1) { g_last_error = "objects_local_tracks: 1..34 keypoints (object state <= 112 columns), >= 1 frame"; return ORCVIO_ERR_INVALID; }
-        std::vector<int> row0(F, 0);
         int rows = 0;
         for (int f = 0; f < F; ++f) {
             if (ob.frame_clone[f] >= N) { g_last_error = "objects_local_tracks: frame_clone out of the window"; return ORCVIO_ERR_INVALID; }
             if (ob.frame_clone[f] < 0) continue;
             int nv = 0;
-            for (int k = 0; k < K; ++k) {
-                const double a = ob.frame_zs[((size_t)f * K + k) * 2], b = ob.frame_zs[((size_t)f * K + k) * 2 + 1];
-                if (std::isfinite(a) && std::isfinite(b)) ++nv;   // row finite test, ObjectLM.cpp:171-198
-            }
-            row0[f] = rows_tot + rows;
+            const double* zs = ob.frame_zs + (size_t)f * K * 2;
+            for (int k = 0; k < K; ++k)
+                if (std::isfinite(zs[2 * k]) && std::isfinite(zs[2 * k + 1])) ++nv;   // row finite test, ObjectLM.cpp:171-198
             rows += 2 * nv + 4;
         }
         if (rows <= ncol) continue;   // nullspace_project_inplace_svd returns false
-        Use u{t, rows_tot, rows, ncol, hin.size(), hi.size()};
-        use.push_back(u);
-        hin.insert(hin.end(), ob.wTo, ob.wTo + 16);
-        hin.insert(hin.end(), ob.shape, ob.shape + 3);
-        hin.insert(hin.end(), ob.kps, ob.kps + (size_t)3 * K);
-        hin.insert(hin.end(), ob.frame_wTc, ob.frame_wTc + (size_t)16 * F);
-        hin.insert(hin.end(), ob.frame_zs, ob.frame_zs + (size_t)2 * K * F);
-        hin.insert(hin.end(), ob.frame_bbox, ob.frame_bbox + (size_t)4 * F);
-        hi.insert(hi.end(), ob.frame_clone, ob.frame_clone + F);
-        hi.insert(hi.end(), row0.begin(), row0.end());
-        rows_tot += rows;
-        chunk_ptr.push_back(rows_tot);
+        use.push_back(Use{t, pl.rows_tot, rows, ncol, nd, ni});
+        nd += 16 + 3 + (size_t)3 * K + (size_t)F * (16 + 2 * K + 4);
+        ni += (size_t)2 * F;
+        pl.rows_tot += rows;
         dof += rows - ncol;
-        if (ncol > no_max) no_max = ncol;
+        if (ncol > pl.no_max) pl.no_max = ncol;
+        if (F > Fmax) Fmax = F;
     }
-    const int nobj = (int)use.size();
+    pl.nobj = (int)use.size();
     hipStream_t s = pick_stream(h, stream);
     h->last_stream = s;
     double* dst = d_dst ? d_dst : h->d_Ab;
     if (dof_out) *dof_out = dof;
+    prof_begin(h, s);
     { const int rp = objects_prior(h, s, P, "objects_local_tracks"); if (rp != ORCVIO_OK) return rp; }
     h->uploaded = true;
     h->objects_mode = true;
-    h->obj_dof = dof; h->obj_rows = rows_tot; h->obj_count = nobj;
+    h->obj_dof = dof; h->obj_rows = pl.rows_tot; h->obj_count = pl.nobj;
     if (!h->d_obj_accept) { HIPCHK(hipMalloc(&h->d_obj_accept, sizeof(int) * 4)); HIPCHK(hipMalloc(&h->d_obj_gamma, sizeof(double) * 4)); }
-    if (nobj == 0) {
+    if (pl.nobj == 0) {
         HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)NAP * NAP, s));
         return launch_prior_fork(h, s);
     }
-    ObjScratch sc;
-    // the per-object kernel arguments ride at the end of the same staging array: ONE k_object_rows_batch launch evaluates
-    // the rows of every object (a launch per object was 20 x 9 us of the 0.57 ms update of config 3)
+    int rc = objects_scratch(h, &pl);
+    if (rc != ORCVIO_OK) return rc;
+    // staging arena: [track data (doubles) | kernel arguments (doubles) | frame_clone, frame_row0 per track | ridx | rowptr | groups]
     static_assert(sizeof(ObjEvalArgs) % sizeof(double) == 0, "ObjEvalArgs is copied as doubles");
     const size_t arg_dbl = sizeof(ObjEvalArgs) / sizeof(double);
-    const size_t args_off = hin.size();
-    hin.resize(args_off + arg_dbl * use.size());
-    int rc = objects_scratch(h, nobj, rows_tot, no_max, hin.size(), &sc, hi.size());
-    if (rc != ORCVIO_OK) return rc;
-    int Fmax = 1;
+    const size_t args_off = nd;
+    nd += arg_dbl * use.size();
+    const size_t rows = (size_t)pl.rows_tot;
+    const size_t ni_tot = ni + rows + (size_t)pl.nobj + 1 + (size_t)4 * pl.nobj * N;
+    if ((rc = obj_stage_reserve(h, nd * 8 + ni_tot * 4)) != ORCVIO_OK) return rc;
+    double* hd = reinterpret_cast<double*>(h->h_obj_stage);
+    int* hi = reinterpret_cast<int*>(h->h_obj_stage + nd * 8);
+    double* dd = reinterpret_cast<double*>(h->d_obj_in);
+    int* di = reinterpret_cast<int*>(h->d_obj_in + nd * 8);
+    int* ridx = hi + ni;
+    int* rowptr = ridx + rows;
+    ObjGroup* groups = reinterpret_cast<ObjGroup*>(rowptr + pl.nobj + 1);
+    int ng = 0;
+    rowptr[0] = 0;
     for (size_t ui = 0; ui < use.size(); ++ui) {
         const Use& u = use[ui];
         const orcvio_object_track& ob = tracks[u.t];
         const int K = ob.n_keypoints, F = ob.n_frames;
-        if (F > Fmax) Fmax = F;
+        double* q = hd + u.off_d;
+        std::memcpy(q, ob.wTo, 16 * 8); q += 16;
+        std::memcpy(q, ob.shape, 3 * 8); q += 3;
+        std::memcpy(q, ob.kps, (size_t)3 * K * 8); q += 3 * K;
+        std::memcpy(q, ob.frame_wTc, (size_t)16 * F * 8); q += (size_t)16 * F;
+        std::memcpy(q, ob.frame_zs, (size_t)2 * K * F * 8); q += (size_t)2 * K * F;
+        std::memcpy(q, ob.frame_bbox, (size_t)4 * F * 8);
+        int* fc = hi + u.off_i;
+        int* fr0 = fc + F;
+        // rows of the frames in frame order (the reference's interleaved layout); groups by clone for the compression
+        int first[ORCVIO_MAX_CLONES], count[ORCVIO_MAX_CLONES];
+        for (int c = 0; c < N; ++c) { first[c] = -1; count[c] = 0; }
+        int rr = u.row0;
+        bool contiguous = true;   // every clone's rows are one contiguous run (frames map to distinct clones)
+        std::vector<int>& fnr = h->obj_fnr;
+        fnr.assign(F, 0);
+        for (int f = 0; f < F; ++f) {
+            fc[f] = ob.frame_clone[f];
+            fr0[f] = 0;
+            if (fc[f] < 0) continue;
+            int nv = 0;
+            const double* zs = ob.frame_zs + (size_t)f * K * 2;
+            for (int k = 0; k < K; ++k)
+                if (std::isfinite(zs[2 * k]) && std::isfinite(zs[2 * k + 1])) ++nv;
+            fr0[f] = rr;
+            const int c = fc[f], nr = 2 * nv + 4;
+            fnr[f] = nr;
+            if (first[c] < 0) first[c] = rr; else if (first[c] + count[c] != rr) contiguous = false;
+            count[c] += nr;
+            rr += nr;
+        }
+        if (contiguous) {
+            for (int r = u.row0; r < rr; ++r) ridx[r] = r;
+            for (int c = 0; c < N; ++c)
+                if (count[c] > 0) groups[ng++] = ObjGroup{first[c], first[c] + count[c], c, (int)ui};
+        } else {   // two frames of the object share a clone: group the rows through the index list
+            int pos = u.row0;
+            for (int c = 0; c < N; ++c) {
+                if (count[c] == 0) continue;
+                const int g0 = pos;
+                for (int f = 0; f < F; ++f)
+                    if (fc[f] == c)
+                        for (int r = 0; r < fnr[f]; ++r) ridx[pos++] = fr0[f] + r;
+                groups[ng++] = ObjGroup{g0, pos, c, (int)ui};
+            }
+        }
+        rowptr[ui + 1] = rr;
         ObjEvalArgs a;
-        a.wTo = sc.d_extra_d + u.off_d; a.shape = a.wTo + 16; a.kps = a.shape + 3; a.frame_wTc = a.kps + 3 * K;
+        a.wTo = dd + u.off_d; a.shape = a.wTo + 16; a.kps = a.shape + 3; a.frame_wTc = a.kps + 3 * K;
         a.frame_zs = a.frame_wTc + (size_t)16 * F; a.frame_bbox = a.frame_zs + (size_t)2 * K * F;
-        a.frame_clone = sc.d_extra_i + u.off_i; a.frame_row0 = a.frame_clone + F;
-        a.K = K; a.F = F; a.ncol = u.ncol; a.ldhf = no_max; a.row_cols = sc.d_cols;
+        a.frame_clone = di + u.off_i; a.frame_row0 = a.frame_clone + F;
+        a.K = K; a.F = F; a.ncol = u.ncol; a.ldhf = pl.ldf; a.rcol = pl.no_max; a.row_cols = pl.d_cols;
         a.obj_left = fl->use_left_perturbation; a.new_bbox = fl->use_new_bbox_residual; a.vio_left = fl->vio_use_left_perturbation;
         a.fix_D = fl->fix_dcampose_dimupose_to_identity;
         std::memcpy(a.R_b2c, fl->R_b2c, sizeof(a.R_b2c));
         std::memcpy(a.t_c_b, fl->t_c_b, sizeof(a.t_c_b));
-        a.Hx6 = sc.d_hx; a.Hf = sc.d_hf; a.res = sc.d_res; a.row_clone = sc.d_clone;
-        std::memcpy(hin.data() + args_off + arg_dbl * ui, &a, sizeof(a));
+        a.Hx6 = pl.d_hx; a.Hf = pl.d_hf; a.res = pl.d_res; a.row_clone = pl.d_clone;
+        std::memcpy(hd + args_off + arg_dbl * ui, &a, sizeof(a));
     }
-    HIPCHK(hipMemcpyAsync(sc.d_extra_d, hin.data(), sizeof(double) * hin.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sc.d_extra_i, hi.data(), sizeof(int) * hi.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(sc.d_chunk, chunk_ptr.data(), sizeof(int) * (nobj + 1), hipMemcpyHostToDevice, s));
+    pl.ngroups = ng;
+    pl.d_ridx = di + ni; pl.d_rowptr = pl.d_ridx + rows; pl.d_groups = reinterpret_cast<ObjGroup*>(pl.d_rowptr + pl.nobj + 1);
+    HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (ni + rows + pl.nobj + 1 + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_object_rows_batch, dim3(Fmax, (unsigned)use.size()), dim3(64), 0, s,
-                       reinterpret_cast<const ObjEvalArgs*>(sc.d_extra_d + args_off));
+                       reinterpret_cast<const ObjEvalArgs*>(dd + args_off));
     HIPCHK(hipGetLastError());
-    rc = objects_pipeline(h, s, dst, nobj, rows_tot, no_max, sc);
-    if (rc != ORCVIO_OK) return rc;
-    HIPCHK(hipStreamSynchronize(s));   // hin / hi / chunk_ptr are locals
-    return ORCVIO_OK;
+    return objects_pipeline(h, s, dst, pl);   // (no synchronisation: everything staged lives in the handle's pinned arena)
 }
 
 // Second part: rank-ordered sum of the gathered blocks, replicated solve, joint chi-square gate with the TOTAL degrees
@@ -1933,15 +2044,19 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
     h->A_deferred = false;
     int rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);
     if (rc != ORCVIO_OK) return rc;
+    prof_mark(h, s, "k_gram_reduce");
     // Kalman solve in square-root form, gate, gated write-back
     HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
+    prof_mark(h, s, "join chol(P) (side stream)");
     for (int st = ST_FORM_U; st <= ST_TRSM && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
     if (rc != ORCVIO_OK) return rc;
+    prof_mark(h, s, "k_gemm(U)+k_gemm(M)+k_potrf_solve(M)");
     // table value below 500 dof, on the fly above (:1962-1968); dof 0 (no usable object anywhere) can never pass
     const double thr = dof_total > 0 ? orcvio_msckf_chi2_quantile(dof_total, h->flags.chi2_prob) : -1.0;
     hipLaunchKernelGGL(k_obj_gate, dim3(1), dim3(64), 0, s, h->d_A, NAP, NA, h->d_Z, h->ldz, n, sigma2, thr, h->d_obj_gamma, h->d_obj_accept);
     HIPCHK(hipGetLastError());
     rc = launch_solve_stage(h, s, ST_FINISH);
+    prof_mark(h, s, "k_obj_gate+k_finish_sqrt");
     if (rc == ORCVIO_OK) h->ran = true;
     return rc;
 }
@@ -2085,7 +2200,7 @@ int32_t orcvio_msckf_object_rows_eval(orcvio_msckf_handle* h, const orcvio_objec
     a.wTo = h->d_objH; a.shape = a.wTo + 16; a.kps = a.shape + 3; a.frame_wTc = a.kps + 3 * K;
     a.frame_zs = a.frame_wTc + (size_t)16 * F; a.frame_bbox = a.frame_zs + (size_t)2 * K * F;
     a.frame_clone = h->d_obj_i; a.frame_row0 = h->d_obj_i + F;
-    a.K = K; a.F = F; a.ncol = ncol; a.ldhf = ncol; a.row_cols = nullptr;
+    a.K = K; a.F = F; a.ncol = ncol; a.ldhf = ncol; a.rcol = -1; a.row_cols = nullptr;
     a.obj_left = fl->use_left_perturbation; a.new_bbox = fl->use_new_bbox_residual; a.vio_left = fl->vio_use_left_perturbation;
     a.fix_D = fl->fix_dcampose_dimupose_to_identity;
     std::memcpy(a.R_b2c, fl->R_b2c, sizeof(a.R_b2c));
@@ -2267,6 +2382,22 @@ int32_t orcvio_msckf_update_object_tracks_sharded(orcvio_msckf_handle* h, const 
     rc = orcvio_msckf_objects_download(h, res);
     h->objects_mode = false;
     return rc;
+}
+
+int32_t orcvio_msckf_profile_stages(orcvio_msckf_handle* h, const char** names, double* ms, int32_t* count) {
+    if (!h || !names || !ms || !count) { g_last_error = "profile_stages: null argument"; return ORCVIO_ERR_INVALID; }
+    const int ns = h->prof_n > 0 ? h->prof_n - 1 : 0;
+    if (*count < ns) { g_last_error = "profile_stages: output arrays too small"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    if (ns > 0) HIPCHK(hipEventSynchronize(h->prof_ev[ns]));
+    for (int i = 0; i < ns; ++i) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, h->prof_ev[i], h->prof_ev[i + 1]));
+        ms[i] = t;
+        names[i] = h->prof_names[i];
+    }
+    *count = ns;
+    return ORCVIO_OK;
 }
 
 // ---- per-kernel profile -------------------------------------------------------------------------

@@ -20,7 +20,7 @@
 //   k_potrf_reg    register-resident single-workgroup Cholesky; k_potrf_solve: the same + the triangular solve
 //                  in one launch; k_potrf (LDS panels) and k_trsm_rl / k_trsm_lds for large windows and batches
 //   k_gemm, k_finish_sqrt   split-K MFMA products of the Kalman solve (:1682-1753)
-//   k_obj_*        object blocks (:2154-2193)
+//   k_obj_*        object blocks (:2154-2193): per-(object, clone) cross products + one compact Gram per object
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -2050,9 +2050,11 @@ __global__ __launch_bounds__(64) void k_trsm_rl(const double* __restrict__ L, lo
 __global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, int ldr, const double* __restrict__ Dinv, int nn,
                                                   const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
                                                   const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
-                                                  size_t strideR = 0, size_t strideD = 0, size_t strideB = 0, size_t strideZ = 0) {
+                                                  size_t strideR = 0, size_t strideD = 0, size_t strideB = 0, size_t strideZ = 0,
+                                                  size_t strideBx = 0) {
     __shared__ __attribute__((aligned(16))) double sL[2][16][TRSM_LDP];
     // batched use: blockIdx.y selects the system
+    if (bx) bx += (size_t)blockIdx.y * strideBx;
     R += (size_t)blockIdx.y * strideR;
     Dinv += (size_t)blockIdx.y * strideD;
     B1 += (size_t)blockIdx.y * strideB;
@@ -2297,37 +2299,102 @@ __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ 
 // ---------------------------------------------------------------------------------------
 // Object blocks (reference OrcVIO::removeLostObjects, src/orcvio.cpp:2154-2193)
 // ---------------------------------------------------------------------------------------
-// Every object row touches one clone (6 non-zeros of Hx) and the object's own state columns Hf.
-// k_obj_build writes the augmented stack  Xaug[row] = [Hx scattered | res | 0-pad (NAP) | Hf | 0-pad],
-// width W = NAP + NOP.  Its Gram per object holds  B = X^T X, C = Hf^T X, F = Hf^T Hf, and the
-// left-nullspace projection of math_utils.hpp:287-312 is the Schur complement  A' = B - C^T F^-1 C
-// (any orthonormal basis of the left nullspace of Hf gives the same A'), formed with the Cholesky
-// factor of F:  Y = L_F^-1 C,  A' = B - Y^T Y.
-__global__ __launch_bounds__(256) void k_obj_build(const int* __restrict__ row_clone, const double* __restrict__ Hx6,
-                                                   const double* __restrict__ Hf, const double* __restrict__ res,
-                                                   const int* __restrict__ row_obj_cols, int rows, int no_max, int leg, int NA,
-                                                   int NAP, int W, double* __restrict__ Xaug) {
-    const int row = blockIdx.x;
-    if (row >= rows) return;
-    const int cb = leg - 15 + 6 * row_clone[row];
-    const int no = row_obj_cols[row];
-    for (int c = threadIdx.x; c < W; c += 256) {
-        double v = 0.0;
-        if (c >= cb && c < cb + 6) v = Hx6[(size_t)row * 6 + (c - cb)];
-        else if (c == NA) v = res[row];
-        else if (c >= NAP && c < NAP + no) v = Hf[(size_t)row * no_max + (c - NAP)];
-        Xaug[(size_t)row * W + c] = v;
+// Every object row touches one clone (6 non-zeros of Hx) and the object's own state columns Hf.  With X = [Hx | r]
+// (scattered into the window's columns) the left-nullspace projection of math_utils.hpp:287-312 is the Schur complement
+//     A' = B - C^T F^-1 C,   B = X^T X,  C = Hf^T X,  F = Hf^T Hf
+// (any orthonormal basis of the left nullspace of Hf gives the same A'), formed with the Cholesky factor of F:
+// Y = L_F^-1 C, A' = B - Y^T Y.  None of B, C, F needs the rows scattered to window width: the rows of an object are
+// grouped by clone, and per (object, clone) group only 6 x (6 + no + 1) numbers are new --
+//     hx^T hx (6 x 6), hx^T r (6)            -> the clone's 7 x 7 tile of B      (Sg, 8 x 8 per (object, clone))
+//     hx^T Hf (6 x no)                       -> the clone's 6 columns of C       (Cd, dense no x NAP per object)
+// while F, Hf^T r and r^T r come from ONE Gram of the compact matrix [Hf | r] per object (Gff).  The stack is read
+// once (rows x (6 + no + 1) doubles); nothing of window width is written except C itself.  (Round 1 wrote the rows
+// scattered to NAP + NOP = 240 columns -- 28.6 MB -- and took a 240 x 240 Gram of that per object -- 94 MB fetched.)
+//
+// Compact row storage: Hx6 [rows][6];  HfR [rows][ldf], ldf = 16 ceil((no_max + 1)/16): columns [0, no) Hf of the
+// object (zero up to no_max), column no_max = the residual, zero behind it.
+// k_obj_cross: one wavefront per (object, clone) group {first, last+1 into ridx, clone, object}; ridx lists the rows of
+// the update grouped by (object, clone).  MFMA with A = hx^T (6 of 16 rows live), B = [Hf | r] tile by tile and hx.
+struct ObjGroup { int r0, r1, clone, obj; };
+__global__ __launch_bounds__(256) void k_obj_cross(const ObjGroup* __restrict__ groups, int ngroups, const int* __restrict__ ridx,
+                                                   const double* __restrict__ Hx6, const double* __restrict__ HfR, int ldf,
+                                                   int no_max, int cb0, int NAP, int NOP, int N,
+                                                   double* __restrict__ Cd, double* __restrict__ Sg) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= ngroups) return;
+    const ObjGroup grp = groups[g];
+    const int m = l & 15, kq = l >> 4;
+    const int nt = ldf >> 4;   // <= 8 (object state <= 112 columns)
+    d4 acc[8], ahh = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = d4{0, 0, 0, 0};
+    for (int k0 = grp.r0; k0 < grp.r1; k0 += 8) {   // two k-steps (8 rows) per trip: their loads are in flight together
+        double a[2], b[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool in = k < grp.r1;
+            const int row = ridx[in ? k : grp.r1 - 1];
+            const double av = Hx6[(size_t)row * 6 + (m < 6 ? m : 0)];
+            a[u] = (in && m < 6) ? av : 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < nt) { const double bv = HfR[(size_t)row * ldf + 16 * t + m]; b[u][t] = in ? bv : 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ahh = mfma_f64(a[u], a[u], ahh);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < nt) acc[t] = mfma_f64(a[u], b[u][t], acc[t]);
+        }
+    }
+    // D[mm][nn], mm = kq + 4 r (the hx component, < 6), nn = m
+    double* Co = Cd + (size_t)grp.obj * NOP * NAP;
+    double* So = Sg + ((size_t)grp.obj * N + grp.clone) * 64;
+    const int colb = cb0 + 6 * grp.clone;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int mm = kq + 4 * r;
+        if (mm < 6) {
+            if (m < 6) So[mm * 8 + m] = ahh[r];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t < nt) {
+                    const int i = 16 * t + m;   // column of [Hf | r]
+                    if (i < no_max) Co[(size_t)i * NAP + colb + mm] = acc[t][r];
+                    else if (i == no_max) { So[mm * 8 + 6] = acc[t][r]; So[6 * 8 + mm] = acc[t][r]; }
+                }
+            }
+        }
     }
 }
-
-// dst (NAP x NAP, full symmetric) = sum over objects of the top-left NAP x NAP block of G_o (lower tiles, ld W)
-__global__ __launch_bounds__(256) void k_obj_sum_B(const double* __restrict__ G, int nobj, int W, int NAP, double* __restrict__ dst) {
+// Gff[o] = [Hf | r]^T [Hf | r] (lower tiles) over the rows [row_ptr[o], row_ptr[o+1]) of object o: grid (tiles, objects),
+// sixteen wavefronts split the rows of one tile (as k_gram_pair)
+__global__ __launch_bounds__(1024) void k_obj_gram_ff(const double* __restrict__ HfR, int ldf, const int* __restrict__ row_ptr,
+                                                      double* __restrict__ Gff) {
+    int bi, bj;
+    tile_from_linear(blockIdx.x, bi, bj);
+    const int o = blockIdx.y;
+    gram16_body(HfR, ldf, row_ptr[o], row_ptr[o + 1], bi, bj, Gff + (size_t)o * ldf * ldf, ldf);
+}
+// dst (NAP x NAP, full symmetric) = sum over objects of B_o: clone tiles from Sg, |r|^2 from Gff[no_max][no_max]
+// (objects summed in index order: deterministic)
+__global__ __launch_bounds__(256) void k_obj_assemble_B(const double* __restrict__ Sg, int nobj, int N, const double* __restrict__ Gff,
+                                                        int ldf, int no_max, int cb0, int NA, int NAP, double* __restrict__ dst) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= NAP * NAP) return;
     const int i = idx / NAP, j = idx - i * NAP;
-    const int si = ((i >> 4) >= (j >> 4)) ? i : j, sj = ((i >> 4) >= (j >> 4)) ? j : i;
+    const int ci = (i >= cb0 && i < cb0 + 6 * N) ? (i - cb0) / 6 : -1, cj = (j >= cb0 && j < cb0 + 6 * N) ? (j - cb0) / 6 : -1;
+    const int ei = ci >= 0 ? i - cb0 - 6 * ci : (i == NA ? 6 : -1), ej = cj >= 0 ? j - cb0 - 6 * cj : (j == NA ? 6 : -1);
     double s = 0.0;
-    for (int o = 0; o < nobj; ++o) s += G[(size_t)o * W * W + (size_t)si * W + sj];
+    if (ei == 6 && ej == 6) {
+        for (int o = 0; o < nobj; ++o) s += Gff[(size_t)o * ldf * ldf + (size_t)no_max * ldf + no_max];
+    } else if (ei >= 0 && ej >= 0 && (ci == cj || ci < 0 || cj < 0)) {
+        const int c = ci >= 0 ? ci : cj;
+        for (int o = 0; o < nobj; ++o) s += Sg[((size_t)o * N + c) * 64 + ei * 8 + ej];
+    }
     dst[idx] = s;
 }
 

@@ -24,7 +24,9 @@ struct ObjEvalArgs {
     const int* frame_row0;    // [F] first output row of the frame (only for in-window frames)
     int K, F, ncol;           // ncol = 9 + 3K
     int ldhf;                 // leading dimension of Hf (>= ncol; the columns beyond ncol are written as 0)
-    int* row_cols;            // optional: ncol of the object is written per row (k_obj_build's row_obj_cols)
+    int rcol;                 // >= ncol: the residual is ALSO written to column rcol of the Hf row (compact [Hf | r] rows of the
+                              // object compression, msckf_kernels.hpp k_obj_cross); -1: not
+    int* row_cols;            // optional: ncol of the object is written per row
     int obj_left, new_bbox, vio_left, fix_D;
     double R_b2c[9], t_c_b[3];
     int* row_clone;
@@ -112,6 +114,7 @@ __device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int
         }
         double* hf = p.Hf + (size_t)row * p.ldhf;
         for (int c = 0; c < p.ldhf; ++c) hf[c] = 0.0;
+        if (p.rcol >= 0) hf[p.rcol] = r;
         if (p.row_cols) p.row_cols[row] = ncol;
         for (int c = 0; c < 6; ++c) hf[c] = hpose[c];
         if (hshape) for (int c = 0; c < 3; ++c) hf[6 + c] = hshape[c];
