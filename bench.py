@@ -297,7 +297,7 @@ def main():
                     lat_obj = timed_calls(call, 100, warm=5)
                     objects = dict(percentiles(lat_obj), objects=20, accepted=last['g'][0], dof=last['g'][1],
                                    what='orcvio_msckf_update_object_tracks: 20 cars x 12 keypoints x 30 frames, rows evaluated on the '
-                                        'device, host buffers in, dx and P+ out')
+                                        'device, host buffers (tracks + P) in, dx and P+ out')
                     # per-stage device times of the object update (HIP events between the stages, median of 20 runs)
                     upd.set_stage_profile(True)
                     runs = []
@@ -306,6 +306,42 @@ def main():
                         runs.append(upd.profile_stages())
                     upd.set_stage_profile(False)
                     objects['stage_ms'] = {name: round(float(np.median([r[i][1] for r in runs])), 5) for i, (name, _) in enumerate(runs[0])}
+                    # the north-star frame (config 3): the 400-feature update, then the 20-object update on the P+ it left
+                    # (SURVEY note N7), covariance and its square-root factor resident in HBM in between: tracks + poses in,
+                    # dx out, twice; the prior is restored outside the timed part
+                    fwin = synth.config_window(3)
+                    call_f, _ = upd.make_update_call(fwin, resident_cov=True, want_P=False, commit=True)
+                    oo, ores = upd._result(owin.n, 1)
+                    ores.P_out = None
+
+                    def frame():
+                        call_f()
+                        rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(ores))
+                        assert rc == 0
+                        rc = upd.lib.orcvio_msckf_cov_commit(upd.h)
+                        assert rc == 0
+                    upd.cov_set(fwin.P)
+                    lat_frame = timed_calls(frame, 100, warm=5, after=lambda: upd.cov_set(fwin.P))
+                    objects['frame_config3'] = dict(percentiles(lat_frame), object_update_accepted=int(oo['accept'][0]),
+                                                    what='400-feature update + commit + 20-object update + commit, covariance and its '
+                                                         'factor resident in HBM: host tracks / poses in, dx out (twice)')
+                    # the object update alone in that mode (prior and its factor resident)
+                    upd.cov_set(fwin.P)
+                    call_f()
+
+                    def obj_res():
+                        rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(ores))
+                        assert rc == 0
+                    lat_or = timed_calls(obj_res, 100, warm=5)
+                    objects['resident'] = dict(percentiles(lat_or), what='the object update with the prior and its square-root factor '
+                                                                         'resident (no P upload, no Cholesky of P), P+ left in HBM')
+                    upd.set_stage_profile(True)
+                    runs = []
+                    for _ in range(20):
+                        obj_res()
+                        runs.append(upd.profile_stages())
+                    upd.set_stage_profile(False)
+                    objects['resident']['stage_ms'] = {name: round(float(np.median([r[i][1] for r in runs])), 5) for i, (name, _) in enumerate(runs[0])}
                     upd.upload(win)   # the feature tracks again for what follows
                 except Exception as e:   # never let the side measurement break the metric line
                     objects = dict(error=str(e))

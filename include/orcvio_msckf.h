@@ -149,8 +149,19 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
 /* ORCVIO_OPT_STAGE_PROFILE (default 0): record HIP events between the stages of the object update (rows, compression, the
  * batched factorisation of F, Y, A', the solve, the gate); orcvio_msckf_profile_stages returns the per-stage device times
  * of the last object update (SURVEY.md 8d "device-only time per stage from hipEvents"). */
+/* ORCVIO_OPT_RESIDENT_FACTOR (default 1): orcvio_msckf_cov_commit also keeps a square-root factor of the committed
+ * covariance (S+ = sigma Z^T, a by-product of the solve), and an update whose prior is the resident covariance (P == NULL)
+ * uses it instead of a Cholesky factorisation of P: the second and third update of a frame (pruneImuStateBuffer,
+ * processObjects; src/orcvio.cpp:591-594, System.cpp:551-555) skip that 45 us chain.  cov_augment / cov_remove_clones carry
+ * the factor along, cov_set / cov_propagate drop it.  0 = always factor P. */
+/* ORCVIO_OPT_OBJECT_QR (default 1): the left-nullspace projection of an object's rows against Hf (math_utils.hpp:287-312,
+ * the reference takes a full-U SVD) needs the triangular factor of Hf.  1: a structured Householder QR that uses the arrow
+ * shape of ObjectLM's state ([pose 6 | shape 3 | 3 per keypoint], include/orcvio/obj/ObjectLM.h:117-123; accuracy
+ * cond(Hf) eps -- Hf of a real object has cond ~ 1e8: the keypoint rows have a gauge that only the bbox rows break).  0, and
+ * for rows whose Hf does not have that shape: chol(Hf^T Hf) (cond^2: directions below ~1e-8 of the largest are treated as
+ * null; stats[7] counts them). */
 enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
-       ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6 };
+       ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6, ORCVIO_OPT_RESIDENT_FACTOR = 7, ORCVIO_OPT_OBJECT_QR = 8 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* EKF-SLAM rows of the hybrid filter (existing SLAM features).  For every SLAM feature the current

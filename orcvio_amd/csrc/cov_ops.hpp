@@ -67,4 +67,37 @@ __global__ __launch_bounds__(256) void k_cov_remove(const double* __restrict__ P
     out[idx] = P[(size_t)map[i] * n + map[j]];
 }
 
+
+// ---- the resident square-root factor S (P = S S^T), stored transposed: S(j, i) = F[i * ld + j], i < k (columns of S),
+//      j < n (states) -- the layout of the Cholesky factor of the prior and of Z = L_M^-1 S^T --------------------------------
+// commit: S+ = sigma Z^T if the update was applied (apply == nullptr or *apply != 0), else the prior's own factor
+__global__ __launch_bounds__(256) void k_fac_commit(const double* __restrict__ Z, int ldz, int k, int n, double sigma,
+                                                    const int* __restrict__ apply, const double* __restrict__ prior, long sLi, long sLj,
+                                                    double* __restrict__ out, int ldo) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= k * n) return;
+    const int i = idx / n, j = idx - i * n;
+    const bool app = apply ? (*apply != 0) : true;
+    out[(size_t)i * ldo + j] = app ? sigma * Z[(size_t)i * ldz + j] : prior[(long)j * sLi + (long)i * sLj];
+}
+// stateAugmentation on the factor: the new clone's six rows of S are copies of the IMU's (theta, p) rows
+__global__ __launch_bounds__(256) void k_fac_augment(const double* __restrict__ F, int ld, int k, int n, int pose,
+                                                     double* __restrict__ out, int ldo) {
+    const int m = n + 6;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= k * m) return;
+    const int i = idx / m, j = idx - i * m;
+    const bool nj = j >= pose && j < pose + 6;
+    const int sj = nj ? (j - pose < 3 ? j - pose : j - pose + 3) : (j < pose ? j : j - 6);
+    out[(size_t)i * ldo + j] = F[(size_t)i * ld + sj];
+}
+// marginalisation on the factor: the rows of S of the removed states are deleted (map[j'] = old index of new state j')
+__global__ __launch_bounds__(256) void k_fac_remove(const double* __restrict__ F, int ld, int k, const int* __restrict__ map, int m,
+                                                    double* __restrict__ out, int ldo) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= k * m) return;
+    const int i = idx / m, j = idx - i * m;
+    out[(size_t)i * ldo + j] = F[(size_t)i * ld + map[j]];
+}
+
 }  // namespace orcvio_amd

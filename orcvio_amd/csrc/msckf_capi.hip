@@ -77,6 +77,20 @@ struct orcvio_msckf_handle {
     GraphSlot g_update, g_local, g_finish;
     hipStream_t last_stream = nullptr;   // stream of the last run_update / run_finish (download waits for it)
     double *d_Pres = nullptr, *d_Ptmp = nullptr, *d_covT = nullptr;   // resident covariance, scratch, Phi*P rows
+    // Resident SQUARE-ROOT FACTOR of the resident covariance: P_res = S S^T with S (fac_n x fac_k), stored like the
+    // Cholesky factor of the prior (d_RP): S(i,j) = d_Sres[j * fac_ld + i].  cov_commit keeps S+ = sigma Z^T of the update
+    // that has just run (Z = L_M^-1 S^T is what the solve produces anyway), so the NEXT update of the same frame
+    // (pruneImuStateBuffer, processObjects: src/orcvio.cpp:591-594, System.cpp:551-555) skips the Cholesky of its prior.
+    // cov_augment / cov_remove_clones carry it along (rows copied / deleted); cov_set / cov_propagate invalidate it.
+    double *d_Sres = nullptr, *d_Stmp = nullptr;
+    int fac_n = 0, fac_k = 0, fac_ld = 0;
+    bool fac_valid = false;
+    bool factor_opt = true;             // ORCVIO_OPT_RESIDENT_FACTOR
+    bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
+    bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P
+    bool last_update_objects = false;   // the last finished update was a (gated) object update
+    bool prior_forked = false;          // the Cholesky of the prior runs on the side stream (ev_side must be joined)
+    int kf = 0;                         // columns of the prior's factor = dimension of M (n unless a resident factor is used)
     int* d_covmap = nullptr;
     int res_n = 0;                      // dimension of the resident covariance (0 = none)
     bool pw_missing = false;            // uploaded without positions: triangulate_uploaded must run before the update
@@ -125,6 +139,7 @@ struct orcvio_msckf_handle {
     size_t obj_stage_cap = 0;
     std::vector<ObjUse> obj_use;        // (objects_local_tracks: per-track records, kept across calls: no allocation per frame)
     std::vector<int> obj_fnr;           // rows of every frame of the track being staged
+    std::vector<int> obj_rowkp, obj_Ks; // keypoint block of every row / keypoint count of every object (structured QR of Hf)
     // per-stage device times of the last object update (orcvio_msckf_profile_stages): events recorded between the stages
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -291,7 +306,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_DinvP, h->d_U, h->d_M, h->d_RM, h->d_DinvM, h->d_Z, h->d_La, h->d_DinvA,
                     h->d_W, h->d_Y, h->d_KG, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S,
-                    h->d_Pres, h->d_Ptmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
+                    h->d_Pres, h->d_Ptmp, h->d_Sres, h->d_Stmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
                     h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense, h->d_Rf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -368,6 +383,8 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipMalloc(&h->d_skip, sizeof(int) * max_features));
         HIPCHK(hipMalloc(&h->d_Pres, sizeof(double) * nn));
         HIPCHK(hipMalloc(&h->d_Ptmp, sizeof(double) * nn));
+        HIPCHK(hipMalloc(&h->d_Sres, sizeof(double) * np2));
+        HIPCHK(hipMalloc(&h->d_Stmp, sizeof(double) * np2));
         HIPCHK(hipMalloc(&h->d_covT, sizeof(double) * (46 * (size_t)h->n_max + 2 * 46 * 46)));   // Phi P rows, then Phi and Q
         HIPCHK(hipMalloc(&h->d_covmap, sizeof(int) * h->n_max));
         HIPCHK(hipMalloc(&h->d_tri_valid, sizeof(int) * max_features));
@@ -409,6 +426,7 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipFuncSetAttribute((const void*)k_feature<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         HIPCHK(hipFuncSetAttribute((const void*)k_feature<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         HIPCHK(hipFuncSetAttribute((const void*)k_feature<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        HIPCHK(hipFuncSetAttribute((const void*)k_obj_arrow_qr, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         return ORCVIO_OK;
     }();
     if (rc != ORCVIO_OK) {
@@ -456,6 +474,15 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
         h->n_extra = value;   // takes effect with the next upload / update call (part of the launch signature)
         return ORCVIO_OK;
     }
+    if (option == ORCVIO_OPT_RESIDENT_FACTOR) {
+        h->factor_opt = value != 0;
+        if (!h->factor_opt) h->fac_valid = false;
+        return ORCVIO_OK;
+    }
+    if (option == ORCVIO_OPT_OBJECT_QR) {
+        h->arrow_opt = value != 0;
+        return ORCVIO_OK;
+    }
     if (option == ORCVIO_OPT_STAGE_PROFILE) {
         h->prof_on = value != 0;
         h->prof_n = 0;
@@ -469,6 +496,24 @@ static int factor_layout_clean(orcvio_msckf_handle* h);
 static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s);
 // Gram of the rows stacked under the MSCKF rows (EKF-SLAM rows that passed their gate, caller-projected dense rows)
 static inline const double* extra_gram(const orcvio_msckf_handle* h) { return (h->ekf_F > 0 || h->dense_rows > 0) ? h->d_Gekf : nullptr; }
+
+// The prior of this update comes as P == NULL (resident covariance): if its square-root factor is resident too, the update
+// uses it instead of factoring P (kf = its column count = the dimension of M).
+static void select_prior_factor(orcvio_msckf_handle* h, const double* P) {
+    h->use_factor = !P && h->factor_opt && h->fac_valid && h->fac_n == h->n && h->res_n == h->n &&
+                    round_up(h->fac_k, 16) <= POTRF_MAXN && round_up(h->fac_k, 16) / 16 <= TRSM_MAXBLK &&
+                    round_up(h->fac_k, 16) <= h->NP_max;
+    h->kf = h->use_factor ? h->fac_k : h->n;
+}
+// L(i,j) of the prior's factor = base[i * sLi + j * sLj], i < n, j < kf
+struct PriorFactor { const double* base; long sLi, sLj; };
+static inline void factor_strides(const orcvio_msckf_handle* h, long& sLi, long& sLj);
+static PriorFactor prior_factor(const orcvio_msckf_handle* h) {
+    if (h->use_factor) return PriorFactor{h->d_Sres, 1L, (long)h->fac_ld};
+    long sLi, sLj;
+    factor_strides(h, sLi, sLj);
+    return PriorFactor{h->d_RP, sLi, sLj};
+}
 
 // ---- upload --------------------------------------------------------------------------------
 int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
@@ -511,7 +556,8 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->ekf_F = 0; h->dense_rows = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
-    h->NP = round_up(h->n, 16);
+    select_prior_factor(h, P);
+    h->NP = round_up(h->n > h->kf ? h->n : h->kf, 16);
     h->ldz = round_up(h->n + 1, 16);
     h->reg_path = (h->NP / 16) <= 14;
     { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
@@ -655,7 +701,7 @@ static bool front_defers_assembly(const orcvio_msckf_handle* h) { return front_f
 static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_dst, bool grams_only = false) {
     const FeatArgs a = feature_args(h);
     const double eps = 2.220446049250313e-16;
-    FrontPotrfArgs q{h->d_P, h->n, h->n, 8.0 * eps, h->d_RP, h->NP, h->d_DinvP, h->d_info};
+    FrontPotrfArgs q{h->d_P, h->n, h->n, 8.0 * eps, h->d_RP, h->NP, h->d_DinvP, h->d_info, h->use_factor ? 1 : 0};
     const size_t team = feat_lds_bytes(h->Mmax, h->NAP, h->N);
     const size_t lds = 2 * team > sizeof(double) * POTRF_LDS_DOUBLES ? 2 * team : sizeof(double) * POTRF_LDS_DOUBLES;
     const int team_doubles = (int)(team / sizeof(double));
@@ -810,36 +856,39 @@ static inline bool fused_solve_active(const orcvio_msckf_handle* h) { return h->
 enum { ST_POTRF_P = 0, ST_FORM_U, ST_FORM_M, ST_POTRF_M, ST_TRSM, ST_FINISH, ST_COUNT };
 
 static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) {
-    const int NA = h->NA, NAP = h->NAP, n = h->n, NP = h->NP, ldz = h->ldz;
+    // n = states (rows of the prior's factor), kf = columns of that factor = dimension of M (kf == n unless the resident
+    // factor of an earlier update of the frame is used)
+    const int NA = h->NA, NAP = h->NAP, n = h->n, kf = h->kf, NP = h->NP, ldz = h->ldz;
     const double sigma2 = h->flags.noise_feature * h->flags.noise_feature;
     const double eps = 2.220446049250313e-16;
-    long sLi, sLj;
-    factor_strides(h, sLi, sLj);
-    const double* La = h->d_RP + 15 * sLi;   // L_a(k, j) = Lf(15 + k, j)
+    const PriorFactor pf = prior_factor(h);
+    const long sLi = pf.sLi, sLj = pf.sLj;
+    const double* La = pf.base + 15 * sLi;   // L_a(k, j) = Lf(15 + k, j)
     switch (stage) {
         case ST_POTRF_P:   // P = Lf Lf^T
+            if (h->use_factor) return ORCVIO_OK;   // the factor is resident
             return launch_potrf(h, s, h->d_P, n, n, 8.0 * eps, h->d_RP, h->d_DinvP, h->d_info);
-        case ST_FORM_U:    // U[(NA+1) x n] = [A; b^T] * L_a
+        case ST_FORM_U:    // U[(NA+1) x kf] = [A; b^T] * L_a
             if (h->A_deferred) {   // A = scatter(S) - sum Gpart assembled inside the product (k_front left the Grams only)
                 AsmArgs aa{h->d_S, h->N, h->flags.leg_dim - 15, NA, NAP, h->d_Gpart, h->front_chunks, (size_t)NAP * NAP, getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0,
                            extra_gram(h)};
-                const int tiles = ((NA + 1 + 15) / 16) * ((n + 15) / 16);
-                hipLaunchKernelGGL(k_gemm_asmA, dim3(tiles), dim3(256), 0, s, aa, La, sLi, sLj, NA + 1, n, NA, h->d_U, (long)NP, 1L, (int*)nullptr);
+                const int tiles = ((NA + 1 + 15) / 16) * ((kf + 15) / 16);
+                hipLaunchKernelGGL(k_gemm_asmA, dim3(tiles), dim3(256), 0, s, aa, La, sLi, sLj, NA + 1, kf, NA, h->d_U, (long)NP, 1L, (int*)nullptr);
                 HIPCHK(hipGetLastError());
                 return ORCVIO_OK;
             }
-            return launch_gemm(s, h->d_A, NAP, 1, La, sLi, sLj, NA + 1, n, NA, 1.0, 0.0, 0, h->d_U, NP, 1);
+            return launch_gemm(s, h->d_A, NAP, 1, La, sLi, sLj, NA + 1, kf, NA, 1.0, 0.0, 0, h->d_U, NP, 1);
         case ST_FORM_M:    // M = s2 I + L_a^T U[0:NA]   (upper tiles)
             // (the register-resident Cholesky reads the upper tiles only; the LDS-panel fallback factors the lower triangle in place)
-            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, n, n, NA, 1.0, sigma2, h->reg_path ? 1 : 0, h->d_M, NP, 1, h->d_flag);
+            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, kf, kf, NA, 1.0, sigma2, h->reg_path ? 1 : 0, h->d_M, NP, 1, h->d_flag);
         case ST_POTRF_M:
             if (fused_solve_active(h)) {   // chol(M) + Z = L_M^-1 [Lf^T | g] in one launch (solver workgroups trail the factorisation)
-                const int nbm = (n + 15) / 16, need = potrf_slots_needed(nbm);
+                const int nbm = (kf + 15) / 16, need = potrf_slots_needed(nbm);
                 const int ncb = (n + 1 + 15) / 16;
                 const dim3 grid(1 + (ncb + SOLVE_WPB - 1) / SOLVE_WPB), block(512);
                 const double* g = h->d_U + (size_t)NA * NP;
-#define LAUNCH_PS(NS) hipLaunchKernelGGL(k_potrf_solve<NS>, grid, block, 0, s, h->d_M, NP, n, 0.0, h->d_RM, NP, h->d_DinvM, h->d_info + 2, \
-                                         h->d_flag, h->d_info + 8, h->d_RP, sLj, sLi, n, g, 1L, h->d_Z, ldz)
+#define LAUNCH_PS(NS) hipLaunchKernelGGL(k_potrf_solve<NS>, grid, block, 0, s, h->d_M, NP, kf, 0.0, h->d_RM, NP, h->d_DinvM, h->d_info + 2, \
+                                         h->d_flag, h->d_info + 8, pf.base, sLj, sLi, n, g, 1L, h->d_Z, ldz)
                 if (need <= 4) LAUNCH_PS(4);
                 else if (need <= 8) LAUNCH_PS(8);
                 else if (need <= 12) LAUNCH_PS(12);
@@ -848,13 +897,13 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
                 HIPCHK(hipGetLastError());
                 return ORCVIO_OK;
             }
-            return launch_potrf(h, s, h->d_M, NP, n, 0.0, h->d_RM, h->d_DinvM, h->d_info + 2);
+            return launch_potrf(h, s, h->d_M, NP, kf, 0.0, h->d_RM, h->d_DinvM, h->d_info + 2);
         case ST_TRSM:      // Z = L_M^-1 [Lf^T | g],  g = U[NA][:]
             if (fused_solve_active(h)) return ORCVIO_OK;   // done inside k_potrf_solve
-            return launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_RP, sLj, sLi, n, h->d_U + (size_t)NA * NP, 1, h->d_Z, ldz);
+            return launch_trsm(h, s, h->d_RM, h->d_DinvM, kf, pf.base, sLj, sLi, n, h->d_U + (size_t)NA * NP, 1, h->d_Z, ldz);
         case ST_FINISH: {
             const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
-            hipLaunchKernelGGL(k_finish_sqrt, dim3(tiles), dim3(256), 0, s, h->d_Z, ldz, n, sigma2, h->d_Pout, h->d_dx,
+            hipLaunchKernelGGL(k_finish_sqrt, dim3(tiles), dim3(256), 0, s, h->d_Z, ldz, n, kf, sigma2, h->d_Pout, h->d_dx,
                                h->objects_mode ? h->d_obj_accept : (const int*)nullptr, h->d_P);
             HIPCHK(hipGetLastError());
             return ORCVIO_OK;
@@ -865,6 +914,8 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
 
 // fork: Cholesky of the prior on the side stream (depends on P only)
 static int launch_prior_fork(orcvio_msckf_handle* h, hipStream_t s) {
+    h->prior_forked = !h->use_factor;
+    if (h->use_factor) return ORCVIO_OK;   // the prior's factor is resident: nothing to fork, nothing to join
     HIPCHK(hipEventRecord(h->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     int rc = launch_solve_stage(h, h->side, ST_POTRF_P);   // writes d_info[0..1] itself
@@ -874,7 +925,7 @@ static int launch_prior_fork(orcvio_msckf_handle* h, hipStream_t s) {
 }
 
 static int launch_solve_tail(orcvio_msckf_handle* h, hipStream_t s) {
-    HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));   // join the Cholesky of the prior
+    if (h->prior_forked) HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));   // join the Cholesky of the prior
     int rc = ORCVIO_OK;
     for (int st = ST_FORM_U; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
     return rc;
@@ -898,7 +949,7 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     std::memcpy(&bits, &sg, 8); mix(bits);
     double cp = h->flags.chi2_prob;
     std::memcpy(&bits, &cp, 8); mix(bits);
-    mix(h->graph_epoch); mix(h->ekf_idp); mix(h->ekf_eval); mix(h->ekf_cap); mix(h->dense_cap);
+    mix(h->use_factor); mix(h->kf); mix(h->fac_ld); mix(h->graph_epoch); mix(h->ekf_idp); mix(h->ekf_eval); mix(h->ekf_cap); mix(h->dense_cap);
     mix((unsigned long long)(size_t)h->d_ekf_i); mix((unsigned long long)(size_t)h->d_ekf_d); mix((unsigned long long)(size_t)h->d_ekf_E);
     mix((unsigned long long)(size_t)h->d_slam); mix((unsigned long long)(size_t)h->d_dense); mix((unsigned long long)(size_t)h->d_Gekf);
     mix((unsigned long long)(size_t)h->d_Hs); mix((unsigned long long)(size_t)h->d_P);
@@ -944,7 +995,7 @@ static int run_with_graph(orcvio_msckf_handle* h, orcvio_msckf_handle::GraphSlot
 static int run_local_impl(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
     h->last_stream = s;
     { const int re = launch_ekf(h, s); if (re != ORCVIO_OK) return re; }
-    if (front_fused_active(h)) return launch_front(h, s, dst);   // one launch: tracks, compression, and the prior's factor
+    if (front_fused_active(h)) { h->prior_forked = false; return launch_front(h, s, dst); }   // one launch: tracks, compression, and the prior's factor
     int rc = launch_prior_fork(h, s);
     if (rc != ORCVIO_OK) return rc;
     return run_with_graph(h, h->g_local, launch_signature(h, s, dst, 0), s, [&](bool) {
@@ -981,14 +1032,14 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
     h->last_stream = s;
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     // the Cholesky of the prior was forked by run_local: join it here (outside the captured part)
-    HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
+    if (h->prior_forked) HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
     h->A_deferred = false;   // d_A is the sum of the gathered blocks
     int rc = run_with_graph(h, h->g_finish, launch_signature(h, s, d_blocks, n_blocks), s, [&](bool) {
         int r = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);   // rank-ordered sum of the gathered blocks
         for (int st = ST_FORM_U; st < ST_COUNT && r == ORCVIO_OK; ++st) r = launch_solve_stage(h, s, st);
         return r;
     });
-    if (rc == ORCVIO_OK) h->ran = true;
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; }
     return rc;
 }
 
@@ -1042,6 +1093,7 @@ static int enqueue_update(orcvio_msckf_handle* h, hipStream_t s) {
     h->A_deferred = front_defers_assembly(h);
     if (front_fused_active(h)) {   // one stream, no fork: the prior is factored by workgroup 0 of the feature launch
         // ... and the compression behind the tracks, under the factorisation
+        h->prior_forked = false;
         int rc = launch_front(h, s, h->d_A, h->A_deferred);
         for (int st = ST_FORM_U; st < ST_COUNT && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
         return rc;
@@ -1465,7 +1517,7 @@ int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }   // (a copy of the previous results nobody fetched)
     int rc = run_with_graph(h, h->g_update, launch_signature(h, s, nullptr, 0), s, [&](bool) { return enqueue_update(h, s); });
     h->A_deferred = front_defers_assembly(h);   // (a replayed graph does not pass through enqueue_update)
-    if (rc == ORCVIO_OK) h->ran = true;
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; }
     return rc;
 }
 
@@ -1482,11 +1534,11 @@ int32_t orcvio_msckf_sync(orcvio_msckf_handle* h, void* stream) {
 //   H_thin = R_A (A = R_A^T R_A, zero rows on rank-deficient directions), r_thin = R_A^-T b,
 //   K = P H_thin^T S^-1 = Lf M^-1 L_a^T R_A^T,   G = K H_thin = Lf M^-1 L_a^T A.
 static int compute_optional(orcvio_msckf_handle* h, bool want_thin_or_K, bool want_K, bool want_G) {
-    const int NA = h->NA, NAP = h->NAP, n = h->n, NP = h->NP, ldz = h->ldz;
+    const int NA = h->NA, NAP = h->NAP, n = h->n, kf = h->kf, NP = h->NP, ldz = h->ldz;
     hipStream_t s = h->stream;
-    long sLi, sLj;
-    factor_strides(h, sLi, sLj);
-    const double* La_P = h->d_RP + 15 * sLi;
+    const PriorFactor pf = prior_factor(h);
+    const long sLi = pf.sLi, sLj = pf.sLj;
+    const double* La_P = pf.base + 15 * sLi;
     { const int ra = assemble_deferred(h, s); if (ra != ORCVIO_OK) return ra; }
     if (want_thin_or_K) {   // lower Cholesky factor of the Gram block with the LDS-panel kernel
         HIPCHK(hipMemcpyAsync(h->d_La, h->d_A, sizeof(double) * (size_t)NAP * NAP, hipMemcpyDeviceToDevice, s));
@@ -1496,14 +1548,14 @@ static int compute_optional(orcvio_msckf_handle* h, bool want_thin_or_K, bool wa
         HIPCHK(hipGetLastError());
     }
     if (want_G) {   // W = L_M^-1 U[0:NA]^T (n x NA);  G[:, 15:] = Zn^T W
-        int rc = launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_U, 1, NP, NA, nullptr, 0, h->d_W, NP);
-        if (rc == ORCVIO_OK) rc = launch_gemm(s, h->d_Z, 1, ldz, h->d_W, NP, 1, n, NA, n, 1.0, 0.0, 0, h->d_KG, NP, 1);
+        int rc = launch_trsm(h, s, h->d_RM, h->d_DinvM, kf, h->d_U, 1, NP, NA, nullptr, 0, h->d_W, NP);
+        if (rc == ORCVIO_OK) rc = launch_gemm(s, h->d_Z, 1, ldz, h->d_W, NP, 1, n, NA, kf, 1.0, 0.0, 0, h->d_KG, NP, 1);
         if (rc != ORCVIO_OK) return rc;
     }
     if (want_K) {   // Y = L_a^T R_A^T (n x NA); W = L_M^-1 Y; K = Zn^T W  -> stored after G in d_KG
-        int rc = launch_gemm(s, La_P, sLj, sLi, h->d_La, NAP, 1, n, NA, NA, 1.0, 0.0, 0, h->d_Y, NP, 1);
-        if (rc == ORCVIO_OK) rc = launch_trsm(h, s, h->d_RM, h->d_DinvM, n, h->d_Y, NP, 1, NA, nullptr, 0, h->d_W, NP);
-        if (rc == ORCVIO_OK) rc = launch_gemm(s, h->d_Z, 1, ldz, h->d_W, NP, 1, n, NA, n, 1.0, 0.0, 0, h->d_Y, NP, 1);
+        int rc = launch_gemm(s, La_P, sLj, sLi, h->d_La, NAP, 1, kf, NA, NA, 1.0, 0.0, 0, h->d_Y, NP, 1);
+        if (rc == ORCVIO_OK) rc = launch_trsm(h, s, h->d_RM, h->d_DinvM, kf, h->d_Y, NP, 1, NA, nullptr, 0, h->d_W, NP);
+        if (rc == ORCVIO_OK) rc = launch_gemm(s, h->d_Z, 1, ldz, h->d_W, NP, 1, n, NA, kf, 1.0, 0.0, 0, h->d_Y, NP, 1);
         if (rc != ORCVIO_OK) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
@@ -1676,6 +1728,13 @@ struct ObjPlan {
     ObjGroup* d_groups = nullptr;
     double *d_hx = nullptr, *d_hf = nullptr, *d_res = nullptr;
     double *d_Cd = nullptr, *d_Sg = nullptr, *d_Gff = nullptr;
+    // arrow structure of Hf (structured Householder QR instead of chol(Hf^T Hf)); arrow = false: the Gram route
+    bool arrow = false;
+    int Kmax = 0, rows_max = 0;
+    ObjArrow* d_arrow = nullptr;
+    int2* d_kp_range = nullptr;
+    int* d_kp_rows = nullptr;
+    double* d_Rarrow = nullptr;
 };
 static int obj_stage_reserve(orcvio_msckf_handle* h, size_t bytes) {
     if (bytes <= h->obj_stage_cap) return ORCVIO_OK;
@@ -1699,7 +1758,8 @@ static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
     if ((rc = grow(&h->d_obj_i, &h->cap_obj_i, 2 * rows + 16)) != ORCVIO_OK) return rc;
     if ((rc = grow(&h->d_objH, &h->cap_objH, rows * (6 + pl->ldf + 1) + 16)) != ORCVIO_OK) return rc;
     const size_t nCd = nobj * pl->NOP * NAP, nSg = nobj * N * 64, nGff = nobj * pl->ldf * pl->ldf;
-    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, nCd + nSg + nGff)) != ORCVIO_OK) return rc;
+    const size_t nRa = nobj * (size_t)arrow_stride(pl->Kmax > 0 ? pl->Kmax : 1);
+    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, nCd + nSg + nGff + nRa)) != ORCVIO_OK) return rc;
     if ((rc = grow(&h->d_RF, &h->cap_RF, nobj * ((size_t)pl->NOP * pl->NOP + 7 * 256))) != ORCVIO_OK) return rc;
     if ((rc = grow(&h->d_Yobj, &h->cap_Yobj, nobj * pl->NOP * NAP)) != ORCVIO_OK) return rc;
     pl->d_clone = h->d_obj_i;
@@ -1710,6 +1770,7 @@ static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
     pl->d_Cd = h->d_Gobj;
     pl->d_Sg = pl->d_Cd + nCd;
     pl->d_Gff = pl->d_Sg + nSg;
+    pl->d_Rarrow = pl->d_Gff + nGff;
     return ORCVIO_OK;
 }
 
@@ -1733,7 +1794,19 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
         hipLaunchKernelGGL(k_obj_gram_ff, dim3(nbf * (nbf + 1) / 2, nobj), dim3(1024), 0, s, pl.d_hf, ldf, pl.d_rowptr, pl.d_Gff);
     }
     prof_mark(h, s, "k_obj_cross+k_obj_gram_ff");
-    // F_o = Hf^T Hf (lower tiles of Gff) -> R_F ; Y_o = L_F^-1 C_o, C_o = [Cd_o | Hf^T r]
+    if (pl.arrow) {
+        // R of Hf by structured Householder QR (cond(Hf), not its square: msckf_kernels.hpp), then Y_o = R^-T C_o
+        HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));
+        const size_t lds = sizeof(double) * ((size_t)pl.rows_max * 9 + 32);
+        hipLaunchKernelGGL(k_obj_arrow_qr, dim3(nobj), dim3(512), lds, s, pl.d_arrow, pl.d_kp_range, pl.d_kp_rows, pl.d_hf, ldf, pl.Kmax,
+                           pl.d_Rarrow, h->d_info + 4);
+        prof_mark(h, s, "k_obj_arrow_qr(Hf)");
+        hipLaunchKernelGGL(k_obj_arrow_solve, dim3((NA + 1 + 255) / 256, nobj), dim3(256), 0, s, pl.d_arrow, pl.d_Rarrow, pl.Kmax, pl.d_Cd,
+                           NOP, NAP, NA, pl.d_Gff, ldf, no_max, h->d_Yobj, h->d_info + 4);
+        prof_mark(h, s, "k_obj_arrow_solve(Y)");
+    } else {
+    // (Hf without the arrow structure of ObjectLM's state: the Gram route.)  F_o = Hf^T Hf (lower tiles of Gff) -> R_F ;
+    // Y_o = L_F^-1 C_o, C_o = [Cd_o | Hf^T r]
     {
         const int nbf = NOP / 16, need = potrf_slots_needed(nbf);
         HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));   // the batched factorisation ADDS its pivot counters
@@ -1750,6 +1823,7 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
                            pl.d_Cd, (long)NAP, 1L, NA, pl.d_Gff + (size_t)no_max * ldf, 1L, h->d_Yobj, NAP,
                            (size_t)NOP * NOP, (size_t)7 * 256, (size_t)NOP * NAP, (size_t)NOP * NAP, (size_t)ldf * ldf);
         prof_mark(h, s, "k_trsm_lds(Y) batched");
+    }
     }
     // A' = sum_o B_o - Y^T Y  (Y = all Y_o stacked; padded rows are zero)
     hipLaunchKernelGGL(k_obj_assemble_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, pl.d_Sg, nobj, N, pl.d_Gff, ldf, no_max,
@@ -1778,8 +1852,38 @@ static int objects_prior(orcvio_msckf_handle* h, hipStream_t s, const double* P,
     return ORCVIO_OK;
 }
 
+// Arrow structure of the objects' Hf for the structured QR (k_obj_arrow_qr): rowkp[row] = keypoint block of the row (-1: a
+// border-only row), Ks[o] = keypoint blocks of object o.  Fills arrows / ranges / kp_rows (host mirrors of the device arrays);
+// returns false if some object does not fit the kernel's limits (<= 128 rows per keypoint, <= 2048 rows per object).
+static bool build_arrow(const int* rowkp, const int* rowptr, const int* Ks, int nobj, ObjArrow* arrows, int2* ranges, int* kp_rows,
+                        int* Kmax, int* rows_max) {
+    int off = 0, pos = 0;
+    *Kmax = 0; *rows_max = 0;
+    for (int o = 0; o < nobj; ++o) {
+        const int r0 = rowptr[o], r1 = rowptr[o + 1], K = Ks[o];
+        if (r1 - r0 > 2048 || K > 34) return false;
+        int cnt[35] = {0};
+        for (int r = r0; r < r1; ++r)
+            if (rowkp[r] >= 0) cnt[rowkp[r]]++;
+        int start[35];
+        for (int k = 0; k < K; ++k) {
+            if (cnt[k] > 128) return false;
+            start[k] = pos;
+            ranges[off + k] = int2{pos, pos + cnt[k]};
+            pos += cnt[k];
+        }
+        for (int r = r0; r < r1; ++r)
+            if (rowkp[r] >= 0) kp_rows[start[rowkp[r]]++] = r;
+        arrows[o] = ObjArrow{r0, r1 - r0, K, off};
+        off += K;
+        if (K > *Kmax) *Kmax = K;
+        if (r1 - r0 > *rows_max) *rows_max = r1 - r0;
+    }
+    return true;
+}
+
 // window-dependent sizes of an object update (no tracks)
-static int objects_problem(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int N, const char* who) {
+static int objects_problem(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int N, const double* P, const char* who) {
     if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = std::string(who) + ": leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
     if (N < 1 || N > h->maxN) { g_last_error = std::string(who) + ": window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
     h->flags = *flags;
@@ -1789,7 +1893,8 @@ static int objects_problem(orcvio_msckf_handle* h, const orcvio_msckf_flags* fla
     h->ekf_F = 0; h->dense_rows = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
-    h->NP = round_up(h->n, 16);
+    select_prior_factor(h, P);
+    h->NP = round_up(h->n > h->kf ? h->n : h->kf, 16);
     h->ldz = round_up(h->n + 1, 16);
     h->reg_path = (h->NP / 16) <= 14;
     { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
@@ -1805,7 +1910,7 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
                                    int32_t* dof_out, void* stream) {
     if (!h || !flags || n_objects < 0 || (n_objects > 0 && !objs)) { g_last_error = "objects_local: null argument"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    { const int rp = objects_problem(h, flags, n_clones, "objects_local"); if (rp != ORCVIO_OK) return rp; }
+    { const int rp = objects_problem(h, flags, n_clones, P, "objects_local"); if (rp != ORCVIO_OK) return rp; }
     const int N = n_clones, NAP = h->NAP;
     // usable objects, row offsets, widest object state
     std::vector<int> use;
@@ -1840,29 +1945,53 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     }
     int rc = objects_scratch(h, &pl);
     if (rc != ORCVIO_OK) return rc;
-    // staging arena: [Hx6 rows x 6 | HfR rows x ldf] doubles, then [ridx rows | rowptr nobj+1 | groups 4 x <= nobj N] ints
+    // staging arena: [Hx6 rows x 6 | HfR rows x ldf] doubles, then ints [ridx rows | rowptr nobj+1 | arrows 4 nobj | kp ranges
+    // 2 x sum K | kp_rows rows | groups 4 x <= nobj N]
     const size_t rows = (size_t)pl.rows_tot, ldf = (size_t)pl.ldf;
-    const size_t nd = rows * 6 + rows * ldf, ni = rows + (size_t)pl.nobj + 1 + (size_t)4 * pl.nobj * N;
+    size_t sumK = 0;
+    for (int o : use) sumK += (size_t)((objs[o].n_obj_cols - 9) / 3 > 0 ? (objs[o].n_obj_cols - 9) / 3 : 0);
+    const size_t nd = rows * 6 + rows * ldf;
+    const size_t o_ridx = 0, o_rowptr = o_ridx + rows, o_arrow = o_rowptr + pl.nobj + 1, o_range = o_arrow + (size_t)4 * pl.nobj,
+                 o_kprows = o_range + 2 * sumK, o_groups = o_kprows + rows, ni = o_groups + (size_t)4 * pl.nobj * N;
     if ((rc = obj_stage_reserve(h, nd * 8 + ni * 4)) != ORCVIO_OK) return rc;
     double* hd = reinterpret_cast<double*>(h->h_obj_stage);
     int* hi = reinterpret_cast<int*>(h->h_obj_stage + nd * 8);
     double* hx = hd;
     double* hf = hd + rows * 6;
-    int* ridx = hi;
-    int* rowptr = hi + rows;
-    ObjGroup* groups = reinterpret_cast<ObjGroup*>(hi + rows + pl.nobj + 1);
+    int* ridx = hi + o_ridx;
+    int* rowptr = hi + o_rowptr;
+    ObjGroup* groups = reinterpret_cast<ObjGroup*>(hi + o_groups);
     std::memset(hf, 0, sizeof(double) * rows * ldf);
+    std::vector<int>& rowkp = h->obj_fnr;   // (scratch) keypoint block of every row, -1: border only, -2: no arrow structure
+    rowkp.assign(rows, -1);
+    std::vector<int> Ks(pl.nobj, 0);
+    bool structured = true;
     int r0 = 0, ng = 0;
     rowptr[0] = 0;
     for (size_t ui = 0; ui < use.size(); ++ui) {
         const orcvio_msckf_object_rows& ob = objs[use[ui]];
+        const int nc = ob.n_obj_cols;
+        const bool shape_ok = nc >= 9 && (nc - 9) % 3 == 0;   // [pose 6 | shape 3 | 3 per keypoint], ObjectLM.h:117-123
+        Ks[ui] = shape_ok ? (nc - 9) / 3 : 0;
+        structured = structured && shape_ok;
         int cnt[ORCVIO_MAX_CLONES + 1] = {0};
         for (int r = 0; r < ob.n_rows; ++r) {
             std::memcpy(hx + (size_t)(r0 + r) * 6, ob.Hx6 + (size_t)r * 6, 6 * sizeof(double));
             double* row = hf + (size_t)(r0 + r) * ldf;
-            std::memcpy(row, ob.Hf + (size_t)r * ob.n_obj_cols, ob.n_obj_cols * sizeof(double));
+            const double* src = ob.Hf + (size_t)r * nc;
+            std::memcpy(row, src, nc * sizeof(double));
             row[pl.no_max] = ob.res[r];
             cnt[ob.row_clone[r] + 1]++;
+            if (structured) {   // the row's non-zeros behind the border must lie in ONE keypoint block
+                int blk = -1;
+                for (int c = 9; c < nc; ++c)
+                    if (src[c] != 0.0) {
+                        const int b = (c - 9) / 3;
+                        if (blk >= 0 && b != blk) { structured = false; break; }
+                        blk = b;
+                    }
+                rowkp[r0 + r] = blk;
+            }
         }
         for (int c = 0; c < N; ++c) cnt[c + 1] += cnt[c];
         for (int c = 0; c < N; ++c)
@@ -1874,12 +2003,17 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
         rowptr[ui + 1] = r0;
     }
     pl.ngroups = ng;
+    pl.arrow = structured && h->arrow_opt &&
+               build_arrow(rowkp.data(), rowptr, Ks.data(), pl.nobj, reinterpret_cast<ObjArrow*>(hi + o_arrow),
+                           reinterpret_cast<int2*>(hi + o_range), hi + o_kprows, &pl.Kmax, &pl.rows_max);
+    if (pl.arrow) { rc = objects_scratch(h, &pl); if (rc != ORCVIO_OK) return rc; }   // (room for the arrow factors)
     // device views of the arena
     double* dd = reinterpret_cast<double*>(h->d_obj_in);
     int* di = reinterpret_cast<int*>(h->d_obj_in + nd * 8);
     pl.d_hx = dd; pl.d_hf = dd + rows * 6;
-    pl.d_ridx = di; pl.d_rowptr = di + rows; pl.d_groups = reinterpret_cast<ObjGroup*>(di + rows + pl.nobj + 1);
-    HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (rows + pl.nobj + 1 + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
+    pl.d_ridx = di + o_ridx; pl.d_rowptr = di + o_rowptr; pl.d_groups = reinterpret_cast<ObjGroup*>(di + o_groups);
+    pl.d_arrow = reinterpret_cast<ObjArrow*>(di + o_arrow); pl.d_kp_range = reinterpret_cast<int2*>(di + o_range); pl.d_kp_rows = di + o_kprows;
+    HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (o_groups + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
     return objects_pipeline(h, s, dst, pl);
 }
 
@@ -1891,7 +2025,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
                                           double* d_dst, int32_t* dof_out, void* stream) {
     if (!h || !flags || !fl || n_tracks < 0 || (n_tracks > 0 && !tracks)) { g_last_error = "objects_local_tracks: null argument"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    { const int rp = objects_problem(h, flags, n_clones, "objects_local_tracks"); if (rp != ORCVIO_OK) return rp; }
+    { const int rp = objects_problem(h, flags, n_clones, P, "objects_local_tracks"); if (rp != ORCVIO_OK) return rp; }
     const int N = n_clones, NAP = h->NAP;
     typedef ObjUse Use;
     std::vector<Use>& use = h->obj_use;
@@ -1941,21 +2075,29 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     }
     int rc = objects_scratch(h, &pl);
     if (rc != ORCVIO_OK) return rc;
-    // staging arena: [track data (doubles) | kernel arguments (doubles) | frame_clone, frame_row0 per track | ridx | rowptr | groups]
+    // staging arena: [track data (doubles) | kernel arguments (doubles)], then ints [frame_clone, frame_row0 per track | ridx |
+    // rowptr | arrows | kp ranges | kp_rows | groups]
     static_assert(sizeof(ObjEvalArgs) % sizeof(double) == 0, "ObjEvalArgs is copied as doubles");
     const size_t arg_dbl = sizeof(ObjEvalArgs) / sizeof(double);
     const size_t args_off = nd;
     nd += arg_dbl * use.size();
     const size_t rows = (size_t)pl.rows_tot;
-    const size_t ni_tot = ni + rows + (size_t)pl.nobj + 1 + (size_t)4 * pl.nobj * N;
+    size_t sumK = 0;
+    for (const Use& u : use) sumK += (size_t)tracks[u.t].n_keypoints;
+    const size_t o_ridx = ni, o_rowptr = o_ridx + rows, o_arrow = o_rowptr + pl.nobj + 1, o_range = o_arrow + (size_t)4 * pl.nobj,
+                 o_kprows = o_range + 2 * sumK, o_groups = o_kprows + rows, ni_tot = o_groups + (size_t)4 * pl.nobj * N;
     if ((rc = obj_stage_reserve(h, nd * 8 + ni_tot * 4)) != ORCVIO_OK) return rc;
     double* hd = reinterpret_cast<double*>(h->h_obj_stage);
     int* hi = reinterpret_cast<int*>(h->h_obj_stage + nd * 8);
     double* dd = reinterpret_cast<double*>(h->d_obj_in);
     int* di = reinterpret_cast<int*>(h->d_obj_in + nd * 8);
-    int* ridx = hi + ni;
-    int* rowptr = ridx + rows;
-    ObjGroup* groups = reinterpret_cast<ObjGroup*>(rowptr + pl.nobj + 1);
+    int* ridx = hi + o_ridx;
+    int* rowptr = hi + o_rowptr;
+    ObjGroup* groups = reinterpret_cast<ObjGroup*>(hi + o_groups);
+    std::vector<int>& rowkp = h->obj_rowkp;   // keypoint block of every row (-1: a bbox row) for the structured QR
+    rowkp.assign(rows, -1);
+    std::vector<int>& Ks = h->obj_Ks;
+    Ks.assign(pl.nobj, 0);
     int ng = 0;
     rowptr[0] = 0;
     for (size_t ui = 0; ui < use.size(); ++ui) {
@@ -1985,7 +2127,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
             int nv = 0;
             const double* zs = ob.frame_zs + (size_t)f * K * 2;
             for (int k = 0; k < K; ++k)
-                if (std::isfinite(zs[2 * k]) && std::isfinite(zs[2 * k + 1])) ++nv;
+                if (std::isfinite(zs[2 * k]) && std::isfinite(zs[2 * k + 1])) { rowkp[rr + 2 * nv] = k; rowkp[rr + 2 * nv + 1] = k; ++nv; }
             fr0[f] = rr;
             const int c = fc[f], nr = 2 * nv + 4;
             fnr[f] = nr;
@@ -2009,6 +2151,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
             }
         }
         rowptr[ui + 1] = rr;
+        Ks[ui] = K;
         ObjEvalArgs a;
         a.wTo = dd + u.off_d; a.shape = a.wTo + 16; a.kps = a.shape + 3; a.frame_wTc = a.kps + 3 * K;
         a.frame_zs = a.frame_wTc + (size_t)16 * F; a.frame_bbox = a.frame_zs + (size_t)2 * K * F;
@@ -2022,8 +2165,17 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
         std::memcpy(hd + args_off + arg_dbl * ui, &a, sizeof(a));
     }
     pl.ngroups = ng;
-    pl.d_ridx = di + ni; pl.d_rowptr = pl.d_ridx + rows; pl.d_groups = reinterpret_cast<ObjGroup*>(pl.d_rowptr + pl.nobj + 1);
-    HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (ni + rows + pl.nobj + 1 + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
+    pl.arrow = h->arrow_opt && build_arrow(rowkp.data(), rowptr, Ks.data(), pl.nobj, reinterpret_cast<ObjArrow*>(hi + o_arrow),
+                                           reinterpret_cast<int2*>(hi + o_range), hi + o_kprows, &pl.Kmax, &pl.rows_max);
+    if (pl.arrow) {   // room for the arrow factors (the row arrays the kernel arguments point at do not move: same sizes)
+        double* keep_objH = h->d_objH; int* keep_obj_i = h->d_obj_i;
+        rc = objects_scratch(h, &pl);
+        if (rc != ORCVIO_OK) return rc;
+        if (h->d_objH != keep_objH || h->d_obj_i != keep_obj_i) { g_last_error = "objects_local_tracks: scratch moved"; return ORCVIO_ERR_HIP; }
+    }
+    pl.d_ridx = di + o_ridx; pl.d_rowptr = di + o_rowptr; pl.d_groups = reinterpret_cast<ObjGroup*>(di + o_groups);
+    pl.d_arrow = reinterpret_cast<ObjArrow*>(di + o_arrow); pl.d_kp_range = reinterpret_cast<int2*>(di + o_range); pl.d_kp_rows = di + o_kprows;
+    HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (o_groups + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_object_rows_batch, dim3(Fmax, (unsigned)use.size()), dim3(64), 0, s,
                        reinterpret_cast<const ObjEvalArgs*>(dd + args_off));
     HIPCHK(hipGetLastError());
@@ -2046,18 +2198,18 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
     if (rc != ORCVIO_OK) return rc;
     prof_mark(h, s, "k_gram_reduce");
     // Kalman solve in square-root form, gate, gated write-back
-    HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
+    if (h->prior_forked) HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
     prof_mark(h, s, "join chol(P) (side stream)");
     for (int st = ST_FORM_U; st <= ST_TRSM && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
     if (rc != ORCVIO_OK) return rc;
     prof_mark(h, s, "k_gemm(U)+k_gemm(M)+k_potrf_solve(M)");
     // table value below 500 dof, on the fly above (:1962-1968); dof 0 (no usable object anywhere) can never pass
     const double thr = dof_total > 0 ? orcvio_msckf_chi2_quantile(dof_total, h->flags.chi2_prob) : -1.0;
-    hipLaunchKernelGGL(k_obj_gate, dim3(1), dim3(64), 0, s, h->d_A, NAP, NA, h->d_Z, h->ldz, n, sigma2, thr, h->d_obj_gamma, h->d_obj_accept);
+    hipLaunchKernelGGL(k_obj_gate, dim3(1), dim3(64), 0, s, h->d_A, NAP, NA, h->d_Z, h->ldz, n, h->kf, sigma2, thr, h->d_obj_gamma, h->d_obj_accept);
     HIPCHK(hipGetLastError());
     rc = launch_solve_stage(h, s, ST_FINISH);
     prof_mark(h, s, "k_obj_gate+k_finish_sqrt");
-    if (rc == ORCVIO_OK) h->ran = true;
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = true; }
     return rc;
 }
 
@@ -2456,6 +2608,7 @@ int32_t orcvio_msckf_cov_set(orcvio_msckf_handle* h, int32_t n, const double* P)
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpy(h->d_Pres, P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
     h->res_n = n;
+    h->fac_valid = false;   // a new covariance: its factor is not known
     return ORCVIO_OK;
 }
 
@@ -2484,6 +2637,7 @@ int32_t orcvio_msckf_cov_propagate(orcvio_msckf_handle* h, int32_t leg, const do
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));   // Phi and Q are caller memory
     std::swap(h->d_Pres, h->d_Ptmp);
+    h->fac_valid = false;   // P_LL <- Phi P_LL Phi^T + Q: the factor of the sum is not a row operation on S
     return ORCVIO_OK;
 }
 
@@ -2497,6 +2651,14 @@ int32_t orcvio_msckf_cov_augment(orcvio_msckf_handle* h) {
     HIPCHK(hipGetLastError());
     std::swap(h->d_Pres, h->d_Ptmp);
     h->res_n = m;
+    if (h->fac_valid && h->fac_n == n) {   // the new clone's rows of S are copies of the IMU's (theta, p) rows
+        const int ldo = round_up(m + 1, 16);
+        hipLaunchKernelGGL(k_fac_augment, dim3((h->fac_k * m + 255) / 256), dim3(256), 0, h->stream, h->d_Sres, h->fac_ld, h->fac_k, n,
+                           n - h->n_extra, h->d_Stmp, ldo);
+        HIPCHK(hipGetLastError());
+        std::swap(h->d_Sres, h->d_Stmp);
+        h->fac_n = m; h->fac_ld = ldo;
+    } else h->fac_valid = false;
     return ORCVIO_OK;
 }
 
@@ -2518,6 +2680,14 @@ int32_t orcvio_msckf_cov_remove_clones(orcvio_msckf_handle* h, int32_t leg, cons
     HIPCHK(hipMemcpyAsync(h->d_covmap, map.data(), sizeof(int) * m, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_cov_remove, dim3((m * m + 255) / 256), dim3(256), 0, s, h->d_Pres, n, h->d_covmap, m, h->d_Ptmp);
     HIPCHK(hipGetLastError());
+    if (h->fac_valid && h->fac_n == n) {   // deleting states deletes rows of S
+        const int ldo = round_up(m + 1, 16);
+        hipLaunchKernelGGL(k_fac_remove, dim3((h->fac_k * m + 255) / 256), dim3(256), 0, s, h->d_Sres, h->fac_ld, h->fac_k, h->d_covmap, m,
+                           h->d_Stmp, ldo);
+        HIPCHK(hipGetLastError());
+        std::swap(h->d_Sres, h->d_Stmp);
+        h->fac_n = m; h->fac_ld = ldo;
+    } else h->fac_valid = false;
     HIPCHK(hipStreamSynchronize(s));   // map is a local
     std::swap(h->d_Pres, h->d_Ptmp);
     h->res_n = m;
@@ -2528,9 +2698,18 @@ int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h) {
     if (!h || !h->ran) { g_last_error = "cov_commit: no finished update"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->last_stream ? h->last_stream : h->stream;
-    HIPCHK(hipMemcpyAsync(h->d_Pres, h->d_Pout, sizeof(double) * (size_t)h->n * h->n, hipMemcpyDeviceToDevice, s));
+    const int n = h->n, kf = h->kf;
+    if (h->factor_opt) {   // S+ = sigma Z^T (or the prior's own factor if a gated object update was rejected): read before Pres changes
+        const PriorFactor pf = prior_factor(h);
+        hipLaunchKernelGGL(k_fac_commit, dim3((kf * n + 255) / 256), dim3(256), 0, s, h->d_Z, h->ldz, kf, n, h->flags.noise_feature,
+                           h->last_update_objects ? h->d_obj_accept : (const int*)nullptr, pf.base, pf.sLi, pf.sLj, h->d_Stmp, h->ldz);
+        HIPCHK(hipGetLastError());
+        std::swap(h->d_Sres, h->d_Stmp);
+        h->fac_n = n; h->fac_k = kf; h->fac_ld = h->ldz; h->fac_valid = true;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_Pres, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
     if (s != h->stream) HIPCHK(hipStreamSynchronize(s));   // the other cov_* calls run on the handle's own stream
-    h->res_n = h->n;
+    h->res_n = n;
     return ORCVIO_OK;
 }
 

@@ -1693,6 +1693,7 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
 // ---------------------------------------------------------------------------------------
 struct FrontPotrfArgs {
     const double* X; int ldx; int n; double tol_rel; double* R; int ldr; double* Dinv; int* info;
+    int skip;   // the prior's factor is resident (orcvio_msckf_cov_commit): workgroup 0 has nothing to do
 };
 // The compression (both Grams, then the assembly of A) can run in the same launch: the feature workgroups meet at a
 // device-wide counter (they are all resident: the launch has at most as many workgroups as the device has CUs, one
@@ -1733,6 +1734,7 @@ template <int NPASS, int NSLOT>
 __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int team_doubles, FrontGramArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (blockIdx.x == 0) {
+        if (q.skip) return;
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[0] = wall_clock64();
         potrf_reg_body<NSLOT, false>(smem, q.X, q.ldx, q.n, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, 0, 0, nullptr, nullptr, 1, 0);
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[6] = wall_clock64();
@@ -2261,18 +2263,18 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
     if (lost && l == 0) atomicAdd(lost_flag, 1);   // reported as an error by the host
 }
 
-// P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (n x (n+1), ldz).  One workgroup per lower
+// P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (kdim x (n+1), ldz).  One workgroup per lower
 // tile, split-K over its 4 wavefronts (as k_gemm).
-__global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, double s2,
+__global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, int kdim, double s2,
                                                      double* __restrict__ P_out, double* __restrict__ dx,
                                                      const int* __restrict__ apply = nullptr, const double* __restrict__ P = nullptr) {
     __shared__ double sPart[3][4][64];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     int bi, bj;
     tile_from_linear(blockIdx.x, bi, bj);
-    const int KS = ((n + 15) >> 4) << 2;
+    const int KS = ((kdim + 15) >> 4) << 2;   // Z is kdim x (n + 1): kdim = dimension of M (= n unless a resident factor is used)
     const int k0 = wave * KS;
-    const int Kw = (n - k0 < KS) ? (n - k0) : KS;
+    const int Kw = (kdim - k0 < KS) ? (kdim - k0) : KS;
     d4 acc = tile_product(Z + (size_t)k0 * ldz, 1, ldz, Z + (size_t)k0 * ldz, ldz, 1, n + 1, n + 1, Kw, 16 * bi, 16 * bj, l);
     if (wave > 0) {
 #pragma unroll
@@ -2398,12 +2400,260 @@ __global__ __launch_bounds__(256) void k_obj_assemble_B(const double* __restrict
     dst[idx] = s;
 }
 
+// ---- the triangular factor of Hf by STRUCTURED HOUSEHOLDER QR (no Gram of Hf) ------------------------------------------
+// Y = R^-T C needs the triangular factor R of Hf = Q R.  chol(Hf^T Hf) squares the condition number, and Hf of a real
+// object is badly conditioned by construction: a keypoint row is invariant under "move the object, move every keypoint
+// back" (a gauge of the keypoint rows that only the four bbox rows per frame break), so cond(Hf) ~ 1e8 on the reference's
+// own data (src/tests/data/one_car: 2.5e8) and the Gram loses that direction altogether -- delta_x off by 10 %.  The
+// reference takes the left nullspace from a full-U JacobiSVD (math_utils.hpp:287-312), accurate to cond * eps.
+// Hf is an ARROW matrix (include/orcvio/obj/ObjectLM.h:117-123): columns [pose 6 | shape 3 | keypoint k: 3 each], a
+// keypoint row touches the border (pose, shape) and ITS keypoint's block only, a bbox row the border only.  So:
+//   phase B  one wavefront per keypoint: Householder QR (three reflectors, LAPACK dgeqr2 convention) of its m x 3 block
+//            (m <= 128 rows, two per lane), applied to the nine border columns of the same rows: R_kk (3 x 3), R_kb
+//            (3 x 9), and the rows' border part after elimination (back into LDS)
+//   phase C  the whole workgroup: Householder QR of the eliminated border (all rows x 9, in LDS): R_b (9 x 9)
+// R = [[blockdiag R_kk, R_kb], [0, R_b]] up to the column order.  k_obj_arrow_solve then forms Y = R^-T C by forward
+// substitution, one thread per column of C.  A pivot that is zero to rounding (a keypoint seen in one frame only, an exactly
+// dependent column) is dropped (its row of Y is zero) and counted.
+struct ObjArrow { int row0, rows, K, kp_off; };   // rows [row0, row0 + rows) of the update; K keypoint blocks; kp_off: first
+                                                  // entry of this object in kp_range
+// Rout per object (stride arrow_stride(Kmax)): [K][3 x 3 R_kk | 3 x 9 R_kb] , then 9 x 9 R_b, then the pivot tolerance
+__host__ __device__ inline int arrow_stride(int Kmax) { return 36 * Kmax + 81 + 3; }
+__device__ __forceinline__ double block_sum512(double x, double* sRed, int tid) {   // all 512 threads; deterministic order
+    x = wave_sum(x);
+    __syncthreads();
+    if ((tid & 63) == 0) sRed[tid >> 6] = x;
+    __syncthreads();
+    return ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]));
+}
+__global__ __launch_bounds__(512) void k_obj_arrow_qr(const ObjArrow* __restrict__ objs, const int2* __restrict__ kp_range,
+                                                      const int* __restrict__ kp_rows, const double* __restrict__ HfR, int ldf,
+                                                      int Kmax, double* __restrict__ Rout, int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sB[];   // [rows][9] border part of every row, then 16 doubles of scratch
+    const ObjArrow ob = objs[blockIdx.x];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    double* sRed = sB + (size_t)ob.rows * 9;
+    double* Ro = Rout + (size_t)blockIdx.x * arrow_stride(Kmax);
+    for (int i = tid; i < ob.rows * 9; i += 512) {
+        const int r = i / 9, c = i - 9 * r;
+        sB[i] = HfR[(size_t)(ob.row0 + r) * ldf + c];
+    }
+    __syncthreads();
+    // ---- phase B: the keypoint blocks -----------------------------------------------------------------------------------
+    for (int k = wave; k < ob.K; k += 8) {
+        const int2 rg = kp_range[ob.kp_off + k];
+        const int m = rg.y - rg.x;   // <= 128 (host-checked)
+        int rl[2];
+        bool in[2];
+        double a[2][3], b[2][9];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pos = lane + 64 * u;
+            in[u] = pos < m;
+            rl[u] = in[u] ? kp_rows[rg.x + pos] - ob.row0 : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const double v = HfR[(size_t)(ob.row0 + rl[u]) * ldf + 9 + 3 * k + c]; a[u][c] = in[u] ? v : 0.0; }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) { const double v = sB[rl[u] * 9 + c]; b[u][c] = in[u] ? v : 0.0; }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // rows below the pivot (list positions > j): g_c = sum a_j * col_c over them, for col = a_j (norm^2), a_c>j, b_0..8
+            const bool below0 = lane > j, below1 = true;   // slot 0: position = lane; slot 1: position = lane + 64 > j
+            const double x0 = (in[0] && below0) ? a[0][j] : 0.0, x1 = (in[1] && below1) ? a[1][j] : 0.0;
+            double g[12];
+            g[0] = x0 * x0 + x1 * x1;
+#pragma unroll
+            for (int c = 1; c < 3; ++c) g[c] = (c > j) ? x0 * a[0][c] + x1 * a[1][c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) g[3 + c] = x0 * b[0][c] + x1 * b[1][c];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) g[q] = wave_sum(g[q]);
+            const double alpha = bcast_lane(a[0][j], j);   // pivot entry (0 if the list is shorter than j + 1: a is 0 there)
+            double tau = 0.0, beta = alpha, scale = 0.0;
+            if (g[0] > 0.0) {   // dlarfg: beta = -sign(alpha) ||x||, tau = (beta - alpha) / beta, v = x / (alpha - beta), v_pivot = 1
+                const double nrm = sqrt(alpha * alpha + g[0]);
+                beta = alpha >= 0.0 ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            const double v0 = x0 * scale, v1 = x1 * scale;   // the reflector below the pivot (0 outside)
+            const bool piv = lane == j;                       // slot 0 of lane j is the pivot row
+#pragma unroll
+            for (int c = 1; c < 3; ++c) {
+                if (c > j) {
+                    const double w = tau * (bcast_lane(a[0][c], j) + scale * g[c]);
+                    a[0][c] -= piv ? w : w * v0;
+                    a[1][c] -= w * v1;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const double w = tau * (bcast_lane(b[0][c], j) + scale * g[3 + c]);
+                b[0][c] -= piv ? w : w * v0;
+                b[1][c] -= w * v1;
+            }
+            if (piv) a[0][j] = beta;
+            if (lane > j) a[0][j] = 0.0;
+            a[1][j] = 0.0;
+        }
+        // R_kk rows 0..2 and R_kb rows 0..2 live in slot 0 of lanes 0..2; the other rows go back to the border
+        if (lane < 3) {
+            double* o = Ro + 36 * k + 12 * lane;   // row `lane`: [3 of R_kk | 9 of R_kb]
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = (c >= lane && lane < m) ? a[0][c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) o[3 + c] = lane < m ? b[0][c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (in[u]) {
+                const bool consumed = (u == 0 && lane < 3);
+#pragma unroll
+                for (int c = 0; c < 9; ++c) sB[rl[u] * 9 + c] = consumed ? 0.0 : b[u][c];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase C: the border (all rows x 9, rows tid, tid + 512, ...) --------------------------------------------------
+    constexpr int RPT = 4;   // rows per thread: up to 2048 rows per object (host-checked)
+    double x[RPT][9];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + 512 * q;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) x[q][c] = r < ob.rows ? sB[r * 9 + c] : 0.0;
+    }
+    double pmax = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        // pivot row j is held by thread j (q = 0); publish it
+        __syncthreads();
+        if (tid == j) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sRed[8 + c] = x[0][c];
+        }
+        __syncthreads();
+        double pr[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) pr[c] = sRed[8 + c];
+        const double alpha = (j < ob.rows) ? pr[j] : 0.0;
+        double xb[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) xb[q] = (tid + 512 * q > j) ? x[q][j] : 0.0;   // (rows beyond ob.rows hold zeros)
+        double g[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            double sacc = 0.0;
+            if (c >= j) {
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) sacc += xb[q] * x[q][c];
+            }
+            g[c] = sacc;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+            if (c >= j) g[c] = block_sum512(g[c], sRed, tid);
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (g[j] > 0.0) {
+            const double nrm = sqrt(alpha * alpha + g[j]);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            if (c > j) {
+                const double w = tau * (pr[c] + scale * g[c]);
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int r = tid + 512 * q;
+                    if (r == j) x[q][c] -= w; else x[q][c] -= w * (xb[q] * scale);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + 512 * q;
+            if (r == j) x[q][j] = beta; else if (r > j) x[q][j] = 0.0;
+        }
+        pmax = fmax(pmax, fabs(beta));
+    }
+    // R_b row j = row j of the reduced border (thread j, q = 0)
+    if (tid < 9) {
+        double* o = Ro + 36 * Kmax + 9 * tid;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) o[c] = (c >= tid && tid < ob.rows) ? x[0][c] : 0.0;
+    }
+    // pivot tolerance: a pivot below 1e-13 of the largest one is rounding noise of an exactly dependent column
+    if (tid == 0) {
+        double mx = pmax;
+        for (int k = 0; k < ob.K; ++k)
+            for (int j = 0; j < 3; ++j) mx = fmax(mx, fabs(Ro[36 * k + 12 * j + j]));
+        Ro[36 * Kmax + 81] = 1e-13 * mx;
+    }
+    (void)info;
+}
+// Y_o = R^-T C_o for the arrow factor: one thread per column of C (window columns 0..NA-1 from Cd, column NA = Hf^T r
+// from the compact Gram's residual row).  Rows of Y in the order of Hf's columns; dropped pivots give zero rows.
+__global__ __launch_bounds__(256) void k_obj_arrow_solve(const ObjArrow* __restrict__ objs, const double* __restrict__ Rin, int Kmax,
+                                                         const double* __restrict__ Cd, int NOP, int NAP, int NA,
+                                                         const double* __restrict__ Gff, int ldf, int no_max,
+                                                         double* __restrict__ Y, int* __restrict__ info) {
+    const int o = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+    if (col > NA) return;
+    const ObjArrow ob = objs[o];
+    const double* Ro = Rin + (size_t)o * arrow_stride(Kmax);
+    const double tol = Ro[36 * Kmax + 81];
+    const double* Co = Cd + (size_t)o * NOP * NAP;
+    const double* hr = Gff + (size_t)o * ldf * ldf + (size_t)no_max * ldf;   // row no_max of the compact Gram: (Hf^T r)^T
+    double* Yo = Y + (size_t)o * NOP * NAP;
+    auto Cget = [&](int i) { return col < NA ? Co[(size_t)i * NAP + col] : hr[i]; };
+    double cb[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cb[i] = Cget(i);
+    int dropped = 0;
+    for (int k = 0; k < ob.K; ++k) {
+        const double* Rk = Ro + 36 * k;   // rows j: [R_kk(j, 0..2) | R_kb(j, 0..8)]
+        double y[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double t = Cget(9 + 3 * k + j);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < j) t -= Rk[12 * i + j] * y[i];
+            const double p = Rk[12 * j + j];
+            const bool ok = fabs(p) > tol;
+            dropped += ok ? 0 : 1;
+            y[j] = ok ? t / p : 0.0;
+            Yo[(size_t)(9 + 3 * k + j) * NAP + col] = y[j];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) cb[c] -= Rk[3 + c] * y[0] + Rk[12 + 3 + c] * y[1] + Rk[24 + 3 + c] * y[2];
+    }
+    const double* Rb = Ro + 36 * Kmax;
+    double yb[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double t = cb[j];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            if (i < j) t -= Rb[9 * i + j] * yb[i];
+        const double p = Rb[9 * j + j];
+        const bool ok = fabs(p) > tol;
+        dropped += ok ? 0 : 1;
+        yb[j] = ok ? t / p : 0.0;
+        Yo[(size_t)j * NAP + col] = yb[j];
+    }
+    if (col == 0 && dropped > 0 && info) atomicAdd(info, dropped);
+}
+
 // gamma = (|r'|^2 - |z|^2) / s2 for the joint object block (identity in DESIGN.md), chi-square gate and the
 // NaN check of src/orcvio.cpp:2172-2182.  A[NA][NA] = |r'|^2, z = Z[:, n].
-__global__ void k_obj_gate(const double* __restrict__ A, int NAP, int NA, const double* __restrict__ Z, int ldz, int n, double s2,
+__global__ void k_obj_gate(const double* __restrict__ A, int NAP, int NA, const double* __restrict__ Z, int ldz, int n, int kdim, double s2,
                            double chi2_thr, double* __restrict__ gamma, int* __restrict__ accept) {
     double zz = 0.0;
-    for (int i = threadIdx.x; i < n; i += 64) { const double v = Z[(size_t)i * ldz + n]; zz += v * v; }
+    for (int i = threadIdx.x; i < kdim; i += 64) { const double v = Z[(size_t)i * ldz + n]; zz += v * v; }
     zz = wave_sum(zz);
     if (threadIdx.x == 0) {
         const double g = (A[(size_t)NA * NAP + NA] - zz) / s2;

@@ -40,3 +40,42 @@ def subset_window(win, clone_ids):
     import dataclasses
     return dataclasses.replace(win, obs_ptr=np.asarray(ptr, dtype=np.int32), obs_clone=win.obs_clone[keep].copy(),
                                obs_z=win.obs_z[keep].copy(), obs_zvel=win.obs_zvel[keep].copy())
+
+
+def object_rows_reference(win, obj, obj_left, new_bbox, vio_left):
+    """Rows of one object track in window coordinates through the mirror (functor rows + constructObjectResidualJacobians)."""
+    from oracle import mirror_objects as mo
+    res, Hf, Jc, counts = mo.object_rows(obj.wTo, obj.shape, obj.kps, obj.frames, obj_left, new_bbox)
+    f2c = [fr['clone'] for fr in obj.frames]
+    return mo.construct_object_residual_jacobians(Jc, f2c, Hf, res, counts, [fr['wTc'] for fr in obj.frames],
+                                                  win.R_b2c[0], win.t_c_b[0], vio_left, win.flags.leg_dim, win.N)
+
+
+def objects_update_reference(win, objs, P, obj_left=True, new_bbox=False, vio_left=0):
+    """The object update of System::processObjects -> removeLostObjects with per-object projection (SURVEY note N3) on the
+    prior P: dict(gamma, accept, dof, dx, P_new, blocks) -- the mirror's literal arithmetic (full-U nullspace per object,
+    QR of the stack, S, K, (I - KH) P)."""
+    from oracle import mirror
+    blocks, Hp, rp = [], [], []
+    for ob in objs:
+        Hx, Hf, r, rc, hx6 = object_rows_reference(win, ob, obj_left, new_bbox, vio_left)
+        if Hx.shape[0] <= Hf.shape[1]:
+            continue
+        blocks.append(dict(row_clone=rc, Hx6=hx6, Hf=Hf, res=r))
+        ok, H1, r1 = mirror.nullspace_project_svd(Hf, Hx, r)
+        Hp.append(H1); rp.append(r1)
+    n = P.shape[0]
+    if not Hp:
+        return dict(gamma=float('nan'), accept=0, dof=0, dx=np.zeros(n), P_new=P.copy(), blocks=blocks)
+    H = np.vstack(Hp); r = np.concatenate(rp)
+    s2 = win.flags.noise_feature ** 2
+    Q1, R = np.linalg.qr(H)
+    r1 = Q1.T @ r
+    gamma = float(r1 @ np.linalg.solve(R @ P @ R.T + s2 * np.eye(R.shape[0]), r1) + (r @ r - r1 @ r1) / s2)
+    accept = int(gamma < mirror.chi2_threshold(H.shape[0], win.flags.chi2_prob))
+    if accept:
+        Ht, rt = mirror.qr_compress(H, r)
+        dx, K, Pn = mirror.measurement_update(Ht, rt, P, s2)
+    else:
+        dx, Pn = np.zeros(n), P.copy()
+    return dict(gamma=gamma, accept=accept, dof=H.shape[0], dx=dx, P_new=Pn, blocks=blocks)
