@@ -88,6 +88,10 @@ struct orcvio_msckf_handle {
     bool factor_opt = true;             // ORCVIO_OPT_RESIDENT_FACTOR
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
     bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P
+    int last_run_kind = 0;              // 0: run_update (single GPU), 1: run_local / run_finish (staged or sharded), 2: objects
+    bool front_retry_forked = false;    // (download: the fused front end lost a hand-off; re-running on the forked path)
+    int front_spin_limit = 1 << 19;    // polls before a workgroup of k_front gives up at the device-wide counter (tens of ms)
+    int front_fallbacks = 0;            // how often that happened (orcvio_msckf_debug_read 'fallbacks')
     bool last_update_objects = false;   // the last finished update was a (gated) object update
     bool prior_forked = false;          // the Cholesky of the prior runs on the side stream (ev_side must be joined)
     int kf = 0;                         // columns of the prior's factor = dimension of M (n unless a resident factor is used)
@@ -349,6 +353,7 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
     h->n_cus = prop.multiProcessorCount;
     if (const char* e = getenv("ORCVIO_FUSED_SOLVE")) h->fused_solve = atoi(e);   // diagnostics: defaults of the options
     if (const char* e = getenv("ORCVIO_FUSED_FRONT")) h->front_fused = atoi(e);
+    if (const char* e = getenv("ORCVIO_FRONT_SPIN")) h->front_spin_limit = atoi(e);
     h->maxN = max_clones;
     h->maxF = max_features;
     h->maxObs = max_observations;
@@ -682,7 +687,8 @@ static int launch_feature(orcvio_msckf_handle* h, hipStream_t s) {
 // CU's 160 KB.  Otherwise the caller forks the factorisation to the side stream and launches k_feature.
 static bool front_fused_active(const orcvio_msckf_handle* h) {
     if (!h->front_fused || !h->reg_path || h->F < 1) return false;
-    if (1 + (h->F + 1) / 2 > h->n_cus) return false;
+    if (1 + (h->F + 1) / 2 > h->n_cus) return false;   // one workgroup per CU (by LDS size), all resident at once
+    if (h->front_retry_forked) return false;   // a hand-off of the fused launch timed out: this update is re-run on the forked path
     const size_t team = feat_lds_bytes(h->Mmax, h->NAP, h->N);
     const size_t lds = 2 * team > sizeof(double) * POTRF_LDS_DOUBLES ? 2 * team : sizeof(double) * POTRF_LDS_DOUBLES;
     return lds <= (size_t)160 * 1024 && (h->NAP + 63) / 64 <= 4;
@@ -712,7 +718,7 @@ static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_
     h->front_chunks = g.chunks;
     g.rows_per_chunk = round_up((t3rows + g.chunks - 1) / g.chunks, 4);
     g.Gpart = h->d_Gpart; g.S = h->d_S; g.clone_rows = h->d_clone_ptr; g.counter = h->d_sync; g.lost = h->d_info + 8;
-    g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15; g.plus = extra_gram(h);
+    g.A_dst = compress_dst; g.cb0 = h->flags.leg_dim - 15; g.plus = extra_gram(h); g.spin_limit = h->front_spin_limit;
     if (g.enabled && g.chunks > h->gram_chunks_cap) { g_last_error = "launch_front: too many row chunks"; return ORCVIO_ERR_CAPACITY; }
     dim3 grid(1 + (h->F + 1) / 2), block(512);
     // the window width fixes both template arguments: NPASS = ceil(NAP/64) column passes, and enough register slots
@@ -949,7 +955,7 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     std::memcpy(&bits, &sg, 8); mix(bits);
     double cp = h->flags.chi2_prob;
     std::memcpy(&bits, &cp, 8); mix(bits);
-    mix(h->use_factor); mix(h->kf); mix(h->fac_ld); mix(h->graph_epoch); mix(h->ekf_idp); mix(h->ekf_eval); mix(h->ekf_cap); mix(h->dense_cap);
+    mix(h->front_retry_forked); mix(h->front_spin_limit); mix(h->use_factor); mix(h->kf); mix(h->fac_ld); mix(h->graph_epoch); mix(h->ekf_idp); mix(h->ekf_eval); mix(h->ekf_cap); mix(h->dense_cap);
     mix((unsigned long long)(size_t)h->d_ekf_i); mix((unsigned long long)(size_t)h->d_ekf_d); mix((unsigned long long)(size_t)h->d_ekf_E);
     mix((unsigned long long)(size_t)h->d_slam); mix((unsigned long long)(size_t)h->d_dense); mix((unsigned long long)(size_t)h->d_Gekf);
     mix((unsigned long long)(size_t)h->d_Hs); mix((unsigned long long)(size_t)h->d_P);
@@ -1039,7 +1045,7 @@ int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, 
         for (int st = ST_FORM_U; st < ST_COUNT && r == ORCVIO_OK; ++st) r = launch_solve_stage(h, s, st);
         return r;
     });
-    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; }
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; h->last_run_kind = 1; }
     return rc;
 }
 
@@ -1517,7 +1523,7 @@ int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }   // (a copy of the previous results nobody fetched)
     int rc = run_with_graph(h, h->g_update, launch_signature(h, s, nullptr, 0), s, [&](bool) { return enqueue_update(h, s); });
     h->A_deferred = front_defers_assembly(h);   // (a replayed graph does not pass through enqueue_update)
-    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; }
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; h->last_run_kind = 0; }
     return rc;
 }
 
@@ -1595,9 +1601,20 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
     if (res->gamma && F > 0) std::memcpy(res->gamma, gam, sizeof(double) * F);
     int info[9] = {0};
     std::memcpy(info, so, sizeof(int) * 9);
-    if (info[8] != 0) {   // a wait inside a launch gave up (a solver wavefront of k_potrf_solve, or a workgroup of k_front at its device-wide counter): never on a healthy device
+    if (info[8] != 0) {   // a wait inside a launch gave up: a workgroup of k_front at its device-wide counter (somebody else's kernel
+                          // held CUs it needed), or a solver wavefront of k_potrf_solve
         HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
         HIPCHK(hipMemset(h->d_sync, 0, 256));
+        if (h->last_run_kind == 0 && !h->front_retry_forked) {
+            // single-GPU update: run it again, on the forked path (plain launches, no in-launch device-wide wait), inside this call
+            h->front_retry_forked = true;
+            h->front_fallbacks++;
+            int rr = orcvio_msckf_run_update(h, h->last_stream);
+            if (rr == ORCVIO_OK) rr = download_enqueue(h, h->last_stream ? h->last_stream : h->stream, want_P);
+            h->front_retry_forked = false;
+            if (rr != ORCVIO_OK) return rr;
+            return orcvio_msckf_download(h, res);   // (a second time-out in the forked form is reported as an error below)
+        }
         g_last_error = "k_potrf_solve / k_front: an in-launch hand-off timed out";
         return ORCVIO_ERR_NOT_SPD;
     }
@@ -2209,7 +2226,7 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
     HIPCHK(hipGetLastError());
     rc = launch_solve_stage(h, s, ST_FINISH);
     prof_mark(h, s, "k_obj_gate+k_finish_sqrt");
-    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = true; }
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = true; h->last_run_kind = 2; }
     return rc;
 }
 
@@ -2922,6 +2939,11 @@ int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst
         case 6: src = h->d_Z; bytes = (size_t)h->n * h->ldz * sizeof(double); break;
         case 8: src = h->d_U; bytes = np2; break;
         case 9: src = h->d_sync; bytes = 256; break;   // k_front: counter + diagnostic time stamps
+        case 10: {   // how often an update was re-run on the forked path because the fused front end lost a hand-off
+            if ((size_t)max_bytes < sizeof(int32_t)) return ORCVIO_ERR_INVALID;
+            *reinterpret_cast<int32_t*>(dst) = h->front_fallbacks;
+            return ORCVIO_OK;
+        }
         case 7: {
             int32_t dims[8] = {h->n, h->NA, h->NAP, h->NP, h->m_tot, h->Mmax, h->ldz, h->reg_path ? 1 : 0};
             if ((size_t)max_bytes < sizeof(dims)) return ORCVIO_ERR_INVALID;
@@ -2932,6 +2954,17 @@ int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst
     }
     if ((size_t)max_bytes < bytes) { g_last_error = "debug_read: buffer too small"; return ORCVIO_ERR_INVALID; }
     if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return ORCVIO_OK;
+}
+
+// Test hook: hold `n_cus` compute units for `ms` milliseconds with a spinning kernel on the handle's SIDE stream (returns at once).
+int32_t orcvio_msckf_debug_occupy(orcvio_msckf_handle* h, int32_t n_cus, double ms) {
+    if (!h || n_cus < 1 || ms <= 0.0) return ORCVIO_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    static bool attr = false;
+    if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_debug_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(k_debug_occupy, dim3(n_cus), dim3(64), (size_t)150 * 1024, h->side, (unsigned long long)(ms * 1e5), h->d_info + 40);
+    HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
 

@@ -1707,8 +1707,9 @@ struct FrontGramArgs {
     int* lost;                    // incremented if a wait gives up (reported as an error by the host)
     double* A_dst; int cb0;
     const double* plus;           // optional Gram added to A (EKF-SLAM rows), lower tiles valid
+    int spin_limit;               // polls of the flag line before a waiting workgroup gives up (a few tens of ms)
 };
-__device__ __forceinline__ void front_grid_barrier(int* counter, int target, int* lost, unsigned long long* dbg = nullptr) {
+__device__ __forceinline__ void front_grid_barrier(int* counter, int target, int* lost, int spin_limit, unsigned long long* dbg = nullptr) {
     // Everything that crosses this barrier is written with write-through (sc1) stores and read with sc1 loads
     // (st_pub / ld_sel<true>), so no cache write-back or invalidate is needed: every wavefront waits for its own stores
     // to be acknowledged, one thread bumps the counter and polls it.  (A release/acquire fence pair per workgroup --
@@ -1722,10 +1723,11 @@ __device__ __forceinline__ void front_grid_barrier(int* counter, int target, int
         int* flag = counter + 32;
         const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == target - 1) __hip_atomic_store(flag, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else {   // bounded (~0.5 s): a workgroup that never arrives must not hang the GPU; the update is then flagged
+        else {   // bounded: a workgroup that never arrives (its CU is held by somebody else's kernel) must not hang the GPU;
+                 // the update is then flagged and the host re-runs it on the forked path (orcvio_msckf_download)
             int it = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && it < (1 << 22)) { __builtin_amdgcn_s_sleep(4); ++it; }
-            if (it >= (1 << 22) && lost) atomicAdd(lost, 1);
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && it < spin_limit) { __builtin_amdgcn_s_sleep(4); ++it; }
+            if (it >= spin_limit && lost) atomicAdd(lost, 1);
         }
     }
     __syncthreads();
@@ -1740,6 +1742,10 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[6] = wall_clock64();
         return;
     }
+    // (Persistent teams -- a loop over track pairs so that any track count stays in this launch -- were tried in round 2: with
+    // feature_body inside a loop the kernel spills 141 VGPRs and 2000 tracks took 273 us against 125 + 24 + 19 us for the forked
+    // k_feature / k_gram_pair / k_assemble_A, whose two workgroups per CU also keep more tracks in flight.  Not kept: beyond
+    // 2 (CUs - 1) tracks the update takes the forked form.)
     const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
     const int j = 2 * ((int)blockIdx.x - 1) + team;
     const int local = threadIdx.x & 255;
@@ -1753,7 +1759,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     unsigned long long* stamp = reinterpret_cast<unsigned long long*>(g.counter) + 8;   // diagnostic (bytes 64..): 100 MHz clock
 #define FRONT_STAMP(i) do { if (me == 0 && threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
     FRONT_STAMP(1);
-    front_grid_barrier(g.counter, nfb, g.lost);
+    front_grid_barrier(g.counter, nfb, g.lost, g.spin_limit);
     FRONT_STAMP(2);
     // ---- Grams: (lower tile, chunk) items of T3, then one item per clone of the sparse rows -----------------
     const int nb = p.NAP >> 4, ntiles = nb * (nb + 1) / 2;
@@ -1777,7 +1783,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     FRONT_STAMP(3);
     int phases = 2;
     if (g.enabled == 1) {   // (enabled == 2: the consumer, k_gemm_asmA, assembles A on the fly)
-        front_grid_barrier(g.counter, 2 * nfb, g.lost, me == 0 ? stamp + 7 : nullptr);
+        front_grid_barrier(g.counter, 2 * nfb, g.lost, g.spin_limit, me == 0 ? stamp + 7 : nullptr);
         FRONT_STAMP(4);
         // ---- A = scatter(S) - sum of the partial Grams --------------------------------------------------------
         for (int idx = me * 512 + (int)threadIdx.x; idx < p.NAP * p.NAP; idx += nfb * 512)
@@ -2660,6 +2666,16 @@ __global__ void k_obj_gate(const double* __restrict__ A, int NAP, int NA, const 
         *gamma = g;
         *accept = (g == g && g < chi2_thr) ? 1 : 0;   // NaN anywhere in the rows makes g NaN -> rejected
     }
+}
+
+// Test hook (tests/test_gpu_robustness.py): hold `gridDim.x` compute units for `ticks` of the 100 MHz wall clock (every
+// workgroup takes a whole CU's LDS), so that a co-resident launch next to it cannot get all of its workgroups resident.
+__global__ __launch_bounds__(64) void k_debug_occupy(unsigned long long ticks, int* sink) {
+    extern __shared__ double sOcc[];
+    const unsigned long long t0 = wall_clock64();
+    sOcc[threadIdx.x] = (double)threadIdx.x;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (sOcc[threadIdx.x] < 0.0) *sink = 1;
 }
 
 }  // namespace orcvio_amd

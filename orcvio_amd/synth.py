@@ -203,7 +203,7 @@ def make_new_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_fr
 
 def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,
                 flags: Flags | None = None, estimate_extrin: bool = False,
-                sigma_px: float | None = None, outlier_frac: float = 0.0) -> Window:
+                sigma_px: float | None = None, outlier_frac: float = 0.0, depth=(4.0, 12.0)) -> Window:
     """SURVEY.md Appendix A synthetic generator.
 
     track_len: None -> every feature seen in all N clones; int M -> contiguous
@@ -230,7 +230,7 @@ def make_window(N: int = 30, F: int = 400, seed: int = 0, track_len=None,
     t_c_w = t_b_w + np.einsum('nij,nj->ni', R_b2w, t_c_b)
 
     mid = N // 2
-    depth = rng.uniform(4.0, 12.0, F)
+    depth = rng.uniform(depth[0], depth[1], F)   # (far features: tiny parallax, a nearly rank-deficient H_f)
     xy = rng.uniform(-0.35, 0.35, (F, 2))
     p_c_mid = np.stack([xy[:, 0] * depth, xy[:, 1] * depth, depth], axis=1)
     p_true = p_c_mid @ R_c2w[mid].T + t_c_w[mid]

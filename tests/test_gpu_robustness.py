@@ -1,0 +1,64 @@
+"""Robustness of the fused front end (VERDICT r1 "weak: robustness"): k_front meets at an in-launch device-wide counter and
+therefore needs all its workgroups resident at once.  A kernel of somebody else holding compute units (RCCL on another stream,
+a second handle, a torch op) can strand part of them: the wait is bounded, and the update is then RE-RUN on the forked path
+inside the same call instead of being reported as an error."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from orcvio_amd import capi, synth
+from oracle import oracle
+from helpers import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _fallbacks(upd):
+    upd.lib.orcvio_msckf_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    v = C.c_int32(0)
+    assert upd.lib.orcvio_msckf_debug_read(upd.h, 10, C.byref(v), 4) == 0
+    return v.value
+
+
+def test_update_survives_a_kernel_that_holds_half_the_device(built):
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    try:
+        win = synth.config_window(2)
+        ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
+        good = upd.update_features(win)                      # warm: code objects loaded, graph not yet captured
+        assert rel(good['dx'], ref['dx']) < 1e-6 and _fallbacks(upd) == 0
+        upd.lib.orcvio_msckf_debug_occupy.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+        assert upd.lib.orcvio_msckf_debug_occupy(upd.h, 128, 400.0) == 0   # 128 CUs held for 0.4 s on another stream
+        t0 = time.perf_counter()
+        got = upd.update_features(win)                       # k_front cannot get its 201 workgroups resident
+        dt = time.perf_counter() - t0
+        assert np.array_equal(got['accept'], ref['accept'])
+        assert rel(got['dx'], ref['dx']) < 1e-6 and rel(got['P_new'], ref['P_new']) < 1e-6
+        assert _fallbacks(upd) == 1, 'the stranded launch should have been re-run on the forked path'
+        assert dt < 2.0
+        upd.sync()
+        time.sleep(0.5)                                      # the occupying kernel is gone: the fused path again, no fallback
+        again = upd.update_features(win)
+        assert rel(again['dx'], ref['dx']) < 1e-6 and _fallbacks(upd) == 1
+    finally:
+        upd.close()
+
+
+@pytest.mark.parametrize('F', [509, 510, 511, 2000])
+def test_track_counts_around_the_co_residency_limit(built, F):
+    """Up to 2 (CUs - 1) = 510 tracks the front end is ONE co-resident launch (k_front); beyond that the update takes the forked
+    form (k_feature, k_gram_pair, k_assemble_A with chol(P) on a side stream).  Same results either way."""
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    try:
+        win = synth.make_window(N=30, F=F, seed=F, flags=synth.Flags(use_larvio=1), outlier_frac=0.05)
+        fused = upd.update_features(win)
+        upd.set_fused_front(False)
+        forked = upd.update_features(win)
+        upd.set_fused_front(True)
+        assert np.array_equal(fused['accept'], forked['accept'])
+        assert rel(fused['gamma'], forked['gamma']) < 1e-12
+        assert rel(fused['dx'], forked['dx']) < 1e-10 and rel(fused['P_new'], forked['P_new']) < 1e-12
+    finally:
+        upd.close()
