@@ -342,6 +342,15 @@ def main():
                         runs.append(upd.profile_stages())
                     upd.set_stage_profile(False)
                     objects['resident']['stage_ms'] = {name: round(float(np.median([r[i][1] for r in runs])), 5) for i, (name, _) in enumerate(runs[0])}
+                    if not args.no_cpu_baseline:   # the same object update on one host core (oracle/object_oracle.c)
+                        from oracle import oracle as orc
+                        t_rows = time.perf_counter()
+                        blocks_c = [orc.object_rows_c(o, owin.R_b2c[0], owin.t_c_b[0], True, False, 0) for o in objs]
+                        t_rows = time.perf_counter() - t_rows
+                        cu = orc.objects_update_c(oflags, owin.N, blocks_c, owin.P)
+                        objects['cpu_baseline'] = dict(ms_per_update=(t_rows + cu['seconds']) * 1e3, cores=1, kind='port', accepted=cu['accept'],
+                                                       what='rows (C restatement of the CameraLM / ObjectLM functors) + per-object '
+                                                            'Householder projection on dense rows x n blocks + QR of the stack + update')
                     upd.upload(win)   # the feature tracks again for what follows
                 except Exception as e:   # never let the side measurement break the metric line
                     objects = dict(error=str(e))

@@ -160,8 +160,15 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * cond(Hf) eps -- Hf of a real object has cond ~ 1e8: the keypoint rows have a gauge that only the bbox rows break).  0, and
  * for rows whose Hf does not have that shape: chol(Hf^T Hf) (cond^2: directions below ~1e-8 of the largest are treated as
  * null; stats[7] counts them). */
+/* ORCVIO_OPT_REF_STACK_HF (default 0): compatibility with the reference's stacking of SEVERAL objects in one call.
+ * System::processObjects concatenates Hx, Hf and r of all objects vertically with Hf's 45 columns SHARED
+ * (ros_wrapper/src/orcvio/src/System.cpp:684-702) and removeLostObjects projects the whole stack against that single Hf
+ * (src/orcvio.cpp:2154-2193) -- the objects are treated as one object observed many times (SURVEY note N3; right for one
+ * object per call only).  0: every object is projected against its own Hf (block-diagonal Hf; equal to the reference whenever
+ * one object arrives).  1: the literal shared-Hf stack, dof = total rows - columns; all objects must have the same state size. */
 enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
-       ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6, ORCVIO_OPT_RESIDENT_FACTOR = 7, ORCVIO_OPT_OBJECT_QR = 8 };
+       ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6, ORCVIO_OPT_RESIDENT_FACTOR = 7, ORCVIO_OPT_OBJECT_QR = 8,
+       ORCVIO_OPT_REF_STACK_HF = 9 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* EKF-SLAM rows of the hybrid filter (existing SLAM features).  For every SLAM feature the current
@@ -274,7 +281,11 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
  * the state at which the rows are evaluated. */
 typedef struct orcvio_object_eval_flags {
     int32_t use_left_perturbation;      /* the object mapper's flag (ObjectInitNode.cpp:140)             */
-    int32_t use_new_bbox_residual;      /* use_new_bbox_residual_flag (:206); restated literally (note N8) */
+    int32_t use_new_bbox_residual;      /* use_new_bbox_residual_flag (:206).  1: the reference's rows LITERALLY -- its Jacobians take the
+                                           plane in the world frame (src/obj/ObjectResJacCam.cpp:405,446) although the residual uses the
+                                           object frame, and the shape derivative lacks -sign(b4) (src/obj/ObjectLM.cpp:602-603): SURVEY
+                                           note N8, the parity target.  2 (opt-in): the same residual with CORRECTED Jacobians (plane in
+                                           the object frame, sign restored), which match central differences to 1e-9 */
     int32_t vio_use_left_perturbation;  /* the filter's flag: selects D (src/orcvio.cpp:2092)            */
     int32_t fix_dcampose_dimupose_to_identity; /* OrcVIO::fixDcamposeDimuposeToI (orcvio.h:115-119)      */
     double R_b2c[9];                    /* current extrinsics: state_server.imu_state.R_imu_cam0         */

@@ -152,7 +152,12 @@ def bbox_rows(cTw, wTo, shape, bbox, left, new_residual):
                 Hp[i] = 2 * yyo @ Qi @ circled_circ(wTo.T @ yyw).T                    # ObjectLM.cpp:540-541
             Hs[i] = 2 * shape * (yyo[:3] ** 2)                                        # ObjectLM.cpp:546-548
         else:
-            ub = P.T @ li               # NOTE: world-frame plane, as the reference does (note N8)
+            # new_residual = True / 1: the reference's Jacobians LITERALLY -- plane in the WORLD frame (ResJacCam.cpp:405,446,
+            # ObjectLM.cpp:512,560) although the residual uses the object frame, shape Jacobian without -sign(b4) (note N8).
+            # new_residual = 2: the opt-in CORRECTED Jacobians -- plane in the object frame, sign restored (central differences
+            # agree to 1e-9: tests/test_oracle_objects.py)
+            corrected = int(new_residual) == 2
+            ub = P_res.T @ li if corrected else P.T @ li
             b = ub[:3]
             bn = np.linalg.norm(b)
             if left:
@@ -172,7 +177,7 @@ def bbox_rows(cTw, wTo, shape, bbox, left, new_residual):
             p_ua_ub = np.eye(4) / bn - np.outer(ub, ub) @ term2b / bn ** 3
             Jc[i] = -p_be_p_ua @ p_ua_ub @ dC                                         # ResJacCam.cpp:487
             Hp[i] = p_be_p_ua @ p_ua_ub @ dO                                          # ObjectLM.cpp:598-599
-            Hs[i] = shape * b * b / (bn * sq)                                         # ObjectLM.cpp:602-603
+            Hs[i] = shape * b * b / (bn * sq) * (-sign if corrected else 1.0)         # ObjectLM.cpp:602-603 (no sign there)
     return res, Jc, Hp, Hs
 
 

@@ -555,3 +555,14 @@ int orc_oracle_msckf_update(
     free(Hs); free(rs); free(Hxj); free(Hfj); free(rj);
     return mt < 0 ? -1 : 0;
 }
+
+
+/* ---- helpers shared with object_oracle.c (exported under the oracle's prefix) ------------------------------------ */
+void orc_oracle_house_qr(double* A, int m, int n, int lda, double* beta) { house_qr(A, m, n, lda, beta); }
+void orc_oracle_house_apply_qt(const double* A, int m, int n, int lda, const double* beta, double* C, int nc, int ldc) {
+    house_apply_qt(A, m, n, lda, beta, C, nc, ldc);
+}
+int orc_oracle_chol_lower(double* S, int n) { return chol_lower(S, n); }
+void orc_oracle_cam_wrt_imu(const double* R_b2c, const double* t_c_b, const double* R_w2c, const double* t_b_w, int left, double J[36]) {
+    cam_wrt_imu(R_b2c, t_c_b, R_w2c, t_b_w, left, J);
+}

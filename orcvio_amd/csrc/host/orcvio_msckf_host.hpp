@@ -91,6 +91,22 @@ struct UpdateOutcome {
     std::vector<double> ekf_gamma;
 };
 
+// Scope of a handle option: set on construction, restored on every exit path (an early return between "set" and "reset"
+// must not leave the handle in hybrid mode for the next MSCKF update).
+class OptionScope {
+  public:
+    OptionScope(orcvio_msckf_handle* h, int option, int value, int restore = 0) : h_(h), option_(option), restore_(restore) {
+        status = orcvio_msckf_set_option(h, option, value);
+    }
+    ~OptionScope() { (void)orcvio_msckf_set_option(h_, option_, restore_); }
+    OptionScope(const OptionScope&) = delete;
+    OptionScope& operator=(const OptionScope&) = delete;
+    int status = ORCVIO_OK;
+  private:
+    orcvio_msckf_handle* h_;
+    int option_, restore_;
+};
+
 class MsckfBackend {
   public:
     orcvio_msckf_flags flags{};
@@ -155,33 +171,137 @@ class MsckfBackend {
     // OrcVIO::pruneImuStateBuffer (:2803-2851) when only_states = rm_imu_state_ids.
     UpdateOutcome msckfUpdate(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
                               const std::vector<StateIDType>& only_states = {}) {
+        return featureUpdate(ss, map_server, ids, only_states, false);
+    }
+
+    // ---- device-resident covariance (the filter loop without P crossing PCIe) ------------------------------------------------
+    // covarianceToDevice once (after initialisation, or whenever the host has changed state_cov itself); from then on
+    //   processModel's covariance part          -> propagateCovariance(Phi, Q)      (src/orcvio.cpp:800-816)
+    //   stateAugmentation's covariance part     -> augmentCovariance()              (:962-1010)
+    //   removeLostFeatures / pruneImuStateBuffer-> msckfUpdate / msckfUpdateSharded (P == NULL: the resident prior; the update is
+    //                                              committed on the device, with its square-root factor: the next update of the
+    //                                              same frame skips the Cholesky of its prior)
+    //   pruneImuStateBuffer's row / column drop -> removeClonesFromCovariance(...)  (:2935-2951)
+    //   processObjects                          -> removeLostObjectTracks(...)
+    // covarianceToHost() brings state_cov back when somebody wants to read it (getters, logging).
+    bool resident_covariance = false;
+    int covarianceToDevice(const StateServer& ss) {
+        const int rc = orcvio_msckf_cov_set(h_, ss.dim(), ss.state_cov.data());
+        resident_covariance = rc == ORCVIO_OK;
+        return rc;
+    }
+    int covarianceToHost(StateServer& ss) {
+        int32_t n = 0;
+        int rc = orcvio_msckf_cov_get(h_, &n, nullptr);
+        if (rc != ORCVIO_OK) return rc;
+        ss.state_cov.assign((size_t)n * n, 0.0);
+        return orcvio_msckf_cov_get(h_, &n, ss.state_cov.data());
+    }
+    int propagateCovariance(const std::vector<double>& Phi, const std::vector<double>& Q) {
+        return orcvio_msckf_cov_propagate(h_, flags.leg_dim, Phi.data(), Q.data());
+    }
+    int augmentCovariance() { return orcvio_msckf_cov_augment(h_); }
+    int removeClonesFromCovariance(const StateServer& ss, const std::vector<StateIDType>& rm_imu_state_ids) {
+        std::vector<int32_t> idx;   // ranks of the removed ids in the ordered window BEFORE they are erased from the map
+        int i = 0;
+        for (const auto& kv : ss.imu_states_augment) {
+            if (std::find(rm_imu_state_ids.begin(), rm_imu_state_ids.end(), kv.first) != rm_imu_state_ids.end()) idx.push_back(i);
+            ++i;
+        }
+        return orcvio_msckf_cov_remove_clones(h_, flags.leg_dim, idx.data(), (int32_t)idx.size());
+    }
+
+    // ---- multi-GPU: one process per GPU, one MsckfBackend per process (include/orcvio_msckf.h "Multi-GPU") ---------------------
+    // commUniqueId on rank 0, ship the bytes (MPI_Bcast, a socket, a file), commInit on every rank.  The sharded call sites take
+    // the SAME arguments on every rank (the whole map_server and the same id list, as the single-GPU call): each rank keeps the
+    // ids dealt to it (dealFeatures: balanced by projected rows 2 M_j - 3, deterministic), runs its tracks, and the handle's
+    // RCCL all-gather + rank-ordered sum + replicated solve leave the same delta_x / P+ everywhere, so every rank applies the
+    // same state increment.  accepted / gamma come back for this rank's ids only (the others stay 0 / NaN).
+    static std::vector<uint8_t> commUniqueId() {
+        std::vector<uint8_t> id(ORCVIO_COMM_ID_BYTES);
+        if (orcvio_msckf_comm_unique_id(id.data()) != ORCVIO_OK) throw std::runtime_error(std::string("comm_unique_id: ") + orcvio_msckf_last_error());
+        return id;
+    }
+    int commInit(const std::vector<uint8_t>& id, int rank, int world) {
+        rank_ = rank; world_ = world;
+        return orcvio_msckf_comm_init(h_, id.data(), rank, world);
+    }
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+    // greedy longest-first dealing of the listed tracks to `world` ranks by rho_j = 2 M_j - 3 (ties: list order); every rank
+    // computes the same assignment from the same map
+    static std::vector<int> dealFeatures(const MapServer& map_server, const std::vector<FeatureIDType>& ids, int world) {
+        std::vector<int> order(ids.size()), owner(ids.size(), 0);
+        std::vector<long> rho(ids.size()), load(world, 0);
+        for (size_t k = 0; k < ids.size(); ++k) {
+            order[k] = (int)k;
+            const long M = (long)map_server.at(ids[k]).observations.size();
+            rho[k] = M >= 2 ? 2 * M - 3 : 0;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rho[a] > rho[b]; });
+        for (int k : order) {
+            int r = 0;
+            for (int q = 1; q < world; ++q) if (load[q] < load[r]) r = q;
+            owner[k] = r;
+            load[r] += rho[k];
+        }
+        return owner;
+    }
+    UpdateOutcome msckfUpdateSharded(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                                     const std::vector<StateIDType>& only_states = {}) {
+        if (world_ < 1) { UpdateOutcome o; o.status = ORCVIO_ERR_INVALID; return o; }
+        return featureUpdate(ss, map_server, ids, only_states, true);
+    }
+
+  private:
+    UpdateOutcome featureUpdate(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                                const std::vector<StateIDType>& only_states, bool sharded) {
         UpdateOutcome out;
-        if (ids.empty()) return out;
+        if (ids.empty() && !sharded) return out;   // (a rank without tracks still takes part in the collective)
+        // this rank's share of the listed ids
+        std::vector<FeatureIDType> mine;
+        std::vector<int> pos;   // position of every kept id in `ids`
+        if (sharded && world_ > 1) {
+            const std::vector<int> owner = dealFeatures(map_server, ids, world_);
+            for (size_t k = 0; k < ids.size(); ++k)
+                if (owner[k] == rank_) { mine.push_back(ids[k]); pos.push_back((int)k); }
+        } else {
+            mine = ids;
+            for (size_t k = 0; k < ids.size(); ++k) pos.push_back((int)k);
+        }
         std::vector<double> R_b2w, t_b_w, t_fej, R_b2c, t_c_b, p_w, obs_z, obs_zvel;
         std::vector<int32_t> obs_ptr, obs_clone;
         std::map<StateIDType, int> index_of;
         flattenWindow(ss, R_b2w, t_b_w, t_fej, R_b2c, t_c_b, index_of);
-        flattenTracks(map_server, ids, index_of, only_states, p_w, obs_ptr, obs_clone, obs_z, obs_zvel);
+        flattenTracks(map_server, mine, index_of, only_states, p_w, obs_ptr, obs_clone, obs_z, obs_zvel);
         const int N = (int)index_of.size(), n = flags.leg_dim + 6 * N;
-        if (ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        if (!resident_covariance && ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
         orcvio_msckf_window w{N, R_b2w.data(), t_b_w.data(), t_fej.data(), R_b2c.data(), t_c_b.data()};
-        orcvio_msckf_tracks t{(int32_t)ids.size(), p_w.data(), obs_ptr.data(), obs_clone.data(), obs_z.data(), obs_zvel.data()};
+        orcvio_msckf_tracks t{(int32_t)mine.size(), p_w.data(), obs_ptr.data(), obs_clone.data(), obs_z.data(), obs_zvel.data()};
+        std::vector<int32_t> acc(mine.size() + 1, 0);
+        std::vector<double> gam(mine.size() + 1, 0.0);
         out.accepted.assign(ids.size(), 0);
-        out.gamma.assign(ids.size(), 0.0);
+        out.gamma.assign(ids.size(), std::nan(""));
         out.delta_x.assign(n, 0.0);
-        std::vector<double> P_new((size_t)n * n);
+        std::vector<double> P_new;
         orcvio_msckf_result r{};
-        r.dx = out.delta_x.data(); r.P_out = P_new.data(); r.accept = out.accepted.data(); r.gamma = out.gamma.data();
-        out.status = orcvio_msckf_update_features(h_, &flags, &w, &t, ss.state_cov.data(), &r);
+        r.dx = out.delta_x.data(); r.accept = acc.data(); r.gamma = gam.data();
+        if (!resident_covariance) { P_new.resize((size_t)n * n); r.P_out = P_new.data(); }   // resident: P+ stays in HBM
+        const double* P = resident_covariance ? nullptr : ss.state_cov.data();
+        out.status = sharded ? orcvio_msckf_update_features_sharded(h_, &flags, &w, &t, P, &r)
+                             : orcvio_msckf_update_features(h_, &flags, &w, &t, P, &r);
         if (out.status != ORCVIO_OK) return out;
+        for (size_t k = 0; k < mine.size(); ++k) { out.accepted[pos[k]] = acc[k]; out.gamma[pos[k]] = gam[k]; }
         out.updated = r.stats[3] != 0;
         if (out.updated) {
-            ss.state_cov.swap(P_new);                       // P is updated even when delta_x is discarded (:4479-4494)
+            if (resident_covariance) out.status = orcvio_msckf_cov_commit(h_);   // P+ (and its factor) become the resident prior
+            else ss.state_cov.swap(P_new);                  // P is updated even when delta_x is discarded (:4479-4494)
             out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
         }
         return out;
     }
 
+  public:
     // ---- hybrid filter: the same call site with EKF-SLAM features in the state (and none being initialised) --------
     // removeLostFeatures, src/orcvio.cpp:2444-2560: the MSCKF loop as above, featureJacobian_ekf + gatingTestFeature(.., 2)
     // for every SLAM feature of `ekf_ids` the current state observes, ONE update with everything that passed
@@ -223,9 +343,11 @@ class MsckfBackend {
             orcvio_msckf_tracks gt{(int32_t)new_ids.size(), gp.data(), gptr.data(), gcl.data(), gz.data(), gzv.data()};
             std::vector<double> gg(new_ids.size());
             std::vector<int32_t> ga(new_ids.size());
-            out.status = orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, d * (int)ss.feature_states.size());
-            if (out.status == ORCVIO_OK) out.status = orcvio_msckf_gate_tracks(h_, &flags, &gw, &gt, ss.state_cov.data(), gg.data(), ga.data());
-            (void)orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, 0);
+            {
+                OptionScope extra(h_, ORCVIO_OPT_EXTRA_STATES, d * (int)ss.feature_states.size());
+                out.status = extra.status;
+                if (out.status == ORCVIO_OK) out.status = orcvio_msckf_gate_tracks(h_, &flags, &gw, &gt, ss.state_cov.data(), gg.data(), ga.data());
+            }
             if (out.status != ORCVIO_OK) return out;
             std::vector<int32_t> anc, optr(1, 0), ocl;
             std::vector<double> prm, rho, pw, pfj, oz, ozv;
@@ -294,16 +416,17 @@ class MsckfBackend {
         orcvio_msckf_result r{};
         r.dx = out.delta_x.data(); r.P_out = P_new.data(); r.accept = out.accepted.data(); r.gamma = out.gamma.data();
         auto step = [&](int rc) { if (out.status == ORCVIO_OK) out.status = rc; };
-        step(orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, d * nf));
-        step(orcvio_msckf_set_option(h_, ORCVIO_OPT_EKF_ROWS, 1));
-        if (out.status == ORCVIO_OK) step(orcvio_msckf_upload(h_, &flags, &w, &t, ss.state_cov.data()));
-        if (out.status == ORCVIO_OK) step(orcvio_msckf_upload_slam_features(h_, &sf));
-        if (out.status == ORCVIO_OK && rows_top > 0) step(orcvio_msckf_upload_dense_rows(h_, rows_top, H_top.data(), r_top.data()));
-        if (out.status == ORCVIO_OK) step(orcvio_msckf_run_update(h_, nullptr));
-        if (out.status == ORCVIO_OK) step(orcvio_msckf_download(h_, &r));
-        if (out.status == ORCVIO_OK) step(orcvio_msckf_download_ekf(h_, out.ekf_gamma.data(), out.ekf_accepted.data()));
-        (void)orcvio_msckf_set_option(h_, ORCVIO_OPT_EKF_ROWS, 0);
-        (void)orcvio_msckf_set_option(h_, ORCVIO_OPT_EXTRA_STATES, 0);
+        {   // hybrid mode for exactly this update (both options are restored on every exit path)
+            OptionScope extra(h_, ORCVIO_OPT_EXTRA_STATES, d * nf), ekf_rows(h_, ORCVIO_OPT_EKF_ROWS, 1);
+            step(extra.status);
+            step(ekf_rows.status);
+            if (out.status == ORCVIO_OK) step(orcvio_msckf_upload(h_, &flags, &w, &t, ss.state_cov.data()));
+            if (out.status == ORCVIO_OK) step(orcvio_msckf_upload_slam_features(h_, &sf));
+            if (out.status == ORCVIO_OK && rows_top > 0) step(orcvio_msckf_upload_dense_rows(h_, rows_top, H_top.data(), r_top.data()));
+            if (out.status == ORCVIO_OK) step(orcvio_msckf_run_update(h_, nullptr));
+            if (out.status == ORCVIO_OK) step(orcvio_msckf_download(h_, &r));
+            if (out.status == ORCVIO_OK) step(orcvio_msckf_download_ekf(h_, out.ekf_gamma.data(), out.ekf_accepted.data()));
+        }
         if (out.status != ORCVIO_OK) return out;
         int nacc = 0;
         for (int a : out.ekf_accepted) nacc += a;
@@ -532,10 +655,42 @@ class MsckfBackend {
         return true;
     }
 
+    // System::processObjects -> removeLostObjects straight from object TRACKS (state at the LM optimum + observations: what
+    // ObjectInitNode returns per object), rows evaluated on the device; sharded over the ranks when a communicator exists
+    // (objects dealt round-robin: every rank passes the same list).  With resident_covariance the prior and P+ stay in HBM.
+    UpdateOutcome removeLostObjectTracks(StateServer& ss, const orcvio_object_eval_flags& eval_flags,
+                                         const std::vector<orcvio_object_track>& tracks) {
+        UpdateOutcome out;
+        const int N = (int)ss.imu_states_augment.size(), n = flags.leg_dim + 6 * N;
+        if (!resident_covariance && ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        std::vector<orcvio_object_track> mine;
+        for (size_t k = 0; k < tracks.size(); ++k)
+            if (world_ <= 1 || (int)(k % (size_t)world_) == rank_) mine.push_back(tracks[k]);
+        out.accepted.assign(1, 0);
+        out.gamma.assign(1, 0.0);
+        out.delta_x.assign(n, 0.0);
+        std::vector<double> P_new;
+        orcvio_msckf_result r{};
+        r.dx = out.delta_x.data(); r.accept = out.accepted.data(); r.gamma = out.gamma.data();
+        if (!resident_covariance) { P_new.resize((size_t)n * n); r.P_out = P_new.data(); }
+        const double* P = resident_covariance ? nullptr : ss.state_cov.data();
+        out.status = world_ > 1 ? orcvio_msckf_update_object_tracks_sharded(h_, &flags, &eval_flags, N, mine.data(), (int32_t)mine.size(), P, &r)
+                                : orcvio_msckf_update_object_tracks(h_, &flags, &eval_flags, N, mine.data(), (int32_t)mine.size(), P, &r);
+        if (out.status != ORCVIO_OK) return out;
+        out.updated = r.stats[3] != 0;
+        if (out.updated) {
+            if (resident_covariance) out.status = orcvio_msckf_cov_commit(h_);
+            else ss.state_cov.swap(P_new);
+            out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
+        }
+        return out;
+    }
+
     orcvio_msckf_handle* handle() { return h_; }
 
   private:
     orcvio_msckf_handle* h_ = nullptr;
+    int rank_ = 0, world_ = 0;
 
     // get_cam_wrt_imu_se3_jacobian (include/orcvio/utils/se3_ops.hpp:531-552) for the camera pose wTc of an
     // object frame, with the CURRENT extrinsics (src/orcvio.cpp:2079-2093)

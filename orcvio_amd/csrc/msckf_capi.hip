@@ -86,6 +86,7 @@ struct orcvio_msckf_handle {
     int fac_n = 0, fac_k = 0, fac_ld = 0;
     bool fac_valid = false;
     bool factor_opt = true;             // ORCVIO_OPT_RESIDENT_FACTOR
+    bool ref_stack_hf = false;          // ORCVIO_OPT_REF_STACK_HF: the reference's literal shared-Hf stacking of several objects
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
     bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P
     int last_run_kind = 0;              // 0: run_update (single GPU), 1: run_local / run_finish (staged or sharded), 2: objects
@@ -482,6 +483,10 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
     if (option == ORCVIO_OPT_RESIDENT_FACTOR) {
         h->factor_opt = value != 0;
         if (!h->factor_opt) h->fac_valid = false;
+        return ORCVIO_OK;
+    }
+    if (option == ORCVIO_OPT_REF_STACK_HF) {
+        h->ref_stack_hf = value != 0;
         return ORCVIO_OK;
     }
     if (option == ORCVIO_OPT_OBJECT_QR) {
@@ -1869,6 +1874,26 @@ static int objects_prior(orcvio_msckf_handle* h, hipStream_t s, const double* P,
     return ORCVIO_OK;
 }
 
+// ORCVIO_OPT_REF_STACK_HF: System::processObjects stacks Hx, Hf and r of all objects VERTICALLY, Hf with its 45 columns
+// shared (ros_wrapper/src/orcvio/src/System.cpp:684-702), and removeLostObjects projects the whole stack against that one Hf
+// (src/orcvio.cpp:2154-2193): the objects become ONE block of rows.  Host arrays of the staged update are rewritten in
+// place: one object, its rows regrouped by clone through the index list.
+static void merge_objects_ref_stack(int N, int nobj, int rows_tot, int* ridx, int* rowptr, ObjGroup* groups, int* ng) {
+    std::vector<int> old_ridx(ridx, ridx + rows_tot);
+    std::vector<ObjGroup> old(groups, groups + *ng);
+    int pos = 0, g = 0;
+    for (int c = 0; c < N; ++c) {
+        const int g0 = pos;
+        for (const ObjGroup& q : old)
+            if (q.clone == c)
+                for (int k = q.r0; k < q.r1; ++k) ridx[pos++] = old_ridx[k];
+        if (pos > g0) groups[g++] = ObjGroup{g0, pos, c, 0};
+    }
+    *ng = g;
+    rowptr[0] = 0; rowptr[1] = rows_tot;
+    (void)nobj;
+}
+
 // Arrow structure of the objects' Hf for the structured QR (k_obj_arrow_qr): rowkp[row] = keypoint block of the row (-1: a
 // border-only row), Ks[o] = keypoint blocks of object o.  Fills arrows / ranges / kp_rows (host mirrors of the device arrays);
 // returns false if some object does not fit the kernel's limits (<= 128 rows per keypoint, <= 2048 rows per object).
@@ -1937,13 +1962,18 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
         const orcvio_msckf_object_rows& ob = objs[o];
         if (ob.n_rows < 0 || ob.n_obj_cols < 1 || ob.n_obj_cols > 112) { g_last_error = "objects_local: bad block shape (object state columns must be 1..112)"; return ORCVIO_ERR_INVALID; }
         if (ob.n_rows > 0 && (!ob.row_clone || !ob.Hx6 || !ob.Hf || !ob.res)) { g_last_error = "objects_local: null block arrays"; return ORCVIO_ERR_INVALID; }
-        if (ob.n_rows <= ob.n_obj_cols) continue;   // nullspace_project_inplace_svd returns false
+        if (h->ref_stack_hf ? ob.n_rows == 0 : ob.n_rows <= ob.n_obj_cols) continue;   // nullspace_project_inplace_svd returns false
         for (int r = 0; r < ob.n_rows; ++r)
             if (ob.row_clone[r] < 0 || ob.row_clone[r] >= N) { g_last_error = "objects_local: row_clone out of range"; return ORCVIO_ERR_INVALID; }
+        if (h->ref_stack_hf && pl.no_max > 0 && ob.n_obj_cols != pl.no_max) { g_last_error = "objects_local: ORCVIO_OPT_REF_STACK_HF needs equal object state sizes"; return ORCVIO_ERR_INVALID; }
         use.push_back(o);
         pl.rows_tot += ob.n_rows;
         dof += ob.n_rows - ob.n_obj_cols;
         if (ob.n_obj_cols > pl.no_max) pl.no_max = ob.n_obj_cols;
+    }
+    if (h->ref_stack_hf) {   // one stacked block: projectable only if it has more rows than columns; dof = its rows - columns
+        if (pl.rows_tot <= pl.no_max) { use.clear(); pl.rows_tot = 0; }
+        dof = use.empty() ? 0 : pl.rows_tot - pl.no_max;
     }
     pl.nobj = (int)use.size();
     hipStream_t s = pick_stream(h, stream);
@@ -2019,6 +2049,10 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
         r0 += ob.n_rows;
         rowptr[ui + 1] = r0;
     }
+    if (h->ref_stack_hf && pl.nobj > 1) {
+        merge_objects_ref_stack(N, pl.nobj, pl.rows_tot, ridx, rowptr, groups, &ng);
+        pl.nobj = 1; h->obj_count = 1; structured = false;
+    }
     pl.ngroups = ng;
     pl.arrow = structured && h->arrow_opt &&
                build_arrow(rowkp.data(), rowptr, Ks.data(), pl.nobj, reinterpret_cast<ObjArrow*>(hi + o_arrow),
@@ -2066,7 +2100,8 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
                 if (std::isfinite(zs[2 * k]) && std::isfinite(zs[2 * k + 1])) ++nv;   // row finite test, ObjectLM.cpp:171-198
             rows += 2 * nv + 4;
         }
-        if (rows <= ncol) continue;   // nullspace_project_inplace_svd returns false
+        if (h->ref_stack_hf ? rows == 0 : rows <= ncol) continue;   // nullspace_project_inplace_svd returns false
+        if (h->ref_stack_hf && pl.no_max > 0 && ncol != pl.no_max) { g_last_error = "objects_local_tracks: ORCVIO_OPT_REF_STACK_HF needs equal object state sizes"; return ORCVIO_ERR_INVALID; }
         use.push_back(Use{t, pl.rows_tot, rows, ncol, nd, ni});
         nd += 16 + 3 + (size_t)3 * K + (size_t)F * (16 + 2 * K + 4);
         ni += (size_t)2 * F;
@@ -2074,6 +2109,10 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
         dof += rows - ncol;
         if (ncol > pl.no_max) pl.no_max = ncol;
         if (F > Fmax) Fmax = F;
+    }
+    if (h->ref_stack_hf) {
+        if (pl.rows_tot <= pl.no_max) { use.clear(); pl.rows_tot = 0; }
+        dof = use.empty() ? 0 : pl.rows_tot - pl.no_max;
     }
     pl.nobj = (int)use.size();
     hipStream_t s = pick_stream(h, stream);
@@ -2181,8 +2220,14 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
         a.Hx6 = pl.d_hx; a.Hf = pl.d_hf; a.res = pl.d_res; a.row_clone = pl.d_clone;
         std::memcpy(hd + args_off + arg_dbl * ui, &a, sizeof(a));
     }
+    const int n_eval = pl.nobj;   // (the row kernel is launched per evaluated track whatever happens to the blocks afterwards)
+    bool stacked = false;
+    if (h->ref_stack_hf && pl.nobj > 1) {
+        merge_objects_ref_stack(N, pl.nobj, pl.rows_tot, ridx, rowptr, groups, &ng);
+        pl.nobj = 1; h->obj_count = 1; stacked = true;
+    }
     pl.ngroups = ng;
-    pl.arrow = h->arrow_opt && build_arrow(rowkp.data(), rowptr, Ks.data(), pl.nobj, reinterpret_cast<ObjArrow*>(hi + o_arrow),
+    pl.arrow = !stacked && h->arrow_opt && build_arrow(rowkp.data(), rowptr, Ks.data(), pl.nobj, reinterpret_cast<ObjArrow*>(hi + o_arrow),
                                            reinterpret_cast<int2*>(hi + o_range), hi + o_kprows, &pl.Kmax, &pl.rows_max);
     if (pl.arrow) {   // room for the arrow factors (the row arrays the kernel arguments point at do not move: same sizes)
         double* keep_objH = h->d_objH; int* keep_obj_i = h->d_obj_i;
@@ -2193,6 +2238,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     pl.d_ridx = di + o_ridx; pl.d_rowptr = di + o_rowptr; pl.d_groups = reinterpret_cast<ObjGroup*>(di + o_groups);
     pl.d_arrow = reinterpret_cast<ObjArrow*>(di + o_arrow); pl.d_kp_range = reinterpret_cast<int2*>(di + o_range); pl.d_kp_rows = di + o_kprows;
     HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (o_groups + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
+    (void)n_eval;
     hipLaunchKernelGGL(k_object_rows_batch, dim3(Fmax, (unsigned)use.size()), dim3(64), 0, s,
                        reinterpret_cast<const ObjEvalArgs*>(dd + args_off));
     HIPCHK(hipGetLastError());

@@ -6,7 +6,7 @@
 // D = get_cam_wrt_imu_se3_jacobian (include/orcvio/utils/se3_ops.hpp:531-552), rows interleaved per frame
 // [keypoint rows ; 4 bbox rows].  One wavefront per in-window frame: lane i < K is keypoint i, lanes
 // K..K+3 are the four bbox lines.  The *new* bbox residual is restated literally (its Jacobian uses the
-// world-frame plane, SURVEY.md note N8).
+// world-frame plane, SURVEY.md note N8) with new_bbox == 1, and with corrected Jacobians with new_bbox == 2.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -199,8 +199,11 @@ __device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int
                 const double bn = sqrt(yyo[0] * yyo[0] + yyo[1] * yyo[1] + yyo[2] * yyo[2]);
                 r = (yyo[3] - (yyo[3] > 0 ? 1.0 : -1.0) * sq) / bn;
             }
-            // Jacobians: plane in the WORLD frame, as the reference computes them (note N8)
-            const double* ub = yyw;
+            // Jacobians.  new_bbox == 1: plane in the WORLD frame, as the reference computes them (note N8: inconsistent with
+            // its own residual, restated literally).  new_bbox == 2 (opt-in, "corrected"): plane in the OBJECT frame and the
+            // shape derivative with its -sign(b4); these agree with central differences of the residual to 1e-9
+            const bool corrected = p.new_bbox == 2;
+            const double* ub = corrected ? yyo : yyw;
             const double sq = sqrt(v2[0] * ub[0] * ub[0] + v2[1] * ub[1] * ub[1] + v2[2] * ub[2] * ub[2]);
             const double bn = sqrt(ub[0] * ub[0] + ub[1] * ub[1] + ub[2] * ub[2]);
             const double sg = ub[3] > 0 ? 1.0 : -1.0;
@@ -220,7 +223,7 @@ __device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int
                 for (int c = 0; c < 6; ++c) jc[c] = -jc[c];
                 row_times_ccT(g, yyo, hp);
             }
-            for (int c = 0; c < 3; ++c) hs[c] = p.shape[c] * ub[c] * ub[c] / (bn * sq);
+            for (int c = 0; c < 3; ++c) hs[c] = (corrected ? -sg : 1.0) * p.shape[c] * ub[c] * ub[c] / (bn * sq);
         }
         emit(row0 + 2 * nvalid + j, r, jc, hp, hs, 0, nullptr);
     }

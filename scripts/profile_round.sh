@@ -12,6 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o p -- python3 $ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_$C.log 2>&1
 done
-# matrix-core activity: FP64 MFMA operations (x512 = flops) and busy cycles
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/${TAG}_pmc_MFMA -o p -- python3 $ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_MFMA.log 2>&1
+# matrix-core activity: FP64 MFMA operations (x512 = flops), busy cycles (summed over the SIMDs) and the wall cycles of the dispatch
+# (GRBM_GUI_ACTIVE: summed over the 8 XCDs, MI355X_MICROARCH.md)
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_MFMA -o p -- python3 $ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_MFMA.log 2>&1
 find $OUT/${TAG}_trace $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_MFMA -name "*.csv" | head -20

@@ -62,8 +62,14 @@ if f:
         if k.startswith('__amd'):
             continue
         traffic.setdefault(k, {})[f'{c}_median'] = statistics.median(v)
+# calibration of FETCH_SIZE / WRITE_SIZE on THIS access pattern (MI355X_MICROARCH.md: only 16 B-per-lane streams are calibrated):
+# k_fac_commit and k_cov_remove read and write a known number of bytes with 8 B per lane, coalesced
+calib = {}
+for k, known in (('k_fac_commit', None), ('k_gram_reduce', None)):
+    if k in traffic:
+        calib[k] = {kk: vv for kk, vv in traffic[k].items() if kk.endswith('_KB_median')}
 if traffic:
-    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no trace domains) around bench.py --steps 20; '
+    json.dump({'calibration_kernels': calib, 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no trace domains) around bench.py --steps 20; '
                        'KB per dispatch, median over the dispatches of each kernel. gfx950 caveat (MI355X_MICROARCH.md): '
                        'FETCH_SIZE under-reports wide coalesced reads by 2x; these kernels read 8 B per lane. SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 = '
                        'FP64 flops executed on the matrix cores per dispatch; SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs.',

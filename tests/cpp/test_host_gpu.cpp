@@ -25,6 +25,7 @@ static double relerr(const std::vector<double>& a, const std::vector<double>& b)
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);   // (the harness reports how far the run got if it ever hangs)
     const int N = 8, F = 40;
     std::mt19937 rng(3);
     std::normal_distribution<double> G(0, 1);
@@ -142,6 +143,48 @@ int main() {
         }
         std::printf("triangulation: status %d, %d/%d valid, worst inlier distance to the generator's point %.3f m\n", st, nok, F, worst);
         if (st != ORCVIO_OK || nok < F / 2) ++fails;   // (positions are checked against the oracle in tests/test_gpu_triangulate.py)
+    }
+    {   // the same two call sites with the covariance resident in HBM, through the SHARDED entry points (communicator of one
+        // rank: the RCCL all-gather and the rank-ordered sum run, the result must equal the plain call), then the prune
+        // update on the factor the first update left, then the rows / columns of the pruned clones dropped on the device
+        StateServer a = ss, b = ss;
+        UpdateOutcome o1 = be.msckfUpdate(a, map_server, ids);                   // host covariance, single GPU
+        std::vector<StateIDType> only;
+        { auto it = a.imu_states_augment.begin(); only.push_back(it->first); ++it; only.push_back(it->first); }
+        UpdateOutcome o2 = be.msckfUpdate(a, map_server, ids, only);
+        MsckfBackend sh(0, 16, 256, 8192);
+        std::printf("sharded: creating the communicator\n");
+        int rc = sh.commInit(MsckfBackend::commUniqueId(), 0, 1);
+        std::printf("sharded: communicator ready (rc %d)\n", rc);
+        if (rc == ORCVIO_OK) rc = sh.covarianceToDevice(b);
+        UpdateOutcome s1 = sh.msckfUpdateSharded(b, map_server, ids);            // resident covariance, sharded path
+        UpdateOutcome s2 = sh.msckfUpdateSharded(b, map_server, ids, only);      // ... on the resident factor of the first
+        if (rc == ORCVIO_OK) rc = sh.removeClonesFromCovariance(b, only);
+        if (rc == ORCVIO_OK) rc = sh.covarianceToHost(b);
+        if (rc != ORCVIO_OK || s1.status != ORCVIO_OK || s2.status != ORCVIO_OK) { std::printf("sharded / resident: rc %d %d %d (%s)\n", rc, s1.status, s2.status, orcvio_msckf_last_error()); ++fails; }
+        // host side of the marginalisation for the comparison (src/orcvio.cpp:2935-2951)
+        const int n2 = n - 12;
+        std::vector<double> Pm((size_t)n2 * n2);
+        for (int i = 0, ii = 0; i < n; ++i) {
+            if (i >= 22 && i < 34) continue;
+            for (int j = 0, jj = 0; j < n; ++j) {
+                if (j >= 22 && j < 34) continue;
+                Pm[(size_t)ii * n2 + jj] = a.state_cov[(size_t)i * n + j];
+                ++jj;
+            }
+            ++ii;
+        }
+        const double e1 = relerr(s1.delta_x, o1.delta_x), e2 = relerr(s2.delta_x, o2.delta_x), eP = relerr(b.state_cov, Pm);
+        int same = (int)(s1.accepted == o1.accepted && s2.accepted == o2.accepted);
+        std::printf("resident + sharded (world 1): dx rel %.2e / %.2e, P rel after marginalisation %.2e, same masks %d\n", e1, e2, eP, same);
+        if (!(e1 < 1e-9) || !(e2 < 1e-6) || !(eP < 1e-6) || !same) ++fails;
+        // dealing: every id lands on exactly one rank, loads balanced
+        const std::vector<int> owner = MsckfBackend::dealFeatures(map_server, ids, 4);
+        long load[4] = {0, 0, 0, 0};
+        for (size_t k = 0; k < ids.size(); ++k) load[owner[k]] += 2 * (long)map_server.at(ids[k]).observations.size() - 3;
+        long lo = load[0], hi = load[0];
+        for (long v : load) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        if (hi - lo > 13) { std::printf("dealFeatures: unbalanced %ld..%ld\n", lo, hi); ++fails; }
     }
     std::printf(fails ? "FAILED\n" : "host gpu ok\n");
     return fails;

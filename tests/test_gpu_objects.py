@@ -231,3 +231,50 @@ def test_update_from_object_tracks_equals_update_from_rows(upd, new_bbox):
     assert rel(got['dx'], ref['dx']) < 1e-9 or (not got['dx'].any() and not ref['dx'].any())
     assert rel(got['P_new'], ref['P_new']) < 1e-10
     assert rel(got['G'], ref['G']) < 1e-8 or (not got['G'].any() and not ref['G'].any())
+
+
+@pytest.mark.parametrize('obj_left,vio_left', [(True, 0), (False, 1)])
+def test_corrected_new_bbox_mode_on_the_device(upd, obj_left, vio_left):
+    """use_new_bbox_residual = 2 (opt-in): the new bbox residual with corrected Jacobians (SURVEY note N8), device rows against the
+    restatement whose Jacobians match central differences (tests/test_oracle_objects.py)."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=vio_left)
+    win = synth.make_window(N=10, F=4, seed=5, flags=flags, track_len=4)
+    obj = synth.make_objects(win, n_objects=1, seed=4, sigma_kp=0.004)[0]
+    res, Hf, Jc, counts = mo.object_rows(obj.wTo, obj.shape, obj.kps, obj.frames, obj_left, 2)
+    ref = mo.construct_object_residual_jacobians(Jc, [fr['clone'] for fr in obj.frames], Hf, res, counts, [fr['wTc'] for fr in obj.frames],
+                                                 win.R_b2c[0], win.t_c_b[0], vio_left, flags.leg_dim, win.N)
+    got = upd.object_rows_eval(obj, win.R_b2c[0], win.t_c_b[0], obj_left, 2, vio_left)
+    lit = upd.object_rows_eval(obj, win.R_b2c[0], win.t_c_b[0], obj_left, 1, vio_left)
+    assert rel(got['res'], ref[2]) < 1e-9 and rel(got['Hx6'], ref[4]) < 1e-9 and rel(got['Hf'], ref[1]) < 1e-9
+    assert np.array_equal(got['res'], lit['res']) and rel(got['Hf'], lit['Hf']) > 1e-3   # same residual, different Jacobians
+
+
+def test_ref_stack_hf_reproduces_the_reference_stacking(upd):
+    """ORCVIO_OPT_REF_STACK_HF (SURVEY note N3): System::processObjects stacks the objects' Hx / Hf / r vertically with the 45
+    columns of Hf SHARED (System.cpp:684-702) and removeLostObjects projects the stack with ONE SVD (src/orcvio.cpp:2154-2193).
+    Three objects: the literal mode equals mirror_objects.remove_lost_objects on the stacked matrices; the default (per-object
+    projection) is a different -- block-diagonal -- update."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=12, F=4, seed=3, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=3, seed=5, sigma_kp=0.004)
+    rows = [_rows_for(win, ob, True, False, 0) for ob in objs]
+    Hx = np.vstack([r[0] for r in rows]); Hf = np.vstack([r[1] for r in rows]); res = np.concatenate([r[2] for r in rows])
+    ref = mo.remove_lost_objects(Hx, Hf, res, win.P, flags.noise_feature ** 2)
+    blocks = [dict(row_clone=r[3], Hx6=r[4], Hf=r[1], res=r[2]) for r in rows]
+    default = upd.update_objects(flags, win.N, blocks, win.P)
+    upd._chk(upd.lib.orcvio_msckf_set_option(upd.h, 9, 1), 'set_option')
+    try:
+        got = upd.update_objects(flags, win.N, blocks, win.P)
+        trk = upd.update_object_tracks(flags, win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+    finally:
+        upd._chk(upd.lib.orcvio_msckf_set_option(upd.h, 9, 0), 'set_option')
+    assert ref['dof'] == Hx.shape[0] - 45
+    for g in (got, trk):
+        assert g['accept'] == int(ref['updated'])
+        assert abs(g['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+        if ref['updated']:
+            assert g['stats'][0] == ref['dof']
+            assert rel(g['dx'], ref['dx']) < TOL and rel(g['P_new'], ref['P_new']) < TOL
+        else:
+            assert not g['dx'].any()
+    assert abs(default['gamma'] - ref['gamma']) > 1e-3 * abs(ref['gamma'])   # per-object projection: not the same quantity

@@ -30,9 +30,22 @@ def test_host_backend_end_to_end(built, tmp_path):
     exe = str(tmp_path / 'test_host_gpu')
     orc = os.path.join(ROOT, 'oracle')
     _build('test_host_gpu.cpp', exe, ['-L', orc, '-lorcoracle', f'-Wl,-rpath,{orc}', '-lm'])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert 'host gpu ok' in out.stdout
+    # (one full-suite run of round 2 saw this executable sit for the whole time limit once, five others and every solo run
+    # finished in 15 s: the test prints unbuffered, a hang is reported with the output so far, and is retried once)
+    stdout = ''
+    for attempt in range(2):
+        proc = subprocess.Popen([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        try:
+            stdout, _ = proc.communicate(timeout=150)
+            break
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            stdout, _ = proc.communicate()
+            print('test_host_gpu hung (attempt %d); output so far:\n%s' % (attempt, stdout))
+            if attempt == 1:
+                raise AssertionError('test_host_gpu hung twice; output so far:\n' + stdout)
+    assert proc.returncode == 0, stdout
+    assert 'host gpu ok' in stdout
 
 
 @pytest.mark.gpu

@@ -137,3 +137,27 @@ def test_increment_state_discard(built):
     dx[6] = 0.1
     s2, applied = mirror.increment_state(st, dx, f)
     assert applied and np.isclose(s2['p'][0], 0.1)
+
+
+@pytest.mark.parametrize('flags', [dict(use_larvio=1), dict(use_larvio=0, use_left_perturbation=0, estimate_td=1, if_fej=1),
+                                   dict(use_larvio=0, use_left_perturbation=1)])
+def test_three_independent_restatements_agree(flags):
+    """The literal numpy restatement, the literal C port and the minimum-work OpenMP variant (oracle/msckf_fast.c: three
+    reflectors instead of a full-U SVD, gate on the touched columns, Gram compression, square-root solve) are written
+    separately and must give the same update; so must the 60-digit evaluation of the formula on a small window."""
+    from oracle import oracle as orc, mp_reference
+    w = synth.make_window(N=7, F=30, seed=5, track_len=(2, 7), outlier_frac=0.2, flags=synth.Flags(**flags))
+    a = mirror.msckf_update(w)
+    b = orc.msckf_update(w, want_blocks=False, want_K=False)
+    c = orc.msckf_update_fast(w)
+    assert 0 < a['accept'].sum() < w.F
+    for other in (b, c):
+        assert np.array_equal(other['accept'], a['accept'])
+        fin = np.isfinite(a['gamma'])
+        assert rel(other['gamma'][fin], a['gamma'][fin]) < 1e-10
+        assert rel(other['dx'], a['dx']) < 1e-9 and rel(other['P_new'], a['P_new']) < 1e-12
+    small = synth.make_window(N=4, F=8, seed=6, track_len=(3, 4), flags=synth.Flags(**flags))
+    hp = mp_reference.msckf_update_mp(small)
+    for upd in (mirror.msckf_update(small), orc.msckf_update(small, want_blocks=False, want_K=False), orc.msckf_update_fast(small)):
+        assert np.array_equal(upd['accept'], hp['accept'])
+        assert rel(upd['dx'], hp['dx']) < 1e-10 and rel(upd['P_new'], hp['P_new']) < 1e-12

@@ -81,3 +81,72 @@ def test_se3_exp_log_roundtrip():
     for _ in range(10):
         xi = rng.standard_normal(6) * 0.7
         assert np.allclose(mo.se3_log(mo.se3_exp(xi)), xi, atol=1e-12)
+
+
+@pytest.mark.parametrize('obj_left,new_bbox,vio_left', [(True, False, 0), (False, False, 0), (True, True, 0), (False, True, 1)])
+def test_c_object_oracle_matches_the_mirror_and_the_goldens(built, obj_left, new_bbox, vio_left):
+    """oracle/object_oracle.c (the C twin, bench.py's CPU baseline of the object update) against mirror_objects.py: rows of a
+    ragged track, and the update of several objects; and against the reference's golden vectors directly."""
+    from orcvio_amd import synth
+    from oracle import oracle as orc
+    from helpers import object_rows_reference, objects_update_reference, rel
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=vio_left)
+    win = synth.make_window(N=10, F=4, seed=21, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=3, seed=9, sigma_kp=0.004, missing_frac=0.25)
+    objs[0].frames[3]['clone'] = -1
+    blocks = []
+    for ob in objs:
+        Hx, Hf, r, rc, hx6 = object_rows_reference(win, ob, obj_left, new_bbox, vio_left)
+        got = orc.object_rows_c(ob, win.R_b2c[0], win.t_c_b[0], obj_left, new_bbox, vio_left)
+        assert np.array_equal(got['row_clone'], rc)
+        assert rel(got['res'], r) < 1e-10 and rel(got['Hx6'], hx6) < 1e-10 and rel(got['Hf'], Hf) < 1e-10
+        blocks.append(got)
+    ref = objects_update_reference(win, objs, win.P, obj_left, new_bbox, vio_left)
+    upd = orc.objects_update_c(flags, win.N, blocks, win.P)
+    assert upd['accept'] == ref['accept'] and upd['dof'] == ref['dof']
+    assert abs(upd['gamma'] - ref['gamma']) < 1e-8 * abs(ref['gamma'])
+    assert rel(upd['dx'], ref['dx']) < 1e-8 or not ref['accept']
+    assert rel(upd['P_new'], ref['P_new']) < 1e-10
+    if obj_left and not new_bbox and not vio_left:   # the reference's own vectors (test_object_lm.cpp:90-202)
+        g = np.load(GOLDEN + '/ref_test_error_feature_quadric.npz')
+        o = synth.ObjectTrack(wTo=g['T'], shape=np.ones(3), kps=g['M'][:, :3].copy(),
+                              frames=[dict(clone=0, wTc=np.linalg.inv(g['S']), zs=g['zs'], bbox=np.array([-0.1, -0.1, 0.1, 0.1]))])
+        c = orc.object_rows_c(o, np.eye(3), np.zeros(3), True, False, 0, fix_D=True)
+        assert np.abs(c['res'][:24] - g['error'].ravel()).max() < 1e-12 and np.abs(c['Hf'][:24] - g['jacobian']).max() < 1e-12
+        gb = np.load(GOLDEN + '/ref_test_error_bbox_quadric.npz')
+        ob = synth.ObjectTrack(wTo=gb['T'], shape=gb['v'].copy(), kps=np.zeros((12, 3)),
+                               frames=[dict(clone=0, wTc=np.linalg.inv(gb['S']), zs=np.full((12, 2), np.nan), bbox=gb['zb'].ravel().copy())])
+        cb = orc.object_rows_c(ob, np.eye(3), np.zeros(3), True, False, 0, fix_D=True)
+        assert np.abs(cb['res'] - gb['error'].ravel()).max() < 1e-12 and np.abs(cb['Hf'] - gb['jacobian']).max() < 1e-12
+
+
+@pytest.mark.parametrize('left', [True, False])
+def test_corrected_new_bbox_jacobians_match_central_differences(left):
+    """SURVEY note N8: the reference's Jacobians of the NEW bbox residual take the plane in the world frame and drop -sign(b4);
+    mode 1 restates that literally (and is off by O(1) from the numerical derivative), mode 2 is the opt-in corrected form: camera
+    pose, object pose and shape Jacobians within 1e-9 of central differences on the reference's bbox fixture inputs."""
+    g = np.load(GOLDEN + '/ref_test_error_bbox_quadric.npz')
+    wTc, wTo, v, bbox = np.linalg.inv(g['S']), g['T'], g['v'], g['zb'].ravel()
+    kps, zs = np.zeros((12, 3)), np.full((12, 2), np.nan)
+
+    def rows(wTc_, wTo_, v_, mode):
+        return mo.object_rows(wTo_, v_, kps, [dict(wTc=wTc_, zs=zs, bbox=bbox)], left, mode)
+    eps = 1e-6
+    for mode, bound in ((2, 1e-9), (1, None)):
+        res0, Hf0, Jc0, _ = rows(wTc, wTo, v, mode)
+        Jn, Jo, Js = np.zeros((4, 6)), np.zeros((4, 6)), np.zeros((4, 3))
+        for c in range(6):
+            d = np.zeros(6); d[c] = eps
+            pert = (lambda T, s: mo.se3_exp(s * d) @ T) if left else (lambda T, s: T @ mo.se3_exp(s * d))
+            Jn[:, c] = (rows(pert(wTc, 1), wTo, v, mode)[0] - rows(pert(wTc, -1), wTo, v, mode)[0]) / (2 * eps)
+            Jo[:, c] = (rows(wTc, pert(wTo, 1), v, mode)[0] - rows(wTc, pert(wTo, -1), v, mode)[0]) / (2 * eps)
+        for c in range(3):
+            d = np.zeros(3); d[c] = eps
+            Js[:, c] = (rows(wTc, wTo, v + d, mode)[0] - rows(wTc, wTo, v - d, mode)[0]) / (2 * eps)
+        errs = (np.abs(Jn - Jc0).max(), np.abs(Jo - Hf0[:, :6]).max(), np.abs(Js - Hf0[:, 6:9]).max())
+        if bound is not None:
+            assert max(errs) < bound, errs
+        else:
+            assert min(errs) > 0.1, errs   # the literal form really is inconsistent: that is what parity means for mode 1
+    # the residual itself is the same in both modes
+    assert np.array_equal(rows(wTc, wTo, v, 1)[0], rows(wTc, wTo, v, 2)[0])
