@@ -432,7 +432,6 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
         HIPCHK(hipFuncSetAttribute((const void*)k_feature<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         HIPCHK(hipFuncSetAttribute((const void*)k_feature<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         HIPCHK(hipFuncSetAttribute((const void*)k_feature<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        HIPCHK(hipFuncSetAttribute((const void*)k_obj_arrow_qr, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         return ORCVIO_OK;
     }();
     if (rc != ORCVIO_OK) {
@@ -1757,6 +1756,7 @@ struct ObjPlan {
     int2* d_kp_range = nullptr;
     int* d_kp_rows = nullptr;
     double* d_Rarrow = nullptr;
+    double* d_Bred = nullptr;   // [rows][9] the border of every row after the keypoint blocks have been eliminated
 };
 static int obj_stage_reserve(orcvio_msckf_handle* h, size_t bytes) {
     if (bytes <= h->obj_stage_cap) return ORCVIO_OK;
@@ -1781,7 +1781,7 @@ static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
     if ((rc = grow(&h->d_objH, &h->cap_objH, rows * (6 + pl->ldf + 1) + 16)) != ORCVIO_OK) return rc;
     const size_t nCd = nobj * pl->NOP * NAP, nSg = nobj * N * 64, nGff = nobj * pl->ldf * pl->ldf;
     const size_t nRa = nobj * (size_t)arrow_stride(pl->Kmax > 0 ? pl->Kmax : 1);
-    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, nCd + nSg + nGff + nRa)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, nCd + nSg + nGff + nRa + rows * 9)) != ORCVIO_OK) return rc;
     if ((rc = grow(&h->d_RF, &h->cap_RF, nobj * ((size_t)pl->NOP * pl->NOP + 7 * 256))) != ORCVIO_OK) return rc;
     if ((rc = grow(&h->d_Yobj, &h->cap_Yobj, nobj * pl->NOP * NAP)) != ORCVIO_OK) return rc;
     pl->d_clone = h->d_obj_i;
@@ -1793,6 +1793,7 @@ static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
     pl->d_Sg = pl->d_Cd + nCd;
     pl->d_Gff = pl->d_Sg + nSg;
     pl->d_Rarrow = pl->d_Gff + nGff;
+    pl->d_Bred = pl->d_Rarrow + nRa;
     return ORCVIO_OK;
 }
 
@@ -1802,30 +1803,32 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
     const int NA = h->NA, NAP = h->NAP, N = h->N, nobj = pl.nobj, NOP = pl.NOP, ldf = pl.ldf, no_max = pl.no_max;
     double* d_RF = h->d_RF;
     double* d_DinvF = h->d_RF + (size_t)nobj * NOP * NOP;
-    // zero: Y (padded rows), R_F (strictly-lower tiles), C (clones an object does not see), the clone tiles
-    HIPCHK(hipMemsetAsync(h->d_Yobj, 0, sizeof(double) * (size_t)nobj * NOP * NAP, s));
-    HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
+    // zero: C (clones an object does not see) and the clone tiles; for the Gram route also Y (padded rows) and R_F
+    // (strictly-lower tiles) -- the arrow route writes every entry of Y it reads
+    if (!pl.arrow) {
+        HIPCHK(hipMemsetAsync(h->d_Yobj, 0, sizeof(double) * (size_t)nobj * NOP * NAP, s));
+        HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
+    }
     HIPCHK(hipMemsetAsync(pl.d_Cd, 0, sizeof(double) * ((size_t)nobj * NOP * NAP + (size_t)nobj * N * 64), s));   // Cd and Sg are adjacent
     int rc = launch_prior_fork(h, s);   // Cholesky of P on the side stream
     if (rc != ORCVIO_OK) return rc;
     prof_mark(h, s, "rows+copies");
-    hipLaunchKernelGGL(k_obj_cross, dim3((pl.ngroups + 3) / 4), dim3(256), 0, s, pl.d_groups, pl.ngroups, pl.d_ridx, pl.d_hx, pl.d_hf, ldf,
-                       no_max, h->flags.leg_dim - 15, NAP, NOP, N, pl.d_Cd, pl.d_Sg);
-    {
-        const int nbf = ldf / 16;
-        hipLaunchKernelGGL(k_obj_gram_ff, dim3(nbf * (nbf + 1) / 2, nobj), dim3(1024), 0, s, pl.d_hf, ldf, pl.d_rowptr, pl.d_Gff);
+    {   // cross products, compact Grams and (arrow route) the keypoint blocks of the structured QR: one launch
+        const int nbf = ldf / 16, ntiles = nbf * (nbf + 1) / 2, kp_blocks = pl.arrow ? (pl.Kmax + 1 + 7) / 8 : 0;
+        const int blocks = (pl.ngroups + 7) / 8 + ntiles * nobj + kp_blocks * nobj;
+        hipLaunchKernelGGL(k_obj_front, dim3(blocks), dim3(512), 0, s, pl.d_groups, pl.ngroups, pl.d_ridx, pl.d_hx, pl.d_hf, ldf, no_max,
+                           h->flags.leg_dim - 15, NAP, NOP, N, pl.d_Cd, pl.d_Sg, pl.d_rowptr, pl.d_Gff, nobj, pl.d_arrow, pl.d_kp_range,
+                           pl.d_kp_rows, pl.Kmax, pl.d_Rarrow, pl.d_Bred, kp_blocks);
     }
-    prof_mark(h, s, "k_obj_cross+k_obj_gram_ff");
+    prof_mark(h, s, "k_obj_front");
+    const int solve_xblocks = (NAP + 255) / 256, nb_solve = pl.arrow ? solve_xblocks * nobj : 0;
     if (pl.arrow) {
-        // R of Hf by structured Householder QR (cond(Hf), not its square: msckf_kernels.hpp), then Y_o = R^-T C_o
+        // R of Hf by structured Householder QR (cond(Hf), not its square: msckf_kernels.hpp); the keypoint blocks are done, the border:
         HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));
-        const size_t lds = sizeof(double) * ((size_t)pl.rows_max * 9 + 32);
-        hipLaunchKernelGGL(k_obj_arrow_qr, dim3(nobj), dim3(512), lds, s, pl.d_arrow, pl.d_kp_range, pl.d_kp_rows, pl.d_hf, ldf, pl.Kmax,
-                           pl.d_Rarrow, h->d_info + 4);
-        prof_mark(h, s, "k_obj_arrow_qr(Hf)");
-        hipLaunchKernelGGL(k_obj_arrow_solve, dim3((NA + 1 + 255) / 256, nobj), dim3(256), 0, s, pl.d_arrow, pl.d_Rarrow, pl.Kmax, pl.d_Cd,
-                           NOP, NAP, NA, pl.d_Gff, ldf, no_max, h->d_Yobj, h->d_info + 4);
-        prof_mark(h, s, "k_obj_arrow_solve(Y)");
+        if (pl.rows_max <= 512) hipLaunchKernelGGL(k_obj_border_qr<2>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, pl.d_Rarrow);
+        else if (pl.rows_max <= 1024) hipLaunchKernelGGL(k_obj_border_qr<4>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, pl.d_Rarrow);
+        else hipLaunchKernelGGL(k_obj_border_qr<8>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, pl.d_Rarrow);
+        prof_mark(h, s, "k_obj_border_qr(Hf)");
     } else {
     // (Hf without the arrow structure of ObjectLM's state: the Gram route.)  F_o = Hf^T Hf (lower tiles of Gff) -> R_F ;
     // Y_o = L_F^-1 C_o, C_o = [Cd_o | Hf^T r]
@@ -1847,9 +1850,10 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
         prof_mark(h, s, "k_trsm_lds(Y) batched");
     }
     }
-    // A' = sum_o B_o - Y^T Y  (Y = all Y_o stacked; padded rows are zero)
-    hipLaunchKernelGGL(k_obj_assemble_B, dim3((NAP * NAP + 255) / 256), dim3(256), 0, s, pl.d_Sg, nobj, N, pl.d_Gff, ldf, no_max,
-                       h->flags.leg_dim - 15, NA, NAP, h->d_Ab);
+    // Y_o = R^-T C_o (arrow route) and sum_o B_o in one launch; then A' = sum_o B_o - Y^T Y (Y = all Y_o stacked; padded rows are zero)
+    hipLaunchKernelGGL(k_obj_solve_assemble, dim3(nb_solve + (NAP * NAP + 255) / 256), dim3(256), sizeof(double) * arrow_stride(pl.Kmax > 0 ? pl.Kmax : 1), s,
+                       nb_solve, solve_xblocks, pl.d_arrow, pl.d_Rarrow, pl.Kmax, pl.d_Cd, NOP, NAP, NA, pl.d_Gff, ldf, no_max, h->d_Yobj, h->d_info + 4,
+                       pl.d_Sg, nobj, N, h->flags.leg_dim - 15, h->d_Ab);
     hipLaunchKernelGGL(k_gemm, dim3((NAP / 16) * (NAP / 16)), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
                        NAP, NAP, nobj * NOP, -1.0, 0.0, 0, dst, (long)NAP, 1L, h->d_Ab);
     HIPCHK(hipGetLastError());
@@ -1899,25 +1903,24 @@ static void merge_objects_ref_stack(int N, int nobj, int rows_tot, int* ridx, in
 // returns false if some object does not fit the kernel's limits (<= 128 rows per keypoint, <= 2048 rows per object).
 static bool build_arrow(const int* rowkp, const int* rowptr, const int* Ks, int nobj, ObjArrow* arrows, int2* ranges, int* kp_rows,
                         int* Kmax, int* rows_max) {
+    // per object K + 1 ranges into kp_rows: the rows of keypoint block 0 .. K-1, then the border-only rows
     int off = 0, pos = 0;
     *Kmax = 0; *rows_max = 0;
     for (int o = 0; o < nobj; ++o) {
         const int r0 = rowptr[o], r1 = rowptr[o + 1], K = Ks[o];
         if (r1 - r0 > 2048 || K > 34) return false;
-        int cnt[35] = {0};
-        for (int r = r0; r < r1; ++r)
-            if (rowkp[r] >= 0) cnt[rowkp[r]]++;
-        int start[35];
-        for (int k = 0; k < K; ++k) {
-            if (cnt[k] > 128) return false;
+        int cnt[36] = {0};
+        for (int r = r0; r < r1; ++r) cnt[rowkp[r] >= 0 ? rowkp[r] : K]++;
+        int start[36];
+        for (int k = 0; k <= K; ++k) {
+            if (k < K && cnt[k] > 128) return false;
             start[k] = pos;
             ranges[off + k] = int2{pos, pos + cnt[k]};
             pos += cnt[k];
         }
-        for (int r = r0; r < r1; ++r)
-            if (rowkp[r] >= 0) kp_rows[start[rowkp[r]]++] = r;
+        for (int r = r0; r < r1; ++r) kp_rows[start[rowkp[r] >= 0 ? rowkp[r] : K]++] = r;
         arrows[o] = ObjArrow{r0, r1 - r0, K, off};
-        off += K;
+        off += K + 1;
         if (K > *Kmax) *Kmax = K;
         if (r1 - r0 > *rows_max) *rows_max = r1 - r0;
     }
@@ -1999,7 +2002,7 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     for (int o : use) sumK += (size_t)((objs[o].n_obj_cols - 9) / 3 > 0 ? (objs[o].n_obj_cols - 9) / 3 : 0);
     const size_t nd = rows * 6 + rows * ldf;
     const size_t o_ridx = 0, o_rowptr = o_ridx + rows, o_arrow = o_rowptr + pl.nobj + 1, o_range = o_arrow + (size_t)4 * pl.nobj,
-                 o_kprows = o_range + 2 * sumK, o_groups = o_kprows + rows, ni = o_groups + (size_t)4 * pl.nobj * N;
+                 o_kprows = o_range + 2 * (sumK + (size_t)pl.nobj), o_groups = o_kprows + rows, ni = o_groups + (size_t)4 * pl.nobj * N;
     if ((rc = obj_stage_reserve(h, nd * 8 + ni * 4)) != ORCVIO_OK) return rc;
     double* hd = reinterpret_cast<double*>(h->h_obj_stage);
     int* hi = reinterpret_cast<int*>(h->h_obj_stage + nd * 8);
@@ -2141,7 +2144,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     size_t sumK = 0;
     for (const Use& u : use) sumK += (size_t)tracks[u.t].n_keypoints;
     const size_t o_ridx = ni, o_rowptr = o_ridx + rows, o_arrow = o_rowptr + pl.nobj + 1, o_range = o_arrow + (size_t)4 * pl.nobj,
-                 o_kprows = o_range + 2 * sumK, o_groups = o_kprows + rows, ni_tot = o_groups + (size_t)4 * pl.nobj * N;
+                 o_kprows = o_range + 2 * (sumK + (size_t)pl.nobj), o_groups = o_kprows + rows, ni_tot = o_groups + (size_t)4 * pl.nobj * N;
     if ((rc = obj_stage_reserve(h, nd * 8 + ni_tot * 4)) != ORCVIO_OK) return rc;
     double* hd = reinterpret_cast<double*>(h->h_obj_stage);
     int* hi = reinterpret_cast<int*>(h->h_obj_stage + nd * 8);

@@ -51,7 +51,7 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ double wave_sum(double x) {
+__device__ __forceinline__ double wave_sum_shfl(double x) {   // (round 1's form: six ds_bpermute pairs; kept for reference)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
     return x;
@@ -63,6 +63,28 @@ __device__ __forceinline__ double bcast_lane(double x, int lane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
 }
+
+// Sum over the 64 lanes with DPP moves instead of ds_bpermute shuffles: per step two v_mov_b32_dpp (the halves of the double)
+// and one v_add_f64 -- quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror give every 16-lane row its total;
+// row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the totals along, lane 63 ends up with the wave's total, which
+// v_readlane broadcasts.  About 20 instructions against ~150 for six __shfl_xor of a double.  (Order of summation differs
+// from wave_sum: results agree to rounding, not bit for bit.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double x) {
+    x += dpp_move<0xB1, 0xF>(x);    // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E, 0xF>(x);    // quad_perm [2,3,0,1]
+    x += dpp_move<0x141, 0xF>(x);   // row_half_mirror
+    x += dpp_move<0x140, 0xF>(x);   // row_mirror: every lane of a row holds the row's total
+    x += dpp_move<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3 (the other rows add 0)
+    x += dpp_move<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3
+    return bcast_lane(x, 63);
+}
+__device__ __forceinline__ double wave_sum(double x) { return wave_sum_dpp(x); }
 
 // 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps
 __device__ __forceinline__ double rsqrt_nr(double d) {
@@ -2324,13 +2346,10 @@ __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ 
 // k_obj_cross: one wavefront per (object, clone) group {first, last+1 into ridx, clone, object}; ridx lists the rows of
 // the update grouped by (object, clone).  MFMA with A = hx^T (6 of 16 rows live), B = [Hf | r] tile by tile and hx.
 struct ObjGroup { int r0, r1, clone, obj; };
-__global__ __launch_bounds__(256) void k_obj_cross(const ObjGroup* __restrict__ groups, int ngroups, const int* __restrict__ ridx,
-                                                   const double* __restrict__ Hx6, const double* __restrict__ HfR, int ldf,
-                                                   int no_max, int cb0, int NAP, int NOP, int N,
-                                                   double* __restrict__ Cd, double* __restrict__ Sg) {
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + wave;
-    if (g >= ngroups) return;
+__device__ __forceinline__ void obj_cross_body(const ObjGroup* __restrict__ groups, int g, int l, const int* __restrict__ ridx,
+                                               const double* __restrict__ Hx6, const double* __restrict__ HfR, int ldf,
+                                               int no_max, int cb0, int NAP, int NOP, int N,
+                                               double* __restrict__ Cd, double* __restrict__ Sg) {
     const ObjGroup grp = groups[g];
     const int m = l & 15, kq = l >> 4;
     const int nt = ldf >> 4;   // <= 8 (object state <= 112 columns)
@@ -2378,30 +2397,28 @@ __global__ __launch_bounds__(256) void k_obj_cross(const ObjGroup* __restrict__ 
         }
     }
 }
-// Gff[o] = [Hf | r]^T [Hf | r] (lower tiles) over the rows [row_ptr[o], row_ptr[o+1]) of object o: grid (tiles, objects),
-// sixteen wavefronts split the rows of one tile (as k_gram_pair)
-__global__ __launch_bounds__(1024) void k_obj_gram_ff(const double* __restrict__ HfR, int ldf, const int* __restrict__ row_ptr,
-                                                      double* __restrict__ Gff) {
-    int bi, bj;
-    tile_from_linear(blockIdx.x, bi, bj);
-    const int o = blockIdx.y;
-    gram16_body(HfR, ldf, row_ptr[o], row_ptr[o + 1], bi, bj, Gff + (size_t)o * ldf * ldf, ldf);
-}
 // dst (NAP x NAP, full symmetric) = sum over objects of B_o: clone tiles from Sg, |r|^2 from Gff[no_max][no_max]
 // (objects summed in index order: deterministic)
-__global__ __launch_bounds__(256) void k_obj_assemble_B(const double* __restrict__ Sg, int nobj, int N, const double* __restrict__ Gff,
-                                                        int ldf, int no_max, int cb0, int NA, int NAP, double* __restrict__ dst) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void obj_assemble_B_body(int idx, const double* __restrict__ Sg, int nobj, int N, const double* __restrict__ Gff,
+                                                    int ldf, int no_max, int cb0, int NA, int NAP, double* __restrict__ dst) {
     if (idx >= NAP * NAP) return;
     const int i = idx / NAP, j = idx - i * NAP;
     const int ci = (i >= cb0 && i < cb0 + 6 * N) ? (i - cb0) / 6 : -1, cj = (j >= cb0 && j < cb0 + 6 * N) ? (j - cb0) / 6 : -1;
     const int ei = ci >= 0 ? i - cb0 - 6 * ci : (i == NA ? 6 : -1), ej = cj >= 0 ? j - cb0 - 6 * cj : (j == NA ? 6 : -1);
     double s = 0.0;
-    if (ei == 6 && ej == 6) {
-        for (int o = 0; o < nobj; ++o) s += Gff[(size_t)o * ldf * ldf + (size_t)no_max * ldf + no_max];
-    } else if (ei >= 0 && ej >= 0 && (ci == cj || ci < 0 || cj < 0)) {
-        const int c = ci >= 0 ? ci : cj;
-        for (int o = 0; o < nobj; ++o) s += Sg[((size_t)o * N + c) * 64 + ei * 8 + ej];
+    const bool corner = ei == 6 && ej == 6;
+    const bool tile = !corner && ei >= 0 && ej >= 0 && (ci == cj || ci < 0 || cj < 0);
+    if (corner || tile) {   // (everything else of the block is structurally zero: no loads)
+        const double* base = corner ? Gff + (size_t)no_max * ldf + no_max : Sg + (size_t)(ci >= 0 ? ci : cj) * 64 + ei * 8 + ej;
+        const size_t st = corner ? (size_t)ldf * ldf : (size_t)N * 64;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int o = 0;
+        for (; o + 4 <= nobj; o += 4) {   // four loads in flight; objects summed in a fixed order (deterministic)
+            const double v0 = base[(size_t)o * st], v1 = base[(size_t)(o + 1) * st], v2 = base[(size_t)(o + 2) * st], v3 = base[(size_t)(o + 3) * st];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; o < nobj; ++o) s0 += base[(size_t)o * st];
+        s = (s0 + s1) + (s2 + s3);
     }
     dst[idx] = s;
 }
@@ -2414,10 +2431,10 @@ __global__ __launch_bounds__(256) void k_obj_assemble_B(const double* __restrict
 // reference takes the left nullspace from a full-U JacobiSVD (math_utils.hpp:287-312), accurate to cond * eps.
 // Hf is an ARROW matrix (include/orcvio/obj/ObjectLM.h:117-123): columns [pose 6 | shape 3 | keypoint k: 3 each], a
 // keypoint row touches the border (pose, shape) and ITS keypoint's block only, a bbox row the border only.  So:
-//   phase B  one wavefront per keypoint: Householder QR (three reflectors, LAPACK dgeqr2 convention) of its m x 3 block
+//   phase B  (k_obj_kp_qr) one wavefront per keypoint: Householder QR (three reflectors, LAPACK dgeqr2 convention) of its m x 3 block
 //            (m <= 128 rows, two per lane), applied to the nine border columns of the same rows: R_kk (3 x 3), R_kb
 //            (3 x 9), and the rows' border part after elimination (back into LDS)
-//   phase C  the whole workgroup: Householder QR of the eliminated border (all rows x 9, in LDS): R_b (9 x 9)
+//   phase C  (k_obj_border_qr) one workgroup per object: Householder QR of the eliminated border (all rows x 9): R_b (9 x 9)
 // R = [[blockdiag R_kk, R_kb], [0, R_b]] up to the column order.  k_obj_arrow_solve then forms Y = R^-T C by forward
 // substitution, one thread per column of C.  A pivot that is zero to rounding (a keypoint seen in one frame only, an exactly
 // dependent column) is dropped (its row of Y is zero) and counted.
@@ -2425,141 +2442,150 @@ struct ObjArrow { int row0, rows, K, kp_off; };   // rows [row0, row0 + rows) of
                                                   // entry of this object in kp_range
 // Rout per object (stride arrow_stride(Kmax)): [K][3 x 3 R_kk | 3 x 9 R_kb] , then 9 x 9 R_b, then the pivot tolerance
 __host__ __device__ inline int arrow_stride(int Kmax) { return 36 * Kmax + 81 + 3; }
-__device__ __forceinline__ double block_sum512(double x, double* sRed, int tid) {   // all 512 threads; deterministic order
-    x = wave_sum(x);
-    __syncthreads();
-    if ((tid & 63) == 0) sRed[tid >> 6] = x;
-    __syncthreads();
-    return ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]));
+// Two launches (a first version did both phases in one 1024-thread workgroup per object: 755 spilled VGPRs, 209 us):
+//   k_obj_kp_qr      grid (ceil(Kmax / 4), objects) x 256 threads: one wavefront per (object, keypoint), everything in
+//                    registers; the border part of its rows is rewritten IN PLACE in HfR (columns 0..8; the three pivot rows are
+//                    zeroed) -- k_obj_cross / k_obj_gram_ff have read HfR before
+//   k_obj_border_qr  one 256-thread workgroup per object: the nine reflectors of the eliminated border, rows in registers
+__device__ __forceinline__ void obj_kp_qr_body(const ObjArrow ob, int obj, int k, int lane, const int2* __restrict__ kp_range,
+                                               const int* __restrict__ kp_rows, const double* __restrict__ HfR, int ldf, int Kmax,
+                                               double* __restrict__ Rout, double* __restrict__ Bred) {
+    const int2 rg = kp_range[ob.kp_off + k];
+    if (k == ob.K) {   // the border-only rows (bbox rows): their border goes to Bred as it is
+        for (int p = rg.x + lane; p < rg.y; p += 64) {
+            const int r = kp_rows[p];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Bred[(size_t)r * 9 + c] = HfR[(size_t)r * ldf + c];
+        }
+        return;
+    }
+    double* Ro = Rout + (size_t)obj * arrow_stride(Kmax);
+    const int m = rg.y - rg.x;   // <= 128 (host-checked)
+    int rl[2];
+    bool in[2];
+    double a[2][3], b[2][9];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int pos = lane + 64 * u;
+        in[u] = pos < m;
+        rl[u] = in[u] ? kp_rows[rg.x + pos] : ob.row0;
+        const double* row = HfR + (size_t)rl[u] * ldf;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const double v = row[9 + 3 * k + c]; a[u][c] = in[u] ? v : 0.0; }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { const double v = row[c]; b[u][c] = in[u] ? v : 0.0; }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // rows below the pivot (list positions > j): g_c = sum a_j * col_c over them, for col = a_j (norm^2), a_c>j, b_0..8
+        const bool below0 = lane > j;   // slot 0: position = lane; slot 1: position = lane + 64 > j always
+        const double x0 = (in[0] && below0) ? a[0][j] : 0.0, x1 = in[1] ? a[1][j] : 0.0;
+        double g[12];
+        g[0] = x0 * x0 + x1 * x1;
+#pragma unroll
+        for (int c = 1; c < 3; ++c) g[c] = (c > j) ? x0 * a[0][c] + x1 * a[1][c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) g[3 + c] = x0 * b[0][c] + x1 * b[1][c];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) g[q] = wave_sum_dpp(g[q]);   // (independent: the twelve reductions interleave)
+        const double alpha = bcast_lane(a[0][j], j);   // pivot entry (0 if the list is shorter than j + 1: a is 0 there)
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (g[0] > 0.0) {   // dlarfg: beta = -sign(alpha) ||x||, tau = (beta - alpha) / beta, v = x / (alpha - beta), v_pivot = 1
+            const double nrm = sqrt(alpha * alpha + g[0]);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        const double v0 = x0 * scale, v1 = x1 * scale;   // the reflector below the pivot (0 outside)
+        const bool piv = lane == j;                       // slot 0 of lane j is the pivot row
+#pragma unroll
+        for (int c = 1; c < 3; ++c) {
+            if (c > j) {
+                const double w = tau * (bcast_lane(a[0][c], j) + scale * g[c]);
+                a[0][c] -= piv ? w : w * v0;
+                a[1][c] -= w * v1;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const double w = tau * (bcast_lane(b[0][c], j) + scale * g[3 + c]);
+            b[0][c] -= piv ? w : w * v0;
+            b[1][c] -= w * v1;
+        }
+        if (piv) a[0][j] = beta;
+        if (lane > j) a[0][j] = 0.0;
+        a[1][j] = 0.0;
+    }
+    // R_kk rows 0..2 and R_kb rows 0..2 live in slot 0 of lanes 0..2; the other rows go to the reduced border
+    if (lane < 3) {
+        double* o = Ro + 36 * k + 12 * lane;   // row `lane`: [3 of R_kk | 9 of R_kb]
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (c >= lane && lane < m) ? a[0][c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) o[3 + c] = lane < m ? b[0][c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (in[u]) {
+            const bool consumed = (u == 0 && lane < 3);
+            double* row = Bred + (size_t)rl[u] * 9;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) row[c] = consumed ? 0.0 : b[u][c];
+        }
+    }
 }
-__global__ __launch_bounds__(512) void k_obj_arrow_qr(const ObjArrow* __restrict__ objs, const int2* __restrict__ kp_range,
-                                                      const int* __restrict__ kp_rows, const double* __restrict__ HfR, int ldf,
-                                                      int Kmax, double* __restrict__ Rout, int* __restrict__ info) {
-    extern __shared__ __attribute__((aligned(16))) double sB[];   // [rows][9] border part of every row, then 16 doubles of scratch
+template <int RPT>   // rows per thread: RPT * 256 >= the rows of the largest object (2, 4 or 8)
+__global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restrict__ objs, const double* __restrict__ Bred, int Kmax,
+                                                       double* __restrict__ Rout) {
+    __shared__ double sPiv[16];
+    __shared__ double sPart[4 * 9];
     const ObjArrow ob = objs[blockIdx.x];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    double* sRed = sB + (size_t)ob.rows * 9;
     double* Ro = Rout + (size_t)blockIdx.x * arrow_stride(Kmax);
-    for (int i = tid; i < ob.rows * 9; i += 512) {
-        const int r = i / 9, c = i - 9 * r;
-        sB[i] = HfR[(size_t)(ob.row0 + r) * ldf + c];
-    }
-    __syncthreads();
-    // ---- phase B: the keypoint blocks -----------------------------------------------------------------------------------
-    for (int k = wave; k < ob.K; k += 8) {
-        const int2 rg = kp_range[ob.kp_off + k];
-        const int m = rg.y - rg.x;   // <= 128 (host-checked)
-        int rl[2];
-        bool in[2];
-        double a[2][3], b[2][9];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int pos = lane + 64 * u;
-            in[u] = pos < m;
-            rl[u] = in[u] ? kp_rows[rg.x + pos] - ob.row0 : 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const double v = HfR[(size_t)(ob.row0 + rl[u]) * ldf + 9 + 3 * k + c]; a[u][c] = in[u] ? v : 0.0; }
-#pragma unroll
-            for (int c = 0; c < 9; ++c) { const double v = sB[rl[u] * 9 + c]; b[u][c] = in[u] ? v : 0.0; }
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            // rows below the pivot (list positions > j): g_c = sum a_j * col_c over them, for col = a_j (norm^2), a_c>j, b_0..8
-            const bool below0 = lane > j, below1 = true;   // slot 0: position = lane; slot 1: position = lane + 64 > j
-            const double x0 = (in[0] && below0) ? a[0][j] : 0.0, x1 = (in[1] && below1) ? a[1][j] : 0.0;
-            double g[12];
-            g[0] = x0 * x0 + x1 * x1;
-#pragma unroll
-            for (int c = 1; c < 3; ++c) g[c] = (c > j) ? x0 * a[0][c] + x1 * a[1][c] : 0.0;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) g[3 + c] = x0 * b[0][c] + x1 * b[1][c];
-#pragma unroll
-            for (int q = 0; q < 12; ++q) g[q] = wave_sum(g[q]);
-            const double alpha = bcast_lane(a[0][j], j);   // pivot entry (0 if the list is shorter than j + 1: a is 0 there)
-            double tau = 0.0, beta = alpha, scale = 0.0;
-            if (g[0] > 0.0) {   // dlarfg: beta = -sign(alpha) ||x||, tau = (beta - alpha) / beta, v = x / (alpha - beta), v_pivot = 1
-                const double nrm = sqrt(alpha * alpha + g[0]);
-                beta = alpha >= 0.0 ? -nrm : nrm;
-                tau = (beta - alpha) / beta;
-                scale = 1.0 / (alpha - beta);
-            }
-            const double v0 = x0 * scale, v1 = x1 * scale;   // the reflector below the pivot (0 outside)
-            const bool piv = lane == j;                       // slot 0 of lane j is the pivot row
-#pragma unroll
-            for (int c = 1; c < 3; ++c) {
-                if (c > j) {
-                    const double w = tau * (bcast_lane(a[0][c], j) + scale * g[c]);
-                    a[0][c] -= piv ? w : w * v0;
-                    a[1][c] -= w * v1;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                const double w = tau * (bcast_lane(b[0][c], j) + scale * g[3 + c]);
-                b[0][c] -= piv ? w : w * v0;
-                b[1][c] -= w * v1;
-            }
-            if (piv) a[0][j] = beta;
-            if (lane > j) a[0][j] = 0.0;
-            a[1][j] = 0.0;
-        }
-        // R_kk rows 0..2 and R_kb rows 0..2 live in slot 0 of lanes 0..2; the other rows go back to the border
-        if (lane < 3) {
-            double* o = Ro + 36 * k + 12 * lane;   // row `lane`: [3 of R_kk | 9 of R_kb]
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[c] = (c >= lane && lane < m) ? a[0][c] : 0.0;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) o[3 + c] = lane < m ? b[0][c] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (in[u]) {
-                const bool consumed = (u == 0 && lane < 3);
-#pragma unroll
-                for (int c = 0; c < 9; ++c) sB[rl[u] * 9 + c] = consumed ? 0.0 : b[u][c];
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase C: the border (all rows x 9, rows tid, tid + 512, ...) --------------------------------------------------
-    constexpr int RPT = 4;   // rows per thread: up to 2048 rows per object (host-checked)
+    // thread t holds rows t, t + 256, ... (up to 2048 rows per object, host-checked)
     double x[RPT][9];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const int r = tid + 512 * q;
+        const int r = tid + 256 * q;
+        const double* row = Bred + (size_t)(ob.row0 + (r < ob.rows ? r : 0)) * 9;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) x[q][c] = r < ob.rows ? sB[r * 9 + c] : 0.0;
+        for (int c = 0; c < 9; ++c) { const double v = row[c]; x[q][c] = r < ob.rows ? v : 0.0; }
     }
     double pmax = 0.0;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        // pivot row j is held by thread j (q = 0); publish it
-        __syncthreads();
-        if (tid == j) {
-#pragma unroll
-            for (int c = 0; c < 9; ++c) sRed[8 + c] = x[0][c];
-        }
-        __syncthreads();
-        double pr[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) pr[c] = sRed[8 + c];
-        const double alpha = (j < ob.rows) ? pr[j] : 0.0;
-        double xb[RPT];
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) xb[q] = (tid + 512 * q > j) ? x[q][j] : 0.0;   // (rows beyond ob.rows hold zeros)
+        // partial dot products of column j (rows below the pivot) with the columns j..8: ONE block reduction per reflector
         double g[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
             double sacc = 0.0;
             if (c >= j) {
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) sacc += xb[q] * x[q][c];
+                for (int q = 0; q < RPT; ++q) sacc += ((tid + 256 * q > j) ? x[q][j] : 0.0) * x[q][c];   // (rows beyond ob.rows hold zeros)
             }
             g[c] = sacc;
         }
 #pragma unroll
         for (int c = 0; c < 9; ++c)
-            if (c >= j) g[c] = block_sum512(g[c], sRed, tid);
+            if (c >= j) g[c] = wave_sum_dpp(g[c]);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+                if (c >= j) sPart[wave * 9 + c] = g[c];
+        }
+        if (tid == j) {   // pivot row j is held by thread j (q = 0): publish it
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sPiv[c] = x[0][c];
+        }
+        __syncthreads();
+        double pr[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            pr[c] = sPiv[c];
+            if (c >= j) g[c] = (sPart[c] + sPart[9 + c]) + (sPart[18 + c] + sPart[27 + c]);   // fixed order: deterministic
+        }
+        __syncthreads();   // sPart / sPiv are rewritten by the next reflector
+        const double alpha = (j < ob.rows) ? pr[j] : 0.0;
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (g[j] > 0.0) {
             const double nrm = sqrt(alpha * alpha + g[j]);
@@ -2568,19 +2594,16 @@ __global__ __launch_bounds__(512) void k_obj_arrow_qr(const ObjArrow* __restrict
             scale = 1.0 / (alpha - beta);
         }
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            if (c > j) {
-                const double w = tau * (pr[c] + scale * g[c]);
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + 256 * q;
+            const double vq = r > j ? x[q][j] * scale : 0.0;   // the reflector's entry of this row (the pivot row: 1)
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const int r = tid + 512 * q;
-                    if (r == j) x[q][c] -= w; else x[q][c] -= w * (xb[q] * scale);
+            for (int c = 0; c < 9; ++c) {
+                if (c > j) {
+                    const double w = tau * (pr[c] + scale * g[c]);
+                    x[q][c] -= (r == j) ? w : w * vq;
                 }
             }
-        }
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int r = tid + 512 * q;
             if (r == j) x[q][j] = beta; else if (r > j) x[q][j] = 0.0;
         }
         pmax = fmax(pmax, fabs(beta));
@@ -2598,46 +2621,69 @@ __global__ __launch_bounds__(512) void k_obj_arrow_qr(const ObjArrow* __restrict
             for (int j = 0; j < 3; ++j) mx = fmax(mx, fabs(Ro[36 * k + 12 * j + j]));
         Ro[36 * Kmax + 81] = 1e-13 * mx;
     }
-    (void)info;
 }
 // Y_o = R^-T C_o for the arrow factor: one thread per column of C (window columns 0..NA-1 from Cd, column NA = Hf^T r
 // from the compact Gram's residual row).  Rows of Y in the order of Hf's columns; dropped pivots give zero rows.
-__global__ __launch_bounds__(256) void k_obj_arrow_solve(const ObjArrow* __restrict__ objs, const double* __restrict__ Rin, int Kmax,
-                                                         const double* __restrict__ Cd, int NOP, int NAP, int NA,
-                                                         const double* __restrict__ Gff, int ldf, int no_max,
-                                                         double* __restrict__ Y, int* __restrict__ info) {
-    const int o = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
-    if (col > NA) return;
+__device__ __forceinline__ void obj_arrow_solve_body(double* __restrict__ sR, int o, int col, const ObjArrow* __restrict__ objs,
+                                                     const double* __restrict__ Rin, int Kmax,
+                                                     const double* __restrict__ Cd, int NOP, int NAP, int NA,
+                                                     const double* __restrict__ Gff, int ldf, int no_max,
+                                                     double* __restrict__ Y, int* __restrict__ info) {
+    // (the factor goes to LDS once per workgroup; every thread has the C entries of a batch of keypoints in flight before it
+    // starts substituting: a handful of memory round trips, not one per keypoint)
     const ObjArrow ob = objs[o];
     const double* Ro = Rin + (size_t)o * arrow_stride(Kmax);
-    const double tol = Ro[36 * Kmax + 81];
+    for (int i = threadIdx.x; i < arrow_stride(Kmax); i += 256) sR[i] = Ro[i];
+    __syncthreads();
+    if (col > NA) {   // padding columns of the block: zero (A' = B - Y^T Y is formed over all NAP columns)
+        if (col < NAP)
+            for (int i = 0; i < NOP; ++i) Y[(size_t)o * NOP * NAP + (size_t)i * NAP + col] = 0.0;
+        return;
+    }
+    const double tol = sR[36 * Kmax + 81];
     const double* Co = Cd + (size_t)o * NOP * NAP;
     const double* hr = Gff + (size_t)o * ldf * ldf + (size_t)no_max * ldf;   // row no_max of the compact Gram: (Hf^T r)^T
     double* Yo = Y + (size_t)o * NOP * NAP;
-    auto Cget = [&](int i) { return col < NA ? Co[(size_t)i * NAP + col] : hr[i]; };
+    const bool rcol = col == NA;
+    const double* src = rcol ? hr : Co + col;
+    const size_t st = rcol ? 1 : (size_t)NAP;
     double cb[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) cb[i] = Cget(i);
+    for (int i = 0; i < 9; ++i) cb[i] = src[(size_t)i * st];
     int dropped = 0;
-    for (int k = 0; k < ob.K; ++k) {
-        const double* Rk = Ro + 36 * k;   // rows j: [R_kk(j, 0..2) | R_kb(j, 0..8)]
-        double y[3];
+    constexpr int KB = 12;   // keypoints per batch of loads
+    for (int k0 = 0; k0 < ob.K; k0 += KB) {
+        double c[KB][3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double t = Cget(9 + 3 * k + j);
+        for (int q = 0; q < KB; ++q) {
+            const int k = k0 + q < ob.K ? k0 + q : ob.K - 1;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (i < j) t -= Rk[12 * i + j] * y[i];
-            const double p = Rk[12 * j + j];
-            const bool ok = fabs(p) > tol;
-            dropped += ok ? 0 : 1;
-            y[j] = ok ? t / p : 0.0;
-            Yo[(size_t)(9 + 3 * k + j) * NAP + col] = y[j];
+            for (int j = 0; j < 3; ++j) c[q][j] = src[(size_t)(9 + 3 * k + j) * st];
         }
 #pragma unroll
-        for (int c = 0; c < 9; ++c) cb[c] -= Rk[3 + c] * y[0] + Rk[12 + 3 + c] * y[1] + Rk[24 + 3 + c] * y[2];
+        for (int q = 0; q < KB; ++q) {
+            const int k = k0 + q;
+            if (k < ob.K) {
+                const double* Rk = sR + 36 * k;   // rows j: [R_kk(j, 0..2) | R_kb(j, 0..8)]
+                double y[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double t = c[q][j];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (i < j) t -= Rk[12 * i + j] * y[i];
+                    const double p = Rk[12 * j + j];
+                    const bool ok = fabs(p) > tol;
+                    dropped += ok ? 0 : 1;
+                    y[j] = ok ? t / p : 0.0;
+                    Yo[(size_t)(9 + 3 * k + j) * NAP + col] = y[j];
+                }
+#pragma unroll
+                for (int cc = 0; cc < 9; ++cc) cb[cc] -= Rk[3 + cc] * y[0] + Rk[12 + 3 + cc] * y[1] + Rk[24 + 3 + cc] * y[2];
+            }
+        }
     }
-    const double* Rb = Ro + 36 * Kmax;
+    const double* Rb = sR + 36 * Kmax;
     double yb[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
@@ -2651,7 +2697,63 @@ __global__ __launch_bounds__(256) void k_obj_arrow_solve(const ObjArrow* __restr
         yb[j] = ok ? t / p : 0.0;
         Yo[(size_t)j * NAP + col] = yb[j];
     }
+    for (int i = 9 + 3 * ob.K; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;   // rows behind this object's columns (A' sums Y^T Y over NOP rows)
     if (col == 0 && dropped > 0 && info) atomicAdd(info, dropped);
+}
+
+// ---- the object compression in three launches -------------------------------------------------------------------------
+// Every stage of it is a small latency-bound kernel (~4 us floor each): the independent ones share a launch.
+//   k_obj_front           512-thread workgroups with three roles by blockIdx.x: [0, nb_cross) the (object, clone) cross products, eight
+//                         groups per workgroup; [.., + ntiles * nobj) one tile of an object's compact Gram [Hf | r]^T [Hf | r], its rows
+//                         split over the eight wavefronts; [.., + kp_blocks * nobj) the keypoint blocks of the structured QR, eight per
+//                         workgroup (arrow route only)
+//   k_obj_border_qr       the nine border reflectors, one workgroup per object (arrow route only)
+//   k_obj_solve_assemble  256-thread workgroups: [0, nb_solve) Y = R^-T C (arrow route), then sum_o B_o
+__global__ __launch_bounds__(512) void k_obj_front(const ObjGroup* __restrict__ groups, int ngroups, const int* __restrict__ ridx,
+                                                   const double* __restrict__ Hx6, const double* __restrict__ HfR, int ldf,
+                                                   int no_max, int cb0, int NAP, int NOP, int N, double* __restrict__ Cd, double* __restrict__ Sg,
+                                                   const int* __restrict__ row_ptr, double* __restrict__ Gff, int nobj,
+                                                   const ObjArrow* __restrict__ objs, const int2* __restrict__ kp_range, const int* __restrict__ kp_rows,
+                                                   int Kmax, double* __restrict__ Rout, double* __restrict__ Bred, int kp_blocks) {
+    __shared__ __attribute__((aligned(16))) double sT[8 * 256];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nb_cross = (ngroups + 7) / 8;
+    const int nbf = ldf >> 4, ntiles = nbf * (nbf + 1) / 2;
+    int b = blockIdx.x;
+    if (b < nb_cross) {
+        const int g = b * 8 + wave;
+        if (g < ngroups) obj_cross_body(groups, g, lane, ridx, Hx6, HfR, ldf, no_max, cb0, NAP, NOP, N, Cd, Sg);
+        return;
+    }
+    b -= nb_cross;
+    if (b < ntiles * nobj) {
+        const int o = b / ntiles, tl = b - o * ntiles;
+        int bi, bj;
+        tile_from_linear(tl, bi, bj);
+        gramw_body<8, 20>(sT, HfR, ldf, row_ptr[o], row_ptr[o + 1], bi, bj, Gff + (size_t)o * ldf * ldf, ldf);
+        return;
+    }
+    b -= ntiles * nobj;
+    if (kp_blocks > 0) {
+        const int o = b / kp_blocks, k = (b - o * kp_blocks) * 8 + wave;
+        const ObjArrow ob = objs[o];
+        if (k <= ob.K) obj_kp_qr_body(ob, o, k, lane, kp_range, kp_rows, HfR, ldf, Kmax, Rout, Bred);
+    }
+}
+__global__ __launch_bounds__(256) void k_obj_solve_assemble(int nb_solve, int solve_xblocks, const ObjArrow* __restrict__ objs,
+                                                            const double* __restrict__ Rin, int Kmax, const double* __restrict__ Cd, int NOP,
+                                                            int NAP, int NA, const double* __restrict__ Gff, int ldf, int no_max,
+                                                            double* __restrict__ Y, int* __restrict__ info, const double* __restrict__ Sg,
+                                                            int nobj, int N, int cb0, double* __restrict__ Bdst) {
+    extern __shared__ double sR[];   // arrow_stride(Kmax) doubles (solve role)
+    int b = blockIdx.x;
+    if (b < nb_solve) {
+        const int o = b / solve_xblocks, xb = b - o * solve_xblocks;
+        obj_arrow_solve_body(sR, o, xb * 256 + (int)threadIdx.x, objs, Rin, Kmax, Cd, NOP, NAP, NA, Gff, ldf, no_max, Y, info);
+        return;
+    }
+    b -= nb_solve;
+    obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, Gff, ldf, no_max, cb0, NA, NAP, Bdst);
 }
 
 // gamma = (|r'|^2 - |z|^2) / s2 for the joint object block (identity in DESIGN.md), chi-square gate and the

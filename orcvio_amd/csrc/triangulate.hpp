@@ -30,10 +30,23 @@ struct TriArgs {
     int F;
 };
 
+// sum over the wavefront by DPP moves (two v_mov_b32_dpp + one v_add_f64 per step, then v_readlane of lane 63) instead of six
+// ds_bpermute shuffle pairs: the Levenberg-Marquardt loop below is a chain of these reductions
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double tri_dpp_move(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double tri_wave_sum(double x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    x += tri_dpp_move<0xB1, 0xF>(x);    // quad_perm [1,0,3,2]
+    x += tri_dpp_move<0x4E, 0xF>(x);    // quad_perm [2,3,0,1]
+    x += tri_dpp_move<0x141, 0xF>(x);   // row_half_mirror
+    x += tri_dpp_move<0x140, 0xF>(x);   // row_mirror
+    x += tri_dpp_move<0x142, 0xA>(x);   // row_bcast:15 -> rows 1, 3
+    x += tri_dpp_move<0x143, 0xC>(x);   // row_bcast:31 -> rows 2, 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
 }
 
 __global__ __launch_bounds__(64) void k_triangulate(TriArgs p) {
