@@ -390,6 +390,37 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
                                           const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
                                           double* d_dst, int32_t* dof_out, void* stream);
 
+/* ---- Object update straight from the wire format of the object mapper ------------------------------
+ * One element per orcvio_ros_msgs/ObjectLM message (ros_wrapper/src/orcvio_ros_msgs/msg/ObjectLM.msg) as ObjectInitNode fills it
+ * (ros_wrapper/src/orcvio/src/ObjectInitNode.cpp:1180-1207): the export block of single_levenberg_marquardt
+ * (src/obj/ObjectFeatureInitializer.cpp:394-434).  Matrices are the `data` arrays of the std_msgs/Float64MultiArray fields;
+ * tf::matrixEigenToMsg writes them ROW-MAJOR (dim[0] = rows, dim[1] = cols).  The reference's System::msgToEigen maps that
+ * buffer as COLUMN-major (System.cpp:710-723: SURVEY note N4, the object update could never have been right over ROS);
+ * wire_row_major = 1 (default semantics: what the sender meant) reads the buffers as they were written, 0 reproduces msgToEigen
+ * literally.  Rows are ordered [2 per valid keypoint of frame 0, frame 1, ... ; 4 bbox rows of frame 0, frame 1, ...].
+ * orcvio_msckf_update_object_lm_msgs does, per message, OrcVIO::constructObjectResidualJacobians (src/orcvio.cpp:2017-2151:
+ * exact timestamp match against cur_window_timestamps, D = get_cam_wrt_imu_se3_jacobian of SE3::exp(valid_camera_pose_mat
+ * column) with the CURRENT extrinsics, rows re-interleaved per in-window frame; host arithmetic), then the stacking of
+ * System::processObjects (System.cpp:684-702; per-object projection unless ORCVIO_OPT_REF_STACK_HF) and
+ * OrcVIO::removeLostObjects (:2154-2193) on the device. */
+typedef struct orcvio_object_lm_msg {
+    int64_t object_id;
+    int32_t n_rows;                          /* rows of residual / both Jacobians                                     */
+    int32_t n_obj_cols;                      /* columns of jacobian_wrt_object_state (45 for a 12-keypoint class)     */
+    int32_t n_frames;                        /* timestamps.size() == zs_num_wrt_timestamps.size() == pose columns      */
+    const double* residual;                  /* [n_rows]                                                              */
+    const double* jacobian_wrt_object_state; /* n_rows x n_obj_cols                                                   */
+    const double* jacobian_wrt_sensor_state; /* n_rows x 6                                                            */
+    const double* valid_camera_pose_mat;     /* 6 x n_frames: se3 log (upsilon, omega) of every frame's wTc           */
+    const double* timestamps;                /* [n_frames]                                                            */
+    const int32_t* zs_num_wrt_timestamps;    /* [n_frames] valid keypoints per frame                                  */
+} orcvio_object_lm_msg;
+int32_t orcvio_msckf_update_object_lm_msgs(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
+                                           const double* cur_window_timestamps /* [n_clones] */, const double* R_b2c /* [9] */,
+                                           const double* t_c_b /* [3] */, int32_t fix_dcampose_dimupose_to_identity,
+                                           int32_t wire_row_major, const orcvio_object_lm_msg* msgs, int32_t n_msgs, const double* P,
+                                           orcvio_msckf_result* result);
+
 /* ---- Multi-GPU: the handle owns an RCCL communicator (SURVEY.md 8b "handle owns ... RCCL comm", 8e) --------------------
  * One process per GPU, one handle per process.  The reference has no collectives; the callers this serves are the same
  * three call sites (OrcVIO::removeLostFeatures src/orcvio.cpp:2497-2560, ::pruneImuStateBuffer :2803-2851,

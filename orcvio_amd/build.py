@@ -8,27 +8,31 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, 'lib')
 LIB = os.path.join(LIB_DIR, 'liborcvio_msckf.so')
+LIB_DBG = os.path.join(LIB_DIR, 'liborcvio_msckf_dbg.so')   # the same sources + the orcvio_msckf_debug_* test hooks
 SOURCES = ['msckf_capi.hip']
 DEPS = ['msckf_capi.hip', 'msckf_kernels.hpp', 'msckf_math.hpp', 'object_rows.hpp', 'triangulate.hpp', 'cov_ops.hpp', 'ekf_rows.hpp',
         os.path.join('..', '..', 'include', 'orcvio_msckf.h')]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compiles every HIP source for gfx950 into orcvio_amd/lib/liborcvio_msckf.so."""
-    if not force and not _stale():
-        return LIB
+def build_library(force: bool = False, verbose: bool = False, debug_hooks: bool = False) -> str:
+    """Compiles every HIP source for gfx950 into orcvio_amd/lib/liborcvio_msckf.so (the product: the C-ABI of
+    include/orcvio_msckf.h and nothing else), or with debug_hooks the diagnostics build liborcvio_msckf_dbg.so, which adds the
+    orcvio_msckf_debug_* test hooks (-DORCVIO_DEBUG_HOOKS)."""
+    lib = LIB_DBG if debug_hooks else LIB
+    if not force and not _stale(lib):
+        return lib
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-o', LIB] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-o', lib] + \
+          (['-DORCVIO_DEBUG_HOOKS'] if debug_hooks else []) + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib

@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'liborcvio_msckf.so')
+LIB_DBG_PATH = os.path.join(_HERE, 'lib', 'liborcvio_msckf_dbg.so')   # diagnostics build: + orcvio_msckf_debug_* (tests only)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -35,7 +36,7 @@ EXPORTS = [
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
     'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks', 'orcvio_msckf_new_feature_rows', 'orcvio_msckf_augment_state',
-    'orcvio_msckf_profile_stages',
+    'orcvio_msckf_profile_stages', 'orcvio_msckf_update_object_lm_msgs',
     'orcvio_msckf_comm_unique_id', 'orcvio_msckf_comm_init', 'orcvio_msckf_comm_destroy', 'orcvio_msckf_comm_info',
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
 ]
@@ -72,6 +73,13 @@ class ObjectTrackC(C.Structure):
                 ('frame_wTc', _dp), ('frame_zs', _dp), ('frame_bbox', _dp), ('frame_clone', _ip)]
 
 
+class ObjectLMMsg(C.Structure):
+    """orcvio_object_lm_msg: one orcvio_ros_msgs/ObjectLM message (include/orcvio_msckf.h)."""
+    _fields_ = [('object_id', C.c_int64), ('n_rows', C.c_int32), ('n_obj_cols', C.c_int32), ('n_frames', C.c_int32),
+                ('residual', _dp), ('jacobian_wrt_object_state', _dp), ('jacobian_wrt_sensor_state', _dp),
+                ('valid_camera_pose_mat', _dp), ('timestamps', _dp), ('zs_num_wrt_timestamps', _ip)]
+
+
 class MsckfResult(C.Structure):
     _fields_ = [('dx', _dp), ('P_out', _dp), ('accept', _ip), ('gamma', _dp), ('H_thin', _dp), ('r_thin', _dp),
                 ('K', _dp), ('G', _dp), ('stats', C.c_int32 * 8)]
@@ -96,22 +104,35 @@ class MsckfState(C.Structure):
 
 
 _LIB = None
+_LIB_DBG = None
 
 
-def load():
-    """Loads the HIP library; raises if it has not been built (no fallback)."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f'{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)')
+def load(debug_hooks=False):
+    """Loads the HIP library; raises if it has not been built (no fallback).  debug_hooks: the diagnostics build, which adds the
+    orcvio_msckf_debug_* test hooks (a separate shared object with its own state: handles must stay with the library that
+    created them)."""
+    global _LIB, _LIB_DBG
     try:
         # PyTorch ships its own libamdhip64; importing it first makes this process use ONE HIP
         # runtime (two runtimes in one process cannot both own the device).
         import torch  # noqa: F401
     except Exception:
         pass
-    lib = C.CDLL(LIB_PATH)
+    if debug_hooks:
+        if _LIB_DBG is None:
+            if not os.path.exists(LIB_DBG_PATH):
+                raise RuntimeError(f'{LIB_DBG_PATH} is missing: run __graft_entry__.build()')
+            _LIB_DBG = _bind(C.CDLL(LIB_DBG_PATH))
+        return _LIB_DBG
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)')
+    _LIB = _bind(C.CDLL(LIB_PATH))
+    return _LIB
+
+
+def _bind(lib):
     lib.orcvio_msckf_abi_version.restype = C.c_int32
     lib.orcvio_msckf_last_error.restype = C.c_char_p
     lib.orcvio_msckf_chi2_quantile.restype = C.c_double
@@ -162,7 +183,6 @@ def load():
     lib.orcvio_msckf_run_update_sharded.argtypes = [C.c_void_p, C.c_void_p]
     lib.orcvio_msckf_update_features_sharded.argtypes = lib.orcvio_msckf_update_features.argtypes
     lib.orcvio_msckf_update_object_tracks_sharded.argtypes = lib.orcvio_msckf_update_object_tracks.argtypes
-    _LIB = lib
     return lib
 
 
@@ -217,8 +237,9 @@ def make_flags(f) -> MsckfFlags:
 class MsckfUpdater:
     """Thin owner of one ``orcvio_msckf_handle`` taking ``synth.Window``-shaped inputs."""
 
-    def __init__(self, device=0, max_clones=32, max_features=2048, max_observations=65536):
-        self.lib = load()
+    def __init__(self, device=0, max_clones=32, max_features=2048, max_observations=65536, debug_hooks=False):
+        self.lib = load(debug_hooks)
+        self.debug_hooks = bool(debug_hooks)
         self.h = C.c_void_p()
         rc = self.lib.orcvio_msckf_create(device, max_clones, max_features, max_observations, C.byref(self.h))
         if rc != 0:
@@ -491,6 +512,41 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_update_objects')
         out = self._finish(out, res, 1)
+        out['gamma'] = float(out['gamma'][0])
+        out['accept'] = int(out['accept'][0])
+        return out
+
+    def update_object_lm_msgs(self, flags, n_clones, window_timestamps, R_b2c, t_c_b, msgs, P, fix_D=False, wire_row_major=True):
+        """msgs: list of dict(object_id, residual [rows], jacobian_wrt_object_state [rows, no], jacobian_wrt_sensor_state [rows, 6],
+        valid_camera_pose_mat [6, frames], timestamps [frames], zs_num_wrt_timestamps [frames]) -- the fields of ObjectLM.msg; the
+        2-d arrays are flattened in the wire's order (row-major, or column-major when wire_row_major is False)."""
+        fl = make_flags(flags)
+        order = 'C' if wire_row_major else 'F'
+        arr = (ObjectLMMsg * max(len(msgs), 1))()
+        keep = []
+        for k, m in enumerate(msgs):
+            res = np.ascontiguousarray(m['residual'], dtype=np.float64)
+            jo = np.asarray(m['jacobian_wrt_object_state'], dtype=np.float64)
+            js = np.asarray(m['jacobian_wrt_sensor_state'], dtype=np.float64)
+            pm = np.asarray(m['valid_camera_pose_mat'], dtype=np.float64)
+            ts = np.ascontiguousarray(m['timestamps'], dtype=np.float64)
+            zn = np.ascontiguousarray(m['zs_num_wrt_timestamps'], dtype=np.int32)
+            flat = [np.ascontiguousarray(a.ravel(order=order)) for a in (jo, js, pm)]
+            keep += [res, ts, zn] + flat
+            arr[k] = ObjectLMMsg(int(m.get('object_id', k)), len(res), jo.shape[1], len(ts), _d(res), _d(flat[0]), _d(flat[1]), _d(flat[2]), _d(ts), _i(zn))
+        wt = np.ascontiguousarray(window_timestamps, dtype=np.float64)
+        Rb = np.ascontiguousarray(R_b2c, dtype=np.float64)
+        tb = np.ascontiguousarray(t_c_b, dtype=np.float64)
+        Pc = None if P is None else np.ascontiguousarray(P, dtype=np.float64)
+        n = flags.leg_dim + 6 * n_clones + self.n_extra
+        out, res_ = self._result(n, 1)
+        self.lib.orcvio_msckf_update_object_lm_msgs.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.c_int32, _dp, _dp, _dp, C.c_int32, C.c_int32,
+                                                                C.POINTER(ObjectLMMsg), C.c_int32, _dp, C.POINTER(MsckfResult)]
+        rc = self.lib.orcvio_msckf_update_object_lm_msgs(self.h, C.byref(fl), n_clones, _d(wt), _d(Rb), _d(tb), int(fix_D), int(wire_row_major),
+                                                         arr, len(msgs), _d(Pc), C.byref(res_))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_update_object_lm_msgs')
+        out = self._finish(out, res_, 1)
         out['gamma'] = float(out['gamma'][0])
         out['accept'] = int(out['accept'][0])
         return out

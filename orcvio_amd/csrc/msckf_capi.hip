@@ -37,6 +37,7 @@ static thread_local std::string g_last_error;
     } while (0)
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static void so3_exp_decl(const double w[3], double R[9]);   // Sophus SO3d::exp (defined with incrementState_IMUCam below)
 
 struct ObjUse { int t, row0, rows, ncol; size_t off_d, off_i; };   // a usable object track of the current object update
 
@@ -1756,6 +1757,7 @@ struct ObjPlan {
     int2* d_kp_range = nullptr;
     int* d_kp_rows = nullptr;
     double* d_Rarrow = nullptr;
+    double *d_Hr = nullptr, *d_Hfr = nullptr;   // [nobj][N][NOP] per-clone parts of Hf^T r; [nobj][NOP + 1] their sums and |r|^2
     double* d_Bred = nullptr;   // [rows][9] the border of every row after the keypoint blocks have been eliminated
 };
 static int obj_stage_reserve(orcvio_msckf_handle* h, size_t bytes) {
@@ -1779,9 +1781,9 @@ static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
     int rc;
     if ((rc = grow(&h->d_obj_i, &h->cap_obj_i, 2 * rows + 16)) != ORCVIO_OK) return rc;
     if ((rc = grow(&h->d_objH, &h->cap_objH, rows * (6 + pl->ldf + 1) + 16)) != ORCVIO_OK) return rc;
-    const size_t nCd = nobj * pl->NOP * NAP, nSg = nobj * N * 64, nGff = nobj * pl->ldf * pl->ldf;
+    const size_t nCd = nobj * pl->NOP * NAP, nSg = nobj * N * 64, nHr = nobj * N * pl->NOP, nGff = nobj * pl->ldf * pl->ldf;
     const size_t nRa = nobj * (size_t)arrow_stride(pl->Kmax > 0 ? pl->Kmax : 1);
-    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, nCd + nSg + nGff + nRa + rows * 9)) != ORCVIO_OK) return rc;
+    if ((rc = grow(&h->d_Gobj, &h->cap_Gobj, nCd + nSg + nHr + nGff + nRa + rows * 9 + nobj * (pl->NOP + 1))) != ORCVIO_OK) return rc;
     if ((rc = grow(&h->d_RF, &h->cap_RF, nobj * ((size_t)pl->NOP * pl->NOP + 7 * 256))) != ORCVIO_OK) return rc;
     if ((rc = grow(&h->d_Yobj, &h->cap_Yobj, nobj * pl->NOP * NAP)) != ORCVIO_OK) return rc;
     pl->d_clone = h->d_obj_i;
@@ -1791,9 +1793,11 @@ static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
     pl->d_res = pl->d_hf + rows * pl->ldf;
     pl->d_Cd = h->d_Gobj;
     pl->d_Sg = pl->d_Cd + nCd;
-    pl->d_Gff = pl->d_Sg + nSg;
+    pl->d_Hr = pl->d_Sg + nSg;
+    pl->d_Gff = pl->d_Hr + nHr;
     pl->d_Rarrow = pl->d_Gff + nGff;
     pl->d_Bred = pl->d_Rarrow + nRa;
+    pl->d_Hfr = pl->d_Bred + rows * 9;
     return ORCVIO_OK;
 }
 
@@ -1809,25 +1813,29 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
         HIPCHK(hipMemsetAsync(h->d_Yobj, 0, sizeof(double) * (size_t)nobj * NOP * NAP, s));
         HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
     }
-    HIPCHK(hipMemsetAsync(pl.d_Cd, 0, sizeof(double) * ((size_t)nobj * NOP * NAP + (size_t)nobj * N * 64), s));   // Cd and Sg are adjacent
+    HIPCHK(hipMemsetAsync(pl.d_Cd, 0, sizeof(double) * ((size_t)nobj * NOP * NAP + (size_t)nobj * N * 64 + (size_t)nobj * N * NOP), s));   // Cd, Sg, Hr are adjacent
     int rc = launch_prior_fork(h, s);   // Cholesky of P on the side stream
     if (rc != ORCVIO_OK) return rc;
     prof_mark(h, s, "rows+copies");
-    {   // cross products, compact Grams and (arrow route) the keypoint blocks of the structured QR: one launch
-        const int nbf = ldf / 16, ntiles = nbf * (nbf + 1) / 2, kp_blocks = pl.arrow ? (pl.Kmax + 1 + 7) / 8 : 0;
-        const int blocks = (pl.ngroups + 7) / 8 + ntiles * nobj + kp_blocks * nobj;
+    {   // cross products (they also give Hf^T r and |r|^2), the keypoint blocks of the structured QR (arrow route) or the compact Grams
+        // [Hf | r]^T [Hf | r] (Gram route, which needs F = Hf^T Hf): one launch
+        const int nbf = ldf / 16, gram_tiles = pl.arrow ? 0 : nbf * (nbf + 1) / 2, kp_blocks = pl.arrow ? (pl.Kmax + 1 + 7) / 8 : 0;
+        const int blocks = (pl.ngroups + 7) / 8 + gram_tiles * nobj + kp_blocks * nobj;
         hipLaunchKernelGGL(k_obj_front, dim3(blocks), dim3(512), 0, s, pl.d_groups, pl.ngroups, pl.d_ridx, pl.d_hx, pl.d_hf, ldf, no_max,
-                           h->flags.leg_dim - 15, NAP, NOP, N, pl.d_Cd, pl.d_Sg, pl.d_rowptr, pl.d_Gff, nobj, pl.d_arrow, pl.d_kp_range,
-                           pl.d_kp_rows, pl.Kmax, pl.d_Rarrow, pl.d_Bred, kp_blocks);
+                           h->flags.leg_dim - 15, NAP, NOP, N, pl.d_Cd, pl.d_Sg, pl.d_Hr, pl.d_rowptr, pl.d_Gff, nobj, gram_tiles, pl.d_arrow,
+                           pl.d_kp_range, pl.d_kp_rows, pl.Kmax, pl.d_Rarrow, pl.d_Bred, kp_blocks);
     }
     prof_mark(h, s, "k_obj_front");
     const int solve_xblocks = (NAP + 255) / 256, nb_solve = pl.arrow ? solve_xblocks * nobj : 0;
     if (pl.arrow) {
         // R of Hf by structured Householder QR (cond(Hf), not its square: msckf_kernels.hpp); the keypoint blocks are done, the border:
         HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));
-        if (pl.rows_max <= 512) hipLaunchKernelGGL(k_obj_border_qr<2>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, pl.d_Rarrow);
-        else if (pl.rows_max <= 1024) hipLaunchKernelGGL(k_obj_border_qr<4>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, pl.d_Rarrow);
-        else hipLaunchKernelGGL(k_obj_border_qr<8>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, pl.d_Rarrow);
+#define LAUNCH_BORDER(RPT) hipLaunchKernelGGL(k_obj_border_qr<RPT>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, \
+                                              pl.d_Rarrow, (const double*)pl.d_Hr, (const double*)pl.d_Sg, N, NOP, pl.d_Hfr)
+        if (pl.rows_max <= 512) LAUNCH_BORDER(2);
+        else if (pl.rows_max <= 1024) LAUNCH_BORDER(4);
+        else LAUNCH_BORDER(8);
+#undef LAUNCH_BORDER
         prof_mark(h, s, "k_obj_border_qr(Hf)");
     } else {
     // (Hf without the arrow structure of ObjectLM's state: the Gram route.)  F_o = Hf^T Hf (lower tiles of Gff) -> R_F ;
@@ -1851,9 +1859,13 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
     }
     }
     // Y_o = R^-T C_o (arrow route) and sum_o B_o in one launch; then A' = sum_o B_o - Y^T Y (Y = all Y_o stacked; padded rows are zero)
-    hipLaunchKernelGGL(k_obj_solve_assemble, dim3(nb_solve + (NAP * NAP + 255) / 256), dim3(256), sizeof(double) * arrow_stride(pl.Kmax > 0 ? pl.Kmax : 1), s,
-                       nb_solve, solve_xblocks, pl.d_arrow, pl.d_Rarrow, pl.Kmax, pl.d_Cd, NOP, NAP, NA, pl.d_Gff, ldf, no_max, h->d_Yobj, h->d_info + 4,
-                       pl.d_Sg, nobj, N, h->flags.leg_dim - 15, h->d_Ab);
+    {   // |r|^2 per object: arrow route Hfr[o][NOP] (k_obj_border_qr), Gram route the corner of the compact Gram
+        const double* rr = pl.arrow ? pl.d_Hfr + NOP : pl.d_Gff + (size_t)no_max * ldf + no_max;
+        const size_t rr_stride = pl.arrow ? (size_t)NOP + 1 : (size_t)ldf * ldf;
+        hipLaunchKernelGGL(k_obj_solve_assemble, dim3(nb_solve + (NAP * NAP + 255) / 256), dim3(256), sizeof(double) * arrow_stride(pl.Kmax > 0 ? pl.Kmax : 1), s,
+                           nb_solve, solve_xblocks, pl.d_arrow, pl.d_Rarrow, pl.Kmax, pl.d_Cd, NOP, NAP, NA, (const double*)pl.d_Hfr, h->d_Yobj, h->d_info + 4,
+                           pl.d_Sg, nobj, N, h->flags.leg_dim - 15, rr, rr_stride, h->d_Ab);
+    }
     hipLaunchKernelGGL(k_gemm, dim3((NAP / 16) * (NAP / 16)), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
                        NAP, NAP, nobj * NOP, -1.0, 0.0, 0, dst, (long)NAP, 1L, h->d_Ab);
     HIPCHK(hipGetLastError());
@@ -2370,6 +2382,115 @@ int32_t orcvio_msckf_update_object_tracks(orcvio_msckf_handle* h, const orcvio_m
 }
 
 
+// ---- the object update from ObjectLM messages ----------------------------------------------------
+// Sophus v1.0.0 SE3d::exp, tangent (upsilon, omega): R = exp(omega), t = V upsilon
+static void se3_exp_wire(const double xi[6], double T[16]) {
+    const double* u = xi;
+    const double* w = xi + 3;
+    double R[9];
+    so3_exp_decl(w, R);
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double W2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+    double a, b;
+    if (th < 1e-10) { a = 0.5; b = 1.0 / 6.0; }
+    else { a = (1.0 - std::cos(th)) / th2; b = (th - std::sin(th)) / (th2 * th); }
+    double V[9];
+    for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * W[i] + b * W2[i];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * i + j];
+        T[4 * i + 3] = V[3 * i] * u[0] + V[3 * i + 1] * u[1] + V[3 * i + 2] * u[2];
+    }
+    T[12] = T[13] = T[14] = 0.0; T[15] = 1.0;
+}
+
+int32_t orcvio_msckf_update_object_lm_msgs(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
+                                           const double* cur_window_timestamps, const double* R_b2c, const double* t_c_b,
+                                           int32_t fix_D, int32_t wire_row_major, const orcvio_object_lm_msg* msgs, int32_t n_msgs,
+                                           const double* P, orcvio_msckf_result* result) {
+    if (!h || !flags || !cur_window_timestamps || !R_b2c || !t_c_b || n_msgs < 0 || (n_msgs > 0 && !msgs) || !result) {
+        g_last_error = "update_object_lm_msgs: null argument"; return ORCVIO_ERR_INVALID;
+    }
+    // constructObjectResidualJacobians per message (host arithmetic on a few hundred rows), into compact row blocks
+    struct Block { std::vector<int32_t> clone; std::vector<double> hx6, hf, res; int ncol = 0; };
+    std::vector<Block> blocks;
+    std::vector<orcvio_msckf_object_rows> rows;
+    blocks.reserve(n_msgs);
+    for (int q = 0; q < n_msgs; ++q) {
+        const orcvio_object_lm_msg& m = msgs[q];
+        if (m.n_rows < 0 || m.n_obj_cols < 1 || m.n_frames < 0 || (m.n_rows > 0 && (!m.residual || !m.jacobian_wrt_object_state || !m.jacobian_wrt_sensor_state)) ||
+            (m.n_frames > 0 && (!m.valid_camera_pose_mat || !m.timestamps || !m.zs_num_wrt_timestamps))) {
+            g_last_error = "update_object_lm_msgs: malformed message"; return ORCVIO_ERR_INVALID;
+        }
+        int sum_zs = 0;
+        for (int f = 0; f < m.n_frames; ++f) sum_zs += 2 * m.zs_num_wrt_timestamps[f];
+        if (sum_zs + 4 * m.n_frames > m.n_rows) { g_last_error = "update_object_lm_msgs: fewer rows than 2 x keypoints + 4 x frames"; return ORCVIO_ERR_INVALID; }
+        const int nr = m.n_rows, nc = m.n_obj_cols, nf = m.n_frames;
+        // element (i, j) of a rows x cols wire matrix
+        auto at = [&](const double* d, int rws, int cls, int i, int j) { return wire_row_major ? d[(size_t)i * cls + j] : d[(size_t)j * rws + i]; };
+        Block b;
+        b.ncol = nc;
+        int src = 0;
+        for (int f = 0; f < nf; ++f) {
+            const int zf = 2 * m.zs_num_wrt_timestamps[f];
+            int idx = -1;
+            for (int c = 0; c < n_clones; ++c)
+                if (cur_window_timestamps[c] == m.timestamps[f]) { idx = c; break; }   // exact match (std::find on doubles, :2073)
+            if (idx >= 0) {
+                double D[36];
+                std::memset(D, 0, sizeof(D));
+                if (fix_D) { for (int i = 0; i < 6; ++i) D[6 * i + i] = 1.0; }
+                else {   // :2079-2093
+                    double xi[6], wTc[16];
+                    for (int i = 0; i < 6; ++i) xi[i] = at(m.valid_camera_pose_mat, 6, nf, i, f);
+                    se3_exp_wire(xi, wTc);
+                    double v[3], tbw[3];
+                    for (int i = 0; i < 3; ++i) v[i] = -(R_b2c[3 * i] * t_c_b[0] + R_b2c[3 * i + 1] * t_c_b[1] + R_b2c[3 * i + 2] * t_c_b[2]);
+                    for (int i = 0; i < 3; ++i) tbw[i] = wTc[4 * i] * v[0] + wTc[4 * i + 1] * v[1] + wTc[4 * i + 2] * v[2] + wTc[4 * i + 3];
+                    if (flags->use_left_perturbation) {   // se3_ops.hpp:531-552, rows (upsilon, omega), cols (theta, p)
+                        const double S[9] = {0, -tbw[2], tbw[1], tbw[2], 0, -tbw[0], -tbw[1], tbw[0], 0};
+                        for (int i = 0; i < 3; ++i) {
+                            for (int j = 0; j < 3; ++j) D[6 * i + j] = S[3 * i + j];
+                            D[6 * (3 + i) + i] = 1.0;
+                            D[6 * i + 3 + i] = 1.0;
+                        }
+                    } else {
+                        const double S[9] = {0, -t_c_b[2], t_c_b[1], t_c_b[2], 0, -t_c_b[0], -t_c_b[1], t_c_b[0], 0};
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j) {
+                                double sm = 0;
+                                for (int k = 0; k < 3; ++k) sm += R_b2c[3 * i + k] * S[3 * k + j];
+                                D[6 * i + j] = -sm;
+                                D[6 * (3 + i) + j] = R_b2c[3 * i + j];
+                                D[6 * i + 3 + j] = wTc[4 * j + i];   // R_w2c = R_c2w^T
+                            }
+                    }
+                }
+                auto emit = [&](int r) {
+                    for (int c = 0; c < 6; ++c) {
+                        double sm = 0;
+                        for (int k = 0; k < 6; ++k) sm += at(m.jacobian_wrt_sensor_state, nr, 6, r, k) * D[6 * k + c];
+                        b.hx6.push_back(sm);
+                    }
+                    for (int c = 0; c < nc; ++c) b.hf.push_back(at(m.jacobian_wrt_object_state, nr, nc, r, c));
+                    b.res.push_back(m.residual[r]);
+                    b.clone.push_back(idx);
+                };
+                for (int r = src; r < src + zf; ++r) emit(r);
+                for (int r = sum_zs + 4 * f; r < sum_zs + 4 * f + 4; ++r) emit(r);
+            }
+            src += zf;
+        }
+        if (b.clone.empty()) continue;   // no pose of the object in the window (:2149): the message contributes nothing
+        blocks.push_back(std::move(b));
+    }
+    for (const Block& b : blocks)
+        rows.push_back(orcvio_msckf_object_rows{(int32_t)b.clone.size(), b.ncol, b.clone.data(), b.hx6.data(), b.hf.data(), b.res.data()});
+    return orcvio_msckf_update_objects(h, flags, n_clones, rows.data(), (int32_t)rows.size(), P, result);
+}
+
 // ---- object residual rows ------------------------------------------------------
 int32_t orcvio_msckf_object_rows_eval(orcvio_msckf_handle* h, const orcvio_object_eval_flags* fl, const orcvio_object_track* ob,
                                       int32_t cap_rows, int32_t* n_rows, int32_t* row_clone, double* Hx6, double* Hf, double* res) {
@@ -2880,6 +3001,8 @@ int32_t orcvio_msckf_triangulate(orcvio_msckf_handle* h, const orcvio_triangulat
 }
 
 // ---- incrementState_IMUCam (src/orcvio.cpp:4468-4567): host arithmetic -------------------------
+static void so3_exp(const double w[3], double R[9]);
+static void so3_exp_decl(const double w[3], double R[9]) { so3_exp(w, R); }
 static void so3_exp(const double w[3], double R[9]) {
     // Sophus v1.0.0 SO3d::exp: unit quaternion from the rotation vector, then to a matrix
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
@@ -2961,6 +3084,9 @@ int32_t orcvio_msckf_increment_state(const orcvio_msckf_flags* f, const double* 
     return 1;
 }
 
+// ---- diagnostics: test hooks and ablation timers.  NOT part of the product ABI: compiled only into the diagnostics build
+//      (orcvio_amd/lib/liborcvio_msckf_dbg.so, -DORCVIO_DEBUG_HOOKS), which the tests that need them load explicitly ----------
+#ifdef ORCVIO_DEBUG_HOOKS
 // ---- debug access to intermediate device buffers (tests only; not part of the public header) ---
 // which: 0 Hs [m_tot x NAP], 1 Ab, 2 A (summed block), 3 RP, 4 M, 5 RM, 6 Z, 8 U, 7 dims -> int32[8]
 int32_t orcvio_msckf_debug_read(orcvio_msckf_handle* h, int32_t which, void* dst, int64_t max_bytes) {
@@ -3146,5 +3272,7 @@ int32_t orcvio_msckf_debug_feature_ablate(orcvio_msckf_handle* h, int32_t ablate
     (void)hipEventDestroy(e1);
     return ORCVIO_OK;
 }
+
+#endif  // ORCVIO_DEBUG_HOOKS
 
 }  // extern "C"

@@ -2349,7 +2349,9 @@ struct ObjGroup { int r0, r1, clone, obj; };
 __device__ __forceinline__ void obj_cross_body(const ObjGroup* __restrict__ groups, int g, int l, const int* __restrict__ ridx,
                                                const double* __restrict__ Hx6, const double* __restrict__ HfR, int ldf,
                                                int no_max, int cb0, int NAP, int NOP, int N,
-                                               double* __restrict__ Cd, double* __restrict__ Sg) {
+                                               double* __restrict__ Cd, double* __restrict__ Sg, double* __restrict__ Hr) {
+    // A operand = [hx (6) ; r] ^T: seven live rows.  Rows 0..5 give hx^T [Hf | r | hx] as before; row 6 gives r^T Hf (this
+    // group's part of Hf^T r), r^T hx and r^T r -- the compact Gram of [Hf | r] is not needed for them (arrow route)
     const ObjGroup grp = groups[g];
     const int m = l & 15, kq = l >> 4;
     const int nt = ldf >> 4;   // <= 8 (object state <= 112 columns)
@@ -2363,8 +2365,8 @@ __device__ __forceinline__ void obj_cross_body(const ObjGroup* __restrict__ grou
             const int k = k0 + 4 * u + kq;
             const bool in = k < grp.r1;
             const int row = ridx[in ? k : grp.r1 - 1];
-            const double av = Hx6[(size_t)row * 6 + (m < 6 ? m : 0)];
-            a[u] = (in && m < 6) ? av : 0.0;
+            const double av = m < 6 ? Hx6[(size_t)row * 6 + m] : HfR[(size_t)row * ldf + no_max];   // (m == 6: the residual)
+            a[u] = (in && m < 7) ? av : 0.0;
 #pragma unroll
             for (int t = 0; t < 8; ++t)
                 if (t < nt) { const double bv = HfR[(size_t)row * ldf + 16 * t + m]; b[u][t] = in ? bv : 0.0; }
@@ -2377,21 +2379,31 @@ __device__ __forceinline__ void obj_cross_body(const ObjGroup* __restrict__ grou
                 if (t < nt) acc[t] = mfma_f64(a[u], b[u][t], acc[t]);
         }
     }
-    // D[mm][nn], mm = kq + 4 r (the hx component, < 6), nn = m
+    // D[mm][nn], mm = kq + 4 r (the hx component 0..5, 6 = the residual), nn = m
     double* Co = Cd + (size_t)grp.obj * NOP * NAP;
     double* So = Sg + ((size_t)grp.obj * N + grp.clone) * 64;
+    double* Ho = Hr + ((size_t)grp.obj * N + grp.clone) * NOP;
     const int colb = cb0 + 6 * grp.clone;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int mm = kq + 4 * r;
-        if (mm < 6) {
-            if (m < 6) So[mm * 8 + m] = ahh[r];
+        if (mm < 7) {
+            if (m < 7) So[mm * 8 + m] = ahh[r];   // the 7 x 7 tile [hx | r]^T [hx | r] of this (object, clone)
+            if (mm < 6) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t < nt) {
-                    const int i = 16 * t + m;   // column of [Hf | r]
-                    if (i < no_max) Co[(size_t)i * NAP + colb + mm] = acc[t][r];
-                    else if (i == no_max) { So[mm * 8 + 6] = acc[t][r]; So[6 * 8 + mm] = acc[t][r]; }
+                for (int t = 0; t < 8; ++t) {
+                    if (t < nt) {
+                        const int i = 16 * t + m;   // column of [Hf | r]
+                        if (i < no_max) Co[(size_t)i * NAP + colb + mm] = acc[t][r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t < nt) {
+                        const int i = 16 * t + m;
+                        if (i < NOP) Ho[i] = i < no_max ? acc[t][r] : 0.0;   // this group's part of Hf^T r
+                    }
                 }
             }
         }
@@ -2399,8 +2411,10 @@ __device__ __forceinline__ void obj_cross_body(const ObjGroup* __restrict__ grou
 }
 // dst (NAP x NAP, full symmetric) = sum over objects of B_o: clone tiles from Sg, |r|^2 from Gff[no_max][no_max]
 // (objects summed in index order: deterministic)
-__device__ __forceinline__ void obj_assemble_B_body(int idx, const double* __restrict__ Sg, int nobj, int N, const double* __restrict__ Gff,
-                                                    int ldf, int no_max, int cb0, int NA, int NAP, double* __restrict__ dst) {
+__device__ __forceinline__ void obj_assemble_B_body(int idx, const double* __restrict__ Sg, int nobj, int N, const double* __restrict__ rr,
+                                                    size_t rr_stride, int cb0, int NA, int NAP, double* __restrict__ dst) {
+    // rr[o * rr_stride] = |r|^2 of object o (arrow route: summed over the clone tiles by k_obj_border_qr; Gram route: the corner of
+    // the compact Gram)
     if (idx >= NAP * NAP) return;
     const int i = idx / NAP, j = idx - i * NAP;
     const int ci = (i >= cb0 && i < cb0 + 6 * N) ? (i - cb0) / 6 : -1, cj = (j >= cb0 && j < cb0 + 6 * N) ? (j - cb0) / 6 : -1;
@@ -2409,8 +2423,8 @@ __device__ __forceinline__ void obj_assemble_B_body(int idx, const double* __res
     const bool corner = ei == 6 && ej == 6;
     const bool tile = !corner && ei >= 0 && ej >= 0 && (ci == cj || ci < 0 || cj < 0);
     if (corner || tile) {   // (everything else of the block is structurally zero: no loads)
-        const double* base = corner ? Gff + (size_t)no_max * ldf + no_max : Sg + (size_t)(ci >= 0 ? ci : cj) * 64 + ei * 8 + ej;
-        const size_t st = corner ? (size_t)ldf * ldf : (size_t)N * 64;
+        const double* base = corner ? rr : Sg + (size_t)(ci >= 0 ? ci : cj) * 64 + ei * 8 + ej;
+        const size_t st = corner ? rr_stride : (size_t)N * 64;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int o = 0;
         for (; o + 4 <= nobj; o += 4) {   // four loads in flight; objects summed in a fixed order (deterministic)
@@ -2536,7 +2550,20 @@ __device__ __forceinline__ void obj_kp_qr_body(const ObjArrow ob, int obj, int k
 }
 template <int RPT>   // rows per thread: RPT * 256 >= the rows of the largest object (2, 4 or 8)
 __global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restrict__ objs, const double* __restrict__ Bred, int Kmax,
-                                                       double* __restrict__ Rout) {
+                                                       double* __restrict__ Rout, const double* __restrict__ Hr, const double* __restrict__ Sg,
+                                                       int N, int NOP, double* __restrict__ Hfr) {
+    // prologue (independent of the reflectors): Hf^T r and |r|^2 of the object = the sum of its clone groups' parts, clones in
+    // index order (deterministic); Hfr[o] = [Hf^T r (NOP) | r^T r]
+    if ((int)threadIdx.x <= NOP) {
+        const int i = threadIdx.x;
+        const double* src = i < NOP ? Hr + (size_t)blockIdx.x * N * NOP + i : Sg + (size_t)blockIdx.x * N * 64 + 54;
+        const size_t st = i < NOP ? (size_t)NOP : 64;
+        double s0 = 0.0, s1 = 0.0;
+        int c = 0;
+        for (; c + 2 <= N; c += 2) { s0 += src[(size_t)c * st]; s1 += src[(size_t)(c + 1) * st]; }
+        if (c < N) s0 += src[(size_t)c * st];
+        Hfr[(size_t)blockIdx.x * (NOP + 1) + i] = s0 + s1;
+    }
     __shared__ double sPiv[16];
     __shared__ double sPart[4 * 9];
     const ObjArrow ob = objs[blockIdx.x];
@@ -2627,7 +2654,7 @@ __global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restric
 __device__ __forceinline__ void obj_arrow_solve_body(double* __restrict__ sR, int o, int col, const ObjArrow* __restrict__ objs,
                                                      const double* __restrict__ Rin, int Kmax,
                                                      const double* __restrict__ Cd, int NOP, int NAP, int NA,
-                                                     const double* __restrict__ Gff, int ldf, int no_max,
+                                                     const double* __restrict__ Hfr,
                                                      double* __restrict__ Y, int* __restrict__ info) {
     // (the factor goes to LDS once per workgroup; every thread has the C entries of a batch of keypoints in flight before it
     // starts substituting: a handful of memory round trips, not one per keypoint)
@@ -2642,7 +2669,7 @@ __device__ __forceinline__ void obj_arrow_solve_body(double* __restrict__ sR, in
     }
     const double tol = sR[36 * Kmax + 81];
     const double* Co = Cd + (size_t)o * NOP * NAP;
-    const double* hr = Gff + (size_t)o * ldf * ldf + (size_t)no_max * ldf;   // row no_max of the compact Gram: (Hf^T r)^T
+    const double* hr = Hfr + (size_t)o * (NOP + 1);   // Hf^T r of the object (k_obj_border_qr's prologue)
     double* Yo = Y + (size_t)o * NOP * NAP;
     const bool rcol = col == NA;
     const double* src = rcol ? hr : Co + col;
@@ -2712,17 +2739,17 @@ __device__ __forceinline__ void obj_arrow_solve_body(double* __restrict__ sR, in
 __global__ __launch_bounds__(512) void k_obj_front(const ObjGroup* __restrict__ groups, int ngroups, const int* __restrict__ ridx,
                                                    const double* __restrict__ Hx6, const double* __restrict__ HfR, int ldf,
                                                    int no_max, int cb0, int NAP, int NOP, int N, double* __restrict__ Cd, double* __restrict__ Sg,
-                                                   const int* __restrict__ row_ptr, double* __restrict__ Gff, int nobj,
+                                                   double* __restrict__ Hr, const int* __restrict__ row_ptr, double* __restrict__ Gff, int nobj, int gram_tiles,
                                                    const ObjArrow* __restrict__ objs, const int2* __restrict__ kp_range, const int* __restrict__ kp_rows,
                                                    int Kmax, double* __restrict__ Rout, double* __restrict__ Bred, int kp_blocks) {
     __shared__ __attribute__((aligned(16))) double sT[8 * 256];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nb_cross = (ngroups + 7) / 8;
-    const int nbf = ldf >> 4, ntiles = nbf * (nbf + 1) / 2;
+    const int ntiles = gram_tiles;   // tiles of the compact Gram per object: Gram route only (0 in the arrow route)
     int b = blockIdx.x;
     if (b < nb_cross) {
         const int g = b * 8 + wave;
-        if (g < ngroups) obj_cross_body(groups, g, lane, ridx, Hx6, HfR, ldf, no_max, cb0, NAP, NOP, N, Cd, Sg);
+        if (g < ngroups) obj_cross_body(groups, g, lane, ridx, Hx6, HfR, ldf, no_max, cb0, NAP, NOP, N, Cd, Sg, Hr);
         return;
     }
     b -= nb_cross;
@@ -2742,18 +2769,19 @@ __global__ __launch_bounds__(512) void k_obj_front(const ObjGroup* __restrict__ 
 }
 __global__ __launch_bounds__(256) void k_obj_solve_assemble(int nb_solve, int solve_xblocks, const ObjArrow* __restrict__ objs,
                                                             const double* __restrict__ Rin, int Kmax, const double* __restrict__ Cd, int NOP,
-                                                            int NAP, int NA, const double* __restrict__ Gff, int ldf, int no_max,
+                                                            int NAP, int NA, const double* __restrict__ Hfr,
                                                             double* __restrict__ Y, int* __restrict__ info, const double* __restrict__ Sg,
-                                                            int nobj, int N, int cb0, double* __restrict__ Bdst) {
+                                                            int nobj, int N, int cb0, const double* __restrict__ rr, size_t rr_stride,
+                                                            double* __restrict__ Bdst) {
     extern __shared__ double sR[];   // arrow_stride(Kmax) doubles (solve role)
     int b = blockIdx.x;
     if (b < nb_solve) {
         const int o = b / solve_xblocks, xb = b - o * solve_xblocks;
-        obj_arrow_solve_body(sR, o, xb * 256 + (int)threadIdx.x, objs, Rin, Kmax, Cd, NOP, NAP, NA, Gff, ldf, no_max, Y, info);
+        obj_arrow_solve_body(sR, o, xb * 256 + (int)threadIdx.x, objs, Rin, Kmax, Cd, NOP, NAP, NA, Hfr, Y, info);
         return;
     }
     b -= nb_solve;
-    obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, Gff, ldf, no_max, cb0, NA, NAP, Bdst);
+    obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, rr, rr_stride, cb0, NA, NAP, Bdst);
 }
 
 // gamma = (|r'|^2 - |z|^2) / s2 for the joint object block (identity in DESIGN.md), chi-square gate and the

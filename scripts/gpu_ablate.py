@@ -1,7 +1,7 @@
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orcvio_amd import synth, capi
-upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536)
+upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536, debug_hooks=True)   # diagnostics build: orcvio_msckf_debug_* hooks
 upd.upload(synth.config_window(2))
 f = upd.lib.orcvio_msckf_debug_potrf_ablate
 f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from orcvio_amd import synth, capi
 from oracle import oracle
-upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536)
+upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536, debug_hooks=True)   # diagnostics build: orcvio_msckf_debug_* hooks
 order = sys.argv[1:] or ['small', 'config1']
 for nm in order:
     if nm == 'small':

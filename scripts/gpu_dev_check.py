@@ -60,7 +60,7 @@ def check(win, name, upd, detail=False):
 
 
 def main():
-    upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536)
+    upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536, debug_hooks=True)   # diagnostics build: orcvio_msckf_debug_* hooks
     upd.set_materialize_stack(True)
     ok = True
     cases = []

@@ -3,7 +3,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from orcvio_amd import synth, capi
-upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536)
+upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536, debug_hooks=True)   # diagnostics build: orcvio_msckf_debug_* hooks
 upd.upload(synth.config_window(2))
 for _ in range(5):
     upd.run_update(); upd.sync()

@@ -33,6 +33,14 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, name), f'{name} declared in include/ but not exported'
     assert sorted(capi.EXPORTS) == declared
     assert lib.orcvio_msckf_abi_version() == 1
+    # the product library exports the declared C-ABI and NOTHING of the test scaffolding; the diagnostics build does
+    import subprocess
+    def exported(path):
+        out = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True, check=True).stdout
+        return sorted(set(re.findall(r'\b(orcvio_msckf_[a-z0-9_]+)\b', out)))
+    assert exported(capi.LIB_PATH) == declared
+    dbg = exported(capi.LIB_DBG_PATH)
+    assert set(declared) < set(dbg) and all(n.startswith('orcvio_msckf_debug_') for n in set(dbg) - set(declared))
 
 
 def test_chi2_quantile_matches_table(built):

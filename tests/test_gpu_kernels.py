@@ -1,4 +1,5 @@
-"""GPU unit tests of the factorisation kernels against numpy (every template instantiation)."""
+"""GPU unit tests of the factorisation kernels against numpy (every template instantiation), through the test hooks of the
+diagnostics build (liborcvio_msckf_dbg.so: the product library does not export them)."""
 import numpy as np
 import pytest
 
@@ -10,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope='module')
 def upd(built):
-    u = capi.MsckfUpdater(device=0, max_clones=40, max_features=64, max_observations=1024)
+    u = capi.MsckfUpdater(device=0, max_clones=40, max_features=64, max_observations=1024, debug_hooks=True)
     yield u
     u.close()
 

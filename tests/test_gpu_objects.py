@@ -278,3 +278,40 @@ def test_ref_stack_hf_reproduces_the_reference_stacking(upd):
         else:
             assert not g['dx'].any()
     assert abs(default['gamma'] - ref['gamma']) > 1e-3 * abs(ref['gamma'])   # per-object projection: not the same quantity
+
+
+@pytest.mark.parametrize('wire_row_major', [True, False])
+def test_update_from_object_lm_messages(upd, wire_row_major):
+    """orcvio_msckf_update_object_lm_msgs: the fields of orcvio_ros_msgs/ObjectLM.msg as ObjectInitNode fills them (export block of
+    single_levenberg_marquardt: rows [kp rows of all frames ; bbox rows of all frames], se3 logs of the camera poses, timestamps,
+    keypoint counts) -> constructObjectResidualJacobians (exact timestamp match, D from SE3::exp of the pose column) -> the update.
+    Three objects, some frames outside the window; equal to the mirror's construct + per-object update.  wire_row_major = False
+    feeds the same matrices flattened column-major and reads them as System::msgToEigen does (SURVEY note N4): same result, which
+    is the point -- the two sides of the wire only have to agree."""
+    from helpers import objects_update_reference
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=12, F=4, seed=3, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=3, seed=5, sigma_kp=0.004)
+    stamps = 1000.0 + 0.05 * np.arange(win.N)             # cur_window_timestamps
+    msgs = []
+    for oi, ob in enumerate(objs):
+        frames = list(ob.frames)
+        if oi == 1:                                        # this object also has two frames that have left the window
+            for k in (2, 7):
+                frames[k] = dict(frames[k], clone=-1)
+            ob.frames = frames
+        res, Hf, Jc, counts = mo.object_rows(ob.wTo, ob.shape, ob.kps, frames, True, False)
+        ts = [stamps[fr['clone']] if fr['clone'] >= 0 else 5.0 + k for k, fr in enumerate(frames)]
+        poses = np.stack([mo.se3_log(fr['wTc']) for fr in frames], axis=1)   # 6 x frames (valid_camera_pose_mat, ResJacCam.cpp:583-604)
+        msgs.append(dict(object_id=10 + oi, residual=res, jacobian_wrt_object_state=Hf, jacobian_wrt_sensor_state=Jc,
+                         valid_camera_pose_mat=poses, timestamps=ts, zs_num_wrt_timestamps=counts))
+    ref = objects_update_reference(win, objs, win.P, True, False, 0)
+    got = upd.update_object_lm_msgs(flags, win.N, stamps, win.R_b2c[0], win.t_c_b[0], msgs, win.P, wire_row_major=wire_row_major)
+    assert got['accept'] == ref['accept'] == 1
+    assert got['stats'][0] == ref['dof']
+    assert abs(got['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+    assert rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL
+    # an object none of whose frames is in the window contributes nothing (constructObjectResidualJacobians returns false, :2149)
+    gone = dict(msgs[0], timestamps=[3.0 + k for k in range(len(msgs[0]['timestamps']))])
+    alone = upd.update_object_lm_msgs(flags, win.N, stamps, win.R_b2c[0], win.t_c_b[0], [gone], win.P)
+    assert alone['accept'] == 0 and not alone['dx'].any()

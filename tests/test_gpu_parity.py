@@ -19,8 +19,16 @@ TOL = 1e-6
 
 @pytest.fixture(scope='module')
 def upd(built):
-    u = capi.MsckfUpdater(device=0, max_clones=40, max_features=2048, max_observations=65536)
-    u.set_materialize_stack(True)   # the golden test inspects the projected blocks
+    u = capi.MsckfUpdater(device=0, max_clones=40, max_features=2048, max_observations=65536)   # the product library, default options
+    yield u
+    u.close()
+
+
+@pytest.fixture(scope='module')
+def upd_dbg(built):
+    """Diagnostics build with the projected stack materialised: the golden test inspects the blocks [H' | r'] (debug_read)."""
+    u = capi.MsckfUpdater(device=0, max_clones=40, max_features=2048, max_observations=65536, debug_hooks=True)
+    u.set_materialize_stack(True)
     yield u
     u.close()
 
@@ -42,8 +50,12 @@ def _compare(got, ref, win, tol=TOL):
 
 
 @pytest.mark.parametrize('path', golden_files(), ids=lambda p: p.split('feat_')[-1][:-4])
-def test_golden_vectors(upd, path):
+def test_golden_vectors(upd, upd_dbg, path):
     w, g = window_from_golden(path)
+    prod = upd.update_features(w, want_G=True)   # the product library, nothing materialised: the same update
+    assert np.array_equal(prod['accept'], g['exp_accept']) and rel(prod['dx'], g['exp_dx']) < TOL and rel(prod['P_new'], g['exp_P']) < TOL
+    assert rel(prod['G'], g['exp_G']) < TOL
+    upd = upd_dbg
     got = upd.update_features(w, want_G=True, want_K=True, want_thin=True)
     assert np.array_equal(got['accept'], g['exp_accept'])
     assert rel(got['gamma'], g['exp_gamma']) < 1e-9

@@ -23,7 +23,7 @@ def _fallbacks(upd):
 
 
 def test_update_survives_a_kernel_that_holds_half_the_device(built):
-    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536, debug_hooks=True)   # (occupy / counter hooks)
     try:
         win = synth.config_window(2)
         ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
