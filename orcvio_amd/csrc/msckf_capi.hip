@@ -139,6 +139,7 @@ struct orcvio_msckf_handle {
     // object blocks (allocated on first use, grown on demand)
     double *d_Gobj = nullptr, *d_RF = nullptr, *d_DinvF = nullptr, *d_Yobj = nullptr, *d_objH = nullptr;
     double *d_obj_gamma = nullptr;
+    double obj_thr = -1.0;   // chi-square threshold of the object update being finished (host value, passed to k_finish_sqrt)
     int *d_obj_i = nullptr, *d_obj_accept = nullptr;
     size_t cap_Gobj = 0, cap_RF = 0, cap_Yobj = 0, cap_objH = 0, cap_obj_i = 0;
     char *h_obj_stage = nullptr, *d_obj_in = nullptr;   // input arena of an object update: pinned mirror + device copy (grown on demand)
@@ -914,8 +915,12 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
             return launch_trsm(h, s, h->d_RM, h->d_DinvM, kf, pf.base, sLj, sLi, n, h->d_U + (size_t)NA * NP, 1, h->d_Z, ldz);
         case ST_FINISH: {
             const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
-            hipLaunchKernelGGL(k_finish_sqrt, dim3(tiles), dim3(256), 0, s, h->d_Z, ldz, n, kf, sigma2, h->d_Pout, h->d_dx,
-                               h->objects_mode ? h->d_obj_accept : (const int*)nullptr, h->d_P);
+            ObjGate gate;
+            if (h->objects_mode) {
+                gate.rr = h->d_A + (size_t)NA * h->NAP + NA; gate.thr = h->obj_thr;
+                gate.gamma = h->d_obj_gamma; gate.accept = h->d_obj_accept; gate.gamma_out = h->d_gamma; gate.accept_out = h->d_accept;
+            }
+            hipLaunchKernelGGL(k_finish_sqrt, dim3(tiles), dim3(256), 0, s, h->d_Z, ldz, n, kf, sigma2, h->d_Pout, h->d_dx, gate, h->d_P);
             HIPCHK(hipGetLastError());
             return ORCVIO_OK;
         }
@@ -1803,7 +1808,8 @@ static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
 
 // From the compact rows in device memory to this rank's block in dst (P already in d_P).  The prior's Cholesky factor is
 // forked to the side stream (joined by objects_finish).
-static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, const ObjPlan& pl) {
+static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, const ObjPlan& pl, bool zeroed = false) {
+    // zeroed: k_object_rows_batch has cleared Cd / Sg / Hr and the pivot counters
     const int NA = h->NA, NAP = h->NAP, N = h->N, nobj = pl.nobj, NOP = pl.NOP, ldf = pl.ldf, no_max = pl.no_max;
     double* d_RF = h->d_RF;
     double* d_DinvF = h->d_RF + (size_t)nobj * NOP * NOP;
@@ -1813,7 +1819,7 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
         HIPCHK(hipMemsetAsync(h->d_Yobj, 0, sizeof(double) * (size_t)nobj * NOP * NAP, s));
         HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
     }
-    HIPCHK(hipMemsetAsync(pl.d_Cd, 0, sizeof(double) * ((size_t)nobj * NOP * NAP + (size_t)nobj * N * 64 + (size_t)nobj * N * NOP), s));   // Cd, Sg, Hr are adjacent
+    if (!zeroed) HIPCHK(hipMemsetAsync(pl.d_Cd, 0, sizeof(double) * ((size_t)nobj * NOP * NAP + (size_t)nobj * N * 64 + (size_t)nobj * N * NOP), s));   // Cd, Sg, Hr are adjacent
     int rc = launch_prior_fork(h, s);   // Cholesky of P on the side stream
     if (rc != ORCVIO_OK) return rc;
     prof_mark(h, s, "rows+copies");
@@ -1829,7 +1835,7 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
     const int solve_xblocks = (NAP + 255) / 256, nb_solve = pl.arrow ? solve_xblocks * nobj : 0;
     if (pl.arrow) {
         // R of Hf by structured Householder QR (cond(Hf), not its square: msckf_kernels.hpp); the keypoint blocks are done, the border:
-        HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));
+        if (!zeroed) HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));
 #define LAUNCH_BORDER(RPT) hipLaunchKernelGGL(k_obj_border_qr<RPT>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, \
                                               pl.d_Rarrow, (const double*)pl.d_Hr, (const double*)pl.d_Sg, N, NOP, pl.d_Hfr)
         if (pl.rows_max <= 512) LAUNCH_BORDER(2);
@@ -1842,7 +1848,7 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
     // Y_o = L_F^-1 C_o, C_o = [Cd_o | Hf^T r]
     {
         const int nbf = NOP / 16, need = potrf_slots_needed(nbf);
-        HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));   // the batched factorisation ADDS its pivot counters
+        if (!zeroed) HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));   // the batched factorisation ADDS its pivot counters
         const double tolF = (double)no_max * 2.220446049250313e-16;
         if (need <= 4)
             hipLaunchKernelGGL(k_potrf_reg<4>, dim3(nobj), dim3(512), 0, s, pl.d_Gff, ldf, no_max, tolF, d_RF, NOP, d_DinvF, h->d_info + 4,
@@ -2067,6 +2073,8 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     if (h->ref_stack_hf && pl.nobj > 1) {
         merge_objects_ref_stack(N, pl.nobj, pl.rows_tot, ridx, rowptr, groups, &ng);
         pl.nobj = 1; h->obj_count = 1; structured = false;
+        rc = objects_scratch(h, &pl);   // the scratch of ONE block: Cd | Sg | Hr adjacent again (the row arrays depend on the row count only)
+        if (rc != ORCVIO_OK) return rc;
     }
     pl.ngroups = ng;
     pl.arrow = structured && h->arrow_opt &&
@@ -2091,6 +2099,8 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
                                           double* d_dst, int32_t* dof_out, void* stream) {
     if (!h || !flags || !fl || n_tracks < 0 || (n_tracks > 0 && !tracks)) { g_last_error = "objects_local_tracks: null argument"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
+    static const bool timing = getenv("ORCVIO_TIMING") != nullptr;   // diagnostics: host wall time of the parts of this call
+    const auto tt0 = std::chrono::steady_clock::now();
     { const int rp = objects_problem(h, flags, n_clones, P, "objects_local_tracks"); if (rp != ORCVIO_OK) return rp; }
     const int N = n_clones, NAP = h->NAP;
     typedef ObjUse Use;
@@ -2135,7 +2145,9 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     double* dst = d_dst ? d_dst : h->d_Ab;
     if (dof_out) *dof_out = dof;
     prof_begin(h, s);
+    const auto tt1 = std::chrono::steady_clock::now();
     { const int rp = objects_prior(h, s, P, "objects_local_tracks"); if (rp != ORCVIO_OK) return rp; }
+    const auto tt2 = std::chrono::steady_clock::now();
     h->uploaded = true;
     h->objects_mode = true;
     h->obj_dof = dof; h->obj_rows = pl.rows_tot; h->obj_count = pl.nobj;
@@ -2240,6 +2252,8 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     if (h->ref_stack_hf && pl.nobj > 1) {
         merge_objects_ref_stack(N, pl.nobj, pl.rows_tot, ridx, rowptr, groups, &ng);
         pl.nobj = 1; h->obj_count = 1; stacked = true;
+        rc = objects_scratch(h, &pl);   // the scratch of ONE block: Cd | Sg | Hr adjacent again (the row arrays depend on the row count only)
+        if (rc != ORCVIO_OK) return rc;
     }
     pl.ngroups = ng;
     pl.arrow = !stacked && h->arrow_opt && build_arrow(rowkp.data(), rowptr, Ks.data(), pl.nobj, reinterpret_cast<ObjArrow*>(hi + o_arrow),
@@ -2252,12 +2266,25 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     }
     pl.d_ridx = di + o_ridx; pl.d_rowptr = di + o_rowptr; pl.d_groups = reinterpret_cast<ObjGroup*>(di + o_groups);
     pl.d_arrow = reinterpret_cast<ObjArrow*>(di + o_arrow); pl.d_kp_range = reinterpret_cast<int2*>(di + o_range); pl.d_kp_rows = di + o_kprows;
+    const auto tt3 = std::chrono::steady_clock::now();
     HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (o_groups + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
     (void)n_eval;
-    hipLaunchKernelGGL(k_object_rows_batch, dim3(Fmax, (unsigned)use.size()), dim3(64), 0, s,
-                       reinterpret_cast<const ObjEvalArgs*>(dd + args_off));
+    // the rows, and in the same launch the zeroing of what the compression accumulates into (Cd, Sg, Hr: adjacent) and of the
+    // two pivot counters.  After a merge for ORCVIO_OPT_REF_STACK_HF the scratch layout is another one: plain fills there.
+    const bool fold_zero = !stacked;
+    const size_t nzero = (size_t)pl.nobj * pl.NOP * NAP + (size_t)pl.nobj * N * 64 + (size_t)pl.nobj * N * pl.NOP;
+    const unsigned zero_rows = fold_zero ? (unsigned)((nzero / 2 + (size_t)Fmax * 64 * 8 - 1) / ((size_t)Fmax * 64 * 8)) : 0u;   // ~8 double2 per thread
+    hipLaunchKernelGGL(k_object_rows_batch, dim3(Fmax, (unsigned)use.size() + zero_rows), dim3(64), 0, s,
+                       reinterpret_cast<const ObjEvalArgs*>(dd + args_off), (int)use.size(), pl.d_Cd, nzero, h->d_info + 4);
     HIPCHK(hipGetLastError());
-    return objects_pipeline(h, s, dst, pl);   // (no synchronisation: everything staged lives in the handle's pinned arena)
+    rc = objects_pipeline(h, s, dst, pl, fold_zero);   // (no synchronisation: everything staged lives in the handle's pinned arena)
+    if (timing) {
+        const auto tt4 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "objects_local_tracks: sizes %.1f us, prior (sync + P staging + copy) %.1f us, staging %.1f us, enqueue %.1f us\n", us(tt0, tt1),
+                us(tt1, tt2), us(tt2, tt3), us(tt3, tt4));
+    }
+    return rc;
 }
 
 // Second part: rank-ordered sum of the gathered blocks, replicated solve, joint chi-square gate with the TOTAL degrees
@@ -2272,21 +2299,23 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     h->obj_dof = dof_total;
     h->A_deferred = false;
-    int rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);
-    if (rc != ORCVIO_OK) return rc;
-    prof_mark(h, s, "k_gram_reduce");
+    int rc = ORCVIO_OK;
+    if (!(n_blocks == 1 && d_blocks == h->d_A)) {   // (one-shot single-GPU calls compress into d_A: nothing to sum)
+        rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);
+        if (rc != ORCVIO_OK) return rc;
+        prof_mark(h, s, "k_gram_reduce");
+    }
     // Kalman solve in square-root form, gate, gated write-back
     if (h->prior_forked) HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
     prof_mark(h, s, "join chol(P) (side stream)");
     for (int st = ST_FORM_U; st <= ST_TRSM && rc == ORCVIO_OK; ++st) rc = launch_solve_stage(h, s, st);
     if (rc != ORCVIO_OK) return rc;
     prof_mark(h, s, "k_gemm(U)+k_gemm(M)+k_potrf_solve(M)");
-    // table value below 500 dof, on the fly above (:1962-1968); dof 0 (no usable object anywhere) can never pass
-    const double thr = dof_total > 0 ? orcvio_msckf_chi2_quantile(dof_total, h->flags.chi2_prob) : -1.0;
-    hipLaunchKernelGGL(k_obj_gate, dim3(1), dim3(64), 0, s, h->d_A, NAP, NA, h->d_Z, h->ldz, n, h->kf, sigma2, thr, h->d_obj_gamma, h->d_obj_accept);
-    HIPCHK(hipGetLastError());
+    // table value below 500 dof, on the fly above (:1962-1968); dof 0 (no usable object anywhere) can never pass.  The gate is
+    // decided inside k_finish_sqrt (ObjGate).
+    h->obj_thr = dof_total > 0 ? orcvio_msckf_chi2_quantile(dof_total, h->flags.chi2_prob) : -1.0;
     rc = launch_solve_stage(h, s, ST_FINISH);
-    prof_mark(h, s, "k_obj_gate+k_finish_sqrt");
+    prof_mark(h, s, "k_finish_sqrt (gate inside)");
     if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = true; h->last_run_kind = 2; }
     return rc;
 }
@@ -2295,26 +2324,36 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
 int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) {
     if (!h || !res || !h->ran || !h->objects_mode) { g_last_error = "objects_download: no finished object update"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    if (h->last_stream) HIPCHK(hipStreamSynchronize(h->last_stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipStreamSynchronize(h->side));
     const int n = h->n, NA = h->NA, dof = h->obj_dof, nobj = h->obj_count;
     const orcvio_msckf_flags* flags = &h->flags;
     int rc = ORCVIO_OK;
-    // results
-    int acc = 0;
-    double gam = NAN;
-    HIPCHK(hipMemcpy(&acc, h->d_obj_accept, sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&gam, h->d_obj_gamma, sizeof(double), hipMemcpyDeviceToHost));
-    std::vector<double> dx(n);
-    HIPCHK(hipMemcpy(dx.data(), h->d_dx, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (res->dx) std::memcpy(res->dx, dx.data(), sizeof(double) * n);
-    if (res->P_out) HIPCHK(hipMemcpy(res->P_out, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+    // results: ONE copy of the outputs arena [info | dx | gamma | accept | (P+)] into its pinned mirror (enqueued behind the
+    // update by the one-shot entry points; here for staged callers), one synchronisation
+    const bool want_P = res->P_out != nullptr;
+    if (!(h->dl_pending && (h->dl_with_P || !want_P))) {
+        hipStream_t sd = h->last_stream ? h->last_stream : h->stream;
+        if (h->dl_pending) HIPCHK(hipStreamSynchronize(h->dl_stream));
+        const int rq = download_enqueue(h, sd, want_P);
+        if (rq != ORCVIO_OK) return rq;
+    }
+    HIPCHK(hipStreamSynchronize(h->dl_stream));
+    h->dl_pending = false;
+    const char* so = h->h_stage + h->in_cap;
+    const double* dx = reinterpret_cast<const double*>(so + h->oo_dx);
+    const int acc = *reinterpret_cast<const int*>(so + h->oo_accept);
+    double gam = *reinterpret_cast<const double*>(so + h->oo_gamma);
+    int info[9] = {0};
+    std::memcpy(info, so, sizeof(int) * 9);
+    if (info[8] != 0) {   // a solver wavefront of k_potrf_solve gave up waiting for the factorisation workgroup
+        HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
+        g_last_error = "k_potrf_solve: an in-launch hand-off timed out";
+        return ORCVIO_ERR_NOT_SPD;
+    }
+    if (res->dx) std::memcpy(res->dx, dx, sizeof(double) * n);
+    if (res->P_out) std::memcpy(res->P_out, so + h->oo_Pout, sizeof(double) * (size_t)n * n);
     if (dof == 0) gam = NAN;   // no usable object on any rank (the reference returns before the gate, :2157)
     if (res->accept) res->accept[0] = acc;
     if (res->gamma) res->gamma[0] = gam;
-    int info[8] = {0};
-    HIPCHK(hipMemcpy(info, h->d_info, sizeof(int) * 8, hipMemcpyDeviceToHost));
     std::memset(res->stats, 0, sizeof(res->stats));
     res->stats[0] = acc ? dof : 0;
     res->stats[1] = acc ? NA : 0;
@@ -2349,9 +2388,10 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
                                     orcvio_msckf_result* res) {
     if (!res) { g_last_error = "update_objects: null argument"; return ORCVIO_ERR_INVALID; }
     int32_t dof = 0;
-    int rc = orcvio_msckf_objects_local(h, flags, n_clones, objs, n_objects, P, nullptr, &dof, nullptr);
+    int rc = orcvio_msckf_objects_local(h, flags, n_clones, objs, n_objects, P, h->d_A, &dof, nullptr);
     if (rc != ORCVIO_OK) return rc;
-    rc = orcvio_msckf_objects_finish(h, h->d_Ab, 1, dof, nullptr);
+    rc = orcvio_msckf_objects_finish(h, h->d_A, 1, dof, nullptr);
+    if (rc == ORCVIO_OK) rc = download_enqueue(h, h->stream, res->P_out != nullptr);
     if (rc != ORCVIO_OK) return rc;
     rc = orcvio_msckf_objects_download(h, res);
     h->objects_mode = false;
@@ -2365,10 +2405,11 @@ int32_t orcvio_msckf_update_object_tracks(orcvio_msckf_handle* h, const orcvio_m
     int32_t dof = 0;
     static const bool timing = getenv("ORCVIO_TIMING") != nullptr;   // diagnostics: host wall time of the three parts
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = orcvio_msckf_objects_local_tracks(h, flags, fl, n_clones, tracks, n_tracks, P, nullptr, &dof, nullptr);
+    int rc = orcvio_msckf_objects_local_tracks(h, flags, fl, n_clones, tracks, n_tracks, P, h->d_A, &dof, nullptr);
     if (rc != ORCVIO_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    rc = orcvio_msckf_objects_finish(h, h->d_Ab, 1, dof, nullptr);
+    rc = orcvio_msckf_objects_finish(h, h->d_A, 1, dof, nullptr);
+    if (rc == ORCVIO_OK) rc = download_enqueue(h, h->stream, res->P_out != nullptr);
     if (rc != ORCVIO_OK) return rc;
     const auto t2 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_objects_download(h, res);

@@ -2293,13 +2293,30 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
 
 // P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (kdim x (n+1), ldz).  One workgroup per lower
 // tile, split-K over its 4 wavefronts (as k_gemm).
+// Joint chi-square gate of an object update (gatingTest on the stacked, projected rows, src/orcvio.cpp:2172-2182), decided inside
+// k_finish_sqrt by every workgroup for itself (same arithmetic, same order: same decision): gamma = (|r'|^2 - |z|^2) / s2 with
+// |r'|^2 = *rr (corner of the compressed block) and z = Z[:, n].  Workgroup 0 writes gamma / accept for the consumers after this
+// launch (k_fac_commit, the outputs arena).
+struct ObjGate {
+    const double* rr = nullptr;   // nullptr: no gate (feature updates)
+    double thr = 0.0;
+    double *gamma = nullptr, *gamma_out = nullptr;
+    int *accept = nullptr, *accept_out = nullptr;
+};
 __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, int kdim, double s2,
                                                      double* __restrict__ P_out, double* __restrict__ dx,
-                                                     const int* __restrict__ apply = nullptr, const double* __restrict__ P = nullptr) {
+                                                     ObjGate gate = ObjGate(), const double* __restrict__ P = nullptr) {
     __shared__ double sPart[3][4][64];
+    __shared__ double sZZ[4];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     int bi, bj;
     tile_from_linear(blockIdx.x, bi, bj);
+    if (gate.rr) {   // (loads in flight together with the tile's)
+        double zz = 0.0;
+        for (int i = threadIdx.x; i < kdim; i += 256) { const double v = Z[(size_t)i * ldz + n]; zz += v * v; }
+        zz = wave_sum(zz);
+        if (l == 0) sZZ[wave] = zz;
+    }
     const int KS = ((kdim + 15) >> 4) << 2;   // Z is kdim x (n + 1): kdim = dimension of M (= n unless a resident factor is used)
     const int k0 = wave * KS;
     const int Kw = (kdim - k0 < KS) ? (kdim - k0) : KS;
@@ -2311,7 +2328,12 @@ __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ 
     __syncthreads();
     if (wave > 0) return;
     const int kk = l >> 4, cc = l & 15;
-    const bool app = apply ? (*apply != 0) : true;   // gated object update: leave P and x alone if rejected
+    bool app = true;   // gated object update: leave P and x alone if rejected
+    if (gate.rr) {
+        const double g = (*gate.rr - ((sZZ[0] + sZZ[1]) + (sZZ[2] + sZZ[3]))) / s2;
+        app = (g == g && g < gate.thr);   // NaN anywhere in the rows makes g NaN -> rejected
+        if (blockIdx.x == 0 && l == 0) { *gate.gamma = g; *gate.accept = app ? 1 : 0; *gate.gamma_out = g; *gate.accept_out = app ? 1 : 0; }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const double v = ((acc[r] + sPart[0][r][l]) + sPart[1][r][l]) + sPart[2][r][l];
@@ -2782,20 +2804,6 @@ __global__ __launch_bounds__(256) void k_obj_solve_assemble(int nb_solve, int so
     }
     b -= nb_solve;
     obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, rr, rr_stride, cb0, NA, NAP, Bdst);
-}
-
-// gamma = (|r'|^2 - |z|^2) / s2 for the joint object block (identity in DESIGN.md), chi-square gate and the
-// NaN check of src/orcvio.cpp:2172-2182.  A[NA][NA] = |r'|^2, z = Z[:, n].
-__global__ void k_obj_gate(const double* __restrict__ A, int NAP, int NA, const double* __restrict__ Z, int ldz, int n, int kdim, double s2,
-                           double chi2_thr, double* __restrict__ gamma, int* __restrict__ accept) {
-    double zz = 0.0;
-    for (int i = threadIdx.x; i < kdim; i += 64) { const double v = Z[(size_t)i * ldz + n]; zz += v * v; }
-    zz = wave_sum(zz);
-    if (threadIdx.x == 0) {
-        const double g = (A[(size_t)NA * NAP + NA] - zz) / s2;
-        *gamma = g;
-        *accept = (g == g && g < chi2_thr) ? 1 : 0;   // NaN anywhere in the rows makes g NaN -> rejected
-    }
 }
 
 // Test hook (tests/test_gpu_robustness.py): hold `gridDim.x` compute units for `ticks` of the 100 MHz wall clock (every

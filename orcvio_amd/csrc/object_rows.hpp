@@ -233,7 +233,17 @@ __device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int
 __global__ __launch_bounds__(64) void k_object_rows(ObjEvalArgs p) { object_rows_body(p, blockIdx.x, threadIdx.x); }
 // ... or every object of an update in one launch: grid (most frames of any object, objects), the arguments of object
 // blockIdx.y from a device array (wave-uniform: scalar loads)
-__global__ __launch_bounds__(64) void k_object_rows_batch(const ObjEvalArgs* __restrict__ args) {
+// The blocks behind the objects (blockIdx.y >= nobj) zero the scratch the compression accumulates into (`zero`, nzero doubles)
+// and the two pivot counters -- no fill launches in front of k_obj_front.
+__global__ __launch_bounds__(64) void k_object_rows_batch(const ObjEvalArgs* __restrict__ args, int nobj, double* __restrict__ zero,
+                                                          size_t nzero, int* __restrict__ counters) {
+    if ((int)blockIdx.y >= nobj) {
+        const size_t nblk = (size_t)gridDim.x * (gridDim.y - nobj), b = (size_t)(blockIdx.y - nobj) * gridDim.x + blockIdx.x;
+        double2* z2 = reinterpret_cast<double2*>(zero);   // (the scratch is 16-byte aligned and nzero is even)
+        for (size_t i = b * 64 + threadIdx.x; i < nzero / 2; i += nblk * 64) z2[i] = double2{0.0, 0.0};
+        if (b == 0 && threadIdx.x < 2) counters[threadIdx.x] = 0;
+        return;
+    }
     const ObjEvalArgs p = args[blockIdx.y];
     if ((int)blockIdx.x >= p.F) return;
     object_rows_body(p, blockIdx.x, threadIdx.x);
