@@ -274,6 +274,18 @@ def main():
             lat_res = timed_calls(call_res, reps, after=lambda: upd.cov_set(win.P))
             latency['host_visible_resident_cov'] = dict(percentiles(lat_res),
                                                         what='P = NULL (resident prior), P_out = NULL + cov_commit: tracks + poses in, dx out')
+            # ... and with the Cholesky of the prior started when the covariance was last touched (orcvio_msckf_cov_prefactor behind
+            # propagate / augment, i.e. while the front end still tracks the image): the update finds the factor resident
+
+            def restore_and_prefactor():
+                upd.cov_set(win.P)
+                upd.cov_prefactor()
+                upd.sync()
+            restore_and_prefactor()
+            lat_pre = timed_calls(call_res, reps, after=restore_and_prefactor)
+            latency['host_visible_resident_prefactored'] = dict(
+                percentiles(lat_pre), what='as host_visible_resident_cov, the prior factored ahead of the call (orcvio_msckf_cov_prefactor, '
+                                           'outside the timed part: it runs while the front end tracks the image)')
             upd.upload(win)
             # config 3 adds 20 objects x 12 keypoints to the same window: the object update (a second EKF update per
             # frame in the reference, src/orcvio.cpp:2154-2193) from object tracks, host buffers in and out
@@ -325,6 +337,17 @@ def main():
                     objects['frame_config3'] = dict(percentiles(lat_frame), object_update_accepted=int(oo['accept'][0]),
                                                     what='400-feature update + commit + 20-object update + commit, covariance and its '
                                                          'factor resident in HBM: host tracks / poses in, dx out (twice)')
+                    # the same frame with the prior factored ahead (orcvio_msckf_cov_prefactor when the image arrives)
+
+                    def restore_frame_prior():
+                        upd.cov_set(fwin.P)
+                        upd.cov_prefactor()
+                        upd.sync()
+                    restore_frame_prior()
+                    lat_frame_pre = timed_calls(frame, 100, warm=5, after=restore_frame_prior)
+                    objects['frame_config3_prefactored'] = dict(
+                        percentiles(lat_frame_pre), what='as frame_config3, the Cholesky of the frame\'s prior started ahead of the first '
+                                                         'update (outside the timed part: it runs while the front end tracks the image)')
                     # the object update alone in that mode (prior and its factor resident)
                     upd.cov_set(fwin.P)
                     call_f()

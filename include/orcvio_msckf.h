@@ -502,6 +502,11 @@ int32_t orcvio_msckf_triangulate_uploaded(orcvio_msckf_handle* h, const orcvio_t
  *   cov_remove_clones     OrcVIO::pruneImuStateBuffer, :2935-2951 (non-Schmidt branch): rows/cols of the listed window
  *                         indices (ascending rank in the window) are deleted
  *   cov_commit            resident P <- P+ of the update that has just run (features: always defined; objects: P if rejected)
+ *   cov_prefactor         factor the resident P now, asynchronously (ORCVIO_OPT_RESIDENT_FACTOR): after cov_propagate no
+ *                         square-root factor of P is known and the next update would start with the Cholesky of its prior;
+ *                         called when the image arrives (behind propagate + augment), it moves that off the update's critical
+ *                         path -- the update then finds the factor resident, as the later updates of a frame do.  No-op when
+ *                         the factor is known or the window is too large for the register-resident factorisation (n > 224).
  * orcvio_msckf_upload / orcvio_msckf_update_features / orcvio_msckf_objects_local accept P == NULL: the resident P is
  * used (its dimension must match the window). */
 int32_t orcvio_msckf_cov_set(orcvio_msckf_handle* h, int32_t n, const double* P);
@@ -510,6 +515,7 @@ int32_t orcvio_msckf_cov_propagate(orcvio_msckf_handle* h, int32_t leg_dim, cons
 int32_t orcvio_msckf_cov_augment(orcvio_msckf_handle* h);
 int32_t orcvio_msckf_cov_remove_clones(orcvio_msckf_handle* h, int32_t leg_dim, const int32_t* clone_indices, int32_t count);
 int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h);
+int32_t orcvio_msckf_cov_prefactor(orcvio_msckf_handle* h);
 
 #ifdef __cplusplus
 }

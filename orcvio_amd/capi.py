@@ -33,7 +33,7 @@ EXPORTS = [
     'orcvio_msckf_object_rows_eval', 'orcvio_msckf_triangulation_config_default', 'orcvio_msckf_triangulate',
     'orcvio_msckf_triangulate_uploaded', 'orcvio_msckf_objects_local', 'orcvio_msckf_objects_finish',
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
-    'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit',
+    'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit', 'orcvio_msckf_cov_prefactor',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
     'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks', 'orcvio_msckf_new_feature_rows', 'orcvio_msckf_augment_state',
     'orcvio_msckf_profile_stages', 'orcvio_msckf_update_object_lm_msgs',
@@ -172,6 +172,7 @@ def _bind(lib):
     lib.orcvio_msckf_cov_augment.argtypes = [C.c_void_p]
     lib.orcvio_msckf_cov_remove_clones.argtypes = [C.c_void_p, C.c_int32, _ip, C.c_int32]
     lib.orcvio_msckf_cov_commit.argtypes = [C.c_void_p]
+    lib.orcvio_msckf_cov_prefactor.argtypes = [C.c_void_p]
     lib.orcvio_msckf_update_object_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.c_int32,
                                                       C.POINTER(ObjectTrackC), C.c_int32, _dp, C.POINTER(MsckfResult)]
     lib.orcvio_msckf_objects_local_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.c_int32,
@@ -700,6 +701,10 @@ class MsckfUpdater:
 
     def cov_commit(self):
         self._chk(self.lib.orcvio_msckf_cov_commit(self.h), 'orcvio_msckf_cov_commit')
+
+    def cov_prefactor(self):
+        """Factor the resident covariance now (asynchronously): the next update finds its prior's square-root factor resident."""
+        self._chk(self.lib.orcvio_msckf_cov_prefactor(self.h), 'orcvio_msckf_cov_prefactor')
 
     # -- feature triangulation (Feature::checkMotion + ::initializePosition) ---------------------
     def _tri_config(self, cfg=None):

@@ -201,6 +201,8 @@ class MsckfBackend {
         return orcvio_msckf_cov_propagate(h_, flags.leg_dim, Phi.data(), Q.data());
     }
     int augmentCovariance() { return orcvio_msckf_cov_augment(h_); }
+    // behind propagate + augment, when the image arrives: the Cholesky of the prior runs while the front end tracks the image
+    int prefactorCovariance() { return orcvio_msckf_cov_prefactor(h_); }
     int removeClonesFromCovariance(const StateServer& ss, const std::vector<StateIDType>& rm_imu_state_ids) {
         std::vector<int32_t> idx;   // ranks of the removed ids in the ordered window BEFORE they are erased from the map
         int i = 0;

@@ -1808,8 +1808,9 @@ static int objects_scratch(orcvio_msckf_handle* h, ObjPlan* pl) {
 
 // From the compact rows in device memory to this rank's block in dst (P already in d_P).  The prior's Cholesky factor is
 // forked to the side stream (joined by objects_finish).
-static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, const ObjPlan& pl, bool zeroed = false) {
-    // zeroed: k_object_rows_batch has cleared Cd / Sg / Hr and the pivot counters
+static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, const ObjPlan& pl, bool zeroed = false, bool forked = false) {
+    // zeroed: k_object_rows_batch has cleared Cd / Sg / Hr and the pivot counters;  forked: the caller has forked the Cholesky of
+    // the prior already (right behind the copy of P, before it staged the tracks)
     const int NA = h->NA, NAP = h->NAP, N = h->N, nobj = pl.nobj, NOP = pl.NOP, ldf = pl.ldf, no_max = pl.no_max;
     double* d_RF = h->d_RF;
     double* d_DinvF = h->d_RF + (size_t)nobj * NOP * NOP;
@@ -1820,7 +1821,7 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
         HIPCHK(hipMemsetAsync(d_RF, 0, sizeof(double) * (size_t)nobj * NOP * NOP, s));
     }
     if (!zeroed) HIPCHK(hipMemsetAsync(pl.d_Cd, 0, sizeof(double) * ((size_t)nobj * NOP * NAP + (size_t)nobj * N * 64 + (size_t)nobj * N * NOP), s));   // Cd, Sg, Hr are adjacent
-    int rc = launch_prior_fork(h, s);   // Cholesky of P on the side stream
+    int rc = forked ? ORCVIO_OK : launch_prior_fork(h, s);   // Cholesky of P on the side stream
     if (rc != ORCVIO_OK) return rc;
     prof_mark(h, s, "rows+copies");
     {   // cross products (they also give Hf^T r and |r|^2), the keypoint blocks of the structured QR (arrow route) or the compact Grams
@@ -2156,7 +2157,9 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
         HIPCHK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)NAP * NAP, s));
         return launch_prior_fork(h, s);
     }
-    int rc = objects_scratch(h, &pl);
+    int rc = launch_prior_fork(h, s);   // the Cholesky of P runs on the side stream while the tracks are staged and their rows evaluated
+    if (rc != ORCVIO_OK) return rc;
+    rc = objects_scratch(h, &pl);
     if (rc != ORCVIO_OK) return rc;
     // staging arena: [track data (doubles) | kernel arguments (doubles)], then ints [frame_clone, frame_row0 per track | ridx |
     // rowptr | arrows | kp ranges | kp_rows | groups]
@@ -2277,7 +2280,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     hipLaunchKernelGGL(k_object_rows_batch, dim3(Fmax, (unsigned)use.size() + zero_rows), dim3(64), 0, s,
                        reinterpret_cast<const ObjEvalArgs*>(dd + args_off), (int)use.size(), pl.d_Cd, nzero, h->d_info + 4);
     HIPCHK(hipGetLastError());
-    rc = objects_pipeline(h, s, dst, pl, fold_zero);   // (no synchronisation: everything staged lives in the handle's pinned arena)
+    rc = objects_pipeline(h, s, dst, pl, fold_zero, true);   // (no synchronisation: everything staged lives in the handle's pinned arena)
     if (timing) {
         const auto tt4 = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -2938,6 +2941,35 @@ int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h) {
     HIPCHK(hipMemcpyAsync(h->d_Pres, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
     if (s != h->stream) HIPCHK(hipStreamSynchronize(s));   // the other cov_* calls run on the handle's own stream
     h->res_n = n;
+    return ORCVIO_OK;
+}
+
+// Factor the resident covariance NOW (asynchronously, on the handle's stream): P = L L^T, L kept as the resident square-root
+// factor.  processModel adds Q to the IMU block, after which no factor of P is known; a caller that propagates and augments when
+// the image arrives and updates when the front end has finished tracking it (milliseconds later) takes the Cholesky of the
+// prior -- the one part of the first update of a frame that does not depend on the tracks -- off the update's critical path.
+int32_t orcvio_msckf_cov_prefactor(orcvio_msckf_handle* h) {
+    if (!h || h->res_n == 0) { g_last_error = "cov_prefactor: no resident covariance"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->res_n, nb = (n + 15) / 16;
+    if (!h->factor_opt || (h->fac_valid && h->fac_n == n)) return ORCVIO_OK;   // switched off, or the factor is known already
+    if (nb > 14 || nb * 16 > h->NP_max) return ORCVIO_OK;   // no register-resident factorisation of this size: the update factors P itself
+    const int ld = round_up(n + 1, 16);
+    hipStream_t s = h->stream;
+    // L(i, j) = R[j * ld + i] (k_potrf_reg writes the upper factor R, P = R^T R, full 16 x 16 tiles, zeros below the diagonal): the
+    // layout of the resident factor S (S(i, j) = d_Sres[i + j * fac_ld])
+    const double eps = 2.220446049250313e-16;
+    const int need = potrf_slots_needed(nb);
+#define LAUNCH_PF(NS) hipLaunchKernelGGL(k_potrf_reg<NS>, dim3(1), dim3(512), 0, s, (const double*)h->d_Pres, n, n, 8.0 * eps, h->d_Stmp, ld, h->d_DinvP, \
+                                         h->d_info, (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, 0, 1)
+    if (need <= 4) LAUNCH_PF(4);
+    else if (need <= 8) LAUNCH_PF(8);
+    else if (need <= 12) LAUNCH_PF(12);
+    else LAUNCH_PF(16);
+#undef LAUNCH_PF
+    HIPCHK(hipGetLastError());
+    std::swap(h->d_Sres, h->d_Stmp);
+    h->fac_n = n; h->fac_k = n; h->fac_ld = ld; h->fac_valid = true;
     return ORCVIO_OK;
 }
 

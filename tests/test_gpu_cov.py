@@ -99,9 +99,12 @@ def test_limits(upd):
         upd.cov_augment()
 
 
-def test_filter_loop_keeps_the_covariance_on_the_device(upd):
+@pytest.mark.parametrize('prefactor', [False, True], ids=['chol_in_update', 'prefactored'])
+def test_filter_loop_keeps_the_covariance_on_the_device(upd, prefactor):
     """Three frames of propagate -> augment -> update (prior = resident P) -> commit -> marginalise, with P never sent
-    after the first frame; every step equals the same loop run with the oracle on the host."""
+    after the first frame; every step equals the same loop run with the oracle on the host.  prefactored: the Cholesky of the
+    propagated covariance is started behind the augmentation (orcvio_msckf_cov_prefactor) and the update finds the factor
+    resident -- same results."""
     rng = np.random.default_rng(5)
     N0 = 6
     w0 = synth.make_window(N=N0, F=30, seed=40, track_len=(3, 6))
@@ -116,6 +119,8 @@ def test_filter_loop_keeps_the_covariance_on_the_device(upd):
         P = mc.propagate(P, Phi, Q)
         upd.cov_augment()
         P = mc.augment(P)
+        if prefactor:
+            upd.cov_prefactor()
         N = (P.shape[0] - leg) // 6
         w = synth.make_window(N=N, F=30, seed=41 + frame, track_len=(3, N))
         w.P[:] = P
