@@ -250,6 +250,28 @@ int32_t orcvio_msckf_new_feature_rows(const orcvio_msckf_flags* flags, const orc
                                       double* H_1, double* H_2, double* r_1);
 int32_t orcvio_msckf_augment_state(int32_t n, int32_t n_new, int32_t idp_dim, const double* H_1, const double* H_2, const double* r_1,
                                    double sigma2, const double* dx, const double* P_upd, double* dx_new, double* P_aug);
+/* ... or on the device (either parametrisation, FEJ, td): featureJacobian_ekf_new (src/orcvio.cpp:1481-1572) and the W = [V | U]
+ * split (:2416-2436) for the features that enter the state, evaluated from the window poses of the upload they follow.  The V
+ * parts are appended to the dense rows of that upload (behind those of orcvio_msckf_upload_dense_rows, if any) and take part in
+ * the update; the U parts stay on the device until orcvio_msckf_download_new_feature_blocks fetches H_1 [d k][n], H_2 [k][d][d],
+ * r_1 [d k] for orcvio_msckf_augment_state.  param: invParam (d = 3) or obs_anchor (d = 1); CSR of ALL observations of each
+ * feature (the 1-parameter form drops the anchor's own, :1494-1496).  Call order: upload, [upload_slam_features],
+ * [upload_dense_rows], upload_new_features, run_update, download, download_new_feature_blocks, augment_state. */
+typedef struct orcvio_msckf_new_features {
+    int32_t n_features;
+    int32_t idp_dim;          /* feature_idp_dim: 3 or 1                                      */
+    const int32_t* anchor;    /* [k] Feature::id_anchor as a window index                     */
+    const double* param;      /* [k][3] idp 3: invParam; idp 1: obs_anchor                    */
+    const double* inv_depth;  /* [k]    idp 1: invDepth (NULL for idp 3)                      */
+    const double* p_w;        /* [k][3] Feature::position                                     */
+    const double* p_fej;      /* [k][3] Feature::position_FEJ, read under if_fej              */
+    const int32_t* obs_ptr;   /* [k+1] CSR over the features' observations                    */
+    const int32_t* obs_clone; /* [nobs] window index of the observing state                   */
+    const double* obs_z;      /* [nobs][2]                                                    */
+    const double* obs_zvel;   /* [nobs][2], read under estimate_td                            */
+} orcvio_msckf_new_features;
+int32_t orcvio_msckf_upload_new_features(orcvio_msckf_handle* h, const orcvio_msckf_new_features* feats);
+int32_t orcvio_msckf_download_new_feature_blocks(orcvio_msckf_handle* h, double* H_1, double* H_2, double* r_1);
 /* gamma[F], accept[F] of the SLAM features of the last update (either may be NULL) */
 int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept);
 

@@ -33,7 +33,7 @@ EXPORTS = [
     'orcvio_msckf_object_rows_eval', 'orcvio_msckf_triangulation_config_default', 'orcvio_msckf_triangulate',
     'orcvio_msckf_triangulate_uploaded', 'orcvio_msckf_objects_local', 'orcvio_msckf_objects_finish',
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
-    'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit', 'orcvio_msckf_cov_prefactor',
+    'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit', 'orcvio_msckf_cov_prefactor', 'orcvio_msckf_upload_new_features', 'orcvio_msckf_download_new_feature_blocks',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
     'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks', 'orcvio_msckf_new_feature_rows', 'orcvio_msckf_augment_state',
     'orcvio_msckf_profile_stages', 'orcvio_msckf_update_object_lm_msgs',
@@ -230,6 +230,14 @@ class SlamFeatures(C.Structure):
                 ('p_fej', C.POINTER(C.c_double)), ('z', C.POINTER(C.c_double)), ('z_vel', C.POINTER(C.c_double))]
 
 
+class MsckfNewFeatures(C.Structure):
+    """orcvio_msckf_new_features (include/orcvio_msckf.h)."""
+    _fields_ = [('n_features', C.c_int32), ('idp_dim', C.c_int32), ('anchor', C.POINTER(C.c_int32)),
+                ('param', C.POINTER(C.c_double)), ('inv_depth', C.POINTER(C.c_double)), ('p_w', C.POINTER(C.c_double)),
+                ('p_fej', C.POINTER(C.c_double)), ('obs_ptr', C.POINTER(C.c_int32)), ('obs_clone', C.POINTER(C.c_int32)),
+                ('obs_z', C.POINTER(C.c_double)), ('obs_zvel', C.POINTER(C.c_double))]
+
+
 def make_flags(f) -> MsckfFlags:
     return MsckfFlags(int(f.leg_dim), int(f.use_larvio), int(f.use_left_perturbation), int(f.if_fej),
                       int(f.estimate_td), int(f.discard_large_update), float(f.noise_feature), float(f.chi2_prob))
@@ -304,6 +312,35 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_upload_slam_features')
         self._ekf_F = F
+
+    def upload_new_features(self, win, idp_dim, feats):
+        """Features entering the state (objects as for new_feature_rows): featureJacobian_ekf_new and the W split on the
+        device; the V parts join the dense rows of this upload.  Call download_new_feature_blocks() after the update."""
+        k, d = len(feats), int(idp_dim)
+        ptr, cl, zz, zv = [0], [], [], []
+        for ft in feats:
+            for (c, z, v) in ft.obs:
+                cl.append(c); zz.append(z); zv.append(v)
+            ptr.append(len(cl))
+        ia = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        da = lambda a, shape: np.ascontiguousarray(a, dtype=np.float64).reshape(shape)
+        keep = [ia([f.anchor for f in feats]), da([f.inv_param if d == 3 else f.obs_anchor for f in feats], (k, 3)),
+                da([f.inv_depth for f in feats], (k,)), da([f.p_w for f in feats], (k, 3)),
+                da([f.p_fej if f.p_fej is not None else f.p_w for f in feats], (k, 3)), ia(ptr), ia(cl), da(zz, (-1, 2)), da(zv, (-1, 2))]
+        nf = MsckfNewFeatures(k, d, _i(keep[0]), _d(keep[1]), _d(keep[2]), _d(keep[3]), _d(keep[4]), _i(keep[5]), _i(keep[6]),
+                              _d(keep[7]), _d(keep[8]))
+        rc = self.lib.orcvio_msckf_upload_new_features(self.h, C.byref(nf))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_upload_new_features')
+        self._new = (k, d, win.n)
+
+    def download_new_feature_blocks(self):
+        k, d, n = self._new
+        H_1, H_2, r_1 = np.zeros((d * k, n)), np.zeros((k, d, d)), np.zeros(d * k)
+        rc = self.lib.orcvio_msckf_download_new_feature_blocks(self.h, _d(H_1), _d(H_2), _d(r_1))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_download_new_feature_blocks')
+        return H_1, H_2, r_1
 
     def upload_dense_rows(self, H, r):
         """Caller-projected dense rows over the whole state, stacked as they are (no gate)."""

@@ -218,6 +218,101 @@ __global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
     p.r[2 * f] = r[0]; p.r[2 * f + 1] = r[1];
 }
 
+// ---- features ENTERING the state: featureJacobian_ekf_new (src/orcvio.cpp:1481-1572) and the W = [V | U] split (:2416-2436) ----
+// One workgroup per new feature.  Its 2 M rows [H_x | r] are written dense over the active columns (rows of d_dense, the
+// rows the caller-projected path uses); H_f (2M x d) stays in LDS.  H_f of different features share no column, so the split
+// is one Householder QR of H_f per feature applied to its own rows (U = the first d columns of Q, V the rest; only the two
+// subspaces matter): the first d rows are the U part -- H_1, r_1, and H_2 = the R factor -- and leave the stack (zeroed);
+// the other 2M - d rows are the V part, zero in the new columns, and are stacked under everything else as they are.
+struct EkfNewArgs {
+    int n_new, idp_dim, if_fej, estimate_td, leg, NA, NAP, n;
+    const double* poses;
+    const int* anchor;          // [n_new]
+    const double* param;        // [n_new][3]
+    const double* inv_depth;    // [n_new] (idp 1)
+    const double* p_w;          // [n_new][3]
+    const double* p_fej;        // [n_new][3] (if_fej)
+    const int* obs_ptr; const int* obs_clone; const double* obs_z; const double* obs_zvel;
+    const int* row0;            // [n_new + 1] first row of every feature in `dense`
+    double* dense;              // [rows][NAP]: H(:, 15 : 15 + NA) | r | 0
+    double* H1; double* H2; double* r1;   // [d n_new][n], [n_new][d][d], [d n_new]
+};
+#define EKF_NEW_MAXROWS 64   /* 2 x ORCVIO_MAX_TRACK */
+__global__ __launch_bounds__(256) void k_ekf_new(EkfNewArgs p) {
+    __shared__ double sHf[EKF_NEW_MAXROWS][3];
+    __shared__ double sv[EKF_NEW_MAXROWS];
+    __shared__ double sRed[4];
+    __shared__ int sSkip;
+    const int j = blockIdx.x, tid = threadIdx.x, d = p.idp_dim;
+    const int o0 = p.obs_ptr[j], nobs = p.obs_ptr[j + 1] - o0, a = p.anchor[j];
+    const int r0 = p.row0[j], m = p.row0[j + 1] - r0;   // m = 2 x kept observations
+    double* M = p.dense + (size_t)r0 * p.NAP;
+    if (tid == 0) sSkip = -1;
+    for (int i = tid; i < m * p.NAP; i += 256) M[i] = 0.0;
+    __syncthreads();
+    if (d == 1 && tid < nobs && p.obs_clone[o0 + tid] == a) sSkip = tid;   // the anchor's own observation is not used (:1494-1496)
+    __syncthreads();
+    if (tid < nobs && tid != sSkip) {
+        const int c = tid - ((sSkip >= 0 && tid > sSkip) ? 1 : 0), o = o0 + tid, k = p.obs_clone[o];
+        double He[12], Ha[12], Hx[12], Hf[6], rr[2];
+        ekf_row_blocks(p.poses + (size_t)k * POSE_STRIDE, p.poses + (size_t)a * POSE_STRIDE, k == a, d, p.if_fej, p.param + (size_t)3 * j,
+                       d == 1 ? p.inv_depth[j] : 0.0, p.p_w + (size_t)3 * j, p.p_fej ? p.p_fej + (size_t)3 * j : nullptr, p.obs_z + (size_t)2 * o,
+                       He, Ha, Hx, Hf, rr);
+        for (int b = 0; b < 2; ++b) {
+            double* row = M + (size_t)(2 * c + b) * p.NAP;
+            for (int e = 0; e < 6; ++e) row[p.leg - 15 + 6 * a + e] = Ha[6 * b + e];   // :1561
+            for (int e = 0; e < 6; ++e) row[p.leg - 15 + 6 * k + e] = Hx[6 * b + e];   // :1562 (overwrites if k == a)
+            for (int e = 0; e < 6; ++e) row[e] = He[6 * b + e];                       // :1563 (columns 15..20)
+            if (p.estimate_td) row[6] = p.obs_zvel[(size_t)2 * o + b];                // :1564-1565 (column 21)
+            row[p.NA] = rr[b];
+            for (int e = 0; e < 3; ++e) sHf[2 * c + b][e] = e < d ? Hf[b * d + e] : 0.0;
+        }
+    }
+    __syncthreads();
+    // Householder QR of H_f (m x d, dgeqr2 convention), applied to [H_x | r]: one thread per column
+    for (int q = 0; q < d; ++q) {
+        if (tid < 64) {
+            double part = (tid > q && tid < m) ? sHf[tid][q] * sHf[tid][q] : 0.0;
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (tid == 0) sRed[0] = part;
+        }
+        __syncthreads();
+        const double nrm2 = sRed[0], alpha = sHf[q][q];
+        if (nrm2 != 0.0) {   // (block-uniform)
+            const double nu = sqrt(alpha * alpha + nrm2), bk = alpha >= 0.0 ? -nu : nu;
+            const double beta = (bk - alpha) / bk, sc = 1.0 / (alpha - bk);
+            if (tid < m) sv[tid] = tid < q ? 0.0 : (tid == q ? 1.0 : sHf[tid][q] * sc);
+            __syncthreads();
+            for (int c = tid; c < p.NAP + 3; c += 256) {
+                if (c < p.NAP) {
+                    if (c > p.NA) continue;   // (padding columns stay zero)
+                    double w = 0.0;
+                    for (int i = q; i < m; ++i) w += sv[i] * M[(size_t)i * p.NAP + c];
+                    w *= beta;
+                    for (int i = q; i < m; ++i) M[(size_t)i * p.NAP + c] -= w * sv[i];
+                } else {
+                    const int e = c - p.NAP;   // columns of H_f
+                    if (e < q || e >= d) continue;
+                    double w = 0.0;
+                    for (int i = q; i < m; ++i) w += sv[i] * sHf[i][e];
+                    w *= beta;
+                    for (int i = q; i < m; ++i) sHf[i][e] -= w * sv[i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the U part leaves the stack
+    for (int i = 0; i < d; ++i) {
+        double* h1 = p.H1 + (size_t)(d * j + i) * p.n;
+        for (int c = tid; c < p.n; c += 256) h1[c] = (c >= 15 && c < 15 + p.NA) ? M[(size_t)i * p.NAP + c - 15] : 0.0;
+        if (tid == 0) p.r1[d * j + i] = M[(size_t)i * p.NAP + p.NA];
+        if (tid < d) p.H2[(size_t)j * d * d + i * d + tid] = tid >= i ? sHf[i][tid] : 0.0;
+    }
+    __syncthreads();
+    for (int i = tid; i < d * p.NAP; i += 256) M[i] = 0.0;
+}
+
 __global__ __launch_bounds__(256) void k_add_inplace(double* __restrict__ dst, const double* __restrict__ src, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] += src[i];

@@ -332,8 +332,10 @@ class MsckfBackend {
         // general path: the entering features are gated as tracks on the device first (:2361-2367), the rows of those
         // that pass are rotated on the host (featureJacobian_ekf_new + W split) and their V part rides as dense rows
         std::vector<FeatureIDType> entering1;
-        std::vector<double> H_top, r_top, H1_1, H2_1, r1_1;
+        std::vector<double> H1_1, H2_1, r1_1;
         int rows_top = 0;
+        std::vector<int32_t> e_anc, e_optr(1, 0), e_ocl;          // the entering features, flat (general path)
+        std::vector<double> e_prm, e_rho, e_pw, e_pfj, e_oz, e_ozv;
         if (new_accepted) new_accepted->assign(new_ids.size(), 0);
         if (!shortcut && !new_ids.empty()) {
             const int Nw = (int)index_of.size(), ncols = flags.leg_dim + 6 * Nw + d * (int)ss.feature_states.size();
@@ -351,32 +353,23 @@ class MsckfBackend {
                 if (out.status == ORCVIO_OK) out.status = orcvio_msckf_gate_tracks(h_, &flags, &gw, &gt, ss.state_cov.data(), gg.data(), ga.data());
             }
             if (out.status != ORCVIO_OK) return out;
-            std::vector<int32_t> anc, optr(1, 0), ocl;
-            std::vector<double> prm, rho, pw, pfj, oz, ozv;
             for (size_t k = 0; k < new_ids.size(); ++k) {
                 if (!ga[k]) continue;
                 const Feature& f = map_server.at(new_ids[k]);
                 if (!index_of.count(f.id_anchor)) { out.status = ORCVIO_ERR_INVALID; return out; }
                 entering1.push_back(new_ids[k]);
                 if (new_accepted) (*new_accepted)[k] = 1;
-                anc.push_back(index_of.at(f.id_anchor));
+                e_anc.push_back(index_of.at(f.id_anchor));
                 const double* pp = d == 3 ? f.invParam : f.obs_anchor;
-                prm.insert(prm.end(), pp, pp + 3); rho.push_back(f.invDepth);
-                pw.insert(pw.end(), f.position, f.position + 3); pfj.insert(pfj.end(), f.position_FEJ, f.position_FEJ + 3);
+                e_prm.insert(e_prm.end(), pp, pp + 3); e_rho.push_back(f.invDepth);
+                e_pw.insert(e_pw.end(), f.position, f.position + 3); e_pfj.insert(e_pfj.end(), f.position_FEJ, f.position_FEJ + 3);
                 for (int o = gptr[k]; o < gptr[k + 1]; ++o) {
-                    ocl.push_back(gcl[o]); oz.push_back(gz[2 * o]); oz.push_back(gz[2 * o + 1]); ozv.push_back(gzv[2 * o]); ozv.push_back(gzv[2 * o + 1]);
+                    e_ocl.push_back(gcl[o]); e_oz.push_back(gz[2 * o]); e_oz.push_back(gz[2 * o + 1]); e_ozv.push_back(gzv[2 * o]); e_ozv.push_back(gzv[2 * o + 1]);
                 }
-                optr.push_back((int32_t)ocl.size());
+                e_optr.push_back((int32_t)e_ocl.size());
             }
-            if (!entering1.empty()) {
-                const int k1 = (int)entering1.size();
-                H_top.assign((size_t)2 * ocl.size() * ncols, 0.0); r_top.assign(2 * ocl.size(), 0.0);
-                H1_1.assign((size_t)d * k1 * ncols, 0.0); H2_1.assign((size_t)k1 * d * d, 0.0); r1_1.assign((size_t)d * k1, 0.0);
-                out.status = orcvio_msckf_new_feature_rows(&flags, &gw, d, ncols, k1, anc.data(), prm.data(), rho.data(), pw.data(), pfj.data(),
-                                                           optr.data(), ocl.data(), oz.data(), ozv.data(), &rows_top, H_top.data(), r_top.data(),
-                                                           H1_1.data(), H2_1.data(), r1_1.data());
-                if (out.status != ORCVIO_OK) return out;
-            }
+            // (their rows -- featureJacobian_ekf_new, the W = [V | U] split -- are evaluated on the device behind the upload below:
+            // orcvio_msckf_upload_new_features)
         }
         flattenTracks(map_server, msckf_ids, index_of, {}, p_w, obs_ptr, obs_clone, obs_z, obs_zvel);
         const int N = (int)index_of.size(), nf = (int)ss.feature_states.size();
@@ -424,7 +417,14 @@ class MsckfBackend {
             step(ekf_rows.status);
             if (out.status == ORCVIO_OK) step(orcvio_msckf_upload(h_, &flags, &w, &t, ss.state_cov.data()));
             if (out.status == ORCVIO_OK) step(orcvio_msckf_upload_slam_features(h_, &sf));
-            if (out.status == ORCVIO_OK && rows_top > 0) step(orcvio_msckf_upload_dense_rows(h_, rows_top, H_top.data(), r_top.data()));
+            if (out.status == ORCVIO_OK && !entering1.empty()) {   // the V parts join the stack on the device, the U parts stay there
+                orcvio_msckf_new_features nfs{};
+                nfs.n_features = (int32_t)entering1.size(); nfs.idp_dim = d;
+                nfs.anchor = e_anc.data(); nfs.param = e_prm.data(); nfs.inv_depth = e_rho.data(); nfs.p_w = e_pw.data(); nfs.p_fej = e_pfj.data();
+                nfs.obs_ptr = e_optr.data(); nfs.obs_clone = e_ocl.data(); nfs.obs_z = e_oz.data(); nfs.obs_zvel = e_ozv.data();
+                step(orcvio_msckf_upload_new_features(h_, &nfs));
+                rows_top = 2 * (int)e_ocl.size();   // (an upper bound: only "some rows joined" matters below)
+            }
             if (out.status == ORCVIO_OK) step(orcvio_msckf_run_update(h_, nullptr));
             if (out.status == ORCVIO_OK) step(orcvio_msckf_download(h_, &r));
             if (out.status == ORCVIO_OK) step(orcvio_msckf_download_ekf(h_, out.ekf_gamma.data(), out.ekf_accepted.data()));
@@ -461,6 +461,9 @@ class MsckfBackend {
         if (!entering1.empty()) {   // general path: the tail of measurementUpdate_hybrid from the rotated rows
             const int k1 = (int)entering1.size(), sz1 = d * k1;
             std::vector<double> dx_new(sz1), P_aug((size_t)(n + sz1) * (n + sz1));
+            H1_1.assign((size_t)sz1 * n, 0.0); H2_1.assign((size_t)k1 * d * d, 0.0); r1_1.assign((size_t)sz1, 0.0);
+            out.status = orcvio_msckf_download_new_feature_blocks(h_, H1_1.data(), H2_1.data(), r1_1.data());
+            if (out.status != ORCVIO_OK) return out;
             out.status = orcvio_msckf_augment_state(n, k1, d, H1_1.data(), H2_1.data(), r1_1.data(), flags.noise_feature * flags.noise_feature,
                                                     out.delta_x.data(), P_new.data(), dx_new.data(), P_aug.data());
             if (out.status != ORCVIO_OK) return out;

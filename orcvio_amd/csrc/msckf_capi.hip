@@ -121,6 +121,8 @@ struct orcvio_msckf_handle {
     double* d_dense = nullptr;          // [dense_cap][NAP_max]
     bool ekf_eval = false;              // the four blocks are evaluated on the device from the SLAM features (k_ekf_eval)
     double* d_slam = nullptr;           // [12 cap] param 3 | inv_depth 1 | p_w 3 | p_fej 3 | z 2
+    char* d_new = nullptr; size_t new_cap = 0, new_out_off = 0;   // entering features (orcvio_msckf_upload_new_features): inputs, then H_1 | H_2 | r_1
+    int new_F = 0, new_idp = 3;
     double* d_Rf = nullptr;             // [maxF][6] R factor of every track's H_f (k_feature), for orcvio_msckf_augment_new_features
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     // multi-GPU: RCCL communicator of this handle (orcvio_msckf_comm_init), the all-gather buffer [world][NAP_max^2] and
@@ -314,7 +316,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_W, h->d_Y, h->d_KG, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S,
                     h->d_Pres, h->d_Ptmp, h->d_Sres, h->d_Stmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
-                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense, h->d_Rf};
+                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense, h->d_Rf, h->d_new};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -564,7 +566,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->N = N; h->F = F; h->nobs = nobs;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
     h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
-    h->ekf_F = 0; h->dense_rows = 0;
+    h->ekf_F = 0; h->dense_rows = 0; h->new_F = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     select_prior_factor(h, P);
@@ -1204,17 +1206,13 @@ int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_
     return ORCVIO_OK;
 }
 
+static int dense_reserve(orcvio_msckf_handle* h, int rows);
 int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, const double* H, const double* r) {
     if (!h || !h->uploaded || n_rows < 0 || (n_rows > 0 && (!H || !r))) { g_last_error = "upload_dense_rows: upload the window first"; return ORCVIO_ERR_INVALID; }
     if (h->n_extra > 0 && !h->ekf_mode) { g_last_error = "upload_dense_rows: with extra states set ORCVIO_OPT_EKF_ROWS before the upload"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    if (n_rows > h->dense_cap) {
-        HIPCHK(hipDeviceSynchronize());
-        if (h->d_dense) (void)hipFree(h->d_dense);
-        h->dense_cap = round_up(n_rows, 64);
-        HIPCHK(hipMalloc(&h->d_dense, sizeof(double) * (size_t)h->dense_cap * h->NAP_max));
-        h->graph_epoch++;   // captured graphs hold the freed pointer
-    }
+    h->dense_rows = 0;   // (these rows come first; orcvio_msckf_upload_new_features appends)
+    { const int rc = dense_reserve(h, n_rows); if (rc != ORCVIO_OK) return rc; }
     if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)2 * h->NAP_max * h->NAP_max));
     h->dense_rows = n_rows;
     if (n_rows == 0) return ORCVIO_OK;
@@ -1229,6 +1227,113 @@ int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, c
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->d_dense, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
+    return ORCVIO_OK;
+}
+
+// Dense-row scratch [cap][NAP_max] (caller-projected rows, V parts of entering features); the contents are kept.
+static int dense_reserve(orcvio_msckf_handle* h, int rows) {
+    if (rows <= h->dense_cap) return ORCVIO_OK;
+    HIPCHK(hipDeviceSynchronize());
+    const int cap = round_up(rows, 64);
+    double* nb = nullptr;
+    HIPCHK(hipMalloc(&nb, sizeof(double) * (size_t)cap * h->NAP_max));
+    if (h->d_dense) {
+        if (h->dense_rows > 0) HIPCHK(hipMemcpy(nb, h->d_dense, sizeof(double) * (size_t)h->dense_rows * h->NAP, hipMemcpyDeviceToDevice));
+        (void)hipFree(h->d_dense);
+    }
+    h->d_dense = nb; h->dense_cap = cap;
+    h->graph_epoch++;   // captured graphs hold the freed pointer
+    return ORCVIO_OK;
+}
+
+// Features ENTERING the state, on the device: featureJacobian_ekf_new (src/orcvio.cpp:1481-1572) for every listed feature and
+// the rotation of its rows by W = [V | U] (:2416-2436), k_ekf_new.  The V parts (zero in the new columns) are appended to the
+// dense rows of this upload and take part in the update; the U parts H_1, H_2, r_1 stay on the device for
+// orcvio_msckf_download_new_feature_blocks (-> orcvio_msckf_augment_state after the update).
+int32_t orcvio_msckf_upload_new_features(orcvio_msckf_handle* h, const orcvio_msckf_new_features* nf) {
+    if (!h || !nf || !h->uploaded) { g_last_error = "upload_new_features: upload the window first"; return ORCVIO_ERR_INVALID; }
+    if (h->n_extra > 0 && !h->ekf_mode) { g_last_error = "upload_new_features: with extra states set ORCVIO_OPT_EKF_ROWS before the upload"; return ORCVIO_ERR_INVALID; }
+    const int k = nf->n_features, d = nf->idp_dim, N = h->N;
+    if (k < 0 || (d != 1 && d != 3)) { g_last_error = "upload_new_features: idp_dim must be 1 or 3"; return ORCVIO_ERR_INVALID; }
+    h->new_F = 0;
+    if (k == 0) return ORCVIO_OK;
+    if (!nf->anchor || !nf->param || !nf->p_w || !nf->obs_ptr || !nf->obs_clone || !nf->obs_z || (d == 1 && !nf->inv_depth) ||
+        (h->flags.if_fej && !nf->p_fej) || (h->flags.estimate_td && !nf->obs_zvel)) { g_last_error = "upload_new_features: null array"; return ORCVIO_ERR_INVALID; }
+    const int nobs = nf->obs_ptr[k];
+    std::vector<int> row0(k + 1, 0);
+    for (int j = 0; j < k; ++j) {
+        const int a = nf->anchor[j];
+        if (a < 0 || a >= N) { g_last_error = "upload_new_features: anchor outside the window"; return ORCVIO_ERR_INVALID; }
+        const int M = nf->obs_ptr[j + 1] - nf->obs_ptr[j];
+        if (M < 0 || M > ORCVIO_MAX_TRACK) { g_last_error = "upload_new_features: track longer than ORCVIO_MAX_TRACK"; return ORCVIO_ERR_TRACK_TOO_LONG; }
+        int kept = 0;
+        for (int o = nf->obs_ptr[j]; o < nf->obs_ptr[j + 1]; ++o) {
+            if (nf->obs_clone[o] < 0 || nf->obs_clone[o] >= N) { g_last_error = "upload_new_features: obs_clone outside the window"; return ORCVIO_ERR_INVALID; }
+            if (!(d == 1 && nf->obs_clone[o] == a)) ++kept;   // :1494-1496
+        }
+        if (2 * kept <= d) { g_last_error = "upload_new_features: a feature with too few observations"; return ORCVIO_ERR_INVALID; }
+        row0[j + 1] = row0[j] + 2 * kept;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    const int base = h->dense_rows, rows = row0[k];
+    { const int rc = dense_reserve(h, base + rows); if (rc != ORCVIO_OK) return rc; }
+    if (!h->d_Gekf) HIPCHK(hipMalloc(&h->d_Gekf, sizeof(double) * (size_t)2 * h->NAP_max * h->NAP_max));
+    for (int j = 0; j <= k; ++j) row0[j] += base;
+    // one staging block: doubles [param 3k | inv_depth k | p_w 3k | p_fej 3k | obs_z 2 nobs | obs_zvel 2 nobs], ints [anchor k |
+    // obs_ptr k+1 | obs_clone nobs | row0 k+1]; outputs behind it on the device [H_1 d k n | H_2 k d d | r_1 d k]
+    const size_t nd_in = (size_t)10 * k + (size_t)4 * nobs, ni = (size_t)3 * k + 2 + nobs, n_out = (size_t)d * k * h->n + (size_t)k * d * d + (size_t)d * k;
+    const size_t bytes_in = nd_in * 8 + ((ni * 4 + 7) & ~(size_t)7);
+    if (bytes_in + n_out * 8 > h->new_cap) {
+        HIPCHK(hipDeviceSynchronize());
+        if (h->d_new) (void)hipFree(h->d_new);
+        h->new_cap = (bytes_in + n_out * 8) * 2;
+        HIPCHK(hipMalloc(&h->d_new, h->new_cap));
+    }
+    std::vector<char> st(bytes_in, 0);
+    double* sd = reinterpret_cast<double*>(st.data());
+    int* si = reinterpret_cast<int*>(st.data() + nd_in * 8);
+    std::memcpy(sd, nf->param, sizeof(double) * 3 * k);
+    if (nf->inv_depth) std::memcpy(sd + 3 * k, nf->inv_depth, sizeof(double) * k);
+    std::memcpy(sd + 4 * k, nf->p_w, sizeof(double) * 3 * k);
+    if (nf->p_fej) std::memcpy(sd + 7 * k, nf->p_fej, sizeof(double) * 3 * k);
+    std::memcpy(sd + 10 * k, nf->obs_z, sizeof(double) * 2 * nobs);
+    if (nf->obs_zvel) std::memcpy(sd + 10 * k + 2 * nobs, nf->obs_zvel, sizeof(double) * 2 * nobs);
+    std::memcpy(si, nf->anchor, sizeof(int) * k);
+    std::memcpy(si + k, nf->obs_ptr, sizeof(int) * (k + 1));
+    std::memcpy(si + 2 * k + 1, nf->obs_clone, sizeof(int) * nobs);
+    std::memcpy(si + 2 * k + 1 + nobs, row0.data(), sizeof(int) * (k + 1));
+    hipStream_t s = h->stream;
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(h->d_new, st.data(), bytes_in, hipMemcpyHostToDevice));
+    const double* dd = reinterpret_cast<const double*>(h->d_new);
+    const int* di = reinterpret_cast<const int*>(h->d_new + nd_in * 8);
+    double* dout = reinterpret_cast<double*>(h->d_new + bytes_in);
+    EkfNewArgs a;
+    a.n_new = k; a.idp_dim = d; a.if_fej = h->flags.if_fej; a.estimate_td = h->flags.estimate_td; a.leg = h->flags.leg_dim;
+    a.NA = h->NA; a.NAP = h->NAP; a.n = h->n;
+    a.poses = h->d_poses;
+    a.param = dd; a.inv_depth = dd + 3 * k; a.p_w = dd + 4 * k; a.p_fej = nf->p_fej ? dd + 7 * k : nullptr;
+    a.obs_z = dd + 10 * k; a.obs_zvel = dd + 10 * k + 2 * nobs;
+    a.anchor = di; a.obs_ptr = di + k; a.obs_clone = di + 2 * k + 1; a.row0 = di + 2 * k + 1 + nobs;
+    a.dense = h->d_dense;
+    a.H1 = dout; a.H2 = dout + (size_t)d * k * h->n; a.r1 = a.H2 + (size_t)k * d * d;
+    hipLaunchKernelGGL(k_ekf_new, dim3(k), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    h->dense_rows = base + rows;
+    h->new_F = k; h->new_idp = d; h->new_out_off = bytes_in;
+    return ORCVIO_OK;
+}
+
+// H_1 [d k][n], H_2 [k][d][d] (upper triangular blocks), r_1 [d k] of the features of the last orcvio_msckf_upload_new_features
+int32_t orcvio_msckf_download_new_feature_blocks(orcvio_msckf_handle* h, double* H_1, double* H_2, double* r_1) {
+    if (!h || h->new_F <= 0 || !H_1 || !H_2 || !r_1) { g_last_error = "download_new_feature_blocks: no entering features uploaded"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int k = h->new_F, d = h->new_idp, n = h->n;
+    const double* dout = reinterpret_cast<const double*>(h->d_new + h->new_out_off);
+    HIPCHK(hipMemcpy(H_1, dout, sizeof(double) * (size_t)d * k * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(H_2, dout + (size_t)d * k * n, sizeof(double) * (size_t)k * d * d, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r_1, dout + (size_t)d * k * n + (size_t)k * d * d, sizeof(double) * (size_t)d * k, hipMemcpyDeviceToHost));
     return ORCVIO_OK;
 }
 
@@ -1954,7 +2059,7 @@ static int objects_problem(orcvio_msckf_handle* h, const orcvio_msckf_flags* fla
     h->N = N; h->F = 0; h->nobs = 0;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
     h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
-    h->ekf_F = 0; h->dense_rows = 0;
+    h->ekf_F = 0; h->dense_rows = 0; h->new_F = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     select_prior_factor(h, P);

@@ -152,6 +152,52 @@ def test_frame_with_new_slam_features(upd, idp):
     assert rel(P, ref['P_new']) < TOL
 
 
+@pytest.mark.parametrize('fej', [0, 1], ids=['nofej', 'fej'])
+@pytest.mark.parametrize('idp', [3, 1])
+def test_entering_features_rows_on_the_device(upd, idp, fej):
+    """orcvio_msckf_upload_new_features: featureJacobian_ekf_new and the W = [V | U] split of the entering features evaluated by
+    k_ekf_new from the window poses already in HBM (either parametrisation, FEJ, td) -- the U parts H_1, H_2, r_1 equal the
+    library's host arithmetic, and the joint update with the V parts stacked on the device equals the one with the host's
+    V-part rows handed over as dense rows; the tail (orcvio_msckf_augment_state) then gives the reference's full hybrid update."""
+    w0 = synth.make_window(N=10, F=60, seed=17, track_len=(3, 10), flags=synth.Flags(use_larvio=1, estimate_td=1, if_fej=fej))
+    slam = synth.make_slam_features(w0, 7, seed=5, outlier_frac=0.25)
+    w = synth.with_extra_states(w0, idp * len(slam), seed=4)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 5, seed=9, outlier_frac=0.0)]
+    if fej:   # first-estimate positions that differ from the current ones
+        for i, ft in enumerate(new):
+            ft.p_fej = ft.p_w + 0.01 * np.array([1.0, -0.5, 0.3]) * (i + 1)
+    H_top, r_top, H_1, H_2, r_1 = capi.new_feature_rows(w, idp, new)
+    upd.set_extra_states(w.n_extra)
+    upd.set_ekf_rows_mode(True)
+    try:
+        upd.upload(w)
+        upd.upload_slam_features(idp, slam)
+        upd.upload_dense_rows(H_top, r_top)
+        upd.run_update()
+        upd.sync()
+        ref = upd.download()
+        upd.upload(w)
+        upd.upload_slam_features(idp, slam)
+        upd.upload_new_features(w, idp, new)
+        upd.run_update()
+        upd.sync()
+        got = upd.download()
+        g1, g2, gr = upd.download_new_feature_blocks()
+    finally:
+        upd.set_ekf_rows_mode(False)
+        upd.set_extra_states(0)
+    assert rel(g1, H_1) < 1e-12 and rel(g2, H_2) < 1e-12 and rel(gr, r_1) < 1e-12
+    assert np.array_equal(got['accept'], ref['accept'])
+    assert rel(got['dx'], ref['dx']) < 1e-10
+    assert rel(got['P_new'], ref['P_new']) < 1e-10
+    if not fej:   # ... and against the restatement of the reference's whole hybrid update
+        full = mh.hybrid_update_full(w, slam, new, idp)
+        if full['new_accept'] == list(range(len(new))):
+            dx_new, P = capi.augment_state(idp, g1, g2, gr, w.flags.noise_feature ** 2, got['dx'], got['P_new'])
+            assert rel(np.concatenate([got['dx'], dx_new]), full['dx']) < TOL
+            assert rel(P, full['P_new']) < TOL
+
+
 def test_dense_rows_alone(upd):
     """orcvio_msckf_upload_dense_rows without SLAM features or extra states: arbitrary caller-projected rows stacked
     under the MSCKF blocks."""
