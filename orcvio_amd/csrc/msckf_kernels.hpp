@@ -2574,17 +2574,25 @@ template <int RPT>   // rows per thread: RPT * 256 >= the rows of the largest ob
 __global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restrict__ objs, const double* __restrict__ Bred, int Kmax,
                                                        double* __restrict__ Rout, const double* __restrict__ Hr, const double* __restrict__ Sg,
                                                        int N, int NOP, double* __restrict__ Hfr) {
-    // prologue (independent of the reflectors): Hf^T r and |r|^2 of the object = the sum of its clone groups' parts, clones in
-    // index order (deterministic); Hfr[o] = [Hf^T r (NOP) | r^T r]
-    if ((int)threadIdx.x <= NOP) {
-        const int i = threadIdx.x;
-        const double* src = i < NOP ? Hr + (size_t)blockIdx.x * N * NOP + i : Sg + (size_t)blockIdx.x * N * 64 + 54;
-        const size_t st = i < NOP ? (size_t)NOP : 64;
-        double s0 = 0.0, s1 = 0.0;
-        int c = 0;
-        for (; c + 2 <= N; c += 2) { s0 += src[(size_t)c * st]; s1 += src[(size_t)(c + 1) * st]; }
-        if (c < N) s0 += src[(size_t)c * st];
-        Hfr[(size_t)blockIdx.x * (NOP + 1) + i] = s0 + s1;
+    // prologue (independent of the reflectors): Hf^T r and |r|^2 of the object = the sum of its clone groups' parts.  Value i = thread mod 128,
+    // clones of one parity per half of the workgroup, sixteen loads in flight per thread: one memory round trip, hidden under the row loads
+    // below; the two partial sums are combined in a fixed order at the end of the kernel (deterministic).  Hfr[o] = [Hf^T r | r^T r]
+    __shared__ double sSum[2][128];   // (NOP + 1 <= 113 values)
+    {
+        const int i = threadIdx.x & 127, part = threadIdx.x >> 7;
+        double acc = 0.0;
+        if (i <= NOP) {
+            const double* src = i < NOP ? Hr + (size_t)blockIdx.x * N * NOP + i : Sg + (size_t)blockIdx.x * N * 64 + 54;
+            const size_t st = i < NOP ? (size_t)NOP : 64;
+            for (int c0 = part; c0 < N; c0 += 32) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int c = c0 + 2 * u; const double t = src[(size_t)(c < N ? c : c0) * st]; v[u] = c < N ? t : 0.0; }
+                acc += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                       (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+            }
+        }
+        sSum[part][i] = acc;
     }
     __shared__ double sPiv[16];
     __shared__ double sPart[4 * 9];
@@ -2670,6 +2678,7 @@ __global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restric
             for (int j = 0; j < 3; ++j) mx = fmax(mx, fabs(Ro[36 * k + 12 * j + j]));
         Ro[36 * Kmax + 81] = 1e-13 * mx;
     }
+    if (tid <= NOP) Hfr[(size_t)blockIdx.x * (NOP + 1) + tid] = sSum[0][tid] + sSum[1][tid];   // (behind the barriers of the reflectors)
 }
 // Y_o = R^-T C_o for the arrow factor: one thread per column of C (window columns 0..NA-1 from Cd, column NA = Hf^T r
 // from the compact Gram's residual row).  Rows of Y in the order of Hf's columns; dropped pivots give zero rows.
