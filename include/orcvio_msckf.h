@@ -160,6 +160,12 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * cond(Hf) eps -- Hf of a real object has cond ~ 1e8: the keypoint rows have a gauge that only the bbox rows break).  0, and
  * for rows whose Hf does not have that shape: chol(Hf^T Hf) (cond^2: directions below ~1e-8 of the largest are treated as
  * null; stats[7] counts them). */
+/* ORCVIO_OPT_SCHMIDT_STATES (default 0) = k: the Schmidt-EKF of the reference (use_schmidt, src/orcvio.cpp:1730-1751, :1893-1935,
+ * :2881-2920): the LAST 6 k of the extra states are nuisance states -- clones that left the window but stay in state_cov.  The
+ * update leaves the 6k x 6k nuisance block of the covariance as it was (:1740-1751); SLAM features may
+ * be anchored at them: anchor index N + j in orcvio_msckf_slam_features / _ekf_rows / _new_features addresses nuisance state j,
+ * whose pose comes from orcvio_msckf_upload_nuisance_poses and whose Jacobian block lands in its columns of the nuisance block
+ * (:1591-1606).  N + k <= max_clones.  See also orcvio_msckf_cov_clones_to_nuisance, orcvio_msckf_augment_state_nuisance. */
 /* ORCVIO_OPT_REF_STACK_HF (default 0): compatibility with the reference's stacking of SEVERAL objects in one call.
  * System::processObjects concatenates Hx, Hf and r of all objects vertically with Hf's 45 columns SHARED
  * (ros_wrapper/src/orcvio/src/System.cpp:684-702) and removeLostObjects projects the whole stack against that single Hf
@@ -168,7 +174,7 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * one object arrives).  1: the literal shared-Hf stack, dof = total rows - columns; all objects must have the same state size. */
 enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
        ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6, ORCVIO_OPT_RESIDENT_FACTOR = 7, ORCVIO_OPT_OBJECT_QR = 8,
-       ORCVIO_OPT_REF_STACK_HF = 9 };
+       ORCVIO_OPT_REF_STACK_HF = 9, ORCVIO_OPT_SCHMIDT_STATES = 10 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* EKF-SLAM rows of the hybrid filter (existing SLAM features).  For every SLAM feature the current
@@ -272,6 +278,14 @@ typedef struct orcvio_msckf_new_features {
 } orcvio_msckf_new_features;
 int32_t orcvio_msckf_upload_new_features(orcvio_msckf_handle* h, const orcvio_msckf_new_features* feats);
 int32_t orcvio_msckf_download_new_feature_blocks(orcvio_msckf_handle* h, double* H_1, double* H_2, double* r_1);
+/* Schmidt-EKF (ORCVIO_OPT_SCHMIDT_STATES): poses of the nuisance states (state_server.nui_imu_states), after orcvio_msckf_upload;
+ * nui->n_clones must equal the option's value. */
+int32_t orcvio_msckf_upload_nuisance_poses(orcvio_msckf_handle* h, const orcvio_msckf_window* nui);
+/* orcvio_msckf_augment_state with nui_rows nuisance rows at the end of the state: the new feature states are inserted in front
+ * of them (src/orcvio.cpp:1920-1935); P_aug in the order [old | new | nuisance]. */
+int32_t orcvio_msckf_augment_state_nuisance(int32_t n, int32_t n_new, int32_t idp_dim, int32_t nui_rows, const double* H_1, const double* H_2,
+                                            const double* r_1, double sigma2, const double* dx, const double* P_upd, double* dx_new,
+                                            double* P_aug);
 /* gamma[F], accept[F] of the SLAM features of the last update (either may be NULL) */
 int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept);
 
@@ -538,6 +552,9 @@ int32_t orcvio_msckf_cov_augment(orcvio_msckf_handle* h);
 int32_t orcvio_msckf_cov_remove_clones(orcvio_msckf_handle* h, int32_t leg_dim, const int32_t* clone_indices, int32_t count);
 int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h);
 int32_t orcvio_msckf_cov_prefactor(orcvio_msckf_handle* h);
+/* Schmidt branch of pruneImuStateBuffer (src/orcvio.cpp:2881-2920): the listed clones (window ranks before the call, ascending)
+ * leave the window but stay in the resident covariance as nuisance states -- their blocks move to the end, in the listed order. */
+int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_dim, const int32_t* clone_indices, int32_t count);
 
 #ifdef __cplusplus
 }

@@ -43,3 +43,28 @@ def remove_clones(P, leg, clone_indices):
     for c in clone_indices:
         keep[leg + 6 * c: leg + 6 * c + 6] = False
     return P[np.ix_(keep, keep)].copy()
+
+
+def clones_to_nuisance(P, leg, clone_indices):
+    """Schmidt branch of pruneImuStateBuffer (src/orcvio.cpp:2881-2920), literally: for every listed clone (window ranks
+    BEFORE the call, ascending) the rows / columns behind its block move up by 6 and its own block and cross terms go to the
+    end; the imu state is erased from the window afterwards, so the ranks of the later ones drop by one."""
+    P = P.copy()
+    done = 0
+    for c in clone_indices:
+        rows = cols = P.shape[0]
+        start = leg + 6 * (c - done)
+        end = start + 6
+        if end < rows:
+            P_ss = P[start:end, start:end].copy()
+            P_os_1 = P[start:end, :start].copy()
+            P_os_2 = P[start:end, end:].copy()
+            P[start:start + rows - end, :] = P[end:, :].copy()
+            P[:, start:start + cols - end] = P[:, end:].copy()
+            P[rows - 6:, cols - 6:] = P_ss
+            P[rows - 6:, :start] = P_os_1
+            P[rows - 6:, start:start + cols - end] = P_os_2
+            P[:start, cols - 6:] = P_os_1.T
+            P[start:start + rows - end, cols - 6:] = P_os_2.T
+        done += 1
+    return P

@@ -7,7 +7,10 @@ Follows src/orcvio.cpp:
   featureJacobian_ekf             :1575-1651  (one observation, the current IMU state; anchor inside the window)
   removeLostFeatures, EKF part    :2444-2464  (gatingTestFeature(H_xj, r_j, 2) per SLAM feature, then stacking)
   measurementUpdate_hybrid        :1766-1950  (case sz_new == 0: H_o = [H_msckf; H_ekf], K, dx, (I - K H) P)
-State layout: [legacy LEG | clones 6N | feature states d each] (:1495-1510 without Schmidt nuisance states).
+State layout: [legacy LEG | clones 6N | feature states d each | Schmidt nuisance states 6 each] (:1495-1510).  Schmidt
+(use_schmidt): a window with win.nui set carries the poses of the nuisance states; an anchor index N + j is nuisance state j
+(:1247-1256 its pose, :1591-1606 its columns), the update leaves the nuisance block of P alone (:1740-1751, :1893-1902) and new
+feature states are inserted in front of it (:1920-1935).
 Parity unpinned: the reference has no test of these functions; anchored on its text and on central differences
 (tests/test_oracle_hybrid.py).  Nothing under orcvio_amd/ may import this module.
 """
@@ -34,14 +37,34 @@ class SlamFeature:
     p_fej: np.ndarray = None   # position_FEJ (if_FEJ)
 
 
+def _n_nui(win):
+    return getattr(win, 'n_nui', 0)
+
+
+def _anchor_pose(win, a):
+    """(R_b2w, t_b_w, t_fej) of anchor a: a clone of the window, or (a >= N) nuisance state a - N (:1247-1256)."""
+    if a < win.N:
+        return win.R_b2w[a], win.t_b_w[a], win.t_fej[a]
+    j = a - win.N
+    return win.nui['R_b2w'][j], win.nui['t_b_w'][j], win.nui['t_fej'][j]
+
+
+def anchor_col(win, a):
+    """first column of anchor a's 6 x 6 block: LEG + 6 a, or inside the nuisance block at the end of the state (:1591-1606)"""
+    if a < win.N:
+        return win.flags.leg_dim + 6 * a
+    return win.n - 6 * _n_nui(win) + 6 * (a - win.N)
+
+
 def _poses(win, k, a):
     R_b2c, t_c_b = win.R_b2c[k], win.t_c_b[k]
     R_w2bk = win.R_b2w[k].T
     t_bk_w = win.t_b_w[k]
     R_w2ck = R_b2c @ R_w2bk
     t_ck_w = t_bk_w + win.R_b2w[k] @ t_c_b
-    R_w2ba = win.R_b2w[a].T
-    t_ba_w = win.t_b_w[a]
+    Ra, ta, _ = _anchor_pose(win, a)
+    R_w2ba = Ra.T
+    t_ba_w = ta
     R_w2ca = R_b2c @ R_w2ba
     return R_b2c, t_c_b, R_w2bk, t_bk_w, R_w2ck, t_ck_w, R_w2ba, t_ba_w, R_w2ca
 
@@ -54,7 +77,7 @@ def measurement_jacobian_ekf(win, ft: SlamFeature, idp_dim: int):
     fej = bool(f.if_fej)
     p_fej = ft.p_fej if ft.p_fej is not None else ft.p_w
     if fej:                                                     # :1281-1282 / :1410-1411
-        p_ca = R_b2c @ (R_w2ba @ (p_fej - win.t_fej[a]) - t_c_b)
+        p_ca = R_b2c @ (R_w2ba @ (p_fej - _anchor_pose(win, a)[2]) - t_c_b)
     elif idp_dim == 3:
         p_ca = np.array([ft.inv_param[0] / ft.inv_param[2], ft.inv_param[1] / ft.inv_param[2], 1.0 / ft.inv_param[2]])
     else:
@@ -75,7 +98,7 @@ def measurement_jacobian_ekf(win, ft: SlamFeature, idp_dim: int):
     J_k[1, 1] = 1 / p_ck[2]
     J_k[0, 2] = -p_ck[0] / (p_ck[2] * p_ck[2])
     J_k[1, 2] = -p_ck[1] / (p_ck[2] * p_ck[2])
-    p_baf_w = (p_fej - win.t_fej[a]) if fej else (ft.p_w - t_ba_w)   # :1320-1323
+    p_baf_w = (p_fej - _anchor_pose(win, a)[2]) if fej else (ft.p_w - t_ba_w)   # :1320-1323
     p_bkf_w = (p_fej - win.t_fej[k]) if fej else (ft.p_w - t_bk_w)
     J_xa = np.zeros((3, 6))                                     # :1325-1327
     J_xa[:, :3] = -R_w2ck @ skew(p_baf_w)
@@ -111,7 +134,7 @@ def feature_jacobian_ekf(win, ft: SlamFeature, idx: int, idp_dim: int):
     H_f, H_a, H_x, H_e, r = measurement_jacobian_ekf(win, ft, idp_dim)
     fi = f.leg_dim + 6 * win.N + idp_dim * idx                  # :1612
     H[:, fi:fi + idp_dim] = H_f                                 # :1630 / :1636
-    H[:, f.leg_dim + 6 * ft.anchor: f.leg_dim + 6 * ft.anchor + 6] = H_a   # :1639 (assignment order as the reference:
+    H[:, anchor_col(win, ft.anchor): anchor_col(win, ft.anchor) + 6] = H_a   # :1639 (assignment order as the reference:
     H[:, f.leg_dim + 6 * ft.state: f.leg_dim + 6 * ft.state + 6] = H_x     # :1640  a later block overwrites an earlier one)
     H[:, 15:21] = H_e                                           # :1641
     if f.estimate_td:
@@ -147,8 +170,19 @@ def hybrid_update(win, slam, idp_dim: int, table=None):
     r = np.concatenate(acc_rs)
     H_thin, r_thin = mirror.qr_compress(H, r)
     dx, K, Pn = mirror.measurement_update(H_thin, r_thin, win.P, sigma2)
+    Pn = keep_nuisance_block(win, Pn)
     out.update(dx=dx, P_new=Pn, G=K @ H_thin)
     return out
+
+
+def keep_nuisance_block(win, P_upd):
+    """:1740-1751 / :1893-1902 -- Schmidt: the nuisance block of the updated covariance is the prior's."""
+    m = 6 * _n_nui(win)
+    if m == 0:
+        return P_upd
+    P = P_upd.copy()
+    P[-m:, -m:] = win.P[-m:, -m:]
+    return 0.5 * (P + P.T)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -180,7 +214,7 @@ def feature_jacobian_ekf_new(win, ft: NewSlamFeature, idx_new: int, n_new: int, 
                           p_w=ft.p_w, z=z, z_vel=zv, p_fej=ft.p_fej)
         H_f, H_a, H_x, H_e, rr = measurement_jacobian_ekf(win, one, d)
         H[2 * c:2 * c + 2, fi:fi + d] = H_f                                           # :1550 / :1557
-        H[2 * c:2 * c + 2, f.leg_dim + 6 * ft.anchor: f.leg_dim + 6 * ft.anchor + 6] = H_a   # :1561
+        H[2 * c:2 * c + 2, anchor_col(win, ft.anchor): anchor_col(win, ft.anchor) + 6] = H_a   # :1561
         H[2 * c:2 * c + 2, f.leg_dim + 6 * k: f.leg_dim + 6 * k + 6] = H_x            # :1562
         H[2 * c:2 * c + 2, 15:21] = H_e                                               # :1563
         if f.estimate_td:
@@ -232,13 +266,31 @@ def split_new_rows(win, new_feats, idp_dim: int, table=None):
     return acc, Hn[:m - sz, :win.n], rn[:m - sz], Hn[m - sz:, :win.n], Hn[m - sz:, win.n:], rn[m - sz:]
 
 
-def augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2):
-    """:1811-1821 and :1904-1947 (no nuisance states): the new states' correction and the augmented covariance from the
-    UPDATED legacy covariance.  This part stays with the caller in the integration."""
+def augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2, nui_rows=0):
+    """:1811-1821 and :1904-1947: the new states' correction and the augmented covariance from the UPDATED legacy covariance.
+    This part stays with the caller in the integration.  nui_rows > 0 (Schmidt): the new states are
+    inserted in front of the trailing nuisance rows / columns, block by block as :1920-1935 does."""
     n = P_upd.shape[0]
     sz = H_2.shape[0]
     if sz == 0:
         return dx_leg.copy(), P_upd.copy()
+    if nui_rows > 0:
+        HH = np.linalg.solve(H_2, H_1)
+        dx_new = -HH @ dx_leg + np.linalg.solve(H_2, r_1)
+        nHHP = -HH @ P_upd
+        P22 = -nHHP @ HH.T + sigma2 * np.linalg.inv(H_2.T @ H_2)
+        old_rows = old_cols = n
+        P = np.zeros((n + sz, n + sz))
+        P[:n, :n] = P_upd                                                        # conservativeResize
+        nr = nc = nui_rows
+        P[old_rows + sz - nr:, :old_cols] = P[old_rows - nr:old_rows, :old_cols].copy()                 # :1924-1925
+        P[:old_rows + sz, old_cols + sz - nc:] = P[:old_rows + sz, old_cols - nc:old_cols].copy()       # :1926-1927
+        P[old_rows - nr:old_rows - nr + sz, :old_cols - nc] = nHHP[:, :old_cols - nc]                   # :1929
+        P[old_rows - nr:old_rows - nr + sz, old_cols + sz - nc:] = nHHP[:, old_cols - nc:]              # :1930
+        P[:old_rows - nr, old_cols - nc:old_cols - nc + sz] = nHHP[:, :old_cols - nc].T                 # :1931
+        P[old_rows + sz - nr:, old_cols - nc:old_cols - nc + sz] = nHHP[:, old_cols - nc:].T            # :1932
+        P[old_rows - nr:old_rows - nr + sz, old_cols - nc:old_cols - nc + sz] = P22                     # :1933
+        return np.concatenate([dx_leg, dx_new]), 0.5 * (P + P.T)
     HH = np.linalg.solve(H_2, H_1)
     dx_new = -HH @ dx_leg + np.linalg.solve(H_2, r_1)
     nHHP = -HH @ P_upd
@@ -275,7 +327,8 @@ def hybrid_update_full(win, slam, new_feats, idp_dim: int, table=None):
     K = np.linalg.solve(S, H_o @ P).T
     dx_leg = K @ r_o
     P_upd = (np.eye(win.n) - K @ H_o) @ P                                # :1889-1902
+    P_upd = keep_nuisance_block(win, P_upd)
     P_upd = 0.5 * (P_upd + P_upd.T)
-    dx, P_full = augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2)
+    dx, P_full = augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2, 6 * _n_nui(win))
     return dict(dx=dx, P_new=P_full, accept=base['accept'], ekf_accept=np.array(ea, dtype=np.int32), new_accept=acc,
                 dx_leg=dx_leg, P_upd=P_upd)

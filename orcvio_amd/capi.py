@@ -33,7 +33,8 @@ EXPORTS = [
     'orcvio_msckf_object_rows_eval', 'orcvio_msckf_triangulation_config_default', 'orcvio_msckf_triangulate',
     'orcvio_msckf_triangulate_uploaded', 'orcvio_msckf_objects_local', 'orcvio_msckf_objects_finish',
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
-    'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit', 'orcvio_msckf_cov_prefactor', 'orcvio_msckf_upload_new_features', 'orcvio_msckf_download_new_feature_blocks',
+    'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit', 'orcvio_msckf_cov_prefactor', 'orcvio_msckf_upload_new_features', 'orcvio_msckf_download_new_feature_blocks', 'orcvio_msckf_upload_nuisance_poses',
+    'orcvio_msckf_augment_state_nuisance', 'orcvio_msckf_cov_clones_to_nuisance',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
     'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks', 'orcvio_msckf_new_feature_rows', 'orcvio_msckf_augment_state',
     'orcvio_msckf_profile_stages', 'orcvio_msckf_update_object_lm_msgs',
@@ -173,6 +174,8 @@ def _bind(lib):
     lib.orcvio_msckf_cov_remove_clones.argtypes = [C.c_void_p, C.c_int32, _ip, C.c_int32]
     lib.orcvio_msckf_cov_commit.argtypes = [C.c_void_p]
     lib.orcvio_msckf_cov_prefactor.argtypes = [C.c_void_p]
+    lib.orcvio_msckf_cov_clones_to_nuisance.argtypes = [C.c_void_p, C.c_int32, _ip, C.c_int32]
+    lib.orcvio_msckf_upload_nuisance_poses.argtypes = [C.c_void_p, C.c_void_p]
     lib.orcvio_msckf_update_object_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.c_int32,
                                                       C.POINTER(ObjectTrackC), C.c_int32, _dp, C.POINTER(MsckfResult)]
     lib.orcvio_msckf_objects_local_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.c_int32,
@@ -739,6 +742,20 @@ class MsckfUpdater:
     def cov_commit(self):
         self._chk(self.lib.orcvio_msckf_cov_commit(self.h), 'orcvio_msckf_cov_commit')
 
+    def cov_clones_to_nuisance(self, leg_dim, indices):
+        ix = np.ascontiguousarray(indices, dtype=np.int32)
+        self._chk(self.lib.orcvio_msckf_cov_clones_to_nuisance(self.h, leg_dim, _i(ix), len(ix)), 'orcvio_msckf_cov_clones_to_nuisance')
+
+    def set_schmidt_states(self, k):
+        """ORCVIO_OPT_SCHMIDT_STATES: the last 6 k extra states are Schmidt nuisance states."""
+        self._chk(self.lib.orcvio_msckf_set_option(self.h, 10, int(k)), 'orcvio_msckf_set_option')
+
+    def upload_nuisance_poses(self, nui):
+        """Poses of the nuisance states (synth.Window.nui-shaped dict), after upload()."""
+        arrs = [np.ascontiguousarray(nui[k], dtype=np.float64) for k in ('R_b2w', 't_b_w', 't_fej', 'R_b2c', 't_c_b')]
+        wn = MsckfWindow(arrs[0].shape[0], *[_d(a) for a in arrs])
+        self._chk(self.lib.orcvio_msckf_upload_nuisance_poses(self.h, C.byref(wn)), 'orcvio_msckf_upload_nuisance_poses')
+
     def cov_prefactor(self):
         """Factor the resident covariance now (asynchronously): the next update finds its prior's square-root factor resident."""
         self._chk(self.lib.orcvio_msckf_cov_prefactor(self.h), 'orcvio_msckf_cov_prefactor')
@@ -877,6 +894,23 @@ def new_feature_rows(win, idp_dim, feats):
     if rc != 0:
         raise MsckfError(rc, 'orcvio_msckf_new_feature_rows')
     return H_top[:rows.value].copy(), r_top[:rows.value].copy(), H_1, H_2, r_1
+
+
+def augment_state_nuisance(idp_dim, nui_rows, H_1, H_2, r_1, sigma2, dx, P_upd):
+    """Host arithmetic: augment_state with nui_rows Schmidt nuisance rows at the end (new states go in front of them)."""
+    lib = load()
+    lib.orcvio_msckf_augment_state_nuisance.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                        C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    d, k, n = int(idp_dim), H_2.shape[0], P_upd.shape[0]
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (H_1, H_2, r_1, dx, P_upd)]
+    dx_new = np.zeros(d * k)
+    P_aug = np.zeros((n + d * k, n + d * k))
+    rc = lib.orcvio_msckf_augment_state_nuisance(n, k, d, int(nui_rows), _d(a[0]), _d(a[1]), _d(a[2]), float(sigma2), _d(a[3]), _d(a[4]),
+                                                 _d(dx_new), _d(P_aug))
+    if rc != 0:
+        raise MsckfError(rc, 'orcvio_msckf_augment_state_nuisance')
+    return dx_new, P_aug
 
 
 def augment_state(idp_dim, H_1, H_2, r_1, sigma2, dx, P_upd):

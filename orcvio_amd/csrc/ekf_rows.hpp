@@ -13,7 +13,7 @@
 namespace orcvio_amd {
 
 struct EkfGateArgs {
-    int F, idp_dim, n, leg, N, NA, NAP, estimate_td;
+    int F, idp_dim, n, leg, N, NA, NAP, estimate_td, n_nui;
     const int* anchor; const int* state; const int* slot;
     const double* He; const double* Ha; const double* Hx; const double* Hf; const double* zvel; const double* r;
     const double* P;         // [n][n] prior
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(64) void k_ekf_gate(EkfGateArgs p) {
         if (p.estimate_td) { col = 21; v0 = p.zvel[(size_t)f * 2]; v1 = p.zvel[(size_t)f * 2 + 1]; }
     } else if (t < 13) {               // H_a -> the anchor clone (:1639); the state clone's block overwrites it if they coincide
         const int e = t - 7;
-        if (a != k) { col = p.leg + 6 * a + e; v0 = p.Ha[(size_t)f * 12 + e]; v1 = p.Ha[(size_t)f * 12 + 6 + e]; }
+        // (an anchor index >= N is a Schmidt nuisance state: its 6 columns are in the nuisance block at the end of the state, :1591-1606)
+        if (a != k) { col = (a < p.N ? p.leg + 6 * a : p.n - 6 * p.n_nui + 6 * (a - p.N)) + e; v0 = p.Ha[(size_t)f * 12 + e]; v1 = p.Ha[(size_t)f * 12 + 6 + e]; }
     } else if (t < 19) {               // H_x -> the observing clone (:1640)
         const int e = t - 13;
         col = p.leg + 6 * k + e; v0 = p.Hx[(size_t)f * 12 + e]; v1 = p.Hx[(size_t)f * 12 + 6 + e];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
 // subspaces matter): the first d rows are the U part -- H_1, r_1, and H_2 = the R factor -- and leave the stack (zeroed);
 // the other 2M - d rows are the V part, zero in the new columns, and are stacked under everything else as they are.
 struct EkfNewArgs {
-    int n_new, idp_dim, if_fej, estimate_td, leg, NA, NAP, n;
+    int n_new, idp_dim, if_fej, estimate_td, leg, NA, NAP, n, N, n_nui;
     const double* poses;
     const int* anchor;          // [n_new]
     const double* param;        // [n_new][3]
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(256) void k_ekf_new(EkfNewArgs p) {
                        He, Ha, Hx, Hf, rr);
         for (int b = 0; b < 2; ++b) {
             double* row = M + (size_t)(2 * c + b) * p.NAP;
-            for (int e = 0; e < 6; ++e) row[p.leg - 15 + 6 * a + e] = Ha[6 * b + e];   // :1561
+            const int ca = (a < p.N ? p.leg + 6 * a : p.n - 6 * p.n_nui + 6 * (a - p.N)) - 15;   // (a >= N: a Schmidt nuisance state)
+            for (int e = 0; e < 6; ++e) row[ca + e] = Ha[6 * b + e];                  // :1561
             for (int e = 0; e < 6; ++e) row[p.leg - 15 + 6 * k + e] = Hx[6 * b + e];   // :1562 (overwrites if k == a)
             for (int e = 0; e < 6; ++e) row[e] = He[6 * b + e];                       // :1563 (columns 15..20)
             if (p.estimate_td) row[6] = p.obs_zvel[(size_t)2 * o + b];                // :1564-1565 (column 21)

@@ -87,6 +87,7 @@ struct orcvio_msckf_handle {
     int fac_n = 0, fac_k = 0, fac_ld = 0;
     bool fac_valid = false;
     bool factor_opt = true;             // ORCVIO_OPT_RESIDENT_FACTOR
+    int n_nui = 0;                      // ORCVIO_OPT_SCHMIDT_STATES: Schmidt nuisance states (6 columns each) at the END of the extra states
     bool ref_stack_hf = false;          // ORCVIO_OPT_REF_STACK_HF: the reference's literal shared-Hf stacking of several objects
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
     bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P
@@ -492,6 +493,11 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
         h->ref_stack_hf = value != 0;
         return ORCVIO_OK;
     }
+    if (option == ORCVIO_OPT_SCHMIDT_STATES) {
+        if (value < 0 || value > h->maxN) { g_last_error = "orcvio_msckf_set_option: nuisance states out of range"; return ORCVIO_ERR_INVALID; }
+        h->n_nui = value;   // takes effect with the next upload (part of the launch signature)
+        return ORCVIO_OK;
+    }
     if (option == ORCVIO_OPT_OBJECT_QR) {
         h->arrow_opt = value != 0;
         return ORCVIO_OK;
@@ -568,6 +574,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
     h->ekf_F = 0; h->dense_rows = 0; h->new_F = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
+    if (6 * h->n_nui > h->n_extra || N + h->n_nui > h->maxN) { g_last_error = "orcvio_msckf_upload: nuisance states do not fit the extra states / the pose capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
     select_prior_factor(h, P);
     h->NP = round_up(h->n > h->kf ? h->n : h->kf, 16);
@@ -588,7 +595,7 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     hipStream_t s = h->stream;
     if (!P && h->res_n != h->n) { g_last_error = "orcvio_msckf_upload: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
     const bool with_zvel = tr->obs_zvel && flags->estimate_td;   // read by the kernels only under estimate_td
-    layout_inputs(h, N, F, nobs, with_zvel, P != nullptr, h->n);
+    layout_inputs(h, N + h->n_nui, F, nobs, with_zvel, P != nullptr, h->n);   // (pose slots of the nuisance states behind the window's)
     layout_outputs(h, h->n, F);
     char* st = h->h_stage;
     size_t bytes = h->in_used;
@@ -922,7 +929,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
                 gate.rr = h->d_A + (size_t)NA * h->NAP + NA; gate.thr = h->obj_thr;
                 gate.gamma = h->d_obj_gamma; gate.accept = h->d_obj_accept; gate.gamma_out = h->d_gamma; gate.accept_out = h->d_accept;
             }
-            hipLaunchKernelGGL(k_finish_sqrt, dim3(tiles), dim3(256), 0, s, h->d_Z, ldz, n, kf, sigma2, h->d_Pout, h->d_dx, gate, h->d_P);
+            hipLaunchKernelGGL(k_finish_sqrt, dim3(tiles), dim3(256), 0, s, h->d_Z, ldz, n, kf, sigma2, h->d_Pout, h->d_dx, gate, h->d_P, 6 * h->n_nui);
             HIPCHK(hipGetLastError());
             return ORCVIO_OK;
         }
@@ -961,7 +968,7 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
     mix(h->N); mix(h->F); mix(h->nobs); mix(h->Mmax); mix(h->chunks); mix(h->s_chunks); mix(h->rows_per_chunk);
     mix(h->flags.leg_dim); mix(h->flags.use_larvio); mix(h->flags.use_left_perturbation); mix(h->flags.if_fej);
-    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->front_fused); mix(h->feat_ablate); mix(h->ekf_F); mix(h->ekf_mode); mix(h->n_extra); mix(h->dense_rows);
+    mix(h->flags.estimate_td); mix(h->materialize); mix(h->skip_active); mix(h->fused_solve); mix(h->front_fused); mix(h->feat_ablate); mix(h->ekf_F); mix(h->ekf_mode); mix(h->n_extra); mix(h->n_nui); mix(h->dense_rows);
     unsigned long long bits;
     double sg = h->flags.noise_feature;
     std::memcpy(&bits, &sg, 8); mix(bits);
@@ -1081,7 +1088,7 @@ static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s) {
         }
         EkfGateArgs a;
         a.F = F; a.idp_dim = h->ekf_idp; a.n = h->n; a.leg = h->flags.leg_dim; a.N = h->N; a.NA = h->NA; a.NAP = h->NAP;
-        a.estimate_td = h->flags.estimate_td;
+        a.estimate_td = h->flags.estimate_td; a.n_nui = h->n_nui;
         a.anchor = h->d_ekf_i; a.state = h->d_ekf_i + cap; a.slot = h->d_ekf_i + 2 * cap;
         a.He = h->d_ekf_d; a.Ha = a.He + (size_t)12 * cap; a.Hx = a.Ha + (size_t)12 * cap; a.Hf = a.Hx + (size_t)12 * cap;
         a.zvel = a.Hf + (size_t)6 * cap; a.r = a.zvel + (size_t)2 * cap;
@@ -1151,8 +1158,8 @@ int32_t orcvio_msckf_upload_slam_features(orcvio_msckf_handle* h, const orcvio_m
     if (F > 0 && (!ft->anchor || !ft->state || !ft->slot || !ft->param || !ft->p_w || !ft->z || (d == 1 && !ft->inv_depth) ||
                   (h->flags.if_fej && !ft->p_fej) || (h->flags.estimate_td && !ft->z_vel))) { g_last_error = "upload_slam_features: null array"; return ORCVIO_ERR_INVALID; }
     for (int f = 0; f < F; ++f) {
-        if (ft->anchor[f] < 0 || ft->anchor[f] >= h->N || ft->state[f] < 0 || ft->state[f] >= h->N) { g_last_error = "upload_slam_features: clone index outside the window"; return ORCVIO_ERR_INVALID; }
-        if (ft->slot[f] < 0 || d * (ft->slot[f] + 1) > h->n_extra) { g_last_error = "upload_slam_features: feature slot outside the extra states"; return ORCVIO_ERR_INVALID; }
+        if (ft->anchor[f] < 0 || ft->anchor[f] >= h->N + h->n_nui || ft->state[f] < 0 || ft->state[f] >= h->N) { g_last_error = "upload_slam_features: clone index outside the window"; return ORCVIO_ERR_INVALID; }
+        if (ft->slot[f] < 0 || d * (ft->slot[f] + 1) > h->n_extra - 6 * h->n_nui) { g_last_error = "upload_slam_features: feature slot outside the extra states"; return ORCVIO_ERR_INVALID; }
     }
     HIPCHK(hipSetDevice(h->device));
     { const int rc = ekf_reserve(h, F); if (rc != ORCVIO_OK) return rc; }
@@ -1183,8 +1190,8 @@ int32_t orcvio_msckf_upload_ekf_rows(orcvio_msckf_handle* h, const orcvio_msckf_
     if (F > 0 && (!rows->anchor || !rows->state || !rows->slot || !rows->H_e || !rows->H_a || !rows->H_x || !rows->H_f || !rows->r ||
                   (h->flags.estimate_td && !rows->z_vel))) { g_last_error = "upload_ekf_rows: null array"; return ORCVIO_ERR_INVALID; }
     for (int f = 0; f < F; ++f) {
-        if (rows->anchor[f] < 0 || rows->anchor[f] >= h->N || rows->state[f] < 0 || rows->state[f] >= h->N) { g_last_error = "upload_ekf_rows: clone index outside the window"; return ORCVIO_ERR_INVALID; }
-        if (rows->slot[f] < 0 || d * (rows->slot[f] + 1) > h->n_extra) { g_last_error = "upload_ekf_rows: feature slot outside the extra states"; return ORCVIO_ERR_INVALID; }
+        if (rows->anchor[f] < 0 || rows->anchor[f] >= h->N + h->n_nui || rows->state[f] < 0 || rows->state[f] >= h->N) { g_last_error = "upload_ekf_rows: clone index outside the window"; return ORCVIO_ERR_INVALID; }
+        if (rows->slot[f] < 0 || d * (rows->slot[f] + 1) > h->n_extra - 6 * h->n_nui) { g_last_error = "upload_ekf_rows: feature slot outside the extra states"; return ORCVIO_ERR_INVALID; }
     }
     HIPCHK(hipSetDevice(h->device));
     { const int rc = ekf_reserve(h, F); if (rc != ORCVIO_OK) return rc; }
@@ -1230,6 +1237,28 @@ int32_t orcvio_msckf_upload_dense_rows(orcvio_msckf_handle* h, int32_t n_rows, c
     return ORCVIO_OK;
 }
 
+// Schmidt-EKF: the poses of the nuisance states (state_server.nui_imu_states: clones that left the window but stay in state_cov as
+// nuisance parameters, src/orcvio.cpp:2881-2920), in the pose slots behind the window's: SLAM features may be anchored there
+// (anchor index N + j, :1247-1256, :1591-1606).  After orcvio_msckf_upload, with ORCVIO_OPT_SCHMIDT_STATES = nui->n_clones.
+int32_t orcvio_msckf_upload_nuisance_poses(orcvio_msckf_handle* h, const orcvio_msckf_window* nui) {
+    if (!h || !nui || !h->uploaded) { g_last_error = "upload_nuisance_poses: upload the window first"; return ORCVIO_ERR_INVALID; }
+    if (nui->n_clones != h->n_nui) { g_last_error = "upload_nuisance_poses: count differs from ORCVIO_OPT_SCHMIDT_STATES"; return ORCVIO_ERR_INVALID; }
+    if (h->n_nui == 0) return ORCVIO_OK;
+    if (!nui->R_b2w || !nui->t_b_w || !nui->R_b2c || !nui->t_c_b) { g_last_error = "upload_nuisance_poses: null array"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> rec((size_t)POSE_STRIDE * h->n_nui, 0.0);
+    const double* tfej = nui->t_fej ? nui->t_fej : nui->t_b_w;
+    for (int i = 0; i < h->n_nui; ++i) {
+        double* r = rec.data() + (size_t)POSE_STRIDE * i;
+        std::memcpy(r + POSE_R_B2W, nui->R_b2w + 9 * i, 72); std::memcpy(r + POSE_T_B_W, nui->t_b_w + 3 * i, 24);
+        std::memcpy(r + POSE_T_FEJ, tfej + 3 * i, 24);
+        std::memcpy(r + POSE_R_B2C, nui->R_b2c + 9 * i, 72); std::memcpy(r + POSE_T_C_B, nui->t_c_b + 3 * i, 24);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));   // (behind the copy of the input arena)
+    HIPCHK(hipMemcpy(h->d_poses + (size_t)POSE_STRIDE * h->N, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice));
+    return ORCVIO_OK;
+}
+
 // Dense-row scratch [cap][NAP_max] (caller-projected rows, V parts of entering features); the contents are kept.
 static int dense_reserve(orcvio_msckf_handle* h, int rows) {
     if (rows <= h->dense_cap) return ORCVIO_OK;
@@ -1263,7 +1292,7 @@ int32_t orcvio_msckf_upload_new_features(orcvio_msckf_handle* h, const orcvio_ms
     std::vector<int> row0(k + 1, 0);
     for (int j = 0; j < k; ++j) {
         const int a = nf->anchor[j];
-        if (a < 0 || a >= N) { g_last_error = "upload_new_features: anchor outside the window"; return ORCVIO_ERR_INVALID; }
+        if (a < 0 || a >= N + h->n_nui) { g_last_error = "upload_new_features: anchor outside the window"; return ORCVIO_ERR_INVALID; }
         const int M = nf->obs_ptr[j + 1] - nf->obs_ptr[j];
         if (M < 0 || M > ORCVIO_MAX_TRACK) { g_last_error = "upload_new_features: track longer than ORCVIO_MAX_TRACK"; return ORCVIO_ERR_TRACK_TOO_LONG; }
         int kept = 0;
@@ -1310,7 +1339,7 @@ int32_t orcvio_msckf_upload_new_features(orcvio_msckf_handle* h, const orcvio_ms
     double* dout = reinterpret_cast<double*>(h->d_new + bytes_in);
     EkfNewArgs a;
     a.n_new = k; a.idp_dim = d; a.if_fej = h->flags.if_fej; a.estimate_td = h->flags.estimate_td; a.leg = h->flags.leg_dim;
-    a.NA = h->NA; a.NAP = h->NAP; a.n = h->n;
+    a.NA = h->NA; a.NAP = h->NAP; a.n = h->n; a.N = h->N; a.n_nui = h->n_nui;
     a.poses = h->d_poses;
     a.param = dd; a.inv_depth = dd + 3 * k; a.p_w = dd + 4 * k; a.p_fej = nf->p_fej ? dd + 7 * k : nullptr;
     a.obs_z = dd + 10 * k; a.obs_zvel = dd + 10 * k + 2 * nobs;
@@ -1615,6 +1644,26 @@ int32_t orcvio_msckf_augment_state(int32_t n, int32_t n_new, int32_t idp_dim, co
         }
     for (int r = 0; r < nt; ++r)   // (:1946)
         for (int c = r + 1; c < nt; ++c) { const double m = 0.5 * (P_aug[(size_t)r * nt + c] + P_aug[(size_t)c * nt + r]); P_aug[(size_t)r * nt + c] = m; P_aug[(size_t)c * nt + r] = m; }
+    return ORCVIO_OK;
+}
+
+// ... with Schmidt nuisance states: the new feature states go IN FRONT of the trailing nui_rows nuisance rows / columns
+// (src/orcvio.cpp:1920-1935).  n counts the nuisance states; P_aug [(n + d n_new)^2] in the order [old | new | nuisance].
+int32_t orcvio_msckf_augment_state_nuisance(int32_t n, int32_t n_new, int32_t idp_dim, int32_t nui_rows, const double* H_1, const double* H_2,
+                                            const double* r_1, double sigma2, const double* dx, const double* P_upd, double* dx_new,
+                                            double* P_aug) {
+    if (nui_rows < 0 || nui_rows > n) { g_last_error = "augment_state_nuisance: invalid argument"; return ORCVIO_ERR_INVALID; }
+    const int sz = idp_dim * n_new, nt = n + sz;
+    std::vector<double> T((size_t)nt * nt);
+    const int rc = orcvio_msckf_augment_state(n, n_new, idp_dim, H_1, H_2, r_1, sigma2, dx, P_upd, dx_new, T.data());   // [old + nuisance | new]
+    if (rc != ORCVIO_OK) return rc;
+    std::vector<int> map(nt);   // map[i] = index in T of row / column i of P_aug
+    const int n0 = n - nui_rows;
+    for (int i = 0; i < n0; ++i) map[i] = i;
+    for (int i = 0; i < sz; ++i) map[n0 + i] = n + i;
+    for (int i = 0; i < nui_rows; ++i) map[n0 + sz + i] = n0 + i;
+    for (int i = 0; i < nt; ++i)
+        for (int j = 0; j < nt; ++j) P_aug[(size_t)i * nt + j] = T[(size_t)map[i] * nt + map[j]];
     return ORCVIO_OK;
 }
 
@@ -3030,12 +3079,47 @@ int32_t orcvio_msckf_cov_remove_clones(orcvio_msckf_handle* h, int32_t leg, cons
     return ORCVIO_OK;
 }
 
+// Schmidt branch of pruneImuStateBuffer (src/orcvio.cpp:2881-2920): the listed clones leave the window but STAY in the covariance
+// as nuisance states -- their 6 x 6 blocks and cross terms move to the end, one clone after the other in the listed order.
+// A symmetric permutation: rows of the resident square-root factor move with it.
+int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg, const int32_t* idx, int32_t count) {
+    if (!h || (count > 0 && !idx) || count < 0 || (leg != 22 && leg != 46) || h->res_n < leg) { g_last_error = "cov_clones_to_nuisance: invalid"; return ORCVIO_ERR_INVALID; }
+    if (count == 0) return ORCVIO_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->res_n;
+    std::vector<int> map(n);
+    for (int i = 0; i < n; ++i) map[i] = i;
+    std::vector<int> moved_before;   // window ranks are those BEFORE any of the listed clones has moved (ascending, as rm_imu_state_ids)
+    for (int k = 0; k < count; ++k) {
+        int shift = 0;
+        for (int q : moved_before) if (q < idx[k]) ++shift;
+        const int start = leg + 6 * (idx[k] - shift);
+        if (idx[k] < 0 || start + 6 > n) { g_last_error = "cov_clones_to_nuisance: index out of the window"; return ORCVIO_ERR_INVALID; }
+        std::rotate(map.begin() + start, map.begin() + start + 6, map.end());   // the block goes to the end, everything behind it moves up
+        moved_before.push_back(idx[k]);
+    }
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_covmap, map.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_cov_remove, dim3((n * n + 255) / 256), dim3(256), 0, s, h->d_Pres, n, h->d_covmap, n, h->d_Ptmp);
+    HIPCHK(hipGetLastError());
+    if (h->fac_valid && h->fac_n == n) {
+        hipLaunchKernelGGL(k_fac_remove, dim3((h->fac_k * n + 255) / 256), dim3(256), 0, s, h->d_Sres, h->fac_ld, h->fac_k, h->d_covmap, n,
+                           h->d_Stmp, h->fac_ld);
+        HIPCHK(hipGetLastError());
+        std::swap(h->d_Sres, h->d_Stmp);
+    } else h->fac_valid = false;
+    HIPCHK(hipStreamSynchronize(s));   // map is a local
+    std::swap(h->d_Pres, h->d_Ptmp);
+    return ORCVIO_OK;
+}
+
 int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h) {
     if (!h || !h->ran) { g_last_error = "cov_commit: no finished update"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->last_stream ? h->last_stream : h->stream;
     const int n = h->n, kf = h->kf;
-    if (h->factor_opt) {   // S+ = sigma Z^T (or the prior's own factor if a gated object update was rejected): read before Pres changes
+    if (h->factor_opt && h->n_nui > 0) h->fac_valid = false;   // Schmidt: the nuisance block of P+ is the prior's, so P+ != s2 Z^T Z
+    if (h->factor_opt && h->n_nui == 0) {   // S+ = sigma Z^T (or the prior's own factor if a gated object update was rejected): read before Pres changes
         const PriorFactor pf = prior_factor(h);
         hipLaunchKernelGGL(k_fac_commit, dim3((kf * n + 255) / 256), dim3(256), 0, s, h->d_Z, h->ldz, kf, n, h->flags.noise_feature,
                            h->last_update_objects ? h->d_obj_accept : (const int*)nullptr, pf.base, pf.sLi, pf.sLj, h->d_Stmp, h->ldz);

@@ -2305,7 +2305,8 @@ struct ObjGate {
 };
 __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, int kdim, double s2,
                                                      double* __restrict__ P_out, double* __restrict__ dx,
-                                                     ObjGate gate = ObjGate(), const double* __restrict__ P = nullptr) {
+                                                     ObjGate gate = ObjGate(), const double* __restrict__ P = nullptr, int keep_tail = 0) {
+    // keep_tail: the trailing keep_tail x keep_tail block of P+ is the prior's (Schmidt nuisance states, src/orcvio.cpp:1740-1751)
     __shared__ double sPart[3][4][64];
     __shared__ double sZZ[4];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -2339,7 +2340,8 @@ __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ 
         const double v = ((acc[r] + sPart[0][r][l]) + sPart[1][r][l]) + sPart[2][r][l];
         const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
         if (i < n && jj < n && jj <= i) {
-            const double pv = app ? s2 * v : 0.5 * (P[(size_t)i * n + jj] + P[(size_t)jj * n + i]);
+            const bool prior = !app || (i >= n - keep_tail && jj >= n - keep_tail);
+            const double pv = prior ? 0.5 * (P[(size_t)i * n + jj] + P[(size_t)jj * n + i]) : s2 * v;
             P_out[(size_t)i * n + jj] = pv;
             P_out[(size_t)jj * n + i] = pv;
         } else if (i == n && jj < n) {

@@ -70,6 +70,12 @@ class Window:
     P: np.ndarray          # [n,n] symmetric
     flags: Flags
     n_extra: int = 0       # state columns behind the clones that no row touches (EKF-SLAM feature states)
+    nui: dict = None       # Schmidt nuisance states (the LAST 6 each of the extra states): their poses, dict(R_b2w [k,3,3], t_b_w,
+                           # t_fej, R_b2c, t_c_b) -- clones that left the window but stay in the covariance (use_schmidt)
+
+    @property
+    def n_nui(self):
+        return 0 if self.nui is None else self.nui['R_b2w'].shape[0]
 
     @property
     def N(self):
@@ -130,6 +136,29 @@ def with_extra_states(win: "Window", k: int, seed: int = 0) -> "Window":
     return dataclasses.replace(win, P=np.ascontiguousarray(0.5 * (P + P.T)), n_extra=k)
 
 
+def with_nuisance_states(win: "Window", n_nui: int, seed: int = 0) -> "Window":
+    """The same window with n_nui Schmidt nuisance states behind everything else (src/orcvio.cpp:2881-2920: clones that left
+    the window but stay in state_cov): 6 n_nui more columns at the END of the extra states, correlated with the rest, and
+    their poses (older than the window: the first clone's pose moved back along the trajectory)."""
+    rng = np.random.default_rng(40_000 + seed)
+    n0 = win.n
+    k = 6 * n_nui
+    n = n0 + k
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    P = 1e-5 * (A @ A.T)
+    P[:n0, :n0] += win.P
+    P[n0:, n0:] += np.diag(np.tile([4e-4] * 3 + [1e-2] * 3, n_nui))
+    zero = np.where(np.diag(win.P) == 0.0)[0]
+    P[zero, :] = 0.0
+    P[:, zero] = 0.0
+    step = win.t_b_w[0] - win.t_b_w[min(1, win.N - 1)]
+    nui = dict(R_b2w=np.ascontiguousarray(np.stack([win.R_b2w[0]] * n_nui)),
+               t_b_w=np.ascontiguousarray(np.stack([win.t_b_w[0] + (j + 1) * step + 0.02 * rng.standard_normal(3) for j in range(n_nui)])),
+               R_b2c=np.ascontiguousarray(np.stack([win.R_b2c[0]] * n_nui)), t_c_b=np.ascontiguousarray(np.stack([win.t_c_b[0]] * n_nui)))
+    nui['t_fej'] = np.ascontiguousarray(nui['t_b_w'] + 0.005 * rng.standard_normal((n_nui, 3)))
+    return dataclasses.replace(win, P=np.ascontiguousarray(0.5 * (P + P.T)), n_extra=win.n_extra + k, nui=nui)
+
+
 @dataclasses.dataclass
 class SlamFeature:
     """One EKF-SLAM feature of the hybrid filter as the reference's Feature holds it (anchor clone, inverse-depth
@@ -145,17 +174,23 @@ class SlamFeature:
     p_fej: np.ndarray = None
 
 
-def make_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_frac: float = 0.0):
+def make_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_frac: float = 0.0, nui_frac: float = 0.0):
     """n_feat SLAM features anchored at random earlier clones and observed by the newest one (+ pixel noise; a
-    fraction with gross errors that the 2-dof gate rejects)."""
+    fraction with gross errors that the 2-dof gate rejects).  nui_frac: fraction anchored at a Schmidt nuisance state
+    (anchor index N + j, win.nui)."""
     rng = np.random.default_rng(20_000 + seed)
     k = win.N - 1
     sig = win.flags.noise_feature
     out = []
     for _ in range(n_feat):
         a = int(rng.integers(0, win.N - 1))
-        R_c2w = win.R_b2w[a] @ win.R_b2c[a].T
-        t_c_w = win.t_b_w[a] + win.R_b2w[a] @ win.t_c_b[a]
+        Ra, ta, Rbc, tcb = win.R_b2w[a], win.t_b_w[a], win.R_b2c[a], win.t_c_b[a]
+        if win.n_nui > 0 and rng.random() < nui_frac:
+            j = int(rng.integers(0, win.n_nui))
+            a = win.N + j
+            Ra, ta, Rbc, tcb = win.nui['R_b2w'][j], win.nui['t_b_w'][j], win.nui['R_b2c'][j], win.nui['t_c_b'][j]
+        R_c2w = Ra @ Rbc.T
+        t_c_w = ta + Ra @ tcb
         pc = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(4.0, 12.0)])
         pw = R_c2w @ pc + t_c_w
         inv = np.array([pc[0] / pc[2], pc[1] / pc[2], 1.0 / pc[2]])

@@ -136,3 +136,36 @@ def test_filter_loop_keeps_the_covariance_on_the_device(upd, prefactor):
         upd.cov_remove_clones(leg, [0])
         P = mc.remove_clones(P, leg, [0])
         assert rel(upd.cov_get(), P) < 1e-6
+
+
+def test_clones_to_nuisance_moves_blocks_and_keeps_the_factor(upd):
+    """orcvio_msckf_cov_clones_to_nuisance: the Schmidt branch of pruneImuStateBuffer (src/orcvio.cpp:2881-2920) on the resident
+    covariance equals the literal restatement; the resident square-root factor is permuted with it, so an update right after
+    (which uses that factor) still equals the oracle on the permuted covariance."""
+    leg = 22
+    w = synth.make_window(N=8, F=40, seed=50, track_len=(3, 8))
+    upd.cov_set(w.P)
+    got = upd.update_features(w, resident_cov=True, want_P=False)
+    upd.cov_commit()                                  # P+ and its factor resident
+    P1 = oracle.msckf_update(w)['P_new']
+    assert rel(got['dx'], oracle.msckf_update(w)['dx']) < 1e-6
+    upd.cov_clones_to_nuisance(leg, [1, 4])
+    P2 = mc.clones_to_nuisance(P1, leg, [1, 4])
+    assert rel(upd.cov_get(), P2) < 1e-9
+    # the window is now 6 clones + 12 nuisance columns; an MSCKF update with the resident prior and its (permuted) factor
+    import dataclasses
+    w2 = synth.make_window(N=6, F=25, seed=51, track_len=(3, 6))
+    w2 = dataclasses.replace(w2, P=np.ascontiguousarray(P2), n_extra=12)
+    upd.set_extra_states(12)
+    upd.set_schmidt_states(2)
+    try:
+        got2 = upd.update_features(w2, resident_cov=True, want_P=True)
+    finally:
+        upd.set_schmidt_states(0)
+        upd.set_extra_states(0)
+    from oracle import mirror
+    ref2 = mirror.msckf_update(w2)     # (the numpy restatement knows about extra states)
+    Pn = ref2['P_new'].copy()
+    Pn[-12:, -12:] = P2[-12:, -12:]
+    assert rel(got2['dx'], ref2['dx']) < 1e-6
+    assert rel(got2['P_new'], Pn) < 1e-6

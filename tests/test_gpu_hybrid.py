@@ -300,3 +300,81 @@ def test_captured_graph_survives_a_reallocation_of_the_ekf_rows():
         assert np.array_equal(got['ekf_accept'], ref2['ekf_accept']) and rel(got['dx'], ref2['dx']) < TOL
     finally:
         u.close()
+
+
+# ---- Schmidt nuisance states (use_schmidt) --------------------------------------------------------------------------------
+@pytest.mark.parametrize('on_device', [False, True], ids=['rows', 'features'])
+@pytest.mark.parametrize('idp', [3, 1])
+def test_schmidt_update_with_nuisance_anchors(upd, idp, on_device):
+    """ORCVIO_OPT_SCHMIDT_STATES: SLAM features anchored at nuisance states (their poses from orcvio_msckf_upload_nuisance_poses,
+    their Jacobian block in the nuisance columns), the nuisance block of the covariance untouched by the update
+    (src/orcvio.cpp:1740-1751, :1893-1902) -- against the restatement of the reference's hybrid update."""
+    w0 = synth.make_window(N=10, F=60, seed=21, track_len=(3, 10), flags=synth.Flags(use_larvio=1, estimate_td=1))
+    nf = 8
+    w = synth.with_nuisance_states(synth.with_extra_states(w0, idp * nf, seed=4), 3, seed=5)
+    slam = synth.make_slam_features(w, nf, seed=6, outlier_frac=0.2, nui_frac=0.5)
+    assert any(ft.anchor >= w.N for ft in slam) and any(ft.anchor < w.N for ft in slam)
+    ref = mh.hybrid_update(w, slam, idp)
+    assert 0 < ref['ekf_accept'].sum()
+    upd.set_extra_states(w.n_extra)
+    upd.set_schmidt_states(w.n_nui)
+    upd.set_ekf_rows_mode(True)
+    try:
+        upd.upload(w)
+        upd.upload_nuisance_poses(w.nui)
+        if on_device:
+            upd.upload_slam_features(idp, slam)
+        else:
+            He, Ha, Hx, Hf, r = compact_rows(w, slam, idp)
+            upd.upload_ekf_rows(idp, [f.anchor for f in slam], [f.state for f in slam], list(range(len(slam))), He, Ha, Hx, Hf, r,
+                                z_vel=np.array([f.z_vel for f in slam]))
+        upd.run_update()
+        upd.sync()
+        got = upd.download()
+        g, a = upd.download_ekf()
+    finally:
+        upd.set_ekf_rows_mode(False)
+        upd.set_schmidt_states(0)
+        upd.set_extra_states(0)
+    assert np.array_equal(a, ref['ekf_accept'])
+    assert rel(g, ref['ekf_gamma']) < 1e-9
+    assert np.array_equal(got['accept'], ref['accept'])
+    assert rel(got['dx'], ref['dx']) < TOL
+    assert rel(got['P_new'], ref['P_new']) < TOL
+    m = 6 * w.n_nui
+    assert np.array_equal(got['P_new'][-m:, -m:], w.P[-m:, -m:])      # the prior's block, bit for bit
+
+
+@pytest.mark.parametrize('idp', [3, 1])
+def test_schmidt_frame_with_entering_features(upd, idp):
+    """The whole Schmidt frame: MSCKF tracks, SLAM features (some anchored at nuisance states), features entering the state --
+    their rows on the device, their states inserted IN FRONT of the nuisance block (:1920-1935, orcvio_msckf_augment_state_nuisance)."""
+    w0 = synth.make_window(N=10, F=60, seed=17, track_len=(3, 10), flags=synth.Flags(use_larvio=1, estimate_td=1))
+    slam = synth.make_slam_features(w0, 7, seed=5, outlier_frac=0.25)
+    w = synth.with_nuisance_states(synth.with_extra_states(w0, idp * len(slam), seed=4), 2, seed=8)
+    slam = synth.make_slam_features(w, 7, seed=5, outlier_frac=0.25, nui_frac=0.4)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 4, seed=9)]
+    ref = mh.hybrid_update_full(w, slam, new, idp)
+    acc = ref['new_accept']
+    assert len(acc) > 0
+    upd.set_extra_states(w.n_extra)
+    upd.set_schmidt_states(w.n_nui)
+    upd.set_ekf_rows_mode(True)
+    try:
+        upd.upload(w)
+        upd.upload_nuisance_poses(w.nui)
+        upd.upload_slam_features(idp, slam)
+        upd.upload_new_features(w, idp, [new[i] for i in acc])
+        upd.run_update()
+        upd.sync()
+        got = upd.download()
+        H_1, H_2, r_1 = upd.download_new_feature_blocks()
+    finally:
+        upd.set_ekf_rows_mode(False)
+        upd.set_schmidt_states(0)
+        upd.set_extra_states(0)
+    assert rel(got['dx'], ref['dx_leg']) < TOL
+    assert rel(got['P_new'], ref['P_upd']) < TOL
+    dx_new, P = capi.augment_state_nuisance(idp, 6 * w.n_nui, H_1, H_2, r_1, w.flags.noise_feature ** 2, got['dx'], got['P_new'])
+    assert rel(np.concatenate([got['dx'], dx_new]), ref['dx']) < TOL
+    assert rel(P, ref['P_new']) < TOL

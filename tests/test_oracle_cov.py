@@ -50,3 +50,18 @@ def test_augment_with_rest_rows_inserts_in_front_of_them():
     T = np.vstack([np.eye(n)[:n - k], J, np.eye(n)[n - k:]])   # old poses, the new clone, then the rest
     assert np.allclose(A, T @ P @ T.T, atol=1e-15)
     assert np.array_equal(mc.augment(P, rest=0), mc.augment(P))
+
+
+def test_clones_to_nuisance_is_a_symmetric_permutation():
+    """The block moves of the Schmidt branch of pruneImuStateBuffer (src/orcvio.cpp:2881-2920), restated literally, are the
+    symmetric permutation that takes the listed clones' blocks to the end in the listed order."""
+    rng = np.random.default_rng(3)
+    leg, N, extra = 22, 6, 9
+    n = leg + 6 * N + extra
+    A = rng.standard_normal((n, n))
+    P = A @ A.T
+    for idx in ([1], [0, 3], [2, 3, 5]):
+        got = mc.clones_to_nuisance(P, leg, idx)
+        moved = [leg + 6 * c + e for c in idx for e in range(6)]
+        order = [i for i in range(n) if i not in moved] + moved
+        assert np.array_equal(got, P[np.ix_(order, order)])

@@ -160,3 +160,69 @@ def test_library_host_arithmetic_for_entering_features(built, idp):
     dx_new, P_aug = capi.augment_state(idp, gH_1, gH_2, gr_1, w.flags.noise_feature ** 2, ref['dx_leg'], ref['P_upd'])
     assert rel(np.concatenate([ref['dx_leg'], dx_new]), ref['dx']) < 1e-9
     assert rel(P_aug, ref['P_new']) < 1e-9
+
+
+# ---- Schmidt nuisance states (use_schmidt) --------------------------------------------------------------------------------
+def test_nuisance_anchor_rows_against_central_differences():
+    """A SLAM feature anchored at a Schmidt nuisance state (anchor index N + j): the same four blocks with the nuisance pose
+    as anchor pose (src/orcvio.cpp:1247-1256); H_a lands in the state's columns of the nuisance block (:1591-1606)."""
+    w0 = synth.make_window(N=6, F=2, seed=3, track_len=6, flags=synth.Flags(use_larvio=1))
+    w = synth.with_nuisance_states(synth.with_extra_states(w0, 3 * 4, seed=1), 2, seed=2)
+    slam = synth.make_slam_features(w, 6, seed=4, nui_frac=1.0)
+    assert all(ft.anchor >= w.N for ft in slam)
+    eps = 1e-6
+    for idx, ft in enumerate(slam[:4]):
+        j = ft.anchor - w.N
+        Ra, ta = w.nui['R_b2w'][j], w.nui['t_b_w'][j]
+        R_c2w = Ra @ w.R_b2c[0].T
+        t_c_w = ta + Ra @ w.t_c_b[0]
+        pc = np.array([ft.inv_param[0] / ft.inv_param[2], ft.inv_param[1] / ft.inv_param[2], 1 / ft.inv_param[2]])
+        ft = dataclasses.replace(ft, p_w=R_c2w @ pc + t_c_w)
+        H_f, H_a, H_x, H_e, r = mh.measurement_jacobian_ekf(w, ft, 3)
+
+        def project(d_anchor):
+            Rad = mirror.so3_exp(d_anchor[:3]) @ Ra
+            p_w = Rad @ (w.R_b2c[0].T @ pc + w.t_c_b[0]) + ta + d_anchor[3:]
+            k = ft.state
+            q = w.R_b2c[k] @ (w.R_b2w[k].T @ (p_w - w.t_b_w[k]) - w.t_c_b[k])
+            return q[:2] / q[2]
+        num = np.zeros((2, 6))
+        for c in range(6):
+            d = np.zeros(6)
+            d[c] = eps
+            num[:, c] = (project(d) - project(-d)) / (2 * eps)
+        assert np.allclose(H_a, num, atol=5e-8)
+        H, _ = mh.feature_jacobian_ekf(w, ft, idx, 3)
+        c0 = w.n - 6 * w.n_nui + 6 * j
+        assert np.array_equal(H[:, c0:c0 + 6], H_a)
+        assert np.count_nonzero(H[:, w.flags.leg_dim: w.flags.leg_dim + 6 * (w.N - 1)]) == 0   # no window clone but the observing one
+
+
+def test_schmidt_update_keeps_the_nuisance_block_and_inserts_new_states_in_front_of_it():
+    """:1740-1751 / :1893-1935: the nuisance block of the covariance survives the update unchanged, everything else is
+    (I - K H) P; new feature states go in front of the nuisance rows, i.e. the augmented covariance is the no-Schmidt one
+    with the nuisance rows / columns moved behind the new states."""
+    w0 = synth.make_window(N=8, F=30, seed=11, track_len=(3, 8), flags=synth.Flags(use_larvio=1))
+    slam = synth.make_slam_features(w0, 5, seed=2)
+    w1 = synth.with_extra_states(w0, 3 * len(slam), seed=3)
+    w = synth.with_nuisance_states(w1, 2, seed=4)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 3, seed=6)]
+    got = mh.hybrid_update_full(w, slam, new, 3)
+    m = 12
+    n = w.n
+    sz = 3 * len(got['new_accept'])
+    assert sz > 0
+    assert np.array_equal(got['P_upd'][-m:, -m:], w.P[-m:, -m:])
+    plain = mh.hybrid_update_full(dataclasses.replace(w, nui=None), slam, new, 3)      # same numbers, no Schmidt treatment
+    assert rel(got['P_upd'][:n - m, :], plain['P_upd'][:n - m, :]) < 1e-12
+    order = list(range(n - m)) + list(range(n, n + sz)) + list(range(n - m, n))
+    # (the plain augmentation starts from the plain P_upd: compare against the one built from the Schmidt P_upd)
+    dx_ref, P_ref = mh.augment_after_update(got['P_upd'], got['dx_leg'], *_blocks(w, new, got), w.flags.noise_feature ** 2)
+    assert rel(got['P_new'], P_ref[np.ix_(order, order)]) < 1e-12
+    assert rel(got['dx'], dx_ref) < 1e-12
+
+
+def _blocks(w, new, got):
+    acc, H_top, r_top, H_1, H_2, r_1 = mh.split_new_rows(w, new, 3)
+    assert acc == got['new_accept']
+    return H_1, H_2, r_1
