@@ -552,6 +552,12 @@ int32_t orcvio_msckf_cov_augment(orcvio_msckf_handle* h);
 int32_t orcvio_msckf_cov_remove_clones(orcvio_msckf_handle* h, int32_t leg_dim, const int32_t* clone_indices, int32_t count);
 int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h);
 int32_t orcvio_msckf_cov_prefactor(orcvio_msckf_handle* h);
+/* The tail of measurementUpdate_hybrid on the device (src/orcvio.cpp:1818-1821, :1904-1947; with ORCVIO_OPT_SCHMIDT_STATES :1920-1935):
+ * after an update that carried entering features (orcvio_msckf_upload_new_features) the resident covariance becomes the augmented
+ * one -- P+ with the d k new feature states behind it (in front of the nuisance block) -- computed from H_1, H_2, r_1 still on the
+ * device; dx_new [d k] is returned.  Instead of orcvio_msckf_cov_commit for such an update.  The caller raises
+ * ORCVIO_OPT_EXTRA_STATES by d k before its next upload. */
+int32_t orcvio_msckf_cov_commit_new_features(orcvio_msckf_handle* h, double* dx_new);
 /* Schmidt branch of pruneImuStateBuffer (src/orcvio.cpp:2881-2920): the listed clones (window ranks before the call, ascending)
  * leave the window but stay in the resident covariance as nuisance states -- their blocks move to the end, in the listed order. */
 int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_dim, const int32_t* clone_indices, int32_t count);

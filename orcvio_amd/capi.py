@@ -34,7 +34,7 @@ EXPORTS = [
     'orcvio_msckf_triangulate_uploaded', 'orcvio_msckf_objects_local', 'orcvio_msckf_objects_finish',
     'orcvio_msckf_objects_download', 'orcvio_msckf_cov_set', 'orcvio_msckf_cov_get', 'orcvio_msckf_cov_propagate',
     'orcvio_msckf_cov_augment', 'orcvio_msckf_cov_remove_clones', 'orcvio_msckf_cov_commit', 'orcvio_msckf_cov_prefactor', 'orcvio_msckf_upload_new_features', 'orcvio_msckf_download_new_feature_blocks', 'orcvio_msckf_upload_nuisance_poses',
-    'orcvio_msckf_augment_state_nuisance', 'orcvio_msckf_cov_clones_to_nuisance',
+    'orcvio_msckf_augment_state_nuisance', 'orcvio_msckf_cov_clones_to_nuisance', 'orcvio_msckf_cov_commit_new_features',
     'orcvio_msckf_update_object_tracks', 'orcvio_msckf_objects_local_tracks',
     'orcvio_msckf_upload_ekf_rows', 'orcvio_msckf_download_ekf', 'orcvio_msckf_upload_slam_features', 'orcvio_msckf_upload_dense_rows', 'orcvio_msckf_augment_new_features', 'orcvio_msckf_gate_tracks', 'orcvio_msckf_new_feature_rows', 'orcvio_msckf_augment_state',
     'orcvio_msckf_profile_stages', 'orcvio_msckf_update_object_lm_msgs',
@@ -755,6 +755,14 @@ class MsckfUpdater:
         arrs = [np.ascontiguousarray(nui[k], dtype=np.float64) for k in ('R_b2w', 't_b_w', 't_fej', 'R_b2c', 't_c_b')]
         wn = MsckfWindow(arrs[0].shape[0], *[_d(a) for a in arrs])
         self._chk(self.lib.orcvio_msckf_upload_nuisance_poses(self.h, C.byref(wn)), 'orcvio_msckf_upload_nuisance_poses')
+
+    def cov_commit_new_features(self):
+        """After an update with upload_new_features: the resident covariance becomes the augmented one; returns dx_new."""
+        k, d, _ = self._new
+        dx_new = np.zeros(d * k)
+        self.lib.orcvio_msckf_cov_commit_new_features.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._chk(self.lib.orcvio_msckf_cov_commit_new_features(self.h, _d(dx_new)), 'orcvio_msckf_cov_commit_new_features')
+        return dx_new
 
     def cov_prefactor(self):
         """Factor the resident covariance now (asynchronously): the next update finds its prior's square-root factor resident."""

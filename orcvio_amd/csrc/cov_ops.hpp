@@ -100,4 +100,73 @@ __global__ __launch_bounds__(256) void k_fac_remove(const double* __restrict__ F
     out[(size_t)i * ldo + j] = F[(size_t)i * ld + map[j]];
 }
 
+
+// ---- features entering the state, on the resident covariance: the tail of measurementUpdate_hybrid (src/orcvio.cpp:1818-1821,
+//      :1904-1947) from the blocks k_ekf_new left on the device -------------------------------------------------------------
+// HH = H_2^-1 H_1 (block back-substitution, H_2 upper triangular d x d per feature), column n: x = H_2^-1 r_1;
+// W[j] = (H_2^T H_2)^-1 = R^-1 R^-T.  One thread per (feature, column).
+__global__ __launch_bounds__(256) void k_aug_hh(const double* __restrict__ H1, const double* __restrict__ H2, const double* __restrict__ r1,
+                                                int n, int n_new, int d, double* __restrict__ HH /* [d n_new][n + 1] */,
+                                                double* __restrict__ W /* [n_new][d][d] */, int* __restrict__ singular) {
+    const int j = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_new || c > n) return;
+    const double* R = H2 + (size_t)j * d * d;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int i = d - 1; i >= 0; --i) {
+        double m = c < n ? H1[(size_t)(d * j + i) * n + c] : r1[d * j + i];
+        for (int k = i + 1; k < d; ++k) m -= R[i * d + k] * v[k];
+        v[i] = m / R[i * d + i];
+        HH[(size_t)(d * j + i) * (n + 1) + c] = v[i];
+    }
+    if (c == 0) {
+        double Ri[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bool bad = false;
+        for (int i = 0; i < d; ++i) bad = bad || R[i * d + i] == 0.0;
+        if (bad) *singular = 1;
+        for (int cc = 0; cc < d; ++cc)
+            for (int i = d - 1; i >= 0; --i) {
+                double m = i == cc ? 1.0 : 0.0;
+                for (int k = i + 1; k < d; ++k) m -= R[i * d + k] * Ri[k * d + cc];
+                Ri[i * d + cc] = m / R[i * d + i];
+            }
+        for (int i = 0; i < d; ++i)
+            for (int cc = 0; cc < d; ++cc) {
+                double m = 0.0;
+                for (int k = 0; k < d; ++k) m += Ri[i * d + k] * Ri[cc * d + k];
+                W[(size_t)j * d * d + i * d + cc] = m;
+            }
+    }
+}
+// dx_new[r] = x[r] - HH[r][:] dx: one wavefront per row
+__global__ __launch_bounds__(64) void k_aug_dx(const double* __restrict__ HH, int n, const double* __restrict__ dx, double* __restrict__ dx_new) {
+    const int r = blockIdx.x;
+    const double* row = HH + (size_t)r * (n + 1);
+    double s = 0.0;
+    for (int c = threadIdx.x; c < n; c += 64) s += row[c] * dx[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) dx_new[r] = row[n] - s;
+}
+// P_aug [(n + sz)^2] in the order [old (n - tail) | new (sz) | tail]: P+ , nHHP = -HH P+ (sz x n), Q = nHHP HH^T (sz x sz, so that
+// P22 = -Q + s2 W), symmetrised as :1946 does
+__global__ __launch_bounds__(256) void k_aug_assemble(const double* __restrict__ Pp, int n, int sz, int tail, int d, const double* __restrict__ nHHP,
+                                                      const double* __restrict__ Q, const double* __restrict__ W, double s2,
+                                                      double* __restrict__ out) {
+    const int nt = n + sz, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nt * nt) return;
+    const int i = idx / nt, j = idx - i * nt, n0 = n - tail;
+    auto src = [&](int q) { return q < n0 ? q : (q < n0 + sz ? n + (q - n0) : q - sz); };   // index in the [old + tail | new] order
+    const int a = src(i), b = src(j);
+    double v;
+    if (a < n && b < n) v = 0.5 * (Pp[(size_t)a * n + b] + Pp[(size_t)b * n + a]);
+    else if (a >= n && b < n) v = nHHP[(size_t)(a - n) * n + b];
+    else if (a < n && b >= n) v = nHHP[(size_t)(b - n) * n + a];
+    else {
+        const int r = a - n, c = b - n;
+        double p = -0.5 * (Q[(size_t)r * sz + c] + Q[(size_t)c * sz + r]);
+        if (r / d == c / d) p += 0.5 * s2 * (W[(size_t)(r / d) * d * d + (r % d) * d + (c % d)] + W[(size_t)(r / d) * d * d + (c % d) * d + (r % d)]);
+        v = p;
+    }
+    out[idx] = v;
+}
+
 }  // namespace orcvio_amd

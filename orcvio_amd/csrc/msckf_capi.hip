@@ -122,6 +122,7 @@ struct orcvio_msckf_handle {
     double* d_dense = nullptr;          // [dense_cap][NAP_max]
     bool ekf_eval = false;              // the four blocks are evaluated on the device from the SLAM features (k_ekf_eval)
     double* d_slam = nullptr;           // [12 cap] param 3 | inv_depth 1 | p_w 3 | p_fej 3 | z 2
+    char* d_aug = nullptr; size_t aug_cap = 0;   // scratch of orcvio_msckf_cov_commit_new_features
     char* d_new = nullptr; size_t new_cap = 0, new_out_off = 0;   // entering features (orcvio_msckf_upload_new_features): inputs, then H_1 | H_2 | r_1
     int new_F = 0, new_idp = 3;
     double* d_Rf = nullptr;             // [maxF][6] R factor of every track's H_f (k_feature), for orcvio_msckf_augment_new_features
@@ -317,7 +318,7 @@ static void free_all(orcvio_msckf_handle* h) {
                     h->d_W, h->d_Y, h->d_KG, h->d_Gobj, h->d_RF, h->d_DinvF, h->d_Yobj, h->d_objH,
                     h->d_obj_gamma, h->d_obj_i, h->d_obj_accept, h->d_T3, h->d_Xobs, h->d_S,
                     h->d_Pres, h->d_Ptmp, h->d_Sres, h->d_Stmp, h->d_covT, h->d_covmap, h->d_skip, h->d_tri_valid, h->d_tri_flags, h->d_tri_init, h->d_tri_sol, h->d_tri_cost, h->d_sync,
-                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense, h->d_Rf, h->d_new};
+                    h->d_ekf_i, h->d_ekf_d, h->d_ekf_E, h->d_Gekf, h->d_ekf_gamma, h->d_ekf_accept, h->d_slam, h->d_dense, h->d_Rf, h->d_new, h->d_aug};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -3130,6 +3131,55 @@ int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h) {
     HIPCHK(hipMemcpyAsync(h->d_Pres, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
     if (s != h->stream) HIPCHK(hipStreamSynchronize(s));   // the other cov_* calls run on the handle's own stream
     h->res_n = n;
+    return ORCVIO_OK;
+}
+
+// The tail of measurementUpdate_hybrid on the device (src/orcvio.cpp:1818-1821, :1904-1947): after an update that carried entering
+// features (orcvio_msckf_upload_new_features), the resident covariance becomes the AUGMENTED one -- P+ of the update with the d k
+// new feature states behind it (in front of the nuisance block under ORCVIO_OPT_SCHMIDT_STATES, :1920-1935) -- from the blocks
+// H_1, H_2, r_1 that are still on the device; dx_new [d k] comes back.  Replaces cov_commit + cov_get + augment_state + cov_set for a
+// caller that keeps the covariance in HBM.  The caller raises ORCVIO_OPT_EXTRA_STATES by d k for its next upload.
+int32_t orcvio_msckf_cov_commit_new_features(orcvio_msckf_handle* h, double* dx_new) {
+    if (!h || !h->ran || h->new_F <= 0 || !dx_new) { g_last_error = "cov_commit_new_features: no finished update with entering features"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->n, k = h->new_F, d = h->new_idp, sz = d * k, nt = n + sz, tail = 6 * h->n_nui;
+    if (nt > h->n_max) { g_last_error = "cov_commit_new_features: the augmented state exceeds the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
+    hipStream_t s = h->last_stream ? h->last_stream : h->stream;
+    // scratch behind the blocks: HH [sz][n + 1] | W [k][d][d] | nHHP [sz][n] | Q [sz][sz] | dx_new [sz] | flag
+    const size_t need = ((size_t)sz * (n + 1) + (size_t)k * d * d + (size_t)sz * n + (size_t)sz * sz + sz + 2) * sizeof(double);
+    if (need > h->aug_cap) {
+        HIPCHK(hipDeviceSynchronize());
+        if (h->d_aug) (void)hipFree(h->d_aug);
+        HIPCHK(hipMalloc(&h->d_aug, need * 2));
+        h->aug_cap = need * 2;
+    }
+    double* HH = reinterpret_cast<double*>(h->d_aug);
+    double* W = HH + (size_t)sz * (n + 1);
+    double* nHHP = W + (size_t)k * d * d;
+    double* Q = nHHP + (size_t)sz * n;
+    double* dxn = Q + (size_t)sz * sz;
+    int* flag = reinterpret_cast<int*>(dxn + sz);
+    const double* dout = reinterpret_cast<const double*>(h->d_new + h->new_out_off);
+    const double* H1 = dout; const double* H2 = dout + (size_t)sz * n; const double* r1 = H2 + (size_t)k * d * d;
+    const double s2 = h->flags.noise_feature * h->flags.noise_feature;
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_aug_hh, dim3((n + 1 + 255) / 256, k), dim3(256), 0, s, H1, H2, r1, n, k, d, HH, W, flag);
+    hipLaunchKernelGGL(k_aug_dx, dim3(sz), dim3(64), 0, s, (const double*)HH, n, (const double*)h->d_dx, dxn);
+    int rc = launch_gemm(s, HH, (long)(n + 1), 1L, h->d_Pout, (long)n, 1L, sz, n, n, -1.0, 0.0, 0, nHHP, (long)n, 1L);                 // nHHP = -HH P+
+    if (rc == ORCVIO_OK) rc = launch_gemm(s, nHHP, (long)n, 1L, HH, 1L, (long)(n + 1), sz, sz, n, 1.0, 0.0, 0, Q, (long)sz, 1L);       // Q = nHHP HH^T
+    if (rc != ORCVIO_OK) return rc;
+    hipLaunchKernelGGL(k_aug_assemble, dim3((nt * nt + 255) / 256), dim3(256), 0, s, (const double*)h->d_Pout, n, sz, tail, d, (const double*)nHHP,
+                       (const double*)Q, (const double*)W, s2, h->d_Ptmp);
+    HIPCHK(hipGetLastError());
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(dx_new, dxn, sizeof(double) * sz, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (bad) { g_last_error = "cov_commit_new_features: singular H_2"; return ORCVIO_ERR_NOT_SPD; }
+    std::swap(h->d_Pres, h->d_Ptmp);
+    h->res_n = nt;
+    h->fac_valid = false;   // (the factor of the augmented covariance would have d k more columns: not kept)
+    h->new_F = 0;
     return ORCVIO_OK;
 }
 

@@ -378,3 +378,41 @@ def test_schmidt_frame_with_entering_features(upd, idp):
     dx_new, P = capi.augment_state_nuisance(idp, 6 * w.n_nui, H_1, H_2, r_1, w.flags.noise_feature ** 2, got['dx'], got['P_new'])
     assert rel(np.concatenate([got['dx'], dx_new]), ref['dx']) < TOL
     assert rel(P, ref['P_new']) < TOL
+
+
+@pytest.mark.parametrize('nui', [0, 2], ids=['plain', 'schmidt'])
+@pytest.mark.parametrize('idp', [3, 1])
+def test_entering_features_with_the_covariance_resident(upd, idp, nui):
+    """orcvio_msckf_cov_commit_new_features: the covariance never leaves the device in a frame in which features enter the state --
+    prior = resident covariance, rows of the entering features and the joint update on the device, the H_1 / H_2 tail
+    (src/orcvio.cpp:1818-1821, :1904-1947; :1920-1935 with nuisance states) on the device too; tracks in, dx and dx_new out."""
+    w0 = synth.make_window(N=10, F=60, seed=17, track_len=(3, 10), flags=synth.Flags(use_larvio=1, estimate_td=1))
+    slam = synth.make_slam_features(w0, 7, seed=5, outlier_frac=0.25)
+    w = synth.with_extra_states(w0, idp * len(slam), seed=4)
+    if nui:
+        w = synth.with_nuisance_states(w, nui, seed=8)
+        slam = synth.make_slam_features(w, 7, seed=5, outlier_frac=0.25, nui_frac=0.4)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 4, seed=9)]
+    ref = mh.hybrid_update_full(w, slam, new, idp)
+    acc = ref['new_accept']
+    assert len(acc) > 0
+    upd.cov_set(w.P)
+    upd.set_extra_states(w.n_extra)
+    upd.set_schmidt_states(w.n_nui)
+    upd.set_ekf_rows_mode(True)
+    try:
+        upd.upload(w, resident_cov=True)
+        if nui:
+            upd.upload_nuisance_poses(w.nui)
+        upd.upload_slam_features(idp, slam)
+        upd.upload_new_features(w, idp, [new[i] for i in acc])
+        upd.run_update()
+        upd.sync()
+        got = upd.download()
+        dx_new = upd.cov_commit_new_features()
+    finally:
+        upd.set_ekf_rows_mode(False)
+        upd.set_schmidt_states(0)
+        upd.set_extra_states(0)
+    assert rel(np.concatenate([got['dx'], dx_new]), ref['dx']) < TOL
+    assert rel(upd.cov_get(), ref['P_new']) < TOL
