@@ -151,11 +151,12 @@ def main():
         else:
             upd.run_update_sharded(stream)   # local tracks + compression -> RCCL all-gather -> sum + replicated solve
 
+    gc.collect()
+    gc.disable()   # the timed region is a few ms: an interpreter collection in the middle of it would be most of it (and one
+                   # between warm-up and timing would let the GPU clock down again)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    gc.collect()
-    gc.disable()   # the timed region is tens of ms: an interpreter collection in the middle of it would be most of it
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()

@@ -1285,7 +1285,7 @@ int32_t orcvio_msckf_upload_new_features(orcvio_msckf_handle* h, const orcvio_ms
     if (h->n_extra > 0 && !h->ekf_mode) { g_last_error = "upload_new_features: with extra states set ORCVIO_OPT_EKF_ROWS before the upload"; return ORCVIO_ERR_INVALID; }
     const int k = nf->n_features, d = nf->idp_dim, N = h->N;
     if (k < 0 || (d != 1 && d != 3)) { g_last_error = "upload_new_features: idp_dim must be 1 or 3"; return ORCVIO_ERR_INVALID; }
-    h->new_F = 0;
+    if (h->new_F > 0) { g_last_error = "upload_new_features: already called for this upload (list all entering features in one call)"; return ORCVIO_ERR_INVALID; }
     if (k == 0) return ORCVIO_OK;
     if (!nf->anchor || !nf->param || !nf->p_w || !nf->obs_ptr || !nf->obs_clone || !nf->obs_z || (d == 1 && !nf->inv_depth) ||
         (h->flags.if_fej && !nf->p_fej) || (h->flags.estimate_td && !nf->obs_zvel)) { g_last_error = "upload_new_features: null array"; return ORCVIO_ERR_INVALID; }
