@@ -264,15 +264,16 @@ __host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
     const int R2 = 2 * Mmax;
     size_t dbl = (size_t)R2 * 7 + (size_t)R2 * 6 + R2 + (size_t)R2 * 4 + 64 * 4 + 16 + 4 + 8 * (size_t)NAP + 272 + 272 +
                  (size_t)R2 * feat_lde(Mmax);
-    size_t bytes = dbl * 8 + (size_t)(N + Mmax + 4) * 4;
+    size_t bytes = dbl * 8 + (size_t)(N + Mmax + 4 + Mmax) * 4;   // (... | sC2O N | sOC Mmax | sFlag 4 | sDone Mmax)
     return (bytes + 15) & ~(size_t)15;
 }
 
 // One workgroup of four wavefronts per feature track.
 //   B, C  (wave 0)   per-observation Jacobians, Householder QR of H_f (LAPACK dgeqr2 convention)
 //   D     (all)      compact-WY coefficients of Q^T [J | r] for the column each thread owns (needed for T3)
-//   E     (4 waves)  E = J P J^T, observation l on wave l % 4: u_l = J_l P_aa from coalesced P rows (prefetched one
-//                    observation ahead), E[:, 2l..2l+1] = J u_l^T with the rows of the block in lanes
+//   E     (waves 1-3) E = J P J^T, observations handed out in order through an LDS counter: u_l = J_l P_aa from coalesced P rows
+//                    (prefetched one observation ahead), E[:, 2l..2l+1] = J u_l^T with the rows of the block in lanes; a flag
+//                    per finished observation
 //   G     (wave 0)   the chi-square gate WITHOUT forming the projected block: with Sh = E + s2 I (2M x 2M), Q1 the
 //                    first three columns of Q (range of H_f) and N0 the rest,
 //                        gamma = r'^T (N0^T Sh N0)^-1 r' = || (I - Pi) L^-1 r ||^2,   Sh = L L^T,
@@ -280,10 +281,12 @@ __host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
 //                    N0 (N0^T Sh N0)^-1 N0^T = Sh^-1 - Sh^-1 Q1 (Q1^T Sh^-1 Q1)^-1 Q1^T Sh^-1).  Sh is factored as
 //                    16x16 MFMA tiles held in registers (DPP diagonal sweep of the Cholesky kernels, panel and
 //                    trailing tiles by MFMA on accumulator-layout operands), the four right-hand sides
-//                    [r | Q1] ride along as one more tile column, the projection is modified Gram-Schmidt.
+//                    [r | Q1] ride along as one more tile column, the projection is modified Gram-Schmidt.  The
+//                    factorisation is LEFT-looking, one block column (eight observations) at a time, and starts on a block
+//                    column as soon as its observations are flagged: it runs under phase E, one block column behind.
 //   I     (all)      outputs: T3 (three dense rows), the un-projected sparse rows Xobs, optionally H'.
 // feature_body: track j on the 256 threads `tid` = 0..255 of one four-wavefront team with its own LDS block; the
-// team is a whole workgroup (k_feature) or half of one (k_front).  Its four workgroup barriers are unconditional for a
+// team is a whole workgroup (k_feature) or half of one (k_front).  Its three workgroup barriers are unconditional for a
 // live track, so two teams of one workgroup stay in step.
 template <int NPASS, bool PAD_BARRIERS = false>
 __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, const int tid, double* __restrict__ smem) {
@@ -299,8 +302,8 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
             const size_t r0 = (size_t)p.row_ptr[j], r1 = (size_t)p.row_ptr[j + 1];
             for (size_t e = r0 * p.NAP + tid; e < r1 * p.NAP; e += 256) p.Hs[e] = 0.0;
         }
-        if (PAD_BARRIERS) {   // the other team of the workgroup runs a live track: keep its four barriers company
-            __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+        if (PAD_BARRIERS) {   // the other team of the workgroup runs a live track: keep its three barriers company
+            __syncthreads(); __syncthreads(); __syncthreads();
         }
         return;
     }
@@ -323,10 +326,12 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
     double* sE = sDi + 272;           // [R2][LDE]
     int* sC2O = (int*)(sE + (size_t)R2 * LDE);   // [N]
     int* sOC = sC2O + p.N;                        // [Mmax]
-    int* sFlag = sOC + p.Mmax;                    // [4]  [0] gate verdict, [1] next observation of phase E
+    int* sFlag = sOC + p.Mmax;                    // [4]  [0] gate verdict, [1] next observation of phase E, [2] QR (phase C) done
+    int* sDone = sFlag + 4;                       // [Mmax] observation l of phase E is in sE
 
     for (int i = tid; i < p.N; i += 256) sC2O[i] = -1;
-    if (tid == 0) sFlag[1] = 0;
+    for (int i = tid; i < p.Mmax; i += 256) sDone[i] = 0;
+    if (tid == 0) { sFlag[1] = 0; sFlag[2] = 0; }
     __syncthreads();
 
     // ---- B: per-observation Jacobians (wave 0, lane t <-> observation t) -----------------
@@ -421,11 +426,14 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
 #pragma unroll
             for (int q = 0; q < 4; ++q) sB[t * 4 + q] = b4[q];
         }
+        wave_sync();
+        if (t == 0) __hip_atomic_store(&sFlag[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // sV, sQ, sB are final (phase D reads them)
     }
 
-    // ---- E: E = J P_aa J^T.  Observations are handed out through an LDS counter (wave 0 joins when its QR is done);
-    //         every wave keeps one observation in hand and the P rows of the next one in flight -----------------
-    {
+    // ---- E: E = J P_aa J^T (waves 1..3; wave 0 factors the block columns of E + s2 I as they complete, phase G).
+    //         Observations are handed out IN ORDER through an LDS counter; every wave keeps one observation in hand and
+    //         the P rows of the next one in flight, and flags each finished observation -----------------
+    if (wave > 0) {
         double* sU = sUall + (size_t)wave * 2 * NAP;
         // row-lane data: lane t <-> row t of the 2M-row block
         const bool rowlane = t < M2;
@@ -515,14 +523,17 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                 sE[t * LDE + 2 * l + 1] = e1;
             }
             wave_sync();
+            if (t == 0) __hip_atomic_store(&sDone[l], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS writes of one wave are in order)
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) pcur[ps][c] = pnxt[ps][c];
             l = lnext;
         }
+        if (lend == 0 && wave == 1 && t < M) __hip_atomic_store(&sDone[t], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (diagnostic: phase E ablated)
+        // phase D needs the reflectors of phase C (wave 0 finished them long ago: E is several times longer)
+        while (__hip_atomic_load(&sFlag[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
     }
-    __syncthreads();
 
     // ---- D (waves 1..3, while wave 0 runs the gate): compact-WY coefficients y_q[a] of Q^T [J | r] for the
     //      columns a = (tid - 64) + 192 ps this thread owns; only the outputs need them
@@ -563,6 +574,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
         const int kk = t >> 4, cc = t & 15;
         const int nbk = (M2 + 15) >> 4;
         d4 S[4][4], Bt[4];
+        double li[4][4];   // inv(L11) of every block step, MFMA A operand
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -571,24 +583,50 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                 Bt[a][r] = (i < M2 && cc < 4) ? sB[i * 4 + (cc & 3)] : 0.0;
             }
 #pragma unroll
-            for (int b = a; b < 4; ++b) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * a + kk + 4 * r, c = 16 * b + cc;
-                    const bool in = i < M2 && c < M2;
-                    const double ev = sE[(in ? i : 0) * LDE + (in ? c : 0)];
-                    S[a][b][r] = in ? (ev + ((i == c) ? p.sigma2 : 0.0)) : 0.0;
-                }
-            }
+            for (int q = 0; q < 4; ++q) li[a][q] = 0.0;
         }
         int nzero = 0, nneg = 0;
         if (!(p.ablate & 4)) {
+            // Left-looking by block column b of the upper factor (Sh = R^T R, tiles S[a][b], a <= b): the column is read when
+            // its eight observations are flagged, brought up to date against the finished block rows k < b, its diagonal tile
+            // factored + inverted in one DPP sweep; the right-hand sides follow one block row behind.
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < nbk) {
+            for (int b = 0; b < 4; ++b) {
+                if (b < nbk) {
+                    {   // observations 8b .. 8b+7 (those that exist) are in sE
+                        const int lw = 8 * b + (t & 7);
+                        bool done = lw >= M;
+                        while (true) {
+                            if (!done) done = __hip_atomic_load(&sDone[lw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+                            if (__all(done)) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a <= b; ++a) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * a + kk + 4 * r, c = 16 * b + cc;
+                            const bool in = i < M2 && c < M2;
+                            const double ev = sE[(in ? i : 0) * LDE + (in ? c : 0)];
+                            S[a][b][r] = in ? (ev + ((i == c) ? p.sigma2 : 0.0)) : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < b; ++k) {
+                        d4 x = {0, 0, 0, 0};   // row block k of the factor, block column b: inv(L11_k) * (tile, up to date)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[k][s4], S[k][b][s4], x);
+                        S[k][b] = x;
+#pragma unroll
+                        for (int a = k + 1; a <= b; ++a) {
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) S[a][b] = mfma_f64(-S[k][a][s4], S[k][b][s4], S[a][b]);
+                        }
+                    }
                     // diagonal tile: accumulator layout -> rows in lanes, factor + invert in one DPP sweep
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sD[(kk + 4 * r) * 17 + cc] = S[k][k][r];
+                    for (int r = 0; r < 4; ++r) sD[(kk + 4 * r) * 17 + cc] = S[b][b][r];
                     wave_sync();
                     double v[16], y[16];
 #pragma unroll
@@ -597,46 +635,26 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                         v[c] = (c <= cc) ? av : 0.0;
                         y[c] = (c == cc) ? 1.0 : 0.0;
                     }
-                    DiagStep<0>::run(v, y, 0.0, M2 - 16 * k, nzero, nneg);
+                    DiagStep<0>::run(v, y, 0.0, M2 - 16 * b, nzero, nneg);
                     if (t < 16) {
 #pragma unroll
                         for (int c = 0; c < 16; ++c) sDi[c * 17 + t] = y[c];   // Linv[c][t]
                     }
                     wave_sync();
-                    double li[4];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) li[s4] = sDi[cc * 17 + kk + 4 * s4];
+                    for (int s4 = 0; s4 < 4; ++s4) li[b][s4] = sDi[cc * 17 + kk + 4 * s4];
                     wave_sync();
-                    // panel: row block k of the factor (transposed) and of the right-hand sides
+                    // right-hand sides, block row b (off the critical path of the next block column)
 #pragma unroll
-                    for (int b = k + 1; b < 4; ++b) {
-                        if (b < nbk) {
-                            d4 x = {0, 0, 0, 0};
+                    for (int k = 0; k < b; ++k) {
 #pragma unroll
-                            for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], S[k][b][s4], x);
-                            S[k][b] = x;
-                        }
+                        for (int s4 = 0; s4 < 4; ++s4) Bt[b] = mfma_f64(-S[k][b][s4], Bt[k][s4], Bt[b]);
                     }
                     {
                         d4 x = {0, 0, 0, 0};
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[s4], Bt[k][s4], x);
-                        Bt[k] = x;
-                    }
-                    // trailing tiles
-#pragma unroll
-                    for (int a = k + 1; a < 4; ++a) {
-                        if (a < nbk) {
-#pragma unroll
-                            for (int b = a; b < 4; ++b) {
-                                if (b < nbk) {
-#pragma unroll
-                                    for (int s4 = 0; s4 < 4; ++s4) S[a][b] = mfma_f64(-S[k][a][s4], S[k][b][s4], S[a][b]);
-                                }
-                            }
-#pragma unroll
-                            for (int s4 = 0; s4 < 4; ++s4) Bt[a] = mfma_f64(-S[k][a][s4], Bt[k][s4], Bt[a]);
-                        }
+                        for (int s4 = 0; s4 < 4; ++s4) x = mfma_f64(li[b][s4], Bt[b][s4], x);
+                        Bt[b] = x;
                     }
                 }
             }
@@ -1774,7 +1792,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     if (j < p.F) {
         feature_body<NPASS, true>(p, j, team ? ((local + 128) & 255) : local, smem + (size_t)team * team_doubles);
     } else {   // (an odd track count: the last workgroup has one team)
-        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+        __syncthreads(); __syncthreads(); __syncthreads();
     }
     if (!g.enabled) return;
     const int nfb = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
