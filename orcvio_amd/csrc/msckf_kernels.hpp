@@ -709,38 +709,66 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
             sFlag[0] = ok ? 1 : 0;
         }
     }
-    __syncthreads();
-    const bool ok = sFlag[0] != 0;
-
     // ---- I: outputs -------------------------------------------------------------------------
     // The compression needs only  H'^T H' = X^T X - T3^T T3  (X = [J | r] un-projected, T3 = rows 0..2 of
     // Q^T X: Q is orthogonal), so the 2M-3 dense projected rows are NOT needed downstream: the track
     // hands over its 2M sparse rows (14 non-zeros each) and the three dense rows T3.  The projected block
     // itself is materialised only on request (p.Hs != nullptr; tests and callers that want H').
-    if (p.ablate & 8) return;
+    // Waves 1..3 write T3 and the sparse rows SPECULATIVELY, as for an accepted track, while wave 0 is still in the tail of the
+    // gate; a rejected track overwrites them with zeros behind the barrier (same threads, same addresses: ordered).
+    const bool outputs = !(p.ablate & 8);
+    auto write_t3 = [&](bool live) {
 #pragma unroll
-    for (int ps = 0; ps < NPD; ++ps) {
-        const int a = (tid - 64) + 192 * ps;
-        if (wave > 0 && a < NAP) {
-            int kobs = -1, cc = 0;
-            if (a >= cb0 && a < NAc) {
-                const int cl = (a - cb0) / 6;
-                cc = (a - cb0) - 6 * cl;
-                kobs = sC2O[cl];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                double val = 0.0;
-                if (ok && a <= NA) {
-                    double jv = 0.0;
-                    if (a < 7) jv = sJe[i * 7 + a];
-                    else if (a == NA) jv = sR[i];
-                    else if (kobs == (i >> 1)) jv = sJx[i * 6 + cc];
-                    val = jv - (sV[i * 4 + 0] * yq[ps][0] + sV[i * 4 + 1] * yq[ps][1] + sV[i * 4 + 2] * yq[ps][2]);
+        for (int ps = 0; ps < NPD; ++ps) {
+            const int a = (tid - 64) + 192 * ps;
+            if (a < NAP) {
+                int kobs = -1, cc = 0;
+                if (a >= cb0 && a < NAc) {
+                    const int cl = (a - cb0) / 6;
+                    cc = (a - cb0) - 6 * cl;
+                    kobs = sC2O[cl];
                 }
-                st_pub<PAD_BARRIERS>(&p.T3[((size_t)3 * j + i) * NAP + a], val);   // (k_front: consumed inside the launch)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double val = 0.0;
+                    if (live && a <= NA) {
+                        double jv = 0.0;
+                        if (a < 7) jv = sJe[i * 7 + a];
+                        else if (a == NA) jv = sR[i];
+                        else if (kobs == (i >> 1)) jv = sJx[i * 6 + cc];
+                        val = jv - (sV[i * 4 + 0] * yq[ps][0] + sV[i * 4 + 1] * yq[ps][1] + sV[i * 4 + 2] * yq[ps][2]);
+                    }
+                    st_pub<PAD_BARRIERS>(&p.T3[((size_t)3 * j + i) * NAP + a], val);   // (k_front: consumed inside the launch)
+                }
             }
-            if (p.Hs) {
+        }
+    };
+    // un-projected rows of this track: [H_e(6) td | H_x(6) | r | 0 0], 16 doubles per row, stored at the
+    // observation's position in the clone-sorted order (so that k_gram reads every clone contiguously)
+    auto write_xobs = [&](bool live) {
+        for (int e = tid - 64; e < 16 * M2; e += 192) {
+            const int row = e >> 4, c = e & 15;
+            double v = 0.0;
+            if (live && c < 14) v = (c < 7) ? sJe[row * 7 + c] : ((c < 13) ? sJx[row * 6 + (c - 7)] : sR[row]);
+            st_pub<PAD_BARRIERS>(&p.Xobs[(size_t)32 * p.obs_pos[lo + (row >> 1)] + 16 * (row & 1) + c], v);
+        }
+    };
+    if (outputs && wave > 0) { write_t3(true); write_xobs(true); }
+    __syncthreads();
+    const bool ok = sFlag[0] != 0;
+    if (!outputs) return;
+    if (!ok && wave > 0) { write_t3(false); write_xobs(false); }
+    if (p.Hs && wave > 0) {
+#pragma unroll
+        for (int ps = 0; ps < NPD; ++ps) {
+            const int a = (tid - 64) + 192 * ps;
+            if (a < NAP) {
+                int kobs = -1, cc = 0;
+                if (a >= cb0 && a < NAc) {
+                    const int cl = (a - cb0) / 6;
+                    cc = (a - cb0) - 6 * cl;
+                    kobs = sC2O[cl];
+                }
                 const size_t row0 = (size_t)p.row_ptr[j];
                 for (int i = 3; i < M2; ++i) {
                     double val = 0.0;
@@ -755,14 +783,6 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                 }
             }
         }
-    }
-    // un-projected rows of this track: [H_e(6) td | H_x(6) | r | 0 0], 16 doubles per row, stored at the
-    // observation's position in the clone-sorted order (so that k_gram reads every clone contiguously)
-    for (int e = tid; e < 16 * M2; e += 256) {
-        const int row = e >> 4, c = e & 15;
-        double v = 0.0;
-        if (ok && c < 14) v = (c < 7) ? sJe[row * 7 + c] : ((c < 13) ? sJx[row * 6 + (c - 7)] : sR[row]);
-        st_pub<PAD_BARRIERS>(&p.Xobs[(size_t)32 * p.obs_pos[lo + (row >> 1)] + 16 * (row & 1) + c], v);
     }
 }
 
