@@ -416,3 +416,33 @@ def test_entering_features_with_the_covariance_resident(upd, idp, nui):
         upd.set_extra_states(0)
     assert rel(np.concatenate([got['dx'], dx_new]), ref['dx']) < TOL
     assert rel(upd.cov_get(), ref['P_new']) < TOL
+
+
+def test_entering_features_argument_checks(upd):
+    """orcvio_msckf_upload_new_features: one call per upload, anchors inside the window (or the nuisance states), enough
+    observations; ORCVIO_OPT_SCHMIDT_STATES must fit the extra states and the pose capacity."""
+    w0 = synth.make_window(N=10, F=20, seed=17, track_len=(3, 10), flags=synth.Flags(use_larvio=1))
+    w = synth.with_extra_states(w0, 3, seed=4)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 2, seed=9)]
+    upd.set_extra_states(w.n_extra)
+    upd.set_ekf_rows_mode(True)
+    try:
+        upd.upload(w)
+        upd.upload_new_features(w, 3, new)
+        with pytest.raises(capi.MsckfError):
+            upd.upload_new_features(w, 3, new)              # a second call for the same upload
+        upd.upload(w)
+        import dataclasses
+        bad = [dataclasses.replace(new[0], anchor=w.N)]     # no nuisance states: index N is outside
+        with pytest.raises(capi.MsckfError):
+            upd.upload_new_features(w, 3, bad)
+        short = [dataclasses.replace(new[0], obs=new[0].obs[:1])]
+        with pytest.raises(capi.MsckfError):
+            upd.upload_new_features(w, 3, short)
+        upd.set_schmidt_states(1)                            # 6 nuisance columns do not fit 3 extra states
+        with pytest.raises(capi.MsckfError):
+            upd.upload(w)
+    finally:
+        upd.set_schmidt_states(0)
+        upd.set_ekf_rows_mode(False)
+        upd.set_extra_states(0)

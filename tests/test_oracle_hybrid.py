@@ -226,3 +226,20 @@ def _blocks(w, new, got):
     acc, H_top, r_top, H_1, H_2, r_1 = mh.split_new_rows(w, new, 3)
     assert acc == got['new_accept']
     return H_1, H_2, r_1
+
+
+@pytest.mark.parametrize('idp', [3, 1])
+def test_library_augmentation_in_front_of_the_nuisance_block(built, idp):
+    """orcvio_msckf_augment_state_nuisance (host arithmetic of the library, no device) against the literal block moves of
+    src/orcvio.cpp:1920-1935 in the restatement."""
+    from orcvio_amd import capi
+    w0 = synth.make_window(N=8, F=30, seed=11, track_len=(3, 8), flags=synth.Flags(use_larvio=1))
+    slam = synth.make_slam_features(w0, 5, seed=2)
+    w = synth.with_nuisance_states(synth.with_extra_states(w0, idp * len(slam), seed=3), 2, seed=4)
+    new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 3, seed=6)]
+    ref = mh.hybrid_update_full(w, slam, new, idp)
+    assert len(ref['new_accept']) > 0
+    gH_top, gr_top, gH_1, gH_2, gr_1 = capi.new_feature_rows(w, idp, [new[i] for i in ref['new_accept']])
+    dx_new, P_aug = capi.augment_state_nuisance(idp, 6 * w.n_nui, gH_1, gH_2, gr_1, w.flags.noise_feature ** 2, ref['dx_leg'], ref['P_upd'])
+    assert rel(np.concatenate([ref['dx_leg'], dx_new]), ref['dx']) < 1e-9
+    assert rel(P_aug, ref['P_new']) < 1e-9
