@@ -1989,7 +1989,8 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
     }
     prof_mark(h, s, "k_obj_front");
     const int solve_xblocks = (NAP + 255) / 256, nb_solve = pl.arrow ? solve_xblocks * nobj : 0;
-    if (pl.arrow) {
+    const bool fuse_border = pl.arrow && solve_xblocks == 1;   // border QR + Y + sum B in one launch (one solve workgroup per object)
+    if (pl.arrow && !fuse_border) {
         // R of Hf by structured Householder QR (cond(Hf), not its square: msckf_kernels.hpp); the keypoint blocks are done, the border:
         if (!zeroed) HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));
 #define LAUNCH_BORDER(RPT) hipLaunchKernelGGL(k_obj_border_qr<RPT>, dim3(nobj), dim3(256), 0, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, \
@@ -1999,7 +2000,7 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
         else LAUNCH_BORDER(8);
 #undef LAUNCH_BORDER
         prof_mark(h, s, "k_obj_border_qr(Hf)");
-    } else {
+    } else if (!pl.arrow) {
     // (Hf without the arrow structure of ObjectLM's state: the Gram route.)  F_o = Hf^T Hf (lower tiles of Gff) -> R_F ;
     // Y_o = L_F^-1 C_o, C_o = [Cd_o | Hf^T r]
     {
@@ -2021,6 +2022,19 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
     }
     }
     // Y_o = R^-T C_o (arrow route) and sum_o B_o in one launch; then A' = sum_o B_o - Y^T Y (Y = all Y_o stacked; padded rows are zero)
+    if (fuse_border) {
+        if (!zeroed) HIPCHK(hipMemsetAsync(h->d_info + 4, 0, sizeof(int) * 2, s));
+        const dim3 grid(nobj + (NAP * NAP + 255) / 256);
+        const size_t lds = sizeof(double) * arrow_stride(pl.Kmax > 0 ? pl.Kmax : 1);
+#define LAUNCH_BSA(RPT) hipLaunchKernelGGL(k_obj_border_solve_assemble<RPT>, grid, dim3(256), lds, s, pl.d_arrow, (const double*)pl.d_Bred, pl.Kmax, \
+                                           pl.d_Rarrow, (const double*)pl.d_Hr, (const double*)pl.d_Sg, N, NOP, pl.d_Hfr, (const double*)pl.d_Cd, NAP, NA, \
+                                           h->d_Yobj, h->d_info + 4, nobj, h->flags.leg_dim - 15, h->d_Ab)
+        if (pl.rows_max <= 512) LAUNCH_BSA(2);
+        else if (pl.rows_max <= 1024) LAUNCH_BSA(4);
+        else LAUNCH_BSA(8);
+#undef LAUNCH_BSA
+        prof_mark(h, s, "k_obj_border_solve_assemble");
+    } else
     {   // |r|^2 per object: arrow route Hfr[o][NOP] (k_obj_border_qr), Gram route the corner of the compact Gram
         const double* rr = pl.arrow ? pl.d_Hfr + NOP : pl.d_Gff + (size_t)no_max * ldf + no_max;
         const size_t rr_stride = pl.arrow ? (size_t)NOP + 1 : (size_t)ldf * ldf;
@@ -2031,7 +2045,7 @@ static int objects_pipeline(orcvio_msckf_handle* h, hipStream_t s, double* dst, 
     hipLaunchKernelGGL(k_gemm, dim3((NAP / 16) * (NAP / 16)), dim3(256), 0, s, h->d_Yobj, 1L, (long)NAP, h->d_Yobj, (long)NAP, 1L,
                        NAP, NAP, nobj * NOP, -1.0, 0.0, 0, dst, (long)NAP, 1L, h->d_Ab);
     HIPCHK(hipGetLastError());
-    prof_mark(h, s, "k_obj_assemble_B+k_gemm(A')");
+    prof_mark(h, s, fuse_border ? "k_gemm(A')" : "k_obj_assemble_B+k_gemm(A')");
     return ORCVIO_OK;
 }
 

@@ -2474,7 +2474,10 @@ __device__ __forceinline__ void obj_cross_body(const ObjGroup* __restrict__ grou
 // dst (NAP x NAP, full symmetric) = sum over objects of B_o: clone tiles from Sg, |r|^2 from Gff[no_max][no_max]
 // (objects summed in index order: deterministic)
 __device__ __forceinline__ void obj_assemble_B_body(int idx, const double* __restrict__ Sg, int nobj, int N, const double* __restrict__ rr,
-                                                    size_t rr_stride, int cb0, int NA, int NAP, double* __restrict__ dst) {
+                                                    size_t rr_stride, int cb0, int NA, int NAP, double* __restrict__ dst,
+                                                    const double* corner_value = nullptr) {
+    // corner_value: sum of |r|^2 over all objects, computed by the caller (the launch that also holds the border QR, where the
+    // per-object sums do not exist yet)
     // rr[o * rr_stride] = |r|^2 of object o (arrow route: summed over the clone tiles by k_obj_border_qr; Gram route: the corner of
     // the compact Gram)
     if (idx >= NAP * NAP) return;
@@ -2484,7 +2487,8 @@ __device__ __forceinline__ void obj_assemble_B_body(int idx, const double* __res
     double s = 0.0;
     const bool corner = ei == 6 && ej == 6;
     const bool tile = !corner && ei >= 0 && ej >= 0 && (ci == cj || ci < 0 || cj < 0);
-    if (corner || tile) {   // (everything else of the block is structurally zero: no loads)
+    if (corner && corner_value) s = *corner_value;
+    else if (corner || tile) {   // (everything else of the block is structurally zero: no loads)
         const double* base = corner ? rr : Sg + (size_t)(ci >= 0 ? ci : cj) * 64 + ei * 8 + ej;
         const size_t st = corner ? rr_stride : (size_t)N * 64;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -2611,9 +2615,9 @@ __device__ __forceinline__ void obj_kp_qr_body(const ObjArrow ob, int obj, int k
     }
 }
 template <int RPT>   // rows per thread: RPT * 256 >= the rows of the largest object (2, 4 or 8)
-__global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restrict__ objs, const double* __restrict__ Bred, int Kmax,
-                                                       double* __restrict__ Rout, const double* __restrict__ Hr, const double* __restrict__ Sg,
-                                                       int N, int NOP, double* __restrict__ Hfr) {
+__device__ __forceinline__ void obj_border_qr_body(const int obj, const ObjArrow* __restrict__ objs, const double* __restrict__ Bred, int Kmax,
+                                                   double* __restrict__ Rout, const double* __restrict__ Hr, const double* __restrict__ Sg,
+                                                   int N, int NOP, double* __restrict__ Hfr) {
     // prologue (independent of the reflectors): Hf^T r and |r|^2 of the object = the sum of its clone groups' parts.  Value i = thread mod 128,
     // clones of one parity per half of the workgroup, sixteen loads in flight per thread: one memory round trip, hidden under the row loads
     // below; the two partial sums are combined in a fixed order at the end of the kernel (deterministic).  Hfr[o] = [Hf^T r | r^T r]
@@ -2622,7 +2626,7 @@ __global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restric
         const int i = threadIdx.x & 127, part = threadIdx.x >> 7;
         double acc = 0.0;
         if (i <= NOP) {
-            const double* src = i < NOP ? Hr + (size_t)blockIdx.x * N * NOP + i : Sg + (size_t)blockIdx.x * N * 64 + 54;
+            const double* src = i < NOP ? Hr + (size_t)obj * N * NOP + i : Sg + (size_t)obj * N * 64 + 54;
             const size_t st = i < NOP ? (size_t)NOP : 64;
             for (int c0 = part; c0 < N; c0 += 32) {
                 double v[16];
@@ -2636,9 +2640,9 @@ __global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restric
     }
     __shared__ double sPiv[16];
     __shared__ double sPart[4 * 9];
-    const ObjArrow ob = objs[blockIdx.x];
+    const ObjArrow ob = objs[obj];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    double* Ro = Rout + (size_t)blockIdx.x * arrow_stride(Kmax);
+    double* Ro = Rout + (size_t)obj * arrow_stride(Kmax);
     // thread t holds rows t, t + 256, ... (up to 2048 rows per object, host-checked)
     double x[RPT][9];
 #pragma unroll
@@ -2718,7 +2722,13 @@ __global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restric
             for (int j = 0; j < 3; ++j) mx = fmax(mx, fabs(Ro[36 * k + 12 * j + j]));
         Ro[36 * Kmax + 81] = 1e-13 * mx;
     }
-    if (tid <= NOP) Hfr[(size_t)blockIdx.x * (NOP + 1) + tid] = sSum[0][tid] + sSum[1][tid];   // (behind the barriers of the reflectors)
+    if (tid <= NOP) Hfr[(size_t)obj * (NOP + 1) + tid] = sSum[0][tid] + sSum[1][tid];   // (behind the barriers of the reflectors)
+}
+template <int RPT>
+__global__ __launch_bounds__(256) void k_obj_border_qr(const ObjArrow* __restrict__ objs, const double* __restrict__ Bred, int Kmax,
+                                                       double* __restrict__ Rout, const double* __restrict__ Hr, const double* __restrict__ Sg,
+                                                       int N, int NOP, double* __restrict__ Hfr) {
+    obj_border_qr_body<RPT>((int)blockIdx.x, objs, Bred, Kmax, Rout, Hr, Sg, N, NOP, Hfr);
 }
 // Y_o = R^-T C_o for the arrow factor: one thread per column of C (window columns 0..NA-1 from Cd, column NA = Hf^T r
 // from the compact Gram's residual row).  Rows of Y in the order of Hf's columns; dropped pivots give zero rows.
@@ -2853,6 +2863,41 @@ __global__ __launch_bounds__(256) void k_obj_solve_assemble(int nb_solve, int so
     }
     b -= nb_solve;
     obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, rr, rr_stride, cb0, NA, NAP, Bdst);
+}
+
+// Border QR, Y = R^-T C and sum_o B_o in ONE launch (windows with NAP <= 256: one solve workgroup per object).  Workgroup o < nobj:
+// the nine border reflectors of object o, then -- R_b and H_f^T r of the object are this workgroup's own writes -- the forward
+// substitution; the others: the sum of the clone tiles.  |r|^2 summed over all (object, clone) tiles by the workgroup that owns the
+// corner element (fixed assignment, LDS tree: deterministic).
+template <int RPT>
+__global__ __launch_bounds__(256) void k_obj_border_solve_assemble(const ObjArrow* __restrict__ objs, const double* __restrict__ Bred, int Kmax,
+                                                                   double* __restrict__ Rarrow, const double* __restrict__ Hr,
+                                                                   const double* __restrict__ Sg, int N, int NOP, double* __restrict__ Hfr,
+                                                                   const double* __restrict__ Cd, int NAP, int NA, double* __restrict__ Y,
+                                                                   int* __restrict__ info, int nobj, int cb0, double* __restrict__ Bdst) {
+    extern __shared__ double sR[];   // arrow_stride(Kmax) doubles (solve role)
+    int b = blockIdx.x;
+    if (b < nobj) {
+        obj_border_qr_body<RPT>(b, objs, Bred, Kmax, Rarrow, Hr, Sg, N, NOP, Hfr);
+        __syncthreads();   // (drains this workgroup's stores of R_b, the tolerance and H_f^T r)
+        obj_arrow_solve_body(sR, b, (int)threadIdx.x, objs, Rarrow, Kmax, Cd, NOP, NAP, NA, Hfr, Y, info);
+        return;
+    }
+    b -= nobj;
+    __shared__ double sCorner[256];
+    const int corner = NA * NAP + NA;
+    const bool corner_block = corner >= b * 256 && corner < b * 256 + 256;   // (workgroup-uniform)
+    if (corner_block) {
+        double sacc = 0.0;
+        for (int q = threadIdx.x; q < nobj * N; q += 256) sacc += Sg[(size_t)q * 64 + 54];
+        sCorner[threadIdx.x] = sacc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) sCorner[threadIdx.x] += sCorner[threadIdx.x + w];
+            __syncthreads();
+        }
+    }
+    obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, nullptr, 0, cb0, NA, NAP, Bdst, corner_block ? sCorner : nullptr);
 }
 
 // Test hook (tests/test_gpu_robustness.py): hold `gridDim.x` compute units for `ticks` of the 100 MHz wall clock (every
