@@ -532,7 +532,11 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
         }
         if (lend == 0 && wave == 1 && t < M) __hip_atomic_store(&sDone[t], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (diagnostic: phase E ablated)
         // phase D needs the reflectors of phase C (wave 0 finished them long ago: E is several times longer)
-        while (__hip_atomic_load(&sFlag[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+#pragma unroll 1
+        for (int it = 0; it < (1 << 22); ++it) {   // (bounded)
+            if (__hip_atomic_load(&sFlag[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
     }
 
     // ---- D (waves 1..3, while wave 0 runs the gate): compact-WY coefficients y_q[a] of Q^T [J | r] for the
@@ -596,11 +600,13 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                     {   // observations 8b .. 8b+7 (those that exist) are in sE
                         const int lw = 8 * b + (t & 7);
                         bool done = lw >= M;
-                        while (true) {
+#pragma unroll 1
+                        for (int it = 0; it < (1 << 22); ++it) {   // (bounded: never more than phase E takes -- a few microseconds)
                             if (!done) done = __hip_atomic_load(&sDone[lw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
                             if (__all(done)) break;
                             __builtin_amdgcn_s_sleep(1);
                         }
+                        if (!__all(done)) ++nneg;   // (the track is rejected rather than gated on an incomplete E)
                     }
 #pragma unroll
                     for (int a = 0; a <= b; ++a) {
