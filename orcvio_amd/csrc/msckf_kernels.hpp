@@ -264,7 +264,7 @@ __host__ __device__ inline size_t feat_lds_bytes(int Mmax, int NAP, int N) {
     const int R2 = 2 * Mmax;
     size_t dbl = (size_t)R2 * 7 + (size_t)R2 * 6 + R2 + (size_t)R2 * 4 + 64 * 4 + 16 + 4 + 8 * (size_t)NAP + 272 + 272 +
                  (size_t)R2 * feat_lde(Mmax);
-    size_t bytes = dbl * 8 + (size_t)(N + Mmax + 4 + Mmax) * 4;   // (... | sC2O N | sOC Mmax | sFlag 4 | sDone Mmax)
+    size_t bytes = dbl * 8 + (size_t)(N + Mmax + 4 + 2 * Mmax) * 4;   // (... | sC2O N | sOC Mmax | sFlag 4 | sDone Mmax | sLim Mmax)
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -328,6 +328,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
     int* sOC = sC2O + p.N;                        // [Mmax]
     int* sFlag = sOC + p.Mmax;                    // [4]  [0] gate verdict, [1] next observation of phase E, [2] QR (phase C) done
     int* sDone = sFlag + 4;                       // [Mmax] observation l of phase E is in sE
+    int* sLim = sDone + p.Mmax;                   // [Mmax] columns of P that observation l needs: [0, sLim[l]) (upper triangle of E only)
 
     for (int i = tid; i < p.N; i += 256) sC2O[i] = -1;
     for (int i = tid; i < p.Mmax; i += 256) sDone[i] = 0;
@@ -359,6 +360,15 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
             for (int c = 0; c < 3; ++c) { a0[c] = Hf[c]; a1[c] = Hf[3 + c]; }
             sOC[t] = ci;
             sC2O[ci] = t;
+        }
+        {   // Only the upper triangle of E = J P J^T is used (rows <= columns; the gate mirrors inside its diagonal tiles), so the
+            // column pair of observation l needs u_l = J_l P only at the columns of the clones of observations <= l (and the
+            // extrinsic / td columns in front): a prefix maximum of the clone indices (they ascend in every track the
+            // reference produces; the maximum keeps any order correct)
+            int mx = (t < M) ? p.obs_clone[lo + t] : -1;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { const int v = __shfl_up(mx, o); if (t >= o) mx = v > mx ? v : mx; }
+            if (t < M) sLim[t] = cb0 + 6 * mx + 6;
         }
     }
     __syncthreads();   // the Jacobians are all phase E needs: waves 1..3 start on it while wave 0 does the QR
@@ -467,24 +477,33 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
         };
         double pcur[NPASS][6], pnxt[NPASS][6];
         int l = grab();
+        int lim = 0, limn = 0;   // (wave-uniform) columns of P this / the next observation needs
         if (l < lend) {
+            lim = __builtin_amdgcn_readfirstlane(sLim[l]);
+            lim = lim < NA ? lim : NA;
             const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[l]) * n + 15;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
-                const int a = t + 64 * ps;
+                if (64 * ps < lim) {
+                    const int a = t + 64 * ps;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) pcur[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
+                    for (int c = 0; c < 6; ++c) pcur[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
+                }
             }
         }
         while (l < lend) {
             const int lnext = grab();
             if (lnext < lend) {
+                limn = __builtin_amdgcn_readfirstlane(sLim[lnext]);
+                limn = limn < NA ? limn : NA;
                 const double* Prow = p.P + (size_t)(p.leg + 6 * sOC[lnext]) * n + 15;
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
-                    const int a = t + 64 * ps;
+                    if (64 * ps < limn) {
+                        const int a = t + 64 * ps;
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) pnxt[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
+                        for (int c = 0; c < 6; ++c) pnxt[ps][c] = Prow[(size_t)c * n + (a < NA ? a : NA - 1)];
+                    }
                 }
             }
             double jl0e[7], jl1e[7], jl0x[6], jl1x[6];
@@ -495,7 +514,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int a = t + 64 * ps;
-                if (a < NA) {
+                if (a < lim) {
                     double u0 = 0.0, u1 = 0.0;
                     if (ext_live) {
 #pragma unroll
@@ -511,7 +530,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                 }
             }
             wave_sync();
-            if (rowlane) {
+            if (rowlane && t <= 2 * l + 1) {   // (rows <= columns 2l, 2l+1: the upper triangle)
                 double e0 = 0.0, e1 = 0.0;
                 if (ext_live) {   // P symmetric: zero rows <=> zero columns, so u at the ext columns is zero too
 #pragma unroll
@@ -529,6 +548,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
 #pragma unroll
                 for (int c = 0; c < 6; ++c) pcur[ps][c] = pnxt[ps][c];
             l = lnext;
+            lim = limn;
         }
         if (lend == 0 && wave == 1 && t < M) __hip_atomic_store(&sDone[t], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (diagnostic: phase E ablated)
         // phase D needs the reflectors of phase C (wave 0 finished them long ago: E is several times longer)
@@ -614,7 +634,8 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                         for (int r = 0; r < 4; ++r) {
                             const int i = 16 * a + kk + 4 * r, c = 16 * b + cc;
                             const bool in = i < M2 && c < M2;
-                            const double ev = sE[(in ? i : 0) * LDE + (in ? c : 0)];
+                            const int iu = i <= c ? i : c, cu = i <= c ? c : i;   // (phase E fills rows <= columns only)
+                            const double ev = sE[(in ? iu : 0) * LDE + (in ? cu : 0)];
                             S[a][b][r] = in ? (ev + ((i == c) ? p.sigma2 : 0.0)) : 0.0;
                         }
                     }
