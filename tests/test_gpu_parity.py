@@ -342,3 +342,23 @@ def test_random_shapes_and_flags(upd, seed):
     ref = oracle.msckf_update(w)
     got = upd.update_features(w, want_G=True)
     _compare(got, ref, w)
+
+
+def test_observation_order_within_a_track_does_not_matter(upd):
+    """The reference lists a track's observations in ascending state id; the device forms only the upper triangle of the gate's
+    E = J P J^T and limits the columns of P an observation reads by a PREFIX MAXIMUM of the clone indices -- any order of the
+    observations gives the same gate and the same update."""
+    w = synth.make_window(N=12, F=80, seed=23, track_len=(3, 12), outlier_frac=0.2)
+    rng = np.random.default_rng(1)
+    oc, oz, ov = w.obs_clone.copy(), w.obs_z.copy(), w.obs_zvel.copy()
+    for j in range(w.F):
+        lo, hi = int(w.obs_ptr[j]), int(w.obs_ptr[j + 1])
+        perm = lo + rng.permutation(hi - lo)
+        oc[lo:hi], oz[lo:hi], ov[lo:hi] = w.obs_clone[perm], w.obs_z[perm], w.obs_zvel[perm]
+    ws = dataclasses.replace(w, obs_clone=np.ascontiguousarray(oc), obs_z=np.ascontiguousarray(oz), obs_zvel=np.ascontiguousarray(ov))
+    a, b = upd.update_features(w), upd.update_features(ws)
+    assert np.array_equal(a['accept'], b['accept']) and 0 < a['accept'].sum() < w.F
+    assert rel(b['gamma'], a['gamma']) < 1e-9
+    assert rel(b['dx'], a['dx']) < 1e-9 and rel(b['P_new'], a['P_new']) < 1e-9
+    ref = oracle.msckf_update(w)
+    assert rel(b['dx'], ref['dx']) < TOL and rel(b['P_new'], ref['P_new']) < TOL
