@@ -111,8 +111,8 @@ typedef struct orcvio_msckf_result {
     int32_t stats[8]; /* [0] stacked rows (accepted)  [1] rows of H_thin  [2] accepted blocks
                          [3] 1 if an update was applied to P  [4] 1 if the reference's
                          large-update test (:4479) would discard delta_x  [5] zero-variance
-                         directions of the prior (dropped pivots of chol(P))  [6] pivots of chol(P)
-                         below -tol (the prior was not PSD)  [7] objects: rank-deficient H_f columns */
+                         directions of the prior (dropped pivots of chol(P))  [6] != 0: some pivot of chol(P)
+                         fell below -tol (the prior was not PSD)  [7] objects: rank-deficient H_f columns */
 } orcvio_msckf_result;
 
 typedef struct orcvio_msckf_handle orcvio_msckf_handle;

@@ -138,16 +138,16 @@ __device__ __forceinline__ void diag_fill(double (&v)[16], double (&y)[16], doub
         dpp_fnmac<C>(y[C], m, x);   // Linv[C][r] -= L[C][J] * Linv[J][r]
     }
 }
-struct PivotScale {   // 1/sqrt(d) of a pivot, 0 for a dropped one; counters of dropped / negative pivots
-    template <int J>
-    static __device__ __forceinline__ bool classify(double d, double tol, int nlive, int& nzero, int& nneg) {
-        const bool live = J < nlive;
-        const bool ok = live && (d > tol);
-        nzero += (live && !ok) ? 1 : 0;
-        nneg += (live && d < -tol) ? 1 : 0;
-        return ok;
-    }
-};
+// Pivot bookkeeping of the sweep: a pivot d <= tol is dropped (scale 0: its column of L and its row of the inverse become
+// zero -- zero-variance states, rank-deficient Grams).  The sweep itself only keeps the smallest pivot it met (one v_min per
+// pivot; the padding rows of a last tile carry 1 on the diagonal, so they are ordinary pivots): "some pivot < -tol" follows from
+// it, and the NUMBER of dropped pivots is counted afterwards, off the chain, from the zero diagonal entries of L.  (Per-pivot
+// counters were eight more VALU instructions on an issue-bound chain: 4.5 k -> 4.0 k cycles per tile, scripts/micro/diag_bench.)
+__device__ __forceinline__ double asm_min(double a, double b) {
+    double d;
+    asm volatile("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 #ifndef ORCVIO_DIAG_NEWTON
 #define ORCVIO_DIAG_NEWTON 1
 #endif
@@ -158,7 +158,7 @@ struct DiagStep {
     // its reciprocal square root hang off `inv` through a chain of dependent operations that is as short as possible
     // (a dependent FP64 operation costs ~25-40 cycles here whatever is issued in between).
     static __device__ __forceinline__ void step(double (&v)[16], double (&y)[16], double inv, double u, double a1, double c15,
-                                                double tol, int nlive, int& nzero, int& nneg) {
+                                                double tol, double& dmin) {
         if constexpr (J + 1 < 16) {
             const double w = asm_mul(u, inv);
             const double d = asm_fnma(w, w, a1);
@@ -168,7 +168,8 @@ struct DiagStep {
             v[J] = m;
             y[J] = x;
             const double h = asm_mul(d, 0.5);
-            const bool ok = PivotScale::classify<J + 1>(d, tol, nlive, nzero, nneg);
+            const bool ok = d > tol;
+            dmin = asm_min(dmin, d);
             asm volatile("s_nop 1" ::"v"(m), "v"(x));
             dpp_fnmac<J + 1>(v[J + 1], m, m);
             dpp_fnmac<J + 1>(y[J + 1], m, x);
@@ -202,26 +203,28 @@ struct DiagStep {
             diag_fill<J, J + 13>(v, y, m, x);
             diag_fill<J, J + 14>(v, y, m, x);
             diag_fill<J, J + 15>(v, y, m, x);
-            DiagStep<J + 1>::step(v, y, ok ? r : 0.0, un, an, c15, tol, nlive, nzero, nneg);
+            DiagStep<J + 1>::step(v, y, ok ? r : 0.0, un, an, c15, tol, dmin);
         } else {
             v[J] = asm_mul(v[J], inv);
             y[J] = asm_mul(y[J], inv);
         }
     }
-    static __device__ __forceinline__ void run(double (&v)[16], double (&y)[16], double tol, int nlive, int& nzero, int& nneg) {
+    // dmin: running minimum of the pivots (start it at +infinity); tile rows beyond the matrix must carry 1 on the diagonal
+    static __device__ __forceinline__ void run(double (&v)[16], double (&y)[16], double tol, double& dmin) {
         static_assert(J == 0, "the sweep starts at pivot 0");
         double c15 = 1.5;
         asm volatile("" : "+v"(c15));   // keep 1.5 in a register pair (not an inline constant)
         const double d = dpp_row_bcast<0>(v[0]);
         const double u = dpp_row_bcast<1>(v[0]);
         const double a1 = dpp_row_bcast<1>(v[1]);
-        const bool ok = PivotScale::classify<0>(d, tol, nlive, nzero, nneg);
+        const bool ok = d > tol;
+        dmin = asm_min(dmin, d);
         const double r0 = asm_rsq(d);
         const double h = asm_mul(d, 0.5);
         asm volatile("s_nop 1" ::"v"(r0));
         const double r1 = asm_mul(r0, asm_fnma(h, asm_mul(r0, r0), c15));
         const double r2 = asm_mul(r1, asm_fnma(h, asm_mul(r1, r1), c15));
-        step(v, y, ok ? r2 : 0.0, u, a1, c15, tol, nlive, nzero, nneg);
+        step(v, y, ok ? r2 : 0.0, u, a1, c15, tol, dmin);
     }
 };
 __device__ __forceinline__ void wave_sync() {
@@ -609,7 +612,8 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
 #pragma unroll
             for (int q = 0; q < 4; ++q) li[a][q] = 0.0;
         }
-        int nzero = 0, nneg = 0;
+        double dmin = INFINITY;   // smallest pivot of the factorisation
+        int nneg = 0;             // (a wait that gave up)
         if (!(p.ablate & 4)) {
             // Left-looking by block column b of the upper factor (Sh = R^T R, tiles S[a][b], a <= b): the column is read when
             // its eight observations are flagged, brought up to date against the finished block rows k < b, its diagonal tile
@@ -636,7 +640,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                             const bool in = i < M2 && c < M2;
                             const int iu = i <= c ? i : c, cu = i <= c ? c : i;   // (phase E fills rows <= columns only)
                             const double ev = sE[(in ? iu : 0) * LDE + (in ? cu : 0)];
-                            S[a][b][r] = in ? (ev + ((i == c) ? p.sigma2 : 0.0)) : 0.0;
+                            S[a][b][r] = in ? (ev + ((i == c) ? p.sigma2 : 0.0)) : ((i == c) ? 1.0 : 0.0);   // (padding: unit diagonal)
                         }
                     }
 #pragma unroll
@@ -662,7 +666,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                         v[c] = (c <= cc) ? av : 0.0;
                         y[c] = (c == cc) ? 1.0 : 0.0;
                     }
-                    DiagStep<0>::run(v, y, 0.0, M2 - 16 * b, nzero, nneg);
+                    DiagStep<0>::run(v, y, 0.0, dmin);
                     if (t < 16) {
 #pragma unroll
                         for (int c = 0; c < 16; ++c) sDi[c * 17 + t] = y[c];   // Linv[c][t]
@@ -727,7 +731,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
             axpy(c0, d3y * i3, c3);
         }
         const double gam = red(dot(c0, c0));
-        const bool fail = (nzero + nneg) > 0 || !(gam == gam);
+        const bool fail = nneg > 0 || !(dmin > 0.0) || !(gam == gam);   // a non-positive (or NaN) pivot: Sh is not positive definite
         const int dof = M2 - 3;
         const bool ok = (!fail) && (gam < p.chi2[dof]);
         if (t == 0) {
@@ -1342,7 +1346,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
         // =====================================================================================
         // Role 1 -- the critical chain
         // =====================================================================================
-        int nzero = 0, nneg = 0;
+        double dmin = INFINITY;   // smallest pivot (-> "some pivot below -tol"; wave 4 counts the dropped ones)
         double mx = 0.0;   // largest diagonal entry -> pivot tolerance
         // Only tile 0 and the n diagonal entries (one gather) stand between the launch and the first sweep: eight loads
         // in flight, one memory latency.  Wave 4 brings the other diagonal tiles into LDS meanwhile.
@@ -1353,7 +1357,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                 const int i = kk + 4 * r, j = cc;
                 const bool in = i < n && j < n;
                 const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
-                d0[r] = in ? xv : 0.0;
+                d0[r] = in ? xv : ((i == j) ? 1.0 : 0.0);   // (rows beyond the matrix: unit diagonal, ordinary pivots)
                 const int e = l + 64 * r;
                 const double dv = X[(size_t)(e < n ? e : 0) * (ldx + 1)];
                 dd[r] = (e < n) ? dv : 0.0;
@@ -1386,7 +1390,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                 y[c] = (c == cc) ? 1.0 : 0.0;
             }
             POTRF_STAMP(2, 3 * kb);
-            if (!(ablate & 1)) DiagStep<0>::run(v, y, tol, n - 16 * kb, nzero, nneg);
+            if (!(ablate & 1)) DiagStep<0>::run(v, y, tol, dmin);
             POTRF_STAMP(2, 3 * kb + 1);
             if (l < 16) {
                 double* pL = &sL[0][0][0] + z + (kb & 1) * 272;
@@ -1452,12 +1456,10 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (l == 0) {
-            if (info_store) { info[0] = nzero; info[1] = nneg; }
-            else {
-                if (nzero) atomicAdd(&info[0], nzero);
-                if (nneg) atomicAdd(&info[1], nneg);
-            }
+        if (l == 0) {   // info[1]: some pivot below -tol (the matrix is not positive semi-definite); info[0] is wave 4's
+            const int nneg = (dmin < -tol) ? 1 : 0;
+            if (info_store) info[1] = nneg;
+            else if (nneg) atomicAdd(&info[1], nneg);
         }
     } else if (wave == 4) {
         // =====================================================================================
@@ -1474,7 +1476,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                     const int i = 16 * k + kk + 4 * r, j = 16 * k + cc;
                     const bool in = k < nb && i < n && j < n;
                     const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
-                    dg[k - 1][r] = in ? xv : 0.0;
+                    dg[k - 1][r] = in ? xv : ((i == j) ? 1.0 : 0.0);   // (rows beyond the matrix: unit diagonal)
                 }
             }
 #pragma unroll
@@ -1485,6 +1487,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                 }
             }
         }
+        int ndrop = 0;   // dropped pivots (zero diagonal entries of L), counted here: off the chain
         for (int kb = 0; kb < nb; ++kb) {
             int z = 0;
             asm volatile("" : "+v"(z));
@@ -1498,6 +1501,10 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             double* ub = R + (size_t)(16 * kb) * ldr + 16 * kb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) st_tile<PUB>(ub + (size_t)(4 * r) * ldr, lane_b, (kk + 4 * r <= cc) ? pL[cc * 17 + kk + 4 * r] : 0.0);
+            {
+                const bool dropped = l < 16 && pL[(l & 15) * 18] == 0.0;   // L11[l][l] (rows beyond the matrix hold 1)
+                ndrop += __builtin_popcountll(__ballot(dropped));
+            }
             if (kb < ksw && !(ablate & 8)) {
                 // the later diagonal tiles of the early steps (the workers are the bottleneck there): -= panel^T panel once
                 // the panel tiles of this step are all in LDS; two tiles in flight
@@ -1527,6 +1534,10 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                     }
                 }
             }
+        }
+        if (l == 0) {   // info[0]: dropped pivots (zero-variance states of a prior, rank-deficient directions of a Gram)
+            if (info_store) info[0] = ndrop;
+            else if (ndrop) atomicAdd(&info[0], ndrop);
         }
     } else {
         // =====================================================================================

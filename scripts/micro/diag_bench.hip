@@ -15,7 +15,8 @@ __global__ void k_diag(const double* X, double* out, unsigned long long* st, int
         double v[16], y[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) { v[c] = v0[c] + rep * 1e-12; y[c] = y0[c]; }
-        if (MODE == 0) DiagStep<0>::run(v, y, 1e-300, 16, nz, nn);
+        double dmin = 1e300;
+        if (MODE == 0) { DiagStep<0>::run(v, y, 1e-300, dmin); acc += dmin; }
         if (MODE == 1) {   // updates only (no pivot math): issue cost of the 240 DPP FMAs
             double m = v[0], x = y[0];
             diag_fill<0, 1>(v, y, m, x); diag_fill<0, 2>(v, y, m, x); diag_fill<0, 3>(v, y, m, x); diag_fill<0, 4>(v, y, m, x);
