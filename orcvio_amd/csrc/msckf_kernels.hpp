@@ -151,16 +151,21 @@ __device__ __forceinline__ double asm_min(double a, double b) {
 #ifndef ORCVIO_DIAG_NEWTON
 #define ORCVIO_DIAG_NEWTON 1
 #endif
-template <int J>
+template <int J, bool DROP = true>
 struct DiagStep {
-    // inv: scale 1/sqrt(d_J) of pivot J (0 for a dropped pivot).  u, a1: entries (J+1, J) and (J+1, J+1) of the tile as
-    // they stand before this step, already broadcast to every lane, so that the next pivot d_{J+1} = a1 - (u inv)^2 and
-    // its reciprocal square root hang off `inv` through a chain of dependent operations that is as short as possible
-    // (a dependent FP64 operation costs ~25-40 cycles here whatever is issued in between).
-    static __device__ __forceinline__ void step(double (&v)[16], double (&y)[16], double inv, double u, double a1, double c15,
+    // inv: scale 1/sqrt(d_J) of pivot J (0 for a dropped pivot).  a1: entry (J+1, J+1) of the tile as it stands before this step,
+    // already broadcast to every lane; entry (J+1, J) is read with a DPP broadcast by the multiply-add itself, so that the next
+    // pivot d_{J+1} = a1 - (u inv)^2 and its reciprocal square root hang off `inv` through a chain of dependent operations that is
+    // as short as possible (a dependent FP64 operation costs ~25-40 cycles here whatever is issued in between).
+    // DROP = false (matrices that are positive definite by construction: M = s2 I + ...): no pivot test, no select on the chain;
+    // a non-positive pivot still shows in dmin.
+    static __device__ __forceinline__ void step(double (&v)[16], double (&y)[16], double inv, double a1, double c15,
                                                 double tol, double& dmin) {
         if constexpr (J + 1 < 16) {
-            const double w = asm_mul(u, inv);
+            double w = 0.0;
+            asm volatile("" : "+v"(w));
+            dpp_fnmac<J + 1>(w, v[J], inv);   // -L[J+1][J] on every lane (only its square is used; v[J] was last written a step ago;
+                                              // v_mul_f64 has no DPP form, v_fmac_f64 has)
             const double d = asm_fnma(w, w, a1);
             const double r0 = asm_rsq(d);
             const double m = asm_mul(v[J], inv);
@@ -168,18 +173,15 @@ struct DiagStep {
             v[J] = m;
             y[J] = x;
             const double h = asm_mul(d, 0.5);
-            const bool ok = d > tol;
+            const bool ok = DROP ? d > tol : true;
             dmin = asm_min(dmin, d);
             asm volatile("s_nop 1" ::"v"(m), "v"(x));
             dpp_fnmac<J + 1>(v[J + 1], m, m);
             dpp_fnmac<J + 1>(y[J + 1], m, x);
             const double t1 = asm_mul(r0, r0);
             diag_fill<J, J + 2>(v, y, m, x);
-            double un = 0.0, an = 0.0;
-            if constexpr (J + 2 < 16) {
-                un = dpp_row_bcast<J + 2>(v[J + 1]);   // (leading s_nop 1 inside)
-                an = dpp_row_bcast<J + 2>(v[J + 2]);
-            }
+            double an = 0.0;
+            if constexpr (J + 2 < 16) an = dpp_row_bcast<J + 2>(v[J + 2]);   // (leading s_nop 1 inside)
             const double t2 = asm_fnma(h, t1, c15);
             diag_fill<J, J + 3>(v, y, m, x);
             double r = asm_mul(r0, t2);
@@ -203,7 +205,7 @@ struct DiagStep {
             diag_fill<J, J + 13>(v, y, m, x);
             diag_fill<J, J + 14>(v, y, m, x);
             diag_fill<J, J + 15>(v, y, m, x);
-            DiagStep<J + 1>::step(v, y, ok ? r : 0.0, un, an, c15, tol, dmin);
+            DiagStep<J + 1, DROP>::step(v, y, ok ? r : 0.0, an, c15, tol, dmin);
         } else {
             v[J] = asm_mul(v[J], inv);
             y[J] = asm_mul(y[J], inv);
@@ -215,16 +217,15 @@ struct DiagStep {
         double c15 = 1.5;
         asm volatile("" : "+v"(c15));   // keep 1.5 in a register pair (not an inline constant)
         const double d = dpp_row_bcast<0>(v[0]);
-        const double u = dpp_row_bcast<1>(v[0]);
         const double a1 = dpp_row_bcast<1>(v[1]);
-        const bool ok = d > tol;
+        const bool ok = DROP ? d > tol : true;
         dmin = asm_min(dmin, d);
         const double r0 = asm_rsq(d);
         const double h = asm_mul(d, 0.5);
         asm volatile("s_nop 1" ::"v"(r0));
         const double r1 = asm_mul(r0, asm_fnma(h, asm_mul(r0, r0), c15));
         const double r2 = asm_mul(r1, asm_fnma(h, asm_mul(r1, r1), c15));
-        step(v, y, ok ? r2 : 0.0, u, a1, c15, tol, dmin);
+        step(v, y, ok ? r2 : 0.0, a1, c15, tol, dmin);
     }
 };
 __device__ __forceinline__ void wave_sync() {
@@ -1390,7 +1391,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                 y[c] = (c == cc) ? 1.0 : 0.0;
             }
             POTRF_STAMP(2, 3 * kb);
-            if (!(ablate & 1)) DiagStep<0>::run(v, y, tol, dmin);
+            if (!(ablate & 1)) DiagStep<0, !PUB>::run(v, y, tol, dmin);   // (PUB: the matrix is M, positive definite by construction)
             POTRF_STAMP(2, 3 * kb + 1);
             if (l < 16) {
                 double* pL = &sL[0][0][0] + z + (kb & 1) * 272;
