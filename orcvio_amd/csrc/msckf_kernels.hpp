@@ -105,6 +105,12 @@ __device__ __forceinline__ double dpp_row_bcast(double a) {
     return d;
 }
 template <int C>
+__device__ __forceinline__ double dpp_row_bcast_bare(double a) {   // no wait states in front: the caller has placed two instructions behind the write of `a`
+    double d;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=&v"(d) : "v"(a), "n"(C));
+    return d;
+}
+template <int C>
 __device__ __forceinline__ void dpp_fnmac(double& acc, double a, double b) {   // acc -= a[lane C of the row] * b
     asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(C));
 }
@@ -175,14 +181,15 @@ struct DiagStep {
             const double h = asm_mul(d, 0.5);
             const bool ok = DROP ? d > tol : true;
             dmin = asm_min(dmin, d);
-            asm volatile("s_nop 1" ::"v"(m), "v"(x));
+            // (DPP reads need two wait states behind the write of their source: h and the minimum stand between x and the first
+            //  update; the update of y[J+2] and t2 between the write of v[J+2] and its broadcast -- no s_nop on this chain)
             dpp_fnmac<J + 1>(v[J + 1], m, m);
             dpp_fnmac<J + 1>(y[J + 1], m, x);
             const double t1 = asm_mul(r0, r0);
             diag_fill<J, J + 2>(v, y, m, x);
-            double an = 0.0;
-            if constexpr (J + 2 < 16) an = dpp_row_bcast<J + 2>(v[J + 2]);   // (leading s_nop 1 inside)
             const double t2 = asm_fnma(h, t1, c15);
+            double an = 0.0;
+            if constexpr (J + 2 < 16) an = dpp_row_bcast_bare<J + 2>(v[J + 2]);
             diag_fill<J, J + 3>(v, y, m, x);
             double r = asm_mul(r0, t2);
             diag_fill<J, J + 4>(v, y, m, x);
