@@ -4,8 +4,9 @@
 using namespace orcvio_amd;
 
 template <int MODE>
-__global__ void k_diag(const double* X, double* out, unsigned long long* st, int reps) {
+__global__ void k_diag(const double* X, double* out, unsigned long long* st, int reps, int lanes) {
     const int l = threadIdx.x, cc = l & 15;
+    if (l >= lanes) return;   // (lanes = 16: does a DP instruction get cheaper with three quarters of EXEC off?)
     double v0[16], y0[16];
     for (int c = 0; c < 16; ++c) { v0[c] = (c <= cc) ? X[cc * 16 + c] : 0.0; y0[c] = (c == cc) ? 1.0 : 0.0; }
     double acc = 0;
@@ -39,14 +40,15 @@ int main() {
     hipMalloc(&dX, sizeof(h)); hipMalloc(&dO, 64 * 8); hipMalloc(&dS, 8);
     hipMemcpy(dX, h, sizeof(h), hipMemcpyHostToDevice);
     const int reps = 200;
+    for (int lanes = 64; lanes >= 16; lanes -= 48)
     for (int mode = 0; mode < 2; ++mode) {
         for (int it = 0; it < 2; ++it) {
-            if (mode == 0) hipLaunchKernelGGL(k_diag<0>, dim3(1), dim3(64), 0, 0, dX, dO, dS, reps);
-            else hipLaunchKernelGGL(k_diag<1>, dim3(1), dim3(64), 0, 0, dX, dO, dS, reps);
+            if (mode == 0) hipLaunchKernelGGL(k_diag<0>, dim3(1), dim3(64), 0, 0, dX, dO, dS, reps, lanes);
+            else hipLaunchKernelGGL(k_diag<1>, dim3(1), dim3(64), 0, 0, dX, dO, dS, reps, lanes);
             hipDeviceSynchronize();
         }
         unsigned long long s; hipMemcpy(&s, dS, 8, hipMemcpyDeviceToHost);
-        printf("mode %d: %.0f cycles per 16x16 tile (mode 1 = 30 DPP fnmacs only)\n", mode, (double)s / reps);
+        printf("lanes %d mode %d: %.0f cycles per 16x16 tile (mode 1 = 30 DPP fnmacs only)\n", lanes, mode, (double)s / reps);
     }
     return 0;
 }
