@@ -674,7 +674,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
                         v[c] = (c <= cc) ? av : 0.0;
                         y[c] = (c == cc) ? 1.0 : 0.0;
                     }
-                    DiagStep<0>::run(v, y, 0.0, dmin);
+                    DiagStep<0, false>::run(v, y, 0.0, dmin);   // (Sh = E + s2 I is positive definite unless the prior is not PSD: caught by dmin)
                     if (t < 16) {
 #pragma unroll
                         for (int c = 0; c < 16; ++c) sDi[c * 17 + t] = y[c];   // Linv[c][t]
