@@ -6,7 +6,7 @@ import pytest
 
 from orcvio_amd import capi, synth
 from oracle import mirror_objects as mo
-from helpers import rel
+from helpers import rel, objects_update_reference, random_object_case
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -315,3 +315,30 @@ def test_update_from_object_lm_messages(upd, wire_row_major):
     gone = dict(msgs[0], timestamps=[3.0 + k for k in range(len(msgs[0]['timestamps']))])
     alone = upd.update_object_lm_msgs(flags, win.N, stamps, win.R_b2c[0], win.t_c_b[0], [gone], win.P)
     assert alone['accept'] == 0 and not alone['dx'].any()
+
+
+@pytest.mark.parametrize('seed', list(range(12)) + [13, 16, 28, 35, 66, 1060])
+def test_random_object_windows_including_rank_deficient_blocks(upd, seed):
+    """A bounded slice of scripts/gpu_soak_objects.py (2 600 random windows on the GPU box, 555 of them with a rank-deficient H_f,
+    no failure): random windows and object tracks through orcvio_msckf_update_object_tracks against the mirror.  Seeds 13 ... 1060
+    hold objects whose H_f is RANK DEFICIENT (a keypoint never seen in the window, or seen once; for 1060 a dependent border
+    column, whose noise pivot a tolerance of 1e-13 kept -- the update came back as NaN): there the device projects onto the whole
+    left null space and counts rows - columns for the gate (helpers.objects_update_reference, full_nullspace), the reference
+    keeps rows - columns directions of it picked by Eigen's pivoted QR -- not determined by the inputs."""
+    case = random_object_case(seed)
+    win, objs = case['win'], case['objs']
+    ref = objects_update_reference(win, objs, win.P, case['obj_left'], case['new_bbox'], case['vio_left'], full_nullspace=True)
+    if seed >= 13:
+        assert ref['rank_deficient'] > 0
+    if case['resident']:
+        upd.cov_set(win.P)
+    got = upd.update_object_tracks(case['flags'], win.N, objs, None if case['resident'] else win.P, win.R_b2c[0], win.t_c_b[0],
+                                   case['obj_left'], case['new_bbox'], case['vio_left'])
+    assert got['accept'] == ref['accept']
+    if np.isfinite(ref['gamma']):
+        assert abs(got['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+    if ref['accept']:
+        assert got['stats'][0] == ref['dof']
+        assert rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL
+    else:
+        assert not got['dx'].any() and rel(got['P_new'], win.P) < 1e-15
