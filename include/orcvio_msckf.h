@@ -38,7 +38,12 @@ enum {
     ORCVIO_ERR_CAPACITY = 3,       /* window / tracks exceed the handle's capacity      */
     ORCVIO_ERR_TRACK_TOO_LONG = 4, /* a track has more than ORCVIO_MAX_TRACK observations */
     ORCVIO_ERR_HIP = 5,            /* HIP runtime error during the call (see last_error) */
-    ORCVIO_ERR_NOT_SPD = 6         /* S = H P H^T + sigma^2 I not positive definite      */
+    ORCVIO_ERR_NOT_SPD = 6         /* S = H P H^T + sigma^2 I not positive definite in double (sigma^2 lost beside H P H^T: a
+                                      prior beyond ~1e16 sigma^2 in scale, sigma = 0), or a non-finite result (NaN / Inf in the
+                                      prior, the poses or the noise).  NO UPDATE: the device leaves P and x alone (P+ = P,
+                                      dx = 0), the resident covariance and its factor are untouched, and cov_commit refuses
+                                      until the next successful update.  (The reference has no such guard: its LDLT
+                                      returns whatever comes out, src/orcvio.cpp:1690-1697.) */
 };
 
 #define ORCVIO_MAX_TRACK 32   /* observations per feature track handled by the wave kernel */

@@ -70,14 +70,14 @@ __global__ __launch_bounds__(256) void k_cov_remove(const double* __restrict__ P
 
 // ---- the resident square-root factor S (P = S S^T), stored transposed: S(j, i) = F[i * ld + j], i < k (columns of S),
 //      j < n (states) -- the layout of the Cholesky factor of the prior and of Z = L_M^-1 S^T --------------------------------
-// commit: S+ = sigma Z^T if the update was applied (apply == nullptr or *apply != 0), else the prior's own factor
+// commit: S+ = sigma Z^T if the update was applied (apply == nullptr or *apply != 0, and *fail == 0), else the prior's own factor
 __global__ __launch_bounds__(256) void k_fac_commit(const double* __restrict__ Z, int ldz, int k, int n, double sigma,
                                                     const int* __restrict__ apply, const double* __restrict__ prior, long sLi, long sLj,
-                                                    double* __restrict__ out, int ldo) {
+                                                    double* __restrict__ out, int ldo, const int* __restrict__ fail) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= k * n) return;
     const int i = idx / n, j = idx - i * n;
-    const bool app = apply ? (*apply != 0) : true;
+    const bool app = (apply ? (*apply != 0) : true) && fail[0] == 0 && fail[1] == 0;   // (fail: the pivot counters of chol(M); k_finish_sqrt kept P)
     out[(size_t)i * ldo + j] = app ? sigma * Z[(size_t)i * ldz + j] : prior[(long)j * sLi + (long)i * sLj];
 }
 // stateAugmentation on the factor: the new clone's six rows of S are copies of the IMU's (theta, p) rows

@@ -552,7 +552,9 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     HIPCHK(hipStreamSynchronize(h->stream));   // the pinned staging buffer of the previous upload is free again
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     if (N > h->maxN || F > h->maxF) { g_last_error = "orcvio_msckf_upload: exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
+    if (F > 0 && tr->obs_ptr[0] < 0) { g_last_error = "orcvio_msckf_upload: obs_ptr starts below zero"; return ORCVIO_ERR_INVALID; }
     const int nobs = F > 0 ? tr->obs_ptr[F] : 0;
+    if (nobs < 0) { g_last_error = "orcvio_msckf_upload: obs_ptr not monotone"; return ORCVIO_ERR_INVALID; }
     if (nobs > h->maxObs) { g_last_error = "orcvio_msckf_upload: too many observations"; return ORCVIO_ERR_CAPACITY; }
     if (F > 0 && (!tr->obs_clone || !tr->obs_z)) { g_last_error = "orcvio_msckf_upload: null track arrays"; return ORCVIO_ERR_INVALID; }
     if (flags->estimate_td && F > 0 && !tr->obs_zvel) { g_last_error = "orcvio_msckf_upload: obs_zvel required with estimate_td"; return ORCVIO_ERR_INVALID; }
@@ -926,6 +928,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
         case ST_FINISH: {
             const int nb = (n + 1 + 15) / 16, tiles = nb * (nb + 1) / 2;
             ObjGate gate;
+            gate.fail = h->d_info + 2;   // chol(M) of this update met a non-positive pivot: P+ = P, dx = 0
             if (h->objects_mode) {
                 gate.rr = h->d_A + (size_t)NA * h->NAP + NA; gate.thr = h->obj_thr;
                 gate.gamma = h->d_obj_gamma; gate.accept = h->d_obj_accept; gate.gamma_out = h->d_gamma; gate.accept_out = h->d_accept;
@@ -1289,6 +1292,7 @@ int32_t orcvio_msckf_upload_new_features(orcvio_msckf_handle* h, const orcvio_ms
     if (k == 0) return ORCVIO_OK;
     if (!nf->anchor || !nf->param || !nf->p_w || !nf->obs_ptr || !nf->obs_clone || !nf->obs_z || (d == 1 && !nf->inv_depth) ||
         (h->flags.if_fej && !nf->p_fej) || (h->flags.estimate_td && !nf->obs_zvel)) { g_last_error = "upload_new_features: null array"; return ORCVIO_ERR_INVALID; }
+    if (nf->obs_ptr[0] < 0) { g_last_error = "upload_new_features: obs_ptr starts below zero"; return ORCVIO_ERR_INVALID; }
     const int nobs = nf->obs_ptr[k];
     std::vector<int> row0(k + 1, 0);
     for (int j = 0; j < k; ++j) {
@@ -1798,7 +1802,17 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
     }
     res->stats[5] = info[0];   // zero-variance directions of the prior (dropped pivots of chol(P))
     res->stats[6] = info[1];   // pivots of chol(P) below -tol: the prior was not PSD
-    if (info[2] != 0) { g_last_error = "M = s2 I + L^T A L is not positive definite (non-finite input?)"; return ORCVIO_ERR_NOT_SPD; }
+    if (info[2] != 0 || info[3] != 0) {   // the device left P and x alone (k_finish_sqrt: P+ = P, dx = 0); the resident covariance is intact
+        h->ran = false;                    // (nothing to commit)
+        g_last_error = "M = s2 I + L^T A L is not positive definite (a prior beyond ~1e16 s2 in scale, or non-finite input): no update";
+        return ORCVIO_ERR_NOT_SPD;
+    }
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(dx[i])) {   // NaN / Inf somewhere in the inputs (a NaN pivot does not show in the smallest pivot)
+            h->ran = false;            // (cov_commit would make a non-finite P+ the resident covariance)
+            g_last_error = "non-finite result (NaN / Inf in the prior, the poses or the noise): no update";
+            return ORCVIO_ERR_NOT_SPD;
+        }
     const bool want_thin = res->H_thin || res->r_thin;
     if (want_thin || res->K || res->G) {
         int rc = compute_optional(h, want_thin || res->K, res->K != nullptr, res->G != nullptr);
@@ -3137,7 +3151,8 @@ int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h) {
     if (h->factor_opt && h->n_nui == 0) {   // S+ = sigma Z^T (or the prior's own factor if a gated object update was rejected): read before Pres changes
         const PriorFactor pf = prior_factor(h);
         hipLaunchKernelGGL(k_fac_commit, dim3((kf * n + 255) / 256), dim3(256), 0, s, h->d_Z, h->ldz, kf, n, h->flags.noise_feature,
-                           h->last_update_objects ? h->d_obj_accept : (const int*)nullptr, pf.base, pf.sLi, pf.sLj, h->d_Stmp, h->ldz);
+                           h->last_update_objects ? h->d_obj_accept : (const int*)nullptr, pf.base, pf.sLi, pf.sLj, h->d_Stmp, h->ldz,
+                           (const int*)(h->d_info + 2));
         HIPCHK(hipGetLastError());
         std::swap(h->d_Sres, h->d_Stmp);
         h->fac_n = n; h->fac_k = kf; h->fac_ld = h->ldz; h->fac_valid = true;
@@ -3274,7 +3289,9 @@ int32_t orcvio_msckf_triangulate(orcvio_msckf_handle* h, const orcvio_triangulat
     const int N = w->n_clones, F = tr->n_features;
     if (N < 1 || F < 0) { g_last_error = "orcvio_msckf_triangulate: bad sizes"; return ORCVIO_ERR_INVALID; }
     if (N > h->maxN || F > h->maxF) { g_last_error = "orcvio_msckf_triangulate: exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
+    if (F > 0 && tr->obs_ptr[0] < 0) { g_last_error = "orcvio_msckf_triangulate: obs_ptr starts below zero"; return ORCVIO_ERR_INVALID; }
     const int nobs = F > 0 ? tr->obs_ptr[F] : 0;
+    if (nobs < 0) { g_last_error = "orcvio_msckf_triangulate: obs_ptr not monotone"; return ORCVIO_ERR_INVALID; }
     if (nobs > h->maxObs) { g_last_error = "orcvio_msckf_triangulate: too many observations"; return ORCVIO_ERR_CAPACITY; }
     if (F > 0 && (!tr->obs_clone || !tr->obs_z)) { g_last_error = "orcvio_msckf_triangulate: null track arrays"; return ORCVIO_ERR_INVALID; }
     if (is_initialized && !tr->p_w) { g_last_error = "orcvio_msckf_triangulate: is_initialized needs tracks->p_w"; return ORCVIO_ERR_INVALID; }

@@ -1465,7 +1465,8 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
         }
         __builtin_amdgcn_s_setprio(0);
         if (l == 0) {   // info[1]: some pivot below -tol (the matrix is not positive semi-definite); info[0] is wave 4's
-            const int nneg = (dmin < -tol) ? 1 : 0;
+            // (PUB: M = s2 I + ... is factored without a pivot test -- any pivot that is not positive is a failure)
+            const int nneg = PUB ? (!(dmin > 0.0) ? 1 : 0) : ((dmin < -tol) ? 1 : 0);
             if (info_store) info[1] = nneg;
             else if (nneg) atomicAdd(&info[1], nneg);
         }
@@ -2386,6 +2387,9 @@ struct ObjGate {
     double thr = 0.0;
     double *gamma = nullptr, *gamma_out = nullptr;
     int *accept = nullptr, *accept_out = nullptr;
+    const int* fail = nullptr;   // the two pivot counters of chol(M) (dropped, non-positive); either != 0: M was not positive definite
+                                 // (non-finite or absurdly scaled input) and the update is not applied (P+ = P, dx = 0), for feature
+                                 // and object updates alike
 };
 __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, int kdim, double s2,
                                                      double* __restrict__ P_out, double* __restrict__ dx,
@@ -2414,9 +2418,11 @@ __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ 
     if (wave > 0) return;
     const int kk = l >> 4, cc = l & 15;
     bool app = true;   // gated object update: leave P and x alone if rejected
+    const bool failed = gate.fail && (gate.fail[0] != 0 || gate.fail[1] != 0);
+    if (failed) app = false;
     if (gate.rr) {
         const double g = (*gate.rr - ((sZZ[0] + sZZ[1]) + (sZZ[2] + sZZ[3]))) / s2;
-        app = (g == g && g < gate.thr);   // NaN anywhere in the rows makes g NaN -> rejected
+        app = !failed && (g == g && g < gate.thr);   // NaN anywhere in the rows makes g NaN -> rejected
         if (blockIdx.x == 0 && l == 0) { *gate.gamma = g; *gate.accept = app ? 1 : 0; *gate.gamma_out = g; *gate.accept_out = app ? 1 : 0; }
     }
 #pragma unroll

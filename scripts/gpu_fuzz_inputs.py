@@ -1,0 +1,194 @@
+"""Degenerate and malformed inputs through the C-ABI on the GPU box: every case must come back as a status code or as a result
+whose flags say what happened -- never a crash, a hang or silent garbage; and a later well-formed update on the same handle must
+still equal the oracle.  Each case is printed BEFORE it runs (a crash names its case).  usage: python scripts/gpu_fuzz_inputs.py"""
+import sys, os, json, dataclasses
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import numpy as np
+from orcvio_amd import capi, synth
+from oracle import oracle
+from helpers import rel
+
+upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=8192)
+base = synth.make_window(N=8, F=40, seed=3, track_len=(3, 8), outlier_frac=0.1)
+ref = oracle.msckf_update(base, want_blocks=False, want_K=False)
+report, bad = [], []
+
+
+def healthy(tag):
+    got = upd.update_features(base)
+    ok = np.array_equal(got['accept'], ref['accept']) and rel(got['dx'], ref['dx']) < 1e-6 and rel(got['P_new'], ref['P_new']) < 1e-6
+    if not ok:
+        bad.append(f'{tag}: the handle does not reproduce the oracle afterwards')
+    return ok
+
+
+def case(tag, win, expect, **kw):
+    """expect: 'error' (a status code), 'no_update' (dx = 0, P unchanged), 'flag6' (non-PSD prior reported), 'finite' (a finite
+    result), 'zero' (dx = 0 and P unchanged whatever the flags), 'any' (only: no crash, no hang, the handle stays usable), 'same_as' + window (the result equals the oracle on another window)."""
+    print('case', tag, flush=True)
+    entry = dict(case=tag, expect=expect if isinstance(expect, str) else 'same_as')
+    try:
+        got = upd.update_features(win, **kw)
+        entry.update(outcome='result', stats=got['stats'].tolist(), finite=bool(np.isfinite(got['dx']).all() and np.isfinite(got['P_new']).all()))
+        if expect == 'error':
+            bad.append(f'{tag}: expected a status code, got a result')
+        elif expect == 'no_update':
+            if got['dx'].any() or rel(got['P_new'], win.P) > 1e-15 or got['stats'][3] != 0:
+                bad.append(f'{tag}: expected no update')
+        elif expect == 'zero':
+            if got['dx'].any() or rel(got['P_new'], win.P) > 1e-15:
+                bad.append(f'{tag}: expected dx = 0 and an unchanged covariance')
+        elif expect == 'any':
+            pass
+        elif expect == 'error_or_finite':
+            if not entry['finite']:
+                bad.append(f'{tag}: a non-finite result came back without a status code')
+        elif expect == 'flag6':
+            if got['stats'][6] == 0:
+                bad.append(f'{tag}: a non-PSD prior was not reported in stats[6]')
+        elif expect == 'finite':
+            if not entry['finite']:
+                bad.append(f'{tag}: non-finite result')
+        elif not isinstance(expect, str):
+            r2 = oracle.msckf_update(expect, want_blocks=False, want_K=False)
+            e = rel(got['dx'], r2['dx']), rel(got['P_new'], r2['P_new'])
+            entry['e_dx'], entry['e_P'] = e
+            if not (e[0] < 1e-6 and e[1] < 1e-6):
+                bad.append(f'{tag}: differs from the oracle on the equivalent window: {e}')
+    except capi.MsckfError as e:
+        entry.update(outcome='status', message=str(e)[:160])
+        if expect not in ('error', 'any', 'error_or_finite'):
+            bad.append(f'{tag}: unexpected status code: {e}')
+    report.append(entry)
+    healthy(tag)
+
+
+R = dataclasses.replace
+healthy('start')
+# ---- malformed index arrays ------------------------------------------------------------------------
+p = base.obs_ptr.copy(); p[0] = -2
+case('obs_ptr starts below zero', R(base, obs_ptr=p), 'error')
+p = base.obs_ptr.copy(); p[5], p[6] = p[6], p[5]
+case('obs_ptr not monotone', R(base, obs_ptr=p), 'error')
+c = base.obs_clone.copy(); c[7] = base.N
+case('obs_clone == N', R(base, obs_clone=c), 'error')
+c = base.obs_clone.copy(); c[0] = -1
+case('obs_clone == -1', R(base, obs_clone=c), 'error')
+case('leg_dim 23', R(base, flags=R(base.flags, leg_dim=23)), 'error')
+big = synth.make_window(N=8, F=600, seed=4, track_len=(3, 8))
+case('F above the capacity of the handle', big, 'error')
+wide = synth.make_window(N=33, F=10, seed=4, track_len=(3, 8))
+case('N above the capacity of the handle', wide, 'error')
+# ---- empty and trivial shapes ------------------------------------------------------------------------
+empty = R(base, p_w=np.zeros((0, 3)), obs_ptr=np.zeros(1, dtype=np.int32), obs_clone=np.zeros(0, dtype=np.int32), obs_z=np.zeros((0, 2)), obs_zvel=np.zeros((0, 2)))
+case('no tracks', empty, 'no_update')
+one = synth.make_window(N=8, F=30, seed=5, track_len=1)
+case('every track has one observation', one, 'no_update')
+n1 = synth.make_window(N=1, F=5, seed=5, track_len=1)
+case('a window of one clone', n1, 'no_update')
+# ---- non-finite and extreme values -----------------------------------------------------------------
+z = base.obs_z.copy(); z[int(base.obs_ptr[3])] = np.nan
+drop3 = R(base, obs_ptr=np.concatenate([base.obs_ptr[:4], base.obs_ptr[4:] - (base.obs_ptr[4] - base.obs_ptr[3])]).astype(np.int32),
+          obs_clone=np.delete(base.obs_clone, np.s_[base.obs_ptr[3]:base.obs_ptr[4]]), obs_z=np.delete(base.obs_z, np.s_[base.obs_ptr[3]:base.obs_ptr[4]], axis=0),
+          obs_zvel=np.delete(base.obs_zvel, np.s_[base.obs_ptr[3]:base.obs_ptr[4]], axis=0))   # track 3 with no observation at all
+case('NaN in one observation: that track is rejected, the rest is the usual update', R(base, obs_z=z), drop3)
+pw = base.p_w.copy(); pw[5] = np.inf
+drop5 = R(base, obs_ptr=np.concatenate([base.obs_ptr[:6], base.obs_ptr[6:] - (base.obs_ptr[6] - base.obs_ptr[5])]).astype(np.int32),
+          obs_clone=np.delete(base.obs_clone, np.s_[base.obs_ptr[5]:base.obs_ptr[6]]), obs_z=np.delete(base.obs_z, np.s_[base.obs_ptr[5]:base.obs_ptr[6]], axis=0),
+          obs_zvel=np.delete(base.obs_zvel, np.s_[base.obs_ptr[5]:base.obs_ptr[6]], axis=0))
+case('Inf in one feature position', R(base, p_w=pw), drop5)
+pw = base.p_w.copy(); pw[:] = np.nan
+case('NaN in every feature position', R(base, p_w=pw), 'no_update')
+Pn = base.P.copy(); Pn[30, 30] = np.nan
+case('NaN in the prior', R(base, P=Pn), 'error')
+case('zero prior', R(base, P=np.zeros_like(base.P)), 'zero')
+Pneg = base.P.copy(); Pneg[25, 25] = -1.0
+case('prior with a negative diagonal entry', R(base, P=Pneg), 'flag6')
+case('prior scaled by 1e30 (s2 is lost in M = s2 I + L^T A L: not positive definite in double, as S = H P H^T + s2 I is for the reference)', R(base, P=base.P * 1e30), 'error_or_finite')
+case('prior scaled by 1e-30', R(base, P=base.P * 1e-30), 'finite')
+case('prior scaled by 1e200', R(base, P=base.P * 1e200), 'error_or_finite')
+case('prior scaled by 1e-200', R(base, P=base.P * 1e-200), 'finite')
+case('noise_feature = 0', R(base, flags=R(base.flags, noise_feature=0.0)), 'error_or_finite')
+case('noise_feature = NaN', R(base, flags=R(base.flags, noise_feature=float('nan'))), 'error_or_finite')
+case('chi2_prob = 1.5 (no quantile: every track is rejected)', R(base, flags=R(base.flags, chi2_prob=1.5)), 'no_update')
+behind = base.p_w.copy(); behind[:] = base.t_b_w[0] - np.array([0.0, 0.0, 50.0])
+case('features behind the cameras', R(base, p_w=behind), 'finite')
+same = R(base, R_b2w=np.repeat(base.R_b2w[:1], base.N, 0), t_b_w=np.repeat(base.t_b_w[:1], base.N, 0), t_fej=np.repeat(base.t_fej[:1], base.N, 0))
+case('all clones at the same pose (no parallax: rank-deficient H_f)', same, 'finite')
+
+# ---- a failed update must leave the resident covariance (and its factor) alone -------------------------------------------------
+print('case resident covariance after a failed update', flush=True)
+upd.cov_set(base.P)
+g0 = upd.update_features(base, resident_cov=True, want_P=False)
+upd.cov_commit()                       # P+ and its factor resident
+Pres = upd.cov_get()
+try:
+    upd.update_features(R(base, flags=R(base.flags, noise_feature=float('nan'))), resident_cov=True, want_P=False)
+    bad.append('resident: NaN noise gave no status code')
+except capi.MsckfError:
+    pass
+try:
+    upd.cov_commit()
+    bad.append('resident: cov_commit accepted a failed update')
+except capi.MsckfError:
+    pass
+if not np.array_equal(upd.cov_get(), Pres):
+    bad.append('resident: the covariance changed after a failed update')
+w2 = R(base, P=Pres)
+r2 = oracle.msckf_update(w2, want_blocks=False, want_K=False)
+g2 = upd.update_features(w2, resident_cov=True)   # the next update uses the resident factor: still the oracle's
+if not (np.array_equal(g2['accept'], r2['accept']) and rel(g2['dx'], r2['dx']) < 1e-6 and rel(g2['P_new'], r2['P_new']) < 1e-6):
+    bad.append('resident: the update after a failed one differs from the oracle')
+report.append(dict(case='resident covariance after a failed update', outcome='checked'))
+
+# ---- the object update from tracks ------------------------------------------------------------------------
+import copy
+oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+owin = synth.make_window(N=10, F=4, seed=0, flags=oflags, track_len=4)
+objs = synth.make_objects(owin, n_objects=3, seed=1, sigma_kp=0.004)
+oargs = lambda o, P=owin.P: (oflags, owin.N, o, P, owin.R_b2c[0], owin.t_c_b[0], True, False, 0)
+good = upd.update_object_tracks(*oargs(objs))
+
+
+def ocase(tag, o, expect, P=owin.P):
+    print('case', tag, flush=True)
+    entry = dict(case=tag, expect=expect)
+    try:
+        got = upd.update_object_tracks(*oargs(o, P))
+        entry.update(outcome='result', accept=got['accept'], stats=got['stats'].tolist(), finite=bool(np.isfinite(got['dx']).all() and np.isfinite(got['P_new']).all()))
+        if expect == 'error':
+            bad.append(f'{tag}: expected a status code, got a result')
+        elif expect == 'no_update' and (got['accept'] != 0 or got['dx'].any() or rel(got['P_new'], P) > 1e-15):
+            bad.append(f'{tag}: expected no update')
+    except capi.MsckfError as e:
+        entry.update(outcome='status', message=str(e)[:160])
+        if expect != 'error':
+            bad.append(f'{tag}: unexpected status code: {e}')
+    report.append(entry)
+    again = upd.update_object_tracks(*oargs(objs))
+    if not (again['accept'] == good['accept'] and rel(again['dx'], good['dx']) < 1e-12 and rel(again['P_new'], good['P_new']) < 1e-12):
+        bad.append(f'{tag}: the handle does not reproduce the object update afterwards')
+    healthy(tag)
+
+
+ocase('no object tracks', [], 'no_update')
+o = copy.deepcopy(objs); o[1].wTo[0, 3] = np.nan
+ocase('NaN in one object pose (check_nan: no update)', o, 'no_update')
+o = copy.deepcopy(objs); o[0].frames[2]['zs'][:] = np.nan
+ocase('a frame with no visible keypoint', o, 'any')
+o = copy.deepcopy(objs); o[0].frames[1]['clone'] = owin.N
+ocase('frame_clone == N', o, 'error')
+o = copy.deepcopy(objs)
+for fr in o[2].frames: fr['clone'] = -1
+ocase('an object with every frame outside the window', o, 'any')
+o = copy.deepcopy(objs)
+for ob in o:
+    for fr in ob.frames: fr['clone'] = -1
+ocase('every frame of every object outside the window', o, 'no_update')
+o = copy.deepcopy(objs); o[0].frames[0]['bbox'][:] = np.inf
+ocase('Inf in a bounding box', o, 'no_update')
+o = copy.deepcopy(objs); o[0].kps = np.zeros((0, 3))
+for fr in o[0].frames: fr['zs'] = np.zeros((0, 2))
+ocase('an object with no keypoint', o, 'error')
+print(json.dumps(dict(cases=report, problems=bad), indent=1, default=str))

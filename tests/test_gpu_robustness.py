@@ -62,3 +62,19 @@ def test_track_counts_around_the_co_residency_limit(built, F):
         assert rel(fused['dx'], forked['dx']) < 1e-10 and rel(fused['P_new'], forked['P_new']) < 1e-12
     finally:
         upd.close()
+
+
+def test_malformed_and_degenerate_inputs_never_crash_or_poison_the_handle(built):
+    """scripts/gpu_fuzz_inputs.py in a child process (a crash of the library would take the test runner with it): malformed index
+    arrays come back as status codes; empty / one-observation / one-clone windows, NaN / Inf in a track, a zero prior are 'no
+    update' or the update without the offending track; a prior that is not PSD is flagged in stats[6]; a prior or a noise
+    value that makes M = s2 I + L^T A L lose positive definiteness (scale 1e30, s2 = 0, NaN) is ORCVIO_ERR_NOT_SPD with P and x
+    left alone ON THE DEVICE (the resident covariance and its factor survive, cov_commit refuses); after every case the same
+    handle reproduces the oracle on a well-formed window."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'gpu_fuzz_inputs.py')], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rep = json.loads(out.stdout[out.stdout.index('{\n'):])
+    assert len(rep['cases']) >= 30
+    assert rep['problems'] == []
