@@ -321,7 +321,9 @@ def hybrid_update_full(win, slam, new_feats, idp_dim: int, table=None):
     acc, H_top, r_top, H_1, H_2, r_1 = split_new_rows(win, new_feats, idp_dim, table)
     if H_top.shape[0]:
         blocks.append(H_top); rs.append(r_top)
-    H_o = np.vstack(blocks); r_o = np.concatenate(rs)
+    # (no row at all in the top stack -- nothing passed its gate and every entering feature has exactly idp_dim rows, or none
+    #  enters: the reference goes on with a 0-row H_o, :1777-1818: dx_leg = 0, P unchanged; with sz_r == 0 it returns, :1775)
+    H_o = np.vstack(blocks) if blocks else np.zeros((0, win.n)); r_o = np.concatenate(rs) if rs else np.zeros(0)
     P = win.P
     S = H_o @ P @ H_o.T + sigma2 * np.eye(H_o.shape[0])                  # :1811-1815
     K = np.linalg.solve(S, H_o @ P).T
