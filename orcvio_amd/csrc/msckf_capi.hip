@@ -3585,9 +3585,19 @@ int32_t orcvio_msckf_debug_potrf_stamps(orcvio_msckf_handle* h, unsigned long lo
     const int n = h->n, NP = h->NP;
     const char* ab = getenv("ORCVIO_POTRF_ABLATE");   // diagnostic only: phases switched off (results are garbage)
     const int ablate = ab ? atoi(ab) : 0;
-    for (int rep = 0; rep < 4; ++rep)
-        hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
-                           h->d_info + 6, d, (size_t)0, (size_t)0, (size_t)0, 0, ablate);
+    // ORCVIO_POTRF_COLD (after a finished update): factor M instead, each time right behind the k_gemm that writes it from all
+    // XCDs -- the conditions of the replayed graph (cold L2 of the factorising CU's XCD) instead of a warm repetition
+    const bool cold = getenv("ORCVIO_POTRF_COLD") != nullptr && h->ran;
+    for (int rep = 0; rep < 4; ++rep) {
+        if (cold) {
+            const int rcf = launch_solve_stage(h, h->stream, ST_FORM_M);
+            if (rcf != ORCVIO_OK) return rcf;
+            hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, h->stream, h->d_M, NP, h->kf, 0.0, h->d_RM, NP, h->d_DinvM,
+                               h->d_info + 6, d, (size_t)0, (size_t)0, (size_t)0, 0, ablate, 0);
+        } else
+            hipLaunchKernelGGL(k_potrf_reg<16>, dim3(1), dim3(512), 0, h->stream, h->d_P, n, n, 1.8e-15, h->d_RP, NP, h->d_DinvP,
+                               h->d_info + 6, d, (size_t)0, (size_t)0, (size_t)0, 0, ablate);
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out256, d, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost));
     (void)hipFree(d);

@@ -5,6 +5,8 @@ import numpy as np
 from orcvio_amd import synth, capi
 upd = capi.MsckfUpdater(max_clones=32, max_features=2048, max_observations=65536, debug_hooks=True)   # diagnostics build: orcvio_msckf_debug_* hooks
 upd.upload(synth.config_window(2))
+if os.environ.get('ORCVIO_POTRF_COLD'):   # factor M right behind the k_gemm that writes it (the conditions of the replayed graph)
+    upd.run_update(); upd.sync()
 f = upd.lib.orcvio_msckf_debug_potrf_stamps
 f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 buf = (C.c_uint64 * 256)()
