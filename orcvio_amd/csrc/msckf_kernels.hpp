@@ -1495,6 +1495,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                     for (int r = 0; r < 4; ++r) sDg[k][r][l] = dg[k - 1][r];
                 }
             }
+            POTRF_STAMP(2, 50);   // (wave 4: the diagonal tiles are in LDS)
         }
         int ndrop = 0;   // dropped pivots (zero diagonal entries of L), counted here: off the chain
         for (int kb = 0; kb < nb; ++kb) {
@@ -1608,6 +1609,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[s][r] = (dead || (edge && !cin)) ? 0.0 : acc[s][r];
         }
+        POTRF_STAMP(wave == 1 ? 1 : 3, 56);   // every tile of this wave has arrived
         // every load of this wave is in flight before the first use (loads and stores share one in-order counter)
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
@@ -1626,6 +1628,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                 }
             }
         }
+        POTRF_STAMP(wave == 1 ? 1 : 3, 57);   // row 0 staged
         auto slots_below = [&](int x) -> int {   // slots of this worker whose tile index is < x
             const int v = x - wi;
             return v <= 0 ? 0 : (v + POTRF_NW - 1) / POTRF_NW;

@@ -18,7 +18,7 @@ wall = (st[193] - st[192]) * 10e-3   # us (100 MHz)
 cyc = w0[63] - w0[0]
 print(f'rc {rc}  wall {wall:.1f} us  cycles {cyc}  -> {cyc / wall / 1e3:.2f} GHz')
 print('wave0: start->loads %d, factor0 %d' % (w0[1] - t0, w0[2] - w0[1]))
-print('wave1: start %d, all loads issued %d' % (w1[0] - t0, w1[1] - t0))
+print('wave1: start %d, all loads issued %d, all tiles arrived %d, row 0 staged %d; wave 4: diagonal tiles in LDS %d' % (w1[0] - t0, w1[1] - t0, w1[56] - t0, w1[57] - t0, w2[50] - t0))
 print(' kb |  w0: waitA  waitB  dupd  factor | w1: toA   A    panel  B   trailing')
 for kb in range(13):
     a, b, c, d = w0[3 + 4 * kb], w0[4 + 4 * kb], w0[5 + 4 * kb], w0[6 + 4 * kb]
