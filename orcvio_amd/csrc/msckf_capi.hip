@@ -3272,7 +3272,10 @@ int32_t orcvio_msckf_triangulate_uploaded(orcvio_msckf_handle* h, const orcvio_t
     if (h->pw_missing && is_initialized) { g_last_error = "triangulate_uploaded: is_initialized needs uploaded positions"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
-    if (is_initialized && h->F > 0) HIPCHK(hipMemcpyAsync(h->d_tri_init, is_initialized, sizeof(int) * h->F, hipMemcpyHostToDevice, s));
+    if (is_initialized && h->F > 0) {
+        HIPCHK(hipMemcpyAsync(h->d_tri_init, is_initialized, sizeof(int) * h->F, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));   // is_initialized is the caller's (pageable) memory: it may be reused as soon as this call returns
+    }
     int rc = launch_triangulate(h, cfg, is_initialized != nullptr, true, s);
     if (rc != ORCVIO_OK) return rc;
     h->skip_active = true;
