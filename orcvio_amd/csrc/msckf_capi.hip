@@ -151,6 +151,7 @@ struct orcvio_msckf_handle {
     std::vector<ObjUse> obj_use;        // (objects_local_tracks: per-track records, kept across calls: no allocation per frame)
     std::vector<int> obj_fnr;           // rows of every frame of the track being staged
     std::vector<int> obj_rowkp, obj_Ks; // keypoint block of every row / keypoint count of every object (structured QR of Hf)
+    std::vector<unsigned long long> obj_vmask;   // (objects_local_tracks) observed keypoints of every frame of the track being staged
     // per-stage device times of the last object update (orcvio_msckf_profile_stages): events recorded between the stages
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -2363,10 +2364,15 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     int* ridx = hi + o_ridx;
     int* rowptr = hi + o_rowptr;
     ObjGroup* groups = reinterpret_cast<ObjGroup*>(hi + o_groups);
-    std::vector<int>& rowkp = h->obj_rowkp;   // keypoint block of every row (-1: a bbox row) for the structured QR
-    rowkp.assign(rows, -1);
-    std::vector<int>& Ks = h->obj_Ks;
-    Ks.assign(pl.nobj, 0);
+    // The arrow structure of the structured QR of Hf (per object K + 1 row lists: the rows of every keypoint block, then the
+    // border-only rows) is written here, frame by frame, straight from the observation masks -- the order of build_arrow (rows
+    // ascending within a list), without a pass over the 15 000 rows of a config-3 update per array.
+    ObjArrow* arrows = reinterpret_cast<ObjArrow*>(hi + o_arrow);
+    int2* kp_ranges = reinterpret_cast<int2*>(hi + o_range);
+    int* kp_rows = hi + o_kprows;
+    const bool want_arrow = h->arrow_opt && !(h->ref_stack_hf && pl.nobj > 1);
+    bool arrow_ok = want_arrow;
+    int arrow_off = 0, arrow_pos = 0, arrow_Kmax = 0, arrow_rows_max = 0;
     int ng = 0;
     rowptr[0] = 0;
     for (size_t ui = 0; ui < use.size(); ++ui) {
@@ -2389,14 +2395,20 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
         bool contiguous = true;   // every clone's rows are one contiguous run (frames map to distinct clones)
         std::vector<int>& fnr = h->obj_fnr;
         fnr.assign(F, 0);
+        int kcnt[36] = {0};   // rows of every keypoint block, [K]: border-only rows
+        std::vector<unsigned long long>& vmask = h->obj_vmask;   // observed keypoints of every frame of this track
+        vmask.assign(F, 0ull);
         for (int f = 0; f < F; ++f) {
             fc[f] = ob.frame_clone[f];
             fr0[f] = 0;
             if (fc[f] < 0) continue;
             int nv = 0;
+            unsigned long long mk = 0ull;
             const double* zs = ob.frame_zs + (size_t)f * K * 2;
             for (int k = 0; k < K; ++k)
-                if (std::isfinite(zs[2 * k]) && std::isfinite(zs[2 * k + 1])) { rowkp[rr + 2 * nv] = k; rowkp[rr + 2 * nv + 1] = k; ++nv; }
+                if (std::isfinite(zs[2 * k]) && std::isfinite(zs[2 * k + 1])) { mk |= 1ull << k; kcnt[k] += 2; ++nv; }
+            vmask[f] = mk;
+            kcnt[K] += 4;
             fr0[f] = rr;
             const int c = fc[f], nr = 2 * nv + 4;
             fnr[f] = nr;
@@ -2420,7 +2432,32 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
             }
         }
         rowptr[ui + 1] = rr;
-        Ks[ui] = K;
+        if (arrow_ok) {
+            if (rr - u.row0 > 2048) arrow_ok = false;
+            int start[36];
+            for (int k = 0; k <= K && arrow_ok; ++k) {
+                if (k < K && kcnt[k] > 128) { arrow_ok = false; break; }
+                start[k] = arrow_pos;
+                kp_ranges[arrow_off + k] = int2{arrow_pos, arrow_pos + kcnt[k]};
+                arrow_pos += kcnt[k];
+            }
+            if (arrow_ok) {
+                for (int f = 0; f < F; ++f) {
+                    if (fc[f] < 0) continue;
+                    const unsigned long long mk = vmask[f];
+                    int rj = fr0[f];
+                    for (int k = 0; k < K; ++k)
+                        if (mk >> k & 1ull) { int& st = start[k]; kp_rows[st] = rj; kp_rows[st + 1] = rj + 1; st += 2; rj += 2; }
+                    int& sb = start[K];
+                    kp_rows[sb] = rj; kp_rows[sb + 1] = rj + 1; kp_rows[sb + 2] = rj + 2; kp_rows[sb + 3] = rj + 3;
+                    sb += 4;
+                }
+                arrows[ui] = ObjArrow{u.row0, rr - u.row0, K, arrow_off};
+                arrow_off += K + 1;
+                if (K > arrow_Kmax) arrow_Kmax = K;
+                if (rr - u.row0 > arrow_rows_max) arrow_rows_max = rr - u.row0;
+            }
+        }
         ObjEvalArgs a;
         a.wTo = dd + u.off_d; a.shape = a.wTo + 16; a.kps = a.shape + 3; a.frame_wTc = a.kps + 3 * K;
         a.frame_zs = a.frame_wTc + (size_t)16 * F; a.frame_bbox = a.frame_zs + (size_t)2 * K * F;
@@ -2442,8 +2479,8 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
         if (rc != ORCVIO_OK) return rc;
     }
     pl.ngroups = ng;
-    pl.arrow = !stacked && h->arrow_opt && build_arrow(rowkp.data(), rowptr, Ks.data(), pl.nobj, reinterpret_cast<ObjArrow*>(hi + o_arrow),
-                                           reinterpret_cast<int2*>(hi + o_range), hi + o_kprows, &pl.Kmax, &pl.rows_max);
+    pl.arrow = !stacked && want_arrow && arrow_ok;
+    if (pl.arrow) { pl.Kmax = arrow_Kmax; pl.rows_max = arrow_rows_max; }
     if (pl.arrow) {   // room for the arrow factors (the row arrays the kernel arguments point at do not move: same sizes)
         double* keep_objH = h->d_objH; int* keep_obj_i = h->d_obj_i;
         rc = objects_scratch(h, &pl);
