@@ -2774,11 +2774,12 @@ __device__ __forceinline__ void obj_border_qr_body(const int obj, const ObjArrow
     // triangular factor is >= the smallest singular value: with cond(Hf) ~ 2.5e8 on the reference's own data real pivots stay
     // above 4e-9 of the largest; the noise pivot of a dependent border column reached 1e-13 in the randomised soak,
     // scripts/gpu_soak_objects.py seed 1060 -- a tolerance of 1e-13 kept it and the update came back as NaN.)
-    if (tid == 0) {
+    if (wave == 0) {   // (the 3 K pivots of the keypoint blocks: one memory round trip for the wavefront, not one per keypoint for a thread)
         double mx = pmax;
-        for (int k = 0; k < ob.K; ++k)
-            for (int j = 0; j < 3; ++j) mx = fmax(mx, fabs(Ro[36 * k + 12 * j + j]));
-        Ro[36 * Kmax + 81] = 1e-11 * mx;
+        for (int e = lane; e < 3 * ob.K; e += 64) mx = fmax(mx, fabs(Ro[36 * (e / 3) + 13 * (e % 3)]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        if (lane == 0) Ro[36 * Kmax + 81] = 1e-11 * mx;
     }
     if (tid <= NOP) Hfr[(size_t)obj * (NOP + 1) + tid] = sSum[0][tid] + sSum[1][tid];   // (behind the barriers of the reflectors)
 }
