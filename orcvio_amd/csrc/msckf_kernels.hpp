@@ -2672,7 +2672,14 @@ __device__ __forceinline__ void obj_kp_qr_body(const ObjArrow ob, int obj, int k
 template <int RPT>   // rows per thread: RPT * 256 >= the rows of the largest object (2, 4 or 8)
 __device__ __forceinline__ void obj_border_qr_body(const int obj, const ObjArrow* __restrict__ objs, const double* __restrict__ Bred, int Kmax,
                                                    double* __restrict__ Rout, const double* __restrict__ Hr, const double* __restrict__ Sg,
-                                                   int N, int NOP, double* __restrict__ Hfr) {
+                                                   int N, int NOP, double* __restrict__ Hfr, double* __restrict__ sArrow = nullptr) {
+    // sArrow (the fused launch): LDS copy of the object's arrow factor for the substitution that follows in the same workgroup -- the
+    // keypoint blocks (written by the launch before) are fetched HERE, with the rows, and R_b / the tolerance go to it directly: the
+    // substitution starts without a round trip through memory for the factor this workgroup has just finished
+    if (sArrow) {
+        const double* Rg = Rout + (size_t)obj * arrow_stride(Kmax);
+        for (int i = threadIdx.x; i < 36 * Kmax; i += 256) sArrow[i] = Rg[i];
+    }
     // prologue (independent of the reflectors): Hf^T r and |r|^2 of the object = the sum of its clone groups' parts.  Value i = thread mod 128,
     // clones of one parity per half of the workgroup, sixteen loads in flight per thread: one memory round trip, hidden under the row loads
     // below; the two partial sums are combined in a fixed order at the end of the kernel (deterministic).  Hfr[o] = [Hf^T r | r^T r]
@@ -2768,7 +2775,11 @@ __device__ __forceinline__ void obj_border_qr_body(const int obj, const ObjArrow
     if (tid < 9) {
         double* o = Ro + 36 * Kmax + 9 * tid;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) o[c] = (c >= tid && tid < ob.rows) ? x[0][c] : 0.0;
+        for (int c = 0; c < 9; ++c) {
+            const double v = (c >= tid && tid < ob.rows) ? x[0][c] : 0.0;
+            o[c] = v;
+            if (sArrow) sArrow[36 * Kmax + 9 * tid + c] = v;
+        }
     }
     // pivot tolerance: a pivot below 1e-11 of the largest one is rounding noise of an exactly dependent column.  (Every pivot of a
     // triangular factor is >= the smallest singular value: with cond(Hf) ~ 2.5e8 on the reference's own data real pivots stay
@@ -2776,10 +2787,14 @@ __device__ __forceinline__ void obj_border_qr_body(const int obj, const ObjArrow
     // scripts/gpu_soak_objects.py seed 1060 -- a tolerance of 1e-13 kept it and the update came back as NaN.)
     if (wave == 0) {   // (the 3 K pivots of the keypoint blocks: one memory round trip for the wavefront, not one per keypoint for a thread)
         double mx = pmax;
-        for (int e = lane; e < 3 * ob.K; e += 64) mx = fmax(mx, fabs(Ro[36 * (e / 3) + 13 * (e % 3)]));
+        const double* piv = sArrow ? sArrow : Ro;   // (the LDS copy is complete: the reflectors' barriers stand in between)
+        for (int e = lane; e < 3 * ob.K; e += 64) mx = fmax(mx, fabs(piv[36 * (e / 3) + 13 * (e % 3)]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-        if (lane == 0) Ro[36 * Kmax + 81] = 1e-11 * mx;
+        if (lane == 0) {
+            Ro[36 * Kmax + 81] = 1e-11 * mx;
+            if (sArrow) sArrow[36 * Kmax + 81] = 1e-11 * mx;
+        }
     }
     if (tid <= NOP) Hfr[(size_t)obj * (NOP + 1) + tid] = sSum[0][tid] + sSum[1][tid];   // (behind the barriers of the reflectors)
 }
@@ -2795,13 +2810,15 @@ __device__ __forceinline__ void obj_arrow_solve_body(double* __restrict__ sR, in
                                                      const double* __restrict__ Rin, int Kmax,
                                                      const double* __restrict__ Cd, int NOP, int NAP, int NA,
                                                      const double* __restrict__ Hfr,
-                                                     double* __restrict__ Y, int* __restrict__ info) {
+                                                     double* __restrict__ Y, int* __restrict__ info, bool preloaded = false) {
     // (the factor goes to LDS once per workgroup; every thread has the C entries of a batch of keypoints in flight before it
     // starts substituting: a handful of memory round trips, not one per keypoint)
     const ObjArrow ob = objs[o];
     const double* Ro = Rin + (size_t)o * arrow_stride(Kmax);
-    for (int i = threadIdx.x; i < arrow_stride(Kmax); i += 256) sR[i] = Ro[i];
-    __syncthreads();
+    if (!preloaded) {   // (preloaded: the fused launch filled sR in obj_border_qr_body, a barrier stands in between)
+        for (int i = threadIdx.x; i < arrow_stride(Kmax); i += 256) sR[i] = Ro[i];
+        __syncthreads();
+    }
     if (col > NA) {   // padding columns of the block: zero (A' = B - Y^T Y is formed over all NAP columns)
         if (col < NAP)
             for (int i = 0; i < NOP; ++i) Y[(size_t)o * NOP * NAP + (size_t)i * NAP + col] = 0.0;
@@ -2937,9 +2954,9 @@ __global__ __launch_bounds__(256) void k_obj_border_solve_assemble(const ObjArro
     extern __shared__ double sR[];   // arrow_stride(Kmax) doubles (solve role)
     int b = blockIdx.x;
     if (b < nobj) {
-        obj_border_qr_body<RPT>(b, objs, Bred, Kmax, Rarrow, Hr, Sg, N, NOP, Hfr);
-        __syncthreads();   // (drains this workgroup's stores of R_b, the tolerance and H_f^T r)
-        obj_arrow_solve_body(sR, b, (int)threadIdx.x, objs, Rarrow, Kmax, Cd, NOP, NAP, NA, Hfr, Y, info);
+        obj_border_qr_body<RPT>(b, objs, Bred, Kmax, Rarrow, Hr, Sg, N, NOP, Hfr, sR);
+        __syncthreads();   // (R_b and the tolerance in LDS; drains this workgroup's stores of H_f^T r)
+        obj_arrow_solve_body(sR, b, (int)threadIdx.x, objs, Rarrow, Kmax, Cd, NOP, NAP, NA, Hfr, Y, info, true);
         return;
     }
     b -= nobj;
