@@ -239,8 +239,10 @@ def main():
                     critical_path[k] = item
                 critical_path['chain'] = dict(
                     what='two dependent single-workgroup 202 x 202 Cholesky chains (chol P inside k_front, chol M in '
-                         'k_potrf_solve): 13 block steps x 16 pivots each, ~240 cycles per pivot + one LDS hand-off and eight '
-                         'dependent MFMAs per block step (DESIGN.md 6); the launches are latency-bound, not MFMA- or HBM-bound',
+                         'k_potrf_solve): 13 block steps x 16 pivots each, 180-250 cycles per pivot + one LDS hand-off and eight '
+                         'dependent MFMAs per block step; 92-94 k cycles per factorisation = 11.8 k of tile loads (one CU takes in '
+                         '~26 B per cycle) + steps 0-5 bound by the trailing update on three SIMDs + steps 6-12 bound by the chain '
+                         '(DESIGN.md 6); the launches are latency-bound, not MFMA- or HBM-bound',
                     pivots=2 * n, block_steps=2 * ((n + 15) // 16))
         except Exception:
             pass
