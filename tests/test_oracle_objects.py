@@ -150,3 +150,25 @@ def test_corrected_new_bbox_jacobians_match_central_differences(left):
             assert min(errs) > 0.1, errs   # the literal form really is inconsistent: that is what parity means for mode 1
     # the residual itself is the same in both modes
     assert np.array_equal(rows(wTc, wTo, v, 1)[0], rows(wTc, wTo, v, 2)[0])
+
+
+@pytest.mark.parametrize('seed', [0, 2, 13, 1060])
+def test_whole_null_space_reference_equals_the_svd_reference_on_full_rank_blocks(seed):
+    """helpers.objects_update_reference(full_nullspace=True) -- what the device's object update is held to when some H_f is rank
+    deficient -- is the reference's full-U-SVD projection whenever every H_f has full column rank; on a
+    rank-deficient block (seeds 13, 1060: a keypoint never seen / a dependent border column) it stacks rows - rank directions per
+    object instead of rows - columns, keeps the reference's degrees of freedom for the gate, and the two differ."""
+    from helpers import objects_update_reference, random_object_case, rel
+    c = random_object_case(seed)
+    win, objs = c['win'], c['objs']
+    a = objects_update_reference(win, objs, win.P, c['obj_left'], c['new_bbox'], c['vio_left'])
+    b = objects_update_reference(win, objs, win.P, c['obj_left'], c['new_bbox'], c['vio_left'], full_nullspace=True)
+    assert a['dof'] == b['dof'] and len(a['blocks']) == len(b['blocks'])
+    if b['rank_deficient'] == 0:
+        assert a['accept'] == b['accept']
+        assert abs(a['gamma'] - b['gamma']) < 1e-7 * abs(a['gamma'])
+        assert rel(b['dx'], a['dx']) < 1e-7 or (not a['dx'].any() and not b['dx'].any())
+        assert rel(b['P_new'], a['P_new']) < 1e-9
+    else:
+        assert seed in (13, 1060)
+        assert b['gamma'] >= a['gamma'] * (1 - 1e-9)   # more directions of the same residual: the distance cannot shrink
