@@ -2325,7 +2325,9 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
             if (seen <= kb && !lost) {
 #pragma unroll 1
                 for (int it = 0; it < (1 << 24); ++it) {
-                    seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (scalar load past the scalar cache: the flag is one word for the whole wavefront, and the scalar path answers
+                    //  sooner than a vector load that has to come back to 64 lanes)
+                    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(flag) : "memory");
                     if (seen > kb) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
