@@ -38,12 +38,22 @@ enum {
     ORCVIO_ERR_CAPACITY = 3,       /* window / tracks exceed the handle's capacity      */
     ORCVIO_ERR_TRACK_TOO_LONG = 4, /* a track has more than ORCVIO_MAX_TRACK observations */
     ORCVIO_ERR_HIP = 5,            /* HIP runtime error during the call (see last_error) */
-    ORCVIO_ERR_NOT_SPD = 6         /* S = H P H^T + sigma^2 I not positive definite in double (sigma^2 lost beside H P H^T: a
+    ORCVIO_ERR_NOT_SPD = 6,        /* S = H P H^T + sigma^2 I not positive definite in double (sigma^2 lost beside H P H^T: a
                                       prior beyond ~1e16 sigma^2 in scale, sigma = 0), or a non-finite result (NaN / Inf in the
                                       prior, the poses or the noise).  NO UPDATE: the device leaves P and x alone (P+ = P,
                                       dx = 0), the resident covariance and its factor are untouched, and cov_commit refuses
                                       until the next successful update.  (The reference has no such guard: its LDLT
                                       returns whatever comes out, src/orcvio.cpp:1690-1697.) */
+    ORCVIO_ERR_TIMEOUT = 7,        /* a bounded wait gave up: an in-launch hand-off (k_front's device-wide counter, a solver
+                                      wavefront of k_potrf_solve) after its retry, the creation of the communicator, or a rank
+                                      that never arrived at a collective.  NO UPDATE, nothing to commit (cov_commit refuses);
+                                      after a time-out inside a collective the communicator has been aborted (comm_info
+                                      reports world = 0) and must be created again */
+    ORCVIO_ERR_PEER = 8            /* sharded calls: ANOTHER rank could not take part with its share (its tracks were refused:
+                                      capacity, a track too long, an index out of range).  Every rank still went through the
+                                      collective (the failing rank with an empty share), so nobody hangs; every rank returns an
+                                      error (the failing rank its own status, the others this one) and NO rank has an update
+                                      to commit */
 };
 
 #define ORCVIO_MAX_TRACK 32   /* observations per feature track handled by the wave kernel */
@@ -305,6 +315,43 @@ int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_
                                      const orcvio_msckf_tracks* tracks, const double* P,
                                      orcvio_msckf_result* result);
 
+/* ---- The same update without the copies: the handle's pinned arena, written and read in place ------------------------------
+ * SURVEY.md 8d measures the update from "flat inputs in host memory" to "delta_x, P+ in host memory".  orcvio_msckf_update_features
+ * copies the caller's arrays into the handle's pinned input arena and the results out of its pinned output block; a caller that
+ * flattens its containers (StateServer / MapServer, src/orcvio.cpp:2497-2527, :2803-2848) STRAIGHT INTO the arena and reads the
+ * results where they land saves both copies (326 KB of P each way at 30 clones).
+ *   io_begin   lays the arena out for (n_clones, n_features, n_observations; with_P = 0: the prior is the resident covariance)
+ *              and returns the pointers.  Inputs, to be written by the caller: poses [N][ORCVIO_POSE_STRIDE] (one record per
+ *              clone: R_b2w 9 row-major | t_b_w 3 | t_fej 3 | R_b2c 9 | t_c_b 3 | 1 unused), p_w [F][3], obs_ptr [F+1] (CSR,
+ *              obs_ptr[F] == n_observations), obs_clone, obs_z [nobs][2], obs_zvel [nobs][2] (NULL unless flags->estimate_td),
+ *              P [n][n] (NULL when with_P == 0).  Outputs, valid after io_update returns ORCVIO_OK and until the next call on
+ *              the handle that takes tracks: dx [n], gamma [F], accept [F], P_out [n][n] (written only with want_P).
+ *   io_update  validates what stands in the arena (the index arrays, as orcvio_msckf_upload does), and runs the update: ONE
+ *              launch of a captured graph whose first kernel pulls the arena into HBM and whose last kernel pushes the results
+ *              into the (host-coherent) output block and raises a flag word there; the calling thread spins on that word -- no
+ *              copy-engine transfer, no stream synchronisation.  commit != 0: orcvio_msckf_cov_commit is part of the same launch
+ *              (P+ and its square-root factor become resident; refused on the device if the update is).  stats as in
+ *              orcvio_msckf_result.  The same arena may be updated again (next frame, same sizes) without a new io_begin.
+ * Status codes as orcvio_msckf_update_features; ORCVIO_ERR_TIMEOUT if the results were never published. */
+#define ORCVIO_POSE_STRIDE 28
+typedef struct orcvio_msckf_io {
+    int32_t n;            /* leg_dim + 6 n_clones (+ extra states) */
+    double* poses;
+    double* p_w;
+    int32_t* obs_ptr;
+    int32_t* obs_clone;
+    double* obs_z;
+    double* obs_zvel;
+    double* P;
+    const double* dx;
+    const double* gamma;
+    const int32_t* accept;
+    const double* P_out;
+} orcvio_msckf_io;
+int32_t orcvio_msckf_io_begin(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones, int32_t n_features,
+                              int32_t n_observations, int32_t with_P, orcvio_msckf_io* io);
+int32_t orcvio_msckf_io_update(orcvio_msckf_handle* h, int32_t want_P, int32_t commit, int32_t* stats /* [8] or NULL */);
+
 /* Object update: replaces OrcVIO::removeLostObjects (src/orcvio.cpp:2154-2193) for one
  * object block (nullspace projection against Hf -> gate with dof = rows -> NaN check ->
  * measurementUpdate_msckf).  result->accept/gamma have length 1. */
@@ -479,11 +526,29 @@ int32_t orcvio_msckf_comm_unique_id(uint8_t* id /* [ORCVIO_COMM_ID_BYTES] */);
 int32_t orcvio_msckf_comm_init(orcvio_msckf_handle* h, const uint8_t* id, int32_t rank, int32_t world);
 int32_t orcvio_msckf_comm_destroy(orcvio_msckf_handle* h);
 int32_t orcvio_msckf_comm_info(orcvio_msckf_handle* h, int32_t* rank, int32_t* world); /* world = 0: no communicator */
+/* Bounded waits: nothing here hangs on a rank that never arrives.  comm_unique_id / comm_init give up after ORCVIO_COMM_TIMEOUT_S
+ * seconds (environment, default 180) and return ORCVIO_ERR_TIMEOUT; so does every call below that waits for a stream carrying a
+ * collective (comm_barrier, comm_allreduce_max, the one-shot sharded updates, orcvio_msckf_sync on a handle with a communicator) --
+ * the communicator is then ABORTED (comm_info reports world = 0) and must be created again by all ranks.
+ *   comm_barrier         everything enqueued on the handle's stream before is finished on EVERY rank when it returns
+ *   comm_allreduce_max   values[i] <- max over the ranks, count <= 8 (e.g. the slowest rank's time of a timed region)
+ * so that a process needs no second communicator (and no second RCCL stream) beside the handle's for its bookkeeping. */
+int32_t orcvio_msckf_comm_barrier(orcvio_msckf_handle* h);
+int32_t orcvio_msckf_comm_allreduce_max(orcvio_msckf_handle* h, double* values, int32_t count);
 /* The sharded feature update.  run_update_sharded: staged form on the tracks of the last orcvio_msckf_upload (this rank's
  * share), results stay in HBM (orcvio_msckf_download fetches them).  update_features_sharded: host buffers in and out like
  * orcvio_msckf_update_features; `tracks` are THIS RANK's tracks, result->accept / gamma are theirs, result->dx / P_out are
  * the joint update's (identical on every rank); stats[0], [2] count this rank's accepted rows / tracks.
- * Every rank must make the same call in the same order (it contains a collective). */
+ * Every rank must make the same call in the same order (it contains a collective).
+ * Errors and the collective: the window and the prior are replicated, so a refusal they cause (null argument, leg_dim, capacity of
+ * the window, P == NULL without a matching resident covariance) hits every rank alike BEFORE the collective and every rank
+ * returns it.  A refusal only THIS rank's share can cause (capacity, a track longer than ORCVIO_MAX_TRACK, an index out of range)
+ * does not leave the others waiting: the rank takes part with an empty share and a status word behind its block, every rank
+ * finishes the collective, the failing rank returns its own status, all others ORCVIO_ERR_PEER, and no rank has an update to
+ * commit.  A HIP / RCCL failure between the local part and the collective (ORCVIO_ERR_HIP) cannot be repaired that way: the
+ * other ranks run into the bounded wait (ORCVIO_ERR_TIMEOUT, communicator aborted).  An in-launch time-out AFTER the collective
+ * (ORCVIO_ERR_TIMEOUT from download) is rank-local: that rank has no update, the others do -- treat it as fatal for the joint
+ * filter. */
 int32_t orcvio_msckf_run_update_sharded(orcvio_msckf_handle* h, void* stream);
 int32_t orcvio_msckf_update_features_sharded(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags,
                                              const orcvio_msckf_window* window, const orcvio_msckf_tracks* tracks,

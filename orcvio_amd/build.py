@@ -10,7 +10,7 @@ LIB_DIR = os.path.join(_HERE, 'lib')
 LIB = os.path.join(LIB_DIR, 'liborcvio_msckf.so')
 LIB_DBG = os.path.join(LIB_DIR, 'liborcvio_msckf_dbg.so')   # the same sources + the orcvio_msckf_debug_* test hooks
 SOURCES = ['msckf_capi.hip']
-DEPS = ['msckf_capi.hip', 'msckf_kernels.hpp', 'msckf_math.hpp', 'object_rows.hpp', 'triangulate.hpp', 'cov_ops.hpp', 'ekf_rows.hpp',
+DEPS = ['msckf_capi.hip', 'io_ops.hpp', 'msckf_kernels.hpp', 'msckf_math.hpp', 'object_rows.hpp', 'triangulate.hpp', 'cov_ops.hpp', 'ekf_rows.hpp',
         os.path.join('..', '..', 'include', 'orcvio_msckf.h')]
 
 

@@ -20,7 +20,7 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
 STATUS = {0: 'OK', 1: 'ERR_INVALID', 2: 'ERR_NO_DEVICE', 3: 'ERR_CAPACITY', 4: 'ERR_TRACK_TOO_LONG',
-          5: 'ERR_HIP', 6: 'ERR_NOT_SPD'}
+          5: 'ERR_HIP', 6: 'ERR_NOT_SPD', 7: 'ERR_TIMEOUT', 8: 'ERR_PEER'}
 
 # every symbol include/orcvio_msckf.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -40,6 +40,7 @@ EXPORTS = [
     'orcvio_msckf_profile_stages', 'orcvio_msckf_update_object_lm_msgs',
     'orcvio_msckf_comm_unique_id', 'orcvio_msckf_comm_init', 'orcvio_msckf_comm_destroy', 'orcvio_msckf_comm_info',
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
+    'orcvio_msckf_comm_barrier', 'orcvio_msckf_comm_allreduce_max', 'orcvio_msckf_io_begin', 'orcvio_msckf_io_update',
 ]
 
 
@@ -79,6 +80,15 @@ class ObjectLMMsg(C.Structure):
     _fields_ = [('object_id', C.c_int64), ('n_rows', C.c_int32), ('n_obj_cols', C.c_int32), ('n_frames', C.c_int32),
                 ('residual', _dp), ('jacobian_wrt_object_state', _dp), ('jacobian_wrt_sensor_state', _dp),
                 ('valid_camera_pose_mat', _dp), ('timestamps', _dp), ('zs_num_wrt_timestamps', _ip)]
+
+
+class MsckfIo(C.Structure):
+    """orcvio_msckf_io: the handle's pinned arena, written and read in place (include/orcvio_msckf.h)."""
+    _fields_ = [('n', C.c_int32), ('poses', _dp), ('p_w', _dp), ('obs_ptr', _ip), ('obs_clone', _ip), ('obs_z', _dp),
+                ('obs_zvel', _dp), ('P', _dp), ('dx', _dp), ('gamma', _dp), ('accept', _ip), ('P_out', _dp)]
+
+
+POSE_STRIDE = 28   # ORCVIO_POSE_STRIDE: R_b2w 9 | t_b_w 3 | t_fej 3 | R_b2c 9 | t_c_b 3 | 1 unused
 
 
 class MsckfResult(C.Structure):
@@ -185,6 +195,10 @@ def _bind(lib):
     lib.orcvio_msckf_comm_destroy.argtypes = [C.c_void_p]
     lib.orcvio_msckf_comm_info.argtypes = [C.c_void_p, _ip, _ip]
     lib.orcvio_msckf_run_update_sharded.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orcvio_msckf_comm_barrier.argtypes = [C.c_void_p]
+    lib.orcvio_msckf_comm_allreduce_max.argtypes = [C.c_void_p, _dp, C.c_int32]
+    lib.orcvio_msckf_io_begin.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(MsckfIo)]
+    lib.orcvio_msckf_io_update.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _ip]
     lib.orcvio_msckf_update_features_sharded.argtypes = lib.orcvio_msckf_update_features.argtypes
     lib.orcvio_msckf_update_object_tracks_sharded.argtypes = lib.orcvio_msckf_update_object_tracks.argtypes
     return lib
@@ -411,6 +425,16 @@ class MsckfUpdater:
         self._chk(self.lib.orcvio_msckf_comm_info(self.h, C.byref(r), C.byref(w)), 'orcvio_msckf_comm_info')
         return r.value, w.value
 
+    def comm_barrier(self):
+        """Everything enqueued on the handle's stream is finished on every rank (bounded wait: ERR_TIMEOUT, never a hang)."""
+        self._chk(self.lib.orcvio_msckf_comm_barrier(self.h), 'orcvio_msckf_comm_barrier')
+
+    def comm_allreduce_max(self, values):
+        """max over the ranks of up to 8 doubles, through the handle's communicator."""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._chk(self.lib.orcvio_msckf_comm_allreduce_max(self.h, _d(v), int(v.size)), 'orcvio_msckf_comm_allreduce_max')
+        return v
+
     def run_update_sharded(self, stream=None):
         """This rank's uploaded tracks -> block -> RCCL all-gather -> rank-ordered sum -> replicated solve."""
         self._chk(self.lib.orcvio_msckf_run_update_sharded(self.h, C.c_void_p(stream) if stream else None),
@@ -509,6 +533,64 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_update_features')
         return self._finish(out, res, win.F)
+
+    # -- the zero-copy boundary: the handle's pinned arena written and read in place ----------------
+    def io_begin(self, flags, N, F, nobs, with_P=True):
+        """orcvio_msckf_io_begin: returns numpy VIEWS of the handle's pinned arena -- inputs to fill (poses [N, 28], p_w, obs_ptr,
+        obs_clone, obs_z, obs_zvel or None, P or None) and outputs to read after io_update (dx, gamma, accept, P_out)."""
+        fl = make_flags(flags)
+        io = MsckfIo()
+        self._chk(self.lib.orcvio_msckf_io_begin(self.h, C.byref(fl), int(N), int(F), int(nobs), int(bool(with_P)), C.byref(io)), 'orcvio_msckf_io_begin')
+        n = int(io.n)
+        view = lambda ptr, shape: None if not ptr else np.ctypeslib.as_array(ptr, shape=shape)
+        self.n, self.F = n, int(F)
+        self._io_keep = (fl, io)
+        return dict(n=n, poses=view(io.poses, (N, POSE_STRIDE)), p_w=view(io.p_w, (max(F, 1), 3))[:F], obs_ptr=view(io.obs_ptr, (F + 1,)),
+                    obs_clone=view(io.obs_clone, (max(nobs, 1),))[:nobs], obs_z=view(io.obs_z, (max(nobs, 1), 2))[:nobs],
+                    obs_zvel=None if not io.obs_zvel else view(io.obs_zvel, (max(nobs, 1), 2))[:nobs], P=view(io.P, (n, n)),
+                    dx=view(io.dx, (n,)), gamma=view(io.gamma, (max(F, 1),))[:F], accept=view(io.accept, (max(F, 1),))[:F],
+                    P_out=view(io.P_out, (n, n)))
+
+    def io_fill(self, io, win, with_P=True):
+        """Writes a synth.Window into the arena views of io_begin (what a caller's flatten step does in place)."""
+        io['poses'][:, 0:9] = win.R_b2w.reshape(win.N, 9)
+        io['poses'][:, 9:12] = win.t_b_w
+        io['poses'][:, 12:15] = win.t_fej
+        io['poses'][:, 15:24] = win.R_b2c.reshape(win.N, 9)
+        io['poses'][:, 24:27] = win.t_c_b
+        io['poses'][:, 27] = 0.0
+        io['obs_ptr'][:] = win.obs_ptr
+        if win.F:
+            io['p_w'][:] = win.p_w
+            io['obs_clone'][:] = win.obs_clone
+            io['obs_z'][:] = win.obs_z
+            if io['obs_zvel'] is not None:
+                io['obs_zvel'][:] = win.obs_zvel
+        if with_P:
+            io['P'][:] = win.P
+
+    def io_update(self, want_P=True, commit=False):
+        """orcvio_msckf_io_update on what stands in the arena; returns the stats (the results are in the io_begin views)."""
+        stats = np.zeros(8, dtype=np.int32)
+        self._chk(self.lib.orcvio_msckf_io_update(self.h, int(bool(want_P)), int(bool(commit)), _i(stats)), 'orcvio_msckf_io_update')
+        return stats
+
+    def make_io_call(self, win, resident_cov=False, want_P=True, commit=False):
+        """io_begin + the window written into the arena ONCE: returns (call, views) where call() is orcvio_msckf_io_update alone --
+        the per-frame cost of a caller that flattens its containers straight into the arena (bench.py's latency modes)."""
+        io = self.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=not resident_cov)
+        self.io_fill(io, win, with_P=not resident_cov)
+        lib, h = self.lib, self.h
+        stats = np.zeros(8, dtype=np.int32)
+        args = (h, int(bool(want_P)), int(bool(commit)), _i(stats))
+
+        def call():
+            rc = lib.orcvio_msckf_io_update(*args)
+            if rc != 0:
+                raise MsckfError(rc, 'orcvio_msckf_io_update')
+        call._keep = (io, stats)
+        io['stats'] = stats
+        return call, io
 
     def make_update_call(self, win, resident_cov=False, want_P=True, commit=False):
         """The one-shot update with the argument structs marshalled ONCE: returns (call, out) where call() runs

@@ -22,6 +22,12 @@
 #include "cov_ops.hpp"
 #include "ekf_rows.hpp"
 #include "object_rows.hpp"
+#include "io_ops.hpp"
+#include <immintrin.h>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 using namespace orcvio_amd;
 
@@ -69,13 +75,32 @@ struct orcvio_msckf_handle {
     size_t oo_dx = 0, oo_gamma = 0, oo_accept = 0, oo_Pout = 0;
     bool dl_pending = false, dl_with_P = false;      // a device -> host copy of the outputs is in flight on dl_stream
     hipStream_t dl_stream = nullptr;
-    // graph policy: a launch graph is captured only when the same launch signature is seen twice in a row
+    // graph policy: a launch graph is captured when a launch signature is seen for the SECOND time (not necessarily in a
+    // row); a slot keeps up to GRAPH_WAYS captured graphs (least recently used one replaced).  More than one way, because
+    // the signature contains every pointer a graph bakes in and some of them alternate: the resident square-root factor
+    // is double-buffered (cov_commit / cov_prefactor / cov_augment swap d_Sres and d_Stmp), so a filter that repeats one
+    // shape replays two graphs in turn (a single slot keyed without that pointer replayed a stale factor).
+    static constexpr int GRAPH_WAYS = 6;
     struct GraphSlot {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        unsigned long long sig = 0, last = 0;
+        struct Way { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long long sig = 0, used = 0; };
+        Way way[GRAPH_WAYS];
+        unsigned long long seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // signatures met once (no graph yet), ring
+        int seen_at = 0;
+        unsigned long long tick = 0;
     };
-    GraphSlot g_update, g_local, g_finish;
+    GraphSlot g_update, g_local, g_finish, g_io;
+    // ---- zero-copy boundary (orcvio_msckf_io_*): the pinned arena is device-visible and host-coherent, the first kernel of the
+    // graph pulls the inputs out of it, the last one pushes the results into it and raises h_flag
+    char* h_stage_dev = nullptr;              // device-visible address of h_stage
+    unsigned long long* h_flag = nullptr;     // host-coherent word: publications so far (k_publish)
+    unsigned long long* h_flag_dev = nullptr;
+    unsigned long long* d_seq = nullptr;      // device-side twin (the value k_publish stores to the flag)
+    int* d_pubcnt = nullptr;                  // arrival counter of k_publish's workgroups
+    unsigned long long flag_seen = 0;         // last sequence number the host has waited for
+    bool io_open = false, io_with_P = false;  // orcvio_msckf_io_begin has laid the arena out and the caller is filling it
+    double io_spin_seconds = 2.0;             // bound of the host's wait on h_flag (then: stream synchronisation, then ERR_TIMEOUT)
+    bool last_sharded = false;                // the last finished update went through the handle's all-gather (status words in info[9..12])
+    int shard_status = 0;                     // sharded calls: this rank's own status travelling with its block (ORCVIO_ERR_PEER)
     hipStream_t last_stream = nullptr;   // stream of the last run_update / run_finish (download waits for it)
     double *d_Pres = nullptr, *d_Ptmp = nullptr, *d_covT = nullptr;   // resident covariance, scratch, Phi*P rows
     // Resident SQUARE-ROOT FACTOR of the resident covariance: P_res = S S^T with S (fac_n x fac_k), stored like the
@@ -132,6 +157,7 @@ struct orcvio_msckf_handle {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0;
     double *d_gather = nullptr, *d_dofs = nullptr;
+    hipStream_t comm_stream = nullptr;  // carries the early exchange of the degrees of freedom of a sharded object update
     double* h_dofs = nullptr;           // pinned [2 * world]
     bool A_deferred = false;            // the last run left S / Gpart only: d_A is assembled on demand (assemble_deferred)
     int front_chunks = 1;               // T3 row chunks of the last k_front launch
@@ -328,10 +354,13 @@ static void free_all(orcvio_msckf_handle* h) {
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
-    for (auto* g : {&h->g_update, &h->g_local, &h->g_finish}) {
-        if (g->exec) (void)hipGraphExecDestroy(g->exec);
-        if (g->graph) (void)hipGraphDestroy(g->graph);
-    }
+    for (auto* g : {&h->g_update, &h->g_local, &h->g_finish, &h->g_io})
+        for (auto& w : g->way) {
+            if (w.exec) (void)hipGraphExecDestroy(w.exec);
+            if (w.graph) (void)hipGraphDestroy(w.graph);
+        }
+    if (h->h_flag) (void)hipHostFree(h->h_flag);
+    if (h->d_seq) (void)hipFree(h->d_seq);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->side) (void)hipStreamDestroy(h->side);
 }
@@ -389,7 +418,17 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
             HIPCHK(hipMalloc(&h->d_outs, h->outs_cap));
             HIPCHK(hipMemset(h->d_in, 0, h->in_cap));
             h->stage_bytes = h->in_cap + h->outs_cap;
-            HIPCHK(hipHostMalloc(&h->h_stage, h->stage_bytes, hipHostMallocDefault));
+            // pinned, mapped into the device's address space, host-coherent (fine-grained): kernels read the inputs from it
+            // (k_ingest) and write the results into it (k_publish); the copy engines can use it as before
+            HIPCHK(hipHostMalloc(&h->h_stage, h->stage_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+            HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_stage_dev), h->h_stage, 0));
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_flag), 256, hipHostMallocMapped | hipHostMallocCoherent));
+            HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_flag_dev), h->h_flag, 0));
+            std::memset(h->h_flag, 0, 256);
+            HIPCHK(hipMalloc(&h->d_seq, 256));
+            HIPCHK(hipMemset(h->d_seq, 0, 256));
+            h->d_pubcnt = reinterpret_cast<int*>(h->d_seq) + 32;   // (own 128-byte line)
+            if (const char* e = getenv("ORCVIO_IO_SPIN_SECONDS")) h->io_spin_seconds = atof(e);
             layout_inputs(h, max_clones, max_features, max_observations, true, true, h->n_max);
             layout_outputs(h, h->n_max, max_features);
         }
@@ -515,13 +554,17 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
 
 static int factor_layout_clean(orcvio_msckf_handle* h);
 static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s);
+static int comm_stream_wait(orcvio_msckf_handle* h, hipStream_t s, const char* who);
+static int feature_outcome(orcvio_msckf_handle* h, const char* so, int32_t* stats);
+static int run_finish_impl(orcvio_msckf_handle* h, const double* d_blocks, int n_blocks, size_t stride, const double* meta0, hipStream_t s);
+static int objects_finish_impl(orcvio_msckf_handle* h, const double* d_blocks, int n_blocks, size_t stride, const double* meta0, int dof_total, hipStream_t s);
 // Gram of the rows stacked under the MSCKF rows (EKF-SLAM rows that passed their gate, caller-projected dense rows)
 static inline const double* extra_gram(const orcvio_msckf_handle* h) { return (h->ekf_F > 0 || h->dense_rows > 0) ? h->d_Gekf : nullptr; }
 
 // The prior of this update comes as P == NULL (resident covariance): if its square-root factor is resident too, the update
 // uses it instead of factoring P (kf = its column count = the dimension of M).
-static void select_prior_factor(orcvio_msckf_handle* h, const double* P) {
-    h->use_factor = !P && h->factor_opt && h->fac_valid && h->fac_n == h->n && h->res_n == h->n &&
+static void select_prior_factor(orcvio_msckf_handle* h, bool with_P) {
+    h->use_factor = !with_P && h->factor_opt && h->fac_valid && h->fac_n == h->n && h->res_n == h->n &&
                     round_up(h->fac_k, 16) <= POTRF_MAXN && round_up(h->fac_k, 16) / 16 <= TRSM_MAXBLK &&
                     round_up(h->fac_k, 16) <= h->NP_max;
     h->kf = h->use_factor ? h->fac_k : h->n;
@@ -537,56 +580,32 @@ static PriorFactor prior_factor(const orcvio_msckf_handle* h) {
 }
 
 // ---- upload --------------------------------------------------------------------------------
-int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
-                            const orcvio_msckf_tracks* tr, const double* P) {
-    if (!h || !flags || !w || !tr || !w->R_b2w || !w->t_b_w || !w->R_b2c || !w->t_c_b || !tr->obs_ptr) {
-        g_last_error = "orcvio_msckf_upload: null argument";
-        return ORCVIO_ERR_INVALID;
-    }
-    if (flags->leg_dim != 22 && flags->leg_dim != 46) {
-        g_last_error = "orcvio_msckf_upload: leg_dim must be 22 or 46";
-        return ORCVIO_ERR_INVALID;
-    }
-    const int N = w->n_clones, F = tr->n_features;
-    if (N < 1 || F < 0) { g_last_error = "orcvio_msckf_upload: bad sizes"; return ORCVIO_ERR_INVALID; }
+// Three steps: upload_begin (sizes -> problem dimensions, arena layout), the caller's arrays written into the pinned arena
+// (by orcvio_msckf_upload from its arguments, or by the caller itself through orcvio_msckf_io_begin's pointers), and
+// upload_finalize (validation of what stands in the arena, the derived index arrays).  The arena reaches the device by one
+// asynchronous copy (staged callers) or by the first kernel of the update's graph (k_ingest, orcvio_msckf_io_update).
+static int upload_begin(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int N, int F, int nobs, bool with_P, bool have_zvel,
+                        const char* who) {
+    if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = std::string(who) + ": leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
+    if (N < 1 || F < 0) { g_last_error = std::string(who) + ": bad sizes"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));   // the pinned staging buffer of the previous upload is free again
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
-    if (N > h->maxN || F > h->maxF) { g_last_error = "orcvio_msckf_upload: exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
-    if (F > 0 && tr->obs_ptr[0] < 0) { g_last_error = "orcvio_msckf_upload: obs_ptr starts below zero"; return ORCVIO_ERR_INVALID; }
-    const int nobs = F > 0 ? tr->obs_ptr[F] : 0;
-    if (nobs < 0) { g_last_error = "orcvio_msckf_upload: obs_ptr not monotone"; return ORCVIO_ERR_INVALID; }
-    if (nobs > h->maxObs) { g_last_error = "orcvio_msckf_upload: too many observations"; return ORCVIO_ERR_CAPACITY; }
-    if (F > 0 && (!tr->obs_clone || !tr->obs_z)) { g_last_error = "orcvio_msckf_upload: null track arrays"; return ORCVIO_ERR_INVALID; }
-    if (flags->estimate_td && F > 0 && !tr->obs_zvel) { g_last_error = "orcvio_msckf_upload: obs_zvel required with estimate_td"; return ORCVIO_ERR_INVALID; }
-    // row offsets, track-length limits, index validation
-    h->h_row_ptr.assign(F + 1, 0);
-    int Mmax = 2;
-    for (int j = 0; j < F; ++j) {
-        const int M = tr->obs_ptr[j + 1] - tr->obs_ptr[j];
-        if (M < 0) { g_last_error = "orcvio_msckf_upload: obs_ptr not monotone"; return ORCVIO_ERR_INVALID; }
-        if (M > ORCVIO_MAX_TRACK) { g_last_error = "orcvio_msckf_upload: track longer than ORCVIO_MAX_TRACK"; return ORCVIO_ERR_TRACK_TOO_LONG; }
-        if (M > Mmax) Mmax = M;
-        h->h_row_ptr[j + 1] = h->h_row_ptr[j] + (M >= 2 ? 2 * M - 3 : 0);
-    }
-    for (int o = 0; o < nobs; ++o)
-        if (tr->obs_clone[o] < 0 || tr->obs_clone[o] >= N) { g_last_error = "orcvio_msckf_upload: obs_clone out of range"; return ORCVIO_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
+    if (N > h->maxN || F > h->maxF) { g_last_error = std::string(who) + ": exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
+    if (nobs < 0) { g_last_error = std::string(who) + ": obs_ptr not monotone"; return ORCVIO_ERR_INVALID; }
+    if (nobs > h->maxObs) { g_last_error = std::string(who) + ": too many observations"; return ORCVIO_ERR_CAPACITY; }
+    if (flags->estimate_td && F > 0 && !have_zvel) { g_last_error = std::string(who) + ": obs_zvel required with estimate_td"; return ORCVIO_ERR_INVALID; }
+    const int n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
+    if (n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
+    if (6 * h->n_nui > h->n_extra || N + h->n_nui > h->maxN) { g_last_error = std::string(who) + ": nuisance states do not fit the extra states / the pose capacity"; return ORCVIO_ERR_CAPACITY; }
+    if (!with_P && h->res_n != n) { g_last_error = std::string(who) + ": P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
+    h->uploaded = false; h->ran = false; h->io_open = false;
     h->flags = *flags;
     h->N = N; h->F = F; h->nobs = nobs;
-    h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
+    h->n = n;
     h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
     h->ekf_F = 0; h->dense_rows = 0; h->new_F = 0;
-    if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
-    if (6 * h->n_nui > h->n_extra || N + h->n_nui > h->maxN) { g_last_error = "orcvio_msckf_upload: nuisance states do not fit the extra states / the pose capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
-    select_prior_factor(h, P);
-    h->NP = round_up(h->n > h->kf ? h->n : h->kf, 16);
-    h->ldz = round_up(h->n + 1, 16);
-    h->reg_path = (h->NP / 16) <= 14;
-    { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
-    h->m_tot = h->h_row_ptr[F];
-    h->Mmax = Mmax;
     // chi-square table (src/orcvio.cpp:481-494)
     if (h->chi2_prob_cached != flags->chi2_prob) {
         h->h_chi2.assign(ORCVIO_CHI2_TABLE, 0.0);
@@ -595,59 +614,73 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
         HIPCHK(hipStreamSynchronize(h->stream));
         h->chi2_prob_cached = flags->chi2_prob;
     }
-    // ---- stage everything in pinned memory in the arena's layout: ONE asynchronous copy ---------------------
-    hipStream_t s = h->stream;
-    if (!P && h->res_n != h->n) { g_last_error = "orcvio_msckf_upload: P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
-    const bool with_zvel = tr->obs_zvel && flags->estimate_td;   // read by the kernels only under estimate_td
-    layout_inputs(h, N + h->n_nui, F, nobs, with_zvel, P != nullptr, h->n);   // (pose slots of the nuisance states behind the window's)
+    const bool with_zvel = have_zvel && flags->estimate_td;   // read by the kernels only under estimate_td
+    layout_inputs(h, N + h->n_nui, F, nobs, with_zvel, with_P, h->n);   // (pose slots of the nuisance states behind the window's)
     layout_outputs(h, h->n, F);
+    h->io_with_P = with_P;
+    return ORCVIO_OK;
+}
+
+// bytes of the arena that travel: everything in front of P, and P itself when the prior comes from the host
+static inline size_t upload_bytes(const orcvio_msckf_handle* h) {
+    return h->io_with_P ? h->io_P + sizeof(double) * (size_t)h->n * h->n : h->in_used;
+}
+
+// The arena holds poses, obs_ptr, p_w, obs_clone, obs_z (obs_zvel, P): validate the index arrays and derive row_ptr (rows of
+// every projected block), clone_obs / clone_ptr (observations grouped by clone: the sparse part of the compression).
+static int upload_finalize(orcvio_msckf_handle* h, const char* who) {
+    const int N = h->N, F = h->F, nobs = h->nobs;
+    // the prior: the caller's P in the arena, or the resident covariance -- with its square-root factor if that is known NOW
+    // (an orcvio_msckf_io_update may follow a commit, a cov_set, an augmentation of the previous one)
+    if (!h->io_with_P) {
+        if (h->res_n != h->n) { g_last_error = std::string(who) + ": P == NULL but the resident covariance does not match the window"; return ORCVIO_ERR_INVALID; }
+        h->d_P = h->d_Pres;
+    }
+    select_prior_factor(h, h->io_with_P);
+    h->NP = round_up(h->n > h->kf ? h->n : h->kf, 16);
+    h->ldz = round_up(h->n + 1, 16);
+    h->reg_path = (h->NP / 16) <= 14;
+    { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
     char* st = h->h_stage;
-    size_t bytes = h->in_used;
-    if (P) {   // the largest part first: the copy engine could start on it while the rest is staged (one copy all the same)
-        std::memcpy(st + h->io_P, P, sizeof(double) * (size_t)h->n * h->n);
-        bytes = h->io_P + sizeof(double) * (size_t)h->n * h->n;
+    const int* obs_ptr = reinterpret_cast<const int*>(st + h->io_optr);
+    const int* obs_clone = reinterpret_cast<const int*>(st + h->io_oclone);
+    if (F > 0 && obs_ptr[0] < 0) { g_last_error = std::string(who) + ": obs_ptr starts below zero"; return ORCVIO_ERR_INVALID; }
+    if (F > 0 && obs_ptr[F] != nobs) { g_last_error = std::string(who) + ": obs_ptr[F] differs from the number of observations"; return ORCVIO_ERR_INVALID; }
+    // row offsets, track-length limits
+    h->h_row_ptr.resize(F + 1);
+    int* row_ptr = h->h_row_ptr.data();
+    row_ptr[0] = 0;
+    int Mmax = 2;
+    for (int j = 0; j < F; ++j) {
+        const int M = obs_ptr[j + 1] - obs_ptr[j];
+        if (M < 0) { g_last_error = std::string(who) + ": obs_ptr not monotone"; return ORCVIO_ERR_INVALID; }
+        if (M > ORCVIO_MAX_TRACK) { g_last_error = std::string(who) + ": track longer than ORCVIO_MAX_TRACK"; return ORCVIO_ERR_TRACK_TOO_LONG; }
+        if (M > Mmax) Mmax = M;
+        row_ptr[j + 1] = row_ptr[j] + (M >= 2 ? 2 * M - 3 : 0);
     }
-    {   // poses, obs_ptr, row_ptr
-        double* poses = reinterpret_cast<double*>(st + h->io_poses);
-        const double* tfej = w->t_fej ? w->t_fej : w->t_b_w;
-        for (int i = 0; i < N; ++i) {
-            double* r = poses + (size_t)POSE_STRIDE * i;
-            std::memcpy(r + POSE_R_B2W, w->R_b2w + 9 * i, 9 * sizeof(double));
-            std::memcpy(r + POSE_T_B_W, w->t_b_w + 3 * i, 3 * sizeof(double));
-            std::memcpy(r + POSE_T_FEJ, tfej + 3 * i, 3 * sizeof(double));
-            std::memcpy(r + POSE_R_B2C, w->R_b2c + 9 * i, 9 * sizeof(double));
-            std::memcpy(r + POSE_T_C_B, w->t_c_b + 3 * i, 3 * sizeof(double));
-            r[27] = 0.0;
-        }
-        std::memcpy(st + h->io_optr, tr->obs_ptr, sizeof(int) * (F + 1));
-        std::memcpy(st + h->io_rptr, h->h_row_ptr.data(), sizeof(int) * (F + 1));
-    }
+    std::memcpy(st + h->io_rptr, row_ptr, sizeof(int) * (F + 1));
     // observations grouped by clone: position of every observation in the clone-sorted order, and the row range of
-    // every clone (two rows per observation) for the sparse part of the compression
+    // every clone (two rows per observation) for the sparse part of the compression; the clone indices are checked on the way
     {
         int cnt[ORCVIO_MAX_CLONES + 2] = {0};
-        for (int o = 0; o < nobs; ++o) cnt[tr->obs_clone[o] + 1]++;
+        unsigned bad = 0;
+        for (int o = 0; o < nobs; ++o) {
+            const unsigned c = (unsigned)obs_clone[o];
+            bad |= (c >= (unsigned)N);
+            cnt[(c < (unsigned)N ? c : 0u) + 1]++;
+        }
+        if (bad) { g_last_error = std::string(who) + ": obs_clone out of range"; return ORCVIO_ERR_INVALID; }
         for (int i = 0; i < N; ++i) cnt[i + 1] += cnt[i];
         int* clone_obs = reinterpret_cast<int*>(st + h->io_cobs);
         int fill[ORCVIO_MAX_CLONES + 2];
         std::memcpy(fill, cnt, sizeof(int) * (N + 1));
-        for (int o = 0; o < nobs; ++o) clone_obs[o] = fill[tr->obs_clone[o]]++;
+        for (int o = 0; o < nobs; ++o) clone_obs[o] = fill[obs_clone[o]]++;
         int* cptr = reinterpret_cast<int*>(st + h->io_cptr);   // [0..N] row offsets
         for (int i = 0; i <= N; ++i) cptr[i] = 2 * cnt[i];
         h->s_chunks = N;
     }
-    if (F > 0) {
-        if (tr->p_w) std::memcpy(st + h->io_pw, tr->p_w, sizeof(double) * 3 * F);
-        else std::memset(st + h->io_pw, 0, sizeof(double) * 3 * F);   // positions come from orcvio_msckf_triangulate_uploaded
-        if (nobs > 0) {
-            std::memcpy(st + h->io_oclone, tr->obs_clone, sizeof(int) * nobs);
-            std::memcpy(st + h->io_z, tr->obs_z, sizeof(double) * 2 * nobs);
-            if (with_zvel) std::memcpy(st + h->io_zvel, tr->obs_zvel, sizeof(double) * 2 * nobs);
-        }
-    }
-    HIPCHK(hipMemcpyAsync(h->d_in, st, bytes, hipMemcpyHostToDevice, s));
-    // (no synchronisation: the staging buffer is rewritten only by the next upload, which the caller issues after the
-    // download / sync of this update; the kernels are ordered behind the copy on the same stream)
+    h->m_tot = row_ptr[F];
+    h->Mmax = Mmax;
     // Gram chunking: a workgroup of 16 wavefronts per (tile, chunk); up to 1024 rows per chunk keeps every wavefront
     // at one batch of loads (64 rows) and the number of partial Grams small
     int chunks = (3 * F + 1023) / 1024;
@@ -662,7 +695,65 @@ int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* fl
     h->ran = false;
     h->skip_active = false;
     h->objects_mode = false;   // (a staged object update may have left it set)
+    return ORCVIO_OK;
+}
+
+// the caller's arrays -> the arena (orcvio_msckf_upload and the copying one-shot calls)
+static void stage_inputs(orcvio_msckf_handle* h, const orcvio_msckf_window* w, const orcvio_msckf_tracks* tr, const double* P) {
+    const int N = h->N, F = h->F, nobs = h->nobs;
+    char* st = h->h_stage;
+    if (P) std::memcpy(st + h->io_P, P, sizeof(double) * (size_t)h->n * h->n);
+    double* poses = reinterpret_cast<double*>(st + h->io_poses);
+    const double* tfej = w->t_fej ? w->t_fej : w->t_b_w;
+    for (int i = 0; i < N; ++i) {
+        double* r = poses + (size_t)POSE_STRIDE * i;
+        std::memcpy(r + POSE_R_B2W, w->R_b2w + 9 * i, 9 * sizeof(double));
+        std::memcpy(r + POSE_T_B_W, w->t_b_w + 3 * i, 3 * sizeof(double));
+        std::memcpy(r + POSE_T_FEJ, tfej + 3 * i, 3 * sizeof(double));
+        std::memcpy(r + POSE_R_B2C, w->R_b2c + 9 * i, 9 * sizeof(double));
+        std::memcpy(r + POSE_T_C_B, w->t_c_b + 3 * i, 3 * sizeof(double));
+        r[27] = 0.0;
+    }
+    std::memcpy(st + h->io_optr, tr->obs_ptr, sizeof(int) * (F + 1));
+    if (F > 0) {
+        if (tr->p_w) std::memcpy(st + h->io_pw, tr->p_w, sizeof(double) * 3 * F);
+        else std::memset(st + h->io_pw, 0, sizeof(double) * 3 * F);   // positions come from orcvio_msckf_triangulate_uploaded
+        if (nobs > 0) {
+            std::memcpy(st + h->io_oclone, tr->obs_clone, sizeof(int) * nobs);
+            std::memcpy(st + h->io_z, tr->obs_z, sizeof(double) * 2 * nobs);
+            if (h->io_zvel != h->io_z) std::memcpy(st + h->io_zvel, tr->obs_zvel, sizeof(double) * 2 * nobs);
+        }
+    }
+}
+
+static int upload_to_arena(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
+                           const orcvio_msckf_tracks* tr, const double* P, const char* who) {
+    if (!h || !flags || !w || !tr || !w->R_b2w || !w->t_b_w || !w->R_b2c || !w->t_c_b || !tr->obs_ptr) {
+        g_last_error = std::string(who) + ": null argument";
+        return ORCVIO_ERR_INVALID;
+    }
+    const int N = w->n_clones, F = tr->n_features;
+    if (N < 1 || F < 0) { g_last_error = std::string(who) + ": bad sizes"; return ORCVIO_ERR_INVALID; }
+    if (F > h->maxF) { g_last_error = std::string(who) + ": exceeds handle capacity"; return ORCVIO_ERR_CAPACITY; }
+    if (F > 0 && tr->obs_ptr[0] < 0) { g_last_error = std::string(who) + ": obs_ptr starts below zero"; return ORCVIO_ERR_INVALID; }
+    const int nobs = F > 0 ? tr->obs_ptr[F] : 0;   // (observations in front of obs_ptr[0] are carried along unused)
+    if (F > 0 && nobs > 0 && (!tr->obs_clone || !tr->obs_z)) { g_last_error = std::string(who) + ": null track arrays"; return ORCVIO_ERR_INVALID; }
+    int rc = upload_begin(h, flags, N, F, nobs, P != nullptr, tr->obs_zvel != nullptr, who);
+    if (rc != ORCVIO_OK) return rc;
+    stage_inputs(h, w, tr, P);
+    rc = upload_finalize(h, who);
+    if (rc != ORCVIO_OK) return rc;
     h->pw_missing = (F > 0 && !tr->p_w);
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_upload(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
+                            const orcvio_msckf_tracks* tr, const double* P) {
+    const int rc = upload_to_arena(h, flags, w, tr, P, "orcvio_msckf_upload");
+    if (rc != ORCVIO_OK) return rc;
+    // ONE asynchronous copy (no synchronisation: the staging buffer is rewritten only by the next upload, which the caller
+    // issues after the download / sync of this update; the kernels are ordered behind the copy on the same stream)
+    HIPCHK(hipMemcpyAsync(h->d_in, h->h_stage, upload_bytes(h), hipMemcpyHostToDevice, h->stream));
     return ORCVIO_OK;
 }
 
@@ -763,6 +854,11 @@ static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_
     return ORCVIO_OK;
 }
 
+static int asm_dbg() {   // diagnostics switch of the assembly kernels, read once (getenv on the hot path)
+    static const int v = [] { const char* e = getenv("ORCVIO_ASM_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 // compression: A = X^T X - T3^T T3  (sparse rows summed per clone, dense rows by MFMA Gram)
 static int launch_gram(orcvio_msckf_handle* h, hipStream_t s) {
     const int nb = h->NAP / 16, ntiles = nb * (nb + 1) / 2;
@@ -782,7 +878,7 @@ static int launch_assemble(orcvio_msckf_handle* h, hipStream_t s, double* dst) {
     const int total = h->NAP * h->NAP;
     hipLaunchKernelGGL(k_assemble_A, dim3((total + 255) / 256), dim3(256), 0, s, h->d_S, h->F > 0 ? h->N : 0,
                        h->flags.leg_dim - 15, h->NA, h->NAP, h->d_Gpart, h->chunks, (size_t)total, dst,
-                       getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0, extra_gram(h));
+                       asm_dbg(), extra_gram(h));
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -799,9 +895,13 @@ static int assemble_deferred(orcvio_msckf_handle* h, hipStream_t s) {
     return ORCVIO_OK;
 }
 
-static int launch_reduce(orcvio_msckf_handle* h, hipStream_t s, const double* parts, int nparts, double* dst) {
+// stride: doubles between consecutive blocks (0: packed); meta0: the status words behind the first block of a sharded update
+// (nullptr: none) -- the launch leaves [first failing rank + 1, its status, total dof, total accepted rows] in info[9..12]
+static int launch_reduce(orcvio_msckf_handle* h, hipStream_t s, const double* parts, int nparts, double* dst, size_t stride = 0,
+                         const double* meta0 = nullptr) {
     const int total = h->NAP * h->NAP;
-    hipLaunchKernelGGL(k_gram_reduce, dim3((total + 255) / 256), dim3(256), 0, s, parts, nparts, (size_t)total, h->NAP, dst);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((total + 255) / 256), dim3(256), 0, s, parts, nparts, stride ? stride : (size_t)total, h->NAP, dst,
+                       meta0, h->d_info + 9);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -895,7 +995,7 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
             return launch_potrf(h, s, h->d_P, n, n, 8.0 * eps, h->d_RP, h->d_DinvP, h->d_info);
         case ST_FORM_U:    // U[(NA+1) x kf] = [A; b^T] * L_a
             if (h->A_deferred) {   // A = scatter(S) - sum Gpart assembled inside the product (k_front left the Grams only)
-                AsmArgs aa{h->d_S, h->N, h->flags.leg_dim - 15, NA, NAP, h->d_Gpart, h->front_chunks, (size_t)NAP * NAP, getenv("ORCVIO_ASM_DBG") ? atoi(getenv("ORCVIO_ASM_DBG")) : 0,
+                AsmArgs aa{h->d_S, h->N, h->flags.leg_dim - 15, NA, NAP, h->d_Gpart, h->front_chunks, (size_t)NAP * NAP, asm_dbg(),
                            extra_gram(h)};
                 const int tiles = ((NA + 1 + 15) / 16) * ((kf + 15) / 16);
                 hipLaunchKernelGGL(k_gemm_asmA, dim3(tiles), dim3(256), 0, s, aa, La, sLi, sLj, NA + 1, kf, NA, h->d_U, (long)NP, 1L, (int*)nullptr);
@@ -983,37 +1083,57 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     mix((unsigned long long)(size_t)h->d_ekf_i); mix((unsigned long long)(size_t)h->d_ekf_d); mix((unsigned long long)(size_t)h->d_ekf_E);
     mix((unsigned long long)(size_t)h->d_slam); mix((unsigned long long)(size_t)h->d_dense); mix((unsigned long long)(size_t)h->d_Gekf);
     mix((unsigned long long)(size_t)h->d_Hs); mix((unsigned long long)(size_t)h->d_P);
+    // the resident square-root factor is double-buffered and every user of it is a captured kernel argument (prior_factor):
+    // its address belongs to the signature (a same-shape update after cov_commit replayed the OTHER buffer)
+    mix(h->use_factor ? (unsigned long long)(size_t)h->d_Sres : 0ull);
     mix((unsigned long long)(size_t)s); mix((unsigned long long)(size_t)p0); mix((unsigned long long)extra);
     return sig;
 }
 
 static int run_with_graph(orcvio_msckf_handle* h, orcvio_msckf_handle::GraphSlot& slot, unsigned long long sig, hipStream_t s,
                           const std::function<int(bool)>& enqueue) {
+    typedef orcvio_msckf_handle::GraphSlot::Way Way;
     if (h->use_graph && s != nullptr) {
-        if (!(slot.exec && slot.sig == sig) && sig == slot.last) {
-            if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
-            if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
-            if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                const int rc_c = enqueue(true);
-                hipGraph_t g = nullptr;
-                const hipError_t e_end = hipStreamEndCapture(s, &g);
-                if (rc_c == ORCVIO_OK && e_end == hipSuccess && g && hipGraphInstantiate(&slot.exec, g, nullptr, nullptr, 0) == hipSuccess) {
-                    slot.graph = g;
-                    slot.sig = sig;
+        Way* hit = nullptr;
+        for (Way& w : slot.way)
+            if (w.exec && w.sig == sig) { hit = &w; break; }
+        if (!hit) {
+            bool seen = false;
+            for (unsigned long long v : slot.seen) seen = seen || (v == sig && sig != 0);
+            if (seen) {   // second time: capture into a free way, or over the least recently used one
+                Way* dst = &slot.way[0];
+                for (Way& w : slot.way) {
+                    if (!w.exec) { dst = &w; break; }
+                    if (w.used < dst->used) dst = &w;
+                }
+                if (dst->exec) { (void)hipGraphExecDestroy(dst->exec); dst->exec = nullptr; }
+                if (dst->graph) { (void)hipGraphDestroy(dst->graph); dst->graph = nullptr; }
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                    const int rc_c = enqueue(true);
+                    hipGraph_t g = nullptr;
+                    const hipError_t e_end = hipStreamEndCapture(s, &g);
+                    if (rc_c == ORCVIO_OK && e_end == hipSuccess && g && hipGraphInstantiate(&dst->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                        dst->graph = g;
+                        dst->sig = sig;
+                        hit = dst;
+                    } else {
+                        if (g) (void)hipGraphDestroy(g);
+                        dst->exec = nullptr;
+                        (void)hipGetLastError();
+                        h->use_graph = false;   // capture is not available here: plain launches from now on
+                    }
                 } else {
-                    if (g) (void)hipGraphDestroy(g);
-                    slot.exec = nullptr;
                     (void)hipGetLastError();
-                    h->use_graph = false;   // capture is not available here: plain launches from now on
+                    h->use_graph = false;
                 }
             } else {
-                (void)hipGetLastError();
-                h->use_graph = false;
+                slot.seen[slot.seen_at] = sig;
+                slot.seen_at = (slot.seen_at + 1) & 7;
             }
         }
-        slot.last = sig;
-        if (slot.exec && slot.sig == sig) {
-            HIPCHK(hipGraphLaunch(slot.exec, s));
+        if (hit) {
+            hit->used = ++slot.tick;
+            HIPCHK(hipGraphLaunch(hit->exec, s));
             return ORCVIO_OK;
         }
     }
@@ -1055,22 +1175,28 @@ int32_t orcvio_msckf_block_ptr(orcvio_msckf_handle* h, double** d_block, int64_t
     return ORCVIO_OK;
 }
 
-int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks, void* stream) {
-    if (!h || !h->uploaded || !d_blocks || n_blocks < 1) { g_last_error = "run_finish: invalid"; return ORCVIO_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = pick_stream(h, stream);
+static int run_finish_impl(orcvio_msckf_handle* h, const double* d_blocks, int n_blocks, size_t stride, const double* meta0, hipStream_t s) {
     h->last_stream = s;
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     // the Cholesky of the prior was forked by run_local: join it here (outside the captured part)
     if (h->prior_forked) HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
     h->A_deferred = false;   // d_A is the sum of the gathered blocks
-    int rc = run_with_graph(h, h->g_finish, launch_signature(h, s, d_blocks, n_blocks), s, [&](bool) {
-        int r = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);   // rank-ordered sum of the gathered blocks
+    unsigned long long sig = launch_signature(h, s, d_blocks, n_blocks);
+    sig = (sig ^ (unsigned long long)stride) * 1099511628211ull;
+    sig = (sig ^ (unsigned long long)(size_t)meta0) * 1099511628211ull;
+    int rc = run_with_graph(h, h->g_finish, sig, s, [&](bool) {
+        int r = launch_reduce(h, s, d_blocks, n_blocks, h->d_A, stride, meta0);   // rank-ordered sum of the gathered blocks
         for (int st = ST_FORM_U; st < ST_COUNT && r == ORCVIO_OK; ++st) r = launch_solve_stage(h, s, st);
         return r;
     });
-    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; h->last_run_kind = 1; }
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; h->last_run_kind = 1; h->last_sharded = false; }
     return rc;
+}
+
+int32_t orcvio_msckf_run_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks, void* stream) {
+    if (!h || !h->uploaded || !d_blocks || n_blocks < 1) { g_last_error = "run_finish: invalid"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    return run_finish_impl(h, d_blocks, n_blocks, 0, nullptr, pick_stream(h, stream));
 }
 
 // EKF-SLAM rows of this upload: gate every feature against the prior (2 degrees of freedom), accepted rows -> dense
@@ -1693,14 +1819,18 @@ int32_t orcvio_msckf_run_update(orcvio_msckf_handle* h, void* stream) {
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }   // (a copy of the previous results nobody fetched)
     int rc = run_with_graph(h, h->g_update, launch_signature(h, s, nullptr, 0), s, [&](bool) { return enqueue_update(h, s); });
     h->A_deferred = front_defers_assembly(h);   // (a replayed graph does not pass through enqueue_update)
-    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; h->last_run_kind = 0; }
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = false; h->last_run_kind = 0; h->last_sharded = false; }
     return rc;
 }
 
 int32_t orcvio_msckf_sync(orcvio_msckf_handle* h, void* stream) {
     if (!h) return ORCVIO_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(pick_stream(h, stream)));
+    if (h->comm) {   // the stream may carry a collective: a bounded wait (ORCVIO_ERR_TIMEOUT instead of a hang)
+        const int rw = comm_stream_wait(h, pick_stream(h, stream), "orcvio_msckf_sync");
+        if (rw != ORCVIO_OK) return rw;
+    } else
+        HIPCHK(hipStreamSynchronize(pick_stream(h, stream)));
     HIPCHK(hipStreamSynchronize(h->side));
     return ORCVIO_OK;
 }
@@ -1769,8 +1899,8 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
     if (res->P_out) std::memcpy(res->P_out, so + h->oo_Pout, sizeof(double) * (size_t)n * n);
     if (res->accept && F > 0) std::memcpy(res->accept, acc, sizeof(int) * F);
     if (res->gamma && F > 0) std::memcpy(res->gamma, gam, sizeof(double) * F);
-    int info[9] = {0};
-    std::memcpy(info, so, sizeof(int) * 9);
+    int info[16] = {0};
+    std::memcpy(info, so, sizeof(int) * 16);
     if (info[8] != 0) {   // a wait inside a launch gave up: a workgroup of k_front at its device-wide counter (somebody else's kernel
                           // held CUs it needed), or a solver wavefront of k_potrf_solve
         HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
@@ -1785,35 +1915,24 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
             if (rr != ORCVIO_OK) return rr;
             return orcvio_msckf_download(h, res);   // (a second time-out in the forked form is reported as an error below)
         }
+        // the solve ran through on stale bytes: nothing of this update may be committed
+        h->ran = false;
         g_last_error = "k_potrf_solve / k_front: an in-launch hand-off timed out";
-        return ORCVIO_ERR_NOT_SPD;
+        return ORCVIO_ERR_TIMEOUT;
     }
-    int stacked = 0, nacc = 0;
-    for (int j = 0; j < F; ++j)
-        if (acc[j]) { stacked += h->h_row_ptr[j + 1] - h->h_row_ptr[j]; ++nacc; }
-    std::memset(res->stats, 0, sizeof(res->stats));
-    res->stats[0] = stacked;
-    res->stats[1] = stacked > 0 ? NA : 0;
-    res->stats[2] = nacc;
-    res->stats[3] = stacked > 0 ? 1 : 0;
-    if (h->flags.discard_large_update) {
-        const double nv = std::sqrt(dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
-        const double np = std::sqrt(dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8]);
-        res->stats[4] = (nv > 1.0 || np > 1.5) ? 1 : 0;   // src/orcvio.cpp:4479-4494
+    if (h->last_sharded && info[9] != 0) {   // sharded update: another rank took part with an empty share and a status word
+        h->ran = false;                            // (no rank commits: every rank returns an error)
+        g_last_error = "sharded update: rank " + std::to_string(info[9] - 1) + " could not take part with its tracks (status " + std::to_string(info[10]) + ")";
+        return ORCVIO_ERR_PEER;
     }
-    res->stats[5] = info[0];   // zero-variance directions of the prior (dropped pivots of chol(P))
-    res->stats[6] = info[1];   // pivots of chol(P) below -tol: the prior was not PSD
-    if (info[2] != 0 || info[3] != 0) {   // the device left P and x alone (k_finish_sqrt: P+ = P, dx = 0); the resident covariance is intact
-        h->ran = false;                    // (nothing to commit)
-        g_last_error = "M = s2 I + L^T A L is not positive definite (a prior beyond ~1e16 s2 in scale, or non-finite input): no update";
-        return ORCVIO_ERR_NOT_SPD;
+    {
+        const int ro = feature_outcome(h, so, res->stats);
+        if (ro != ORCVIO_OK) return ro;
     }
-    for (int i = 0; i < n; ++i)
-        if (!std::isfinite(dx[i])) {   // NaN / Inf somewhere in the inputs (a NaN pivot does not show in the smallest pivot)
-            h->ran = false;            // (cov_commit would make a non-finite P+ the resident covariance)
-            g_last_error = "non-finite result (NaN / Inf in the prior, the poses or the noise): no update";
-            return ORCVIO_ERR_NOT_SPD;
-        }
+    if (h->last_sharded) {   // the joint update is applied whenever ANY rank stacked rows (the gathered status words)
+        res->stats[1] = info[12] > 0 ? NA : 0;
+        res->stats[3] = info[12] > 0 ? 1 : 0;
+    }
     const bool want_thin = res->H_thin || res->r_thin;
     if (want_thin || res->K || res->G) {
         int rc = compute_optional(h, want_thin || res->K, res->K != nullptr, res->G != nullptr);
@@ -1846,30 +1965,229 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
     return ORCVIO_OK;
 }
 
+// ---- the zero-copy update (orcvio_msckf_io_begin / _io_update; the copying one-shot calls run on it too) ----------------------
+// ONE graph launch per update: k_ingest (pinned arena -> HBM) -> the update's kernels -> k_check_finite -> [the commit of P+ and
+// its square-root factor] -> k_publish (results -> host-coherent memory, then the flag).  No copy-engine transfer, no stream
+// synchronisation: the calling thread spins on the flag.
+static unsigned long long io_signature(const orcvio_msckf_handle* h, hipStream_t s, bool want_P, bool commit) {
+    unsigned long long sig = launch_signature(h, s, h->h_stage_dev, (long)(0x100 | (want_P ? 1 : 0) | (commit ? 2 : 0)));
+    auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
+    mix((unsigned long long)upload_bytes(h)); mix((unsigned long long)(size_t)h->d_Stmp); mix((unsigned long long)(size_t)h->d_Pres);
+    mix(h->factor_opt); mix((unsigned long long)h->outs_small);
+    return sig;
+}
+
+static int io_enqueue(orcvio_msckf_handle* h, hipStream_t s, bool want_P, bool commit) {
+    const int n = h->n;
+    {   // inputs: one pass over the arena, 16 bytes per lane, enough workgroups for the block to be one or two iterations
+        const size_t n16 = (upload_bytes(h) + 15) / 16;
+        int grid = (int)((n16 + 255) / 256);
+        if (grid > 4 * h->n_cus) grid = 4 * h->n_cus;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, s, reinterpret_cast<const u32x4*>(h->h_stage_dev), reinterpret_cast<u32x4*>(h->d_in), n16);
+    }
+    int rc = enqueue_update(h, s);
+    if (rc != ORCVIO_OK) return rc;
+    hipLaunchKernelGGL(k_check_finite, dim3(1), dim3(64), 0, s, (const double*)h->d_dx, n, h->d_info + 13);
+    if (commit) {   // the device-side twin of orcvio_msckf_cov_commit, refused by the kernels themselves if the update was
+        if (h->factor_opt && h->n_nui == 0) {
+            const PriorFactor pf = prior_factor(h);
+            hipLaunchKernelGGL(k_fac_commit, dim3((h->kf * n + 255) / 256), dim3(256), 0, s, h->d_Z, h->ldz, h->kf, n, h->flags.noise_feature,
+                               (const int*)nullptr, pf.base, pf.sLi, pf.sLj, h->d_Stmp, h->ldz, (const int*)(h->d_info + 2));
+        }
+        const size_t nn = (size_t)n * n;
+        hipLaunchKernelGGL(k_commit_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, (const double*)h->d_Pout, h->d_Pres, nn, (const int*)h->d_info);
+    }
+    PublishArgs pa;
+    pa.small_src = reinterpret_cast<const u32x4*>(h->d_outs);
+    pa.small_dst = reinterpret_cast<u32x4*>(h->h_stage_dev + h->in_cap);
+    pa.small16 = h->outs_small / 16;
+    pa.P_src = reinterpret_cast<const u32x4*>(h->d_outs + h->oo_Pout);
+    pa.P_dst = reinterpret_cast<u32x4*>(h->h_stage_dev + h->in_cap + h->oo_Pout);
+    pa.P16 = want_P ? (sizeof(double) * (size_t)n * n + 15) / 16 : 0;
+    pa.counter = h->d_pubcnt; pa.seq = h->d_seq; pa.flag = h->h_flag_dev;
+    hipLaunchKernelGGL(k_publish, dim3(want_P ? 1 + 48 : 1), dim3(256), 0, s, pa);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+
+// Wait for the next publication: spin on the host-coherent flag (bounded), then fall back to a stream synchronisation.
+static int io_wait(orcvio_msckf_handle* h, hipStream_t s) {
+    const unsigned long long expected = h->flag_seen + 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    bool late = false;
+    while (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) < expected) {
+        _mm_pause();
+        if ((++spins & 4095u) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > h->io_spin_seconds) { late = true; break; }
+    }
+    if (late) {
+        HIPCHK(hipStreamSynchronize(s));   // (the in-launch waits of the kernels are bounded: the stream drains)
+        const unsigned long long now = __atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE);
+        if (now < expected) {
+            h->flag_seen = now;
+            g_last_error = "io_update: the results were not published";
+            return ORCVIO_ERR_TIMEOUT;
+        }
+    }
+    h->flag_seen = __atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE);
+    return ORCVIO_OK;
+}
+
+// statistics and refusals of a finished feature update from the published small block (shared with orcvio_msckf_download)
+static int feature_outcome(orcvio_msckf_handle* h, const char* so, int32_t* stats) {
+    const int n = h->n, F = h->F;
+    const double* dx = reinterpret_cast<const double*>(so + h->oo_dx);
+    const int* acc = reinterpret_cast<const int*>(so + h->oo_accept);
+    const int* info = reinterpret_cast<const int*>(so);
+    int stacked = 0, nacc = 0;
+    const int* row_ptr = h->h_row_ptr.data();
+    for (int j = 0; j < F; ++j)
+        if (acc[j]) { stacked += row_ptr[j + 1] - row_ptr[j]; ++nacc; }
+    if (stats) {
+        std::memset(stats, 0, sizeof(int32_t) * 8);
+        stats[0] = stacked;
+        stats[1] = stacked > 0 ? h->NA : 0;
+        stats[2] = nacc;
+        stats[3] = stacked > 0 ? 1 : 0;
+        if (h->flags.discard_large_update) {
+            const double nv = std::sqrt(dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
+            const double np = std::sqrt(dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8]);
+            stats[4] = (nv > 1.0 || np > 1.5) ? 1 : 0;   // src/orcvio.cpp:4479-4494
+        }
+        stats[5] = info[0];   // zero-variance directions of the prior (dropped pivots of chol(P))
+        stats[6] = info[1];   // pivots of chol(P) below -tol: the prior was not PSD
+    }
+    if (info[2] != 0 || info[3] != 0) {   // the device left P and x alone (k_finish_sqrt: P+ = P, dx = 0); the resident covariance is intact
+        h->ran = false;                    // (nothing to commit)
+        g_last_error = "M = s2 I + L^T A L is not positive definite (a prior beyond ~1e16 s2 in scale, or non-finite input): no update";
+        return ORCVIO_ERR_NOT_SPD;
+    }
+    bool finite = true;
+    for (int i = 0; i < n; ++i) finite = finite && std::isfinite(dx[i]);
+    if (!finite) {   // NaN / Inf somewhere in the inputs (a NaN pivot does not show in the smallest pivot)
+        h->ran = false;   // (cov_commit would make a non-finite P+ the resident covariance)
+        g_last_error = "non-finite result (NaN / Inf in the prior, the poses or the noise): no update";
+        return ORCVIO_ERR_NOT_SPD;
+    }
+    return ORCVIO_OK;
+}
+
+// the update on what stands in the arena (after upload_finalize): results in the pinned output block when this returns
+static int io_run(orcvio_msckf_handle* h, bool want_P, bool commit, int32_t* stats) {
+    if (h->pw_missing) { g_last_error = "update: tracks were uploaded without positions and have not been triangulated"; return ORCVIO_ERR_INVALID; }
+    hipStream_t s = h->stream;
+    h->last_stream = s;
+    if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
+    int rc = run_with_graph(h, h->g_io, io_signature(h, s, want_P, commit), s, [&](bool) { return io_enqueue(h, s, want_P, commit); });
+    h->A_deferred = front_defers_assembly(h);   // (a replayed graph does not pass through enqueue_update)
+    if (rc != ORCVIO_OK) return rc;
+    h->ran = true; h->last_update_objects = false; h->last_run_kind = 0; h->last_sharded = false;
+    rc = io_wait(h, s);
+    if (rc != ORCVIO_OK) { h->ran = false; return rc; }
+    const char* so = h->h_stage + h->in_cap;
+    const int* info = reinterpret_cast<const int*>(so);
+    if (info[8] != 0) {
+        // a workgroup of k_front gave up at its device-wide counter (somebody else's kernel held compute units it needed), or a
+        // solver wavefront of k_potrf_solve: run the update again on the forked path (plain launches, no in-launch device-wide
+        // wait), inside this call; the inputs are in HBM already.  The commit kernels of the first attempt refused themselves.
+        HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
+        HIPCHK(hipMemset(h->d_sync, 0, 256));
+        h->front_retry_forked = true;
+        h->front_fallbacks++;
+        int rr = orcvio_msckf_run_update(h, s);
+        if (rr == ORCVIO_OK) rr = download_enqueue(h, s, want_P);
+        h->front_retry_forked = false;
+        if (rr != ORCVIO_OK) { h->ran = false; return rr; }
+        HIPCHK(hipStreamSynchronize(s));
+        h->dl_pending = false;
+        if (info[8] != 0) {   // (the copy has refreshed the pinned block)
+            HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
+            h->ran = false;
+            g_last_error = "k_potrf_solve / k_front: an in-launch hand-off timed out twice";
+            return ORCVIO_ERR_TIMEOUT;
+        }
+        rr = feature_outcome(h, so, stats);
+        if (rr == ORCVIO_OK && commit) rr = orcvio_msckf_cov_commit(h);
+        return rr;
+    }
+    rc = feature_outcome(h, so, stats);
+    if (rc != ORCVIO_OK) return rc;
+    if (commit) {   // the kernels have written S+ into the spare factor buffer and P+ over the resident covariance
+        if (h->factor_opt && h->n_nui == 0) {
+            std::swap(h->d_Sres, h->d_Stmp);
+            h->fac_n = h->n; h->fac_k = h->kf; h->fac_ld = h->ldz; h->fac_valid = true;
+        } else if (h->n_nui > 0) h->fac_valid = false;   // Schmidt: the nuisance block of P+ is the prior's, so P+ != s2 Z^T Z
+        h->res_n = h->n;
+    }
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_io_begin(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones, int32_t n_features,
+                              int32_t n_observations, int32_t with_P, orcvio_msckf_io* io) {
+    if (!h || !flags || !io) { g_last_error = "io_begin: null argument"; return ORCVIO_ERR_INVALID; }
+    const int rc = upload_begin(h, flags, n_clones, n_features, n_observations, with_P != 0, true, "orcvio_msckf_io_begin");
+    if (rc != ORCVIO_OK) return rc;
+    char* st = h->h_stage;
+    io->n = h->n;
+    io->poses = reinterpret_cast<double*>(st + h->io_poses);
+    io->obs_ptr = reinterpret_cast<int32_t*>(st + h->io_optr);
+    io->p_w = reinterpret_cast<double*>(st + h->io_pw);
+    io->obs_clone = reinterpret_cast<int32_t*>(st + h->io_oclone);
+    io->obs_z = reinterpret_cast<double*>(st + h->io_z);
+    io->obs_zvel = h->io_zvel != h->io_z ? reinterpret_cast<double*>(st + h->io_zvel) : nullptr;
+    io->P = with_P ? reinterpret_cast<double*>(st + h->io_P) : nullptr;
+    const char* so = st + h->in_cap;
+    io->dx = reinterpret_cast<const double*>(so + h->oo_dx);
+    io->gamma = reinterpret_cast<const double*>(so + h->oo_gamma);
+    io->accept = reinterpret_cast<const int32_t*>(so + h->oo_accept);
+    io->P_out = reinterpret_cast<const double*>(so + h->oo_Pout);
+    h->io_open = true;
+    return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_io_update(orcvio_msckf_handle* h, int32_t want_P, int32_t commit, int32_t* stats) {
+    if (!h || !h->io_open) { g_last_error = "io_update: call orcvio_msckf_io_begin first"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = upload_finalize(h, "orcvio_msckf_io_update");
+    if (rc != ORCVIO_OK) return rc;   // (the arena keeps its layout: the caller may repair its arrays and call again)
+    h->pw_missing = false;
+    h->io_open = true;   // ... and may run the next update of the same shape without a new io_begin
+    return io_run(h, want_P != 0, commit != 0, stats);
+}
+
 int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* window,
                                      const orcvio_msckf_tracks* tracks, const double* P, orcvio_msckf_result* result) {
-    // one block in, the launches, one block out, ONE synchronisation
+    // the copying form of orcvio_msckf_io_begin / _io_update: the caller's arrays are copied into the arena, the results out of it
     static const bool timing = getenv("ORCVIO_TIMING") != nullptr;   // diagnostics: calls slower than 2 ms are broken down
     if (!result) { g_last_error = "update_features: null result"; return ORCVIO_ERR_INVALID; }
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = orcvio_msckf_upload(h, flags, window, tracks, P);
+    int rc = upload_to_arena(h, flags, window, tracks, P, "orcvio_msckf_update_features");
     if (rc != ORCVIO_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    rc = orcvio_msckf_run_update(h, nullptr);
-    if (rc != ORCVIO_OK) return rc;
-    rc = download_enqueue(h, h->stream, result->P_out != nullptr);
-    if (rc != ORCVIO_OK) return rc;
-    const auto t2 = std::chrono::steady_clock::now();
-    HIPCHK(hipStreamSynchronize(h->stream));
+    const bool want_P = result->P_out != nullptr;
+    rc = io_run(h, want_P, false, result->stats);
     const auto t3 = std::chrono::steady_clock::now();
-    rc = orcvio_msckf_download(h, result);
+    if (rc != ORCVIO_OK) return rc;
+    const int n = h->n, F = h->F;
+    const char* so = h->h_stage + h->in_cap;
+    if (result->dx) std::memcpy(result->dx, so + h->oo_dx, sizeof(double) * n);
+    if (result->P_out) std::memcpy(result->P_out, so + h->oo_Pout, sizeof(double) * (size_t)n * n);
+    if (result->accept && F > 0) std::memcpy(result->accept, so + h->oo_accept, sizeof(int) * F);
+    if (result->gamma && F > 0) std::memcpy(result->gamma, so + h->oo_gamma, sizeof(double) * F);
+    if (result->H_thin || result->r_thin || result->K || result->G) {   // optional outputs: the staged download computes them
+        orcvio_msckf_result opt = *result;
+        opt.dx = nullptr; opt.P_out = nullptr; opt.accept = nullptr; opt.gamma = nullptr;
+        rc = orcvio_msckf_download(h, &opt);
+        if (rc != ORCVIO_OK) return rc;
+    }
     const auto t4 = std::chrono::steady_clock::now();
     if (timing) {
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         static int calls = 0;
         if (us(t0, t4) > 2000.0 || (++calls % 64) == 0)
-            fprintf(stderr, "update_features: upload %.0f us, enqueue %.0f us, sync %.0f us, unpack %.0f us\n", us(t0, t1), us(t1, t2),
-                    us(t2, t3), us(t3, t4));
+            fprintf(stderr, "update_features: staging %.0f us, launch + wait %.0f us, unpack %.0f us\n", us(t0, t1), us(t1, t3), us(t3, t4));
     }
     return rc;
 }
@@ -2141,7 +2459,7 @@ static int objects_problem(orcvio_msckf_handle* h, const orcvio_msckf_flags* fla
     h->ekf_F = 0; h->dense_rows = 0; h->new_F = 0;
     if (h->n > h->n_max) { g_last_error = "window + extra states exceed the handle's capacity"; return ORCVIO_ERR_CAPACITY; }
     h->NAP = round_up(h->NA + 1, 16);
-    select_prior_factor(h, P);
+    select_prior_factor(h, P != nullptr);
     h->NP = round_up(h->n > h->kf ? h->n : h->kf, 16);
     h->ldz = round_up(h->n + 1, 16);
     h->reg_path = (h->NP / 16) <= 14;
@@ -2512,21 +2830,19 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
 
 // Second part: rank-ordered sum of the gathered blocks, replicated solve, joint chi-square gate with the TOTAL degrees
 // of freedom of all ranks' objects, gated write-back.
-int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks, int32_t dof_total, void* stream) {
-    if (!h || !h->uploaded || !h->objects_mode || !d_blocks || n_blocks < 1) { g_last_error = "objects_finish: no local object block"; return ORCVIO_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = pick_stream(h, stream);
+static int objects_finish_impl(orcvio_msckf_handle* h, const double* d_blocks, int n_blocks, size_t stride, const double* meta0, int dof_total,
+                               hipStream_t s) {
     h->last_stream = s;
-    const int n = h->n, NA = h->NA, NAP = h->NAP;
-    const double sigma2 = h->flags.noise_feature * h->flags.noise_feature;
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
     h->obj_dof = dof_total;
     h->A_deferred = false;
     int rc = ORCVIO_OK;
     if (!(n_blocks == 1 && d_blocks == h->d_A)) {   // (one-shot single-GPU calls compress into d_A: nothing to sum)
-        rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A);
+        rc = launch_reduce(h, s, d_blocks, n_blocks, h->d_A, stride, meta0);
         if (rc != ORCVIO_OK) return rc;
         prof_mark(h, s, "k_gram_reduce");
+    } else {
+        HIPCHK(hipMemsetAsync(h->d_info + 9, 0, sizeof(int) * 4, s));   // (no shard status words in this update)
     }
     // Kalman solve in square-root form, gate, gated write-back
     if (h->prior_forked) HIPCHK(hipStreamWaitEvent(s, h->ev_side, 0));
@@ -2539,8 +2855,16 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
     h->obj_thr = dof_total > 0 ? orcvio_msckf_chi2_quantile(dof_total, h->flags.chi2_prob) : -1.0;
     rc = launch_solve_stage(h, s, ST_FINISH);
     prof_mark(h, s, "k_finish_sqrt (gate inside)");
-    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = true; h->last_run_kind = 2; }
+    if (rc == ORCVIO_OK) { h->ran = true; h->last_update_objects = true; h->last_run_kind = 2; h->last_sharded = meta0 != nullptr; }
     return rc;
+}
+
+// Second part: rank-ordered sum of the gathered blocks, replicated solve, joint chi-square gate with the TOTAL degrees
+// of freedom of all ranks' objects, gated write-back.
+int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks, int32_t dof_total, void* stream) {
+    if (!h || !h->uploaded || !h->objects_mode || !d_blocks || n_blocks < 1) { g_last_error = "objects_finish: no local object block"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    return objects_finish_impl(h, d_blocks, n_blocks, 0, nullptr, dof_total, pick_stream(h, stream));
 }
 
 // Results of an object update (after orcvio_msckf_objects_finish): accept[0], gamma[0], dx, P_out, stats, optional G.
@@ -2565,13 +2889,31 @@ int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_resul
     const double* dx = reinterpret_cast<const double*>(so + h->oo_dx);
     const int acc = *reinterpret_cast<const int*>(so + h->oo_accept);
     double gam = *reinterpret_cast<const double*>(so + h->oo_gamma);
-    int info[9] = {0};
-    std::memcpy(info, so, sizeof(int) * 9);
-    if (info[8] != 0) {   // a solver wavefront of k_potrf_solve gave up waiting for the factorisation workgroup
+    int info[16] = {0};
+    std::memcpy(info, so, sizeof(int) * 16);
+    if (info[8] != 0) {   // a solver wavefront of k_potrf_solve gave up waiting for the factorisation workgroup: the solve ran
+                          // through on stale bytes and nothing of this update may be committed
         HIPCHK(hipMemset(h->d_info + 8, 0, sizeof(int)));
+        h->ran = false;
         g_last_error = "k_potrf_solve: an in-launch hand-off timed out";
+        return ORCVIO_ERR_TIMEOUT;
+    }
+    if (h->last_sharded && info[9] != 0) {   // sharded update: another rank took part with an empty share and a status word
+        h->ran = false;
+        g_last_error = "sharded object update: rank " + std::to_string(info[9] - 1) + " could not take part with its tracks (status " + std::to_string(info[10]) + ")";
+        return ORCVIO_ERR_PEER;
+    }
+    if (info[2] != 0 || info[3] != 0) {   // as orcvio_msckf_download: the device left P and x alone, nothing to commit
+        h->ran = false;
+        g_last_error = "M = s2 I + L^T A L is not positive definite (a prior beyond ~1e16 s2 in scale, or non-finite input): no update";
         return ORCVIO_ERR_NOT_SPD;
     }
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(dx[i])) {
+            h->ran = false;   // (cov_commit would make a non-finite P+ the resident covariance)
+            g_last_error = "non-finite result (NaN / Inf in the prior, the rows or the noise): no update";
+            return ORCVIO_ERR_NOT_SPD;
+        }
     if (res->dx) std::memcpy(res->dx, dx, sizeof(double) * n);
     if (res->P_out) std::memcpy(res->P_out, so + h->oo_Pout, sizeof(double) * (size_t)n * n);
     if (dof == 0) gam = NAN;   // no usable object on any rank (the reference returns before the gate, :2157)
@@ -2688,9 +3030,15 @@ int32_t orcvio_msckf_update_object_lm_msgs(orcvio_msckf_handle* h, const orcvio_
             (m.n_frames > 0 && (!m.valid_camera_pose_mat || !m.timestamps || !m.zs_num_wrt_timestamps))) {
             g_last_error = "update_object_lm_msgs: malformed message"; return ORCVIO_ERR_INVALID;
         }
-        int sum_zs = 0;
-        for (int f = 0; f < m.n_frames; ++f) sum_zs += 2 * m.zs_num_wrt_timestamps[f];
-        if (sum_zs + 4 * m.n_frames > m.n_rows) { g_last_error = "update_object_lm_msgs: fewer rows than 2 x keypoints + 4 x frames"; return ORCVIO_ERR_INVALID; }
+        if (m.n_obj_cols > 112) { g_last_error = "update_object_lm_msgs: object state columns must be 1..112"; return ORCVIO_ERR_INVALID; }
+        long sum_zs_l = 0;
+        for (int f = 0; f < m.n_frames; ++f) {
+            // counts arrive from the wire: a negative one would lower the sum and let a row range start outside the arrays
+            if (m.zs_num_wrt_timestamps[f] < 0 || m.zs_num_wrt_timestamps[f] > (1 << 20)) { g_last_error = "update_object_lm_msgs: negative keypoint count"; return ORCVIO_ERR_INVALID; }
+            sum_zs_l += 2L * m.zs_num_wrt_timestamps[f];
+        }
+        if (sum_zs_l + 4L * m.n_frames > (long)m.n_rows) { g_last_error = "update_object_lm_msgs: fewer rows than 2 x keypoints + 4 x frames"; return ORCVIO_ERR_INVALID; }
+        const int sum_zs = (int)sum_zs_l;
         const int nr = m.n_rows, nc = m.n_obj_cols, nf = m.n_frames;
         // element (i, j) of a rows x cols wire matrix
         auto at = [&](const double* d, int rws, int cls, int i, int j) { return wire_row_major ? d[(size_t)i * cls + j] : d[(size_t)j * rws + i]; };
@@ -2824,18 +3172,27 @@ int32_t orcvio_msckf_object_rows_eval(orcvio_msckf_handle* h, const orcvio_objec
 // ---- multi-GPU: RCCL communicator owned by the handle ---------------------------------------
 // RCCL is loaded with dlopen on first use, so the library has no link-time dependency on it and a single-GPU caller
 // never loads it.  In a process that already holds librccl.so.1 (PyTorch ships one) the same instance is reused.
+// Every wait that another rank can strand is BOUNDED (ORCVIO_COMM_TIMEOUT_S, default 180 s): the creation of the
+// communicator runs on a helper thread the caller stops waiting for, the streams that carry a collective are polled; a
+// time-out aborts the communicator and returns ORCVIO_ERR_TIMEOUT -- never a hang.
 namespace {
 struct RcclApi {
     void* lib = nullptr;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 RcclApi g_rccl;
+double comm_timeout_seconds() {
+    static const double t = [] { const char* e = getenv("ORCVIO_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 180.0; return v > 0.0 ? v : 180.0; }();
+    return t;
+}
 }  // namespace
 
 static int rccl_load() {
@@ -2855,8 +3212,8 @@ static int rccl_load() {
     a.lib = lib;
 #define RCCL_SYM(name) a.name = reinterpret_cast<decltype(a.name)>(dlsym(lib, "nccl" #name)); \
     if (!a.name) { g_last_error = "RCCL: symbol nccl" #name " missing"; dlclose(lib); return ORCVIO_ERR_NO_DEVICE; }
-    RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(AllGather) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd)
-    RCCL_SYM(GetErrorString)
+    RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(CommAbort) RCCL_SYM(AllGather) RCCL_SYM(AllReduce)
+    RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd) RCCL_SYM(GetErrorString)
 #undef RCCL_SYM
     g_rccl = a;
     return ORCVIO_OK;
@@ -2870,27 +3227,84 @@ static int rccl_load() {
         }                                                                                                   \
     } while (0)
 
+// A blocking RCCL call on a helper thread, waited for with a bound.  If the caller gives up, the thread is left to finish (or
+// to sit) on its own and cleans up what it produced; the shared state outlives both.
+namespace {
+struct BoundedCall {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    ncclResult_t result = ncclSuccess;
+    ncclComm_t comm = nullptr;
+    ncclUniqueId id;
+};
+}  // namespace
+
 int32_t orcvio_msckf_comm_unique_id(uint8_t* id) {
     if (!id) { g_last_error = "comm_unique_id: null"; return ORCVIO_ERR_INVALID; }
     { const int rl = rccl_load(); if (rl != ORCVIO_OK) return rl; }
     static_assert(sizeof(ncclUniqueId) == ORCVIO_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
-    ncclUniqueId u;
-    RCCLCHK(g_rccl.GetUniqueId(&u));
-    std::memcpy(id, &u, sizeof(u));
+    auto st = std::make_shared<BoundedCall>();
+    std::thread([st] {
+        ncclUniqueId u;
+        const ncclResult_t r = g_rccl.GetUniqueId(&u);
+        std::lock_guard<std::mutex> lk(st->m);
+        st->id = u; st->result = r; st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(st->m);
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(comm_timeout_seconds()), [&] { return st->done; })) {
+        st->abandoned = true;
+        g_last_error = "comm_unique_id: ncclGetUniqueId did not return within ORCVIO_COMM_TIMEOUT_S";
+        return ORCVIO_ERR_TIMEOUT;
+    }
+    if (st->result != ncclSuccess) { g_last_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(st->result); return ORCVIO_ERR_HIP; }
+    std::memcpy(id, &st->id, sizeof(ncclUniqueId));
     return ORCVIO_OK;
+}
+
+// a rank that never arrives leaves the others in a collective for ever: give the communicator up instead
+static void comm_abort(orcvio_msckf_handle* h) {
+    if (h->comm) { (void)g_rccl.CommAbort(h->comm); h->comm = nullptr; }
+    h->comm_world = 0; h->comm_rank = 0;
+    h->graph_epoch++;
+}
+
+// Wait for a stream that carries a collective: polled, bounded.  Spins for the first two milliseconds (an update takes a
+// fraction of one), then naps between polls.
+static int comm_stream_wait(orcvio_msckf_handle* h, hipStream_t s, const char* who) {
+    if (!h->comm) { HIPCHK(hipStreamSynchronize(s)); return ORCVIO_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = comm_timeout_seconds();
+    for (unsigned it = 0;; ++it) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return ORCVIO_OK;
+        if (e != hipErrorNotReady) { g_last_error = std::string(who) + ": " + hipGetErrorString(e); return ORCVIO_ERR_HIP; }
+        if ((it & 63u) == 63u) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > limit) {
+                comm_abort(h);
+                g_last_error = std::string(who) + ": a rank did not arrive at the collective within ORCVIO_COMM_TIMEOUT_S; the communicator has been aborted";
+                return ORCVIO_ERR_TIMEOUT;
+            }
+            if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+    }
 }
 
 int32_t orcvio_msckf_comm_destroy(orcvio_msckf_handle* h) {
     if (!h) return ORCVIO_ERR_INVALID;
     if (h->comm) {
         (void)hipSetDevice(h->device);
-        (void)hipDeviceSynchronize();
-        (void)g_rccl.CommDestroy(h->comm);
+        (void)comm_stream_wait(h, h->stream, "comm_destroy");
+        if (h->comm && h->comm_stream) (void)comm_stream_wait(h, h->comm_stream, "comm_destroy");
+        if (h->comm) (void)g_rccl.CommDestroy(h->comm);
         h->comm = nullptr;
     }
     if (h->d_gather) { (void)hipFree(h->d_gather); h->d_gather = nullptr; }
     if (h->d_dofs) { (void)hipFree(h->d_dofs); h->d_dofs = nullptr; }
     if (h->h_dofs) { (void)hipHostFree(h->h_dofs); h->h_dofs = nullptr; }
+    if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
     h->comm_world = 0; h->comm_rank = 0;
     h->graph_epoch++;
     return ORCVIO_OK;
@@ -2899,16 +3313,38 @@ int32_t orcvio_msckf_comm_destroy(orcvio_msckf_handle* h) {
 int32_t orcvio_msckf_comm_init(orcvio_msckf_handle* h, const uint8_t* id, int32_t rank, int32_t world) {
     if (!h || !id || world < 1 || rank < 0 || rank >= world) { g_last_error = "comm_init: invalid rank / world"; return ORCVIO_ERR_INVALID; }
     { const int rl = rccl_load(); if (rl != ORCVIO_OK) return rl; }
-    if (h->comm) (void)orcvio_msckf_comm_destroy(h);
+    if (h->comm || h->d_gather) (void)orcvio_msckf_comm_destroy(h);
     HIPCHK(hipSetDevice(h->device));
-    ncclUniqueId u;
-    std::memcpy(&u, id, sizeof(u));
-    RCCLCHK(g_rccl.CommInitRank(&h->comm, world, u, rank));
+    auto st = std::make_shared<BoundedCall>();
+    std::memcpy(&st->id, id, sizeof(ncclUniqueId));
+    const int device = h->device;
+    std::thread([st, device, world, rank] {
+        (void)hipSetDevice(device);
+        ncclComm_t c = nullptr;
+        const ncclResult_t r = g_rccl.CommInitRank(&c, world, st->id, rank);
+        std::unique_lock<std::mutex> lk(st->m);
+        st->result = r; st->comm = c; st->done = true;
+        const bool orphan = st->abandoned;
+        st->cv.notify_all();
+        lk.unlock();
+        if (orphan && r == ncclSuccess && c) (void)g_rccl.CommAbort(c);   // nobody is waiting for it any more
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(st->m);
+        if (!st->cv.wait_for(lk, std::chrono::duration<double>(comm_timeout_seconds()), [&] { return st->done; })) {
+            st->abandoned = true;
+            g_last_error = "comm_init: ncclCommInitRank did not return within ORCVIO_COMM_TIMEOUT_S (a rank missing, or the bootstrap stuck)";
+            return ORCVIO_ERR_TIMEOUT;
+        }
+        if (st->result != ncclSuccess) { g_last_error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(st->result); return ORCVIO_ERR_HIP; }
+        h->comm = st->comm;
+    }
     h->comm_rank = rank; h->comm_world = world;
-    const size_t pp = (size_t)h->NAP_max * h->NAP_max;
-    HIPCHK(hipMalloc(&h->d_gather, sizeof(double) * pp * world));
-    HIPCHK(hipMalloc(&h->d_dofs, sizeof(double) * 2 * world));
-    HIPCHK(hipHostMalloc(&h->h_dofs, sizeof(double) * 2 * world, hipHostMallocDefault));
+    const size_t slot = (size_t)h->NAP_max * h->NAP_max + ORCVIO_SHARD_META;
+    HIPCHK(hipMalloc(&h->d_gather, sizeof(double) * slot * world));
+    HIPCHK(hipMalloc(&h->d_dofs, sizeof(double) * 2 * (world + 8)));
+    HIPCHK(hipHostMalloc(&h->h_dofs, sizeof(double) * 2 * (world + 8), hipHostMallocDefault));
+    HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     h->graph_epoch++;
     return ORCVIO_OK;
 }
@@ -2920,36 +3356,80 @@ int32_t orcvio_msckf_comm_info(orcvio_msckf_handle* h, int32_t* rank, int32_t* w
     return ORCVIO_OK;
 }
 
-// this rank's tracks -> its block, written straight into its slot of the gather buffer -> in-place all-gather (the one
-// data-path collective; <= 295 KB per rank, latency-bound over xGMI) -> rank-ordered sum + replicated solve
+// max over the ranks of count <= 8 doubles (the bench contract's MAX over ranks; a caller's own consistency checks), through the
+// handle's communicator on the handle's stream: everything enqueued there before is finished on every rank when it returns, so
+// with count = 0 this is the barrier.
+int32_t orcvio_msckf_comm_allreduce_max(orcvio_msckf_handle* h, double* values, int32_t count) {
+    if (!h || count < 0 || count > 8 || (count > 0 && !values)) { g_last_error = "comm_allreduce_max: 0..8 values"; return ORCVIO_ERR_INVALID; }
+    if (!h->comm) { g_last_error = "comm_allreduce_max: no communicator (orcvio_msckf_comm_init)"; return ORCVIO_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    double* hb = h->h_dofs + 2 * h->comm_world;       // pinned scratch behind the dofs: [8]
+    double* db = h->d_dofs + 2 * h->comm_world;
+    for (int i = 0; i < 8; ++i) hb[i] = i < count ? values[i] : 0.0;
+    HIPCHK(hipMemcpyAsync(db, hb, sizeof(double) * 8, hipMemcpyHostToDevice, s));
+    RCCLCHK(g_rccl.AllReduce(db, db, 8, ncclDouble, ncclMax, h->comm, s));
+    HIPCHK(hipMemcpyAsync(hb, db, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
+    { const int rw = comm_stream_wait(h, s, "comm_allreduce_max"); if (rw != ORCVIO_OK) return rw; }
+    for (int i = 0; i < count; ++i) values[i] = hb[i];
+    return ORCVIO_OK;
+}
+int32_t orcvio_msckf_comm_barrier(orcvio_msckf_handle* h) { return orcvio_msckf_comm_allreduce_max(h, nullptr, 0); }
+
+// this rank's tracks -> its block, written straight into its slot of the gather buffer, a few status words behind it -> in-place
+// all-gather (the one data-path collective; <= 295 KB per rank, latency-bound over xGMI) -> rank-ordered sum + replicated solve
+static inline size_t shard_slot(const orcvio_msckf_handle* h) { return (size_t)h->NAP * h->NAP + ORCVIO_SHARD_META; }
+
 int32_t orcvio_msckf_run_update_sharded(orcvio_msckf_handle* h, void* stream) {
     if (!h || !h->uploaded || h->pw_missing) { g_last_error = "run_update_sharded: nothing uploaded (or positions missing)"; return ORCVIO_ERR_INVALID; }
     if (!h->comm) { g_last_error = "run_update_sharded: no communicator (orcvio_msckf_comm_init)"; return ORCVIO_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
-    const size_t ne = (size_t)h->NAP * h->NAP;
-    double* mine = h->d_gather + ne * h->comm_rank;
+    const size_t ne = (size_t)h->NAP * h->NAP, slot = shard_slot(h);
+    double* mine = h->d_gather + slot * h->comm_rank;
     int rc = run_local_impl(h, s, mine);
     if (rc != ORCVIO_OK) return rc;
-    RCCLCHK(g_rccl.AllGather(mine, h->d_gather, ne, ncclDouble, h->comm, s));
-    return orcvio_msckf_run_finish(h, h->d_gather, h->comm_world, s);
+    hipLaunchKernelGGL(k_shard_meta, dim3(1), dim3(64), 0, s, mine + ne, h->shard_status, 0, h->F > 0 ? (const int*)h->d_accept : (const int*)nullptr,
+                       (const int*)h->d_row_ptr, h->F);
+    HIPCHK(hipGetLastError());
+    RCCLCHK(g_rccl.AllGather(mine, h->d_gather, slot, ncclDouble, h->comm, s));
+    rc = run_finish_impl(h, h->d_gather, h->comm_world, slot, h->d_gather + ne, s);
+    h->last_sharded = rc == ORCVIO_OK;
+    return rc;
 }
+
+// a status that only THIS rank's share can have caused (the window and the prior are replicated, so every other refusal hits
+// all ranks alike, before the collective)
+static inline bool per_rank_status(int rc) { return rc == ORCVIO_ERR_CAPACITY || rc == ORCVIO_ERR_TRACK_TOO_LONG || rc == ORCVIO_ERR_INVALID; }
 
 int32_t orcvio_msckf_update_features_sharded(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* window,
                                              const orcvio_msckf_tracks* tracks, const double* P, orcvio_msckf_result* result) {
-    if (!result) { g_last_error = "update_features_sharded: null result"; return ORCVIO_ERR_INVALID; }
-    int rc = orcvio_msckf_upload(h, flags, window, tracks, P);
+    if (!h || !result) { g_last_error = "update_features_sharded: null argument"; return ORCVIO_ERR_INVALID; }
+    if (!h->comm) { g_last_error = "update_features_sharded: no communicator (orcvio_msckf_comm_init)"; return ORCVIO_ERR_INVALID; }
+    int own = ORCVIO_OK;
+    std::string own_error;
+    int rc = upload_to_arena(h, flags, window, tracks, P, "orcvio_msckf_update_features_sharded");
+    if (rc != ORCVIO_OK && per_rank_status(rc)) {
+        // This rank's tracks were refused.  The other ranks are on their way into the all-gather: take part with an EMPTY share
+        // and a status word, so that nobody waits for ever and every rank learns of it (ORCVIO_ERR_PEER).
+        own = rc; own_error = g_last_error;
+        const int32_t zero = 0;
+        orcvio_msckf_tracks none{};
+        none.n_features = 0; none.obs_ptr = &zero;
+        rc = upload_to_arena(h, flags, window, &none, P, "orcvio_msckf_update_features_sharded");
+        if (rc != ORCVIO_OK) { g_last_error = own_error; return own; }   // the window itself is unusable: every rank returns here alike
+    }
     if (rc != ORCVIO_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_in, h->h_stage, upload_bytes(h), hipMemcpyHostToDevice, h->stream));
+    h->shard_status = own;
     rc = orcvio_msckf_run_update_sharded(h, nullptr);
+    h->shard_status = 0;
     if (rc != ORCVIO_OK) return rc;
     rc = download_enqueue(h, h->stream, result->P_out != nullptr);
     if (rc != ORCVIO_OK) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    { const int rw = comm_stream_wait(h, h->stream, "update_features_sharded"); if (rw != ORCVIO_OK) { h->ran = false; h->dl_pending = false; return rw; } }
     rc = orcvio_msckf_download(h, result);
-    if (rc == ORCVIO_OK) {   // the joint update is applied whenever ANY rank stacked rows: P+ != P decides, not the local count
-        result->stats[1] = h->NA;
-        result->stats[3] = 1;
-    }
+    if (own != ORCVIO_OK) { g_last_error = own_error; return own; }
     return rc;
 }
 
@@ -2965,25 +3445,42 @@ int32_t orcvio_msckf_update_object_tracks_sharded(orcvio_msckf_handle* h, const 
     // NAP is a function of the window only: known before the local part runs
     const int n = flags ? flags->leg_dim + 6 * n_clones + h->n_extra : 0;
     const int NA = h->ekf_mode ? n - 15 : n - h->n_extra - 15;
-    const size_t ne = (size_t)round_up(NA + 1, 16) * round_up(NA + 1, 16);
-    double* mine = h->d_gather + ne * rank;
+    const size_t ne = (size_t)round_up(NA + 1, 16) * round_up(NA + 1, 16), slot = ne + ORCVIO_SHARD_META;
+    if (flags && (NA < 1 || round_up(NA + 1, 16) > h->NAP_max)) { g_last_error = "update_object_tracks_sharded: window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
+    double* mine = h->d_gather + slot * rank;
     int32_t dof = 0;
+    int own = ORCVIO_OK;
+    std::string own_error;
     int rc = orcvio_msckf_objects_local_tracks(h, flags, eval_flags, n_clones, tracks, n_tracks, P, mine, &dof, nullptr);
+    if (rc != ORCVIO_OK && per_rank_status(rc) && flags && eval_flags) {   // this rank's tracks were refused: an empty share + a status word
+        own = rc; own_error = g_last_error;
+        rc = orcvio_msckf_objects_local_tracks(h, flags, eval_flags, n_clones, nullptr, 0, P, mine, &dof, nullptr);
+        if (rc != ORCVIO_OK) { g_last_error = own_error; return own; }   // the window / prior is unusable: every rank returns here alike
+        dof = 0;
+    }
     if (rc != ORCVIO_OK) return rc;
+    hipLaunchKernelGGL(k_shard_meta, dim3(1), dim3(64), 0, s, mine + ne, own, (int)dof, (const int*)nullptr, (const int*)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    // The gate's threshold is the chi-square quantile of the TOTAL degrees of freedom, host arithmetic above 500 like the
+    // reference's (src/orcvio.cpp:1962-1968), and every rank knows its own share of them before its kernels have run: the
+    // dofs travel FIRST, on a stream of their own, and the host reads them while the device works on this rank's rows -- no
+    // synchronisation in the middle of the update.
     h->h_dofs[world + rank] = (double)dof;
-    HIPCHK(hipMemcpyAsync(h->d_dofs + rank, h->h_dofs + world + rank, sizeof(double), hipMemcpyHostToDevice, s));
-    RCCLCHK(g_rccl.GroupStart());
-    RCCLCHK(g_rccl.AllGather(mine, h->d_gather, ne, ncclDouble, h->comm, s));
-    RCCLCHK(g_rccl.AllGather(h->d_dofs + rank, h->d_dofs, 1, ncclDouble, h->comm, s));
-    RCCLCHK(g_rccl.GroupEnd());
-    HIPCHK(hipMemcpyAsync(h->h_dofs, h->d_dofs, sizeof(double) * world, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));   // the gate threshold is a function of the total dof (host-side quantile)
+    HIPCHK(hipMemcpyAsync(h->d_dofs + rank, h->h_dofs + world + rank, sizeof(double), hipMemcpyHostToDevice, h->comm_stream));
+    RCCLCHK(g_rccl.AllGather(h->d_dofs + rank, h->d_dofs, 1, ncclDouble, h->comm, h->comm_stream));
+    HIPCHK(hipMemcpyAsync(h->h_dofs, h->d_dofs, sizeof(double) * world, hipMemcpyDeviceToHost, h->comm_stream));
+    RCCLCHK(g_rccl.AllGather(mine, h->d_gather, slot, ncclDouble, h->comm, s));
+    { const int rw = comm_stream_wait(h, h->comm_stream, "update_object_tracks_sharded"); if (rw != ORCVIO_OK) return rw; }
     int dof_total = 0;
     for (int r = 0; r < world; ++r) dof_total += (int)h->h_dofs[r];
-    rc = orcvio_msckf_objects_finish(h, h->d_gather, world, dof_total, nullptr);
+    rc = objects_finish_impl(h, h->d_gather, world, slot, h->d_gather + ne, dof_total, s);
     if (rc != ORCVIO_OK) return rc;
+    rc = download_enqueue(h, s, res->P_out != nullptr);
+    if (rc != ORCVIO_OK) return rc;
+    { const int rw = comm_stream_wait(h, s, "update_object_tracks_sharded"); if (rw != ORCVIO_OK) { h->ran = false; h->dl_pending = false; return rw; } }
     rc = orcvio_msckf_objects_download(h, res);
     h->objects_mode = false;
+    if (own != ORCVIO_OK) { g_last_error = own_error; return own; }
     return rc;
 }
 

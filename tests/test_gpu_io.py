@@ -1,0 +1,134 @@
+"""The zero-copy boundary (orcvio_msckf_io_begin / _io_update: the handle's pinned arena written and read in place, inputs pulled
+by the first kernel of the graph, results pushed into host-coherent memory by the last, the caller waiting on a flag word) and
+the launch-graph cache behind it, against the oracle -- and the sequence ADVICE r2 (high) describes: more than three same-shape
+updates on the resident covariance, each followed by a commit, where a single graph keyed without the address of the
+double-buffered square-root factor replayed a stale factor."""
+import numpy as np
+import pytest
+
+from orcvio_amd import capi, synth
+from oracle import oracle
+from helpers import rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def upd(built):
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=1024, max_observations=32768)
+    yield u
+    u.close()
+
+
+def _ref(win):
+    return oracle.msckf_update(win, want_blocks=False, want_K=False)
+
+
+@pytest.mark.parametrize('shape', [dict(N=8, F=40, track_len=(3, 8)), dict(N=20, F=150, track_len=(3, 6)), dict(N=30, F=400, track_len=None),
+                                   dict(N=30, F=700, track_len=None)])
+def test_io_update_equals_the_oracle(upd, shape):
+    win = synth.make_window(seed=11, outlier_frac=0.1, **shape)
+    ref = _ref(win)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]))
+    upd.io_fill(io, win)
+    for it in range(5):   # plain launches, then the captured graph, then its replays
+        stats = upd.io_update(want_P=True)
+        assert np.array_equal(io['accept'], ref['accept']), it
+        assert rel(io['dx'], ref['dx']) < 1e-6 and rel(io['P_out'], ref['P_new']) < 1e-6, it
+        assert np.allclose(io['gamma'], ref['gamma'], rtol=1e-8, equal_nan=True)
+        assert stats[2] == int(ref['accept'].sum()) and stats[3] == 1
+        io['dx'][:] = 0.0; io['P_out'][:] = 0.0; io['accept'][:] = -1   # the next publication must rewrite them
+    # the copying call runs on the same machinery
+    got = upd.update_features(win, want_G=True)
+    assert rel(got['dx'], ref['dx']) < 1e-6 and rel(got['P_new'], ref['P_new']) < 1e-6 and rel(got['G'], ref['G']) < 1e-6
+
+
+def test_new_inputs_in_the_same_arena(upd):
+    """One io_begin, several frames of the same sizes with different contents: the arena is re-read by every update."""
+    wins = [synth.make_window(N=12, F=60, seed=s, track_len=8, outlier_frac=0.2) for s in (1, 2, 3, 4)]
+    io = upd.io_begin(wins[0].flags, 12, 60, int(wins[0].obs_ptr[-1]))
+    for w in wins * 2:
+        upd.io_fill(io, w)
+        upd.io_update(want_P=True)
+        ref = _ref(w)
+        assert np.array_equal(io['accept'], ref['accept'])
+        assert rel(io['dx'], ref['dx']) < 1e-6 and rel(io['P_out'], ref['P_new']) < 1e-6
+
+
+def test_arena_contents_are_validated(upd):
+    win = synth.make_window(N=6, F=10, seed=1, track_len=(3, 6))
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]))
+    upd.io_fill(io, win)
+    io['obs_clone'][3] = 99
+    with pytest.raises(capi.MsckfError) as e:
+        upd.io_update()
+    assert e.value.code == 1
+    io['obs_clone'][3] = win.obs_clone[3]
+    io['obs_ptr'][4] = io['obs_ptr'][3] - 1
+    with pytest.raises(capi.MsckfError):
+        upd.io_update()
+    upd.io_fill(io, win)   # repaired: the same arena works
+    upd.io_update()
+    assert rel(io['dx'], _ref(win)['dx']) < 1e-6
+    with pytest.raises(capi.MsckfError):   # more observations than the handle holds
+        upd.io_begin(win.flags, win.N, win.F, 10 ** 7)
+
+
+@pytest.mark.parametrize('prefactor', [False, True])
+@pytest.mark.parametrize('path', ['io', 'copying'])
+def test_same_shape_updates_on_the_resident_covariance(upd, prefactor, path):
+    """update + commit, six times, same shape, the prior resident -- every update must see the factor the
+    previous commit left (it alternates between two buffers) and equal the oracle's chain."""
+    N, F = 10, 80
+    wins = [synth.make_window(N=N, F=F, seed=100 + k, track_len=N, sigma_px=0.008) for k in range(6)]
+    P = wins[0].P.copy()
+    upd.cov_set(P)
+    if prefactor:
+        upd.cov_prefactor()
+    if path == 'io':
+        io = upd.io_begin(wins[0].flags, N, F, int(wins[0].obs_ptr[-1]), with_P=False)
+    for k, w in enumerate(wins):
+        w.P[:] = P
+        ref = _ref(w)
+        if path == 'io':
+            upd.io_fill(io, w, with_P=False)
+            upd.io_update(want_P=False, commit=True)
+            dx, acc = io['dx'].copy(), io['accept'].copy()
+        else:
+            got = upd.update_features(w, resident_cov=True, want_P=False)
+            upd.cov_commit()
+            dx, acc = got['dx'], got['accept']
+        assert np.array_equal(acc, ref['accept']), k
+        assert rel(dx, ref['dx']) < 1e-6, (k, rel(dx, ref['dx']))
+        P = ref['P_new']
+        assert rel(upd.cov_get(), P) < 1e-6, k
+
+
+def test_refused_update_is_not_committed(upd):
+    """A non-finite prior: the device refuses the update (ORCVIO_ERR_NOT_SPD) and the commit inside the same launch refuses itself."""
+    win = synth.make_window(N=8, F=30, seed=5, track_len=8)
+    upd.cov_set(win.P)
+    good = upd.cov_get()
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=True)
+    upd.io_fill(io, win)
+    io['P'][20, 20] = np.nan
+    with pytest.raises(capi.MsckfError) as e:
+        upd.io_update(want_P=True, commit=True)
+    assert e.value.code == 6
+    assert np.array_equal(upd.cov_get(), good)
+    with pytest.raises(capi.MsckfError):
+        upd.cov_commit()
+    upd.io_fill(io, win)
+    upd.io_update(want_P=True, commit=True)
+    assert rel(upd.cov_get(), _ref(win)['P_new']) < 1e-6
+
+
+def test_graph_cache_keeps_several_shapes(upd):
+    """Shapes that alternate (the feature update and the prune update of a frame) each keep their captured graph."""
+    a = synth.make_window(N=10, F=50, seed=1, track_len=10)
+    b = synth.make_window(N=10, F=20, seed=2, track_len=(3, 5))
+    ra, rb = _ref(a), _ref(b)
+    for _ in range(6):
+        ga = upd.update_features(a)
+        gb = upd.update_features(b)
+        assert rel(ga['dx'], ra['dx']) < 1e-6 and rel(gb['dx'], rb['dx']) < 1e-6
