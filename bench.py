@@ -6,14 +6,22 @@ Kalman solve -> dx, P+) on inputs already resident in HBM (the contract's `value
 N=1: config 2 (30 clones x 400 features x 30 observations).  N>1 (weak scaling): every rank holds its own shard of
 400 features of ONE joint update; per step the ranks all-gather their compressed blocks over RCCL -- through the
 communicator the library handle owns (orcvio_msckf_comm_init / orcvio_msckf_run_update_sharded) -- and each performs
-the replicated Kalman solve.
+the replicated Kalman solve.  There is ONE RCCL communicator per process: the handle's.  The contract's barrier and
+max-over-ranks go through it (orcvio_msckf_comm_barrier / _comm_allreduce_max); the 128-byte unique id travels through a
+file under the temporary directory -- no torch.distributed process group is created.
 
 `python bench.py --gpus N` without a launcher spawns the N ranks itself (torch.distributed.run, before anything in this
 process touches a GPU); under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
 
-Besides the contract line, the N=1 run reports the per-update LATENCY distribution (median / p95 over >= 200 updates,
-SURVEY.md 8d) in three modes: device-resident, host-visible (flat inputs in host memory -> dx, P+ in host memory) and
-host-visible with the covariance resident in HBM (tracks + poses in, dx out).
+Besides the contract line, the N=1 run reports
+  latency        per-update latency (median / p95 over >= 200 updates): device-resident, host-visible through
+                 the handle's pinned arena written in place (orcvio_msckf_io_update), host-visible through the copying call,
+                 and with the covariance resident in HBM;
+  objects_update config 3's object update and the north-star frame (400 features, then 20 objects);
+  configs        one entry per BASELINE configuration besides the metric's (1, 3 as a frame, one rank's share of 4, 5):
+                 device-resident ms, host-visible median / p95, and the CPU restatement beside each (1 thread, all cores);
+  stream_config1 the reference's operating point as a filter loop on the resident covariance (euroc.yaml's flags: hybrid
+                 filter with in-state features, ragged tracks): frames/s and per-frame p95.
 """
 import argparse
 import gc
@@ -22,6 +30,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -62,6 +71,34 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def ship_unique_id(capi, rank, world):
+    """The 128 bytes of ncclGetUniqueId from rank 0 to the other ranks of this node: a file under the temporary directory,
+    named after the launcher's process id and the rendezvous port (both the same for every rank of one launch, different
+    for the next), written under another name and renamed, removed by rank 0 when everybody has it."""
+    if world == 1:
+        return capi.comm_unique_id(), None
+    tag = '%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'))
+    path = os.path.join(tempfile.gettempdir(), f'orcvio_bench_comm_id_{tag}')
+    if rank == 0:
+        uid = capi.comm_unique_id()
+        with open(path + '.part', 'wb') as f:
+            f.write(uid)
+        os.replace(path + '.part', path)
+        return uid, path
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, 'rb') as f:
+                uid = f.read()
+            if len(uid) == capi.COMM_ID_BYTES:
+                return uid, None
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > 180:
+            raise SystemExit(f'bench.py rank {rank}: no communicator id from rank 0 after 180 s ({path})')
+        time.sleep(0.01)
+
+
 def percentiles(samples_ms):
     import numpy as np
     a = np.sort(np.asarray(samples_ms))
@@ -89,12 +126,159 @@ def timed_calls(fn, reps, warm=10, after=None):
     return out
 
 
+def device_resident_ms(upd, steps=100, warm=10):
+    """ms per update of the uploaded window, graph replay back to back, one synchronisation at the end."""
+    for _ in range(warm):
+        upd.run_update()
+    upd.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        upd.run_update()
+    upd.sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def cpu_leg(orc, win, budget_s, what):
+    """The CPU restatement beside a configuration: one thread (the literal port) and all cores (minimum-work algorithm, OpenMP),
+    bounded: a window whose single-threaded update would exceed the budget is timed on its first tracks and scaled by the
+    track count (the per-track work dominates and is the same for every track of these windows)."""
+    import dataclasses
+    import numpy as np
+    out = dict(what=what)
+    est = 2.7e-3 * win.F * (win.N / 30.0) ** 2 * float(np.mean(np.diff(win.obs_ptr)) / 30.0)   # ~1.1 s at config 2 on the round-2 hosts
+    sub, scale = win, 1.0
+    if est > budget_s and win.F > 50:
+        keep = max(50, int(win.F * budget_s / est))
+        nobs = int(win.obs_ptr[keep])
+        sub = dataclasses.replace(win, p_w=win.p_w[:keep].copy(), obs_ptr=win.obs_ptr[:keep + 1].copy(), obs_clone=win.obs_clone[:nobs].copy(),
+                                  obs_z=win.obs_z[:nobs].copy(), obs_zvel=win.obs_zvel[:nobs].copy())
+        scale = win.F / keep
+    try:
+        t = orc.msckf_update(sub, want_blocks=False, want_K=False)['seconds']
+        out['one_thread'] = dict(ms_per_update=t * scale * 1e3, cores=1, kind='port',
+                                 sample='the whole window' if scale == 1.0 else f'the first {sub.F} of {win.F} tracks, scaled by the track count')
+    except Exception as e:
+        out['one_thread'] = dict(error=str(e))
+    try:
+        orc.msckf_update_fast(win)
+        best = min(orc.msckf_update_fast(win)['seconds'] for _ in range(3))
+        out['all_cores'] = dict(ms_per_update=best * 1e3, cores=orc.msckf_update_fast(win)['threads'], kind='port (minimum-work algorithm, OpenMP)')
+    except Exception as e:
+        out['all_cores'] = dict(error=str(e))
+    return out
+
+
+def config_table(upd, capi, synth, orc, reps, cpu_budget_s):
+    """One entry per BASELINE configuration besides the metric's: GPU device-resident ms, host-visible median / p95 (the
+    arena written in place), CPU figures beside each."""
+    from orcvio_amd import sharding
+    out = {}
+    shard4, _ = sharding.shard_window(synth.config_window(4), 0, 4)   # what one of config 4's four ranks holds: 500 tracks
+    cases = [('config1', synth.config_window(1), 'euroc.yaml shape: 20 clones, 120 ragged tracks (3-6 observations), n = 142'),
+             ('config4_one_rank_share', shard4, 'one rank\'s share of config 4: 30 clones, 500 full tracks (28 500 rows)'),
+             ('config5_one_gpu', synth.config_window(5), 'kitti_raw.yaml flags, 30 clones, 2 000 full tracks (114 000 rows) on ONE GPU: beyond the '
+                                                          'co-residency limit of the fused front end')]
+    for name, win, what in cases:
+        e = dict(what=what, clones=win.N, tracks=win.F, rows=int(sum(max(2 * int(m) - 3, 0) for m in (win.obs_ptr[1:] - win.obs_ptr[:-1]))))
+        upd.upload(win)
+        e['device_resident_ms'] = device_resident_ms(upd, steps=100)
+        call, io = upd.make_io_call(win)
+        e['host_visible'] = percentiles(timed_calls(call, reps))
+        upd.cov_set(win.P)
+        call_r, io = upd.make_io_call(win, resident_cov=True, want_P=False, commit=True)
+        e['host_visible_resident_cov'] = percentiles(timed_calls(call_r, reps, after=lambda: upd.cov_set(win.P)))
+        if orc is not None:
+            e['cpu_baseline'] = cpu_leg(orc, win, cpu_budget_s, 'oracle/msckf_oracle.c (1 thread), oracle/msckf_fast.c (all cores)')
+        out[name] = e
+    return out
+
+
+def stream_config1(upd, capi, synth, frames=240, seed=0):
+    """The reference's operating point as a LOOP on the resident covariance: euroc.yaml's shipped flags (LARVIO Jacobians,
+    sw_size 20, max_track_len 6, max_features_in_one_grid 1 -> the hybrid filter with feature_idp_dim 1 in-state features,
+    config/euroc.yaml:49-109), 20-200 lost features per frame with 3-6 observations each.  Per frame (src/orcvio.cpp:567-594):
+    propagate -> augment -> prefactor (while the front end would track the image) -> the hybrid update (MSCKF tracks + the rows
+    of the in-state features, evaluated on the device) -> commit -> when the window is full: the prune update on the two
+    clones that leave, commit, marginalisation.  The covariance never leaves HBM; tracks and poses go in, dx comes back."""
+    import dataclasses
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import subset_window
+    fl = synth.Flags(use_larvio=1)
+    n_slam, idp, leg = 12, 1, 22
+    rng = np.random.default_rng(seed)
+    cyc = []
+    for k in range(8):   # a cycle of pre-generated frames (the generator is Python: not part of what is timed)
+        N = 20 if k % 2 else 19
+        F = int(rng.integers(20, 201))
+        w0 = synth.make_window(N=N, F=F, seed=1000 + k, track_len=(3, 6), flags=fl, outlier_frac=0.05)
+        w = synth.with_extra_states(w0, idp * n_slam, seed=k)
+        slam = synth.make_slam_features(w, n_slam, seed=k, outlier_frac=0.1)
+        prune = None
+        if N == 20:
+            sub = subset_window(w, [0, 1])
+            both = np.diff(sub.obs_ptr) == 2
+            if both.any():
+                keep = np.repeat(both, np.diff(sub.obs_ptr))
+                ptr = np.concatenate([[0], np.cumsum(np.where(both, 2, 0))]).astype(np.int32)
+                prune = dataclasses.replace(sub, obs_ptr=ptr, obs_clone=sub.obs_clone[keep].copy(), obs_z=sub.obs_z[keep].copy(),
+                                            obs_zvel=sub.obs_zvel[keep].copy())
+        Phi = np.eye(leg) + 0.002 * rng.standard_normal((leg, leg))
+        G = rng.standard_normal((leg, 12))
+        cyc.append(dict(w=w, slam=slam, prune=prune, Phi=Phi, Q=1e-7 * G @ G.T))
+    n18 = leg + 6 * 18 + idp * n_slam
+    P0 = synth.with_extra_states(synth.make_window(N=18, F=1, seed=5, flags=fl), idp * n_slam, seed=1).P
+    assert P0.shape[0] == n18
+    upd.set_extra_states(idp * n_slam)
+    upd.set_ekf_rows_mode(True)
+    times, n_upd = [], 0
+    try:
+        upd.cov_set(P0)
+        gc.collect()
+        gc.disable()
+        for it in range(frames + 16):
+            c = cyc[it % len(cyc)]
+            t = time.perf_counter()
+            upd.cov_propagate(c['Phi'], c['Q'])
+            upd.cov_augment()
+            upd.cov_prefactor()
+            upd.upload(c['w'], resident_cov=True)
+            upd.upload_slam_features(idp, c['slam'])
+            upd.run_update()
+            got = upd.download_dx()
+            upd.cov_commit()
+            n_upd += 1
+            if c['prune'] is not None:
+                upd.upload(c['prune'], resident_cov=True)   # (no rows of the in-state features in this one)
+                upd.run_update()
+                got = upd.download_dx()
+                upd.cov_commit()
+                n_upd += 1
+                upd.cov_remove_clones(leg, [0, 1])
+            upd.sync()
+            if it >= 16:
+                times.append((time.perf_counter() - t) * 1e3)
+            if not np.all(np.isfinite(got)):
+                raise RuntimeError('non-finite dx in the stream')
+        gc.enable()
+    finally:
+        gc.enable()
+        upd.set_ekf_rows_mode(False)
+        upd.set_extra_states(0)
+    p = percentiles(times)
+    return dict(p, frames_per_s=1e3 / p['mean_ms'], updates_per_frame=n_upd / (frames + 16), in_state_features=n_slam,
+                what='euroc.yaml flags, hybrid filter (12 in-state features, 1 parameter each), 19/20-clone window, 20-200 ragged tracks '
+                     'per frame; per frame: propagate, augment, prefactor, hybrid update + commit, every second frame the prune update '
+                     '+ commit + marginalisation of two clones; covariance resident in HBM; includes this script\'s Python marshalling')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the per-configuration table and the config-1 stream')
     ap.add_argument('--clones', type=int, default=30)
     ap.add_argument('--features', type=int, default=400)
     ap.add_argument('--latency-updates', type=int, default=300, help='updates per latency mode (>= 200, SURVEY 8d)')
@@ -105,7 +289,6 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
     from orcvio_amd import capi, synth
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -119,12 +302,6 @@ def main():
     torch.cuda.set_device(local_rank)
     # ORCVIO_BENCH_FORCE_DIST=1 drives the multi-GPU code path (communicator, all-gather) with world size 1
     use_dist = world > 1 or os.environ.get('ORCVIO_BENCH_FORCE_DIST') == '1'
-    if use_dist:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        # torch.distributed carries the barrier and the max-over-ranks of the contract and ships the RCCL unique id;
-        # the data-path collective belongs to the library handle's own communicator
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     N, F = args.clones, args.features
     # weak scaling: one joint update of F*world tracks, dealt across the ranks
@@ -133,62 +310,57 @@ def main():
     win, _ = sharding.shard_window(full, rank, world)
     upd = capi.MsckfUpdater(device=local_rank, max_clones=max(32, N), max_features=max(2048, win.F),
                             max_observations=max(65536, int(win.obs_ptr[-1])))
-    if use_dist:
-        idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device='cuda')
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        upd.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    id_file = None
+    if use_dist:   # the ONE communicator of this process: the handle's
+        uid, id_file = ship_unique_id(capi, rank, world)
+        upd.comm_init(uid, rank, world)
+        upd.comm_barrier()
+        if id_file:
+            os.remove(id_file)
     upd.upload(win)
-    # one explicit (non-default) stream carries the kernels AND the collective: RCCL is ordered after the rank's block
-    # is written and before the solve reads the gathered blocks
-    tstream = torch.cuda.Stream()
-    stream = tstream.cuda_stream
 
-    def step():
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            upd.comm_barrier()   # (bounded: a rank that never arrives is an error, not a hang)
+        torch.cuda.synchronize()
+
+    def step():   # kernels AND the collective on the handle's own stream: RCCL is ordered behind the rank's block and in front of the solve
         if not use_dist:
-            upd.run_update(stream)
+            upd.run_update()
         else:
-            upd.run_update_sharded(stream)   # local tracks + compression -> RCCL all-gather -> sum + replicated solve
+            upd.run_update_sharded()   # local tracks + compression -> RCCL all-gather -> sum + replicated solve
 
     gc.collect()
     gc.disable()   # the timed region is a few ms: an interpreter collection in the middle of it would be most of it (and one
                    # between warm-up and timing would let the GPU clock down again)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
     gc.enable()
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = float(upd.comm_allreduce_max([dt])[0])
     ms = dt / args.steps * 1e3
 
     # per-update latency of the joint update on every rank count (sync after every update)
     def one_sync():
         step()
-        upd.sync(stream)
+        upd.sync()
     lat_dev = timed_calls(one_sync, max(200, args.latency_updates))   # every rank: the sharded step holds a collective
     if use_dist:
-        dist.barrier()
+        upd.comm_barrier()
 
     out = None
     if rank == 0:
         M = N
         W = algorithmic_flops(N, F * world, M)
         # roofline of the dominant kernel, timed live with HIP events on the launch stream
-        prof = upd.profile(reps=20, stream=stream)
+        prof = upd.profile(reps=20)
         n = 22 + 6 * N
         NA = n - 15
         # algorithmic FP64 work attributed to each kernel (DESIGN.md "Roofline accounting")
@@ -249,8 +421,8 @@ def main():
         roofline = dict(bound='mfma', kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic,
                         note='achieved = algorithmic FP64 work of the reference algorithm attributed to this kernel (SURVEY 8d '
-                             'dense minimum) / kernel time measured with HIP events on the launch stream; critical_path lists '
-                             'what every kernel EXECUTES on the matrix cores (PMC) and how busy they are',
+                             'dense minimum) / kernel time, median of 20 launches measured with HIP events on the launch stream; '
+                             'critical_path lists what every kernel EXECUTES on the matrix cores (PMC) and how busy they are',
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},
                         algorithmic_equiv=dict(
                             what='dense-count flops of the reference algorithm divided by OUR kernel time: how fast a dense '
@@ -262,21 +434,29 @@ def main():
         latency = dict(device_resident=dict(percentiles(lat_dev), what='graph replay + stream sync per update, inputs and results in HBM'))
         objects = None
         cpu = None
+        configs = None
+        stream1 = None
+        orc = None
         if world == 1:
             reps = max(200, args.latency_updates)
-            # host-visible: flat inputs in host memory -> dx, P+, gamma, accept in host memory (SURVEY 8d's metric)
+            # host-visible (SURVEY 8d's metric): tracks + poses + P in host memory -> dx, P+, gamma, accept in host memory.  The
+            # caller has written its flat inputs into the handle's pinned arena (orcvio_msckf_io_begin) and reads the results
+            # where they land: ONE graph launch, the calling thread waits on a flag word in host-coherent memory
+            call_io, io = upd.make_io_call(win)
+            latency['host_visible'] = dict(percentiles(timed_calls(call_io, reps)),
+                                           what='orcvio_msckf_io_update: tracks + poses + P in the handle\'s pinned arena (written in place by '
+                                                'the caller) -> dx, P+, gamma, accept in pinned host memory')
+            # ... the copying call: the caller's own arrays are copied into the arena, the results out of it
             call_host, _ = upd.make_update_call(win)   # argument structs marshalled once: the C call is what is timed
-            lat_host = timed_calls(call_host, reps)
-            latency['host_visible'] = dict(percentiles(lat_host),
-                                           what='orcvio_msckf_update_features: tracks + poses + P in, dx, P+, gamma, accept out')
-            # ... with the covariance resident in HBM: only tracks + poses go in, dx / gamma / accept come back, P+ is
-            # committed on the device (orcvio_msckf_cov_commit); the prior is restored outside the timed part
+            latency['host_visible_copying_call'] = dict(percentiles(timed_calls(call_host, reps)),
+                                                        what='orcvio_msckf_update_features: the same through caller-owned buffers (two more copies '
+                                                             'of P, 326 KB each)')
+            # ... with the covariance resident in HBM: only tracks + poses go in, dx / gamma / accept come back, P+ and its
+            # square-root factor are committed on the device inside the same launch; the prior is restored outside the timed part
             upd.cov_set(win.P)
-
-            call_res, _ = upd.make_update_call(win, resident_cov=True, want_P=False, commit=True)
-            lat_res = timed_calls(call_res, reps, after=lambda: upd.cov_set(win.P))
-            latency['host_visible_resident_cov'] = dict(percentiles(lat_res),
-                                                        what='P = NULL (resident prior), P_out = NULL + cov_commit: tracks + poses in, dx out')
+            call_res, io = upd.make_io_call(win, resident_cov=True, want_P=False, commit=True)
+            latency['host_visible_resident_cov'] = dict(percentiles(timed_calls(call_res, reps, after=lambda: upd.cov_set(win.P))),
+                                                        what='resident prior, commit inside the launch: tracks + poses in, dx out')
             # ... and with the Cholesky of the prior started when the covariance was last touched (orcvio_msckf_cov_prefactor behind
             # propagate / augment, i.e. while the front end still tracks the image): the update finds the factor resident
 
@@ -285,103 +465,21 @@ def main():
                 upd.cov_prefactor()
                 upd.sync()
             restore_and_prefactor()
-            lat_pre = timed_calls(call_res, reps, after=restore_and_prefactor)
             latency['host_visible_resident_prefactored'] = dict(
-                percentiles(lat_pre), what='as host_visible_resident_cov, the prior factored ahead of the call (orcvio_msckf_cov_prefactor, '
-                                           'outside the timed part: it runs while the front end tracks the image)')
+                percentiles(timed_calls(call_res, reps, after=restore_and_prefactor)),
+                what='as host_visible_resident_cov, the prior factored ahead of the call (orcvio_msckf_cov_prefactor, outside the timed '
+                     'part: it runs while the front end tracks the image)')
             upd.upload(win)
+            if not args.no_cpu_baseline:
+                from oracle import oracle as orc   # checker used as the reported CPU baseline ("port")
             # config 3 adds 20 objects x 12 keypoints to the same window: the object update (a second EKF update per
             # frame in the reference, src/orcvio.cpp:2154-2193) from object tracks, host buffers in and out
             if N == 30:
                 try:
-                    import ctypes as C
-                    oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
-                    owin = synth.make_window(N=N, F=4, seed=0, flags=oflags, track_len=4)
-                    objs = synth.make_objects(owin, n_objects=20, seed=1, sigma_kp=0.004)
-                    ofl = capi.make_flags(oflags)
-                    ef, arr, keep = upd._object_tracks(objs, owin.R_b2c[0], owin.t_c_b[0], True, False, 0, False)   # marshalled once
-                    Pc = np.ascontiguousarray(owin.P)
-                    last = {}
-
-                    def call():
-                        o, res = upd._result(owin.n, 1)
-                        rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs),
-                                                                       capi._d(Pc), C.byref(res))
-                        assert rc == 0
-                        last['g'] = (int(o['accept'][0]), int(res.stats[0]))
-                    lat_obj = timed_calls(call, 100, warm=5)
-                    objects = dict(percentiles(lat_obj), objects=20, accepted=last['g'][0], dof=last['g'][1],
-                                   what='orcvio_msckf_update_object_tracks: 20 cars x 12 keypoints x 30 frames, rows evaluated on the '
-                                        'device, host buffers (tracks + P) in, dx and P+ out')
-                    # per-stage device times of the object update (HIP events between the stages, median of 20 runs)
-                    upd.set_stage_profile(True)
-                    runs = []
-                    for _ in range(20):
-                        call()
-                        runs.append(upd.profile_stages())
-                    upd.set_stage_profile(False)
-                    objects['stage_ms'] = {name: round(float(np.median([r[i][1] for r in runs])), 5) for i, (name, _) in enumerate(runs[0])}
-                    # the north-star frame (config 3): the 400-feature update, then the 20-object update on the P+ it left
-                    # (SURVEY note N7), covariance and its square-root factor resident in HBM in between: tracks + poses in,
-                    # dx out, twice; the prior is restored outside the timed part
-                    fwin = synth.config_window(3)
-                    call_f, _ = upd.make_update_call(fwin, resident_cov=True, want_P=False, commit=True)
-                    oo, ores = upd._result(owin.n, 1)
-                    ores.P_out = None
-
-                    def frame():
-                        call_f()
-                        rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(ores))
-                        assert rc == 0
-                        rc = upd.lib.orcvio_msckf_cov_commit(upd.h)
-                        assert rc == 0
-                    upd.cov_set(fwin.P)
-                    lat_frame = timed_calls(frame, 100, warm=5, after=lambda: upd.cov_set(fwin.P))
-                    objects['frame_config3'] = dict(percentiles(lat_frame), object_update_accepted=int(oo['accept'][0]),
-                                                    what='400-feature update + commit + 20-object update + commit, covariance and its '
-                                                         'factor resident in HBM: host tracks / poses in, dx out (twice)')
-                    # the same frame with the prior factored ahead (orcvio_msckf_cov_prefactor when the image arrives)
-
-                    def restore_frame_prior():
-                        upd.cov_set(fwin.P)
-                        upd.cov_prefactor()
-                        upd.sync()
-                    restore_frame_prior()
-                    lat_frame_pre = timed_calls(frame, 100, warm=5, after=restore_frame_prior)
-                    objects['frame_config3_prefactored'] = dict(
-                        percentiles(lat_frame_pre), what='as frame_config3, the Cholesky of the frame\'s prior started ahead of the first '
-                                                         'update (outside the timed part: it runs while the front end tracks the image)')
-                    # the object update alone in that mode (prior and its factor resident)
-                    upd.cov_set(fwin.P)
-                    call_f()
-
-                    def obj_res():
-                        rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(ores))
-                        assert rc == 0
-                    lat_or = timed_calls(obj_res, 100, warm=5)
-                    objects['resident'] = dict(percentiles(lat_or), what='the object update with the prior and its square-root factor '
-                                                                         'resident (no P upload, no Cholesky of P), P+ left in HBM')
-                    upd.set_stage_profile(True)
-                    runs = []
-                    for _ in range(20):
-                        obj_res()
-                        runs.append(upd.profile_stages())
-                    upd.set_stage_profile(False)
-                    objects['resident']['stage_ms'] = {name: round(float(np.median([r[i][1] for r in runs])), 5) for i, (name, _) in enumerate(runs[0])}
-                    if not args.no_cpu_baseline:   # the same object update on one host core (oracle/object_oracle.c)
-                        from oracle import oracle as orc
-                        t_rows = time.perf_counter()
-                        blocks_c = [orc.object_rows_c(o, owin.R_b2c[0], owin.t_c_b[0], True, False, 0) for o in objs]
-                        t_rows = time.perf_counter() - t_rows
-                        cu = orc.objects_update_c(oflags, owin.N, blocks_c, owin.P)
-                        objects['cpu_baseline'] = dict(ms_per_update=(t_rows + cu['seconds']) * 1e3, cores=1, kind='port', accepted=cu['accept'],
-                                                       what='rows (C restatement of the CameraLM / ObjectLM functors) + per-object '
-                                                            'Householder projection on dense rows x n blocks + QR of the stack + update')
-                    upd.upload(win)   # the feature tracks again for what follows
+                    objects = objects_section(upd, capi, synth, orc, np, win)
                 except Exception as e:   # never let the side measurement break the metric line
-                    objects = dict(error=str(e))
-            if not args.no_cpu_baseline:
-                from oracle import oracle as orc   # checker used as the reported CPU baseline ("port")
+                    objects = dict(error=repr(e))
+            if orc is not None:
                 reps_c = 2
                 t = []
                 for _ in range(reps_c):
@@ -400,6 +498,22 @@ def main():
                                                  'compression), tracks parallelised with OpenMP over the host cores')
                 except Exception as e:
                     cpu['all_cores'] = dict(error=str(e))
+            if not args.no_configs and N == 30 and F == 400:
+                try:
+                    configs = config_table(upd, capi, synth, orc, 100, 0.8)
+                    if objects and 'frame_config3' in objects:
+                        configs['config3_frame'] = dict(what='400-feature update, then the 20-object update on the P+ it left (SURVEY note N7), '
+                                                             'covariance resident in between: see objects_update.frame_config3',
+                                                        host_visible=objects['frame_config3'], cpu_baseline=dict(
+                                                            features=cpu and dict(ms_per_update=1e3 / cpu['value'], cores=1, kind='port'),
+                                                            objects=objects.get('cpu_baseline')))
+                except Exception as e:
+                    configs = dict(error=repr(e))
+                try:
+                    stream1 = stream_config1(upd, capi, synth)
+                except Exception as e:
+                    stream1 = dict(error=repr(e))
+                upd.upload(win)
         # Weak scaling: every rank keeps one 400-feature shard, a step is ONE joint update of 400 x world features
         # (rank-local tracks + compression, one RCCL all-gather, replicated solve).  `value` is the whole-job
         # aggregate in the metric's own unit -- 400-feature update shards processed per second by all ranks =
@@ -415,15 +529,13 @@ def main():
                                     '400 N features = N units',
                                joint_updates_per_s=args.steps / dt, features_per_joint_update=F * world,
                                parallelism=f'features sharded over {world} GPU(s), all-gather of compressed blocks through '
-                                           'the handle\'s RCCL communicator',
+                                           'the handle\'s RCCL communicator (the only communicator of the process)',
                                value_is='device-resident throughput (inputs in HBM when the timed region starts, as the bench '
                                         'contract requires); the host-visible per-update latency SURVEY 8d defines is in `latency`'),
-                   roofline=roofline, cpu_baseline=cpu, latency=latency, objects_update=objects)
+                   roofline=roofline, cpu_baseline=cpu, latency=latency, objects_update=objects, configs=configs, stream_config1=stream1)
     if use_dist:
-        dist.barrier()
+        upd.comm_barrier()
     upd.close()
-    if use_dist:
-        dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
         try:   # RCCL writes its version banner through C stdio: flush that buffer first so that the JSON line comes last
@@ -432,6 +544,106 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)   # the one JSON line, last thing on stdout
+
+
+def objects_section(upd, capi, synth, orc, np, win):
+    """Config 3's object update (20 cars x 12 keypoints x 30 frames) and the north-star frame."""
+    import ctypes as C
+    N = win.N
+    oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    owin = synth.make_window(N=N, F=4, seed=0, flags=oflags, track_len=4)
+    objs = synth.make_objects(owin, n_objects=20, seed=1, sigma_kp=0.004)
+    ofl = capi.make_flags(oflags)
+    ef, arr, keep = upd._object_tracks(objs, owin.R_b2c[0], owin.t_c_b[0], True, False, 0, False)   # marshalled once
+    Pc = np.ascontiguousarray(owin.P)
+    last = {}
+
+    def call():
+        o, res = upd._result(owin.n, 1)
+        rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs),
+                                                       capi._d(Pc), C.byref(res))
+        assert rc == 0
+        last['g'] = (int(o['accept'][0]), int(res.stats[0]))
+    lat_obj = timed_calls(call, 100, warm=5)
+    objects = dict(percentiles(lat_obj), objects=20, accepted=last['g'][0], dof=last['g'][1],
+                   what='orcvio_msckf_update_object_tracks: 20 cars x 12 keypoints x 30 frames, rows evaluated on the '
+                        'device, host buffers (tracks + P) in, dx and P+ out')
+    # per-stage device times of the object update (HIP events between the stages, median of 20 runs)
+    upd.set_stage_profile(True)
+    runs = []
+    for _ in range(20):
+        call()
+        runs.append(upd.profile_stages())
+    upd.set_stage_profile(False)
+    objects['stage_ms'] = {name: round(float(np.median([r[i][1] for r in runs])), 5) for i, (name, _) in enumerate(runs[0])}
+    # the north-star frame (config 3): the 400-feature update, then the 20-object update on the P+ it left
+    # (SURVEY note N7), covariance and its square-root factor resident in HBM in between: tracks + poses in,
+    # dx out, twice; the prior is restored outside the timed part
+    fwin = synth.config_window(3)
+    upd.cov_set(fwin.P)
+    call_f, io = upd.make_io_call(fwin, resident_cov=True, want_P=False, commit=True)
+    oo, ores = upd._result(owin.n, 1)
+    ores.P_out = None
+
+    def frame():
+        call_f()
+        rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(ores))
+        assert rc == 0
+        rc = upd.lib.orcvio_msckf_cov_commit(upd.h)
+        assert rc == 0
+
+    def renew():   # the object update reuses the handle's arena: lay it out for the feature update again (outside the timed part)
+        nonlocal call_f
+        call_f, _ = upd.make_io_call(fwin, resident_cov=True, want_P=False, commit=True)
+
+    def restore():
+        upd.cov_set(fwin.P)
+        renew()
+    restore()
+    lat_frame = timed_calls(frame, 100, warm=5, after=restore)
+    objects['frame_config3'] = dict(percentiles(lat_frame), object_update_accepted=int(oo['accept'][0]),
+                                    what='400-feature update (arena written in place) with its commit + 20-object update + commit, '
+                                         'covariance and its factor resident in HBM: host tracks / poses in, dx out (twice)')
+    # the same frame with the prior factored ahead (orcvio_msckf_cov_prefactor when the image arrives)
+
+    def restore_frame_prior():
+        upd.cov_set(fwin.P)
+        upd.cov_prefactor()
+        upd.sync()
+        renew()
+    restore_frame_prior()
+    lat_frame_pre = timed_calls(frame, 100, warm=5, after=restore_frame_prior)
+    objects['frame_config3_prefactored'] = dict(
+        percentiles(lat_frame_pre), what='as frame_config3, the Cholesky of the frame\'s prior started ahead of the first '
+                                         'update (outside the timed part: it runs while the front end tracks the image)')
+    # the object update alone in that mode (prior and its factor resident)
+    upd.cov_set(fwin.P)
+    renew()
+    call_f()
+
+    def obj_res():
+        rc = upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(ores))
+        assert rc == 0
+    lat_or = timed_calls(obj_res, 100, warm=5)
+    objects['resident'] = dict(percentiles(lat_or), what='the object update with the prior and its square-root factor '
+                                                         'resident (no P upload, no Cholesky of P), P+ left in HBM')
+    upd.set_stage_profile(True)
+    runs = []
+    for _ in range(20):
+        obj_res()
+        runs.append(upd.profile_stages())
+    upd.set_stage_profile(False)
+    objects['resident']['stage_ms'] = {name: round(float(np.median([r[i][1] for r in runs])), 5) for i, (name, _) in enumerate(runs[0])}
+    if orc is not None:   # the same object update on one host core (oracle/object_oracle.c)
+        t_rows = time.perf_counter()
+        blocks_c = [orc.object_rows_c(o, owin.R_b2c[0], owin.t_c_b[0], True, False, 0) for o in objs]
+        t_rows = time.perf_counter() - t_rows
+        cu = orc.objects_update_c(oflags, owin.N, blocks_c, owin.P)
+        objects['cpu_baseline'] = dict(ms_per_update=(t_rows + cu['seconds']) * 1e3, cores=1, kind='port', accepted=cu['accept'],
+                                       what='rows (C restatement of the CameraLM / ObjectLM functors) + per-object '
+                                            'Householder projection on dense rows x n blocks + QR of the stack + update')
+    upd.upload(win)   # the feature tracks again for what follows
+    return objects
 
 
 if __name__ == '__main__':

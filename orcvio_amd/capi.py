@@ -928,6 +928,17 @@ class MsckfUpdater:
             raise MsckfError(rc, 'orcvio_msckf_download')
         return self._finish(out, res, self.F)
 
+    def download_dx(self):
+        """dx alone of the finished update (P+ stays in HBM: orcvio_msckf_cov_commit makes it the resident covariance)."""
+        if getattr(self, '_dx_n', None) != self.n:
+            self._dx_buf = np.zeros(self.n)
+            self._dx_res = MsckfResult(_d(self._dx_buf), None, None, None, None, None, None, None)
+            self._dx_n = self.n
+        rc = self.lib.orcvio_msckf_download(self.h, C.byref(self._dx_res))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_download')
+        return self._dx_buf
+
     def set_stage_profile(self, on: bool):
         """ORCVIO_OPT_STAGE_PROFILE: HIP events between the stages of the object update."""
         self._chk(self.lib.orcvio_msckf_set_option(self.h, 6, int(bool(on))), 'orcvio_msckf_set_option')

@@ -16,60 +16,71 @@ __global__ __launch_bounds__(256) void k_ingest(const u32x4* __restrict__ src, u
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
-// resident covariance <- P+ of the update that has just run, unless that update was refused: info[2..3] the pivot counters of
-// chol(M) (k_finish_sqrt kept P), info[8] a hand-off inside a launch timed out (the results are garbage and the host re-runs the
-// update), info[13] a non-finite dx (k_check_finite).  The device-side twin of orcvio_msckf_cov_commit's copy.
-__global__ __launch_bounds__(256) void k_commit_copy(const double* __restrict__ src, double* __restrict__ dst, size_t n,
-                                                     const int* __restrict__ info) {
-    if (info[2] != 0 || info[3] != 0 || info[8] != 0 || info[13] != 0) return;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src[i];
-}
-
-// dx finite?  One wavefront, in front of the commit kernels and the publication: *bad = 1 if any entry of dx is NaN / Inf
-// (a NaN pivot does not show in the smallest-pivot test of chol(M)).
-__global__ __launch_bounds__(64) void k_check_finite(const double* __restrict__ dx, int n, int* __restrict__ bad) {
-    int b = 0;
-    for (int i = threadIdx.x; i < n; i += 64) {
-        const double v = dx[i];
-        b |= !(v - v == 0.0);
-    }
-    const unsigned long long any = __ballot(b != 0);
-    if (threadIdx.x == 0) *bad = any != 0ull ? 1 : 0;
-}
-
-// Results -> host-coherent memory, then the flag.  Workgroup b < nb_small copies the small block [info | dx | gamma |
-// accept]; the others copy P+ (if wanted).  Every storing wave waits for its stores, the workgroup meets, its lane 0 makes
-// them visible at system scope and counts itself in; the workgroup that arrives last bumps the device-side sequence
-// number and stores it to the host flag (release, system scope).  The host spins on that word.
-struct PublishArgs {
+// The epilogue of a zero-copy update, ONE launch behind k_finish_sqrt:
+//   workgroup 0                 the small result block [info | dx | gamma | accept] -> host-coherent memory
+//   workgroups 1 .. nb_P        P+ -> host-coherent memory (want_P)
+//   the others                  the device-side twin of orcvio_msckf_cov_commit (commit): S+ = sigma Z^T (or the prior's own
+//                               factor) into the spare factor buffer, P+ over the resident covariance -- refused by every
+//                               workgroup for itself if the update was (info[2..3] pivot counters of chol(M): k_finish_sqrt
+//                               kept P; info[8] a hand-off inside a launch timed out: the results are garbage and the host
+//                               re-runs the update; a non-finite dx, which no pivot test sees)
+// Every storing wave waits for its stores, the workgroup meets, its lane 0 makes them visible at system scope and counts
+// itself in; the workgroup that arrives last bumps the device-side sequence number and stores it to the host flag (release,
+// system scope).  The host spins on that word.
+struct EpilogueArgs {
     const u32x4* small_src; u32x4* small_dst; size_t small16;
-    const u32x4* P_src; u32x4* P_dst; size_t P16;
+    const u32x4* P_src; u32x4* P_dst; size_t P16; int nb_P;
+    // commit
+    int commit;                   // 0: none, 1: P+ only, 2: P+ and the factor
+    const double* Pout; double* Pres; size_t nn;
+    const double* Z; int ldz, kf, n; double sigma;
+    const double* prior; long sLi, sLj; double* Sout; int ldo;
+    const double* dx; const int* info;
     int* counter;                 // device memory, zero between launches
     unsigned long long* seq;      // device memory: publications so far
-    unsigned long long* flag;     // host-coherent memory: the caller waits for *flag == its expected sequence number
+    unsigned long long* flag;     // host-coherent memory: the caller waits for *flag >= its expected sequence number
 };
-__global__ __launch_bounds__(256) void k_publish(PublishArgs a) {
-    const int nb = gridDim.x;
-    if (blockIdx.x == 0) {
-        for (size_t i = threadIdx.x; i < a.small16; i += 256) a.small_dst[i] = a.small_src[i];
-    }
-    if (a.P16 > 0 && nb > 1 && blockIdx.x > 0) {
-        const size_t stride = (size_t)(nb - 1) * 256;
-        for (size_t i = (size_t)(blockIdx.x - 1) * 256 + threadIdx.x; i < a.P16; i += stride) a.P_dst[i] = a.P_src[i];
-    } else if (a.P16 > 0 && nb == 1) {
-        for (size_t i = threadIdx.x; i < a.P16; i += 256) a.P_dst[i] = a.P_src[i];
+__global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
+    const int nb = gridDim.x, b = blockIdx.x, t = threadIdx.x;
+    if (b == 0) {
+        for (size_t i = t; i < a.small16; i += 256) a.small_dst[i] = a.small_src[i];
+    } else if (b <= a.nb_P) {
+        const size_t stride = (size_t)a.nb_P * 256;
+        for (size_t i = (size_t)(b - 1) * 256 + t; i < a.P16; i += stride) a.P_dst[i] = a.P_src[i];
+    } else if (a.commit) {
+        __shared__ int s_bad;
+        if (t == 0) s_bad = 0;
+        __syncthreads();
+        int bad = 0;
+        for (int i = t; i < a.n; i += 256) { const double v = a.dx[i]; bad |= !(v - v == 0.0); }
+        if (bad) s_bad = 1;
+        __syncthreads();
+        const bool refused = a.info[2] != 0 || a.info[3] != 0 || a.info[8] != 0 || s_bad != 0;
+        const bool applied = a.info[2] == 0 && a.info[3] == 0;
+        const int nbc = nb - 1 - a.nb_P, bc = b - 1 - a.nb_P;
+        const size_t stride = (size_t)nbc * 256;
+        if (!refused)
+            for (size_t i = (size_t)bc * 256 + t; i < a.nn; i += stride) a.Pres[i] = a.Pout[i];
+        if (a.commit == 2) {
+            const size_t kn = (size_t)a.kf * a.n;
+            for (size_t idx = (size_t)bc * 256 + t; idx < kn; idx += stride) {
+                const int i = (int)(idx / a.n), j = (int)(idx - (size_t)i * a.n);
+                a.Sout[(size_t)i * a.ldo + j] = applied ? a.sigma * a.Z[(size_t)i * a.ldz + j] : a.prior[(long)j * a.sLi + (long)i * a.sLj];
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        const int old = atomicAdd(a.counter, 1);
-        if (old == nb - 1) {
-            atomicExch(a.counter, 0);
-            const unsigned long long v = atomicAdd(a.seq, 1ull) + 1ull;
+    if (t == 0) {
+        int old = nb - 1;
+        if (nb > 1) {   // (this workgroup's stores are out before it counts itself in)
             __threadfence_system();
-            __hip_atomic_store(a.flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            old = atomicAdd(a.counter, 1);
+        }
+        if (old == nb - 1) {
+            if (nb > 1) atomicExch(a.counter, 0);
+            const unsigned long long v = atomicAdd(a.seq, 1ull) + 1ull;
+            __hip_atomic_store(a.flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (release: behind everything above)
         }
     }
 }

@@ -92,10 +92,10 @@ struct orcvio_msckf_handle {
     // ---- zero-copy boundary (orcvio_msckf_io_*): the pinned arena is device-visible and host-coherent, the first kernel of the
     // graph pulls the inputs out of it, the last one pushes the results into it and raises h_flag
     char* h_stage_dev = nullptr;              // device-visible address of h_stage
-    unsigned long long* h_flag = nullptr;     // host-coherent word: publications so far (k_publish)
+    unsigned long long* h_flag = nullptr;     // host-coherent word: publications so far (k_epilogue)
     unsigned long long* h_flag_dev = nullptr;
-    unsigned long long* d_seq = nullptr;      // device-side twin (the value k_publish stores to the flag)
-    int* d_pubcnt = nullptr;                  // arrival counter of k_publish's workgroups
+    unsigned long long* d_seq = nullptr;      // device-side twin (the value k_epilogue stores to the flag)
+    int* d_pubcnt = nullptr;                  // arrival counter of k_epilogue's workgroups
     unsigned long long flag_seen = 0;         // last sequence number the host has waited for
     bool io_open = false, io_with_P = false;  // orcvio_msckf_io_begin has laid the arena out and the caller is filling it
     double io_spin_seconds = 2.0;             // bound of the host's wait on h_flag (then: stream synchronisation, then ERR_TIMEOUT)
@@ -419,7 +419,7 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
             HIPCHK(hipMemset(h->d_in, 0, h->in_cap));
             h->stage_bytes = h->in_cap + h->outs_cap;
             // pinned, mapped into the device's address space, host-coherent (fine-grained): kernels read the inputs from it
-            // (k_ingest) and write the results into it (k_publish); the copy engines can use it as before
+            // (k_ingest) and write the results into it (k_epilogue); the copy engines can use it as before
             HIPCHK(hipHostMalloc(&h->h_stage, h->stage_bytes, hipHostMallocMapped | hipHostMallocCoherent));
             HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_stage_dev), h->h_stage, 0));
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_flag), 256, hipHostMallocMapped | hipHostMallocCoherent));
@@ -1966,8 +1966,8 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
 }
 
 // ---- the zero-copy update (orcvio_msckf_io_begin / _io_update; the copying one-shot calls run on it too) ----------------------
-// ONE graph launch per update: k_ingest (pinned arena -> HBM) -> the update's kernels -> k_check_finite -> [the commit of P+ and
-// its square-root factor] -> k_publish (results -> host-coherent memory, then the flag).  No copy-engine transfer, no stream
+// ONE graph launch per update: k_ingest (pinned arena -> HBM) -> the update's kernels -> k_epilogue (results -> host-coherent
+// memory, [the commit of P+ and its square-root factor], then the flag).  No copy-engine transfer, no stream
 // synchronisation: the calling thread spins on the flag.
 static unsigned long long io_signature(const orcvio_msckf_handle* h, hipStream_t s, bool want_P, bool commit) {
     unsigned long long sig = launch_signature(h, s, h->h_stage_dev, (long)(0x100 | (want_P ? 1 : 0) | (commit ? 2 : 0)));
@@ -1988,25 +1988,25 @@ static int io_enqueue(orcvio_msckf_handle* h, hipStream_t s, bool want_P, bool c
     }
     int rc = enqueue_update(h, s);
     if (rc != ORCVIO_OK) return rc;
-    hipLaunchKernelGGL(k_check_finite, dim3(1), dim3(64), 0, s, (const double*)h->d_dx, n, h->d_info + 13);
-    if (commit) {   // the device-side twin of orcvio_msckf_cov_commit, refused by the kernels themselves if the update was
-        if (h->factor_opt && h->n_nui == 0) {
-            const PriorFactor pf = prior_factor(h);
-            hipLaunchKernelGGL(k_fac_commit, dim3((h->kf * n + 255) / 256), dim3(256), 0, s, h->d_Z, h->ldz, h->kf, n, h->flags.noise_feature,
-                               (const int*)nullptr, pf.base, pf.sLi, pf.sLj, h->d_Stmp, h->ldz, (const int*)(h->d_info + 2));
-        }
-        const size_t nn = (size_t)n * n;
-        hipLaunchKernelGGL(k_commit_copy, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, (const double*)h->d_Pout, h->d_Pres, nn, (const int*)h->d_info);
-    }
-    PublishArgs pa;
-    pa.small_src = reinterpret_cast<const u32x4*>(h->d_outs);
-    pa.small_dst = reinterpret_cast<u32x4*>(h->h_stage_dev + h->in_cap);
-    pa.small16 = h->outs_small / 16;
-    pa.P_src = reinterpret_cast<const u32x4*>(h->d_outs + h->oo_Pout);
-    pa.P_dst = reinterpret_cast<u32x4*>(h->h_stage_dev + h->in_cap + h->oo_Pout);
-    pa.P16 = want_P ? (sizeof(double) * (size_t)n * n + 15) / 16 : 0;
-    pa.counter = h->d_pubcnt; pa.seq = h->d_seq; pa.flag = h->h_flag_dev;
-    hipLaunchKernelGGL(k_publish, dim3(want_P ? 1 + 48 : 1), dim3(256), 0, s, pa);
+    // ONE launch behind the update: the results to host-coherent memory, the commit (refused on the device if the update is),
+    // and the flag the caller waits on (k_epilogue)
+    EpilogueArgs ea{};
+    ea.small_src = reinterpret_cast<const u32x4*>(h->d_outs);
+    ea.small_dst = reinterpret_cast<u32x4*>(h->h_stage_dev + h->in_cap);
+    ea.small16 = h->outs_small / 16;
+    ea.P_src = reinterpret_cast<const u32x4*>(h->d_outs + h->oo_Pout);
+    ea.P_dst = reinterpret_cast<u32x4*>(h->h_stage_dev + h->in_cap + h->oo_Pout);
+    ea.P16 = want_P ? (sizeof(double) * (size_t)n * n + 15) / 16 : 0;
+    ea.nb_P = want_P ? 40 : 0;
+    const bool fac = commit && h->factor_opt && h->n_nui == 0;
+    ea.commit = commit ? (fac ? 2 : 1) : 0;
+    ea.Pout = h->d_Pout; ea.Pres = h->d_Pres; ea.nn = (size_t)n * n;
+    const PriorFactor pf = prior_factor(h);
+    ea.Z = h->d_Z; ea.ldz = h->ldz; ea.kf = h->kf; ea.n = n; ea.sigma = h->flags.noise_feature;
+    ea.prior = pf.base; ea.sLi = pf.sLi; ea.sLj = pf.sLj; ea.Sout = h->d_Stmp; ea.ldo = h->ldz;
+    ea.dx = h->d_dx; ea.info = h->d_info;
+    ea.counter = h->d_pubcnt; ea.seq = h->d_seq; ea.flag = h->h_flag_dev;
+    hipLaunchKernelGGL(k_epilogue, dim3(1 + ea.nb_P + (commit ? 40 : 0)), dim3(256), 0, s, ea);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
 }
@@ -2080,11 +2080,20 @@ static int io_run(orcvio_msckf_handle* h, bool want_P, bool commit, int32_t* sta
     hipStream_t s = h->stream;
     h->last_stream = s;
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }
+    static const bool timing = getenv("ORCVIO_TIMING") != nullptr;
+    const auto tl0 = std::chrono::steady_clock::now();
     int rc = run_with_graph(h, h->g_io, io_signature(h, s, want_P, commit), s, [&](bool) { return io_enqueue(h, s, want_P, commit); });
     h->A_deferred = front_defers_assembly(h);   // (a replayed graph does not pass through enqueue_update)
     if (rc != ORCVIO_OK) return rc;
     h->ran = true; h->last_update_objects = false; h->last_run_kind = 0; h->last_sharded = false;
+    const auto tl1 = std::chrono::steady_clock::now();
     rc = io_wait(h, s);
+    if (timing) {
+        static int calls = 0;
+        if ((++calls % 64) == 0)
+            fprintf(stderr, "io_run: launch %.1f us, wait %.1f us\n", std::chrono::duration<double, std::micro>(tl1 - tl0).count(),
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl1).count());
+    }
     if (rc != ORCVIO_OK) { h->ran = false; return rc; }
     const char* so = h->h_stage + h->in_cap;
     const int* info = reinterpret_cast<const int*>(so);
@@ -2149,8 +2158,17 @@ int32_t orcvio_msckf_io_begin(orcvio_msckf_handle* h, const orcvio_msckf_flags* 
 
 int32_t orcvio_msckf_io_update(orcvio_msckf_handle* h, int32_t want_P, int32_t commit, int32_t* stats) {
     if (!h || !h->io_open) { g_last_error = "io_update: call orcvio_msckf_io_begin first"; return ORCVIO_ERR_INVALID; }
+    static const bool timing = getenv("ORCVIO_TIMING") != nullptr;
+    const auto tf0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(h->device));
+    const auto tf1 = std::chrono::steady_clock::now();
     int rc = upload_finalize(h, "orcvio_msckf_io_update");
+    if (timing) {
+        static int calls = 0;
+        if ((++calls % 64) == 0)
+            fprintf(stderr, "io_update: set device %.1f us, finalize %.1f us\n", std::chrono::duration<double, std::micro>(tf1 - tf0).count(),
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tf1).count());
+    }
     if (rc != ORCVIO_OK) return rc;   // (the arena keeps its layout: the caller may repair its arrays and call again)
     h->pw_missing = false;
     h->io_open = true;   // ... and may run the next update of the same shape without a new io_begin
@@ -2453,6 +2471,7 @@ static int objects_problem(orcvio_msckf_handle* h, const orcvio_msckf_flags* fla
     if (flags->leg_dim != 22 && flags->leg_dim != 46) { g_last_error = std::string(who) + ": leg_dim must be 22 or 46"; return ORCVIO_ERR_INVALID; }
     if (N < 1 || N > h->maxN) { g_last_error = std::string(who) + ": window exceeds capacity"; return ORCVIO_ERR_CAPACITY; }
     h->flags = *flags;
+    h->io_open = false;   // (the object update lays the arenas out for itself: a feature update needs a new io_begin)
     h->N = N; h->F = 0; h->nobs = 0;
     h->n = flags->leg_dim + 6 * N + h->n_extra;   // (n_extra: states behind the clones that no row of this update touches)
     h->NA = h->ekf_mode ? h->n - 15 : flags->leg_dim + 6 * N - 15;   // (EKF-SLAM rows reach into the extra states)
@@ -3515,6 +3534,7 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
     const bool front = front_fused_active(h);   // k_front = tracks + compression + chol(P) in one launch: reported as entry 0
     const bool defer = front_defers_assembly(h);
     for (int k = 0; k < nk; ++k) ms[k] = 0.0;
+    std::vector<float> samples[9];   // per kernel: the MEDIAN over the repetitions is reported (one preempted launch is not the kernel's time)
     for (int r = 0; r < reps; ++r) {
         for (int k = 0; k < nk; ++k) {
             if (front && k >= 1 && k <= 3) continue;
@@ -3530,14 +3550,20 @@ int32_t orcvio_msckf_profile_update(orcvio_msckf_handle* h, void* stream, int32_
             HIPCHK(hipEventSynchronize(e1));
             float t = 0.f;
             HIPCHK(hipEventElapsedTime(&t, e0, e1));
-            ms[k] += t;
+            samples[k].push_back(t);
         }
     }
+    for (int k = 0; k < nk; ++k)
+        if (!samples[k].empty()) {
+            std::sort(samples[k].begin(), samples[k].end());
+            const size_t m = samples[k].size();
+            ms[k] = (m & 1) ? samples[k][m / 2] : 0.5 * (samples[k][m / 2 - 1] + samples[k][m / 2]);
+        }
     int no = 0;
     for (int k = 0; k < nk; ++k) {
         if (k == 3 + ST_TRSM && fused_solve_active(h)) continue;   // nothing launched: part of k_potrf_solve(M)
         if (front && k >= 1 && k <= 3) continue;                   // part of k_front
-        ms[no] = ms[k] / reps;
+        ms[no] = ms[k];
         names[no] = (k == 3 + ST_POTRF_M && fused_solve_active(h)) ? "k_potrf_solve(M)" : ((front && k == 0) ? "k_front" : kn[k]);
         ++no;
     }
@@ -3842,7 +3868,7 @@ int32_t orcvio_msckf_triangulate(orcvio_msckf_handle* h, const orcvio_triangulat
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     // this call owns the track buffers: whatever was uploaded for an update is gone
-    h->uploaded = false; h->ran = false; h->skip_active = false; h->objects_mode = false;
+    h->uploaded = false; h->ran = false; h->skip_active = false; h->objects_mode = false; h->io_open = false;
     h->N = N; h->F = F; h->nobs = nobs;
     HIPCHK(hipStreamSynchronize(s));
     if (h->dl_pending) { HIPCHK(hipStreamSynchronize(h->dl_stream)); h->dl_pending = false; }

@@ -25,6 +25,26 @@ static double relerr(const std::vector<double>& a, const std::vector<double>& b)
     return std::sqrt(d / (n > 0 ? n : 1));
 }
 
+// where the threads of this process sit (a bounded wait of the library has fired): name, kernel wait channel, system call
+#include <dirent.h>
+#include <string>
+static void dump_threads() {
+    DIR* d = opendir("/proc/self/task");
+    if (!d) return;
+    while (dirent* e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        const std::string base = std::string("/proc/self/task/") + e->d_name + "/";
+        char buf[3][256] = {{0}, {0}, {0}};
+        const char* files[3] = {"comm", "wchan", "syscall"};
+        for (int i = 0; i < 3; ++i) {
+            FILE* f = fopen((base + files[i]).c_str(), "r");
+            if (f) { if (fgets(buf[i], 255, f)) { char* nl = strchr(buf[i], '\n'); if (nl) *nl = 0; } fclose(f); }
+        }
+        std::printf("thread %s comm=%s wchan=%s syscall=%s\n", e->d_name, buf[0], buf[1], buf[2]);
+    }
+    closedir(d);
+}
+
 int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);   // (the harness reports how far the run got if it ever hangs)
     const int N = 8, F = 40;
@@ -161,8 +181,18 @@ int main() {
         int rc = ORCVIO_OK;
         if (!skip_comm) {
             std::printf("sharded: creating the communicator\n");
-            rc = sh.commInit(MsckfBackend::commUniqueId(), 0, 1);
+            try {
+                rc = sh.commInit(MsckfBackend::commUniqueId(), 0, 1);
+            } catch (const std::exception& e) {
+                std::printf("sharded: %s\n", e.what());
+                rc = ORCVIO_ERR_TIMEOUT;
+            }
             std::printf("sharded: communicator ready (rc %d)\n", rc);
+            if (rc == ORCVIO_ERR_TIMEOUT) {   // the library's bounded wait fired (ORCVIO_COMM_TIMEOUT_S): say where the threads sit
+                std::printf("sharded: %s\n", orcvio_msckf_last_error());
+                dump_threads();
+                return 77;
+            }
         } else std::printf("sharded: SKIPPED (ORCVIO_TEST_SKIP_COMM), plain entry point on the resident covariance\n");
         if (rc == ORCVIO_OK) rc = sh.covarianceToDevice(b);
         UpdateOutcome s1 = skip_comm ? sh.msckfUpdate(b, map_server, ids) : sh.msckfUpdateSharded(b, map_server, ids);   // resident covariance, sharded path

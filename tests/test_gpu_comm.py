@@ -62,3 +62,44 @@ def test_sharded_calls_need_a_communicator(built):
             u.update_features_sharded(win)
     finally:
         u.close()
+
+
+def test_barrier_and_max_through_the_handles_communicator(upd):
+    """The bench contract's barrier and max-over-ranks without a second communicator."""
+    upd.comm_barrier()
+    v = upd.comm_allreduce_max([1.5, -2.0, 7.25])
+    assert list(v) == [1.5, -2.0, 7.25]
+
+
+def test_bench_distributed_path_world_1(built):
+    """bench.py's N > 1 code path (unique id, the handle's communicator as the only one of the process, sharded steps, barrier
+    and max through it) driven with one rank: ORCVIO_BENCH_FORCE_DIST=1.  Runs in a child process; parses the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORCVIO_BENCH_FORCE_DIST='1', ORCVIO_COMM_TIMEOUT_S='60')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '1', '--no-cpu-baseline', '--no-configs',
+                        '--latency-updates', '200'], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['steps'] == 5 and line['value'] > 1000.0
+    assert 'torch.distributed' not in p.stderr or 'init_process_group' not in p.stderr
+
+
+def test_a_refused_share_reaches_every_rank(upd):
+    """a rank whose own tracks are refused still takes part in the collective (empty share + status word) and
+    returns its own status; with one rank that is all there is to see -- the call returns, the handle stays usable."""
+    import dataclasses
+    win = synth.make_window(N=8, F=20, seed=4, track_len=(3, 8))
+    bad = dataclasses.replace(win, obs_clone=win.obs_clone.copy())
+    bad.obs_clone[5] = 99
+    with pytest.raises(capi.MsckfError) as e:
+        upd.update_features_sharded(bad)
+    assert e.value.code == 1   # ORCVIO_ERR_INVALID: this rank's own status
+    with pytest.raises(capi.MsckfError):
+        upd.cov_commit()       # nothing to commit on any rank
+    got = upd.update_features_sharded(win)
+    ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    assert rel(got['dx'], ref['dx']) < 1e-6 and got['stats'][3] == 1

@@ -30,30 +30,35 @@ def test_host_backend_end_to_end(built, tmp_path):
     exe = str(tmp_path / 'test_host_gpu')
     orc = os.path.join(ROOT, 'oracle')
     _build('test_host_gpu.cpp', exe, ['-L', orc, '-lorcoracle', f'-Wl,-rpath,{orc}', '-lm'])
-    # (one full-suite run of round 2 saw this executable sit for the whole time limit once, five others and every solo run
-    # finished in 15 s: the test prints unbuffered, a hang is reported with the output so far, and is retried once)
-    # A second attempt runs with ORCVIO_TEST_SKIP_COMM=1 (the same updates without creating a second RCCL communicator on the GPU
-    # this pytest process already holds one on; tests/test_gpu_comm.py covers the communicator in-process) and warns.
+    # Round 2 saw this executable sit for ever, now and then, in the creation of its one-rank communicator when it ran inside the
+    # full suite (never alone; scripts/gpu_comm_hang_repro.py: 76 launches beside a parent holding a communicator, none stuck).
+    # The library's waits are bounded now (ORCVIO_COMM_TIMEOUT_S): a stuck bootstrap comes back as ORCVIO_ERR_TIMEOUT, the
+    # executable prints where its threads sit and exits with 77, the evidence goes to gpurun_out/host_gpu_hang.log, and the run
+    # is repeated once without the communicator (ORCVIO_TEST_SKIP_COMM=1: the same updates through the plain entry point;
+    # tests/test_gpu_comm.py covers the communicator in-process).
     import warnings
     stdout = ''
     for attempt in range(2):
-        env = dict(os.environ, ORCVIO_TEST_SKIP_COMM='1') if attempt == 1 else None
+        env = dict(os.environ, ORCVIO_COMM_TIMEOUT_S='45')
+        if attempt == 1:
+            env['ORCVIO_TEST_SKIP_COMM'] = '1'
         proc = subprocess.Popen([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
         try:
-            stdout, _ = proc.communicate(timeout=150)
-            break
+            stdout, _ = proc.communicate(timeout=240)
         except subprocess.TimeoutExpired:
             proc.kill()
             stdout, _ = proc.communicate()
-            msg = 'test_host_gpu hung (attempt %d); output so far:\n%s' % (attempt, stdout)
+            raise AssertionError('test_host_gpu sat beyond every bounded wait; output so far:\n' + stdout)
+        if proc.returncode == 77 and attempt == 0:
+            msg = 'test_host_gpu: the creation of the communicator timed out (bounded wait); output:\n%s' % stdout
             print(msg)
             out_dir = os.path.join(ROOT, 'gpurun_out')
             if os.path.isdir(out_dir):
                 with open(os.path.join(out_dir, 'host_gpu_hang.log'), 'a') as f:
                     f.write(msg + '\n')
-            if attempt == 1:
-                raise AssertionError('test_host_gpu hung twice; output so far:\n' + stdout)
-            warnings.warn('test_host_gpu sat for 150 s in its first attempt (see gpurun_out/host_gpu_hang.log); retried without the communicator')
+            warnings.warn('test_host_gpu: communicator bootstrap timed out (see gpurun_out/host_gpu_hang.log); repeated without it')
+            continue
+        break
     assert proc.returncode == 0, stdout
     assert 'host gpu ok' in stdout
 
