@@ -181,7 +181,11 @@ def config_table(upd, capi, synth, orc, reps, cpu_budget_s):
     for name, win, what in cases:
         e = dict(what=what, clones=win.N, tracks=win.F, rows=int(sum(max(2 * int(m) - 3, 0) for m in (win.obs_ptr[1:] - win.obs_ptr[:-1]))))
         upd.upload(win)
-        e['device_resident_ms'] = device_resident_ms(upd, steps=100)
+
+        def one():
+            upd.run_update()
+            upd.sync()
+        e['device_resident'] = percentiles(timed_calls(one, reps))   # (graph replay + one synchronisation per update)
         call, io = upd.make_io_call(win)
         e['host_visible'] = percentiles(timed_calls(call, reps))
         upd.cov_set(win.P)
@@ -254,6 +258,7 @@ def stream_config1(upd, capi, synth, frames=240, seed=0):
                 got = upd.download_dx()
                 upd.cov_commit()
                 n_upd += 1
+            if c['w'].N == 20:
                 upd.cov_remove_clones(leg, [0, 1])
             upd.sync()
             if it >= 16:

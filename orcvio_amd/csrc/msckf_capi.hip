@@ -96,7 +96,7 @@ struct orcvio_msckf_handle {
     unsigned long long* h_flag_dev = nullptr;
     unsigned long long* d_seq = nullptr;      // device-side twin (the value k_epilogue stores to the flag)
     int* d_pubcnt = nullptr;                  // arrival counter of k_epilogue's workgroups
-    unsigned long long flag_seen = 0;         // last sequence number the host has waited for
+    unsigned long long pub_enqueued = 0;      // publications enqueued so far (k_epilogue launches, stream order): the flag value to wait for
     bool io_open = false, io_with_P = false;  // orcvio_msckf_io_begin has laid the arena out and the caller is filling it
     double io_spin_seconds = 2.0;             // bound of the host's wait on h_flag (then: stream synchronisation, then ERR_TIMEOUT)
     bool last_sharded = false;                // the last finished update went through the handle's all-gather (status words in info[9..12])
@@ -172,6 +172,8 @@ struct orcvio_msckf_handle {
     double obj_thr = -1.0;   // chi-square threshold of the object update being finished (host value, passed to k_finish_sqrt)
     int *d_obj_i = nullptr, *d_obj_accept = nullptr;
     size_t cap_Gobj = 0, cap_RF = 0, cap_Yobj = 0, cap_objH = 0, cap_obj_i = 0;
+    char* h_obj_stage_dev = nullptr;   // device-visible address of h_obj_stage (k_ingest pulls the staged tracks / rows out of it)
+    bool pub_pending = false;          // the results of the last one-shot object update are on their way to the pinned block (k_epilogue): wait on h_flag
     char *h_obj_stage = nullptr, *d_obj_in = nullptr;   // input arena of an object update: pinned mirror + device copy (grown on demand)
     size_t obj_stage_cap = 0;
     std::vector<ObjUse> obj_use;        // (objects_local_tracks: per-track records, kept across calls: no allocation per frame)
@@ -335,6 +337,38 @@ static void layout_outputs(orcvio_msckf_handle* h, int n, int F) {
     h->d_gamma = reinterpret_cast<double*>(h->d_outs + h->oo_gamma);
     h->d_accept = reinterpret_cast<int*>(h->d_outs + h->oo_accept);
     h->d_Pout = reinterpret_cast<double*>(h->d_outs + h->oo_Pout);
+}
+
+// host-pinned (device-visible) -> HBM by a kernel instead of a copy-engine transfer: lower latency for the few hundred KB an
+// update moves, and it can be a node of a captured graph like any other launch
+static int launch_ingest(orcvio_msckf_handle* h, hipStream_t s, const void* src_dev, void* dst, size_t bytes) {
+    if (bytes == 0) return ORCVIO_OK;
+    const size_t n16 = (bytes + 15) / 16;
+    int grid = (int)((n16 + 255) / 256);
+    if (grid > 4 * h->n_cus) grid = 4 * h->n_cus;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, s, reinterpret_cast<const u32x4*>(src_dev), reinterpret_cast<u32x4*>(dst), n16);
+    HIPCHK(hipGetLastError());
+    return ORCVIO_OK;
+}
+// the results of the update on `s` -> the pinned output block, then the flag (k_epilogue without a commit): what replaces
+// the device-to-host copy + stream synchronisation of the one-shot calls
+static int publish_enqueue(orcvio_msckf_handle* h, hipStream_t s, bool want_P) {
+    EpilogueArgs ea{};
+    ea.small_src = reinterpret_cast<const u32x4*>(h->d_outs);
+    ea.small_dst = reinterpret_cast<u32x4*>(h->h_stage_dev + h->in_cap);
+    ea.small16 = h->outs_small / 16;
+    ea.P_src = reinterpret_cast<const u32x4*>(h->d_outs + h->oo_Pout);
+    ea.P_dst = reinterpret_cast<u32x4*>(h->h_stage_dev + h->in_cap + h->oo_Pout);
+    ea.P16 = want_P ? (sizeof(double) * (size_t)h->n * h->n + 15) / 16 : 0;
+    ea.nb_P = want_P ? 40 : 0;
+    ea.commit = 0;
+    ea.counter = h->d_pubcnt; ea.seq = h->d_seq; ea.flag = h->h_flag_dev;
+    hipLaunchKernelGGL(k_epilogue, dim3(1 + ea.nb_P), dim3(256), 0, s, ea);
+    HIPCHK(hipGetLastError());
+    h->pub_pending = true;
+    h->pub_enqueued++;
+    return ORCVIO_OK;
 }
 
 // ---- create / destroy ---------------------------------------------------------------------
@@ -554,6 +588,7 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
 
 static int factor_layout_clean(orcvio_msckf_handle* h);
 static int launch_ekf(orcvio_msckf_handle* h, hipStream_t s);
+static int io_wait(orcvio_msckf_handle* h, hipStream_t s);
 static int comm_stream_wait(orcvio_msckf_handle* h, hipStream_t s, const char* who);
 static int feature_outcome(orcvio_msckf_handle* h, const char* so, int32_t* stats);
 static int run_finish_impl(orcvio_msckf_handle* h, const double* d_blocks, int n_blocks, size_t stride, const double* meta0, hipStream_t s);
@@ -1979,14 +2014,9 @@ static unsigned long long io_signature(const orcvio_msckf_handle* h, hipStream_t
 
 static int io_enqueue(orcvio_msckf_handle* h, hipStream_t s, bool want_P, bool commit) {
     const int n = h->n;
-    {   // inputs: one pass over the arena, 16 bytes per lane, enough workgroups for the block to be one or two iterations
-        const size_t n16 = (upload_bytes(h) + 15) / 16;
-        int grid = (int)((n16 + 255) / 256);
-        if (grid > 4 * h->n_cus) grid = 4 * h->n_cus;
-        if (grid < 1) grid = 1;
-        hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, s, reinterpret_cast<const u32x4*>(h->h_stage_dev), reinterpret_cast<u32x4*>(h->d_in), n16);
-    }
-    int rc = enqueue_update(h, s);
+    // inputs: one pass over the arena, 16 bytes per lane, enough workgroups for the block to be one or two iterations
+    int rc = launch_ingest(h, s, h->h_stage_dev, h->d_in, upload_bytes(h));
+    if (rc == ORCVIO_OK) rc = enqueue_update(h, s);
     if (rc != ORCVIO_OK) return rc;
     // ONE launch behind the update: the results to host-coherent memory, the commit (refused on the device if the update is),
     // and the flag the caller waits on (k_epilogue)
@@ -2013,7 +2043,7 @@ static int io_enqueue(orcvio_msckf_handle* h, hipStream_t s, bool want_P, bool c
 
 // Wait for the next publication: spin on the host-coherent flag (bounded), then fall back to a stream synchronisation.
 static int io_wait(orcvio_msckf_handle* h, hipStream_t s) {
-    const unsigned long long expected = h->flag_seen + 1;
+    const unsigned long long expected = h->pub_enqueued;   // (the latest publication on the stream: earlier ones nobody waited for are covered)
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     bool late = false;
@@ -2026,12 +2056,11 @@ static int io_wait(orcvio_msckf_handle* h, hipStream_t s) {
         HIPCHK(hipStreamSynchronize(s));   // (the in-launch waits of the kernels are bounded: the stream drains)
         const unsigned long long now = __atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE);
         if (now < expected) {
-            h->flag_seen = now;
+            h->pub_enqueued = now;   // (a launch that never ran does not publish later either)
             g_last_error = "io_update: the results were not published";
             return ORCVIO_ERR_TIMEOUT;
         }
     }
-    h->flag_seen = __atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE);
     return ORCVIO_OK;
 }
 
@@ -2085,6 +2114,7 @@ static int io_run(orcvio_msckf_handle* h, bool want_P, bool commit, int32_t* sta
     int rc = run_with_graph(h, h->g_io, io_signature(h, s, want_P, commit), s, [&](bool) { return io_enqueue(h, s, want_P, commit); });
     h->A_deferred = front_defers_assembly(h);   // (a replayed graph does not pass through enqueue_update)
     if (rc != ORCVIO_OK) return rc;
+    h->pub_enqueued++;   // (one k_epilogue per launch, captured or not)
     h->ran = true; h->last_update_objects = false; h->last_run_kind = 0; h->last_sharded = false;
     const auto tl1 = std::chrono::steady_clock::now();
     rc = io_wait(h, s);
@@ -2278,7 +2308,8 @@ static int obj_stage_reserve(orcvio_msckf_handle* h, size_t bytes) {
     if (h->d_obj_in) (void)hipFree(h->d_obj_in);
     h->h_obj_stage = nullptr; h->d_obj_in = nullptr; h->obj_stage_cap = 0;
     const size_t cap = (bytes * 3 / 2 + 4095) & ~(size_t)4095;
-    HIPCHK(hipHostMalloc(&h->h_obj_stage, cap, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&h->h_obj_stage, cap, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_obj_stage_dev), h->h_obj_stage, 0));
     HIPCHK(hipMalloc(&h->d_obj_in, cap));
     h->obj_stage_cap = cap;
     return ORCVIO_OK;
@@ -2412,7 +2443,8 @@ static int objects_prior(orcvio_msckf_handle* h, hipStream_t s, const double* P,
     layout_outputs(h, n, 1);
     if (P) {
         std::memcpy(h->h_stage + h->io_P, P, sizeof(double) * (size_t)n * n);
-        HIPCHK(hipMemcpyAsync(h->d_P, h->h_stage + h->io_P, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, s));
+        const int ri = launch_ingest(h, s, h->h_stage_dev + h->io_P, h->d_P, sizeof(double) * (size_t)n * n);
+        if (ri != ORCVIO_OK) return ri;
     }
     return ORCVIO_OK;
 }
@@ -2609,7 +2641,7 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     pl.d_hx = dd; pl.d_hf = dd + rows * 6;
     pl.d_ridx = di + o_ridx; pl.d_rowptr = di + o_rowptr; pl.d_groups = reinterpret_cast<ObjGroup*>(di + o_groups);
     pl.d_arrow = reinterpret_cast<ObjArrow*>(di + o_arrow); pl.d_kp_range = reinterpret_cast<int2*>(di + o_range); pl.d_kp_rows = di + o_kprows;
-    HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (o_groups + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
+    { const int ri = launch_ingest(h, s, h->h_obj_stage_dev, h->d_obj_in, nd * 8 + (o_groups + (size_t)4 * ng) * 4); if (ri != ORCVIO_OK) return ri; }
     return objects_pipeline(h, s, dst, pl);
 }
 
@@ -2827,7 +2859,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     pl.d_ridx = di + o_ridx; pl.d_rowptr = di + o_rowptr; pl.d_groups = reinterpret_cast<ObjGroup*>(di + o_groups);
     pl.d_arrow = reinterpret_cast<ObjArrow*>(di + o_arrow); pl.d_kp_range = reinterpret_cast<int2*>(di + o_range); pl.d_kp_rows = di + o_kprows;
     const auto tt3 = std::chrono::steady_clock::now();
-    HIPCHK(hipMemcpyAsync(h->d_obj_in, h->h_obj_stage, nd * 8 + (o_groups + (size_t)4 * ng) * 4, hipMemcpyHostToDevice, s));
+    { const int ri = launch_ingest(h, s, h->h_obj_stage_dev, h->d_obj_in, nd * 8 + (o_groups + (size_t)4 * ng) * 4); if (ri != ORCVIO_OK) return ri; }
     (void)n_eval;
     // the rows, and in the same launch the zeroing of what the compression accumulates into (Cd, Sg, Hr: adjacent) and of the
     // two pivot counters.  After a merge for ORCVIO_OPT_REF_STACK_HF the scratch layout is another one: plain fills there.
@@ -2896,14 +2928,20 @@ int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_resul
     // results: ONE copy of the outputs arena [info | dx | gamma | accept | (P+)] into its pinned mirror (enqueued behind the
     // update by the one-shot entry points; here for staged callers), one synchronisation
     const bool want_P = res->P_out != nullptr;
-    if (!(h->dl_pending && (h->dl_with_P || !want_P))) {
-        hipStream_t sd = h->last_stream ? h->last_stream : h->stream;
-        if (h->dl_pending) HIPCHK(hipStreamSynchronize(h->dl_stream));
-        const int rq = download_enqueue(h, sd, want_P);
-        if (rq != ORCVIO_OK) return rq;
+    if (h->pub_pending) {   // the one-shot calls: k_epilogue is pushing the results into the pinned block; wait on its flag
+        h->pub_pending = false;
+        const int rw = io_wait(h, h->last_stream ? h->last_stream : h->stream);
+        if (rw != ORCVIO_OK) { h->ran = false; return rw; }
+    } else {
+        if (!(h->dl_pending && (h->dl_with_P || !want_P))) {
+            hipStream_t sd = h->last_stream ? h->last_stream : h->stream;
+            if (h->dl_pending) HIPCHK(hipStreamSynchronize(h->dl_stream));
+            const int rq = download_enqueue(h, sd, want_P);
+            if (rq != ORCVIO_OK) return rq;
+        }
+        HIPCHK(hipStreamSynchronize(h->dl_stream));
+        h->dl_pending = false;
     }
-    HIPCHK(hipStreamSynchronize(h->dl_stream));
-    h->dl_pending = false;
     const char* so = h->h_stage + h->in_cap;
     const double* dx = reinterpret_cast<const double*>(so + h->oo_dx);
     const int acc = *reinterpret_cast<const int*>(so + h->oo_accept);
@@ -2975,7 +3013,7 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     int rc = orcvio_msckf_objects_local(h, flags, n_clones, objs, n_objects, P, h->d_A, &dof, nullptr);
     if (rc != ORCVIO_OK) return rc;
     rc = orcvio_msckf_objects_finish(h, h->d_A, 1, dof, nullptr);
-    if (rc == ORCVIO_OK) rc = download_enqueue(h, h->stream, res->P_out != nullptr);
+    if (rc == ORCVIO_OK) rc = publish_enqueue(h, h->stream, res->P_out != nullptr);   // results -> pinned block, then the flag
     if (rc != ORCVIO_OK) return rc;
     rc = orcvio_msckf_objects_download(h, res);
     h->objects_mode = false;
@@ -2993,7 +3031,7 @@ int32_t orcvio_msckf_update_object_tracks(orcvio_msckf_handle* h, const orcvio_m
     if (rc != ORCVIO_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_objects_finish(h, h->d_A, 1, dof, nullptr);
-    if (rc == ORCVIO_OK) rc = download_enqueue(h, h->stream, res->P_out != nullptr);
+    if (rc == ORCVIO_OK) rc = publish_enqueue(h, h->stream, res->P_out != nullptr);   // results -> pinned block, then the flag
     if (rc != ORCVIO_OK) return rc;
     const auto t2 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_objects_download(h, res);
