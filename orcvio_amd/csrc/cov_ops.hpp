@@ -80,6 +80,14 @@ __global__ __launch_bounds__(256) void k_fac_commit(const double* __restrict__ Z
     const bool app = (apply ? (*apply != 0) : true) && fail[0] == 0 && fail[1] == 0;   // (fail: the pivot counters of chol(M); k_finish_sqrt kept P)
     out[(size_t)i * ldo + j] = app ? sigma * Z[(size_t)i * ldz + j] : prior[(long)j * sLi + (long)i * sLj];
 }
+// prefactor: the Cholesky of the REVERSED covariance (potrf_reg_body, rev) gives S(j, i) = L'(n-1-j, i); stored in the resident
+// factor's own layout F[i * ld + j] (rows of the state in natural order), padding zeroed
+__global__ __launch_bounds__(256) void k_fac_flip(const double* __restrict__ Rrev, int ldr, int n, double* __restrict__ out, int ldo) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * ldo) return;
+    const int i = idx / ldo, j = idx - i * ldo;
+    out[(size_t)i * ldo + j] = (j < n) ? Rrev[(size_t)i * ldr + (n - 1 - j)] : 0.0;
+}
 // stateAugmentation on the factor: the new clone's six rows of S are copies of the IMU's (theta, p) rows
 __global__ __launch_bounds__(256) void k_fac_augment(const double* __restrict__ F, int ld, int k, int n, int pose,
                                                      double* __restrict__ out, int ldo) {

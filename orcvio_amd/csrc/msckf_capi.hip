@@ -116,6 +116,13 @@ struct orcvio_msckf_handle {
     bool ref_stack_hf = false;          // ORCVIO_OPT_REF_STACK_HF: the reference's literal shared-Hf stacking of several objects
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
     bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P
+    // The prior's Cholesky is taken of the REVERSED matrix (potrf_reg_body, rev): P = S S^T with S(i, c) = L'(n-1-i, c), whose
+    // rows 15 .. n-1 (the states measurement rows touch) are zero in the last 15 columns -- M = s2 I + L_a^T A L_a is
+    // diag(M', s2 I_15) and only M' (kf - 15) is formed and factored.  `tail` = those trailing columns of the factor in use
+    // (15, or 0: LDS-panel path, unfused solve, a resident factor that has been through an augmentation); fac_tail = the same
+    // for the resident factor (kept by commit / remove_clones / clones_to_nuisance, dropped by augment).
+    bool rev_prior_opt = true;          // ORCVIO_REV_PRIOR=0: the plain Cholesky (tail 0), same results
+    int tail = 0, fac_tail = 0;
     int last_run_kind = 0;              // 0: run_update (single GPU), 1: run_local / run_finish (staged or sharded), 2: objects
     bool front_retry_forked = false;    // (download: the fused front end lost a hand-off; re-running on the forked path)
     int front_spin_limit = 1 << 19;    // polls before a workgroup of k_front gives up at the device-wide counter (tens of ms)
@@ -341,8 +348,12 @@ static void layout_outputs(orcvio_msckf_handle* h, int n, int F) {
 
 // host-pinned (device-visible) -> HBM by a kernel instead of a copy-engine transfer: lower latency for the few hundred KB an
 // update moves, and it can be a node of a captured graph like any other launch
-static int launch_ingest(orcvio_msckf_handle* h, hipStream_t s, const void* src_dev, void* dst, size_t bytes) {
+static int launch_ingest(orcvio_msckf_handle* h, hipStream_t s, const void* src_dev, void* dst, size_t bytes, bool kernel = true) {
     if (bytes == 0) return ORCVIO_OK;
+    if (!kernel) {   // the copy engine (pinned memory: asynchronous)
+        HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyHostToDevice, s));
+        return ORCVIO_OK;
+    }
     const size_t n16 = (bytes + 15) / 16;
     int grid = (int)((n16 + 255) / 256);
     if (grid > 4 * h->n_cus) grid = 4 * h->n_cus;
@@ -350,6 +361,19 @@ static int launch_ingest(orcvio_msckf_handle* h, hipStream_t s, const void* src_
     hipLaunchKernelGGL(k_ingest, dim3(grid), dim3(256), 0, s, reinterpret_cast<const u32x4*>(src_dev), reinterpret_cast<u32x4*>(dst), n16);
     HIPCHK(hipGetLastError());
     return ORCVIO_OK;
+}
+static bool obj_ingest_kernel() {   // diagnostics: ORCVIO_OBJ_INGEST=0 moves the inputs of an object update with the copy engine
+    static const bool v = [] { const char* e = getenv("ORCVIO_OBJ_INGEST"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+// The results of a one-shot object update: device-to-host copy + stream synchronisation (default), or ORCVIO_OBJ_PUBLISH=1:
+// k_epilogue + the flag, as the feature updates do.  Measured on one box (scripts/gpu_obj_timing.py, config 3, median ms, host
+// buffers / resident prior): ingest kernel + copy out 0.2118 / 0.1625, ingest kernel + flag 0.2111 / 0.1684, copy engine both
+// ways 0.2175 / 0.1684 -- the object update is a chain of a dozen plain launches whose enqueue the host is still busy with
+// when the first kernels run, so the wake-up is not what it waits for.
+static bool obj_publish_kernel() {
+    static const bool v = [] { const char* e = getenv("ORCVIO_OBJ_PUBLISH"); return e ? atoi(e) != 0 : false; }();
+    return v;
 }
 // the results of the update on `s` -> the pinned output block, then the flag (k_epilogue without a commit): what replaces
 // the device-to-host copy + stream synchronisation of the one-shot calls
@@ -425,6 +449,7 @@ int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_feat
     if (const char* e = getenv("ORCVIO_FUSED_SOLVE")) h->fused_solve = atoi(e);   // diagnostics: defaults of the options
     if (const char* e = getenv("ORCVIO_FUSED_FRONT")) h->front_fused = atoi(e);
     if (const char* e = getenv("ORCVIO_FRONT_SPIN")) h->front_spin_limit = atoi(e);
+    if (const char* e = getenv("ORCVIO_REV_PRIOR")) h->rev_prior_opt = atoi(e) != 0;
     h->maxN = max_clones;
     h->maxF = max_features;
     h->maxObs = max_observations;
@@ -604,11 +629,18 @@ static void select_prior_factor(orcvio_msckf_handle* h, bool with_P) {
                     round_up(h->fac_k, 16) <= h->NP_max;
     h->kf = h->use_factor ? h->fac_k : h->n;
 }
+// ... and whether the factor in use ends in columns that are zero in the active rows (call when reg_path is known)
+static inline bool rev_prior_active(const orcvio_msckf_handle* h) { return h->rev_prior_opt && h->reg_path && h->fused_solve && !h->use_factor; }
+static void select_tail(orcvio_msckf_handle* h) {
+    const int t = h->use_factor ? h->fac_tail : (rev_prior_active(h) ? 15 : 0);
+    h->tail = (h->reg_path && h->fused_solve && t > 0 && h->kf - t >= 16) ? t : 0;
+}
 // L(i,j) of the prior's factor = base[i * sLi + j * sLj], i < n, j < kf
 struct PriorFactor { const double* base; long sLi, sLj; };
 static inline void factor_strides(const orcvio_msckf_handle* h, long& sLi, long& sLj);
 static PriorFactor prior_factor(const orcvio_msckf_handle* h) {
     if (h->use_factor) return PriorFactor{h->d_Sres, 1L, (long)h->fac_ld};
+    if (rev_prior_active(h)) return PriorFactor{h->d_RP + (h->n - 1), -1L, (long)h->NP};   // S(i, c) = L'(n-1-i, c) = RP[c NP + n-1-i]
     long sLi, sLj;
     factor_strides(h, sLi, sLj);
     return PriorFactor{h->d_RP, sLi, sLj};
@@ -675,6 +707,7 @@ static int upload_finalize(orcvio_msckf_handle* h, const char* who) {
     h->NP = round_up(h->n > h->kf ? h->n : h->kf, 16);
     h->ldz = round_up(h->n + 1, 16);
     h->reg_path = (h->NP / 16) <= 14;
+    select_tail(h);
     { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
     char* st = h->h_stage;
     const int* obs_ptr = reinterpret_cast<const int*>(st + h->io_optr);
@@ -852,7 +885,7 @@ static bool front_defers_assembly(const orcvio_msckf_handle* h) { return front_f
 static int launch_front(orcvio_msckf_handle* h, hipStream_t s, double* compress_dst, bool grams_only = false) {
     const FeatArgs a = feature_args(h);
     const double eps = 2.220446049250313e-16;
-    FrontPotrfArgs q{h->d_P, h->n, h->n, 8.0 * eps, h->d_RP, h->NP, h->d_DinvP, h->d_info, h->use_factor ? 1 : 0};
+    FrontPotrfArgs q{h->d_P, h->n, h->n, 8.0 * eps, h->d_RP, h->NP, h->d_DinvP, h->d_info, h->use_factor ? 1 : 0, rev_prior_active(h) ? 1 : 0};
     const size_t team = feat_lds_bytes(h->Mmax, h->NAP, h->N);
     const size_t lds = 2 * team > sizeof(double) * POTRF_LDS_DOUBLES ? 2 * team : sizeof(double) * POTRF_LDS_DOUBLES;
     const int team_doubles = (int)(team / sizeof(double));
@@ -959,7 +992,7 @@ static int factor_layout_clean(orcvio_msckf_handle* h) {
 // Cholesky X = L L^T.  reg path: upper factor R (L = R^T) written to `out` (ld = NP), L(i,j) = out[j*NP + i];
 // LDS-panel path: X copied to `out`, factored in place (lower), L(i,j) = out[i*NP + j].
 static int launch_potrf(orcvio_msckf_handle* h, hipStream_t s, const double* X, int ldx, int nn, double tol_rel, double* out,
-                        double* Dinv, int* info) {
+                        double* Dinv, int* info, int rev = 0) {
     const int NP = h->NP;
     if (h->reg_path) {
         const int nb = (nn + 15) / 16, noff = nb * (nb - 1) / 2;
@@ -967,7 +1000,7 @@ static int launch_potrf(orcvio_msckf_handle* h, hipStream_t s, const double* X, 
         (void)noff;
         // zero_lower = 0: `out` is d_RP / d_RM, whose strictly-lower tiles factor_layout_clean() keeps zero
 #define LAUNCH_PR(NS) hipLaunchKernelGGL(k_potrf_reg<NS>, dim3(1), dim3(512), 0, s, X, ldx, nn, tol_rel, out, NP, Dinv, info, \
-                                         (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, 0, 0)
+                                         (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, 0, 0, rev)
         if (need <= 4) LAUNCH_PR(4);
         else if (need <= 8) LAUNCH_PR(8);
         else if (need <= 12) LAUNCH_PR(12);
@@ -1024,31 +1057,32 @@ static int launch_solve_stage(orcvio_msckf_handle* h, hipStream_t s, int stage) 
     const PriorFactor pf = prior_factor(h);
     const long sLi = pf.sLi, sLj = pf.sLj;
     const double* La = pf.base + 15 * sLi;   // L_a(k, j) = Lf(15 + k, j)
+    const int kfa = kf - h->tail;            // columns of the factor that are not zero in the active rows: dimension of M' (M = diag(M', s2 I))
     switch (stage) {
         case ST_POTRF_P:   // P = Lf Lf^T
             if (h->use_factor) return ORCVIO_OK;   // the factor is resident
-            return launch_potrf(h, s, h->d_P, n, n, 8.0 * eps, h->d_RP, h->d_DinvP, h->d_info);
+            return launch_potrf(h, s, h->d_P, n, n, 8.0 * eps, h->d_RP, h->d_DinvP, h->d_info, rev_prior_active(h) ? 1 : 0);
         case ST_FORM_U:    // U[(NA+1) x kf] = [A; b^T] * L_a
             if (h->A_deferred) {   // A = scatter(S) - sum Gpart assembled inside the product (k_front left the Grams only)
                 AsmArgs aa{h->d_S, h->N, h->flags.leg_dim - 15, NA, NAP, h->d_Gpart, h->front_chunks, (size_t)NAP * NAP, asm_dbg(),
                            extra_gram(h)};
-                const int tiles = ((NA + 1 + 15) / 16) * ((kf + 15) / 16);
-                hipLaunchKernelGGL(k_gemm_asmA, dim3(tiles), dim3(256), 0, s, aa, La, sLi, sLj, NA + 1, kf, NA, h->d_U, (long)NP, 1L, (int*)nullptr);
+                const int tiles = ((NA + 1 + 15) / 16) * ((kfa + 15) / 16);
+                hipLaunchKernelGGL(k_gemm_asmA, dim3(tiles), dim3(256), 0, s, aa, La, sLi, sLj, NA + 1, kfa, NA, h->d_U, (long)NP, 1L, (int*)nullptr);
                 HIPCHK(hipGetLastError());
                 return ORCVIO_OK;
             }
-            return launch_gemm(s, h->d_A, NAP, 1, La, sLi, sLj, NA + 1, kf, NA, 1.0, 0.0, 0, h->d_U, NP, 1);
+            return launch_gemm(s, h->d_A, NAP, 1, La, sLi, sLj, NA + 1, kfa, NA, 1.0, 0.0, 0, h->d_U, NP, 1);
         case ST_FORM_M:    // M = s2 I + L_a^T U[0:NA]   (upper tiles)
             // (the register-resident Cholesky reads the upper tiles only; the LDS-panel fallback factors the lower triangle in place)
-            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, kf, kf, NA, 1.0, sigma2, h->reg_path ? 1 : 0, h->d_M, NP, 1, h->d_flag);
+            return launch_gemm(s, La, sLj, sLi, h->d_U, NP, 1, kfa, kfa, NA, 1.0, sigma2, h->reg_path ? 1 : 0, h->d_M, NP, 1, h->d_flag);
         case ST_POTRF_M:
             if (fused_solve_active(h)) {   // chol(M) + Z = L_M^-1 [Lf^T | g] in one launch (solver workgroups trail the factorisation)
-                const int nbm = (kf + 15) / 16, need = potrf_slots_needed(nbm);
+                const int nbm = (kfa + 15) / 16, need = potrf_slots_needed(nbm);
                 const int ncb = (n + 1 + 15) / 16;
                 const dim3 grid(1 + (ncb + SOLVE_WPB - 1) / SOLVE_WPB), block(512);
                 const double* g = h->d_U + (size_t)NA * NP;
-#define LAUNCH_PS(NS) hipLaunchKernelGGL(k_potrf_solve<NS>, grid, block, 0, s, h->d_M, NP, kf, 0.0, h->d_RM, NP, h->d_DinvM, h->d_info + 2, \
-                                         h->d_flag, h->d_info + 8, pf.base, sLj, sLi, n, g, 1L, h->d_Z, ldz)
+#define LAUNCH_PS(NS) hipLaunchKernelGGL(k_potrf_solve<NS>, grid, block, 0, s, h->d_M, NP, kfa, 0.0, h->d_RM, NP, h->d_DinvM, h->d_info + 2, \
+                                         h->d_flag, h->d_info + 8, pf.base, sLj, sLi, n, g, 1L, h->d_Z, ldz, h->tail, 1.0 / h->flags.noise_feature)
                 if (need <= 4) LAUNCH_PS(4);
                 else if (need <= 8) LAUNCH_PS(8);
                 else if (need <= 12) LAUNCH_PS(12);
@@ -1121,6 +1155,7 @@ static unsigned long long launch_signature(const orcvio_msckf_handle* h, hipStre
     // the resident square-root factor is double-buffered and every user of it is a captured kernel argument (prior_factor):
     // its address belongs to the signature (a same-shape update after cov_commit replayed the OTHER buffer)
     mix(h->use_factor ? (unsigned long long)(size_t)h->d_Sres : 0ull);
+    mix(h->tail); mix(rev_prior_active(h));
     mix((unsigned long long)(size_t)s); mix((unsigned long long)(size_t)p0); mix((unsigned long long)extra);
     return sig;
 }
@@ -1875,7 +1910,9 @@ int32_t orcvio_msckf_sync(orcvio_msckf_handle* h, void* stream) {
 //   H_thin = R_A (A = R_A^T R_A, zero rows on rank-deficient directions), r_thin = R_A^-T b,
 //   K = P H_thin^T S^-1 = Lf M^-1 L_a^T R_A^T,   G = K H_thin = Lf M^-1 L_a^T A.
 static int compute_optional(orcvio_msckf_handle* h, bool want_thin_or_K, bool want_K, bool want_G) {
-    const int NA = h->NA, NAP = h->NAP, n = h->n, kf = h->kf, NP = h->NP, ldz = h->ldz;
+    // (kf: the columns of the prior's factor that take part in M' -- the trailing h->tail ones are zero in the active rows, so
+    //  U, W and the products below have nothing there)
+    const int NA = h->NA, NAP = h->NAP, n = h->n, kf = h->kf - h->tail, NP = h->NP, ldz = h->ldz;
     hipStream_t s = h->stream;
     const PriorFactor pf = prior_factor(h);
     const long sLi = pf.sLi, sLj = pf.sLj;
@@ -2156,7 +2193,7 @@ static int io_run(orcvio_msckf_handle* h, bool want_P, bool commit, int32_t* sta
     if (commit) {   // the kernels have written S+ into the spare factor buffer and P+ over the resident covariance
         if (h->factor_opt && h->n_nui == 0) {
             std::swap(h->d_Sres, h->d_Stmp);
-            h->fac_n = h->n; h->fac_k = h->kf; h->fac_ld = h->ldz; h->fac_valid = true;
+            h->fac_n = h->n; h->fac_k = h->kf; h->fac_ld = h->ldz; h->fac_valid = true; h->fac_tail = h->tail;
         } else if (h->n_nui > 0) h->fac_valid = false;   // Schmidt: the nuisance block of P+ is the prior's, so P+ != s2 Z^T Z
         h->res_n = h->n;
     }
@@ -2443,7 +2480,7 @@ static int objects_prior(orcvio_msckf_handle* h, hipStream_t s, const double* P,
     layout_outputs(h, n, 1);
     if (P) {
         std::memcpy(h->h_stage + h->io_P, P, sizeof(double) * (size_t)n * n);
-        const int ri = launch_ingest(h, s, h->h_stage_dev + h->io_P, h->d_P, sizeof(double) * (size_t)n * n);
+        const int ri = launch_ingest(h, s, h->h_stage_dev + h->io_P, h->d_P, sizeof(double) * (size_t)n * n, obj_ingest_kernel());
         if (ri != ORCVIO_OK) return ri;
     }
     return ORCVIO_OK;
@@ -2514,6 +2551,7 @@ static int objects_problem(orcvio_msckf_handle* h, const orcvio_msckf_flags* fla
     h->NP = round_up(h->n > h->kf ? h->n : h->kf, 16);
     h->ldz = round_up(h->n + 1, 16);
     h->reg_path = (h->NP / 16) <= 14;
+    select_tail(h);
     { const int rcl = factor_layout_clean(h); if (rcl != ORCVIO_OK) return rcl; }
     h->m_tot = 0; h->Mmax = 2; h->chunks = 1; h->rows_per_chunk = 8;
     h->h_row_ptr.assign(1, 0);
@@ -2641,7 +2679,7 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
     pl.d_hx = dd; pl.d_hf = dd + rows * 6;
     pl.d_ridx = di + o_ridx; pl.d_rowptr = di + o_rowptr; pl.d_groups = reinterpret_cast<ObjGroup*>(di + o_groups);
     pl.d_arrow = reinterpret_cast<ObjArrow*>(di + o_arrow); pl.d_kp_range = reinterpret_cast<int2*>(di + o_range); pl.d_kp_rows = di + o_kprows;
-    { const int ri = launch_ingest(h, s, h->h_obj_stage_dev, h->d_obj_in, nd * 8 + (o_groups + (size_t)4 * ng) * 4); if (ri != ORCVIO_OK) return ri; }
+    { const int ri = launch_ingest(h, s, h->h_obj_stage_dev, h->d_obj_in, nd * 8 + (o_groups + (size_t)4 * ng) * 4, obj_ingest_kernel()); if (ri != ORCVIO_OK) return ri; }
     return objects_pipeline(h, s, dst, pl);
 }
 
@@ -2859,7 +2897,7 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
     pl.d_ridx = di + o_ridx; pl.d_rowptr = di + o_rowptr; pl.d_groups = reinterpret_cast<ObjGroup*>(di + o_groups);
     pl.d_arrow = reinterpret_cast<ObjArrow*>(di + o_arrow); pl.d_kp_range = reinterpret_cast<int2*>(di + o_range); pl.d_kp_rows = di + o_kprows;
     const auto tt3 = std::chrono::steady_clock::now();
-    { const int ri = launch_ingest(h, s, h->h_obj_stage_dev, h->d_obj_in, nd * 8 + (o_groups + (size_t)4 * ng) * 4); if (ri != ORCVIO_OK) return ri; }
+    { const int ri = launch_ingest(h, s, h->h_obj_stage_dev, h->d_obj_in, nd * 8 + (o_groups + (size_t)4 * ng) * 4, obj_ingest_kernel()); if (ri != ORCVIO_OK) return ri; }
     (void)n_eval;
     // the rows, and in the same launch the zeroing of what the compression accumulates into (Cd, Sg, Hr: adjacent) and of the
     // two pivot counters.  After a merge for ORCVIO_OPT_REF_STACK_HF the scratch layout is another one: plain fills there.
@@ -3013,7 +3051,8 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
     int rc = orcvio_msckf_objects_local(h, flags, n_clones, objs, n_objects, P, h->d_A, &dof, nullptr);
     if (rc != ORCVIO_OK) return rc;
     rc = orcvio_msckf_objects_finish(h, h->d_A, 1, dof, nullptr);
-    if (rc == ORCVIO_OK) rc = publish_enqueue(h, h->stream, res->P_out != nullptr);   // results -> pinned block, then the flag
+    if (rc == ORCVIO_OK) rc = obj_publish_kernel() ? publish_enqueue(h, h->stream, res->P_out != nullptr)   // results -> pinned block, then the flag
+                                                   : download_enqueue(h, h->stream, res->P_out != nullptr);
     if (rc != ORCVIO_OK) return rc;
     rc = orcvio_msckf_objects_download(h, res);
     h->objects_mode = false;
@@ -3031,7 +3070,8 @@ int32_t orcvio_msckf_update_object_tracks(orcvio_msckf_handle* h, const orcvio_m
     if (rc != ORCVIO_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_objects_finish(h, h->d_A, 1, dof, nullptr);
-    if (rc == ORCVIO_OK) rc = publish_enqueue(h, h->stream, res->P_out != nullptr);   // results -> pinned block, then the flag
+    if (rc == ORCVIO_OK) rc = obj_publish_kernel() ? publish_enqueue(h, h->stream, res->P_out != nullptr)   // results -> pinned block, then the flag
+                                                   : download_enqueue(h, h->stream, res->P_out != nullptr);
     if (rc != ORCVIO_OK) return rc;
     const auto t2 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_objects_download(h, res);
@@ -3670,6 +3710,7 @@ int32_t orcvio_msckf_cov_augment(orcvio_msckf_handle* h) {
         HIPCHK(hipGetLastError());
         std::swap(h->d_Sres, h->d_Stmp);
         h->fac_n = m; h->fac_ld = ldo;
+        h->fac_tail = 0;   // (the new clone's rows are copies of IMU rows: not zero in the trailing columns)
     } else h->fac_valid = false;
     return ORCVIO_OK;
 }
@@ -3753,7 +3794,7 @@ int32_t orcvio_msckf_cov_commit(orcvio_msckf_handle* h) {
                            (const int*)(h->d_info + 2));
         HIPCHK(hipGetLastError());
         std::swap(h->d_Sres, h->d_Stmp);
-        h->fac_n = n; h->fac_k = kf; h->fac_ld = h->ldz; h->fac_valid = true;
+        h->fac_n = n; h->fac_k = kf; h->fac_ld = h->ldz; h->fac_valid = true; h->fac_tail = h->tail;
     }
     HIPCHK(hipMemcpyAsync(h->d_Pres, h->d_Pout, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
     if (s != h->stream) HIPCHK(hipStreamSynchronize(s));   // the other cov_* calls run on the handle's own stream
@@ -3823,19 +3864,24 @@ int32_t orcvio_msckf_cov_prefactor(orcvio_msckf_handle* h) {
     const int ld = round_up(n + 1, 16);
     hipStream_t s = h->stream;
     // L(i, j) = R[j * ld + i] (k_potrf_reg writes the upper factor R, P = R^T R, full 16 x 16 tiles, zeros below the diagonal): the
-    // layout of the resident factor S (S(i, j) = d_Sres[i + j * fac_ld])
+    // layout of the resident factor S (S(i, j) = d_Sres[i + j * fac_ld]).  With the reversed factorisation (rev_prior_opt) the
+    // factor comes out with its rows in reverse order: it is written to scratch and flipped into place, and its last 15 columns
+    // are zero in the active rows (fac_tail)
     const double eps = 2.220446049250313e-16;
     const int need = potrf_slots_needed(nb);
-#define LAUNCH_PF(NS) hipLaunchKernelGGL(k_potrf_reg<NS>, dim3(1), dim3(512), 0, s, (const double*)h->d_Pres, n, n, 8.0 * eps, h->d_Stmp, ld, h->d_DinvP, \
-                                         h->d_info, (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, 0, 1)
+    const bool rev = h->rev_prior_opt && h->fused_solve && n - 15 >= 16;
+    double* dst = rev ? h->d_KG : h->d_Stmp;   // (d_KG: scratch of the optional outputs, free between updates)
+#define LAUNCH_PF(NS) hipLaunchKernelGGL(k_potrf_reg<NS>, dim3(1), dim3(512), 0, s, (const double*)h->d_Pres, n, n, 8.0 * eps, dst, ld, h->d_DinvP, \
+                                         h->d_info, (unsigned long long*)nullptr, (size_t)0, (size_t)0, (size_t)0, 0, 0, 1, rev ? 1 : 0)
     if (need <= 4) LAUNCH_PF(4);
     else if (need <= 8) LAUNCH_PF(8);
     else if (need <= 12) LAUNCH_PF(12);
     else LAUNCH_PF(16);
 #undef LAUNCH_PF
+    if (rev) hipLaunchKernelGGL(k_fac_flip, dim3((n * ld + 255) / 256), dim3(256), 0, s, (const double*)dst, ld, n, h->d_Stmp, ld);
     HIPCHK(hipGetLastError());
     std::swap(h->d_Sres, h->d_Stmp);
-    h->fac_n = n; h->fac_k = n; h->fac_ld = ld; h->fac_valid = true;
+    h->fac_n = n; h->fac_k = n; h->fac_ld = ld; h->fac_valid = true; h->fac_tail = rev ? 15 : 0;
     return ORCVIO_OK;
 }
 

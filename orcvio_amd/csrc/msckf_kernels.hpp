@@ -1338,7 +1338,13 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                                                double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                int* __restrict__ info, int from_lower, int ablate, int* __restrict__ flag,
                                                unsigned long long* __restrict__ stamps = nullptr, int info_store = 0,
-                                               int zero_lower = 1) {
+                                               int zero_lower = 1, int rev = 0) {
+    // rev: factor the REVERSED matrix X'(i, j) = X(n-1-i, n-1-j) (only with from_lower = 0).  The prior's Cholesky is taken
+    // that way: with P = S S^T, S(i, c) = L'(n-1-i, c), the rows of S that belong to the states the measurement rows touch
+    // (15 .. n-1) are the FIRST n - 15 rows of the lower-triangular L', so they are zero in the last 15 columns of S --
+    // M = s2 I + L_a^T A L_a is then block diagonal, diag(M', s2 I_15), and only the (n-15) x (n-15) block M' needs a
+    // factorisation (one block step and a fifth of the flops less at 30 clones).  Loads only: tile (a, b) of X' is read
+    // through per-lane offsets from the far corner of X.
     // zero_lower: write zeros to the strictly-lower tiles of R.  0 when the caller keeps them zero itself (the handle's
     // factors: zeroed when the leading dimension changes, never written otherwise).
     // info_store: single-workgroup launches WRITE their two counters (no zeroing launch needed); batched launches add
@@ -1379,7 +1385,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             for (int r = 0; r < 4; ++r) {
                 const int i = kk + 4 * r, j = cc;
                 const bool in = i < n && j < n;
-                const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
+                const double xv = X[(size_t)(in ? (rev ? n - 1 - i : i) : 0) * ldx + (in ? (rev ? n - 1 - j : j) : 0)];
                 d0[r] = in ? xv : ((i == j) ? 1.0 : 0.0);   // (rows beyond the matrix: unit diagonal, ordinary pivots)
                 const int e = l + 64 * r;
                 const double dv = X[(size_t)(e < n ? e : 0) * (ldx + 1)];
@@ -1499,7 +1505,7 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * k + kk + 4 * r, j = 16 * k + cc;
                     const bool in = k < nb && i < n && j < n;
-                    const double xv = X[(size_t)(in ? i : 0) * ldx + (in ? j : 0)];
+                    const double xv = X[(size_t)(in ? (rev ? n - 1 - i : i) : 0) * ldx + (in ? (rev ? n - 1 - j : j) : 0)];
                     dg[k - 1][r] = in ? xv : ((i == j) ? 1.0 : 0.0);   // (rows beyond the matrix: unit diagonal)
                 }
             }
@@ -1599,6 +1605,14 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
         unsigned loNr[4], loEr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { loNr[r] = loN + r * rstep; loEr[r] = loE + r * rstep; }
+        if (rev) {   // element (kk + 4r, cc) of tile (ta, tb) of X' is X(n-1 - 16 ta - kk - 4r, n-1 - 16 tb - cc): the lane's
+                     // offset from X counts DOWN from the far corner, the tile's (uniform) offset is subtracted from it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                loNr[r] = (unsigned)((n - 1 - kk - 4 * r) * ldx + (n - 1 - cc)) * 8u;
+                loEr[r] = (unsigned)((n - 1 - kk - 4 * r) * ldx + (n - 1 - ccE)) * 8u;
+            }
+        }
         const char* Xb = reinterpret_cast<const char*>(X);
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
@@ -1607,7 +1621,15 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             if (tab[s] >= 0) {   // (wave-uniform)
                 const int ta = tab[s] & 255, tb = tab[s] >> 8;
                 const unsigned off = (unsigned)(from_lower ? (16 * tb) * ldx + 16 * ta : (16 * ta) * ldx + 16 * tb) * 8u;
-                if (tb == nb - 1) {
+                if (rev) {
+                    if (tb == nb - 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[s][r] = *reinterpret_cast<const double*>(Xb + (size_t)(loEr[r] - off));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[s][r] = *reinterpret_cast<const double*>(Xb + (size_t)(loNr[r] - off));
+                    }
+                } else if (tb == nb - 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[s][r] = *reinterpret_cast<const double*>(Xb + (size_t)(off + loEr[r]));
                 } else {
@@ -1799,13 +1821,13 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
                                                    double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                    int* __restrict__ info, unsigned long long* __restrict__ stamps = nullptr,
                                                    size_t strideX = 0, size_t strideR = 0, size_t strideD = 0,
-                                                   int from_lower = 0, int ablate = 0, int zero_lower = 1) {
+                                                   int from_lower = 0, int ablate = 0, int zero_lower = 1, int rev = 0) {
     // batched use: workgroup b factors X + b*strideX into R + b*strideR (Dinv + b*strideD);
     // from_lower: the symmetric input has only its lower tiles filled, read element (i,j) as (j,i)
     __shared__ __attribute__((aligned(16))) double sPotrf[POTRF_LDS_DOUBLES];
     potrf_reg_body<NSLOT, false>(sPotrf, X + (size_t)blockIdx.x * strideX, ldx, n, tol_rel, R + (size_t)blockIdx.x * strideR, ldr,
                                  Dinv + (size_t)blockIdx.x * strideD, info, from_lower, ablate, nullptr, stamps,
-                                 gridDim.x == 1 ? 1 : 0, zero_lower);
+                                 gridDim.x == 1 ? 1 : 0, zero_lower, rev);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1819,6 +1841,7 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
 struct FrontPotrfArgs {
     const double* X; int ldx; int n; double tol_rel; double* R; int ldr; double* Dinv; int* info;
     int skip;   // the prior's factor is resident (orcvio_msckf_cov_commit): workgroup 0 has nothing to do
+    int rev;    // factor the reversed matrix (potrf_reg_body): the last 15 columns of the factor are zero in the active rows
 };
 // The compression (both Grams, then the assembly of A) can run in the same launch: the feature workgroups meet at a
 // device-wide counter (they are all resident: the launch has at most as many workgroups as the device has CUs, one
@@ -1863,7 +1886,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     if (blockIdx.x == 0) {
         if (q.skip) return;
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[0] = wall_clock64();
-        potrf_reg_body<NSLOT, false>(smem, q.X, q.ldx, q.n, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, 0, 0, nullptr, nullptr, 1, 0);
+        potrf_reg_body<NSLOT, false>(smem, q.X, q.ldx, q.n, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, 0, 0, nullptr, nullptr, 1, 0, q.rev);
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[6] = wall_clock64();
         return;
     }
@@ -2302,7 +2325,11 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
                                                      double* __restrict__ R, int ldr, double* __restrict__ Dinv,
                                                      int* __restrict__ info, int* __restrict__ flag, int* __restrict__ lost_flag,
                                                      const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
-                                                     const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz) {
+                                                     const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
+                                                     int tail = 0, double tail_scale = 0.0) {
+    // tail: M = diag(X (n x n), s2 I_tail) -- the right-hand sides B1 have `tail` more rows behind the n that take part in the
+    // factorisation (the last columns of the prior's factor, zero in the active rows: potrf_reg_body, rev); their rows of Z are
+    // B1 / sigma (tail_scale), the extra column's are zero.
     if (blockIdx.x == 0) {
         __shared__ __attribute__((aligned(16))) double sPotrf[POTRF_LDS_DOUBLES];
         potrf_reg_body<NSLOT, true>(sPotrf, X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag, nullptr, 1, 0);   // lower tiles: kept zero by the handle
@@ -2315,6 +2342,10 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
     const int cb = (blockIdx.x - 1) * SOLVE_WPB + wave;
     if (wave >= SOLVE_WPB || cb * 16 >= ncols) return;
     const int col = cb * 16 + cc;
+    for (int e = l; e < 16 * tail; e += 64) {   // (independent of the factorisation: out of the way first)
+        const int i = n + (e >> 4), c = cb * 16 + (e & 15);
+        if (c < ncols) Z[(size_t)i * ldz + c] = (c < nc1) ? tail_scale * B1[(long)i * sB1i + (long)c * sB1c] : 0.0;
+    }
     d4 acc[14];
 #pragma unroll
     for (int kb = 0; kb < 14; ++kb) {
