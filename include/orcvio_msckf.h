@@ -187,9 +187,23 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * (src/orcvio.cpp:2154-2193) -- the objects are treated as one object observed many times (SURVEY note N3; right for one
  * object per call only).  0: every object is projected against its own Hf (block-diagonal Hf; equal to the reference whenever
  * one object arrives).  1: the literal shared-Hf stack, dof = total rows - columns; all objects must have the same state size. */
+/* ORCVIO_OPT_OBJECT_DOF (default 0): degrees of freedom of the object gate (src/orcvio.cpp:2172-2176).  0: rows - columns of H_f,
+ * the reference's count.  1: rows - rank(H_f).  They differ only for a rank-deficient H_f (a keypoint never seen inside the window
+ * has three zero columns, one seen in a single frame two rows for three columns): the reference keeps rows - columns directions of
+ * the left null space -- which ones is decided by rounding noise in its SVD -- while this library projects onto the whole null
+ * space (rows - rank directions), so that with the reference's count gamma sums more directions than its threshold
+ * counts (biased towards rejection); 1 makes the threshold count what gamma sums.  (One more host synchronisation per object
+ * update in that mode: the rank is what the structured QR finds on the device.) */
+/* ORCVIO_OPT_REF_H2_LDLT (default 0): the tail of measurementUpdate_hybrid for features ENTERING the state.  The reference solves
+ * with `H_2.ldlt()` (src/orcvio.cpp:1826-1827) where H_2 is the upper-triangular R of the new features' H_f (SPQR, :2421-2436):
+ * Eigen's LDLT reads the LOWER triangle only, so the reference divides by diag(H_2).  0 (default): the triangular system is
+ * solved (what the algebra of :1818-1821 means; identical to the reference for feature_idp_dim = 1, every shipped configuration).
+ * 1: the reference's literal arithmetic (affects orcvio_msckf_augment_new_features and orcvio_msckf_cov_commit_new_features; the
+ * handle-less orcvio_msckf_augment_state has the twin orcvio_msckf_augment_state_ref_ldlt).  P22 uses (H_2^T H_2)^-1 either way,
+ * as the reference does (:1907-1908). */
 enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
        ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6, ORCVIO_OPT_RESIDENT_FACTOR = 7, ORCVIO_OPT_OBJECT_QR = 8,
-       ORCVIO_OPT_REF_STACK_HF = 9, ORCVIO_OPT_SCHMIDT_STATES = 10 };
+       ORCVIO_OPT_REF_STACK_HF = 9, ORCVIO_OPT_SCHMIDT_STATES = 10, ORCVIO_OPT_OBJECT_DOF = 11, ORCVIO_OPT_REF_H2_LDLT = 12 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* EKF-SLAM rows of the hybrid filter (existing SLAM features).  For every SLAM feature the current
@@ -299,6 +313,12 @@ int32_t orcvio_msckf_upload_nuisance_poses(orcvio_msckf_handle* h, const orcvio_
 /* orcvio_msckf_augment_state with nui_rows nuisance rows at the end of the state: the new feature states are inserted in front
  * of them (src/orcvio.cpp:1920-1935); P_aug in the order [old | new | nuisance]. */
 int32_t orcvio_msckf_augment_state_nuisance(int32_t n, int32_t n_new, int32_t idp_dim, int32_t nui_rows, const double* H_1, const double* H_2,
+                                            const double* r_1, double sigma2, const double* dx, const double* P_upd, double* dx_new,
+                                            double* P_aug);
+/* orcvio_msckf_augment_state_nuisance (nui_rows may be 0) with the reference's LITERAL `H_2.ldlt().solve(..)` for HH and dx_new
+ * (src/orcvio.cpp:1826-1827: an LDLT of the lower triangle of the upper-triangular H_2, i.e. division by its diagonal); see
+ * ORCVIO_OPT_REF_H2_LDLT.  Differs from the corrected form for feature_idp_dim = 3 only. */
+int32_t orcvio_msckf_augment_state_ref_ldlt(int32_t n, int32_t n_new, int32_t idp_dim, int32_t nui_rows, const double* H_1, const double* H_2,
                                             const double* r_1, double sigma2, const double* dx, const double* P_upd, double* dx_new,
                                             double* P_aug);
 /* gamma[F], accept[F] of the SLAM features of the last update (either may be NULL) */

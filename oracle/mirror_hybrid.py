@@ -266,17 +266,24 @@ def split_new_rows(win, new_feats, idp_dim: int, table=None):
     return acc, Hn[:m - sz, :win.n], rn[:m - sz], Hn[m - sz:, :win.n], Hn[m - sz:, win.n:], rn[m - sz:]
 
 
-def augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2, nui_rows=0):
+def augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2, nui_rows=0, ref_ldlt=False):
     """:1811-1821 and :1904-1947: the new states' correction and the augmented covariance from the UPDATED legacy covariance.
     This part stays with the caller in the integration.  nui_rows > 0 (Schmidt): the new states are
-    inserted in front of the trailing nuisance rows / columns, block by block as :1920-1935 does."""
+    inserted in front of the trailing nuisance rows / columns, block by block as :1920-1935 does.
+    ref_ldlt: the reference's LITERAL `H_2.ldlt().solve(..)` (:1826-1827).  H_2 is upper triangular (the R of the new features'
+    H_f) and Eigen's LDLT<MatrixXd, Lower> reads the lower triangle only: it factors diag(H_2).  False: the triangular system is
+    solved, which is what the derivation (and :1907-1908's own H_2^T H_2) means.  Equal for feature_idp_dim = 1."""
     n = P_upd.shape[0]
     sz = H_2.shape[0]
     if sz == 0:
         return dx_leg.copy(), P_upd.copy()
+    if ref_ldlt:
+        H_2s = np.diag(np.diag(np.tril(H_2)))   # what the LDLT of the lower triangle of an upper-triangular matrix sees
+    else:
+        H_2s = H_2
     if nui_rows > 0:
-        HH = np.linalg.solve(H_2, H_1)
-        dx_new = -HH @ dx_leg + np.linalg.solve(H_2, r_1)
+        HH = np.linalg.solve(H_2s, H_1)
+        dx_new = -HH @ dx_leg + np.linalg.solve(H_2s, r_1)
         nHHP = -HH @ P_upd
         P22 = -nHHP @ HH.T + sigma2 * np.linalg.inv(H_2.T @ H_2)
         old_rows = old_cols = n
@@ -291,8 +298,8 @@ def augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2, nui_rows=0):
         P[old_rows + sz - nr:, old_cols - nc:old_cols - nc + sz] = nHHP[:, old_cols - nc:].T            # :1932
         P[old_rows - nr:old_rows - nr + sz, old_cols - nc:old_cols - nc + sz] = P22                     # :1933
         return np.concatenate([dx_leg, dx_new]), 0.5 * (P + P.T)
-    HH = np.linalg.solve(H_2, H_1)
-    dx_new = -HH @ dx_leg + np.linalg.solve(H_2, r_1)
+    HH = np.linalg.solve(H_2s, H_1)
+    dx_new = -HH @ dx_leg + np.linalg.solve(H_2s, r_1)
     nHHP = -HH @ P_upd
     P22 = -nHHP @ HH.T + sigma2 * np.linalg.inv(H_2.T @ H_2)
     P = np.zeros((n + sz, n + sz))
@@ -303,7 +310,7 @@ def augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2, nui_rows=0):
     return np.concatenate([dx_leg, dx_new]), 0.5 * (P + P.T)
 
 
-def hybrid_update_full(win, slam, new_feats, idp_dim: int, table=None):
+def hybrid_update_full(win, slam, new_feats, idp_dim: int, table=None, ref_ldlt=False):
     """removeLostFeatures + measurementUpdate_hybrid with MSCKF tracks, existing SLAM features and new ones."""
     f = win.flags
     sigma2 = f.noise_feature ** 2
@@ -331,6 +338,6 @@ def hybrid_update_full(win, slam, new_feats, idp_dim: int, table=None):
     P_upd = (np.eye(win.n) - K @ H_o) @ P                                # :1889-1902
     P_upd = keep_nuisance_block(win, P_upd)
     P_upd = 0.5 * (P_upd + P_upd.T)
-    dx, P_full = augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2, 6 * _n_nui(win))
+    dx, P_full = augment_after_update(P_upd, dx_leg, H_1, H_2, r_1, sigma2, 6 * _n_nui(win), ref_ldlt=ref_ldlt)
     return dict(dx=dx, P_new=P_full, accept=base['accept'], ekf_accept=np.array(ea, dtype=np.int32), new_accept=acc,
                 dx_leg=dx_leg, P_upd=P_upd)

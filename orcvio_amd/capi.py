@@ -41,6 +41,7 @@ EXPORTS = [
     'orcvio_msckf_comm_unique_id', 'orcvio_msckf_comm_init', 'orcvio_msckf_comm_destroy', 'orcvio_msckf_comm_info',
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
     'orcvio_msckf_comm_barrier', 'orcvio_msckf_comm_allreduce_max', 'orcvio_msckf_io_begin', 'orcvio_msckf_io_update',
+    'orcvio_msckf_augment_state_ref_ldlt',
 ]
 
 
@@ -828,6 +829,14 @@ class MsckfUpdater:
         ix = np.ascontiguousarray(indices, dtype=np.int32)
         self._chk(self.lib.orcvio_msckf_cov_clones_to_nuisance(self.h, leg_dim, _i(ix), len(ix)), 'orcvio_msckf_cov_clones_to_nuisance')
 
+    def set_object_dof_rank(self, on: bool):
+        """ORCVIO_OPT_OBJECT_DOF: 1 = the object gate counts rows - rank(H_f) degrees of freedom (default rows - columns)."""
+        self._chk(self.lib.orcvio_msckf_set_option(self.h, 11, int(bool(on))), 'orcvio_msckf_set_option')
+
+    def set_ref_h2_ldlt(self, on: bool):
+        """ORCVIO_OPT_REF_H2_LDLT: the reference's literal H_2.ldlt() in the tail of the hybrid update (default: triangular solve)."""
+        self._chk(self.lib.orcvio_msckf_set_option(self.h, 12, int(bool(on))), 'orcvio_msckf_set_option')
+
     def set_schmidt_states(self, k):
         """ORCVIO_OPT_SCHMIDT_STATES: the last 6 k extra states are Schmidt nuisance states."""
         self._chk(self.lib.orcvio_msckf_set_option(self.h, 10, int(k)), 'orcvio_msckf_set_option')
@@ -997,18 +1006,19 @@ def new_feature_rows(win, idp_dim, feats):
     return H_top[:rows.value].copy(), r_top[:rows.value].copy(), H_1, H_2, r_1
 
 
-def augment_state_nuisance(idp_dim, nui_rows, H_1, H_2, r_1, sigma2, dx, P_upd):
-    """Host arithmetic: augment_state with nui_rows Schmidt nuisance rows at the end (new states go in front of them)."""
+def augment_state_nuisance(idp_dim, nui_rows, H_1, H_2, r_1, sigma2, dx, P_upd, ref_ldlt=False):
+    """Host arithmetic: augment_state with nui_rows Schmidt nuisance rows at the end (new states go in front of them).
+    ref_ldlt: the reference's literal H_2.ldlt() (orcvio_msckf_augment_state_ref_ldlt)."""
     lib = load()
-    lib.orcvio_msckf_augment_state_nuisance.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+    fn = lib.orcvio_msckf_augment_state_ref_ldlt if ref_ldlt else lib.orcvio_msckf_augment_state_nuisance
+    fn.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                         C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
     d, k, n = int(idp_dim), H_2.shape[0], P_upd.shape[0]
     a = [np.ascontiguousarray(x, dtype=np.float64) for x in (H_1, H_2, r_1, dx, P_upd)]
     dx_new = np.zeros(d * k)
     P_aug = np.zeros((n + d * k, n + d * k))
-    rc = lib.orcvio_msckf_augment_state_nuisance(n, k, d, int(nui_rows), _d(a[0]), _d(a[1]), _d(a[2]), float(sigma2), _d(a[3]), _d(a[4]),
-                                                 _d(dx_new), _d(P_aug))
+    rc = fn(n, k, d, int(nui_rows), _d(a[0]), _d(a[1]), _d(a[2]), float(sigma2), _d(a[3]), _d(a[4]), _d(dx_new), _d(P_aug))
     if rc != 0:
         raise MsckfError(rc, 'orcvio_msckf_augment_state_nuisance')
     return dx_new, P_aug

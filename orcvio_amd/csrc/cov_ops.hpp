@@ -115,14 +115,16 @@ __global__ __launch_bounds__(256) void k_fac_remove(const double* __restrict__ F
 // W[j] = (H_2^T H_2)^-1 = R^-1 R^-T.  One thread per (feature, column).
 __global__ __launch_bounds__(256) void k_aug_hh(const double* __restrict__ H1, const double* __restrict__ H2, const double* __restrict__ r1,
                                                 int n, int n_new, int d, double* __restrict__ HH /* [d n_new][n + 1] */,
-                                                double* __restrict__ W /* [n_new][d][d] */, int* __restrict__ singular) {
+                                                double* __restrict__ W /* [n_new][d][d] */, int* __restrict__ singular, int diag_only = 0) {
+    // diag_only: the reference's literal H_2.ldlt().solve(..) on an upper-triangular H_2 = division by its diagonal (src/orcvio.cpp:1826-1827)
     const int j = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (j >= n_new || c > n) return;
     const double* R = H2 + (size_t)j * d * d;
     double v[3] = {0.0, 0.0, 0.0};
     for (int i = d - 1; i >= 0; --i) {
         double m = c < n ? H1[(size_t)(d * j + i) * n + c] : r1[d * j + i];
-        for (int k = i + 1; k < d; ++k) m -= R[i * d + k] * v[k];
+        if (!diag_only)
+            for (int k = i + 1; k < d; ++k) m -= R[i * d + k] * v[k];
         v[i] = m / R[i * d + i];
         HH[(size_t)(d * j + i) * (n + 1) + c] = v[i];
     }

@@ -60,6 +60,10 @@ struct StateServer {
     // hybrid filter: ids of the EKF-SLAM features in the state, in state order (StateServer::feature_states,
     // include/orcvio/state.h; their columns follow the clones, src/orcvio.cpp:1495-1510)
     std::vector<FeatureIDType> feature_states;
+    // Schmidt-EKF (use_schmidt, src/orcvio.cpp:2881-2920): clones that left the window but stay in state_cov as nuisance
+    // states, their 6 x 6 blocks BEHIND the feature states, in the order of nui_ids; SLAM features may stay anchored at them
+    std::vector<StateIDType> nui_ids;
+    IMUStateServer nui_imu_states;
     int dim() const { return (int)std::lround(std::sqrt((double)state_cov.size())); }
 };
 
@@ -322,7 +326,26 @@ class MsckfBackend {
         // Shortcut for the 3-parameter form when the MSCKF rows are LARVIO's (the same error-state convention as the SLAM
         // rows) and FEJ is off: the V part of an entering feature IS its MSCKF block.  Otherwise its rows
         // are restated literally on the host and ride as dense rows.
-        const bool shortcut = d == 3 && flags.use_larvio && !flags.if_fej;
+        const int k_nui = (int)ss.nui_ids.size();   // Schmidt nuisance states behind the feature states (:1730-1751, :1893-1935)
+        const bool shortcut = d == 3 && flags.use_larvio && !flags.if_fej && k_nui == 0;   // (orcvio_msckf_augment_new_features: no nuisance block)
+        // window index of a feature's anchor: a clone of the window, or nuisance state j as N + j (:1247-1256, :1591-1606)
+        auto anchor_index = [&](const std::map<StateIDType, int>& index_of, StateIDType id) -> int {
+            auto it = index_of.find(id);
+            if (it != index_of.end()) return it->second;
+            auto jt = std::find(ss.nui_ids.begin(), ss.nui_ids.end(), id);
+            return jt == ss.nui_ids.end() ? -1 : (int)index_of.size() + (int)(jt - ss.nui_ids.begin());
+        };
+        // poses of the nuisance states, in nui_ids order (orcvio_msckf_upload_nuisance_poses)
+        std::vector<double> nR_b2w, nt_b_w, nt_fej, nR_b2c, nt_c_b;
+        for (StateIDType id : ss.nui_ids) {
+            auto it = ss.nui_imu_states.find(id);
+            if (it == ss.nui_imu_states.end()) { out.status = ORCVIO_ERR_INVALID; return out; }
+            const IMUState_Aug& a = it->second;
+            nR_b2w.insert(nR_b2w.end(), a.orientation, a.orientation + 9); nt_b_w.insert(nt_b_w.end(), a.position, a.position + 3);
+            nt_fej.insert(nt_fej.end(), a.position_FEJ, a.position_FEJ + 3);
+            nR_b2c.insert(nR_b2c.end(), a.R_imu_cam0, a.R_imu_cam0 + 9); nt_c_b.insert(nt_c_b.end(), a.t_cam0_imu, a.t_cam0_imu + 3);
+        }
+        orcvio_msckf_window nui_w{k_nui, nR_b2w.data(), nt_b_w.data(), nt_fej.data(), nR_b2c.data(), nt_c_b.data()};
         std::vector<FeatureIDType> msckf_ids(msckf_ids_in);
         if (shortcut) msckf_ids.insert(msckf_ids.end(), new_ids.begin(), new_ids.end());
         std::vector<double> R_b2w, t_b_w, t_fej, R_b2c, t_c_b, p_w, obs_z, obs_zvel;
@@ -338,7 +361,7 @@ class MsckfBackend {
         std::vector<double> e_prm, e_rho, e_pw, e_pfj, e_oz, e_ozv;
         if (new_accepted) new_accepted->assign(new_ids.size(), 0);
         if (!shortcut && !new_ids.empty()) {
-            const int Nw = (int)index_of.size(), ncols = flags.leg_dim + 6 * Nw + d * (int)ss.feature_states.size();
+            const int Nw = (int)index_of.size(), ncols = flags.leg_dim + 6 * Nw + d * (int)ss.feature_states.size() + 6 * k_nui;
             if (ss.dim() != ncols) { out.status = ORCVIO_ERR_INVALID; return out; }
             std::vector<double> gp, gz, gzv;
             std::vector<int32_t> gptr, gcl;
@@ -348,7 +371,7 @@ class MsckfBackend {
             std::vector<double> gg(new_ids.size());
             std::vector<int32_t> ga(new_ids.size());
             {
-                OptionScope extra(h_, ORCVIO_OPT_EXTRA_STATES, d * (int)ss.feature_states.size());
+                OptionScope extra(h_, ORCVIO_OPT_EXTRA_STATES, d * (int)ss.feature_states.size() + 6 * k_nui);
                 out.status = extra.status;
                 if (out.status == ORCVIO_OK) out.status = orcvio_msckf_gate_tracks(h_, &flags, &gw, &gt, ss.state_cov.data(), gg.data(), ga.data());
             }
@@ -356,10 +379,10 @@ class MsckfBackend {
             for (size_t k = 0; k < new_ids.size(); ++k) {
                 if (!ga[k]) continue;
                 const Feature& f = map_server.at(new_ids[k]);
-                if (!index_of.count(f.id_anchor)) { out.status = ORCVIO_ERR_INVALID; return out; }
+                if (anchor_index(index_of, f.id_anchor) < 0) { out.status = ORCVIO_ERR_INVALID; return out; }
                 entering1.push_back(new_ids[k]);
                 if (new_accepted) (*new_accepted)[k] = 1;
-                e_anc.push_back(index_of.at(f.id_anchor));
+                e_anc.push_back(anchor_index(index_of, f.id_anchor));
                 const double* pp = d == 3 ? f.invParam : f.obs_anchor;
                 e_prm.insert(e_prm.end(), pp, pp + 3); e_rho.push_back(f.invDepth);
                 e_pw.insert(e_pw.end(), f.position, f.position + 3); e_pfj.insert(e_pfj.end(), f.position_FEJ, f.position_FEJ + 3);
@@ -373,7 +396,7 @@ class MsckfBackend {
         }
         flattenTracks(map_server, msckf_ids, index_of, {}, p_w, obs_ptr, obs_clone, obs_z, obs_zvel);
         const int N = (int)index_of.size(), nf = (int)ss.feature_states.size();
-        const int base = flags.leg_dim + 6 * N, n = base + d * nf;
+        const int base = flags.leg_dim + 6 * N, n = base + d * nf + 6 * k_nui;
         if (ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
         const StateIDType imu_id = ss.imu_state.id;
         if (!index_of.count(imu_id)) { out.status = ORCVIO_ERR_INVALID; return out; }
@@ -384,8 +407,8 @@ class MsckfBackend {
             const Feature& f = map_server.at(fid);
             auto it = std::find(ss.feature_states.begin(), ss.feature_states.end(), fid);
             auto ob = f.observations.find(imu_id);
-            if (it == ss.feature_states.end() || ob == f.observations.end() || !index_of.count(f.id_anchor)) { out.status = ORCVIO_ERR_INVALID; return out; }
-            anchor.push_back(index_of.at(f.id_anchor));
+            if (it == ss.feature_states.end() || ob == f.observations.end() || anchor_index(index_of, f.id_anchor) < 0) { out.status = ORCVIO_ERR_INVALID; return out; }
+            anchor.push_back(anchor_index(index_of, f.id_anchor));
             state.push_back(index_of.at(imu_id));
             slot.push_back((int32_t)(it - ss.feature_states.begin()));
             const double* prm = d == 3 ? f.invParam : f.obs_anchor;
@@ -412,10 +435,13 @@ class MsckfBackend {
         r.dx = out.delta_x.data(); r.P_out = P_new.data(); r.accept = out.accepted.data(); r.gamma = out.gamma.data();
         auto step = [&](int rc) { if (out.status == ORCVIO_OK) out.status = rc; };
         {   // hybrid mode for exactly this update (both options are restored on every exit path)
-            OptionScope extra(h_, ORCVIO_OPT_EXTRA_STATES, d * nf), ekf_rows(h_, ORCVIO_OPT_EKF_ROWS, 1);
+            OptionScope extra(h_, ORCVIO_OPT_EXTRA_STATES, d * nf + 6 * k_nui), ekf_rows(h_, ORCVIO_OPT_EKF_ROWS, 1),
+                        schmidt(h_, ORCVIO_OPT_SCHMIDT_STATES, k_nui);
             step(extra.status);
             step(ekf_rows.status);
+            step(schmidt.status);
             if (out.status == ORCVIO_OK) step(orcvio_msckf_upload(h_, &flags, &w, &t, ss.state_cov.data()));
+            if (out.status == ORCVIO_OK && k_nui > 0) step(orcvio_msckf_upload_nuisance_poses(h_, &nui_w));
             if (out.status == ORCVIO_OK) step(orcvio_msckf_upload_slam_features(h_, &sf));
             if (out.status == ORCVIO_OK && !entering1.empty()) {   // the V parts join the stack on the device, the U parts stay there
                 orcvio_msckf_new_features nfs{};
@@ -464,8 +490,10 @@ class MsckfBackend {
             H1_1.assign((size_t)sz1 * n, 0.0); H2_1.assign((size_t)k1 * d * d, 0.0); r1_1.assign((size_t)sz1, 0.0);
             out.status = orcvio_msckf_download_new_feature_blocks(h_, H1_1.data(), H2_1.data(), r1_1.data());
             if (out.status != ORCVIO_OK) return out;
-            out.status = orcvio_msckf_augment_state(n, k1, d, H1_1.data(), H2_1.data(), r1_1.data(), flags.noise_feature * flags.noise_feature,
-                                                    out.delta_x.data(), P_new.data(), dx_new.data(), P_aug.data());
+            // (with nuisance states the new feature states go IN FRONT of the nuisance block, :1920-1935; delta_x = [dx_leg ; dx_new])
+            out.status = orcvio_msckf_augment_state_nuisance(n, k1, d, 6 * k_nui, H1_1.data(), H2_1.data(), r1_1.data(),
+                                                             flags.noise_feature * flags.noise_feature, out.delta_x.data(), P_new.data(), dx_new.data(),
+                                                             P_aug.data());
             if (out.status != ORCVIO_OK) return out;
             out.delta_x.insert(out.delta_x.end(), dx_new.begin(), dx_new.end());
             P_new.swap(P_aug);
@@ -478,13 +506,17 @@ class MsckfBackend {
         if (!out.state_incremented) return out;
         for (int i = 0; i < nf_all; ++i) {                            // (:1836-1887)
             Feature& f = map_server.at(ss.feature_states[i]);
-            const IMUState_Aug& a = ss.imu_states_augment.at(f.id_anchor);
+            // the anchor: a clone of the window, or a nuisance state (:1850-1857)
+            const bool anchored_at_nui = std::find(ss.nui_ids.begin(), ss.nui_ids.end(), f.id_anchor) != ss.nui_ids.end();
+            const IMUState_Aug& a = anchored_at_nui ? ss.nui_imu_states.at(f.id_anchor) : ss.imu_states_augment.at(f.id_anchor);
+            // delta_x = [dx_leg (old feature states, then the nuisance states) ; dx_new]: an entering feature reads behind dx_leg (:1864-1878)
+            const int at = i < nf ? base + d * i : n + d * (i - nf);
             double p_c[3];
             if (d == 3) {
-                for (int k = 0; k < 3; ++k) f.invParam[k] += out.delta_x[base + 3 * i + k];
+                for (int k = 0; k < 3; ++k) f.invParam[k] += out.delta_x[at + k];
                 p_c[0] = f.invParam[0] / f.invParam[2]; p_c[1] = f.invParam[1] / f.invParam[2]; p_c[2] = 1.0 / f.invParam[2];
             } else {
-                f.invDepth += out.delta_x[base + i];
+                f.invDepth += out.delta_x[at];
                 p_c[0] = f.obs_anchor[0] / f.invDepth; p_c[1] = f.obs_anchor[1] / f.invDepth; p_c[2] = 1.0 / f.invDepth;
             }
             for (int k = 0; k < 3; ++k)

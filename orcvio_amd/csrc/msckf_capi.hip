@@ -113,6 +113,8 @@ struct orcvio_msckf_handle {
     bool fac_valid = false;
     bool factor_opt = true;             // ORCVIO_OPT_RESIDENT_FACTOR
     int n_nui = 0;                      // ORCVIO_OPT_SCHMIDT_STATES: Schmidt nuisance states (6 columns each) at the END of the extra states
+    bool obj_dof_rank = false;          // ORCVIO_OPT_OBJECT_DOF = 1: the object gate counts rows - rank(H_f) degrees of freedom (default: rows - columns, the reference's count)
+    bool ref_h2_ldlt = false;           // ORCVIO_OPT_REF_H2_LDLT: the reference's literal H_2.ldlt() (diag(H_2)) in the tail of the hybrid update
     bool ref_stack_hf = false;          // ORCVIO_OPT_REF_STACK_HF: the reference's literal shared-Hf stacking of several objects
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
     bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P
@@ -596,6 +598,14 @@ int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t 
     if (option == ORCVIO_OPT_SCHMIDT_STATES) {
         if (value < 0 || value > h->maxN) { g_last_error = "orcvio_msckf_set_option: nuisance states out of range"; return ORCVIO_ERR_INVALID; }
         h->n_nui = value;   // takes effect with the next upload (part of the launch signature)
+        return ORCVIO_OK;
+    }
+    if (option == ORCVIO_OPT_OBJECT_DOF) {
+        h->obj_dof_rank = value != 0;
+        return ORCVIO_OK;
+    }
+    if (option == ORCVIO_OPT_REF_H2_LDLT) {
+        h->ref_h2_ldlt = value != 0;
         return ORCVIO_OK;
     }
     if (option == ORCVIO_OPT_OBJECT_QR) {
@@ -1647,7 +1657,34 @@ int32_t orcvio_msckf_augment_new_features(orcvio_msckf_handle* h, const orcvio_m
             for (int c = 0; c < 3; ++c) M1[3 * i + c] = Rca[3 * i] * Jf[c] + Rca[3 * i + 1] * Jf[3 + c] + Rca[3 * i + 2] * Jf[6 + c];
         for (int i = 0; i < 3; ++i)
             for (int c = 0; c < 3; ++c) H2[3 * i + c] = R[3 * i] * M1[c] + R[3 * i + 1] * M1[3 + c] + R[3 * i + 2] * M1[6 + c];
-        inv3(H2, &H2i[9 * j]);
+        if (h->ref_h2_ldlt) {
+            // The reference's literal tail: its U is the Q factor of H_f in the INVERSE-DEPTH parametrisation (SPQR, :2421-2428), so
+            // its H_2 is that matrix's upper-triangular R, and H_2.ldlt() (:1826-1827) reads the lower triangle of it -- the diagonal.
+            // Here U = Q_1 of H_f(xyz) (same column space): H_2 = Q_3 R_idp by a 3 x 3 Gram-Schmidt QR, the three rows of H_1 and r_1
+            // are rotated by Q_3^T into the reference's basis (up to the signs of the rows, which the diagonal division cancels).
+            double Q3[9], Rr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < 3; ++c) {
+                double v[3] = {H2[c], H2[3 + c], H2[6 + c]};
+                for (int q = 0; q < c; ++q) {
+                    const double dq = Q3[q] * v[0] + Q3[3 + q] * v[1] + Q3[6 + q] * v[2];
+                    Rr[3 * q + c] = dq;
+                    for (int i = 0; i < 3; ++i) v[i] -= dq * Q3[3 * i + q];
+                }
+                const double nv = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                Rr[3 * c + c] = nv;
+                for (int i = 0; i < 3; ++i) Q3[3 * i + c] = v[i] / nv;
+            }
+            double rot[3];
+            for (int c = 0; c < n; ++c) {
+                for (int i = 0; i < 3; ++i) rot[i] = Q3[i] * H1[(size_t)(3 * j) * n + c] + Q3[3 + i] * H1[(size_t)(3 * j + 1) * n + c] + Q3[6 + i] * H1[(size_t)(3 * j + 2) * n + c];
+                for (int i = 0; i < 3; ++i) H1[(size_t)(3 * j + i) * n + c] = rot[i];
+            }
+            for (int i = 0; i < 3; ++i) rot[i] = Q3[i] * r1s[3 * j] + Q3[3 + i] * r1s[3 * j + 1] + Q3[6 + i] * r1s[3 * j + 2];
+            for (int i = 0; i < 3; ++i) r1s[3 * j + i] = rot[i];
+            std::memcpy(H2, Rr, sizeof(Rr));
+            for (int i = 0; i < 9; ++i) H2i[9 * j + i] = 0.0;
+            for (int i = 0; i < 3; ++i) H2i[9 * j + 4 * i] = 1.0 / H2[4 * i];
+        } else inv3(H2, &H2i[9 * j]);
         double HtH[9];
         for (int i = 0; i < 3; ++i)
             for (int c = 0; c < 3; ++c) HtH[3 * i + c] = H2[i] * H2[c] + H2[3 + i] * H2[3 + c] + H2[6 + i] * H2[6 + c];
@@ -1787,8 +1824,11 @@ int32_t orcvio_msckf_new_feature_rows(const orcvio_msckf_flags* flags, const orc
 // (The reference writes H_2.ldlt().solve(.), which for d = 3 reads only the lower triangle of an upper-triangular H_2;
 // the triangular system is solved here.  For the 1-parameter form of the shipped configurations H_2 is diagonal and the
 // two coincide.)
-int32_t orcvio_msckf_augment_state(int32_t n, int32_t n_new, int32_t idp_dim, const double* H_1, const double* H_2, const double* r_1,
-                                   double sigma2, const double* dx, const double* P_upd, double* dx_new, double* P_aug) {
+// diag_only: the reference's literal arithmetic for HH and dx_new -- `H_2.ldlt().solve(..)` (src/orcvio.cpp:1826-1827) on an
+// UPPER-triangular H_2: Eigen's LDLT reads the lower triangle only, i.e. diag(H_2) (the same thing for the 1 x 1 blocks of
+// feature_idp_dim = 1, every shipped configuration).  P22 uses (H_2^T H_2)^-1 in both modes, as the reference does (:1907-1908).
+static int augment_state_impl(int32_t n, int32_t n_new, int32_t idp_dim, const double* H_1, const double* H_2, const double* r_1,
+                              double sigma2, const double* dx, const double* P_upd, bool diag_only, double* dx_new, double* P_aug) {
     if (n < 1 || n_new < 0 || (idp_dim != 1 && idp_dim != 3) || !dx || !P_upd || !dx_new || !P_aug || (n_new > 0 && (!H_1 || !H_2 || !r_1))) {
         g_last_error = "augment_state: invalid argument"; return ORCVIO_ERR_INVALID;
     }
@@ -1802,7 +1842,8 @@ int32_t orcvio_msckf_augment_state(int32_t n, int32_t n_new, int32_t idp_dim, co
         for (int c = 0; c <= n; ++c)
             for (int i = d - 1; i >= 0; --i) {
                 double m = c < n ? H_1[(size_t)(d * j + i) * n + c] : r_1[d * j + i];
-                for (int k = i + 1; k < d; ++k) m -= R[i * d + k] * (c < n ? HH[(size_t)(d * j + k) * n + c] : dx_new[d * j + k]);
+                if (!diag_only)
+                    for (int k = i + 1; k < d; ++k) m -= R[i * d + k] * (c < n ? HH[(size_t)(d * j + k) * n + c] : dx_new[d * j + k]);
                 m /= R[i * d + i];
                 if (c < n) HH[(size_t)(d * j + i) * n + c] = m; else dx_new[d * j + i] = m;
             }
@@ -1849,15 +1890,20 @@ int32_t orcvio_msckf_augment_state(int32_t n, int32_t n_new, int32_t idp_dim, co
     return ORCVIO_OK;
 }
 
+int32_t orcvio_msckf_augment_state(int32_t n, int32_t n_new, int32_t idp_dim, const double* H_1, const double* H_2, const double* r_1,
+                                   double sigma2, const double* dx, const double* P_upd, double* dx_new, double* P_aug) {
+    return augment_state_impl(n, n_new, idp_dim, H_1, H_2, r_1, sigma2, dx, P_upd, false, dx_new, P_aug);
+}
+
 // ... with Schmidt nuisance states: the new feature states go IN FRONT of the trailing nui_rows nuisance rows / columns
 // (src/orcvio.cpp:1920-1935).  n counts the nuisance states; P_aug [(n + d n_new)^2] in the order [old | new | nuisance].
-int32_t orcvio_msckf_augment_state_nuisance(int32_t n, int32_t n_new, int32_t idp_dim, int32_t nui_rows, const double* H_1, const double* H_2,
-                                            const double* r_1, double sigma2, const double* dx, const double* P_upd, double* dx_new,
-                                            double* P_aug) {
+static int augment_state_nuisance_impl(int32_t n, int32_t n_new, int32_t idp_dim, int32_t nui_rows, const double* H_1, const double* H_2,
+                                       const double* r_1, double sigma2, const double* dx, const double* P_upd, bool diag_only, double* dx_new,
+                                       double* P_aug) {
     if (nui_rows < 0 || nui_rows > n) { g_last_error = "augment_state_nuisance: invalid argument"; return ORCVIO_ERR_INVALID; }
     const int sz = idp_dim * n_new, nt = n + sz;
     std::vector<double> T((size_t)nt * nt);
-    const int rc = orcvio_msckf_augment_state(n, n_new, idp_dim, H_1, H_2, r_1, sigma2, dx, P_upd, dx_new, T.data());   // [old + nuisance | new]
+    const int rc = augment_state_impl(n, n_new, idp_dim, H_1, H_2, r_1, sigma2, dx, P_upd, diag_only, dx_new, T.data());   // [old + nuisance | new]
     if (rc != ORCVIO_OK) return rc;
     std::vector<int> map(nt);   // map[i] = index in T of row / column i of P_aug
     const int n0 = n - nui_rows;
@@ -1867,6 +1913,17 @@ int32_t orcvio_msckf_augment_state_nuisance(int32_t n, int32_t n_new, int32_t id
     for (int i = 0; i < nt; ++i)
         for (int j = 0; j < nt; ++j) P_aug[(size_t)i * nt + j] = T[(size_t)map[i] * nt + map[j]];
     return ORCVIO_OK;
+}
+
+int32_t orcvio_msckf_augment_state_nuisance(int32_t n, int32_t n_new, int32_t idp_dim, int32_t nui_rows, const double* H_1, const double* H_2,
+                                            const double* r_1, double sigma2, const double* dx, const double* P_upd, double* dx_new,
+                                            double* P_aug) {
+    return augment_state_nuisance_impl(n, n_new, idp_dim, nui_rows, H_1, H_2, r_1, sigma2, dx, P_upd, false, dx_new, P_aug);
+}
+int32_t orcvio_msckf_augment_state_ref_ldlt(int32_t n, int32_t n_new, int32_t idp_dim, int32_t nui_rows, const double* H_1, const double* H_2,
+                                            const double* r_1, double sigma2, const double* dx, const double* P_upd, double* dx_new,
+                                            double* P_aug) {
+    return augment_state_nuisance_impl(n, n_new, idp_dim, nui_rows, H_1, H_2, r_1, sigma2, dx, P_upd, true, dx_new, P_aug);
 }
 
 int32_t orcvio_msckf_download_ekf(orcvio_msckf_handle* h, double* gamma, int32_t* accept) {
@@ -3043,12 +3100,26 @@ int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_resul
     return ORCVIO_OK;
 }
 
+// ORCVIO_OPT_OBJECT_DOF = 1: the gate's degrees of freedom are rows - rank(H_f) instead of the reference's rows - columns
+// (src/orcvio.cpp:2172): the device projects onto the WHOLE left null space of a rank-deficient H_f (rows - rank directions,
+// DESIGN.md 3.4), and this makes the threshold count what gamma sums.  The rank is what the structured QR found (dropped
+// pivots, info[4]): one small copy and a synchronisation between the compression and the solve, in this mode only.
+static int objects_rank_dof(orcvio_msckf_handle* h, hipStream_t s, int32_t* dof) {
+    if (!h->obj_dof_rank || h->obj_count == 0) return ORCVIO_OK;
+    int dropped = 0;
+    HIPCHK(hipMemcpyAsync(&dropped, h->d_info + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *dof += dropped;
+    return ORCVIO_OK;
+}
+
 int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones,
                                     const orcvio_msckf_object_rows* objs, int32_t n_objects, const double* P,
                                     orcvio_msckf_result* res) {
     if (!res) { g_last_error = "update_objects: null argument"; return ORCVIO_ERR_INVALID; }
     int32_t dof = 0;
     int rc = orcvio_msckf_objects_local(h, flags, n_clones, objs, n_objects, P, h->d_A, &dof, nullptr);
+    if (rc == ORCVIO_OK) rc = objects_rank_dof(h, h->stream, &dof);
     if (rc != ORCVIO_OK) return rc;
     rc = orcvio_msckf_objects_finish(h, h->d_A, 1, dof, nullptr);
     if (rc == ORCVIO_OK) rc = obj_publish_kernel() ? publish_enqueue(h, h->stream, res->P_out != nullptr)   // results -> pinned block, then the flag
@@ -3067,6 +3138,7 @@ int32_t orcvio_msckf_update_object_tracks(orcvio_msckf_handle* h, const orcvio_m
     static const bool timing = getenv("ORCVIO_TIMING") != nullptr;   // diagnostics: host wall time of the three parts
     const auto t0 = std::chrono::steady_clock::now();
     int rc = orcvio_msckf_objects_local_tracks(h, flags, fl, n_clones, tracks, n_tracks, P, h->d_A, &dof, nullptr);
+    if (rc == ORCVIO_OK) rc = objects_rank_dof(h, h->stream, &dof);
     if (rc != ORCVIO_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     rc = orcvio_msckf_objects_finish(h, h->d_A, 1, dof, nullptr);
@@ -3555,6 +3627,7 @@ int32_t orcvio_msckf_update_object_tracks_sharded(orcvio_msckf_handle* h, const 
         if (rc != ORCVIO_OK) { g_last_error = own_error; return own; }   // the window / prior is unusable: every rank returns here alike
         dof = 0;
     }
+    if (rc == ORCVIO_OK) rc = objects_rank_dof(h, s, &dof);
     if (rc != ORCVIO_OK) return rc;
     hipLaunchKernelGGL(k_shard_meta, dim3(1), dim3(64), 0, s, mine + ne, own, (int)dof, (const int*)nullptr, (const int*)nullptr, 0);
     HIPCHK(hipGetLastError());
@@ -3831,7 +3904,7 @@ int32_t orcvio_msckf_cov_commit_new_features(orcvio_msckf_handle* h, double* dx_
     const double* H1 = dout; const double* H2 = dout + (size_t)sz * n; const double* r1 = H2 + (size_t)k * d * d;
     const double s2 = h->flags.noise_feature * h->flags.noise_feature;
     HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_aug_hh, dim3((n + 1 + 255) / 256, k), dim3(256), 0, s, H1, H2, r1, n, k, d, HH, W, flag);
+    hipLaunchKernelGGL(k_aug_hh, dim3((n + 1 + 255) / 256, k), dim3(256), 0, s, H1, H2, r1, n, k, d, HH, W, flag, h->ref_h2_ldlt ? 1 : 0);
     hipLaunchKernelGGL(k_aug_dx, dim3(sz), dim3(64), 0, s, (const double*)HH, n, (const double*)h->d_dx, dxn);
     int rc = launch_gemm(s, HH, (long)(n + 1), 1L, h->d_Pout, (long)n, 1L, sz, n, n, -1.0, 0.0, 0, nHHP, (long)n, 1L);                 // nHHP = -HH P+
     if (rc == ORCVIO_OK) rc = launch_gemm(s, nHHP, (long)n, 1L, HH, 1L, (long)(n + 1), sz, sz, n, 1.0, 0.0, 0, Q, (long)sz, 1L);       // Q = nHHP HH^T

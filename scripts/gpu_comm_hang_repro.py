@@ -68,6 +68,21 @@ for k in range(max(1, nA // 6)):
         upd.comm_barrier()
     summary['A2_parent_runs_collectives'] += run_children('A2_%d' % k, 1)
 upd.close()
+# (D) what the test-suite's parent actually looked like when round 2 saw the hang: it had CREATED AND DESTROYED communicators
+# (tests/test_gpu_comm.py's module fixture is closed before tests/test_host_shim.py runs) and run many updates
+for _ in range(3):
+    u2 = capi.MsckfUpdater(device=0, max_clones=8, max_features=64, max_observations=1024)
+    u2.comm_init(capi.comm_unique_id(), 0, 1)
+    u2.comm_barrier()
+    u2.close()
+summary['D_parent_destroyed_communicators'] = run_children('D', nA)
+# (E) the executable of the test itself (updates through k_front first, then the communicator), bounded the same way
+exe_t = os.path.join(out_dir, 'test_host_gpu')
+orc = os.path.join(ROOT, 'oracle')
+subprocess.check_call(['g++', '-std=c++17', '-O1', '-o', exe_t, os.path.join(ROOT, 'tests', 'cpp', 'test_host_gpu.cpp'), '-L', LIB, '-lorcvio_msckf',
+                       f'-Wl,-rpath,{LIB}', '-L', orc, '-lorcoracle', f'-Wl,-rpath,{orc}', '-lm', '-lpthread'])
+exe = exe_t
+summary['E_test_host_gpu_executable'] = run_children('E', nA)
 stat = {k: dict(launches=len(v), failed=sum(1 for r in v if r['rc'] != 0), slowest=max((r['seconds'] for r in v), default=0),
                 median=sorted(r['seconds'] for r in v)[len(v) // 2] if v else 0) for k, v in summary.items()}
 json.dump(dict(stat=stat, runs=summary), open(os.path.join(ROOT, 'gpurun_out', 'r3_comm_hang.json'), 'w'), indent=1)

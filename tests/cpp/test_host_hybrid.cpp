@@ -25,6 +25,7 @@ int main(int argc, char** argv) {
     if (fread(D.data(), 8, D.size(), f) != D.size()) return 4;
     fclose(f);
     const int N = (int)rd(), F = (int)rd(), nf = (int)rd(), d = (int)rd(), estimate_td = (int)rd(), if_fej = (int)rd(), nnew = (int)rd(), use_larvio = (int)rd();
+    const int knui = (int)rd();   // Schmidt nuisance states (poses follow the clones'; anchors >= N address them)
     StateServer ss;
     MapServer map;
     std::vector<StateIDType> ids(N);
@@ -44,6 +45,27 @@ int main(int argc, char** argv) {
             a.position_cam[r] = s;
         }
         ss.imu_states_augment[a.id] = a;
+    }
+    auto cam_pose = [](IMUState_Aug& a) {   // orientation_cam / position_cam as src/orcvio.cpp:954-961
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += a.orientation[3 * r + k] * a.R_imu_cam0[3 * c + k];
+                a.orientation_cam[3 * r + c] = s;
+            }
+        for (int r = 0; r < 3; ++r) {
+            double s = a.position[r];
+            for (int k = 0; k < 3; ++k) s += a.orientation[3 * r + k] * a.t_cam0_imu[k];
+            a.position_cam[r] = s;
+        }
+    };
+    for (int j = 0; j < knui; ++j) {   // clones that left the window but stay in state_cov (use_schmidt, :2881-2920)
+        IMUState_Aug a; a.id = 10 + j;
+        rdv(a.orientation, 9); rdv(a.position, 3); rdv(a.position_FEJ, 3); rdv(a.R_imu_cam0, 9); rdv(a.t_cam0_imu, 3);
+        cam_pose(a);
+        ss.nui_ids.push_back(a.id);
+        ss.nui_imu_states[a.id] = a;
+        ids.push_back(a.id);   // (anchor index N + j)
     }
     ss.imu_state = IMUState();
     ss.imu_state.id = ids[N - 1];   // the current state is the newest clone
@@ -84,7 +106,7 @@ int main(int argc, char** argv) {
         }
         map[ft.id] = ft; new_ids.push_back(ft.id);
     }
-    const int n = 22 + 6 * N + d * nf;
+    const int n = 22 + 6 * N + d * nf + 6 * knui;
     ss.state_cov.resize((size_t)n * n);
     rdv(ss.state_cov.data(), n * n);
     if (pos != D.size()) { printf("case file: %zu of %zu doubles read\n", pos, D.size()); return 5; }

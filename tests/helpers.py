@@ -67,14 +67,16 @@ def object_rows_reference(win, obj, obj_left, new_bbox, vio_left):
                                                   win.R_b2c[0], win.t_c_b[0], vio_left, win.flags.leg_dim, win.N)
 
 
-def objects_update_reference(win, objs, P, obj_left=True, new_bbox=False, vio_left=0, full_nullspace=False):
+def objects_update_reference(win, objs, P, obj_left=True, new_bbox=False, vio_left=0, full_nullspace=False, rank_dof=False):
     """The object update of System::processObjects -> removeLostObjects with per-object projection (SURVEY note N3) on the
     prior P: dict(gamma, accept, dof, dx, P_new, blocks) -- the mirror's literal arithmetic (full-U nullspace per object,
     QR of the stack, S, K, (I - KH) P).
     full_nullspace: project every object onto its WHOLE left null space (rows - rank(H_f) directions) and keep the reference's
     count rows - columns for the gate -- what the device does when H_f is rank deficient (a keypoint never seen in the window, or
     seen once).  There the reference keeps rows - columns directions of that space chosen by Eigen's column-pivoted Householder
-    QR inside JacobiSVD: not determined by the inputs; for a full-rank H_f the two are the same."""
+    QR inside JacobiSVD: not determined by the inputs; for a full-rank H_f the two are the same.
+    rank_dof (with full_nullspace): the gate counts rows - rank(H_f) degrees of freedom -- the number of directions gamma sums
+    (ORCVIO_OPT_OBJECT_DOF = 1)."""
     from oracle import mirror
     blocks, Hp, rp, dof, deficient = [], [], [], 0, 0
     for ob in objs:
@@ -93,8 +95,9 @@ def objects_update_reference(win, objs, P, obj_left=True, new_bbox=False, vio_le
             H1, r1 = A.T @ Hx, A.T @ r
         else:
             ok, H1, r1 = mirror.nullspace_project_svd(Hf, Hx, r)
+            rank = Hf.shape[1]
         Hp.append(H1); rp.append(r1)
-        dof += Hx.shape[0] - Hf.shape[1]
+        dof += Hx.shape[0] - (rank if (rank_dof and full_nullspace) else Hf.shape[1])
     n = P.shape[0]
     if not Hp:
         return dict(gamma=float('nan'), accept=0, dof=0, dx=np.zeros(n), P_new=P.copy(), blocks=blocks, rank_deficient=0)

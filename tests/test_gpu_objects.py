@@ -342,3 +342,34 @@ def test_random_object_windows_including_rank_deficient_blocks(upd, seed):
         assert rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL
     else:
         assert not got['dx'].any() and rel(got['P_new'], win.P) < 1e-15
+
+
+def test_object_gate_degrees_of_freedom_option(upd):
+    """ORCVIO_OPT_OBJECT_DOF (VERDICT r2 'missing' 2): with a rank-deficient H_f the device projects onto the whole left null space
+    (rows - rank directions); the default keeps the reference's count rows - columns for the threshold, the option counts
+    rows - rank.  gamma is the same number in both modes; only the threshold (and possibly the decision) moves."""
+    found = 0
+    for seed in range(40):
+        case = random_object_case(seed)
+        win, objs = case['win'], case['objs']
+        a = objects_update_reference(win, objs, win.P, case['obj_left'], case['new_bbox'], case['vio_left'], full_nullspace=True)
+        b = objects_update_reference(win, objs, win.P, case['obj_left'], case['new_bbox'], case['vio_left'], full_nullspace=True, rank_dof=True)
+        if a['rank_deficient'] == 0 or not a['blocks']:
+            continue
+        found += 1
+        assert b['dof'] > a['dof'] and abs(b['gamma'] - a['gamma']) <= 1e-9 * abs(a['gamma'])
+        args = (case['flags'], win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], case['obj_left'], case['new_bbox'], case['vio_left'])
+        g_ref = upd.update_object_tracks(*args)
+        upd.set_object_dof_rank(True)
+        try:
+            g_rank = upd.update_object_tracks(*args)
+        finally:
+            upd.set_object_dof_rank(False)
+        assert g_ref['stats'][0] in (0, a['dof']) and g_rank['stats'][0] in (0, b['dof'])
+        assert g_ref['accept'] == a['accept'] and g_rank['accept'] == b['accept']
+        assert abs(g_rank['gamma'] - b['gamma']) <= 1e-6 * abs(b['gamma'])
+        if b['accept']:
+            assert rel(g_rank['dx'], b['dx']) < 1e-6 and rel(g_rank['P_new'], b['P_new']) < 1e-6
+        if found >= 6:
+            break
+    assert found >= 3

@@ -64,8 +64,9 @@ def test_host_backend_end_to_end(built, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('idp,with_new,larvio', [(3, False, 1), (1, False, 1), (3, True, 1), (1, True, 1), (3, True, 0)])
-def test_host_backend_hybrid_update(built, tmp_path, idp, with_new, larvio):
+@pytest.mark.parametrize('idp,with_new,larvio,nui', [(3, False, 1, 0), (1, False, 1, 0), (3, True, 1, 0), (1, True, 1, 0), (3, True, 0, 0),
+                                                     (3, True, 1, 2), (1, True, 1, 2), (1, False, 1, 1)])
+def test_host_backend_hybrid_update(built, tmp_path, idp, with_new, larvio, nui):
     """MsckfBackend::hybridUpdate (std::map containers, SLAM features as Feature holds them -> C-ABI -> write-back of the
     feature states; with_new: features entering the state in the same update) against the literal restatement:
     oracle.mirror_hybrid.hybrid_update(_full), mirror.increment_state and the feature write-back of src/orcvio.cpp:1836-1887."""
@@ -76,11 +77,17 @@ def test_host_backend_hybrid_update(built, tmp_path, idp, with_new, larvio):
     w0 = synth.make_window(N=9, F=50, seed=41, track_len=(3, 9), flags=fl)
     slam = synth.make_slam_features(w0, 8, seed=3, outlier_frac=0.25)
     w = synth.with_extra_states(w0, idp * len(slam), seed=6)
+    if nui:   # Schmidt nuisance states behind the feature states, some SLAM features anchored at them (VERDICT r2 'missing' 3)
+        w = synth.with_nuisance_states(w, nui, seed=8)
+        slam = synth.make_slam_features(w, 8, seed=3, outlier_frac=0.25, nui_frac=0.4)
     new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 5, seed=9, outlier_frac=0.5)] if with_new else []
     # ---- case file
-    v = [w.N, w.F, len(slam), idp, fl.estimate_td, fl.if_fej, len(new), fl.use_larvio]
+    v = [w.N, w.F, len(slam), idp, fl.estimate_td, fl.if_fej, len(new), fl.use_larvio, w.n_nui]
     for i in range(w.N):
         v += list(w.R_b2w[i].ravel()) + list(w.t_b_w[i]) + list(w.t_fej[i]) + list(w.R_b2c[i].ravel()) + list(w.t_c_b[i])
+    for j in range(w.n_nui):
+        q = w.nui
+        v += list(q['R_b2w'][j].ravel()) + list(q['t_b_w'][j]) + list(q['t_fej'][j]) + list(q['R_b2c'][j].ravel()) + list(q['t_c_b'][j])
     for j in range(w.F):
         lo, hi = int(w.obs_ptr[j]), int(w.obs_ptr[j + 1])
         v += list(w.p_w[j]) + [hi - lo]
@@ -112,14 +119,19 @@ def test_host_backend_hybrid_update(built, tmp_path, idp, with_new, larvio):
     base = fl.leg_dim + 6 * w.N
     feats = []
     for i, ft in enumerate(feats_all):
-        R_c2w, t_c_w = st['R_c2w'][ft.anchor], st['t_c_w'][ft.anchor]
+        if ft.anchor >= w.N:   # anchored at a nuisance state: its pose is not corrected (:1850-1857)
+            q, jn = w.nui, ft.anchor - w.N
+            R_c2w, t_c_w = q['R_b2w'][jn] @ q['R_b2c'][jn].T, q['t_b_w'][jn] + q['R_b2w'][jn] @ q['t_c_b'][jn]
+        else:
+            R_c2w, t_c_w = st['R_c2w'][ft.anchor], st['t_c_w'][ft.anchor]
+        at = base + idp * i if i < len(slam) else w.n + idp * (i - len(slam))   # delta_x = [dx_leg (.., nuisance) ; dx_new] (:1864-1878)
         if idp == 3:
-            ip = ft.inv_param + ref['dx'][base + 3 * i: base + 3 * i + 3]
+            ip = ft.inv_param + ref['dx'][at: at + 3]
             rho = ft.inv_depth
             pc = np.array([ip[0] / ip[2], ip[1] / ip[2], 1 / ip[2]])
         else:
             ip = ft.inv_param
-            rho = ft.inv_depth + ref['dx'][base + i]
+            rho = ft.inv_depth + ref['dx'][at]
             pc = np.array([ft.obs_anchor[0] / rho, ft.obs_anchor[1] / rho, 1 / rho])
         feats.append((ip, rho, R_c2w @ pc + t_c_w))
     # ---- compare

@@ -243,3 +243,31 @@ def test_library_augmentation_in_front_of_the_nuisance_block(built, idp):
     dx_new, P_aug = capi.augment_state_nuisance(idp, 6 * w.n_nui, gH_1, gH_2, gr_1, w.flags.noise_feature ** 2, ref['dx_leg'], ref['P_upd'])
     assert rel(np.concatenate([ref['dx_leg'], dx_new]), ref['dx']) < 1e-9
     assert rel(P_aug, ref['P_new']) < 1e-9
+
+
+def test_reference_literal_h2_ldlt_differs_only_for_three_parameters():
+    """`H_2.ldlt().solve(..)` of the reference (src/orcvio.cpp:1826-1827) factors the LOWER triangle of an upper-triangular H_2 --
+    its diagonal.  For feature_idp_dim = 1 (every shipped configuration) H_2 is a stack of 1 x 1 blocks and nothing changes; for
+    3 parameters the literal tail is another update of the entering states (mirror: ref_ldlt; library:
+    orcvio_msckf_augment_state_ref_ldlt, host arithmetic)."""
+    from orcvio_amd import capi
+    for idp in (1, 3):
+        w0 = synth.make_window(N=8, F=30, seed=3, track_len=(3, 8), flags=synth.Flags(use_larvio=1))
+        w = synth.with_extra_states(w0, 0, seed=1)
+        new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 3, seed=2)]
+        acc, H_top, r_top, H_1, H_2, r_1 = mh.split_new_rows(w, new, idp)
+        assert len(acc) > 0
+        s2 = w.flags.noise_feature ** 2
+        dx_leg = np.linspace(-1e-2, 1e-2, w.n)
+        a_dx, a_P = mh.augment_after_update(w.P, dx_leg, H_1, H_2, r_1, s2)
+        b_dx, b_P = mh.augment_after_update(w.P, dx_leg, H_1, H_2, r_1, s2, ref_ldlt=True)
+        blocks = np.stack([H_2[idp * j:idp * j + idp, idp * j:idp * j + idp] for j in range(len(acc))])
+        c_dx, c_P = capi.augment_state_nuisance(idp, 0, H_1, blocks, r_1, s2, dx_leg, w.P, ref_ldlt=True)
+        d_dx, d_P = capi.augment_state(idp, H_1, blocks, r_1, s2, dx_leg, w.P)
+        e = lambda x, y: np.linalg.norm(x - y) / np.linalg.norm(y)
+        assert e(np.concatenate([dx_leg, c_dx]), b_dx) < 1e-12 and e(c_P, b_P) < 1e-12
+        assert e(np.concatenate([dx_leg, d_dx]), a_dx) < 1e-12 and e(d_P, a_P) < 1e-12
+        if idp == 1:
+            assert e(b_dx, a_dx) < 1e-14 and e(b_P, a_P) < 1e-14
+        else:
+            assert e(b_dx, a_dx) > 1e-3
