@@ -423,11 +423,23 @@ def main():
                     pivots=2 * n, block_steps=2 * ((n + 15) // 16))
         except Exception:
             pass
+        executed = None
+        if critical_path and dom in critical_path and 'executed_mfma_tflops' in critical_path[dom]:
+            executed = dict(mfma_tflops=critical_path[dom]['executed_mfma_tflops'], frac=critical_path[dom]['executed_mfma_tflops'] / FP64_PEAK_TFLOPS,
+                            mfma_busy_frac=critical_path[dom].get('mfma_busy_frac'),
+                            what='FP64 matrix-core work this kernel EXECUTES (PMC SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flop of the committed profile) / '
+                                 'its time in this run: the utilisation figure')
         roofline = dict(bound='mfma', kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic,
-                        note='achieved = algorithmic FP64 work of the reference algorithm attributed to this kernel (SURVEY 8d '
-                             'dense minimum) / kernel time, median of 20 launches measured with HIP events on the launch stream; '
-                             'critical_path lists what every kernel EXECUTES on the matrix cores (PMC) and how busy they are',
+                        frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic, executed=executed,
+                        per_kernel_frac={k: round(kflops[k] / (prof[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) for k in prof},
+                        note='achieved = algorithmic FP64 work of the reference algorithm attributed to the dominant kernel (SURVEY 8d '
+                             'dense minimum-work count W of what the launch covers) / kernel time, median of 20 launches measured with HIP '
+                             'events on the launch stream.  For k_front (tracks + compression + chol P) that count is the DENSE count of the '
+                             'reference algorithm -- H\'PH\'^T of every track, the QR of the 22 800-row stack -- which this launch does not '
+                             'execute (13 non-zeros per un-projected row, Gram form): frac can exceed 1 there and says how fast a dense '
+                             'implementation would have to run, not how busy the matrix cores are -- `executed` is that.  For the '
+                             'factorisation + solve kernel (k_potrf_solve(M), the dominant kernel of rounds 1-2, per_kernel_frac) the count '
+                             'n^3/3 + n^2 (n+1) IS the work: 0.3 % of peak, a latency-bound chain (critical_path).',
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},
                         algorithmic_equiv=dict(
                             what='dense-count flops of the reference algorithm divided by OUR kernel time: how fast a dense '
