@@ -16,76 +16,6 @@ __global__ __launch_bounds__(256) void k_ingest(const u32x4* __restrict__ src, u
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
-// k_ingest with the derived index arrays made on the way: the observations grouped by clone (a stable counting sort of obs_clone;
-// the sparse part of the compression reads every clone's rows contiguously) -- position of every observation in the clone-sorted
-// order (clone_obs) and the first sparse row of every clone (clone_ptr = 2 x the exclusive prefix of the clone counts).  The host
-// used to make them in two scalar passes over the observations (~6 us at 12 000 observations, on the critical path of a
-// zero-copy update); here block 0 does it while the other blocks copy, out of the same pinned bytes.
-//   block 0:  keys -> per-thread counts per clone (LDS) -> exclusive scan over the threads, per clone -> clone bases -> positions
-//   blocks 1..: the three byte ranges of the arena that travel (the two derived arrays lie between them and are not copied)
-// Limits (the caller checks them): nobs <= 255 * 256, N <= 64.  Dynamic LDS: 256 * 64 * 3 bytes + the keys as bytes.
-struct IngestSortArgs {
-    const u32x4* src[3]; u32x4* dst[3]; unsigned long long n16[3];
-    const int* obs_clone_host;    // [nobs] in the pinned arena (16-byte aligned)
-    int* clone_obs;               // [nobs] device
-    int* clone_ptr;               // [N + 1] device
-    int nobs, N;
-};
-#define INGEST_SORT_T 256
-__host__ __device__ inline size_t ingest_sort_lds(int nobs) { return (size_t)INGEST_SORT_T * 64 * 3 + (((size_t)nobs + 15) & ~(size_t)15); }
-__global__ __launch_bounds__(INGEST_SORT_T) void k_ingest_sort(IngestSortArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sort[];
-    if (blockIdx.x > 0) {
-        const size_t stride = (size_t)(gridDim.x - 1) * INGEST_SORT_T;
-        for (int q = 0; q < 3; ++q)
-            for (size_t i = (size_t)(blockIdx.x - 1) * INGEST_SORT_T + threadIdx.x; i < a.n16[q]; i += stride) a.dst[q][i] = __builtin_nontemporal_load(a.src[q] + i);
-        return;
-    }
-    unsigned char* cnt = smem_sort;                                                            // [T][64] observations of clone b among this thread's keys
-    unsigned short* off = reinterpret_cast<unsigned short*>(smem_sort + INGEST_SORT_T * 64);   // [T][64] ... among the threads in front of it
-    unsigned char* key = smem_sort + INGEST_SORT_T * 64 * 3;                                   // [nobs] the clone indices as bytes
-    __shared__ int base[65];
-    const int t = threadIdx.x;
-    {   // the keys out of pinned memory once, 16 bytes per lane (a scalar read of host memory is a PCIe round trip each)
-        const u32x4* k4 = reinterpret_cast<const u32x4*>(a.obs_clone_host);
-        const int n4 = (a.nobs + 3) / 4;
-        for (int i = t; i < n4; i += INGEST_SORT_T) {
-            const u32x4 v = __builtin_nontemporal_load(k4 + i);
-            key[4 * i] = (unsigned char)v.x; key[4 * i + 1] = (unsigned char)v.y; key[4 * i + 2] = (unsigned char)v.z; key[4 * i + 3] = (unsigned char)v.w;
-        }
-    }
-    for (int b = 0; b < a.N; ++b) cnt[t * 64 + b] = 0;
-    __syncthreads();
-    const int per = (a.nobs + INGEST_SORT_T - 1) / INGEST_SORT_T;
-    const int k0 = t * per, k1 = (k0 + per < a.nobs) ? k0 + per : a.nobs;
-    for (int k = k0; k < k1; ++k) cnt[t * 64 + key[k]]++;
-    __syncthreads();
-    const int wave = t >> 6, l = t & 63;
-    for (int b = wave; b < a.N; b += INGEST_SORT_T / 64) {   // exclusive scan of cnt[.][b] over the threads: 4 per lane, then across the lanes
-        int c[4], s = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { c[i] = cnt[(4 * l + i) * 64 + b]; s += c[i]; }
-        int inc = s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (l >= o) inc += v; }
-        int run = inc - s;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { off[(4 * l + i) * 64 + b] = (unsigned short)run; run += c[i]; }
-        if (l == 63) base[b + 1] = inc;   // observations of clone b
-    }
-    __syncthreads();
-    if (t == 0) {
-        base[0] = 0;
-        for (int b = 0; b < a.N; ++b) base[b + 1] += base[b];
-    }
-    __syncthreads();
-    if (t <= a.N) a.clone_ptr[t] = 2 * base[t];
-    for (int k = k0; k < k1; ++k) {
-        const int b = key[k];
-        a.clone_obs[k] = base[b] + (int)off[t * 64 + b]++;
-    }
-}
-
 // The epilogue of a zero-copy update, ONE launch behind k_finish_sqrt:
 //   workgroup 0                 the small result block [info | dx | gamma | accept] -> host-coherent memory
 //   workgroups 1 .. nb_P        P+ -> host-coherent memory (want_P)

@@ -97,7 +97,6 @@ struct orcvio_msckf_handle {
     unsigned long long* d_seq = nullptr;      // device-side twin (the value k_epilogue stores to the flag)
     int* d_pubcnt = nullptr;                  // arrival counter of k_epilogue's workgroups
     unsigned long long pub_enqueued = 0;      // publications enqueued so far (k_epilogue launches, stream order): the flag value to wait for
-    bool sort_on_device = false;              // the grouping of the observations by clone is made by k_ingest_sort (zero-copy updates)
     bool io_open = false, io_with_P = false;  // orcvio_msckf_io_begin has laid the arena out and the caller is filling it
     double io_spin_seconds = 2.0;             // bound of the host's wait on h_flag (then: stream synchronisation, then ERR_TIMEOUT)
     bool last_sharded = false;                // the last finished update went through the handle's all-gather (status words in info[9..12])
@@ -706,7 +705,7 @@ static inline size_t upload_bytes(const orcvio_msckf_handle* h) {
 
 // The arena holds poses, obs_ptr, p_w, obs_clone, obs_z (obs_zvel, P): validate the index arrays and derive row_ptr (rows of
 // every projected block), clone_obs / clone_ptr (observations grouped by clone: the sparse part of the compression).
-static int upload_finalize(orcvio_msckf_handle* h, const char* who, bool may_sort_on_device = false) {
+static int upload_finalize(orcvio_msckf_handle* h, const char* who) {
     const int N = h->N, F = h->F, nobs = h->nobs;
     // the prior: the caller's P in the arena, or the resident covariance -- with its square-root factor if that is known NOW
     // (an orcvio_msckf_io_update may follow a commit, a cov_set, an augmentation of the previous one)
@@ -740,16 +739,11 @@ static int upload_finalize(orcvio_msckf_handle* h, const char* who, bool may_sor
     std::memcpy(st + h->io_rptr, row_ptr, sizeof(int) * (F + 1));
     // observations grouped by clone: position of every observation in the clone-sorted order, and the row range of
     // every clone (two rows per observation) for the sparse part of the compression; the clone indices are checked on the way.
-    // A zero-copy update leaves the grouping to the first kernel of its graph (k_ingest_sort: the same stable order) and only
-    // checks the indices here -- one vectorisable pass instead of two scalar ones.
-    static const bool device_sort_env = [] { const char* e = getenv("ORCVIO_DEVICE_SORT"); return e ? atoi(e) != 0 : true; }();
-    h->sort_on_device = may_sort_on_device && device_sort_env && nobs > 0 && nobs <= 255 * INGEST_SORT_T && N <= 64;
-    if (h->sort_on_device) {
-        unsigned bad = 0;
-        for (int o = 0; o < nobs; ++o) bad |= (unsigned)((unsigned)obs_clone[o] >= (unsigned)N);
-        if (bad) { g_last_error = std::string(who) + ": obs_clone out of range"; return ORCVIO_ERR_INVALID; }
-        h->s_chunks = N;
-    } else {
+    // (Two scalar passes over the observations, ~8 us at 12 000 of them, on the critical path of a zero-copy update.  Tried in
+    //  round 3 and not kept: the same stable counting sort by one workgroup of the ingest kernel while the others copy -- the
+    //  host's part fell to 1.6 us, but that workgroup needed ~30 us (a PCIe round trip for the keys, then 47 dependent LDS
+    //  byte updates per thread, twice) against 9.5 us for the copy it was to hide under: 0.148 ms per update instead of 0.127.)
+    {
         int cnt[ORCVIO_MAX_CLONES + 2] = {0};
         unsigned bad = 0;
         for (int o = 0; o < nobs; ++o) {
@@ -815,7 +809,7 @@ static void stage_inputs(orcvio_msckf_handle* h, const orcvio_msckf_window* w, c
 }
 
 static int upload_to_arena(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, const orcvio_msckf_window* w,
-                           const orcvio_msckf_tracks* tr, const double* P, const char* who, bool may_sort_on_device = false) {
+                           const orcvio_msckf_tracks* tr, const double* P, const char* who) {
     if (!h || !flags || !w || !tr || !w->R_b2w || !w->t_b_w || !w->R_b2c || !w->t_c_b || !tr->obs_ptr) {
         g_last_error = std::string(who) + ": null argument";
         return ORCVIO_ERR_INVALID;
@@ -829,7 +823,7 @@ static int upload_to_arena(orcvio_msckf_handle* h, const orcvio_msckf_flags* fla
     int rc = upload_begin(h, flags, N, F, nobs, P != nullptr, tr->obs_zvel != nullptr, who);
     if (rc != ORCVIO_OK) return rc;
     stage_inputs(h, w, tr, P);
-    rc = upload_finalize(h, who, may_sort_on_device);
+    rc = upload_finalize(h, who);
     if (rc != ORCVIO_OK) return rc;
     h->pw_missing = (F > 0 && !tr->p_w);
     return ORCVIO_OK;
@@ -2111,37 +2105,15 @@ int32_t orcvio_msckf_download(orcvio_msckf_handle* h, orcvio_msckf_result* res) 
 static unsigned long long io_signature(const orcvio_msckf_handle* h, hipStream_t s, bool want_P, bool commit) {
     unsigned long long sig = launch_signature(h, s, h->h_stage_dev, (long)(0x100 | (want_P ? 1 : 0) | (commit ? 2 : 0)));
     auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
-    mix((unsigned long long)upload_bytes(h)); mix((unsigned long long)(size_t)h->d_Stmp); mix((unsigned long long)(size_t)h->d_Pres); mix(h->sort_on_device);
+    mix((unsigned long long)upload_bytes(h)); mix((unsigned long long)(size_t)h->d_Stmp); mix((unsigned long long)(size_t)h->d_Pres);
     mix(h->factor_opt); mix((unsigned long long)h->outs_small);
     return sig;
 }
 
 static int io_enqueue(orcvio_msckf_handle* h, hipStream_t s, bool want_P, bool commit) {
     const int n = h->n;
-    // inputs: one pass over the arena, 16 bytes per lane, enough workgroups for the block to be one or two iterations; block 0
-    // groups the observations by clone meanwhile (k_ingest_sort), unless the host has done that (upload_finalize)
-    int rc = ORCVIO_OK;
-    if (h->sort_on_device) {
-        IngestSortArgs ia{};
-        const size_t lo[3] = {0, h->io_pw, h->io_z}, hi[3] = {h->io_cptr, h->io_cobs, upload_bytes(h)};   // (clone_ptr and clone_obs lie between)
-        size_t total16 = 0;
-        for (int q = 0; q < 3; ++q) {
-            ia.src[q] = reinterpret_cast<const u32x4*>(h->h_stage_dev + lo[q]);
-            ia.dst[q] = reinterpret_cast<u32x4*>(h->d_in + lo[q]);
-            ia.n16[q] = (hi[q] - lo[q] + 15) / 16;
-            total16 += ia.n16[q];
-        }
-        ia.obs_clone_host = reinterpret_cast<const int*>(h->h_stage_dev + h->io_oclone);
-        ia.clone_obs = h->d_clone_obs; ia.clone_ptr = h->d_clone_ptr; ia.nobs = h->nobs; ia.N = h->N;
-        int grid = (int)((total16 + INGEST_SORT_T - 1) / INGEST_SORT_T);
-        if (grid > 4 * h->n_cus) grid = 4 * h->n_cus;
-        if (grid < 1) grid = 1;
-        static bool attr_set = false;
-        if (!attr_set) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ingest_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-        hipLaunchKernelGGL(k_ingest_sort, dim3(1 + grid), dim3(INGEST_SORT_T), ingest_sort_lds(h->nobs), s, ia);
-        HIPCHK(hipGetLastError());
-    } else
-        rc = launch_ingest(h, s, h->h_stage_dev, h->d_in, upload_bytes(h));
+    // inputs: one pass over the arena, 16 bytes per lane, enough workgroups for the block to be one or two iterations
+    int rc = launch_ingest(h, s, h->h_stage_dev, h->d_in, upload_bytes(h));
     if (rc == ORCVIO_OK) rc = enqueue_update(h, s);
     if (rc != ORCVIO_OK) return rc;
     // ONE launch behind the update: the results to host-coherent memory, the commit (refused on the device if the update is),
@@ -2318,7 +2290,7 @@ int32_t orcvio_msckf_io_update(orcvio_msckf_handle* h, int32_t want_P, int32_t c
     const auto tf0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(h->device));
     const auto tf1 = std::chrono::steady_clock::now();
-    int rc = upload_finalize(h, "orcvio_msckf_io_update", true);
+    int rc = upload_finalize(h, "orcvio_msckf_io_update");
     if (timing) {
         static int calls = 0;
         if ((++calls % 64) == 0)
@@ -2337,7 +2309,7 @@ int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_
     static const bool timing = getenv("ORCVIO_TIMING") != nullptr;   // diagnostics: calls slower than 2 ms are broken down
     if (!result) { g_last_error = "update_features: null result"; return ORCVIO_ERR_INVALID; }
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = upload_to_arena(h, flags, window, tracks, P, "orcvio_msckf_update_features", true);
+    int rc = upload_to_arena(h, flags, window, tracks, P, "orcvio_msckf_update_features");
     if (rc != ORCVIO_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     const bool want_P = result->P_out != nullptr;
