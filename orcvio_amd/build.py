@@ -10,8 +10,8 @@ LIB_DIR = os.path.join(_HERE, 'lib')
 LIB = os.path.join(LIB_DIR, 'liborcvio_msckf.so')
 LIB_DBG = os.path.join(LIB_DIR, 'liborcvio_msckf_dbg.so')   # the same sources + the orcvio_msckf_debug_* test hooks
 SOURCES = ['msckf_capi.hip']
-DEPS = ['msckf_capi.hip', 'io_ops.hpp', 'msckf_kernels.hpp', 'msckf_math.hpp', 'object_rows.hpp', 'triangulate.hpp', 'cov_ops.hpp', 'ekf_rows.hpp',
-        os.path.join('..', '..', 'include', 'orcvio_msckf.h')]
+# every file the one translation unit is made of: the C-ABI sections (capi_*.inc), the kernel headers, the public header
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp', '.inc'))) + [os.path.join('..', '..', 'include', 'orcvio_msckf.h')]
 
 
 def _stale(lib) -> bool:
