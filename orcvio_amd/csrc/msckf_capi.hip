@@ -18,6 +18,7 @@
 
 #include <functional>
 #include "msckf_kernels.hpp"
+#include "feature_split.hpp"
 #include "triangulate.hpp"
 #include "cov_ops.hpp"
 #include "ekf_rows.hpp"
@@ -160,6 +161,9 @@ struct orcvio_msckf_handle {
     char* d_new = nullptr; size_t new_cap = 0, new_out_off = 0;   // entering features (orcvio_msckf_upload_new_features): inputs, then H_1 | H_2 | r_1
     int new_F = 0, new_idp = 3;
     double* d_Rf = nullptr;             // [maxF][6] R factor of every track's H_f (k_feature), for orcvio_msckf_augment_new_features
+    double* d_split = nullptr;          // scratch of the two-kernel front end for many tracks (feature_split.hpp): E and the gate's right-hand sides per track
+    size_t split_cap = 0;
+    int split_min_tracks = 1800;        // ORCVIO_SPLIT_TRACKS: track count from which k_feature_e + k_feature_gate replace k_feature (0 = never)
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     // multi-GPU: RCCL communicator of this handle (orcvio_msckf_comm_init), the all-gather buffer [world][NAP_max^2] and
     // the gathered degrees of freedom of a sharded object update

@@ -47,6 +47,27 @@ def test_2000_features_against_the_oracle(upd, cfg):
         assert got['stats'][4] == int(nv > 1.0 or npos > 1.5)
 
 
+@pytest.mark.parametrize('case', [dict(F=300, track_len=(3, 30), outlier_frac=0.2, seed=3),
+                                  dict(F=700, track_len=None, outlier_frac=0.05, seed=4, estimate_extrin=True),
+                                  dict(F=1, track_len=5, seed=5)])
+def test_split_tracks_front_end_against_the_fused_one(built, monkeypatch, case):
+    """k_feature_e + k_feature_gate (the form for F >= ORCVIO_SPLIT_TRACKS, 1 800 by default: the 2 000-track tests above run it)
+    forced on small ragged windows with rejected tracks, against k_feature on the same window: same gate decisions, same update."""
+    win = synth.make_window(N=30, flags=synth.Flags(use_larvio=1), **case)
+    out = {}
+    for name, thr in (('fused', '0'), ('split', '1')):
+        monkeypatch.setenv('ORCVIO_SPLIT_TRACKS', thr)   # read when the handle is created
+        u = capi.MsckfUpdater(device=0, max_clones=32, max_features=1024, max_observations=32768)
+        try:
+            out[name] = u.update_features(win)
+        finally:
+            u.close()
+    a, b = out['fused'], out['split']
+    assert np.array_equal(a['accept'], b['accept']) and (case['F'] == 1 or 0 < a['accept'].sum() < win.F)
+    assert rel(b['gamma'], a['gamma']) < 1e-9
+    assert rel(b['dx'], a['dx']) < 1e-9 and rel(b['P_new'] - win.P, a['P_new'] - win.P) < 1e-9
+
+
 def test_config4_four_shards_features_and_objects(upd):
     """Config 4 dealt four ways.  Features: each shard's block through run_local_to, the four blocks side by side (what the
     all-gather leaves on every rank), run_finish: equal to the oracle's single 2000-feature update.  Objects: 100 cars dealt
