@@ -138,6 +138,26 @@ def device_resident_ms(upd, steps=100, warm=10):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def fast_cpu_sweep(orc, win, reps=4):
+    """oracle/msckf_fast.c (the sparsity the device path exploits: 13 non-zeros per row in E = X P X^T, Gram form X^T X - T3^T T3)
+    over OpenMP team sizes: {threads: best ms}, the best team first.  One thread is part of the sweep: the honest single-core
+    figure of the minimum-work algorithm beside the literal port's."""
+    import ctypes
+    lib = orc.lib()
+    host = os.cpu_count() or 1
+    teams = sorted({t for t in (1, 4, 8, 16, 32, 64, 128, host) if t <= host})
+    sweep = {}
+    try:
+        for t in teams:
+            lib.orc_fast_set_threads(ctypes.c_int(t))
+            orc.msckf_update_fast(win)   # (team start-up)
+            sweep[t] = min(orc.msckf_update_fast(win)['seconds'] for _ in range(reps)) * 1e3
+    finally:
+        lib.orc_fast_set_threads(ctypes.c_int(0))
+    best = min(sweep, key=sweep.get)
+    return best, sweep
+
+
 def cpu_leg(orc, win, budget_s, what):
     """The CPU restatement beside a configuration: one thread (the literal port) and all cores (minimum-work algorithm, OpenMP),
     bounded: a window whose single-threaded update would exceed the budget is timed on its first tracks and scaled by the
@@ -160,9 +180,9 @@ def cpu_leg(orc, win, budget_s, what):
     except Exception as e:
         out['one_thread'] = dict(error=str(e))
     try:
-        orc.msckf_update_fast(win)
-        best = min(orc.msckf_update_fast(win)['seconds'] for _ in range(3))
-        out['all_cores'] = dict(ms_per_update=best * 1e3, cores=orc.msckf_update_fast(win)['threads'], kind='port (minimum-work algorithm, OpenMP)')
+        best, sweep = fast_cpu_sweep(orc, win, reps=3)
+        out['all_cores'] = dict(ms_per_update=sweep[best], cores=best, kind='port (minimum-work algorithm, OpenMP; best team of the sweep)',
+                                ms_by_threads={str(t): round(v, 3) for t, v in sweep.items()})
     except Exception as e:
         out['all_cores'] = dict(error=str(e))
     return out
@@ -385,7 +405,13 @@ def main():
         kflops['k_front'] = kflops['k_feature'] + kflops['k_gram'] + kflops['k_potrf(P)']
         # k_potrf(P) runs on a side stream, overlapped with k_feature/k_gram: not on the critical path
         crit = {k: v for k, v in prof.items() if k != 'k_potrf(P)'}
-        dom = max(crit, key=crit.get)
+        longest = max(crit, key=crit.get)
+        # The roofline is quoted for the factorisation + solve launch whenever the update runs in its fused form: the step is two
+        # dependent 202-pivot Cholesky chains (chol P inside k_front, chol M here: ~80 % of it), and this launch is the one whose
+        # SURVEY count (n^3/3 + n^2 (n+1)) is the work it executes.  k_front is a few us LONGER (the max of chol P and the tracks),
+        # but the SURVEY count of what it covers is the dense H'PH'^T / QR-of-the-stack count that it does not execute: its
+        # dense-equivalent and executed figures are in `longest_kernel`.
+        dom = 'k_potrf_solve(M)' if 'k_potrf_solve(M)' in crit and 'k_front' in crit else longest
         achieved = kflops[dom] / (prof[dom] * 1e-3) / 1e12
         # HBM traffic and executed matrix-core work of every kernel: PMC counters (FETCH_SIZE + WRITE_SIZE,
         # SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; separate rocprofv3 passes) of the committed profile of
@@ -399,11 +425,15 @@ def main():
             import glob
             pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]))['kernels']
             if N == 30 and F == 400:
-                if key_of.get(dom) in pm:
-                    traffic = 1024.0 * (pm[key_of[dom]]['FETCH_SIZE_KB_median'] + pm[key_of[dom]]['WRITE_SIZE_KB_median'])
+                def pmc_of(k):   # (the template argument of the factorisation kernels follows the active block count: match the name)
+                    want = key_of.get(k, '').split('<')[0]
+                    hits = [v for name, v in pm.items() if want and name.split('<')[0] == want]
+                    return pm.get(key_of.get(k)) or (hits[0] if len(hits) == 1 else None)
+                if pmc_of(dom):
+                    traffic = 1024.0 * (pmc_of(dom)['FETCH_SIZE_KB_median'] + pmc_of(dom)['WRITE_SIZE_KB_median'])
                 critical_path = {}
                 for k, t_ms in prof.items():
-                    e = pm.get(key_of.get(k))
+                    e = pmc_of(k)
                     if not e:
                         continue
                     item = dict(ms=round(t_ms, 5))
@@ -432,14 +462,21 @@ def main():
         roofline = dict(bound='mfma', kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic, executed=executed,
                         per_kernel_frac={k: round(kflops[k] / (prof[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) for k in prof},
-                        note='achieved = algorithmic FP64 work of the reference algorithm attributed to the dominant kernel (SURVEY 8d '
-                             'dense minimum-work count W of what the launch covers) / kernel time, median of 20 launches measured with HIP '
-                             'events on the launch stream.  For k_front (tracks + compression + chol P) that count is the DENSE count of the '
-                             'reference algorithm -- H\'PH\'^T of every track, the QR of the 22 800-row stack -- which this launch does not '
-                             'execute (13 non-zeros per un-projected row, Gram form): frac can exceed 1 there and says how fast a dense '
-                             'implementation would have to run, not how busy the matrix cores are -- `executed` is that.  For the '
-                             'factorisation + solve kernel (k_potrf_solve(M), the dominant kernel of rounds 1-2, per_kernel_frac) the count '
-                             'n^3/3 + n^2 (n+1) IS the work: 0.3 % of peak, a latency-bound chain (critical_path).',
+                        longest_kernel=dict(
+                            kernel=longest, ms=round(prof[longest], 5),
+                            dense_equivalent_tflops=round(kflops[longest] / (prof[longest] * 1e-3) / 1e12, 3),
+                            executed_mfma_tflops=(critical_path or {}).get(longest, {}).get('executed_mfma_tflops'),
+                            what='the longest launch by time.  For k_front (tracks + compression + chol P in one launch; its critical path is '
+                                 'the 202-pivot chain of chol P) the SURVEY count of what it covers is the DENSE count of the reference '
+                                 "algorithm -- H'PH'^T of every track, the QR of the 22 800-row stack -- which it does not execute (13 "
+                                 'non-zeros per un-projected row, Gram form): dense_equivalent_tflops says how fast a dense implementation '
+                                 'would have to run to match (it can exceed the peak), executed_mfma_tflops what the matrix cores do'),
+                        note='achieved = algorithmic FP64 work of the reference algorithm attributed to the kernel (SURVEY 8d: n^3/3 + '
+                             'n^2 (n+1) for the factorisation of M and the two triangular solves, n = 202 -- the count of the full-size '
+                             'problem although the launch factors the 187 active columns only) / kernel time, median of 20 launches '
+                             'measured with HIP events on the launch stream.  0.3-0.4 % of the FP64 matrix peak: a latency-bound chain '
+                             '(critical_path.chain), as is chol P inside k_front; per_kernel_frac lists every launch of the step by the '
+                             'same rule.',
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},
                         algorithmic_equiv=dict(
                             what='dense-count flops of the reference algorithm divided by OUR kernel time: how fast a dense '
@@ -508,11 +545,14 @@ def main():
                                   'image, so this is NOT the Eigen denominator of the >= 50x target in BASELINE.json',
                            host_cores=os.cpu_count())
                 try:   # best-effort all-cores CPU variant (minimum-work algorithm, tracks parallelised)
-                    fast = orc.msckf_update_fast(win)
-                    tf = min(orc.msckf_update_fast(win)['seconds'] for _ in range(5))
-                    cpu['all_cores'] = dict(value=1.0 / tf, unit='updates/s', cores=fast['threads'], ms_per_update=tf * 1e3,
-                                            what='same results with the minimum-work algorithm (3 reflectors, active columns, Gram '
-                                                 'compression), tracks parallelised with OpenMP over the host cores')
+                    best, sweep = fast_cpu_sweep(orc, win, reps=5)
+                    cpu['all_cores'] = dict(value=1e3 / sweep[best], unit='updates/s', cores=best, ms_per_update=sweep[best],
+                                            ms_by_threads={str(t): round(v, 3) for t, v in sweep.items()},
+                                            what='same results with the minimum-work algorithm on the CPU -- the sparsity the device '
+                                                 'path exploits (E = X P X^T from 13 non-zeros per row, three reflectors, Gram form '
+                                                 'X^T X - T3^T T3, square-root solve), tracks parallelised with OpenMP; the best team '
+                                                 'size of the sweep.  This, not the literal port, is the CPU figure a tuned host '
+                                                 'implementation would be near')
                 except Exception as e:
                     cpu['all_cores'] = dict(error=str(e))
             if not args.no_configs and N == 30 and F == 400:
