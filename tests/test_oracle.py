@@ -161,3 +161,21 @@ def test_three_independent_restatements_agree(flags):
     for upd in (mirror.msckf_update(small), orc.msckf_update(small, want_blocks=False, want_K=False), orc.msckf_update_fast(small)):
         assert np.array_equal(upd['accept'], hp['accept'])
         assert rel(upd['dx'], hp['dx']) < 1e-10 and rel(upd['P_new'], hp['P_new']) < 1e-12
+
+
+def test_fast_port_with_live_extrinsics_and_team_sizes():
+    """oracle/msckf_fast.c (bench.py's all-cores CPU figure) on a window whose extrinsic rows of P are live, one thread and a
+    team: same gate decisions and update as the literal port."""
+    import ctypes
+    from oracle import oracle as orc
+    w = synth.make_window(N=9, F=40, seed=11, track_len=(3, 9), outlier_frac=0.15, estimate_extrin=True, flags=synth.Flags(use_larvio=1))
+    ref = orc.msckf_update(w, want_blocks=False, want_K=False)
+    try:
+        for team in (1, 3):
+            orc.lib().orc_fast_set_threads(ctypes.c_int(team))
+            got = orc.msckf_update_fast(w)
+            assert got['threads'] == team
+            assert np.array_equal(got['accept'], ref['accept']) and 0 < ref['accept'].sum() < w.F
+            assert rel(got['dx'], ref['dx']) < 1e-9 and rel(got['P_new'], ref['P_new']) < 1e-12
+    finally:
+        orc.lib().orc_fast_set_threads(ctypes.c_int(0))
