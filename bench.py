@@ -418,17 +418,22 @@ def main():
         # this round, per launch; null if that profile does not list the kernel
         traffic = None
         critical_path = None
-        key_of = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<16>', 'k_potrf_solve(M)': 'k_potrf_solve<16>',
+        key_of = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<16>', 'k_potrf_solve(M)': 'k_potrf_solve<>',
                   'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt', 'k_gram': 'k_gram_pair', 'k_assemble': 'k_assemble_A',
                   'k_front': 'k_front<3, 16>', 'k_gemm(U)': 'k_gemm_asmA', 'k_gemm(M)': 'k_gemm'}
         try:
             import glob
             pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]))['kernels']
             if N == 30 and F == 400:
-                def pmc_of(k):   # (the template argument of the factorisation kernels follows the active block count: match the name)
-                    want = key_of.get(k, '').split('<')[0]
-                    hits = [v for name, v in pm.items() if want and name.split('<')[0] == want]
-                    return pm.get(key_of.get(k)) or (hits[0] if len(hits) == 1 else None)
+                def pmc_of(k):   # (the template argument of the factorisation kernels is the block-column capacity: the smallest
+                    #                  instantiation that holds this problem's active columns is the one the update launches)
+                    if key_of.get(k) in pm:
+                        return pm[key_of[k]]
+                    want, need = key_of.get(k, '').split('<')[0], (NA + 15) // 16
+                    hits = sorted((int(name.split('<')[1].rstrip('>')), name) for name in pm
+                                  if want and name.split('<')[0] == want and name.split('<')[1].rstrip('>').isdigit())
+                    hits = [name for cap, name in hits if cap >= need]
+                    return pm[hits[0]] if hits else None
                 if pmc_of(dom):
                     traffic = 1024.0 * (pmc_of(dom)['FETCH_SIZE_KB_median'] + pmc_of(dom)['WRITE_SIZE_KB_median'])
                 critical_path = {}
