@@ -260,10 +260,83 @@ class MsckfBackend {
     }
 
   private:
+    // Single GPU: the containers are flattened STRAIGHT INTO the handle's pinned arena (orcvio_msckf_io_begin) and the results are
+    // read where the device put them (orcvio_msckf_io_update: one graph launch, the thread waits on a flag word) -- the same walk
+    // over state_server / map_server as flattenWindow / flattenTracks, without the vectors in between.  With the covariance
+    // resident neither P nor P+ moves and the commit is part of the launch.
+    UpdateOutcome featureUpdateInPlace(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                                       const std::vector<StateIDType>& only_states) {
+        UpdateOutcome out;
+        std::map<StateIDType, int> index_of;
+        int N = 0;
+        for (const auto& kv : ss.imu_states_augment) index_of[kv.first] = N++;
+        const int n = flags.leg_dim + 6 * N, F = (int)ids.size();
+        if (!resident_covariance && ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        auto clone_of = [&](StateIDType id) -> int {   // window index of an observation that takes part, or -1
+            if (!only_states.empty() && std::find(only_states.begin(), only_states.end(), id) == only_states.end()) return -1;
+            auto it = index_of.find(id);
+            return it == index_of.end() ? -1 : it->second;   // (-1: observation of a clone that left the window)
+        };
+        int nobs = 0;   // the arena is laid out for exact sizes: count first
+        for (FeatureIDType fid : ids)
+            for (const auto& ob : map_server.at(fid).observations) nobs += clone_of(ob.first) >= 0;
+        orcvio_msckf_io io{};
+        out.status = orcvio_msckf_io_begin(h_, &flags, N, F, nobs, resident_covariance ? 0 : 1, &io);
+        if (out.status != ORCVIO_OK) return out;
+        const int nn = io.n;   // (n + the extra states of a hybrid filter, if the handle carries any)
+        if (!resident_covariance && nn != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        int i = 0;
+        for (const auto& kv : ss.imu_states_augment) {
+            const IMUState_Aug& a = kv.second;
+            double* q = io.poses + (size_t)ORCVIO_POSE_STRIDE * i++;
+            std::memcpy(q, a.orientation, sizeof(a.orientation));
+            std::memcpy(q + 9, a.position, sizeof(a.position));
+            std::memcpy(q + 12, a.position_FEJ, sizeof(a.position_FEJ));
+            std::memcpy(q + 15, a.R_imu_cam0, sizeof(a.R_imu_cam0));
+            std::memcpy(q + 24, a.t_cam0_imu, sizeof(a.t_cam0_imu));
+            q[27] = 0.0;
+        }
+        int o = 0;
+        io.obs_ptr[0] = 0;
+        for (int k = 0; k < F; ++k) {
+            const Feature& f = map_server.at(ids[k]);
+            std::memcpy(io.p_w + 3 * (size_t)k, f.position, 3 * sizeof(double));
+            for (const auto& ob : f.observations) {
+                const int c = clone_of(ob.first);
+                if (c < 0) continue;
+                io.obs_clone[o] = c;
+                io.obs_z[2 * (size_t)o] = ob.second.x; io.obs_z[2 * (size_t)o + 1] = ob.second.y;
+                if (io.obs_zvel) {
+                    auto v = f.observations_vel.find(ob.first);
+                    io.obs_zvel[2 * (size_t)o] = v == f.observations_vel.end() ? 0.0 : v->second.x;
+                    io.obs_zvel[2 * (size_t)o + 1] = v == f.observations_vel.end() ? 0.0 : v->second.y;
+                }
+                ++o;
+            }
+            io.obs_ptr[k + 1] = o;
+        }
+        if (!resident_covariance) std::memcpy(io.P, ss.state_cov.data(), sizeof(double) * (size_t)n * n);
+        int32_t stats[8] = {0};
+        // resident: P+ and its square-root factor become the resident prior inside the same launch (refused on the device if the
+        // update is); host covariance: P+ is read from the arena
+        out.status = orcvio_msckf_io_update(h_, resident_covariance ? 0 : 1, resident_covariance ? 1 : 0, stats);
+        if (out.status != ORCVIO_OK) return out;
+        out.accepted.assign(io.accept, io.accept + F);
+        out.gamma.assign(io.gamma, io.gamma + F);
+        out.delta_x.assign(io.dx, io.dx + nn);
+        out.updated = stats[3] != 0;
+        if (out.updated) {
+            if (!resident_covariance) ss.state_cov.assign(io.P_out, io.P_out + (size_t)n * n);   // P is updated even when delta_x is discarded (:4479-4494)
+            out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
+        }
+        return out;
+    }
+
     UpdateOutcome featureUpdate(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
                                 const std::vector<StateIDType>& only_states, bool sharded) {
         UpdateOutcome out;
         if (ids.empty() && !sharded) return out;   // (a rank without tracks still takes part in the collective)
+        if (!sharded) return featureUpdateInPlace(ss, map_server, ids, only_states);
         // this rank's share of the listed ids
         std::vector<FeatureIDType> mine;
         std::vector<int> pos;   // position of every kept id in `ids`

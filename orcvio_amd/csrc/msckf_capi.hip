@@ -126,6 +126,7 @@ struct orcvio_msckf_handle {
     // for the resident factor (kept by commit / remove_clones / clones_to_nuisance, dropped by augment).
     bool rev_prior_opt = true;          // ORCVIO_REV_PRIOR=0: the plain Cholesky (tail 0), same results
     int tail = 0, fac_tail = 0;
+    bool obj_status_cleared = false;    // k_object_rows_batch of the current object update has zeroed the shard status words (info[9..12])
     int last_run_kind = 0;              // 0: run_update (single GPU), 1: run_local / run_finish (staged or sharded), 2: objects
     bool front_retry_forked = false;    // (download: the fused front end lost a hand-off; re-running on the forked path)
     int front_spin_limit = 1 << 19;    // polls before a workgroup of k_front gives up at the device-wide counter (tens of ms)

@@ -249,14 +249,14 @@ __global__ __launch_bounds__(64) void k_object_rows(ObjEvalArgs p) { object_rows
 // ... or every object of an update in one launch: grid (most frames of any object, objects), the arguments of object
 // blockIdx.y from a device array (wave-uniform: scalar loads)
 // The blocks behind the objects (blockIdx.y >= nobj) zero the scratch the compression accumulates into (`zero`, nzero doubles)
-// and the two pivot counters -- no fill launches in front of k_obj_front.
+// the two pivot counters and the shard status words -- no fill launches in front of k_obj_front or of the solve.
 __global__ __launch_bounds__(64) void k_object_rows_batch(const ObjEvalArgs* __restrict__ args, int nobj, double* __restrict__ zero,
                                                           size_t nzero, int* __restrict__ counters) {
     if ((int)blockIdx.y >= nobj) {
         const size_t nblk = (size_t)gridDim.x * (gridDim.y - nobj), b = (size_t)(blockIdx.y - nobj) * gridDim.x + blockIdx.x;
         double2* z2 = reinterpret_cast<double2*>(zero);   // (the scratch is 16-byte aligned and nzero is even)
         for (size_t i = b * 64 + threadIdx.x; i < nzero / 2; i += nblk * 64) z2[i] = double2{0.0, 0.0};
-        if (b == 0 && threadIdx.x < 2) counters[threadIdx.x] = 0;
+        if (b == 0 && (threadIdx.x < 2 || (threadIdx.x >= 5 && threadIdx.x < 9))) counters[threadIdx.x] = 0;   // info[4,5]: pivots; info[9..12]: shard status words
         return;
     }
     const ObjEvalArgs p = args[blockIdx.y];

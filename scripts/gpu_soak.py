@@ -11,7 +11,7 @@ from helpers import rel, scatter_tracks
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-upd = capi.MsckfUpdater(device=0, max_clones=40, max_features=2048, max_observations=65536)
+upd = capi.MsckfUpdater(device=0, max_clones=40, max_features=2560, max_observations=81920)
 
 
 fails, n_done, worst = [], 0, dict(dx=0.0, P=0.0, gamma=0.0)
@@ -20,7 +20,8 @@ seed = seed0
 while time.time() < t_end:
     rng = np.random.default_rng(770000 + seed)
     N = int(rng.integers(2, 41))
-    F = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 720)], p=[0.4, 0.45, 0.15]))
+    # (1 800 tracks and more: the two-launch tracks front end)
+    F = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 720), rng.integers(1800, 2400)], p=[0.4, 0.43, 0.15, 0.02]))
     variant = int(rng.integers(0, 3))
     flags = synth.Flags(use_larvio=int(variant == 0), use_left_perturbation=int(variant == 1), if_fej=int(rng.integers(0, 2)),
                         estimate_td=int(rng.integers(0, 2)), leg_dim=int(rng.choice([22, 22, 46])),
@@ -29,8 +30,11 @@ while time.time() < t_end:
     lo = int(rng.integers(1, min(N, 6) + 1))
     hi = int(rng.integers(lo, min(N, 32) + 1))
     mode = int(rng.integers(0, 3))   # 0 host P, 1 resident, 2 resident + prefactored
+    inplace = bool(rng.integers(0, 2))   # orcvio_msckf_io_begin / _io_update (the caller writes into the arena) or the copying call
+    if F >= 1800:
+        hi = max(lo, min(hi, 12))   # (bounded oracle time: ~3 ms per track of 30 observations)
     par = dict(seed=seed, N=N, F=F, variant=variant, fej=flags.if_fej, td=flags.estimate_td, leg=flags.leg_dim, s=flags.noise_feature,
-               scattered=scattered, lo=lo, hi=hi, mode=mode)
+               scattered=scattered, lo=lo, hi=hi, mode=mode, inplace=inplace)
     try:
         if scattered:
             w = synth.make_window(N=N, F=F, seed=seed, track_len=None, flags=flags, outlier_frac=float(rng.choice([0.0, 0.3])), sigma_px=0.008)
@@ -38,12 +42,18 @@ while time.time() < t_end:
         else:
             w = synth.make_window(N=N, F=F, seed=seed, track_len=(lo, hi), flags=flags, outlier_frac=float(rng.choice([0.0, 0.3])), sigma_px=0.008)
         ref = oracle.msckf_update(w)
-        if mode == 0:
-            got = upd.update_features(w)
-        else:
+        if mode != 0:
             upd.cov_set(w.P)
             if mode == 2:
                 upd.cov_prefactor()
+        if inplace:
+            io = upd.io_begin(w.flags, w.N, w.F, int(w.obs_ptr[-1]), with_P=mode == 0)
+            upd.io_fill(io, w, with_P=mode == 0)
+            upd.io_update(want_P=True, commit=False)
+            got = dict(dx=io['dx'].copy(), gamma=io['gamma'].copy(), accept=io['accept'].copy(), P_new=io['P_out'].copy())
+        elif mode == 0:
+            got = upd.update_features(w)
+        else:
             got = upd.update_features(w, resident_cov=True)
         ok = np.array_equal(got['accept'], ref['accept'])
         fin = np.isfinite(ref['gamma'])

@@ -11,7 +11,7 @@ from test_gpu_hybrid import run, rel
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+upd = capi.MsckfUpdater(device=0, max_clones=48, max_features=2048, max_observations=65536)   # n up to 22 + 180 + 90: beyond n = 224 the LDS-panel factorisation
 fails, n_done, worst = [], 0, dict(dx=0.0, P=0.0, gamma=0.0)
 t_end = time.time() + budget
 seed = seed0
