@@ -211,10 +211,41 @@ def config_table(upd, capi, synth, orc, reps, cpu_budget_s):
         upd.cov_set(win.P)
         call_r, io = upd.make_io_call(win, resident_cov=True, want_P=False, commit=True)
         e['host_visible_resident_cov'] = percentiles(timed_calls(call_r, reps, after=lambda: upd.cov_set(win.P)))
-        if orc is not None:
-            e['cpu_baseline'] = cpu_leg(orc, win, cpu_budget_s, 'oracle/msckf_oracle.c (1 thread), oracle/msckf_fast.c (all cores)')
         out[name] = e
-    return out
+    # the other half of a config-4 rank's share: 25 of the 100 objects (12 keypoints x 30 frames each), object update from tracks
+    try:
+        import ctypes as C
+        import numpy as np
+        oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+        owin = synth.make_window(N=30, F=4, seed=0, flags=oflags, track_len=4)
+        objs = synth.make_objects(owin, n_objects=25, seed=4, sigma_kp=0.004)
+        ofl = capi.make_flags(oflags)
+        ef, arr, keep = upd._object_tracks(objs, owin.R_b2c[0], owin.t_c_b[0], True, False, 0, False)
+        Pc = np.ascontiguousarray(owin.P)
+        o, res = upd._result(owin.n, 1)
+
+        def host():
+            assert upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), capi._d(Pc), C.byref(res)) == 0
+        e = dict(what='25 objects x 12 keypoints x 30 frames (a quarter of config 4\'s 100), orcvio_msckf_update_object_tracks', objects=25,
+                 host_visible=percentiles(timed_calls(host, reps, warm=5)), accepted=int(o['accept'][0]), dof=int(res.stats[0]))
+        upd.cov_set(owin.P); upd.cov_prefactor(); upd.sync()
+        o2, res2 = upd._result(owin.n, 1)
+        res2.P_out = None
+
+        def resident():
+            assert upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(res2)) == 0
+        e['host_visible_resident_cov'] = percentiles(timed_calls(resident, reps, warm=5))
+        out['config4_one_rank_share']['objects'] = e
+    except Exception as ex:
+        out['config4_one_rank_share']['objects'] = dict(error=repr(ex))
+    return out, cases
+
+
+def config_cpu_legs(configs, cases, orc, cpu_budget_s):
+    """The CPU legs of the table, run LAST in bench.py: their OpenMP teams (up to one thread per hardware thread) would
+    otherwise still be winding down under the GPU latency measurements."""
+    for name, win, what in cases:
+        configs[name]['cpu_baseline'] = cpu_leg(orc, win, cpu_budget_s, 'oracle/msckf_oracle.c (1 thread), oracle/msckf_fast.c (all cores)')
 
 
 def stream_config1(upd, capi, synth, frames=240, seed=0):
@@ -538,6 +569,18 @@ def main():
                     objects = objects_section(upd, capi, synth, orc, np, win)
                 except Exception as e:   # never let the side measurement break the metric line
                     objects = dict(error=repr(e))
+            cases = None
+            if not args.no_configs and N == 30 and F == 400:
+                try:
+                    configs, cases = config_table(upd, capi, synth, orc, 100, 0.8)
+                except Exception as e:
+                    configs = dict(error=repr(e))
+                try:
+                    stream1 = stream_config1(upd, capi, synth)
+                except Exception as e:
+                    stream1 = dict(error=repr(e))
+                upd.upload(win)
+            # every GPU figure is taken: now the CPU legs (their OpenMP teams spin down for a while after each call)
             if orc is not None:
                 reps_c = 2
                 t = []
@@ -560,9 +603,10 @@ def main():
                                                  'implementation would be near')
                 except Exception as e:
                     cpu['all_cores'] = dict(error=str(e))
-            if not args.no_configs and N == 30 and F == 400:
+            if cases is not None:
                 try:
-                    configs = config_table(upd, capi, synth, orc, 100, 0.8)
+                    if orc is not None:
+                        config_cpu_legs(configs, cases, orc, 0.8)
                     if objects and 'frame_config3' in objects:
                         configs['config3_frame'] = dict(what='400-feature update, then the 20-object update on the P+ it left (SURVEY note N7), '
                                                              'covariance resident in between: see objects_update.frame_config3',
@@ -570,12 +614,7 @@ def main():
                                                             features=cpu and dict(ms_per_update=1e3 / cpu['value'], cores=1, kind='port'),
                                                             objects=objects.get('cpu_baseline')))
                 except Exception as e:
-                    configs = dict(error=repr(e))
-                try:
-                    stream1 = stream_config1(upd, capi, synth)
-                except Exception as e:
-                    stream1 = dict(error=repr(e))
-                upd.upload(win)
+                    configs['cpu_legs_error'] = repr(e)
         # Weak scaling: every rank keeps one 400-feature shard, a step is ONE joint update of 400 x world features
         # (rank-local tracks + compression, one RCCL all-gather, replicated solve).  `value` is the whole-job
         # aggregate in the metric's own unit -- 400-feature update shards processed per second by all ranks =
