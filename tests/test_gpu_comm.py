@@ -41,6 +41,27 @@ def test_sharded_feature_update_world_1(upd, shape):
     assert rel(st['dx'], one['dx']) < 1e-12 and rel(st['P_new'], one['P_new']) < 1e-12
 
 
+@pytest.mark.parametrize('F', [300, 700])
+def test_sharded_update_on_the_resident_covariance_with_the_prior_factored_ahead(upd, F):
+    """orcvio_msckf_cov_prefactor in front of the sharded call (the factor of the prior is there when the tracks arrive), the
+    commit, and a second sharded update on the factor the first one left: equal to the oracle run twice.  F = 700: the forked
+    front end around the all-gather."""
+    win = synth.make_window(N=30, F=F, seed=9, outlier_frac=0.1)
+    ref1 = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    upd.cov_set(win.P)
+    upd.cov_prefactor()
+    got1 = upd.update_features_sharded(win, resident_cov=True)
+    assert np.array_equal(got1['accept'], ref1['accept'])
+    assert rel(got1['dx'], ref1['dx']) < 1e-6 and rel(got1['P_new'], ref1['P_new']) < 1e-6
+    upd.cov_commit()
+    import dataclasses
+    win2 = dataclasses.replace(synth.make_window(N=30, F=F, seed=10), P=ref1['P_new'])
+    ref2 = oracle.msckf_update(win2, want_blocks=False, want_K=False)
+    got2 = upd.update_features_sharded(win2, resident_cov=True)
+    assert np.array_equal(got2['accept'], ref2['accept'])
+    assert rel(got2['dx'], ref2['dx']) < 1e-6 and rel(got2['P_new'], ref2['P_new']) < 1e-6
+
+
 def test_sharded_object_update_world_1(upd):
     oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
     win = synth.make_window(N=12, F=4, seed=0, flags=oflags, track_len=4)
