@@ -1524,7 +1524,6 @@ __device__ __forceinline__ void potrf_reg_body(double* __restrict__ lds, const d
             asm volatile("" : "+v"(z));
             if (PUB) lds_barrier_drain(); else lds_barrier();   // A
             const double* pDi = &sDi[0][0][0] + z + (kb & 1) * 272;
-            const double* g = &sDg[0][0][0] + z + kb * 256 + l;
 #pragma unroll
             for (int r = 0; r < 4; ++r) st_pub<PUB>(Dinv + (size_t)kb * 256 + l + 64 * r, pDi[(kk + 4 * r) * 17 + cc]);   // element l + 64 r = (row kk + 4r, column cc)
             // R11 = L11^T from the row copy the sweep left in sL[kb & 1] (written before this barrier)
@@ -2220,7 +2219,7 @@ __global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, 
     const int nblk = (nn + 15) >> 4;
     const int ncols = nc1 + (bx ? 1 : 0);
     const int col = (blockIdx.x * 4 + wave) * 16 + cc;
-    const bool wave_live = (blockIdx.x * 4 + wave) * 16 < ncols;
+    const bool wave_live = (int)(blockIdx.x * 4 + wave) * 16 < ncols;
     d4 acc[14];
 #pragma unroll
     for (int kb = 0; kb < 14; ++kb) {
