@@ -170,3 +170,33 @@ def test_two_rank_sharded_object_update_equals_single_update(built):
     assert d0 == d1 == H.shape[0]
     assert np.array_equal(A0, A1) and np.array_equal(dx0, dx1) and np.array_equal(P0, P1)
     assert rel(dx0, dx) < 1e-8 and rel(P0, Pn) < 1e-9
+
+
+def test_bench_ships_the_communicator_id_between_two_ranks(tmp_path):
+    """bench.py's rendezvous for N > 1 (no torch.distributed process group: the 128 bytes of ncclGetUniqueId go through a file
+    named after the launcher's pid and the rendezvous port): two rank processes of one launcher end up with the same id, the
+    file is rank 0's to remove.  No GPU is touched (ncclGetUniqueId needs none)."""
+    import subprocess
+    code = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "from orcvio_amd import capi\n"
+        "rank = int(os.environ['RANK'])\n"
+        "uid, path = bench.ship_unique_id(capi, rank, 2)\n"
+        "print('UID', rank, bytes(uid).hex(), path or '-')\n")
+    env = dict(os.environ, MASTER_PORT='29871', TMPDIR=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, '-c', code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in (1, 0)]   # (rank 1 first: it has to wait for the file)
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    got = {}
+    for out, _ in outs:
+        for ln in out.splitlines():
+            if ln.startswith('UID'):
+                _, rank, hexid, path = ln.split()
+                got[int(rank)] = (hexid, path)
+    assert set(got) == {0, 1}
+    assert got[0][0] == got[1][0] and len(got[0][0]) == 256
+    assert got[1][1] == '-' and os.path.exists(got[0][1])   # rank 0 owns the file (bench.py removes it after the first barrier)
+    assert os.path.dirname(got[0][1]) == str(tmp_path)
