@@ -705,6 +705,36 @@ def objects_section(upd, capi, synth, orc, np, win):
     objects['frame_config3'] = dict(percentiles(lat_frame), object_update_accepted=int(oo['accept'][0]),
                                     what='400-feature update (arena written in place) with its commit + 20-object update + commit, '
                                          'covariance and its factor resident in HBM: host tracks / poses in, dx out (twice)')
+    # ... and in ONE call (orcvio_msckf_io_update_frame): the same two updates, the object tracks' compression -- which depends on
+    # neither the prior nor the feature update -- running on its own stream beside the feature update's solve
+    frame_call = {}
+
+    def renew_frame(prefactor=False):
+        upd.cov_set(fwin.P)
+        if prefactor:
+            upd.cov_prefactor()
+            upd.sync()
+        io = upd.io_begin(fwin.flags, fwin.N, fwin.F, int(fwin.obs_ptr[-1]), with_P=False)
+        upd.io_fill(io, fwin, with_P=False)
+        frame_call['c'], frame_call['o'] = upd.make_frame_call(fwin, oflags, objs, owin.R_b2c[0], owin.t_c_b[0], True, False, 0, False, True)
+    renew_frame()
+    def run_frame():
+        frame_call['c']()
+        frame_call['last'] = frame_call['o']   # (the result buffers of the call that ran: renew_frame makes new ones)
+    lat_frame1 = timed_calls(run_frame, 100, warm=5, after=renew_frame)
+    objects['frame_config3_one_call'] = dict(
+        percentiles(lat_frame1), object_update_accepted=int(frame_call['last']()[1]['accept']),
+        what='orcvio_msckf_io_update_frame: the same frame in one call -- feature update + commit, object update + commit, the object '
+             'tracks\' compression (rows, structured QR, A\') on its own stream beside the feature update\'s solve; results identical to '
+             'the two calls (tests/test_gpu_frame.py)')
+
+    def renew_frame_pre():
+        renew_frame(True)
+    renew_frame_pre()
+    objects['frame_config3_one_call_prefactored'] = dict(
+        percentiles(timed_calls(run_frame, 100, warm=5, after=renew_frame_pre)),
+        what='as frame_config3_one_call, the Cholesky of the frame\'s prior started ahead of the call')
+    restore()
     # the same frame with the prior factored ahead (orcvio_msckf_cov_prefactor when the image arrives)
 
     def restore_frame_prior():

@@ -372,6 +372,7 @@ int32_t orcvio_msckf_io_begin(orcvio_msckf_handle* h, const orcvio_msckf_flags* 
                               int32_t n_observations, int32_t with_P, orcvio_msckf_io* io);
 int32_t orcvio_msckf_io_update(orcvio_msckf_handle* h, int32_t want_P, int32_t commit, int32_t* stats /* [8] or NULL */);
 
+
 /* Object update: replaces OrcVIO::removeLostObjects (src/orcvio.cpp:2154-2193) for one
  * object block (nullspace projection against Hf -> gate with dof = rows -> NaN check ->
  * measurementUpdate_msckf).  result->accept/gamma have length 1. */
@@ -497,6 +498,25 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
                                           const orcvio_object_eval_flags* eval_flags, int32_t n_clones,
                                           const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
                                           double* d_dst, int32_t* dof_out, void* stream);
+
+/* ---- One frame in one call: the feature update, then the object update on the covariance it leaves -------------------------
+ * System::imageCallback runs Estimator->processFeatures (its last update: OrcVIO::removeLostFeatures / pruneImuStateBuffer) and
+ * then processObjects -> OrcVIO::removeLostObjects on the same state (ros_wrapper/src/orcvio/src/System.cpp:548-554).  This call
+ * is orcvio_msckf_io_update(h, 0, commit = 1, ..) on what stands in the arena (orcvio_msckf_io_begin with with_P = 0: the prior
+ * is the resident covariance) followed by orcvio_msckf_update_object_tracks(.., P = NULL, ..) -- same kernels, same results --
+ * except that the object tracks' COMPRESSION (rows, structured QR, A': it depends on neither the prior nor the feature update)
+ * runs on a stream of its own beside the feature update's solve, where the device is otherwise idle; only the object solve
+ * waits for the feature update's commit.
+ *   features   dx [n], gamma [F], accept [F] (caller-owned, each may be NULL) and stats; P_out / K / G / thin outputs must be NULL
+ *   objects    as orcvio_msckf_update_object_tracks (dx, gamma[0], accept[0], stats; P_out / G are served by the two calls in
+ *              sequence); commit_objects != 0: orcvio_msckf_cov_commit after an accepted object update
+ * Status: a refused feature update (ORCVIO_ERR_NOT_SPD ..) returns its code and NOTHING of the frame is applied; a failure of the
+ * object half returns its code with the feature update applied and committed (features->stats[3] says so).  After the call the
+ * arena belongs to the object update: the next frame starts with orcvio_msckf_io_begin.  ORCVIO_FRAME_OVERLAP=0 (environment)
+ * runs the two halves one behind the other. */
+int32_t orcvio_msckf_io_update_frame(orcvio_msckf_handle* h, orcvio_msckf_result* features, const orcvio_msckf_flags* object_flags,
+                                     const orcvio_object_eval_flags* eval_flags, const orcvio_object_track* tracks, int32_t n_tracks,
+                                     int32_t commit_objects, orcvio_msckf_result* objects);
 
 /* ---- Object update straight from the wire format of the object mapper ------------------------------
  * One element per orcvio_ros_msgs/ObjectLM message (ros_wrapper/src/orcvio_ros_msgs/msg/ObjectLM.msg) as ObjectInitNode fills it

@@ -41,7 +41,7 @@ EXPORTS = [
     'orcvio_msckf_comm_unique_id', 'orcvio_msckf_comm_init', 'orcvio_msckf_comm_destroy', 'orcvio_msckf_comm_info',
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
     'orcvio_msckf_comm_barrier', 'orcvio_msckf_comm_allreduce_max', 'orcvio_msckf_io_begin', 'orcvio_msckf_io_update',
-    'orcvio_msckf_augment_state_ref_ldlt',
+    'orcvio_msckf_augment_state_ref_ldlt', 'orcvio_msckf_io_update_frame',
 ]
 
 
@@ -191,6 +191,8 @@ def _bind(lib):
                                                       C.POINTER(ObjectTrackC), C.c_int32, _dp, C.POINTER(MsckfResult)]
     lib.orcvio_msckf_objects_local_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.c_int32,
                                                       C.POINTER(ObjectTrackC), C.c_int32, _dp, C.c_void_p, _ip, C.c_void_p]
+    lib.orcvio_msckf_io_update_frame.argtypes = [C.c_void_p, C.POINTER(MsckfResult), C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags),
+                                                 C.POINTER(ObjectTrackC), C.c_int32, C.c_int32, C.POINTER(MsckfResult)]
     lib.orcvio_msckf_comm_unique_id.argtypes = [C.c_char_p]
     lib.orcvio_msckf_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
     lib.orcvio_msckf_comm_destroy.argtypes = [C.c_void_p]
@@ -781,6 +783,42 @@ class MsckfUpdater:
         out['gamma'] = float(out['gamma'][0])
         out['accept'] = int(out['accept'][0])
         return out
+
+    def update_frame(self, win, oflags, objs, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D=False, commit_objects=True):
+        """orcvio_msckf_io_update_frame: the feature update of `win` on the resident covariance (arena written in place, committed
+        inside the launch) and the object update of `objs` on the covariance it leaves, the objects' compression beside the
+        features' solve.  Returns (features, objects) result dicts."""
+        io = self.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+        self.io_fill(io, win, with_P=False)
+        call, outs = self.make_frame_call(win, oflags, objs, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D, commit_objects)
+        call()
+        return outs()
+
+    def make_frame_call(self, win, oflags, objs, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D=False, commit_objects=True):
+        """Arguments of orcvio_msckf_io_update_frame marshalled once (the arena must have been laid out and filled: io_begin /
+        io_fill with with_P=False): returns (call, outs) -- call() is the C call alone, outs() the two result dicts."""
+        ofl = make_flags(oflags)
+        ef, arr, keep = self._object_tracks(objs, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D)
+        out_f, res_f = self._result(win.n, win.F)
+        res_f.P_out = None
+        out_o, res_o = self._result(win.n, 1)
+        res_o.P_out = None
+        lib, h, nobj, co = self.lib, self.h, len(objs), int(bool(commit_objects))
+        hold = (ofl, ef, arr, keep, out_f, res_f, out_o, res_o)
+
+        def call():
+            rc = lib.orcvio_msckf_io_update_frame(h, C.byref(res_f), C.byref(ofl), C.byref(ef), arr, nobj, co, C.byref(res_o))
+            if rc != 0:
+                raise MsckfError(rc, 'orcvio_msckf_io_update_frame')
+
+        def outs():
+            f = self._finish(dict(out_f), res_f, win.F)
+            o = self._finish(dict(out_o), res_o, 1)
+            o['gamma'] = float(o['gamma'][0])
+            o['accept'] = int(o['accept'][0])
+            return f, o
+        call.hold = hold
+        return call, outs
 
     # -- staged, device-resident form -----------------------------------------------------
     def upload(self, win, without_positions=False, resident_cov=False):

@@ -126,6 +126,11 @@ struct orcvio_msckf_handle {
     // for the resident factor (kept by commit / remove_clones / clones_to_nuisance, dropped by augment).
     bool rev_prior_opt = true;          // ORCVIO_REV_PRIOR=0: the plain Cholesky (tail 0), same results
     int tail = 0, fac_tail = 0;
+    // orcvio_msckf_io_update_frame: the object tracks' compression runs on a stream of its own beside the feature update's solve
+    hipStream_t obj_stream = nullptr;
+    hipEvent_t ev_obj = nullptr;
+    bool frame_mode = false;            // (objects_prior: no stream synchronisation, nothing of the prior is staged)
+    size_t out_shift = 0;               // host mirror of the outputs arena: offset of the block the next download lands in / is read from
     bool obj_status_cleared = false;    // k_object_rows_batch of the current object update has zeroed the shard status words (info[9..12])
     int last_run_kind = 0;              // 0: run_update (single GPU), 1: run_local / run_finish (staged or sharded), 2: objects
     bool front_retry_forked = false;    // (download: the fused front end lost a hand-off; re-running on the forked path)
@@ -218,6 +223,7 @@ struct orcvio_msckf_handle {
     // host staging
     std::vector<double> h_poses, h_chi2;
     std::vector<int> h_row_ptr;
+    std::vector<int> frame_row_ptr;     // orcvio_msckf_io_update_frame: the feature half's row offsets while the object half uses h_row_ptr
     double chi2_prob_cached = -1.0;
 };
 
@@ -244,6 +250,7 @@ const char* orcvio_msckf_last_error(void) { return g_last_error.c_str(); }
 #include "capi_objects.inc"   // the object update: staging, compression pipeline, finish / download, ObjectLM messages, row evaluation
 #include "capi_comm.inc"   // the handle's RCCL communicator, bounded waits, the sharded updates
 #include "capi_cov.inc"   // per-kernel profile, the device-resident covariance and its square-root factor
+#include "capi_frame.inc"   // one frame in one call: feature update + object update, the objects' compression beside the features' solve
 #include "capi_state.inc"   // triangulation, incrementState_IMUCam (host arithmetic)
 #include "capi_debug.inc"   // diagnostics build only: test hooks and ablation timers
 

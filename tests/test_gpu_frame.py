@@ -1,0 +1,174 @@
+"""orcvio_msckf_io_update_frame: the feature update and the object update of one frame in one call (System::imageCallback,
+ros_wrapper/src/orcvio/src/System.cpp:548-554), the object tracks' compression running beside the feature update's solve.
+It must equal the two calls in sequence -- orcvio_msckf_io_update(commit) then orcvio_msckf_update_object_tracks on the
+resident covariance -- bit for bit (same kernels, same arguments), and the oracle run step by step within the tolerance."""
+import dataclasses
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from orcvio_amd import capi, synth
+from oracle import oracle
+from helpers import rel, objects_update_reference
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def upd(built):
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    yield u
+    u.close()
+
+
+def _two_calls(upd, win, objs, new_bbox=False):
+    """the reference form: io_update with its commit, then the object update on the resident covariance, then its commit"""
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win, with_P=False)
+    stats = upd.io_update(want_P=False, commit=True)
+    f = dict(dx=io['dx'].copy(), gamma=io['gamma'].copy(), accept=io['accept'].copy(), stats=stats)
+    o = upd.update_object_tracks(win.flags, win.N, objs, None, win.R_b2c[0], win.t_c_b[0], True, new_bbox, 0)
+    upd.cov_commit()
+    return f, o
+
+
+def _frame(upd, win, objs, new_bbox=False):
+    return upd.update_frame(win, win.flags, objs, win.R_b2c[0], win.t_c_b[0], True, new_bbox, 0)
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.mark.parametrize('N,F,nobj,new_bbox', [(10, 60, 3, False), (30, 400, 20, False), (30, 400, 20, True), (20, 120, 1, False)])
+def test_frame_equals_the_two_calls_and_the_oracle(upd, N, F, nobj, new_bbox):
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=N, F=F, seed=4, flags=flags, track_len=None if N == 30 else (3, N), outlier_frac=0.05)
+    objs = synth.make_objects(win, n_objects=nobj, seed=2, sigma_kp=0.004)
+    upd.cov_set(win.P)
+    f0, o0 = _two_calls(upd, win, objs, new_bbox)
+    P0 = upd.cov_get()
+    upd.cov_set(win.P)
+    f1, o1 = _frame(upd, win, objs, new_bbox)
+    P1 = upd.cov_get()
+    # the two forms: identical
+    assert _same(f1['dx'], f0['dx']) and _same(f1['gamma'], f0['gamma']) and _same(f1['accept'], f0['accept'])
+    assert _same(f1['stats'][:5], f0['stats'][:5])
+    assert o1['accept'] == o0['accept'] and _same(o1['gamma'], o0['gamma']) and _same(o1['dx'], o0['dx']) and _same(o1['stats'], o0['stats'])
+    assert _same(P1, P0)
+    # ... and the oracle, step by step
+    ref1 = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    ref2 = objects_update_reference(win, objs, ref1['P_new'], True, new_bbox, 0)
+    assert np.array_equal(f1['accept'], ref1['accept']) and rel(f1['dx'], ref1['dx']) < TOL
+    assert o1['accept'] == ref2['accept'] and abs(o1['gamma'] - ref2['gamma']) < 1e-6 * abs(ref2['gamma'])
+    assert rel(o1['dx'], ref2['dx']) < TOL and rel(P1, ref2['P_new']) < TOL
+
+
+def test_frames_in_a_row(upd):
+    """six frames on the covariance the previous one left (the launch-graph cache replays the feature half; the spare factor
+    buffer alternates): every frame equals the two calls"""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=12, F=90, seed=7, flags=flags, track_len=(3, 12), outlier_frac=0.05)
+    wins = [dataclasses.replace(synth.make_window(N=12, F=90, seed=70 + k, flags=flags, track_len=(3, 12)), P=win.P) for k in range(6)]
+    objs = [synth.make_objects(win, n_objects=2 + (k % 3), seed=30 + k, sigma_kp=0.004) for k in range(6)]
+    upd.cov_set(win.P)
+    seq = [_two_calls(upd, w, o) for w, o in zip(wins, objs)]
+    P_seq = upd.cov_get()
+    upd.cov_set(win.P)
+    for k, (w, o) in enumerate(zip(wins, objs)):
+        f, ob = _frame(upd, w, o)
+        assert _same(f['dx'], seq[k][0]['dx']) and _same(f['accept'], seq[k][0]['accept']), k
+        assert ob['accept'] == seq[k][1]['accept'] and _same(ob['dx'], seq[k][1]['dx']), k
+    assert _same(upd.cov_get(), P_seq)
+
+
+def test_frame_without_objects_and_with_a_rejected_object_update(upd):
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=10, F=40, seed=4, flags=flags, track_len=(3, 10))
+    ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    upd.cov_set(win.P)
+    f, o = _frame(upd, win, [])
+    assert rel(f['dx'], ref['dx']) < TOL and o['accept'] == 0 and not np.any(o['dx'])
+    assert rel(upd.cov_get(), ref['P_new']) < TOL   # the feature update stands, nothing else happened
+    bad = synth.make_objects(win, n_objects=2, seed=6, sigma_kp=0.2)   # 25 sigma keypoint noise: the gate fails
+    upd.cov_set(win.P)
+    f, o = _frame(upd, win, bad)
+    assert o['accept'] == 0 and rel(f['dx'], ref['dx']) < TOL
+    assert rel(upd.cov_get(), ref['P_new']) < TOL
+    # the factor the feature half committed is still the resident one: the next update on it equals the update on P+
+    win2 = dataclasses.replace(win, P=ref['P_new'])
+    again = upd.update_features(win2, resident_cov=True, want_P=True)
+    ref2 = oracle.msckf_update(win2, want_blocks=False, want_K=False)
+    assert rel(again['dx'], ref2['dx']) < TOL and rel(again['P_new'], ref2['P_new']) < TOL
+
+
+def test_refused_feature_half_applies_nothing(upd):
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=10, F=40, seed=4, flags=flags, track_len=(3, 10))
+    objs = synth.make_objects(win, n_objects=2, seed=2, sigma_kp=0.004)
+    bad = win.P.copy()
+    bad[20, 20] = np.nan   # a non-finite prior: the device refuses the feature update and its commit
+    upd.cov_set(bad)
+    with pytest.raises(capi.MsckfError) as e:
+        _frame(upd, win, objs)
+    assert e.value.code == 6   # ORCVIO_ERR_NOT_SPD
+    assert np.array_equal(upd.cov_get(), bad, equal_nan=True)   # neither half was applied
+    # the handle goes on: the same frame on a sound prior equals the two calls
+    upd.cov_set(win.P)
+    f0, o0 = _two_calls(upd, win, objs)
+    upd.cov_set(win.P)
+    f1, o1 = _frame(upd, win, objs)
+    assert _same(f1['dx'], f0['dx']) and _same(o1['dx'], o0['dx']) and o1['accept'] == o0['accept']
+
+
+def test_refused_object_half_keeps_the_feature_update(upd):
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=10, F=40, seed=4, flags=flags, track_len=(3, 10))
+    objs = synth.make_objects(win, n_objects=2, seed=2, sigma_kp=0.004)
+    objs[1].frames[0]['clone'] = 99   # a frame outside the window
+    ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    upd.cov_set(win.P)
+    with pytest.raises(capi.MsckfError) as e:
+        _frame(upd, win, objs)
+    assert e.value.code == 1   # ORCVIO_ERR_INVALID from the object half
+    assert rel(upd.cov_get(), ref['P_new']) < TOL   # the feature update was applied and committed
+
+
+def test_frame_needs_the_resident_covariance_in_the_arena(upd):
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=8, F=20, seed=4, flags=flags, track_len=(3, 8))
+    upd.cov_set(win.P)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=True)
+    upd.io_fill(io, win, with_P=True)
+    call, _ = upd.make_frame_call(win, win.flags, [], win.R_b2c[0], win.t_c_b[0], True, False, 0)
+    with pytest.raises(capi.MsckfError) as e:
+        call()
+    assert e.value.code == 1
+
+
+def test_the_sequential_switch_gives_the_same_frame(built):
+    """ORCVIO_FRAME_OVERLAP=0 (read once per process): the two halves one behind the other -- same numbers"""
+    code = (
+        "import sys, json\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import numpy as np\n"
+        "from orcvio_amd import capi, synth\n"
+        "u = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384)\n"
+        "fl = synth.Flags(use_larvio=0, use_left_perturbation=0)\n"
+        "w = synth.make_window(N=10, F=60, seed=4, flags=fl, track_len=(3, 10), outlier_frac=0.05)\n"
+        "ob = synth.make_objects(w, n_objects=3, seed=2, sigma_kp=0.004)\n"
+        "u.cov_set(w.P)\n"
+        "f, o = u.update_frame(w, w.flags, ob, w.R_b2c[0], w.t_c_b[0], True, False, 0)\n"
+        "print('OUT', json.dumps(dict(fdx=f['dx'].tolist(), odx=o['dx'].tolist(), acc=int(o['accept']), P=u.cov_get().tolist())))\n")
+    outs = []
+    for mode in ('1', '0'):
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, ORCVIO_FRAME_OVERLAP=mode), timeout=600)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+        import json
+        outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('OUT')][-1][4:]))
+    assert outs[0] == outs[1] and outs[0]['acc'] == 1
