@@ -264,31 +264,30 @@ class MsckfBackend {
     // read where the device put them (orcvio_msckf_io_update: one graph launch, the thread waits on a flag word) -- the same walk
     // over state_server / map_server as flattenWindow / flattenTracks, without the vectors in between.  With the covariance
     // resident neither P nor P+ moves and the commit is part of the launch.
-    UpdateOutcome featureUpdateInPlace(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
-                                       const std::vector<StateIDType>& only_states) {
-        UpdateOutcome out;
+    // the window and the listed tracks written into the arena of orcvio_msckf_io_begin (sizes counted first: the arena is laid
+    // out for exact sizes); with_P: state_cov copied behind them
+    int fillArena(const StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                  const std::vector<StateIDType>& only_states, bool with_P, orcvio_msckf_io* io, int* n_out) {
         std::map<StateIDType, int> index_of;
         int N = 0;
         for (const auto& kv : ss.imu_states_augment) index_of[kv.first] = N++;
         const int n = flags.leg_dim + 6 * N, F = (int)ids.size();
-        if (!resident_covariance && ss.dim() != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        if (with_P && ss.dim() != n) return ORCVIO_ERR_INVALID;
         auto clone_of = [&](StateIDType id) -> int {   // window index of an observation that takes part, or -1
             if (!only_states.empty() && std::find(only_states.begin(), only_states.end(), id) == only_states.end()) return -1;
             auto it = index_of.find(id);
             return it == index_of.end() ? -1 : it->second;   // (-1: observation of a clone that left the window)
         };
-        int nobs = 0;   // the arena is laid out for exact sizes: count first
+        int nobs = 0;
         for (FeatureIDType fid : ids)
             for (const auto& ob : map_server.at(fid).observations) nobs += clone_of(ob.first) >= 0;
-        orcvio_msckf_io io{};
-        out.status = orcvio_msckf_io_begin(h_, &flags, N, F, nobs, resident_covariance ? 0 : 1, &io);
-        if (out.status != ORCVIO_OK) return out;
-        const int nn = io.n;   // (n + the extra states of a hybrid filter, if the handle carries any)
-        if (!resident_covariance && nn != n) { out.status = ORCVIO_ERR_INVALID; return out; }
+        int rc = orcvio_msckf_io_begin(h_, &flags, N, F, nobs, with_P ? 1 : 0, io);
+        if (rc != ORCVIO_OK) return rc;
+        if (with_P && io->n != n) return ORCVIO_ERR_INVALID;   // (io->n: n + the extra states of a hybrid filter, if the handle carries any)
         int i = 0;
         for (const auto& kv : ss.imu_states_augment) {
             const IMUState_Aug& a = kv.second;
-            double* q = io.poses + (size_t)ORCVIO_POSE_STRIDE * i++;
+            double* q = io->poses + (size_t)ORCVIO_POSE_STRIDE * i++;
             std::memcpy(q, a.orientation, sizeof(a.orientation));
             std::memcpy(q + 9, a.position, sizeof(a.position));
             std::memcpy(q + 12, a.position_FEJ, sizeof(a.position_FEJ));
@@ -297,25 +296,37 @@ class MsckfBackend {
             q[27] = 0.0;
         }
         int o = 0;
-        io.obs_ptr[0] = 0;
+        io->obs_ptr[0] = 0;
         for (int k = 0; k < F; ++k) {
             const Feature& f = map_server.at(ids[k]);
-            std::memcpy(io.p_w + 3 * (size_t)k, f.position, 3 * sizeof(double));
+            std::memcpy(io->p_w + 3 * (size_t)k, f.position, 3 * sizeof(double));
             for (const auto& ob : f.observations) {
                 const int c = clone_of(ob.first);
                 if (c < 0) continue;
-                io.obs_clone[o] = c;
-                io.obs_z[2 * (size_t)o] = ob.second.x; io.obs_z[2 * (size_t)o + 1] = ob.second.y;
-                if (io.obs_zvel) {
+                io->obs_clone[o] = c;
+                io->obs_z[2 * (size_t)o] = ob.second.x; io->obs_z[2 * (size_t)o + 1] = ob.second.y;
+                if (io->obs_zvel) {
                     auto v = f.observations_vel.find(ob.first);
-                    io.obs_zvel[2 * (size_t)o] = v == f.observations_vel.end() ? 0.0 : v->second.x;
-                    io.obs_zvel[2 * (size_t)o + 1] = v == f.observations_vel.end() ? 0.0 : v->second.y;
+                    io->obs_zvel[2 * (size_t)o] = v == f.observations_vel.end() ? 0.0 : v->second.x;
+                    io->obs_zvel[2 * (size_t)o + 1] = v == f.observations_vel.end() ? 0.0 : v->second.y;
                 }
                 ++o;
             }
-            io.obs_ptr[k + 1] = o;
+            io->obs_ptr[k + 1] = o;
         }
-        if (!resident_covariance) std::memcpy(io.P, ss.state_cov.data(), sizeof(double) * (size_t)n * n);
+        if (with_P) std::memcpy(io->P, ss.state_cov.data(), sizeof(double) * (size_t)n * n);
+        *n_out = io->n;
+        return ORCVIO_OK;
+    }
+
+    UpdateOutcome featureUpdateInPlace(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                                       const std::vector<StateIDType>& only_states) {
+        UpdateOutcome out;
+        const int F = (int)ids.size();
+        orcvio_msckf_io io{};
+        int nn = 0;
+        out.status = fillArena(ss, map_server, ids, only_states, !resident_covariance, &io, &nn);
+        if (out.status != ORCVIO_OK) return out;
         int32_t stats[8] = {0};
         // resident: P+ and its square-root factor become the resident prior inside the same launch (refused on the device if the
         // update is); host covariance: P+ is read from the arena
@@ -326,7 +337,7 @@ class MsckfBackend {
         out.delta_x.assign(io.dx, io.dx + nn);
         out.updated = stats[3] != 0;
         if (out.updated) {
-            if (!resident_covariance) ss.state_cov.assign(io.P_out, io.P_out + (size_t)n * n);   // P is updated even when delta_x is discarded (:4479-4494)
+            if (!resident_covariance) ss.state_cov.assign(io.P_out, io.P_out + (size_t)nn * nn);   // P is updated even when delta_x is discarded (:4479-4494)
             out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
         }
         return out;
@@ -794,6 +805,52 @@ class MsckfBackend {
             out.state_incremented = incrementState_IMUCam(ss, out.delta_x);
         }
         return out;
+    }
+
+    // ---- one frame: System::imageCallback's processFeatures update followed by processObjects (System.cpp:548-554) ----------
+    // With the covariance resident and one GPU this is ONE library call (orcvio_msckf_io_update_frame): the object tracks'
+    // compression runs beside the feature update's solve.  `eval_flags` carries the extrinsics the object rows are evaluated
+    // with: the frame call takes them as they are BEFORE the feature update, which is what the sequence would use unless the
+    // filter estimates the extrinsics (no shipped configuration does) -- then, or without the resident covariance, or over several
+    // ranks, the two call sites run one behind the other.
+    struct FrameOutcome { UpdateOutcome features, objects; };
+    bool estimates_extrinsics = false;
+    FrameOutcome frameUpdate(StateServer& ss, const MapServer& map_server, const std::vector<FeatureIDType>& ids,
+                             const std::vector<StateIDType>& only_states, const orcvio_object_eval_flags& eval_flags,
+                             const std::vector<orcvio_object_track>& tracks) {
+        FrameOutcome fo;
+        if (!resident_covariance || world_ > 1 || ids.empty() || estimates_extrinsics) {
+            fo.features = msckfUpdate(ss, map_server, ids, only_states);
+            if (fo.features.status == ORCVIO_OK) fo.objects = removeLostObjectTracks(ss, eval_flags, tracks);
+            return fo;
+        }
+        const int F = (int)ids.size();
+        orcvio_msckf_io io{};
+        int nn = 0;
+        fo.features.status = fillArena(ss, map_server, ids, only_states, false, &io, &nn);
+        if (fo.features.status != ORCVIO_OK) return fo;
+        fo.features.accepted.assign(F, 0);
+        fo.features.gamma.assign(F, 0.0);
+        fo.features.delta_x.assign(nn, 0.0);
+        fo.objects.accepted.assign(1, 0);
+        fo.objects.gamma.assign(1, 0.0);
+        fo.objects.delta_x.assign(nn, 0.0);
+        std::vector<int32_t> acc(F + 1, 0);
+        orcvio_msckf_result rf{}, ro{};
+        rf.dx = fo.features.delta_x.data(); rf.accept = acc.data(); rf.gamma = fo.features.gamma.data();
+        std::vector<int32_t> oacc(1, 0);
+        ro.dx = fo.objects.delta_x.data(); ro.accept = oacc.data(); ro.gamma = fo.objects.gamma.data();
+        const int rc = orcvio_msckf_io_update_frame(h_, &rf, &flags, &eval_flags, tracks.data(), (int32_t)tracks.size(), 1, &ro);
+        fo.features.updated = rf.stats[3] != 0;
+        for (int k = 0; k < F; ++k) fo.features.accepted[k] = acc[k];
+        if (rc != ORCVIO_OK && !fo.features.updated) { fo.features.status = rc; return fo; }   // nothing of the frame was applied
+        if (fo.features.updated) fo.features.state_incremented = incrementState_IMUCam(ss, fo.features.delta_x);
+        fo.objects.status = rc;
+        if (rc != ORCVIO_OK) return fo;
+        fo.objects.accepted[0] = oacc[0];
+        fo.objects.updated = ro.stats[3] != 0;
+        if (fo.objects.updated) fo.objects.state_incremented = incrementState_IMUCam(ss, fo.objects.delta_x);
+        return fo;
     }
 
     orcvio_msckf_handle* handle() { return h_; }

@@ -224,6 +224,83 @@ int main() {
         for (long v : load) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
         if (hi - lo > 13) { std::printf("dealFeatures: unbalanced %ld..%ld\n", lo, hi); ++fails; }
     }
+    {   // one frame: the feature update, then processObjects' update (System.cpp:548-554), covariance resident -- the two call
+        // sites one behind the other against MsckfBackend::frameUpdate (ONE library call, the objects' compression beside the
+        // features' solve): same corrections, same covariance
+        const int K = 4, FR = 6;
+        const double centre[3] = {9.0, 0.4, 0.1}, shape[3] = {0.9, 0.6, 0.5};
+        double wTo[16] = {1, 0, 0, centre[0], 0, 1, 0, centre[1], 0, 0, 1, centre[2], 0, 0, 0, 1};
+        const double kps[K * 3] = {0.6, 0.3, 0.2, -0.5, 0.35, 0.1, 0.4, -0.3, -0.25, -0.45, -0.2, 0.3};
+        std::vector<double> wTc((size_t)FR * 16), zs((size_t)FR * K * 2), bb((size_t)FR * 4);
+        std::vector<int32_t> fclone(FR);
+        int i = 0, fidx = 0;
+        for (auto& kv : ss.imu_states_augment) {
+            if (i >= 1 && fidx < FR) {
+                const IMUState_Aug& a = kv.second;
+                double tcw[3], Rwc[9];
+                for (int k = 0; k < 3; ++k) tcw[k] = a.position[k] + a.orientation[k * 3] * a.t_cam0_imu[0] + a.orientation[k * 3 + 1] * a.t_cam0_imu[1] + a.orientation[k * 3 + 2] * a.t_cam0_imu[2];
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rwc[r * 3 + c] = a.R_imu_cam0[r * 3] * a.orientation[c * 3] + a.R_imu_cam0[r * 3 + 1] * a.orientation[c * 3 + 1] + a.R_imu_cam0[r * 3 + 2] * a.orientation[c * 3 + 2];
+                double* T = &wTc[(size_t)fidx * 16];   // camera -> world: [Rwc^T | tcw]
+                for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[r * 4 + c] = Rwc[c * 3 + r]; T[r * 4 + 3] = tcw[r]; }
+                T[12] = T[13] = T[14] = 0; T[15] = 1;
+                for (int k = 0; k < K; ++k) {
+                    double d[3], pc[3];
+                    for (int c = 0; c < 3; ++c) d[c] = centre[c] + kps[k * 3 + c] - tcw[c];
+                    for (int c = 0; c < 3; ++c) pc[c] = Rwc[c * 3] * d[0] + Rwc[c * 3 + 1] * d[1] + Rwc[c * 3 + 2] * d[2];
+                    zs[((size_t)fidx * K + k) * 2] = pc[0] / pc[2] + 0.004 * G(rng);
+                    zs[((size_t)fidx * K + k) * 2 + 1] = pc[1] / pc[2] + 0.004 * G(rng);
+                }
+                // bounding box of the ellipsoid's outline: dual conic C = Pm Q Pm^T, Q = wTo diag(a^2, b^2, c^2, -1) wTo^T, Pm = [Rwc | -Rwc tcw]
+                double Pm[12], Q[16] = {0}, C[9] = {0};
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) Pm[r * 4 + c] = Rwc[r * 3 + c];
+                    Pm[r * 4 + 3] = -(Rwc[r * 3] * tcw[0] + Rwc[r * 3 + 1] * tcw[1] + Rwc[r * 3 + 2] * tcw[2]);
+                }
+                const double dg[4] = {shape[0] * shape[0], shape[1] * shape[1], shape[2] * shape[2], -1.0};
+                for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) for (int k = 0; k < 4; ++k) Q[r * 4 + c] += wTo[r * 4 + k] * dg[k] * wTo[c * 4 + k];
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) for (int k = 0; k < 4; ++k) for (int l = 0; l < 4; ++l) C[r * 3 + c] += Pm[r * 4 + k] * Q[k * 4 + l] * Pm[c * 4 + l];
+                const double sx = std::sqrt(C[2] * C[2] - C[0] * C[8]), sy = std::sqrt(C[5] * C[5] - C[4] * C[8]);
+                double x0 = (C[2] - sx) / C[8], x1 = (C[2] + sx) / C[8], y0 = (C[5] - sy) / C[8], y1 = (C[5] + sy) / C[8];
+                if (x0 > x1) std::swap(x0, x1);
+                if (y0 > y1) std::swap(y0, y1);
+                bb[(size_t)fidx * 4] = x0 + 0.002 * G(rng); bb[(size_t)fidx * 4 + 1] = y0 + 0.002 * G(rng);
+                bb[(size_t)fidx * 4 + 2] = x1 + 0.002 * G(rng); bb[(size_t)fidx * 4 + 3] = y1 + 0.002 * G(rng);
+                fclone[fidx] = i;
+                ++fidx;
+            }
+            ++i;
+        }
+        orcvio_object_track trk{};
+        trk.n_keypoints = K; trk.n_frames = FR; trk.wTo = wTo; trk.shape = shape; trk.kps = kps;
+        trk.frame_wTc = wTc.data(); trk.frame_zs = zs.data(); trk.frame_bbox = bb.data(); trk.frame_clone = fclone.data();
+        std::vector<orcvio_object_track> trks(1, trk);
+        orcvio_object_eval_flags ef{};
+        ef.use_left_perturbation = 1; ef.use_new_bbox_residual = 0; ef.vio_use_left_perturbation = 0; ef.fix_dcampose_dimupose_to_identity = 0;
+        std::memcpy(ef.R_b2c, ss.imu_state.R_imu_cam0, sizeof(ef.R_b2c));
+        std::memcpy(ef.t_c_b, ss.imu_state.t_cam0_imu, sizeof(ef.t_c_b));
+        MsckfBackend fr(0, 16, 256, 8192);
+        StateServer a = ss, b = ss;
+        int rc = fr.covarianceToDevice(a);
+        UpdateOutcome f1 = fr.msckfUpdate(a, map_server, ids);
+        UpdateOutcome o1 = fr.removeLostObjectTracks(a, ef, trks);
+        if (rc == ORCVIO_OK) rc = fr.covarianceToHost(a);
+        int rc2 = fr.covarianceToDevice(b);
+        MsckfBackend::FrameOutcome fo = fr.frameUpdate(b, map_server, ids, {}, ef, trks);
+        if (rc2 == ORCVIO_OK) rc2 = fr.covarianceToHost(b);
+        if (rc != ORCVIO_OK || rc2 != ORCVIO_OK || f1.status != ORCVIO_OK || o1.status != ORCVIO_OK || fo.features.status != ORCVIO_OK || fo.objects.status != ORCVIO_OK) {
+            std::printf("frame: status %d %d / %d %d / %d %d (%s)\n", rc, rc2, f1.status, o1.status, fo.features.status, fo.objects.status, orcvio_msckf_last_error());
+            ++fails;
+        } else {
+            const double e1 = relerr(fo.features.delta_x, f1.delta_x), e2 = o1.updated ? relerr(fo.objects.delta_x, o1.delta_x) : 0.0, eP = relerr(b.state_cov, a.state_cov);
+            double epos = 0;
+            for (auto& kv : a.imu_states_augment)
+                for (int k = 0; k < 3; ++k) epos = std::fmax(epos, std::fabs(kv.second.position[k] - b.imu_states_augment.at(kv.first).position[k]));
+            std::printf("frame in one call: object update accepted %d / %d (gamma %.3f), dx rel %.2e / %.2e, P rel %.2e, clone positions differ by %.2e\n",
+                        (int)o1.updated, (int)fo.objects.updated, o1.gamma[0], e1, e2, eP, epos);
+            if (!(e1 < 1e-12) || !(e2 < 1e-12) || !(eP < 1e-12) || !(epos < 1e-13) || o1.updated != fo.objects.updated || f1.accepted != fo.features.accepted) ++fails;
+            if (!o1.updated) { std::printf("frame: the object update of the test was rejected\n"); ++fails; }
+        }
+    }
     std::printf(fails ? "FAILED\n" : "host gpu ok\n");
     return fails;
 }
