@@ -609,8 +609,11 @@ def main():
                         config_cpu_legs(configs, cases, orc, 0.8)
                     if objects and 'frame_config3' in objects:
                         configs['config3_frame'] = dict(what='400-feature update, then the 20-object update on the P+ it left (SURVEY note N7), '
-                                                             'covariance resident in between: see objects_update.frame_config3',
-                                                        host_visible=objects['frame_config3'], cpu_baseline=dict(
+                                                             'covariance resident in between; host_visible: ONE call '
+                                                             '(orcvio_msckf_io_update_frame), two_calls: orcvio_msckf_io_update + '
+                                                             'orcvio_msckf_update_object_tracks + cov_commit; see objects_update',
+                                                        host_visible=objects.get('frame_config3_one_call', objects['frame_config3']),
+                                                        two_calls=objects['frame_config3'], cpu_baseline=dict(
                                                             features=cpu and dict(ms_per_update=1e3 / cpu['value'], cores=1, kind='port'),
                                                             objects=objects.get('cpu_baseline')))
                 except Exception as e:

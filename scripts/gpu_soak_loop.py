@@ -1,7 +1,8 @@
 """Randomised soak of the filter LOOP on the device-resident covariance (the part with state across calls: the resident P, its
 square-root factor kept / dropped / permuted, the captured graphs): random runs of frames, each
 propagate -> augment -> [prefactor] -> feature update -> commit -> [prune update on the two oldest clones -> commit] ->
-[object update -> commit] -> [marginalise random clones], P never sent after the first frame; every dx and the covariance at the
+[object update -> commit] -> [marginalise random clones] (one frame in four: feature update and object update in ONE call,
+orcvio_msckf_io_update_frame), P never sent after the first frame; every dx and the covariance at the
 end of every frame against the same loop on the host (C oracle for the feature updates, numpy mirrors for the rest).
 usage: python scripts/gpu_soak_loop.py [seconds] [first_seed]"""
 import sys, os, json, time, dataclasses
@@ -62,12 +63,22 @@ while time.time() < t_end:
             w = synth.make_window(N=N, F=F, seed=1000 * seed + fr, flags=flags, track_len=(min(3, N), N), outlier_frac=out_frac, sigma_px=0.008)
             w.P[:] = P
             ref = oracle.msckf_update(w, want_blocks=False, want_K=False)
-            got = upd.update_features(w, resident_cov=True, want_P=False)
-            upd.cov_commit()
-            good &= check('features', par, got['dx'], ref['dx'], np.array_equal(got['accept'], ref['accept']))
-            P = ref['P_new']
+            one_call = N >= 4 and rng.integers(0, 4) == 0   # features + objects of the frame in ONE call (orcvio_msckf_io_update_frame)
+            if one_call:
+                objs = synth.make_objects(w, n_objects=int(rng.integers(1, 4)), seed=seed + fr, sigma_kp=float(rng.choice([0.004, 0.1])))
+                ol, nb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+                ref3 = objects_update_reference(dataclasses.replace(w, P=ref['P_new']), objs, ref['P_new'], ol, nb, flags.use_left_perturbation, full_nullspace=True)
+                gf, go = upd.update_frame(w, flags, objs, w.R_b2c[0], w.t_c_b[0], ol, nb, flags.use_left_perturbation)
+                good &= check('frame: features', par, gf['dx'], ref['dx'], np.array_equal(gf['accept'], ref['accept']))
+                good &= check('frame: objects', par, go['dx'], ref3['dx'], go['accept'] == ref3['accept'])
+                P = ref3['P_new']
+            else:
+                got = upd.update_features(w, resident_cov=True, want_P=False)
+                upd.cov_commit()
+                good &= check('features', par, got['dx'], ref['dx'], np.array_equal(got['accept'], ref['accept']))
+                P = ref['P_new']
             # 2: the prune update on the two oldest clones
-            if N >= 3 and rng.integers(0, 2):
+            if not one_call and N >= 3 and rng.integers(0, 2):
                 sub = subset_window(w, [0, 1])
                 both = np.diff(sub.obs_ptr) == 2
                 if both.any():
@@ -81,7 +92,7 @@ while time.time() < t_end:
                     good &= check('prune', par, g2['dx'], ref2['dx'], np.array_equal(g2['accept'], ref2['accept']))
                     P = ref2['P_new']
             # 3: objects
-            if N >= 4 and rng.integers(0, 3) == 0:
+            if not one_call and N >= 4 and rng.integers(0, 3) == 0:
                 wo = dataclasses.replace(w, P=P)
                 objs = synth.make_objects(wo, n_objects=int(rng.integers(1, 4)), seed=seed + fr, sigma_kp=float(rng.choice([0.004, 0.1])))
                 ol, nb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
