@@ -172,3 +172,50 @@ def test_the_sequential_switch_gives_the_same_frame(built):
         import json
         outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('OUT')][-1][4:]))
     assert outs[0] == outs[1] and outs[0]['acc'] == 1
+
+
+def _fallbacks(u):
+    import ctypes as C
+    u.lib.orcvio_msckf_debug_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    v = C.c_int32(0)
+    assert u.lib.orcvio_msckf_debug_read(u.h, 10, C.byref(v), 4) == 0
+    return v.value
+
+
+def test_frame_survives_a_kernel_that_holds_half_the_device(built):
+    """The feature half's fused front end needs its workgroups resident at once; with 128 CUs held by somebody else it loses its
+    in-launch hand-off -- the frame is then run again as the two calls, inside the same call, and the object half that ran
+    meanwhile on the un-committed prior is discarded.  In normal frames the object kernels beside the feature update never
+    cause that (fall-back counter stays at 0)."""
+    import ctypes as C
+    import time
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536, debug_hooks=True)
+    try:
+        flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+        win = synth.make_window(N=30, F=400, seed=4, flags=flags, track_len=None, outlier_frac=0.05)
+        objs = synth.make_objects(win, n_objects=20, seed=2, sigma_kp=0.004)
+        u.cov_set(win.P)
+        f0, o0 = _two_calls(u, win, objs)
+        P0 = u.cov_get()
+        for _ in range(5):   # ordinary frames: the objects' kernels beside the feature update never strand its front end
+            u.cov_set(win.P)
+            f1, o1 = _frame(u, win, objs)
+            assert _same(f1['dx'], f0['dx']) and _same(o1['dx'], o0['dx'])
+        assert _fallbacks(u) == 0
+        u.cov_set(win.P)
+        u.lib.orcvio_msckf_debug_occupy.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+        assert u.lib.orcvio_msckf_debug_occupy(u.h, 128, 400.0) == 0   # 128 CUs held for 0.4 s on another stream
+        t0 = time.perf_counter()
+        f2, o2 = _frame(u, win, objs)
+        dt = time.perf_counter() - t0
+        assert _fallbacks(u) == 1 and dt < 2.5
+        assert np.array_equal(f2['accept'], f0['accept']) and rel(f2['dx'], f0['dx']) < 1e-9
+        assert o2['accept'] == o0['accept'] and rel(o2['dx'], o0['dx']) < 1e-9
+        assert rel(u.cov_get(), P0) < 1e-9
+        u.sync()
+        time.sleep(0.5)
+        u.cov_set(win.P)
+        f3, o3 = _frame(u, win, objs)   # the occupying kernel is gone: the overlapped form again
+        assert _same(f3['dx'], f0['dx']) and _same(o3['dx'], o0['dx']) and _fallbacks(u) == 1
+    finally:
+        u.close()
