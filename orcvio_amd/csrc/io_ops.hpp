@@ -24,9 +24,9 @@ __global__ __launch_bounds__(256) void k_ingest(const u32x4* __restrict__ src, u
 //                               workgroup for itself if the update was (info[2..3] pivot counters of chol(M): k_finish_sqrt
 //                               kept P; info[8] a hand-off inside a launch timed out: the results are garbage and the host
 //                               re-runs the update; a non-finite dx, which no pivot test sees)
-// Every storing wave waits for its stores, the workgroup meets, its lane 0 makes them visible at system scope and counts
-// itself in; the workgroup that arrives last bumps the device-side sequence number and stores it to the host flag (release,
-// system scope).  The host spins on that word.
+// Every wave that stores to host memory waits for its stores, the workgroup meets, its lane 0 makes them visible at system scope
+// and counts itself in; the one that arrives last bumps the device-side sequence number and stores it to the host flag
+// (release, system scope).  The host spins on that word.  The commit workgroups are not waited for: see below.
 struct EpilogueArgs {
     const u32x4* small_src; u32x4* small_dst; size_t small16;
     const u32x4* P_src; u32x4* P_dst; size_t P16; int nb_P;
@@ -69,16 +69,22 @@ __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
             }
         }
     }
+    // the flag rises when what the HOST reads is out (workgroups 0 .. nb_P); the commit workgroups write device memory only, which
+    // whatever comes next on the stream sees by stream order -- the caller has its results 3-4 us before they are done
+    const int npub = 1 + a.nb_P;
+    if (b >= npub) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-        int old = nb - 1;
-        if (nb > 1) {   // (this workgroup's stores are out before it counts itself in)
+        int old = npub - 1;
+        if (npub > 1) {   // (this workgroup's stores are out before it counts itself in)
             __threadfence_system();
             old = atomicAdd(a.counter, 1);
+        } else {
+            __threadfence_system();
         }
-        if (old == nb - 1) {
-            if (nb > 1) atomicExch(a.counter, 0);
+        if (old == npub - 1) {
+            if (npub > 1) atomicExch(a.counter, 0);
             const unsigned long long v = atomicAdd(a.seq, 1ull) + 1ull;
             __hip_atomic_store(a.flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (release: behind everything above)
         }
