@@ -223,6 +223,7 @@ struct orcvio_msckf_handle {
     // host staging
     std::vector<double> h_poses, h_chi2;
     std::vector<int> h_row_ptr;
+    std::vector<unsigned char> track_is_run;   // upload_finalize: the track's clones are a contiguous run
     std::vector<int> frame_row_ptr;     // orcvio_msckf_io_update_frame: the feature half's row offsets while the object half uses h_row_ptr
     double chi2_prob_cached = -1.0;
 };
