@@ -79,3 +79,15 @@ b = os.path.join(src, f'{tag}_bench.json')
 if os.path.exists(b) and os.path.getsize(b) > 10:
     shutil.copy(b, os.path.join(dst, f'{tag}_bench.json'))
     print('bench ->', f'profiles/{tag}_bench.json')
+    # the per-configuration table of the same line on its own (<tag>_configs.json): configs, the config-3 frame legs, the config-1 stream
+    try:
+        line = json.load(open(b))
+        if line.get('configs'):
+            obj = line.get('objects_update') or {}
+            frames = {k: obj[k] for k in ('frame_config3', 'frame_config3_prefactored', 'frame_config3_one_call', 'frame_config3_one_call_prefactored') if k in obj}
+            json.dump({'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'latency': line.get('latency'),
+                       'configs': line['configs'], 'config3_frame_legs': frames, 'stream_config1': line.get('stream_config1'),
+                       'cpu_baseline': line.get('cpu_baseline')}, open(os.path.join(dst, f'{tag}_configs.json'), 'w'), indent=1)
+            print('configs ->', f'profiles/{tag}_configs.json')
+    except Exception as e:
+        print('configs: skipped', e)
