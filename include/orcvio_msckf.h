@@ -371,6 +371,12 @@ typedef struct orcvio_msckf_io {
 int32_t orcvio_msckf_io_begin(orcvio_msckf_handle* h, const orcvio_msckf_flags* flags, int32_t n_clones, int32_t n_features,
                               int32_t n_observations, int32_t with_P, orcvio_msckf_io* io);
 int32_t orcvio_msckf_io_update(orcvio_msckf_handle* h, int32_t want_P, int32_t commit, int32_t* stats /* [8] or NULL */);
+/* The same in two halves, for a caller with work of its own to do meanwhile (the next image, the object mapper's reply):
+ *   io_submit   validates the arena and LAUNCHES the update (returns after ~20 us of host time; nothing is waited for)
+ *   io_collect  waits for the results (the flag word) and reports the outcome exactly as io_update does
+ * Between the two calls the handle must not be used for anything else, and the arena must not be written. */
+int32_t orcvio_msckf_io_submit(orcvio_msckf_handle* h, int32_t want_P, int32_t commit);
+int32_t orcvio_msckf_io_collect(orcvio_msckf_handle* h, int32_t* stats /* [8] or NULL */);
 
 
 /* Object update: replaces OrcVIO::removeLostObjects (src/orcvio.cpp:2154-2193) for one

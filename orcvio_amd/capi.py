@@ -41,7 +41,7 @@ EXPORTS = [
     'orcvio_msckf_comm_unique_id', 'orcvio_msckf_comm_init', 'orcvio_msckf_comm_destroy', 'orcvio_msckf_comm_info',
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
     'orcvio_msckf_comm_barrier', 'orcvio_msckf_comm_allreduce_max', 'orcvio_msckf_io_begin', 'orcvio_msckf_io_update',
-    'orcvio_msckf_augment_state_ref_ldlt', 'orcvio_msckf_io_update_frame',
+    'orcvio_msckf_augment_state_ref_ldlt', 'orcvio_msckf_io_update_frame', 'orcvio_msckf_io_submit', 'orcvio_msckf_io_collect',
 ]
 
 
@@ -202,6 +202,8 @@ def _bind(lib):
     lib.orcvio_msckf_comm_allreduce_max.argtypes = [C.c_void_p, _dp, C.c_int32]
     lib.orcvio_msckf_io_begin.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(MsckfIo)]
     lib.orcvio_msckf_io_update.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _ip]
+    lib.orcvio_msckf_io_submit.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.orcvio_msckf_io_collect.argtypes = [C.c_void_p, _ip]
     lib.orcvio_msckf_update_features_sharded.argtypes = lib.orcvio_msckf_update_features.argtypes
     lib.orcvio_msckf_update_object_tracks_sharded.argtypes = lib.orcvio_msckf_update_object_tracks.argtypes
     return lib
@@ -576,6 +578,15 @@ class MsckfUpdater:
         """orcvio_msckf_io_update on what stands in the arena; returns the stats (the results are in the io_begin views)."""
         stats = np.zeros(8, dtype=np.int32)
         self._chk(self.lib.orcvio_msckf_io_update(self.h, int(bool(want_P)), int(bool(commit)), _i(stats)), 'orcvio_msckf_io_update')
+        return stats
+
+    def io_submit(self, want_P=True, commit=False):
+        """orcvio_msckf_io_submit: the update on what stands in the arena is launched; io_collect() waits for it."""
+        self._chk(self.lib.orcvio_msckf_io_submit(self.h, int(bool(want_P)), int(bool(commit))), 'orcvio_msckf_io_submit')
+
+    def io_collect(self):
+        stats = np.zeros(8, dtype=np.int32)
+        self._chk(self.lib.orcvio_msckf_io_collect(self.h, _i(stats)), 'orcvio_msckf_io_collect')
         return stats
 
     def make_io_call(self, win, resident_cov=False, want_P=True, commit=False):

@@ -98,6 +98,7 @@ struct orcvio_msckf_handle {
     unsigned long long* d_seq = nullptr;      // device-side twin (the value k_epilogue stores to the flag)
     int* d_pubcnt = nullptr;                  // arrival counter of k_epilogue's workgroups
     unsigned long long pub_enqueued = 0;      // publications enqueued so far (k_epilogue launches, stream order): the flag value to wait for
+    bool io_submitted = false, io_sub_P = false, io_sub_commit = false;   // orcvio_msckf_io_submit: launched, not yet collected
     bool io_open = false, io_with_P = false;  // orcvio_msckf_io_begin has laid the arena out and the caller is filling it
     double io_spin_seconds = 2.0;             // bound of the host's wait on h_flag (then: stream synchronisation, then ERR_TIMEOUT)
     bool last_sharded = false;                // the last finished update went through the handle's all-gather (status words in info[9..12])

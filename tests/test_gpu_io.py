@@ -132,3 +132,28 @@ def test_graph_cache_keeps_several_shapes(upd):
         ga = upd.update_features(a)
         gb = upd.update_features(b)
         assert rel(ga['dx'], ra['dx']) < 1e-6 and rel(gb['dx'], rb['dx']) < 1e-6
+
+
+def test_submit_and_collect_equal_io_update(upd):
+    """orcvio_msckf_io_submit / _io_collect: the launch and the wait as two calls (the caller's thread is free in between);
+    same results as io_update, on a host prior with P+ back and on the resident covariance with the commit inside the launch."""
+    import time
+    win = synth.make_window(N=12, F=80, seed=21, track_len=(3, 12), outlier_frac=0.1)
+    ref = _ref(win)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=True)
+    upd.io_fill(io, win)
+    upd.io_submit(want_P=True, commit=False)
+    with pytest.raises(capi.MsckfError):
+        upd.io_submit(want_P=True, commit=False)   # one submission at a time
+    time.sleep(0.002)                              # (the caller's own work)
+    stats = upd.io_collect()
+    assert stats[3] == 1 and np.array_equal(io['accept'], ref['accept'])
+    assert rel(io['dx'], ref['dx']) < 1e-6 and rel(io['P_out'], ref['P_new']) < 1e-6
+    with pytest.raises(capi.MsckfError):
+        upd.io_collect()                           # nothing submitted
+    upd.cov_set(win.P)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win, with_P=False)
+    upd.io_submit(want_P=False, commit=True)
+    upd.io_collect()
+    assert rel(io['dx'], ref['dx']) < 1e-6 and rel(upd.cov_get(), ref['P_new']) < 1e-6
