@@ -219,3 +219,18 @@ def test_frame_survives_a_kernel_that_holds_half_the_device(built):
         assert _same(f3['dx'], f0['dx']) and _same(o3['dx'], o0['dx']) and _fallbacks(u) == 1
     finally:
         u.close()
+
+
+def test_frame_without_feature_tracks(upd):
+    """no lost feature in this frame, objects all the same: the feature half is an update with no rows (P+ = P, committed), the
+    object half runs on it"""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=10, F=20, seed=4, flags=flags, track_len=(3, 10))
+    none = dataclasses.replace(win, p_w=win.p_w[:0].copy(), obs_ptr=np.zeros(1, dtype=np.int32), obs_clone=win.obs_clone[:0].copy(),
+                               obs_z=win.obs_z[:0].copy(), obs_zvel=win.obs_zvel[:0].copy())
+    objs = synth.make_objects(win, n_objects=2, seed=2, sigma_kp=0.004)
+    ref = objects_update_reference(win, objs, win.P, True, False, 0)
+    upd.cov_set(win.P)
+    f, o = _frame(upd, none, objs)
+    assert not f['stats'][3] and not np.any(f['dx'])
+    assert o['accept'] == ref['accept'] == 1 and rel(o['dx'], ref['dx']) < TOL and rel(upd.cov_get(), ref['P_new']) < TOL
