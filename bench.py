@@ -236,6 +236,18 @@ def config_table(upd, capi, synth, orc, reps, cpu_budget_s):
             assert upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(res2)) == 0
         e['host_visible_resident_cov'] = percentiles(timed_calls(resident, reps, warm=5))
         out['config4_one_rank_share']['objects'] = e
+        # ... and the whole share as ONE frame call: the 500 tracks' update + commit, then the 25 objects' update + commit
+        fc = {}
+
+        def renew():
+            upd.cov_set(shard4.P)
+            io = upd.io_begin(shard4.flags, shard4.N, shard4.F, int(shard4.obs_ptr[-1]), with_P=False)
+            upd.io_fill(io, shard4, with_P=False)
+            fc['c'], fc['o'] = upd.make_frame_call(shard4, oflags, objs, owin.R_b2c[0], owin.t_c_b[0], True, False, 0, False, True)
+        renew()
+        out['config4_one_rank_share']['frame_one_call'] = dict(
+            percentiles(timed_calls(lambda: fc['c'](), reps, warm=5, after=renew)),
+            what='orcvio_msckf_io_update_frame: 500 tracks + 25 objects, both updates committed, host tracks in, dx out twice')
     except Exception as ex:
         out['config4_one_rank_share']['objects'] = dict(error=repr(ex))
     return out, cases
