@@ -137,6 +137,9 @@ def test_refused_object_half_keeps_the_feature_update(upd):
         _frame(upd, win, objs)
     assert e.value.code == 1   # ORCVIO_ERR_INVALID from the object half
     assert rel(upd.cov_get(), ref['P_new']) < TOL   # the feature update was applied and committed
+    with pytest.raises(capi.MsckfError):
+        upd.cov_commit()                             # ... and nothing else is left to commit
+    assert rel(upd.cov_get(), ref['P_new']) < TOL
 
 
 def test_frame_needs_the_resident_covariance_in_the_arena(upd):
