@@ -132,6 +132,13 @@ struct orcvio_msckf_handle {
     hipEvent_t ev_obj = nullptr;
     bool frame_mode = false;            // (objects_prior: no stream synchronisation, nothing of the prior is staged)
     size_t out_shift = 0;               // host mirror of the outputs arena: offset of the block the next download lands in / is read from
+    // small host -> device transfers (SLAM feature records, Phi / Q, nuisance poses) go through a ring of pinned bounce buffers:
+    // a host memcpy and an asynchronous copy each, no stream synchronisation (aux_copies)
+    char* h_aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t aux_cap[4] = {0, 0, 0, 0};
+    hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool aux_busy[4] = {false, false, false, false};
+    int aux_next = 0;
     bool obj_status_cleared = false;    // k_object_rows_batch of the current object update has zeroed the shard status words (info[9..12])
     int last_run_kind = 0;              // 0: run_update (single GPU), 1: run_local / run_finish (staged or sharded), 2: objects
     bool front_retry_forked = false;    // (download: the fused front end lost a hand-off; re-running on the forked path)
