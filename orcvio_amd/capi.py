@@ -335,6 +335,44 @@ class MsckfUpdater:
             raise MsckfError(rc, 'orcvio_msckf_upload_slam_features')
         self._ekf_F = F
 
+    def make_upload_call(self, win, resident_cov=False):
+        """orcvio_msckf_upload with its argument structs marshalled once: returns call() -- the C call alone (what a C++ caller
+        pays per frame; bench.py's stream)."""
+        fl, w, t, arrs = self._structs(win)
+        lib, h, P = self.lib, self.h, (None if resident_cov else _d(arrs['P']))
+        n, F = win.n, win.F
+
+        def call():
+            rc = lib.orcvio_msckf_upload(h, C.byref(fl), C.byref(w), C.byref(t), P)
+            if rc != 0:
+                raise MsckfError(rc, 'orcvio_msckf_upload')
+            self.n, self.F = n, F
+        call.hold = (fl, w, t, arrs)
+        return call
+
+    def make_slam_call(self, idp_dim, slam, slots=None):
+        """orcvio_msckf_upload_slam_features with the records marshalled once: returns call()."""
+        F = len(slam)
+        ia = [np.ascontiguousarray(a, dtype=np.int32) for a in ([f.anchor for f in slam], [f.state for f in slam],
+                                                                 list(range(F)) if slots is None else slots)]
+        param = np.ascontiguousarray([f.inv_param if idp_dim == 3 else f.obs_anchor for f in slam], dtype=np.float64).reshape(F, 3)
+        rho = np.ascontiguousarray([f.inv_depth for f in slam], dtype=np.float64)
+        pw = np.ascontiguousarray([f.p_w for f in slam], dtype=np.float64).reshape(F, 3)
+        pf = np.ascontiguousarray([f.p_fej if f.p_fej is not None else f.p_w for f in slam], dtype=np.float64).reshape(F, 3)
+        z = np.ascontiguousarray([f.z for f in slam], dtype=np.float64).reshape(F, 2)
+        zv = np.ascontiguousarray([f.z_vel for f in slam], dtype=np.float64).reshape(F, 2)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        st = SlamFeatures(F, int(idp_dim), ip(ia[0]), ip(ia[1]), ip(ia[2]), _d(param), _d(rho), _d(pw), _d(pf), _d(z), _d(zv))
+        lib, h = self.lib, self.h
+
+        def call():
+            rc = lib.orcvio_msckf_upload_slam_features(h, C.byref(st))
+            if rc != 0:
+                raise MsckfError(rc, 'orcvio_msckf_upload_slam_features')
+            self._ekf_F = F
+        call.hold = (ia, param, rho, pw, pf, z, zv, st)
+        return call
+
     def upload_new_features(self, win, idp_dim, feats):
         """Features entering the state (objects as for new_feature_rows): featureJacobian_ekf_new and the W split on the
         device; the V parts join the dense rows of this upload.  Call download_new_feature_blocks() after the update."""
