@@ -374,7 +374,9 @@ int32_t orcvio_msckf_io_update(orcvio_msckf_handle* h, int32_t want_P, int32_t c
 /* The same in two halves, for a caller with work of its own to do meanwhile (the next image, the object mapper's reply):
  *   io_submit   validates the arena and LAUNCHES the update (returns after ~20 us of host time; nothing is waited for)
  *   io_collect  waits for the results (the flag word) and reports the outcome exactly as io_update does
- * Between the two calls the handle must not be used for anything else, and the arena must not be written. */
+ * Between the two calls the handle must not be used for anything else, and the arena must not be written.
+ * Hybrid filter: the rows of the in-state features (orcvio_msckf_upload_slam_features / _upload_ekf_rows, with ORCVIO_OPT_EKF_ROWS and
+ * ORCVIO_OPT_EXTRA_STATES set) may be handed over between io_begin and io_update / io_submit; they ride in the same launch. */
 int32_t orcvio_msckf_io_submit(orcvio_msckf_handle* h, int32_t want_P, int32_t commit);
 int32_t orcvio_msckf_io_collect(orcvio_msckf_handle* h, int32_t* stats /* [8] or NULL */);
 

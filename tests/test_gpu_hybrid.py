@@ -532,3 +532,35 @@ def test_reference_literal_h2_ldlt_for_new_features_listed_as_tracks(upd):
     assert acc_new == lit['new_accept']
     assert rel(np.concatenate([got['dx'], dx_new]), lit['dx']) < TOL
     assert rel(P_aug, lit['P_new']) < TOL
+
+
+@pytest.mark.parametrize('idp', [1, 3])
+def test_hybrid_update_through_the_in_place_call(upd, idp):
+    """The rows of the in-state features between orcvio_msckf_io_begin and orcvio_msckf_io_update: the hybrid update with the
+    window written in place, the commit inside the launch and the results through the flag word -- equal to the staged form."""
+    fl = synth.Flags(use_larvio=1)
+    w0 = synth.make_window(N=20, F=120, seed=41, track_len=(3, 6), flags=fl, outlier_frac=0.05)
+    slam = synth.make_slam_features(w0, 12, seed=idp, outlier_frac=0.1)
+    w = synth.with_extra_states(w0, idp * len(slam), seed=7)
+    ref = mh.hybrid_update(w, slam, idp)
+    staged = run(upd, w, slam, idp, True)
+    upd.set_extra_states(w.n_extra)
+    upd.set_ekf_rows_mode(True)
+    try:
+        upd.cov_set(w.P)
+        upd.cov_prefactor()
+        for _ in range(3):   # (three times: direct launches, the capture, the replay)
+            upd.cov_set(w.P)
+            upd.cov_prefactor()
+            io = upd.io_begin(w.flags, w.N, w.F, int(w.obs_ptr[-1]), with_P=False)
+            upd.io_fill(io, w, with_P=False)
+            upd.upload_slam_features(idp, slam)
+            upd.io_update(want_P=False, commit=True)
+            assert np.array_equal(io['accept'], ref['accept'])
+            assert rel(io['dx'], ref['dx']) < TOL and rel(io['dx'], staged['dx']) < 1e-12
+            g, a = upd.download_ekf()
+            assert np.array_equal(a, ref['ekf_accept']) and rel(g, ref['ekf_gamma']) < 1e-9
+            assert rel(upd.cov_get(), ref['P_new']) < TOL
+    finally:
+        upd.set_ekf_rows_mode(False)
+        upd.set_extra_states(0)
