@@ -134,8 +134,8 @@ struct orcvio_msckf_handle {
     size_t out_shift = 0;               // host mirror of the outputs arena: offset of the block the next download lands in / is read from
     // small host -> device transfers (SLAM feature records, Phi / Q, nuisance poses) go through a ring of pinned bounce buffers:
     // a host memcpy and an asynchronous copy each, no stream synchronisation (aux_copies)
-    char* h_tri_out = nullptr;          // pinned block for the results of orcvio_msckf_triangulate
-    size_t tri_out_cap = 0;
+    char* h_fetch = nullptr;            // pinned block behind fetch_copies (small device arrays -> the caller's pageable memory)
+    size_t fetch_cap = 0;
     hipEvent_t ev_arena = nullptr;      // behind the last device read of the pinned input arena that was enqueued (upload_begin waits
     bool arena_busy = false;            //  for THAT, not for whatever else the stream carries: a prefactorisation, a commit ..)
     char* h_aux[4] = {nullptr, nullptr, nullptr, nullptr};
