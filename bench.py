@@ -295,14 +295,22 @@ def stream_config1(upd, capi, synth, frames=240, seed=0):
         # the per-frame C calls with their arguments marshalled once (a C++ caller has its containers at hand: the Python
         # wrappers' list comprehensions are not part of what is measured)
         cyc.append(dict(w=w, slam=slam, prune=prune, Phi=np.ascontiguousarray(Phi), Q=np.ascontiguousarray(1e-7 * G @ G.T),
-                        up=upd.make_upload_call(w, resident_cov=True), sl=upd.make_slam_call(idp, slam),
-                        up_prune=None if prune is None else upd.make_upload_call(prune, resident_cov=True)))
+                        sl=upd.make_slam_call(idp, slam)))
     n18 = leg + 6 * 18 + idp * n_slam
     P0 = synth.with_extra_states(synth.make_window(N=18, F=1, seed=5, flags=fl), idp * n_slam, seed=1).P
     assert P0.shape[0] == n18
     upd.set_extra_states(idp * n_slam)
     upd.set_ekf_rows_mode(True)
     times, n_upd = [], 0
+
+    def inplace(c, key, slam_call):
+        win = c[key]
+        io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)   # (same sizes -> same addresses: cheap)
+        upd.io_fill(io, win, with_P=False)
+        if slam_call is not None:
+            slam_call()
+        upd.io_update(want_P=False, commit=True)
+        return io['dx']
     try:
         upd.cov_set(P0)
         gc.collect()
@@ -313,17 +321,12 @@ def stream_config1(upd, capi, synth, frames=240, seed=0):
             upd.cov_propagate(c['Phi'], c['Q'])
             upd.cov_augment()
             upd.cov_prefactor()
-            c['up']()
-            c['sl']()
-            upd.run_update()
-            got = upd.download_dx()
-            upd.cov_commit()
+            # the hybrid update in place: the window written into the arena, the in-state features' records beside it, ONE launch
+            # with the commit inside, dx read where the device put it
+            got = inplace(c, 'w', c['sl'])
             n_upd += 1
             if c['prune'] is not None:
-                c['up_prune']()   # (no rows of the in-state features in this one)
-                upd.run_update()
-                got = upd.download_dx()
-                upd.cov_commit()
+                got = inplace(c, 'prune', None)   # (no rows of the in-state features in this one)
                 n_upd += 1
             if c['w'].N == 20:
                 upd.cov_remove_clones(leg, [0, 1])
@@ -340,7 +343,7 @@ def stream_config1(upd, capi, synth, frames=240, seed=0):
     p = percentiles(times)
     return dict(p, frames_per_s=1e3 / p['mean_ms'], updates_per_frame=n_upd / (frames + 16), in_state_features=n_slam,
                 what='euroc.yaml flags, hybrid filter (12 in-state features, 1 parameter each), 19/20-clone window, 20-200 ragged tracks '
-                     'per frame; per frame: propagate, augment, prefactor, hybrid update + commit, every second frame the prune update '
+                     'per frame; per frame: propagate, augment, prefactor, hybrid update + commit (in place: orcvio_msckf_io_begin / _io_update), every second frame the prune update '
                      '+ commit + marginalisation of two clones; covariance resident in HBM; the C calls\' arguments are marshalled once per '
                      'pre-generated frame, the ctypes call overhead (~12 calls per frame) is included')
 
