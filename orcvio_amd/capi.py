@@ -335,21 +335,6 @@ class MsckfUpdater:
             raise MsckfError(rc, 'orcvio_msckf_upload_slam_features')
         self._ekf_F = F
 
-    def make_upload_call(self, win, resident_cov=False):
-        """orcvio_msckf_upload with its argument structs marshalled once: returns call() -- the C call alone (what a C++ caller
-        pays per frame; bench.py's stream)."""
-        fl, w, t, arrs = self._structs(win)
-        lib, h, P = self.lib, self.h, (None if resident_cov else _d(arrs['P']))
-        n, F = win.n, win.F
-
-        def call():
-            rc = lib.orcvio_msckf_upload(h, C.byref(fl), C.byref(w), C.byref(t), P)
-            if rc != 0:
-                raise MsckfError(rc, 'orcvio_msckf_upload')
-            self.n, self.F = n, F
-        call.hold = (fl, w, t, arrs)
-        return call
-
     def make_slam_call(self, idp_dim, slam, slots=None):
         """orcvio_msckf_upload_slam_features with the records marshalled once: returns call()."""
         F = len(slam)
