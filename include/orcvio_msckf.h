@@ -680,6 +680,20 @@ int32_t orcvio_msckf_cov_commit_new_features(orcvio_msckf_handle* h, double* dx_
  * leave the window but stay in the resident covariance as nuisance states -- their blocks move to the end, in the listed order. */
 int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_dim, const int32_t* clone_indices, int32_t count);
 
+/* ---- Environment switches (read once per process; diagnostics and A/B measurements -- every one of them leaves the results unchanged) ----
+ *   ORCVIO_COMM_TIMEOUT_S   bound of every wait another rank can strand, seconds (default 180)
+ *   ORCVIO_RCCL_LIB         path of the RCCL library to dlopen first (then librccl.so.1 / librccl.so by the loader's search -- an already
+ *                           loaded one, e.g. torch's bundled copy, wins --, then /opt/rocm/lib)
+ *   ORCVIO_FRAME_OVERLAP    0: orcvio_msckf_io_update_frame runs its two halves one behind the other
+ *   ORCVIO_EARLY_INGEST     0: the whole arena is pulled by the ingest node of the launch graph (no early pull under the validation)
+ *   ORCVIO_REV_PRIOR        0: plain Cholesky of the prior (M keeps its 15 IMU columns)
+ *   ORCVIO_SPLIT_TRACKS     track count from which the tracks front end is two launches (default 1800; 0: never)
+ *   ORCVIO_FUSED_FRONT, ORCVIO_FUSED_SOLVE   0: the forked seven-launch front end / the two-launch solve (same as the options)
+ *   ORCVIO_FRONT_SPIN, ORCVIO_IO_SPIN_SECONDS   bounds of the in-launch hand-off of k_front (polls) and of the host's flag spin
+ *   ORCVIO_OBJ_INGEST, ORCVIO_OBJ_PUBLISH   object update: 0 = copy engine instead of the ingest kernel; 1 = results through the flag word
+ *   ORCVIO_TIMING           host wall times of the parts of the one-shot calls on stderr
+ *   ORCVIO_ASM_DBG, ORCVIO_POTRF_ABLATE, ORCVIO_POTRF_COLD   kernel diagnostics (scripts/gpu_*.py) */
+
 #ifdef __cplusplus
 }
 #endif
