@@ -140,8 +140,10 @@ const char* orcvio_msckf_last_error(void);
  * (src/orcvio.cpp:486-494, 1962-1968).  Host-side, no device needed. */
 double orcvio_msckf_chi2_quantile(int32_t dof, double prob);
 
-/* Create / destroy a handle that owns device buffers, streams and a captured launch
- * graph.  device = HIP device ordinal.  Capacity bounds what later calls may pass. */
+/* Create / destroy a handle that owns device buffers, streams and the cache of captured launch
+ * graphs.  device = HIP device ordinal.  Capacity bounds what later calls may pass.
+ * A handle is NOT thread-safe: one thread at a time per handle (the filter thread of the reference is the only caller of these
+ * call sites); different handles may be used from different threads.  orcvio_msckf_last_error() is thread-local. */
 int32_t orcvio_msckf_create(int32_t device, int32_t max_clones, int32_t max_features,
                             int32_t max_observations, orcvio_msckf_handle** out);
 void orcvio_msckf_destroy(orcvio_msckf_handle* h);
