@@ -362,6 +362,9 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args))
+    # the CPU legs sweep OpenMP team sizes: idle pool threads must sleep, not spin (read by the OpenMP runtime when it is loaded,
+    # i.e. with torch: set before that import)
+    os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
 
     import numpy as np
     import torch
@@ -796,6 +799,22 @@ def objects_section(upd, capi, synth, orc, np, win):
         objects['cpu_baseline'] = dict(ms_per_update=(t_rows + cu['seconds']) * 1e3, cores=1, kind='port', accepted=cu['accept'],
                                        what='rows (C restatement of the CameraLM / ObjectLM functors) + per-object '
                                             'Householder projection on dense rows x n blocks + QR of the stack + update')
+        try:   # the minimum-work port of the update (oracle/object_fast.c: Schur-complement projection from the 7 non-zeros per row,
+               # objects in parallel, square-root solve); the rows' evaluation (single-threaded C) is timed beside it
+            host = os.cpu_count() or 1
+            sweep = {}
+            for t in sorted({t for t in (1, 4, 8, 16, 20, 32) if t <= host}):
+                orc.objects_update_fast(oflags, owin.N, blocks_c, owin.P, threads=t)
+                sweep[t] = min(orc.objects_update_fast(oflags, owin.N, blocks_c, owin.P, threads=t)['seconds'] for _ in range(3)) * 1e3
+            best = min(sweep, key=sweep.get)
+            objects['cpu_baseline']['all_cores'] = dict(
+                ms_per_update=sweep[best], rows_ms=t_rows * 1e3, cores=best, ms_by_threads={str(t): round(v, 3) for t, v in sweep.items()},
+                kind='port (minimum-work algorithm, OpenMP; best team of the sweep)',
+                what='the update alone from the evaluated rows: H\'^T H\' = X^T X - Y^T Y with Y = R^-T (H_f^T X) per object (QR of H_f, 7 '
+                     'non-zeros per row), one object per thread, square-root solve, joint gate; same decision and update as the '
+                     'literal port (tests/test_oracle_objects.py)')
+        except Exception as e:
+            objects['cpu_baseline']['all_cores'] = dict(error=repr(e))
     upd.upload(win)   # the feature tracks again for what follows
     return objects
 

@@ -57,6 +57,85 @@ static int chol_psd(double* S, int n, int ld, double tol) {
     return dropped;
 }
 
+/* The Kalman solve in square-root form on a compressed block A ((NA+1)^2, symmetric, index NA = the residual column):
+ * P = L L^T, M = s2 I + L_a^T A L_a, delta_x = L M^-1 L_a^T b, P+ = s2 L M^-1 L^T; *zg2 = |L_M^-1 L_a^T b|^2 (what the joint gate of
+ * the object update needs: gamma = (|r'|^2 - zg2) / s2).  Dense loops parallelised over rows / right-hand sides (nt2 threads).
+ * Shared by orc_fast_msckf_update and orc_fast_objects_update (oracle/object_fast.c). */
+int orc_fast_sqrt_solve(int n, int NA, const double* A, const double* P, double s2, double* dx, double* P_out, double* zg2, int nt2) {
+    const int W = NA + 1;
+    /* ---- square-root Kalman solve ------------------------------------------------------------------------------- */
+    double* L = (double*)malloc((size_t)n * n * sizeof(double));
+    memcpy(L, P, (size_t)n * n * sizeof(double));
+    double mx = 0.0;
+    for (int i = 0; i < n; ++i) if (P[(size_t)i * n + i] > mx) mx = P[(size_t)i * n + i];
+    if (chol_psd(L, n, n, 8.0 * 2.220446049250313e-16 * mx) < 0) { free(L); return -1; }
+    for (int i = 0; i < n; ++i)
+        for (int k = i + 1; k < n; ++k) L[(size_t)i * n + k] = 0.0;
+    /* U = A[0:NA,0:NA] L_a  (NA x n),  L_a = L[15:, :] ;  g = L_a^T b */
+    double* U = (double*)calloc((size_t)NA * n, sizeof(double));
+#pragma omp parallel for schedule(static) num_threads(nt2)
+    for (int i = 0; i < NA; ++i)
+        for (int k = 0; k < NA; ++k) {
+            const double a = A[(size_t)i * W + k];
+            if (a == 0.0) continue;
+            const double* lrow = L + (size_t)(15 + k) * n;
+            double* urow = U + (size_t)i * n;
+            for (int c = 0; c <= 15 + k && c < n; ++c) urow[c] += a * lrow[c];
+        }
+    double* Mm = (double*)calloc((size_t)n * n, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt2)
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < NA; ++k) {
+            const double l = L[(size_t)(15 + k) * n + i];
+            if (l == 0.0) continue;
+            const double* urow = U + (size_t)k * n;
+            double* mrow = Mm + (size_t)i * n;
+            for (int c = 0; c <= i; ++c) mrow[c] += l * urow[c];
+        }
+    for (int i = 0; i < n; ++i) Mm[(size_t)i * n + i] += s2;
+    if (chol_psd(Mm, n, n, 0.0) != 0) { free(L); free(U); free(Mm); return -1; }
+    /* Z^T = (L_M^-1 [L^T | g])^T, one right-hand side per row ((n+1) x n: both operands of the substitution contiguous) */
+    double* Z = (double*)malloc((size_t)(n + 1) * n * sizeof(double));
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt2)
+    for (int c = 0; c <= n; ++c) {
+        double* z = Z + (size_t)c * n;
+        for (int i = 0; i < n; ++i) {
+            double s;
+            if (c < n) s = L[(size_t)c * n + i];
+            else {
+                s = 0.0;
+                for (int k = 0; k < NA; ++k) s += L[(size_t)(15 + k) * n + i] * A[(size_t)k * W + NA];
+            }
+            const double* mrow = Mm + (size_t)i * n;
+            for (int k = 0; k < i; ++k) s -= mrow[k] * z[k];
+            z[i] = s / mrow[i];
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt2)
+    for (int a = 0; a < n; ++a) {
+        const double* za = Z + (size_t)a * n;
+        for (int b = 0; b <= a; ++b) {
+            const double* zb = Z + (size_t)b * n;
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += za[i] * zb[i];
+            P_out[(size_t)a * n + b] = s2 * s;
+            P_out[(size_t)b * n + a] = s2 * s;
+        }
+        const double* zg = Z + (size_t)n * n;
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += za[i] * zg[i];
+        dx[a] = s;
+    }
+    if (zg2) {
+        const double* zg = Z + (size_t)n * n;
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += zg[i] * zg[i];
+        *zg2 = s;
+    }
+    free(L); free(U); free(Mm); free(Z);
+    return 0;
+}
+
 static int g_fast_threads = 0;
 void orc_fast_set_threads(int t) { g_fast_threads = t > 0 ? t : 0; }
 
@@ -94,7 +173,7 @@ int orc_fast_msckf_update(int N, int F, const int* flags, double sigma, double c
             accept[j] = 0;
             gamma[j] = NAN;
             if (M < 2 || M > MAXM) continue;
-            const int rows = 2 * M, nc = 7 + 6 * M;
+            const int rows = 2 * M;
             double Hf[2 * MAXM * 3], rv[2 * MAXM];
             for (int k = 0; k < M; ++k) {
                 const int i = obs_clone[o0 + k];
@@ -306,69 +385,9 @@ int orc_fast_msckf_update(int N, int F, const int* flags, double sigma, double c
     for (int i = 0; i < W; ++i)
         for (int k = i + 1; k < W; ++k) A[(size_t)i * W + k] = A[(size_t)k * W + i];
     free(Aacc);
-    /* ---- square-root Kalman solve ------------------------------------------------------------------------------- */
-    double* L = (double*)malloc((size_t)n * n * sizeof(double));
-    memcpy(L, P, (size_t)n * n * sizeof(double));
-    double mx = 0.0;
-    for (int i = 0; i < n; ++i) if (P[(size_t)i * n + i] > mx) mx = P[(size_t)i * n + i];
-    if (chol_psd(L, n, n, 8.0 * 2.220446049250313e-16 * mx) < 0) { free(A); free(L); return -1; }
-    for (int i = 0; i < n; ++i)
-        for (int k = i + 1; k < n; ++k) L[(size_t)i * n + k] = 0.0;
-    /* U = A[0:NA,0:NA] L_a  (NA x n),  L_a = L[15:, :] ;  g = L_a^T b */
-    double* U = (double*)calloc((size_t)NA * n, sizeof(double));
-#pragma omp parallel for schedule(static) num_threads(nt2)
-    for (int i = 0; i < NA; ++i)
-        for (int k = 0; k < NA; ++k) {
-            const double a = A[(size_t)i * W + k];
-            if (a == 0.0) continue;
-            const double* lrow = L + (size_t)(15 + k) * n;
-            double* urow = U + (size_t)i * n;
-            for (int c = 0; c <= 15 + k && c < n; ++c) urow[c] += a * lrow[c];
-        }
-    double* Mm = (double*)calloc((size_t)n * n, sizeof(double));
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nt2)
-    for (int i = 0; i < n; ++i)
-        for (int k = 0; k < NA; ++k) {
-            const double l = L[(size_t)(15 + k) * n + i];
-            if (l == 0.0) continue;
-            const double* urow = U + (size_t)k * n;
-            double* mrow = Mm + (size_t)i * n;
-            for (int c = 0; c <= i; ++c) mrow[c] += l * urow[c];
-        }
-    for (int i = 0; i < n; ++i) Mm[(size_t)i * n + i] += s2;
-    if (chol_psd(Mm, n, n, 0.0) != 0) { free(A); free(L); free(U); free(Mm); return -1; }
-    /* Z^T = (L_M^-1 [L^T | g])^T, one right-hand side per row ((n+1) x n: both operands of the substitution contiguous) */
-    double* Z = (double*)malloc((size_t)(n + 1) * n * sizeof(double));
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nt2)
-    for (int c = 0; c <= n; ++c) {
-        double* z = Z + (size_t)c * n;
-        for (int i = 0; i < n; ++i) {
-            double s;
-            if (c < n) s = L[(size_t)c * n + i];
-            else {
-                s = 0.0;
-                for (int k = 0; k < NA; ++k) s += L[(size_t)(15 + k) * n + i] * A[(size_t)k * W + NA];
-            }
-            const double* mrow = Mm + (size_t)i * n;
-            for (int k = 0; k < i; ++k) s -= mrow[k] * z[k];
-            z[i] = s / mrow[i];
-        }
+    {
+        const int rc = orc_fast_sqrt_solve(n, NA, A, P, s2, dx, P_out, (double*)0, nt2);
+        free(A);
+        return rc;
     }
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nt2)
-    for (int a = 0; a < n; ++a) {
-        const double* za = Z + (size_t)a * n;
-        for (int b = 0; b <= a; ++b) {
-            const double* zb = Z + (size_t)b * n;
-            double s = 0.0;
-            for (int i = 0; i < n; ++i) s += za[i] * zb[i];
-            P_out[(size_t)a * n + b] = s2 * s;
-            P_out[(size_t)b * n + a] = s2 * s;
-        }
-        const double* zg = Z + (size_t)n * n;
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += za[i] * zg[i];
-        dx[a] = s;
-    }
-    free(A); free(L); free(U); free(Mm); free(Z);
-    return 0;
 }

@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, 'liborcoracle.so')
-    srcs = [os.path.join(_HERE, f) for f in ('msckf_oracle.c', 'msckf_fast.c', 'object_oracle.c', 'Makefile')]
+    srcs = [os.path.join(_HERE, f) for f in ('msckf_oracle.c', 'msckf_fast.c', 'object_oracle.c', 'object_fast.c', 'Makefile')]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(['make', '-C', _HERE, '-B', 'liborcoracle.so'], stdout=subprocess.DEVNULL)
@@ -168,6 +168,43 @@ def object_rows_c(obj, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D=False):
     if m == 0:
         return None
     return dict(row_clone=row_clone[:m].copy(), Hx6=Hx6[:m].copy(), Hf=Hf[:m].copy(), res=res[:m].copy())
+
+
+def _object_block_arrays(blocks):
+    ncol = np.array([b['Hf'].shape[1] for b in blocks], dtype=np.int32)
+    ncmax = int(ncol.max()) if len(blocks) else 1
+    ptr = np.concatenate([[0], np.cumsum([len(b['res']) for b in blocks])]).astype(np.int32)
+    rows = int(ptr[-1])
+    rc = np.ascontiguousarray(np.concatenate([b['row_clone'] for b in blocks]) if blocks else np.zeros(0), dtype=np.int32)
+    hx = np.ascontiguousarray(np.vstack([b['Hx6'] for b in blocks]) if blocks else np.zeros((0, 6)), dtype=np.float64)
+    hf = np.zeros((rows, ncmax))
+    for b, a0 in zip(blocks, ptr[:-1]):
+        hf[a0:a0 + len(b['res']), :b['Hf'].shape[1]] = b['Hf']
+    rs = np.ascontiguousarray(np.concatenate([b['res'] for b in blocks]) if blocks else np.zeros(0), dtype=np.float64)
+    return ncol, ncmax, ptr, rc, hx, hf, rs
+
+
+def objects_update_fast(flags, n_clones, blocks, P, threads=None):
+    """oracle/object_fast.c: the object update with the minimum-work algorithm (Schur-complement projection from the 7 non-zeros
+    per row, objects parallelised with OpenMP; bench.py's all-cores CPU figure for the object update, and a second independently
+    written evaluation).  dict(accept, gamma, dof, dx, P_new, seconds, threads)."""
+    n = flags.leg_dim + 6 * n_clones
+    ncol, ncmax, ptr, rc, hx, hf, rs = _object_block_arrays(blocks)
+    Pc = np.ascontiguousarray(P, dtype=np.float64)
+    acc = C.c_int(0); gam = C.c_double(0.0); dof = C.c_int(0); used = C.c_int(0)
+    dx = np.zeros(n); Pn = np.zeros((n, n))
+    if threads is not None:
+        lib().orc_fast_objects_set_threads(C.c_int(int(threads)))
+    t0 = time.perf_counter()
+    rcode = lib().orc_fast_objects_update(C.c_int(n_clones), C.c_int(flags.leg_dim), C.c_int(len(blocks)), _i(ptr), _i(ncol), C.c_int(ncmax),
+                                          _i(rc), _d(hx), _d(hf), _d(rs), _d(Pc), C.c_double(flags.noise_feature), C.c_double(flags.chi2_prob),
+                                          C.byref(acc), C.byref(gam), C.byref(dof), _d(dx), _d(Pn), C.byref(used))
+    dt = time.perf_counter() - t0
+    if threads is not None:
+        lib().orc_fast_objects_set_threads(C.c_int(0))
+    if rcode != 0:
+        raise RuntimeError('fast object update failed (a matrix was not positive definite)')
+    return dict(accept=int(acc.value), gamma=float(gam.value), dof=int(dof.value), dx=dx, P_new=Pn, seconds=dt, threads=int(used.value))
 
 
 def objects_update_c(flags, n_clones, blocks, P):

@@ -172,3 +172,32 @@ def test_whole_null_space_reference_equals_the_svd_reference_on_full_rank_blocks
     else:
         assert seed in (13, 1060)
         assert b['gamma'] >= a['gamma'] * (1 - 1e-9)   # more directions of the same residual: the distance cannot shrink
+
+
+@pytest.mark.parametrize('case', [dict(N=10, nobj=3, missing=0.0, noise=0.004), dict(N=30, nobj=6, missing=0.1, noise=0.004),
+                                  dict(N=12, nobj=2, missing=0.0, noise=0.2)])
+def test_minimum_work_object_port_agrees_with_the_literal_one(built, case):
+    """oracle/object_fast.c (bench.py's all-cores CPU figure for the object update: Schur-complement projection from the 7 non-zeros
+    per row, square-root solve) against oracle/object_oracle.c (literal: reflectors applied to dense rows, QR of the stack) and
+    the numpy reference: same gate decision, same update.  Full-rank H_f (every keypoint seen): the two projections coincide."""
+    import ctypes
+    from orcvio_amd import synth
+    from oracle import oracle as orc
+    from helpers import objects_update_reference, rel
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=case['N'], F=4, seed=23, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=case['nobj'], seed=5, sigma_kp=case['noise'], missing_frac=case['missing'])
+    blocks = [orc.object_rows_c(ob, win.R_b2c[0], win.t_c_b[0], True, False, 0) for ob in objs]
+    ref = objects_update_reference(win, objs, win.P, True, False, 0)
+    lit = orc.objects_update_c(flags, win.N, blocks, win.P)
+    for team in (1, 3):
+        got = orc.objects_update_fast(flags, win.N, blocks, win.P, threads=team)
+        assert got['threads'] == min(team, len(blocks))
+        assert got['accept'] == lit['accept'] == ref['accept'] and got['dof'] == lit['dof']
+        assert abs(got['gamma'] - lit['gamma']) < 1e-7 * abs(lit['gamma'])
+        if ref['accept']:
+            assert rel(got['dx'], lit['dx']) < 1e-7 and rel(got['P_new'], lit['P_new']) < 1e-9
+            assert rel(got['dx'], ref['dx']) < 1e-7
+        else:
+            assert not np.any(got['dx']) and np.array_equal(got['P_new'], win.P)
+    assert ref['accept'] == (0 if case['noise'] > 0.1 else 1)
