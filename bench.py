@@ -362,9 +362,6 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args))
-    # the CPU legs sweep OpenMP team sizes: idle pool threads must sleep, not spin (read by the OpenMP runtime when it is loaded,
-    # i.e. with torch: set before that import)
-    os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
 
     import numpy as np
     import torch
