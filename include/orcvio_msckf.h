@@ -203,9 +203,16 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * 1: the reference's literal arithmetic (affects orcvio_msckf_augment_new_features and orcvio_msckf_cov_commit_new_features; the
  * handle-less orcvio_msckf_augment_state has the twin orcvio_msckf_augment_state_ref_ldlt).  P22 uses (H_2^T H_2)^-1 either way,
  * as the reference does (:1907-1908). */
+/* ORCVIO_OPT_OBJECT_REFINE (default 1): how an object whose H_f is ill conditioned is projected (structured-QR route only).  The
+ * fast route takes Y = Q_1^T [H_x | r] from the semi-normal equations R^-T (H_f^T [H_x | r]), accurate to cond(H_f) eps; the
+ * reference's full-U SVD (math_utils.hpp:287-312) is backward stable.  1: objects whose triangular factor R has |R|_F |R^-1|_F above 3e6
+ * (an estimate of cond(H_f) from above, formed on the device; every real car: cond(H_f) ~ 3e8 on the reference's one_car frames) form the basis explicitly, row by row (q_i R = h_i), take
+ * Y from it and correct for its loss of orthonormality -- delta_x within 1e-9 of a 50-digit evaluation where the fast
+ * route has 1.4e-6.  0: never.  2: every object.  orcvio_msckf_objects_refined reports how many objects of the last update took it. */
 enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
        ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6, ORCVIO_OPT_RESIDENT_FACTOR = 7, ORCVIO_OPT_OBJECT_QR = 8,
-       ORCVIO_OPT_REF_STACK_HF = 9, ORCVIO_OPT_SCHMIDT_STATES = 10, ORCVIO_OPT_OBJECT_DOF = 11, ORCVIO_OPT_REF_H2_LDLT = 12 };
+       ORCVIO_OPT_REF_STACK_HF = 9, ORCVIO_OPT_SCHMIDT_STATES = 10, ORCVIO_OPT_OBJECT_DOF = 11, ORCVIO_OPT_REF_H2_LDLT = 12,
+       ORCVIO_OPT_OBJECT_REFINE = 13 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* EKF-SLAM rows of the hybrid filter (existing SLAM features).  For every SLAM feature the current
@@ -494,6 +501,9 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
 int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks,
                                     int32_t dof_total, void* stream);
 int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_result* result);
+/* Objects of the last downloaded object update (any entry point) whose projection against H_f went through the explicit basis
+ * (ORCVIO_OPT_OBJECT_REFINE; math_utils.hpp:287-312 is the step it stands for): this rank's objects only. */
+int32_t orcvio_msckf_objects_refined(orcvio_msckf_handle* h, int32_t* count);
 
 /* The object update straight from object TRACKS (state at the LM optimum + observations; the structs of
  * orcvio_msckf_object_rows_eval): the residual rows and Jacobians of CameraLM::Error{Feature,BBox}Quadric /

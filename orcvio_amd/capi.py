@@ -42,6 +42,7 @@ EXPORTS = [
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
     'orcvio_msckf_comm_barrier', 'orcvio_msckf_comm_allreduce_max', 'orcvio_msckf_io_begin', 'orcvio_msckf_io_update',
     'orcvio_msckf_augment_state_ref_ldlt', 'orcvio_msckf_io_update_frame', 'orcvio_msckf_io_submit', 'orcvio_msckf_io_collect',
+    'orcvio_msckf_objects_refined',
 ]
 
 
@@ -904,6 +905,17 @@ class MsckfUpdater:
     def set_object_dof_rank(self, on: bool):
         """ORCVIO_OPT_OBJECT_DOF: 1 = the object gate counts rows - rank(H_f) degrees of freedom (default rows - columns)."""
         self._chk(self.lib.orcvio_msckf_set_option(self.h, 11, int(bool(on))), 'orcvio_msckf_set_option')
+
+    def set_object_refine(self, mode: int):
+        """ORCVIO_OPT_OBJECT_REFINE: 0 never, 1 objects with an ill-conditioned H_f (default), 2 every object take the explicit-basis projection."""
+        self._chk(self.lib.orcvio_msckf_set_option(self.h, 13, int(mode)), 'orcvio_msckf_set_option')
+
+    def objects_refined(self) -> int:
+        """Objects of the last downloaded object update that took the explicit-basis projection."""
+        c = C.c_int32(0)
+        self.lib.orcvio_msckf_objects_refined.argtypes = [C.c_void_p, _ip]
+        self._chk(self.lib.orcvio_msckf_objects_refined(self.h, C.byref(c)), 'orcvio_msckf_objects_refined')
+        return int(c.value)
 
     def set_ref_h2_ldlt(self, on: bool):
         """ORCVIO_OPT_REF_H2_LDLT: the reference's literal H_2.ldlt() in the tail of the hybrid update (default: triangular solve)."""

@@ -118,6 +118,8 @@ struct orcvio_msckf_handle {
     bool obj_dof_rank = false;          // ORCVIO_OPT_OBJECT_DOF = 1: the object gate counts rows - rank(H_f) degrees of freedom (default: rows - columns, the reference's count)
     bool ref_h2_ldlt = false;           // ORCVIO_OPT_REF_H2_LDLT: the reference's literal H_2.ldlt() (diag(H_2)) in the tail of the hybrid update
     bool ref_stack_hf = false;          // ORCVIO_OPT_REF_STACK_HF: the reference's literal shared-Hf stacking of several objects
+    int obj_refine_mode = 1;            // ORCVIO_OPT_OBJECT_REFINE: 0 never, 1 objects with cond_F(R) above 3e6 (default), 2 every object
+    int obj_refined = 0;                // objects of the last downloaded object update that took the explicit-basis projection (k_obj_refine)
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
     bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P
     // The prior's Cholesky is taken of the REVERSED matrix (potrf_reg_body, rev): P = S S^T with S(i, c) = L'(n-1-i, c), whose

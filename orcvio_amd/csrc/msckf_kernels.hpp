@@ -3023,6 +3023,280 @@ __global__ __launch_bounds__(256) void k_obj_border_solve_assemble(const ObjArro
     obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, nullptr, 0, cb0, NA, NAP, Bdst, corner_block ? sCorner : nullptr);
 }
 
+// ---- ill-conditioned Hf: the projection redone with an explicit basis (k_obj_refine) ----------------------------------------
+// Y = Q1^T X is what the Schur complement A' = B - Y^T Y needs (Q1 = an orthonormal basis of range(Hf), X = [Hx | r]).  The launches
+// above take it from the semi-normal equations, Y = R^-T (Hf^T X): the rounding of the products Hf^T X (eps |Hf| |X|) is divided by
+// the small pivots of R, an error of cond(Hf) eps in Y -- 3e-8 on the reference's own one_car frames (cond(Hf) = 3e8: the gauge of
+// the keypoint rows), which the update amplifies to 1.4e-6 in delta_x at a large prior (profiles/r3_conditioning.json) where the
+// reference's full-U SVD (math_utils.hpp:287-312) keeps 4e-10.  The subtraction B - Y^T Y itself is NOT the problem (measured: with
+// Y from explicit Householder reflectors the same subtraction reaches 4e-10).
+// For an object whose factor R has |R|_F |R^-1|_F above 3e6 (formed below: between cond(Hf) and 45 cond(Hf)) this kernel therefore forms the basis EXPLICITLY, row by row,
+//     q_i R = h_i   (a backward-stable triangular solve: Q~ R = Hf + E, |E| <= c eps |Q~| |R| -- the backward error of a Householder QR)
+// and takes Y = Q~^T X directly from the rows (no product with Hf, nothing divided by a small pivot afterwards).  Q~ spans range(Hf)
+// to that backward error but is orthonormal only to cond * eps: T = Q~^T Q~ = I + D.  The projector onto its range is Q~ T^-1 Q~^T,
+// so A' = B - Y^T T^-1 Y = B - Y''^T Y'' with Y'' = (I - D/2) Y = 1.5 Y - 0.5 T Y up to D^2 (< 1e-10 even at the pivot tolerance).
+// Both Q~ and T keep the arrow shape of Hf, so everything is 12 numbers per row.  One 256-thread workgroup per object:
+//   A  q_i for every row (thread per row): [3 keypoint entries | 9 border entries], kept in Qt [row][16] with the row's keypoint index
+//   B  T (per keypoint 3 x 3 and 3 x 9, border 9 x 9) and Q~^T r -- fixed summation orders (deterministic)
+//   C  thread per window column: Y[:, col] from the rows of the column's clone, then the correction; written over the object's Y
+// Objects below the threshold leave after reading their pivots (mode 1, the default); mode 2 refines every object.
+#define OBJ_REFINE_COND 3e6
+__global__ __launch_bounds__(256) void k_obj_refine(const ObjArrow* __restrict__ objs, const int2* __restrict__ kp_range,
+                                                    const int* __restrict__ kp_rows, const ObjGroup* __restrict__ groups, int ngroups,
+                                                    const int* __restrict__ ridx, const double* __restrict__ Hx6,
+                                                    const double* __restrict__ HfR, int ldf, int no_max, int Kmax,
+                                                    const double* __restrict__ Rarrow, double* __restrict__ Qt, double* __restrict__ Y,
+                                                    int NOP, int NAP, int NA, int cb0, int N, int mode, int* __restrict__ refined) {
+    extern __shared__ double sRef[];   // [arrow factor | T in the same layout (36 per keypoint, 81 border) | Q~^T r (NOP)]
+    __shared__ int2 sRange[36];
+    __shared__ int2 sGrp[ORCVIO_MAX_CLONES];
+    __shared__ double sPart[4][54];
+    __shared__ double sMinMax[2];
+    const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ObjArrow ob = objs[o];
+    const int K = ob.K, astr = arrow_stride(Kmax);
+    double* sR = sRef;
+    double* sT = sRef + astr;
+    double* sYr = sT + astr;
+    const double* Ro = Rarrow + (size_t)o * astr;
+    for (int i = tid; i < astr; i += 256) sR[i] = Ro[i];
+    if (tid <= K) sRange[tid] = kp_range[ob.kp_off + tid];
+    if (tid < ORCVIO_MAX_CLONES) sGrp[tid] = int2{0, 0};
+    __syncthreads();
+    const double tol = sR[36 * Kmax + 81];
+    if (mode != 2) {
+        // Condition estimate of the factor: cond_F = |R|_F |R^-1|_F (between cond_2 and 45 cond_2).  The diagonal of an unpivoted
+        // R says nothing (one_car: pivot ratio 5e-4 at cond 3e8), so the inverse is formed -- 12 numbers per keypoint with the arrow
+        // shape: R^-1 = [[R_kk^-1, -R_kk^-1 R_kb R_b^-1], [0, R_b^-1]].  Dropped pivots (zero columns of Q~) are left out.
+        const double* Rb0 = sR + 36 * Kmax;
+        double* sInv = sT;   // (T is not there yet: its first 81 doubles hold R_b^-1 for the estimate)
+        if (tid < 9) {
+            double x[9];
+#pragma unroll
+            for (int i = 8; i >= 0; --i) {
+                double t = (i == tid) ? 1.0 : 0.0;
+#pragma unroll
+                for (int m = 0; m < 9; ++m)
+                    if (m > i) t -= Rb0[9 * i + m] * x[m];
+                const double pv = Rb0[9 * i + i];
+                x[i] = fabs(pv) > tol ? t / pv : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sInv[9 * i + tid] = x[i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double nr = 0.0, ni = 0.0;
+            if (lane < K) {
+                const double* Rk = sR + 36 * lane;
+                double inv[3][3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {   // column j of R_kk^-1
+#pragma unroll
+                    for (int i = 2; i >= 0; --i) {
+                        double t = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                        for (int m = 0; m < 3; ++m)
+                            if (m > i) t -= Rk[12 * i + m] * inv[m][j];
+                        const double pv = Rk[12 * i + i];
+                        inv[i][j] = fabs(pv) > tol ? t / pv : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double w[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        w[c] = (inv[i][0] * Rk[3 + c] + inv[i][1] * Rk[15 + c]) + inv[i][2] * Rk[27 + c];
+                        nr += Rk[12 * i + 3 + c] * Rk[12 * i + 3 + c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 9; ++m)
+                            if (m <= c) v += w[m] * sInv[9 * m + c];
+                        ni += v * v;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { ni += inv[i][j] * inv[i][j]; if (j >= i) nr += Rk[12 * i + j] * Rk[12 * i + j]; }
+                }
+            }
+            for (int e = lane; e < 81; e += 64) { nr += Rb0[e] * Rb0[e]; ni += sInv[e] * sInv[e]; }   // (below the diagonal both hold zeros)
+            nr = wave_sum_dpp(nr);
+            ni = wave_sum_dpp(ni);
+            if (lane == 0) { sMinMax[0] = nr; sMinMax[1] = ni; }
+        }
+        __syncthreads();
+        const double condF2 = sMinMax[0] * sMinMax[1];
+        if (!(condF2 > OBJ_REFINE_COND * OBJ_REFINE_COND)) return;   // (workgroup-uniform; NaN -> the fast route's result stands)
+        __syncthreads();   // (sInv = sT is rewritten below)
+    }
+    if (tid == 0 && refined) atomicAdd(refined, 1);
+    for (int g = tid; g < ngroups; g += 256) {
+        const ObjGroup q = groups[g];
+        if (q.obj == o) sGrp[q.clone] = int2{q.r0, q.r1};
+    }
+    // ---- A: the rows of Q~ -------------------------------------------------------------------------------------------------
+    const int p0 = sRange[0].x, p1 = sRange[K].y;   // (the K + 1 row lists of an object are contiguous in kp_rows)
+    const double* Rb = sR + 36 * Kmax;
+    for (int p = p0 + tid; p < p1; p += 256) {
+        int k = 0;
+        while (k < K && p >= sRange[k].y) ++k;
+        const int row = kp_rows[p];
+        const double* h = HfR + (size_t)row * ldf;
+        double hb[9], qk[3] = {0.0, 0.0, 0.0}, qb[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) hb[c] = h[c];
+        const double res = h[no_max];
+        if (k < K) {
+            const double* Rk = sR + 36 * k;
+            double hk[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) hk[j] = h[9 + 3 * k + j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double t = hk[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (i < j) t -= qk[i] * Rk[12 * i + j];
+                const double pv = Rk[12 * j + j];
+                qk[j] = fabs(pv) > tol ? t / pv : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) hb[c] -= (qk[0] * Rk[3 + c] + qk[1] * Rk[15 + c]) + qk[2] * Rk[27 + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            double t = hb[j];
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i < j) t -= qb[i] * Rb[9 * i + j];
+            const double pv = Rb[9 * j + j];
+            qb[j] = fabs(pv) > tol ? t / pv : 0.0;
+        }
+        double* q = Qt + (size_t)row * 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) q[j] = qk[j];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) q[3 + j] = qb[j];
+        q[12] = (double)k;
+        q[13] = res;
+    }
+    __syncthreads();   // (the rows of Qt are read by other threads of this workgroup below)
+    // ---- B: T = Q~^T Q~ and Q~^T r ---------------------------------------------------------------------------------------------
+    for (int it = tid; it < K * 39; it += 256) {   // keypoint blocks: T_kk (9), T_kb (27), q_k^T r (3); rows in list order
+        const int k = it / 39, v = it - 39 * k;
+        const int i = v < 9 ? v / 3 : (v < 36 ? (v - 9) / 9 : v - 36);
+        const int jb = v < 9 ? v % 3 : (v < 36 ? 3 + (v - 9) % 9 : 13);
+        double acc = 0.0;
+        for (int p = sRange[k].x; p < sRange[k].y; ++p) {
+            const double* q = Qt + (size_t)kp_rows[p] * 16;
+            acc += q[i] * q[jb];
+        }
+        if (v < 36) sT[36 * k + v] = acc; else sYr[9 + 3 * k + i] = acc;
+    }
+    {   // border: T_bb (45 distinct entries) and q_b^T r (9), every thread a slice of the rows
+        double acc[54];
+#pragma unroll
+        for (int v = 0; v < 54; ++v) acc[v] = 0.0;
+        for (int p = p0 + tid; p < p1; p += 256) {
+            const double* q = Qt + (size_t)kp_rows[p] * 16;
+            double qb[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) qb[j] = q[3 + j];
+            const double res = q[13];
+            int v = 0;
+#pragma unroll
+            for (int a = 0; a < 9; ++a) {
+#pragma unroll
+                for (int b = a; b < 9; ++b) acc[v++] += qb[a] * qb[b];
+            }
+#pragma unroll
+            for (int a = 0; a < 9; ++a) acc[45 + a] += qb[a] * res;
+        }
+#pragma unroll
+        for (int v = 0; v < 54; ++v) acc[v] = wave_sum_dpp(acc[v]);
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < 54; ++v) sPart[wave][v] = acc[v];
+        }
+    }
+    __syncthreads();
+    if (tid < 54) {
+        const double s = (sPart[0][tid] + sPart[1][tid]) + (sPart[2][tid] + sPart[3][tid]);
+        if (tid < 45) {
+            int a = 0, rem = tid;
+            while (rem >= 9 - a) { rem -= 9 - a; ++a; }
+            const int b = a + rem;
+            sT[36 * Kmax + 9 * a + b] = s;
+            sT[36 * Kmax + 9 * b + a] = s;
+        } else {
+            sYr[tid - 45] = s;
+        }
+    }
+    __syncthreads();
+    // ---- C: Y[:, col] from the rows, then Y'' = 1.5 Y - 0.5 T Y ----------------------------------------------------------------
+    double* Yo = Y + (size_t)o * NOP * NAP;
+    const double* Tb = sT + 36 * Kmax;
+    for (int col = tid; col < NAP; col += 256) {
+        if (col > NA) {
+            for (int i = 0; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;
+            continue;
+        }
+        const bool rcol = col == NA;
+        double yb[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) yb[j] = rcol ? sYr[j] : 0.0;
+        if (!rcol) {
+            for (int i = 9; i < 9 + 3 * K; ++i) Yo[(size_t)i * NAP + col] = 0.0;
+            const int c = (col >= cb0 && col < cb0 + 6 * N) ? (col - cb0) / 6 : -1;
+            if (c >= 0) {
+                const int e = col - cb0 - 6 * c;
+                const int2 gr = sGrp[c];
+                for (int qi = gr.x; qi < gr.y; ++qi) {
+                    const int row = ridx[qi];
+                    const double x = Hx6[(size_t)row * 6 + e];
+                    const double* q = Qt + (size_t)row * 16;
+                    const int k = (int)q[12];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) yb[j] += q[3 + j] * x;
+                    if (k < K) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) Yo[(size_t)(9 + 3 * k + j) * NAP + col] += q[j] * x;
+                    }
+                }
+            }
+        }
+        double tb[9];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+            double t = 0.0;
+#pragma unroll
+            for (int b = 0; b < 9; ++b) t += Tb[9 * a + b] * yb[b];
+            tb[a] = t;
+        }
+        for (int k = 0; k < K; ++k) {
+            const double* Tk = sT + 36 * k;
+            double yk[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) yk[j] = rcol ? sYr[9 + 3 * k + j] : Yo[(size_t)(9 + 3 * k + j) * NAP + col];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double t = (Tk[3 * j] * yk[0] + Tk[3 * j + 1] * yk[1]) + Tk[3 * j + 2] * yk[2];
+#pragma unroll
+                for (int c2 = 0; c2 < 9; ++c2) t += Tk[9 + 9 * j + c2] * yb[c2];
+                Yo[(size_t)(9 + 3 * k + j) * NAP + col] = 1.5 * yk[j] - 0.5 * t;
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 9; ++c2) tb[c2] += (Tk[9 + c2] * yk[0] + Tk[18 + c2] * yk[1]) + Tk[27 + c2] * yk[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) Yo[(size_t)j * NAP + col] = 1.5 * yb[j] - 0.5 * tb[j];
+        for (int i = 9 + 3 * K; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;
+    }
+}
+
 // Test hook (tests/test_gpu_robustness.py): hold `gridDim.x` compute units for `ticks` of the 100 MHz wall clock (every
 // workgroup takes a whole CU's LDS), so that a co-resident launch next to it cannot get all of its workgroups resident.
 __global__ __launch_bounds__(64) void k_debug_occupy(unsigned long long ticks, int* sink) {

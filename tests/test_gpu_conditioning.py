@@ -118,17 +118,24 @@ def test_conditioning_sweep_object_update(built):
                     ref = mp_reference.objects_update_mp(blocks, win.P, sigma)
                     dbl = objects_update_reference(win, [obj], win.P, True, False, 0)
                     got = u.update_object_tracks(flags, win.N, [obj], win.P, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+                    refined = u.objects_refined()
+                    assert refined == (1 if name == 'one_car' else 0)   # (|R|_F |R^-1|_F: 3.6e8 on the real car, 2.4e5 on the synthetic one; threshold 3e6)
+                    u.set_object_refine(0)   # the fast route alone (round 3), for the record
+                    try:
+                        fast = u.update_object_tracks(flags, win.N, [obj], win.P, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+                    finally:
+                        u.set_object_refine(1)
                     e = dict(object=name, sigma=sigma, pscale=pscale, cond_Hf=float(np.linalg.cond(blocks[0][1])), gamma=ref['gamma'], dof=ref['dof_ref'],
                              accept=ref['accept_ref'], same_decision=bool(got['accept'] == ref['accept_ref']),
                              dev_gamma=abs(got['gamma'] - ref['gamma']) / abs(ref['gamma']), dbl_gamma=abs(dbl['gamma'] - ref['gamma']) / abs(ref['gamma']))
                     if ref['accept_ref'] and got['accept']:
                         e.update(dev_dx=rel(got['dx'], ref['dx']), dbl_dx=rel(dbl['dx'], ref['dx']), dev_P=rel(got['P_new'], ref['P_new']),
-                                 dbl_P=rel(dbl['P_new'], ref['P_new']))
-                        # The device forms the projected Gram as a Schur complement, A' = X^T X - Y^T Y: what cancels there
-                        # is lost, however accurately R was found.  On the reference's real car seen in only FOUR frames (cond(H_f) = 3e8,
-                        # the gauge of the keypoint rows held by sixteen bbox rows) that costs the last digit of the 1e-6 target: recorded,
-                        # bounded a decade above it; the 30-frame update of the same car (tests/test_gpu_fixtures.py) is inside 1e-6.
-                        lim = max(1e-5 if name == 'one_car' else 1e-6, 100 * e['dbl_dx'])
+                                 dbl_P=rel(dbl['P_new'], ref['P_new']), refined=refined,
+                                 fast_dx=rel(fast['dx'], ref['dx']) if fast['accept'] else None)
+                        # Round 4 (VERDICT r3 'next' 1): the bar is north_star's 1e-6 for BOTH objects.  The reference's real car seen in
+                        # four frames has cond(H_f) = 3e8; the semi-normal equations Y = R^-T (H_f^T X) lose cond * eps there (1.4e-6 in
+                        # delta_x at P x 100, round 3) -- ill-conditioned objects now take Y from an explicit basis (k_obj_refine).
+                        lim = max(1e-6, 100 * e['dbl_dx'])
                         assert e['dev_dx'] < lim and e['dev_P'] < lim, e
                         e['inside_1e-6'] = bool(e['dev_dx'] < 1e-6)
                     assert e['dev_gamma'] < max(1e-6, 100 * e['dbl_gamma']), e

@@ -344,6 +344,35 @@ def test_random_object_windows_including_rank_deficient_blocks(upd, seed):
         assert not got['dx'].any() and rel(got['P_new'], win.P) < 1e-15
 
 
+@pytest.mark.parametrize('seed', [0, 3, 5, 9, 13, 16, 28, 35, 66, 1060])
+def test_explicit_basis_projection_on_every_object(upd, seed):
+    """ORCVIO_OPT_OBJECT_REFINE = 2: every object is projected through the explicit basis Q~ = H_f R^-1 with the orthonormality
+    correction (k_obj_refine; by default only objects whose factor has cond_F above 3e6).  Same windows as above -- several
+    objects, missing keypoints, frames outside the window, two frames sharing a clone, rank-deficient H_f (dropped pivots give zero
+    columns of Q~) -- against the mirror, and the count the getter reports."""
+    case = random_object_case(seed)
+    win, objs = case['win'], case['objs']
+    ref = objects_update_reference(win, objs, win.P, case['obj_left'], case['new_bbox'], case['vio_left'], full_nullspace=True)
+    args = (case['flags'], win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], case['obj_left'], case['new_bbox'], case['vio_left'])
+    base = upd.update_object_tracks(*args)
+    n_auto = upd.objects_refined()
+    upd.set_object_refine(2)
+    try:
+        got = upd.update_object_tracks(*args)
+        n_all = upd.objects_refined()
+    finally:
+        upd.set_object_refine(1)
+    assert n_all == len(ref['blocks']) and 0 <= n_auto <= n_all
+    assert got['accept'] == ref['accept'] == base['accept']
+    if np.isfinite(ref['gamma']):
+        assert abs(got['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+    if ref['accept']:
+        assert rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL
+        assert rel(got['dx'], base['dx']) < TOL
+    else:
+        assert not got['dx'].any()
+
+
 def test_object_gate_degrees_of_freedom_option(upd):
     """ORCVIO_OPT_OBJECT_DOF (VERDICT r2 'missing' 2): with a rank-deficient H_f the device projects onto the whole left null space
     (rows - rank directions); the default keeps the reference's count rows - columns for the threshold, the option counts
