@@ -2988,6 +2988,396 @@ __global__ __launch_bounds__(256) void k_obj_solve_assemble(int nb_solve, int so
     obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, rr, rr_stride, cb0, NA, NAP, Bdst);
 }
 
+// ---- ill-conditioned Hf: the projection through an explicit basis (obj_refine_body) ----------------------------------------
+// Y = Q1^T X is what the Schur complement A' = B - Y^T Y needs (Q1 = an orthonormal basis of range(Hf), X = [Hx | r]).  The fast
+// route takes it from the semi-normal equations, Y = R^-T (Hf^T X): the rounding of the products Hf^T X (eps |Hf| |X|) is divided by
+// the small singular values of R, an error of cond(Hf) eps in Y -- 3e-8 on the reference's own one_car frames (cond(Hf) = 3e8: the
+// gauge of the keypoint rows), which the update amplifies to 1.4e-6 in delta_x at a large prior (profiles/r3_conditioning.json) where
+// the reference's full-U SVD (math_utils.hpp:287-312) keeps 4e-10.  The subtraction B - Y^T Y itself is NOT the problem (measured:
+// with Y from explicit Householder reflectors the same subtraction reaches 4e-10).
+// An object whose factor has |R|_F |R^-1|_F above OBJ_REFINE_COND therefore forms the basis EXPLICITLY, row by row,
+//     q_i R = h_i   (a backward-stable triangular solve: Q~ R = Hf + E, |E| <= c eps |Q~| |R| -- the backward error of a Householder QR)
+// and takes Y = Q~^T X directly from the rows (no product with Hf, nothing divided by a small pivot afterwards).  Q~ spans range(Hf)
+// to that backward error but is orthonormal only to cond * eps: T = Q~^T Q~ = I + D.  The projector onto its range is Q~ T^-1 Q~^T,
+// so A' = B - Y^T T^-1 Y = B - Y''^T Y'' with Y'' = (I - D/2) Y = 1.5 Y - 0.5 T Y up to D^2 (< 1e-10 even at the pivot tolerance).
+// Both Q~ and T keep the arrow shape of Hf, so everything is 12 numbers per row.  One 256-thread workgroup per object, the rows of
+// Q~ and of X staged in LDS in the order of the (object, clone) groups (objects of more rows than fit: in global scratch):
+//   P  positions: lp = index of a row in the clone-grouped order; the keypoint lists as lists of positions
+//   A  q_i for every row: [3 keypoint entries | 9 border entries]
+//   B  T (per keypoint 3 x 3 and 3 x 9, border 9 x 9) and Q~^T r -- fixed summation orders (deterministic)
+//   C  thread per window column: Y[:, col] from the rows of the column's clone, keypoints four at a time in registers, corrected and
+//      written over the object's block of Y
+#define OBJ_REFINE_COND 3e6
+#define OBJ_REFINE_ROW_DOUBLES 22   // per row of the staging: q 12 (+1 pad), [hx | r] 7, three ints (position, list entry, keypoint)
+struct RefineArgs {
+    const int2* kp_range; const int* kp_rows; const ObjGroup* groups; int ngroups; const int* ridx;
+    const double* Hx6; const double* HfR; int ldf, no_max;
+    double* scratch;      // [rows_tot][OBJ_REFINE_ROW_DOUBLES] global staging for objects that do not fit the LDS staging
+    int lds_rows;         // rows the LDS staging of the launch holds
+    int mode;             // 1: objects above OBJ_REFINE_COND, 2: every object
+    int* refined;         // counter of refined objects
+    int cb0, N;
+    unsigned long long* stamps;   // diagnostics (ORCVIO_REFINE_STAMPS): wall-clock stamps of object 0's phases
+};
+#define REFINE_STAMP(i) do { if (a.stamps && o == 0 && threadIdx.x == 0) a.stamps[i] = wall_clock64(); } while (0)
+// cond_F^2 of the arrow factor in sR (sInv: 81 doubles of scratch); every thread of the 256 takes part (two barriers), the result is uniform.
+// The diagonal of an unpivoted R says nothing (one_car: pivot ratio 5e-4 at cond 3e8), so the inverse is formed -- 12 numbers per
+// keypoint with the arrow shape: R^-1 = [[R_kk^-1, -R_kk^-1 R_kb R_b^-1], [0, R_b^-1]].  Dropped pivots (zero columns of Q~) are left out.
+__device__ __forceinline__ double obj_arrow_cond2(const double* __restrict__ sR, double* __restrict__ sInv, double* __restrict__ sOut, int K, int Kmax) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double tol = sR[36 * Kmax + 81];
+    const double* Rb0 = sR + 36 * Kmax;
+    if (tid < 9) {
+        double x[9];
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {
+            double t = (i == tid) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < 9; ++m)
+                if (m > i) t -= Rb0[9 * i + m] * x[m];
+            const double pv = Rb0[9 * i + i];
+            x[i] = fabs(pv) > tol ? t / pv : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sInv[9 * i + tid] = x[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double nr = 0.0, ni = 0.0;
+        if (lane < K) {
+            const double* Rk = sR + 36 * lane;
+            double inv[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {   // column j of R_kk^-1
+#pragma unroll
+                for (int i = 2; i >= 0; --i) {
+                    double t = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        if (m > i) t -= Rk[12 * i + m] * inv[m][j];
+                    const double pv = Rk[12 * i + i];
+                    inv[i][j] = fabs(pv) > tol ? t / pv : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double w[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    w[c] = (inv[i][0] * Rk[3 + c] + inv[i][1] * Rk[15 + c]) + inv[i][2] * Rk[27 + c];
+                    nr += Rk[12 * i + 3 + c] * Rk[12 * i + 3 + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 9; ++m)
+                        if (m <= c) v += w[m] * sInv[9 * m + c];
+                    ni += v * v;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { ni += inv[i][j] * inv[i][j]; if (j >= i) nr += Rk[12 * i + j] * Rk[12 * i + j]; }
+            }
+        }
+        for (int e = lane; e < 81; e += 64) { nr += Rb0[e] * Rb0[e]; ni += sInv[e] * sInv[e]; }   // (below the diagonal both hold zeros)
+        nr = wave_sum_dpp(nr);
+        ni = wave_sum_dpp(ni);
+        if (lane == 0) sOut[0] = nr * ni;
+    }
+    __syncthreads();
+    return sOut[0];
+}
+// sR: the object's arrow factor (with the pivot tolerance); sT (arrow_stride doubles), sYr (NOP doubles): LDS scratch; rowbuf: the
+// staging of this object's rows (LDS or global), m * OBJ_REFINE_ROW_DOUBLES doubles.  All 256 threads; writes the object's block of Y.
+template <bool INLDS>
+__device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, const int Kmax, const double* __restrict__ sR,
+                                                double* __restrict__ sT, double* __restrict__ sYr, double* rowbuf, const RefineArgs& a,
+                                                double* __restrict__ Y, int NOP, int NAP, int NA) {
+    __shared__ int2 sRange[36];
+    __shared__ int2 sGrp[ORCVIO_MAX_CLONES];
+    __shared__ double sPartR[4][54];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = ob.K, m = ob.rows, row0 = ob.row0;
+    const double tol = sR[36 * Kmax + 81];
+    constexpr int QS = 13;              // row stride of q: odd, so that the groups of different clones start on different LDS banks
+    double* q = rowbuf;                 // [m][QS]  3 keypoint entries, 9 border entries
+    double* xr = rowbuf + (size_t)m * QS;   // [m][7]  hx (6), r
+    int* sPos = reinterpret_cast<int*>(rowbuf + (size_t)m * (QS + 7));   // [m] row - row0 -> position
+    int* sList = sPos + m;              // [m] the keypoint lists as positions
+    int* sK = sList + m;                // [m] keypoint block of the row at a position (K: border only)
+    REFINE_STAMP(1);
+    if (tid <= K) sRange[tid] = a.kp_range[ob.kp_off + tid];
+    if (tid < ORCVIO_MAX_CLONES) sGrp[tid] = int2{0, 0};
+    __syncthreads();
+    for (int g = tid; g < a.ngroups; g += 256) {
+        const ObjGroup gq = a.groups[g];
+        if (gq.obj == o) sGrp[gq.clone] = int2{gq.r0 - row0, gq.r1 - row0};
+    }
+    // ---- P: positions, [hx | r] in group order; reciprocals of the kept pivots ---------------------------------------------------
+    if (tid < 9 + 3 * K) {
+        const double pv = tid < 9 ? sR[36 * Kmax + 10 * tid] : sR[36 * ((tid - 9) / 3) + 13 * ((tid - 9) % 3)];
+        sYr[tid] = fabs(pv) > tol ? 1.0 / pv : 0.0;
+    }
+    for (int lp = tid; lp < m; lp += 256) {
+        const int row = a.ridx[row0 + lp];
+        sPos[row - row0] = lp;
+        double v[7];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) v[e] = a.Hx6[(size_t)row * 6 + e];
+        v[6] = a.HfR[(size_t)row * a.ldf + a.no_max];
+#pragma unroll
+        for (int e = 0; e < 7; ++e) xr[lp * 7 + e] = v[e];
+    }
+    __syncthreads();
+    REFINE_STAMP(2);
+    // ---- A: the rows of Q~ (thread per entry of the keypoint lists).  (Straight-line code that runs once is bound by instruction
+    // fetch: every loop here is kept rolled except where a register array needs constant indices.) ------------------------------------
+    const int p0 = sRange[0].x, p1 = sRange[K].y;   // (the K + 1 row lists of an object are contiguous in kp_rows)
+    const double* Rb = sR + 36 * Kmax;
+    const double* sRi = sYr;   // reciprocals of the pivots (0: dropped), written in phase P: [9 border | 3 per keypoint]
+#pragma unroll 1
+    for (int p = p0 + tid; p < p1; p += 256) {
+        int k = 0;
+        while (k < K && p >= sRange[k].y) ++k;
+        const int row = a.kp_rows[p];
+        const int lp = sPos[row - row0];
+        sList[p - p0] = lp;
+        sK[lp] = k;
+        const double* h = a.HfR + (size_t)row * a.ldf;
+        double hb[9], qk[3] = {0.0, 0.0, 0.0}, qb[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) hb[c] = h[c];
+        if (k < K) {
+            const double* Rk = sR + 36 * k;
+            const double* rik = sRi + 9 + 3 * k;
+            double hk[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) hk[j] = h[9 + 3 * k + j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double t = hk[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (i < j) t -= qk[i] * Rk[12 * i + j];
+                qk[j] = t * rik[j];
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) hb[c] -= (qk[0] * Rk[3 + c] + qk[1] * Rk[15 + c]) + qk[2] * Rk[27 + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            double t = hb[j];
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i < j) t -= qb[i] * Rb[9 * i + j];
+            qb[j] = t * sRi[j];
+        }
+        double* qo = q + lp * QS;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) qo[j] = qk[j];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) qo[3 + j] = qb[j];
+    }
+    __syncthreads();
+    REFINE_STAMP(3);
+    // ---- B: T = Q~^T Q~ and Q~^T r ---------------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int it = tid; it < K * 39; it += 256) {   // keypoint blocks: T_kk (9), T_kb (27), q_k^T r (3); rows in list order
+        const int k = it / 39, v = it - 39 * k;
+        const int i = v < 9 ? v / 3 : (v < 36 ? (v - 9) / 9 : v - 36);
+        const int jb = v < 9 ? v % 3 : (v < 36 ? 3 + (v - 9) % 9 : -1);
+        double acc = 0.0;
+        const double* bbase = jb >= 0 ? q + jb : xr + 6;   // (one address computation, no branch per operand)
+        const int bstride = jb >= 0 ? QS : 7;
+        const int e0 = sRange[k].x - p0, e1 = sRange[k].y - p0;
+#pragma unroll 1
+        for (int e = e0; e < e1; e += 4) {   // (four rows' operands in flight; rows summed in list order)
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = e + u < e1;
+                const int lp = sList[ok ? e + u : e0];
+                const double a0 = q[lp * QS + i];
+                const double b0 = bbase[lp * bstride];
+                av[u] = ok ? a0 : 0.0;
+                bv[u] = b0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += av[u] * bv[u];
+        }
+        if (v < 36) sT[36 * k + v] = acc; else sYr[9 + 3 * k + i] = acc;   // (the reciprocals kept there were phase A's: dead behind its barrier)
+    }
+    REFINE_STAMP(4);
+    // border: T_bb (45 distinct entries) and q_b^T r (9): thread = (value, quarter of the rows), eight rows in flight
+    double bsum = 0.0;
+    const int bval = tid % 54, bpart = tid / 54;   // (threads 216..255 idle)
+    {
+        int c1 = 0, c2 = 0;
+        if (bval < 45) { int rem = bval; while (rem >= 9 - c1) { rem -= 9 - c1; ++c1; } c2 = c1 + rem; } else { c1 = bval - 45; c2 = -1; }
+        const int per = (m + 3) / 4, l0 = bpart * per, l1 = (l0 + per < m) ? l0 + per : m;
+        const double* bbase = c2 >= 0 ? q + 3 + c2 : xr + 6;
+        const int bstride = c2 >= 0 ? QS : 7;
+        if (bpart < 4) {
+#pragma unroll 1
+            for (int l = l0; l < l1; l += 8) {
+                double av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = l + u < l1;
+                    const int lp = ok ? l + u : l0;
+                    const double a0 = q[lp * QS + 3 + c1];
+                    const double b0 = bbase[lp * bstride];
+                    av[u] = ok ? a0 : 0.0;
+                    bv[u] = b0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bsum += av[u] * bv[u];
+            }
+        }
+    }
+    if (bpart < 4) sPartR[bpart][bval] = bsum;
+    __syncthreads();
+    if (tid < 54) {
+        const double sres = (sPartR[0][tid] + sPartR[1][tid]) + (sPartR[2][tid] + sPartR[3][tid]);
+        if (tid < 45) {
+            int c1 = 0, rem = tid;
+            while (rem >= 9 - c1) { rem -= 9 - c1; ++c1; }
+            const int c2 = c1 + rem;
+            sT[36 * Kmax + 9 * c1 + c2] = sres;
+            sT[36 * Kmax + 9 * c2 + c1] = sres;
+        } else {
+            sYr[tid - 45] = sres;
+        }
+    }
+    __syncthreads();
+    REFINE_STAMP(5);
+    // ---- C: Y[:, col] from the rows, then Y'' = 1.5 Y - 0.5 T Y ----------------------------------------------------------------
+    double* Yo = Y + (size_t)o * NOP * NAP;
+    const double* Tb = sT + 36 * Kmax;
+#pragma unroll 1
+    for (int col = tid; col < NAP; col += 256) {
+        if (col > NA) {
+            for (int i = 0; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;
+            continue;
+        }
+        const bool rcol = col == NA;
+        const int c = (!rcol && col >= a.cb0 && col < a.cb0 + 6 * a.N) ? (col - a.cb0) / 6 : -1;
+        const int e = c >= 0 ? col - a.cb0 - 6 * c : 6;
+        const int2 gr = c >= 0 ? sGrp[c] : int2{0, 0};
+        double yb[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) yb[j] = rcol ? sYr[j] : 0.0;
+#pragma unroll 1
+        for (int l = gr.x; l < gr.y; l += 2) {   // (two rows in flight)
+            double x[2], qv[2][9];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool ok = l + u < gr.y;
+                const int lp = ok ? l + u : gr.x;
+                const double x0 = xr[lp * 7 + e];
+                x[u] = ok ? x0 : 0.0;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) qv[u][j] = q[lp * QS + 3 + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) yb[j] += qv[u][j] * x[u];
+            }
+        }
+        double tb[9];
+#pragma unroll
+        for (int c1 = 0; c1 < 9; ++c1) {
+            double t = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < 9; ++c2) t += Tb[9 * c1 + c2] * yb[c2];
+            tb[c1] = t;
+        }
+#pragma unroll 1
+        for (int kc = 0; kc < K; kc += 4) {
+            double yk[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) yk[u][j] = (rcol && kc + u < K) ? sYr[9 + 3 * (kc + u) + j] : 0.0;
+            }
+#pragma unroll 1
+            for (int l = gr.x; l < gr.y; l += 4) {   // (four rows in flight; a row adds to the slot of its keypoint, if that is one of these four)
+                int kq[4];
+                double q0[4], q1[4], q2[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const bool ok = l + w < gr.y;
+                    const int lp = ok ? l + w : gr.x;
+                    const int kv = sK[lp];
+                    kq[w] = ok ? kv - kc : -1;
+                    const double x = xr[lp * 7 + e];
+                    q0[w] = q[lp * QS] * x; q1[w] = q[lp * QS + 1] * x; q2[w] = q[lp * QS + 2] * x;
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool hit = kq[w] == u;
+                        yk[u][0] += hit ? q0[w] : 0.0; yk[u][1] += hit ? q1[w] : 0.0; yk[u][2] += hit ? q2[w] : 0.0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kc + u;
+                if (k < K) {
+                    const double* Tk = sT + 36 * k;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        double t = (Tk[3 * j] * yk[u][0] + Tk[3 * j + 1] * yk[u][1]) + Tk[3 * j + 2] * yk[u][2];
+#pragma unroll
+                        for (int c2 = 0; c2 < 9; ++c2) t += Tk[9 + 9 * j + c2] * yb[c2];
+                        Yo[(size_t)(9 + 3 * k + j) * NAP + col] = 1.5 * yk[u][j] - 0.5 * t;
+                    }
+#pragma unroll
+                    for (int c2 = 0; c2 < 9; ++c2) tb[c2] += (Tk[9 + c2] * yk[u][0] + Tk[18 + c2] * yk[u][1]) + Tk[27 + c2] * yk[u][2];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) Yo[(size_t)j * NAP + col] = 1.5 * yb[j] - 0.5 * tb[j];
+        for (int i = 9 + 3 * K; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;
+    }
+    REFINE_STAMP(6);
+}
+// sDyn: [factor (arrow_stride) | T (arrow_stride) | Q~^T r (NOP) | row staging (lds_rows * OBJ_REFINE_ROW_DOUBLES)]; the factor is in place.
+// Returns true if the object was refined (uniform over the workgroup).
+__device__ __forceinline__ bool obj_refine_if_needed(const int o, const ObjArrow ob, const int Kmax, double* __restrict__ sDyn,
+                                                     const RefineArgs& a, double* __restrict__ Y, int NOP, int NAP, int NA) {
+    __shared__ double sCond[1];
+    const int astr = arrow_stride(Kmax);
+    double* sR = sDyn;
+    double* sT = sDyn + astr;
+    double* sYr = sT + astr;
+    double* sRows = sYr + NOP;
+    if (a.mode != 2) {
+        const double c2 = obj_arrow_cond2(sR, sT, sCond, ob.K, Kmax);
+        if (!(c2 > OBJ_REFINE_COND * OBJ_REFINE_COND)) return false;   // (NaN: the fast route's result stands)
+        __syncthreads();   // (sT is rewritten)
+    }
+    if (threadIdx.x == 0 && a.refined) atomicAdd(a.refined, 1);
+    if (ob.rows <= a.lds_rows) obj_refine_body<true>(o, ob, Kmax, sR, sT, sYr, sRows, a, Y, NOP, NAP, NA);
+    else obj_refine_body<false>(o, ob, Kmax, sR, sT, sYr, a.scratch + (size_t)ob.row0 * OBJ_REFINE_ROW_DOUBLES, a, Y, NOP, NAP, NA);
+    return true;
+}
+// The stand-alone launch (windows wider than 256 columns, where border QR and substitution are separate launches): one workgroup per
+// object, over the Y the substitution wrote.
+__global__ __launch_bounds__(256) void k_obj_refine(const ObjArrow* __restrict__ objs, int Kmax, const double* __restrict__ Rarrow, RefineArgs a,
+                                                    double* __restrict__ Y, int NOP, int NAP, int NA) {
+    extern __shared__ double sRef[];
+    const int o = blockIdx.x, astr = arrow_stride(Kmax);
+    const double* Ro = Rarrow + (size_t)o * astr;
+    for (int i = threadIdx.x; i < astr; i += 256) sRef[i] = Ro[i];
+    __syncthreads();
+    obj_refine_if_needed(o, objs[o], Kmax, sRef, a, Y, NOP, NAP, NA);
+}
+
 // Border QR, Y = R^-T C and sum_o B_o in ONE launch (windows with NAP <= 256: one solve workgroup per object).  Workgroup o < nobj:
 // the nine border reflectors of object o, then -- R_b and H_f^T r of the object are this workgroup's own writes -- the forward
 // substitution; the others: the sum of the clone tiles.  |r|^2 summed over all (object, clone) tiles by the workgroup that owns the
@@ -2997,12 +3387,28 @@ __global__ __launch_bounds__(256) void k_obj_border_solve_assemble(const ObjArro
                                                                    double* __restrict__ Rarrow, const double* __restrict__ Hr,
                                                                    const double* __restrict__ Sg, int N, int NOP, double* __restrict__ Hfr,
                                                                    const double* __restrict__ Cd, int NAP, int NA, double* __restrict__ Y,
-                                                                   int* __restrict__ info, int nobj, int cb0, double* __restrict__ Bdst) {
-    extern __shared__ double sR[];   // arrow_stride(Kmax) doubles (solve role)
+                                                                   int* __restrict__ info, int nobj, int cb0, double* __restrict__ Bdst, RefineArgs ra) {
+    extern __shared__ double sR[];   // arrow_stride(Kmax) doubles (solve role) [+ the scratch of obj_refine_if_needed when ra.mode != 0]
     int b = blockIdx.x;
     if (b < nobj) {
+        if (ra.stamps && b == 0 && threadIdx.x == 0) ra.stamps[7] = wall_clock64();
         obj_border_qr_body<RPT>(b, objs, Bred, Kmax, Rarrow, Hr, Sg, N, NOP, Hfr, sR);
         __syncthreads();   // (R_b and the tolerance in LDS; drains this workgroup's stores of H_f^T r)
+        if (ra.stamps && b == 0 && threadIdx.x == 0) ra.stamps[0] = wall_clock64();
+        // an ill-conditioned Hf takes Y from the explicit basis (and counts its dropped pivots like the substitution would)
+        if (ra.mode != 0 && obj_refine_if_needed(b, objs[b], Kmax, sR, ra, Y, NOP, NAP, NA)) {
+            if (threadIdx.x == 0 && info) {
+                const ObjArrow ob = objs[b];
+                const double tol = sR[36 * Kmax + 81];
+                int dropped = 0;
+                for (int e = 0; e < 3 * ob.K + 9; ++e) {
+                    const double pv = e < 3 * ob.K ? sR[36 * (e / 3) + 13 * (e % 3)] : sR[36 * Kmax + 10 * (e - 3 * ob.K)];
+                    dropped += fabs(pv) > tol ? 0 : 1;
+                }
+                if (dropped > 0) atomicAdd(info, dropped);
+            }
+            return;
+        }
         obj_arrow_solve_body(sR, b, (int)threadIdx.x, objs, Rarrow, Kmax, Cd, NOP, NAP, NA, Hfr, Y, info, true);
         return;
     }
@@ -3021,280 +3427,6 @@ __global__ __launch_bounds__(256) void k_obj_border_solve_assemble(const ObjArro
         }
     }
     obj_assemble_B_body(b * 256 + (int)threadIdx.x, Sg, nobj, N, nullptr, 0, cb0, NA, NAP, Bdst, corner_block ? sCorner : nullptr);
-}
-
-// ---- ill-conditioned Hf: the projection redone with an explicit basis (k_obj_refine) ----------------------------------------
-// Y = Q1^T X is what the Schur complement A' = B - Y^T Y needs (Q1 = an orthonormal basis of range(Hf), X = [Hx | r]).  The launches
-// above take it from the semi-normal equations, Y = R^-T (Hf^T X): the rounding of the products Hf^T X (eps |Hf| |X|) is divided by
-// the small pivots of R, an error of cond(Hf) eps in Y -- 3e-8 on the reference's own one_car frames (cond(Hf) = 3e8: the gauge of
-// the keypoint rows), which the update amplifies to 1.4e-6 in delta_x at a large prior (profiles/r3_conditioning.json) where the
-// reference's full-U SVD (math_utils.hpp:287-312) keeps 4e-10.  The subtraction B - Y^T Y itself is NOT the problem (measured: with
-// Y from explicit Householder reflectors the same subtraction reaches 4e-10).
-// For an object whose factor R has |R|_F |R^-1|_F above 3e6 (formed below: between cond(Hf) and 45 cond(Hf)) this kernel therefore forms the basis EXPLICITLY, row by row,
-//     q_i R = h_i   (a backward-stable triangular solve: Q~ R = Hf + E, |E| <= c eps |Q~| |R| -- the backward error of a Householder QR)
-// and takes Y = Q~^T X directly from the rows (no product with Hf, nothing divided by a small pivot afterwards).  Q~ spans range(Hf)
-// to that backward error but is orthonormal only to cond * eps: T = Q~^T Q~ = I + D.  The projector onto its range is Q~ T^-1 Q~^T,
-// so A' = B - Y^T T^-1 Y = B - Y''^T Y'' with Y'' = (I - D/2) Y = 1.5 Y - 0.5 T Y up to D^2 (< 1e-10 even at the pivot tolerance).
-// Both Q~ and T keep the arrow shape of Hf, so everything is 12 numbers per row.  One 256-thread workgroup per object:
-//   A  q_i for every row (thread per row): [3 keypoint entries | 9 border entries], kept in Qt [row][16] with the row's keypoint index
-//   B  T (per keypoint 3 x 3 and 3 x 9, border 9 x 9) and Q~^T r -- fixed summation orders (deterministic)
-//   C  thread per window column: Y[:, col] from the rows of the column's clone, then the correction; written over the object's Y
-// Objects below the threshold leave after reading their pivots (mode 1, the default); mode 2 refines every object.
-#define OBJ_REFINE_COND 3e6
-__global__ __launch_bounds__(256) void k_obj_refine(const ObjArrow* __restrict__ objs, const int2* __restrict__ kp_range,
-                                                    const int* __restrict__ kp_rows, const ObjGroup* __restrict__ groups, int ngroups,
-                                                    const int* __restrict__ ridx, const double* __restrict__ Hx6,
-                                                    const double* __restrict__ HfR, int ldf, int no_max, int Kmax,
-                                                    const double* __restrict__ Rarrow, double* __restrict__ Qt, double* __restrict__ Y,
-                                                    int NOP, int NAP, int NA, int cb0, int N, int mode, int* __restrict__ refined) {
-    extern __shared__ double sRef[];   // [arrow factor | T in the same layout (36 per keypoint, 81 border) | Q~^T r (NOP)]
-    __shared__ int2 sRange[36];
-    __shared__ int2 sGrp[ORCVIO_MAX_CLONES];
-    __shared__ double sPart[4][54];
-    __shared__ double sMinMax[2];
-    const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const ObjArrow ob = objs[o];
-    const int K = ob.K, astr = arrow_stride(Kmax);
-    double* sR = sRef;
-    double* sT = sRef + astr;
-    double* sYr = sT + astr;
-    const double* Ro = Rarrow + (size_t)o * astr;
-    for (int i = tid; i < astr; i += 256) sR[i] = Ro[i];
-    if (tid <= K) sRange[tid] = kp_range[ob.kp_off + tid];
-    if (tid < ORCVIO_MAX_CLONES) sGrp[tid] = int2{0, 0};
-    __syncthreads();
-    const double tol = sR[36 * Kmax + 81];
-    if (mode != 2) {
-        // Condition estimate of the factor: cond_F = |R|_F |R^-1|_F (between cond_2 and 45 cond_2).  The diagonal of an unpivoted
-        // R says nothing (one_car: pivot ratio 5e-4 at cond 3e8), so the inverse is formed -- 12 numbers per keypoint with the arrow
-        // shape: R^-1 = [[R_kk^-1, -R_kk^-1 R_kb R_b^-1], [0, R_b^-1]].  Dropped pivots (zero columns of Q~) are left out.
-        const double* Rb0 = sR + 36 * Kmax;
-        double* sInv = sT;   // (T is not there yet: its first 81 doubles hold R_b^-1 for the estimate)
-        if (tid < 9) {
-            double x[9];
-#pragma unroll
-            for (int i = 8; i >= 0; --i) {
-                double t = (i == tid) ? 1.0 : 0.0;
-#pragma unroll
-                for (int m = 0; m < 9; ++m)
-                    if (m > i) t -= Rb0[9 * i + m] * x[m];
-                const double pv = Rb0[9 * i + i];
-                x[i] = fabs(pv) > tol ? t / pv : 0.0;
-            }
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sInv[9 * i + tid] = x[i];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            double nr = 0.0, ni = 0.0;
-            if (lane < K) {
-                const double* Rk = sR + 36 * lane;
-                double inv[3][3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {   // column j of R_kk^-1
-#pragma unroll
-                    for (int i = 2; i >= 0; --i) {
-                        double t = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-                        for (int m = 0; m < 3; ++m)
-                            if (m > i) t -= Rk[12 * i + m] * inv[m][j];
-                        const double pv = Rk[12 * i + i];
-                        inv[i][j] = fabs(pv) > tol ? t / pv : 0.0;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    double w[9];
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) {
-                        w[c] = (inv[i][0] * Rk[3 + c] + inv[i][1] * Rk[15 + c]) + inv[i][2] * Rk[27 + c];
-                        nr += Rk[12 * i + 3 + c] * Rk[12 * i + 3 + c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int m = 0; m < 9; ++m)
-                            if (m <= c) v += w[m] * sInv[9 * m + c];
-                        ni += v * v;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { ni += inv[i][j] * inv[i][j]; if (j >= i) nr += Rk[12 * i + j] * Rk[12 * i + j]; }
-                }
-            }
-            for (int e = lane; e < 81; e += 64) { nr += Rb0[e] * Rb0[e]; ni += sInv[e] * sInv[e]; }   // (below the diagonal both hold zeros)
-            nr = wave_sum_dpp(nr);
-            ni = wave_sum_dpp(ni);
-            if (lane == 0) { sMinMax[0] = nr; sMinMax[1] = ni; }
-        }
-        __syncthreads();
-        const double condF2 = sMinMax[0] * sMinMax[1];
-        if (!(condF2 > OBJ_REFINE_COND * OBJ_REFINE_COND)) return;   // (workgroup-uniform; NaN -> the fast route's result stands)
-        __syncthreads();   // (sInv = sT is rewritten below)
-    }
-    if (tid == 0 && refined) atomicAdd(refined, 1);
-    for (int g = tid; g < ngroups; g += 256) {
-        const ObjGroup q = groups[g];
-        if (q.obj == o) sGrp[q.clone] = int2{q.r0, q.r1};
-    }
-    // ---- A: the rows of Q~ -------------------------------------------------------------------------------------------------
-    const int p0 = sRange[0].x, p1 = sRange[K].y;   // (the K + 1 row lists of an object are contiguous in kp_rows)
-    const double* Rb = sR + 36 * Kmax;
-    for (int p = p0 + tid; p < p1; p += 256) {
-        int k = 0;
-        while (k < K && p >= sRange[k].y) ++k;
-        const int row = kp_rows[p];
-        const double* h = HfR + (size_t)row * ldf;
-        double hb[9], qk[3] = {0.0, 0.0, 0.0}, qb[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) hb[c] = h[c];
-        const double res = h[no_max];
-        if (k < K) {
-            const double* Rk = sR + 36 * k;
-            double hk[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) hk[j] = h[9 + 3 * k + j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double t = hk[j];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    if (i < j) t -= qk[i] * Rk[12 * i + j];
-                const double pv = Rk[12 * j + j];
-                qk[j] = fabs(pv) > tol ? t / pv : 0.0;
-            }
-#pragma unroll
-            for (int c = 0; c < 9; ++c) hb[c] -= (qk[0] * Rk[3 + c] + qk[1] * Rk[15 + c]) + qk[2] * Rk[27 + c];
-        }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            double t = hb[j];
-#pragma unroll
-            for (int i = 0; i < 9; ++i)
-                if (i < j) t -= qb[i] * Rb[9 * i + j];
-            const double pv = Rb[9 * j + j];
-            qb[j] = fabs(pv) > tol ? t / pv : 0.0;
-        }
-        double* q = Qt + (size_t)row * 16;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) q[j] = qk[j];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) q[3 + j] = qb[j];
-        q[12] = (double)k;
-        q[13] = res;
-    }
-    __syncthreads();   // (the rows of Qt are read by other threads of this workgroup below)
-    // ---- B: T = Q~^T Q~ and Q~^T r ---------------------------------------------------------------------------------------------
-    for (int it = tid; it < K * 39; it += 256) {   // keypoint blocks: T_kk (9), T_kb (27), q_k^T r (3); rows in list order
-        const int k = it / 39, v = it - 39 * k;
-        const int i = v < 9 ? v / 3 : (v < 36 ? (v - 9) / 9 : v - 36);
-        const int jb = v < 9 ? v % 3 : (v < 36 ? 3 + (v - 9) % 9 : 13);
-        double acc = 0.0;
-        for (int p = sRange[k].x; p < sRange[k].y; ++p) {
-            const double* q = Qt + (size_t)kp_rows[p] * 16;
-            acc += q[i] * q[jb];
-        }
-        if (v < 36) sT[36 * k + v] = acc; else sYr[9 + 3 * k + i] = acc;
-    }
-    {   // border: T_bb (45 distinct entries) and q_b^T r (9), every thread a slice of the rows
-        double acc[54];
-#pragma unroll
-        for (int v = 0; v < 54; ++v) acc[v] = 0.0;
-        for (int p = p0 + tid; p < p1; p += 256) {
-            const double* q = Qt + (size_t)kp_rows[p] * 16;
-            double qb[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) qb[j] = q[3 + j];
-            const double res = q[13];
-            int v = 0;
-#pragma unroll
-            for (int a = 0; a < 9; ++a) {
-#pragma unroll
-                for (int b = a; b < 9; ++b) acc[v++] += qb[a] * qb[b];
-            }
-#pragma unroll
-            for (int a = 0; a < 9; ++a) acc[45 + a] += qb[a] * res;
-        }
-#pragma unroll
-        for (int v = 0; v < 54; ++v) acc[v] = wave_sum_dpp(acc[v]);
-        if (lane == 0) {
-#pragma unroll
-            for (int v = 0; v < 54; ++v) sPart[wave][v] = acc[v];
-        }
-    }
-    __syncthreads();
-    if (tid < 54) {
-        const double s = (sPart[0][tid] + sPart[1][tid]) + (sPart[2][tid] + sPart[3][tid]);
-        if (tid < 45) {
-            int a = 0, rem = tid;
-            while (rem >= 9 - a) { rem -= 9 - a; ++a; }
-            const int b = a + rem;
-            sT[36 * Kmax + 9 * a + b] = s;
-            sT[36 * Kmax + 9 * b + a] = s;
-        } else {
-            sYr[tid - 45] = s;
-        }
-    }
-    __syncthreads();
-    // ---- C: Y[:, col] from the rows, then Y'' = 1.5 Y - 0.5 T Y ----------------------------------------------------------------
-    double* Yo = Y + (size_t)o * NOP * NAP;
-    const double* Tb = sT + 36 * Kmax;
-    for (int col = tid; col < NAP; col += 256) {
-        if (col > NA) {
-            for (int i = 0; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;
-            continue;
-        }
-        const bool rcol = col == NA;
-        double yb[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) yb[j] = rcol ? sYr[j] : 0.0;
-        if (!rcol) {
-            for (int i = 9; i < 9 + 3 * K; ++i) Yo[(size_t)i * NAP + col] = 0.0;
-            const int c = (col >= cb0 && col < cb0 + 6 * N) ? (col - cb0) / 6 : -1;
-            if (c >= 0) {
-                const int e = col - cb0 - 6 * c;
-                const int2 gr = sGrp[c];
-                for (int qi = gr.x; qi < gr.y; ++qi) {
-                    const int row = ridx[qi];
-                    const double x = Hx6[(size_t)row * 6 + e];
-                    const double* q = Qt + (size_t)row * 16;
-                    const int k = (int)q[12];
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) yb[j] += q[3 + j] * x;
-                    if (k < K) {
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) Yo[(size_t)(9 + 3 * k + j) * NAP + col] += q[j] * x;
-                    }
-                }
-            }
-        }
-        double tb[9];
-#pragma unroll
-        for (int a = 0; a < 9; ++a) {
-            double t = 0.0;
-#pragma unroll
-            for (int b = 0; b < 9; ++b) t += Tb[9 * a + b] * yb[b];
-            tb[a] = t;
-        }
-        for (int k = 0; k < K; ++k) {
-            const double* Tk = sT + 36 * k;
-            double yk[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) yk[j] = rcol ? sYr[9 + 3 * k + j] : Yo[(size_t)(9 + 3 * k + j) * NAP + col];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double t = (Tk[3 * j] * yk[0] + Tk[3 * j + 1] * yk[1]) + Tk[3 * j + 2] * yk[2];
-#pragma unroll
-                for (int c2 = 0; c2 < 9; ++c2) t += Tk[9 + 9 * j + c2] * yb[c2];
-                Yo[(size_t)(9 + 3 * k + j) * NAP + col] = 1.5 * yk[j] - 0.5 * t;
-            }
-#pragma unroll
-            for (int c2 = 0; c2 < 9; ++c2) tb[c2] += (Tk[9 + c2] * yk[0] + Tk[18 + c2] * yk[1]) + Tk[27 + c2] * yk[2];
-        }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) Yo[(size_t)j * NAP + col] = 1.5 * yb[j] - 0.5 * tb[j];
-        for (int i = 9 + 3 * K; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;
-    }
 }
 
 // Test hook (tests/test_gpu_robustness.py): hold `gridDim.x` compute units for `ticks` of the 100 MHz wall clock (every
