@@ -79,19 +79,34 @@ def ship_unique_id(capi, rank, world):
         return capi.comm_unique_id(), None
     tag = '%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'))
     path = os.path.join(tempfile.gettempdir(), f'orcvio_bench_comm_id_{tag}')
+    # A file older than the launcher of THIS run is a leftover of a crashed run with the same tag: rank 0 removes it,
+    # the others never accept it.  The file is created exclusively (no following of a planted link) with owner-only permissions.
+    try:
+        import psutil
+        born = psutil.Process(os.getppid()).create_time() - 1.0
+    except Exception:
+        born = time.time() - 600.0
     if rank == 0:
         uid = capi.comm_unique_id()
-        with open(path + '.part', 'wb') as f:
+        for stale in (path, path + '.part'):
+            try:
+                os.unlink(stale)
+            except FileNotFoundError:
+                pass
+        fd = os.open(path + '.part', os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, 'wb') as f:
             f.write(uid)
         os.replace(path + '.part', path)
         return uid, path
     t0 = time.time()
     while True:
         try:
-            with open(path, 'rb') as f:
-                uid = f.read()
-            if len(uid) == capi.COMM_ID_BYTES:
-                return uid, None
+            st = os.lstat(path)
+            if st.st_mtime >= born and st.st_uid == os.getuid():
+                with open(path, 'rb') as f:
+                    uid = f.read()
+                if len(uid) == capi.COMM_ID_BYTES:
+                    return uid, None
         except FileNotFoundError:
             pass
         if time.time() - t0 > 180:

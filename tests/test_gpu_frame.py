@@ -69,6 +69,37 @@ def test_frame_equals_the_two_calls_and_the_oracle(upd, N, F, nobj, new_bbox):
     assert rel(o1['dx'], ref2['dx']) < TOL and rel(P1, ref2['P_new']) < TOL
 
 
+@pytest.mark.parametrize('case', ['unfused_front', 'many_tracks', 'leg46_wide', 'no_tracks'])
+def test_frame_when_the_feature_half_assembles_A_in_memory(upd, case):
+    """the overlapped frame compresses the objects into the handle's A block on a second stream, which is a race
+    whenever the feature half itself writes and reads that block (ORCVIO_OPT_FUSED_FRONT = 0, more tracks than the fused front end
+    holds, NA > 192, no tracks at all).  Those frames now run their halves in sequence: bit for bit the two calls, ten times over."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0, leg_dim=46 if case == 'leg46_wide' else 22)
+    N, F = {'unfused_front': (12, 90), 'many_tracks': (12, 1100), 'leg46_wide': (28, 60), 'no_tracks': (10, 0)}[case]
+    win = synth.make_window(N=N, F=max(F, 4), seed=5, flags=flags, track_len=(3, min(N, 8)), outlier_frac=0.05)
+    objs = synth.make_objects(win, n_objects=3, seed=2, sigma_kp=0.004)
+    if F == 0:
+        win = dataclasses.replace(win, p_w=win.p_w[:0], obs_ptr=win.obs_ptr[:1], obs_clone=win.obs_clone[:0], obs_z=win.obs_z[:0], obs_zvel=win.obs_zvel[:0])
+    if case == 'unfused_front':
+        upd.set_fused_front(False)
+    try:
+        upd.cov_set(win.P)
+        f0, o0 = _two_calls(upd, win, objs)
+        P0 = upd.cov_get()
+        for _ in range(10):
+            upd.cov_set(win.P)
+            f1, o1 = _frame(upd, win, objs)
+            assert _same(f1['dx'], f0['dx']) and _same(f1['accept'], f0['accept'])
+            assert o1['accept'] == o0['accept'] and _same(o1['dx'], o0['dx']) and _same(o1['gamma'], o0['gamma'])
+            assert _same(upd.cov_get(), P0)
+    finally:
+        upd.set_fused_front(True)
+    if F > 0:
+        ref1 = oracle.msckf_update(win, want_blocks=False, want_K=False)
+        ref2 = objects_update_reference(win, objs, ref1['P_new'], True, False, 0)
+        assert rel(f0['dx'], ref1['dx']) < TOL and o0['accept'] == ref2['accept'] and rel(o0['dx'], ref2['dx']) < TOL
+
+
 def test_frames_in_a_row(upd):
     """six frames on the covariance the previous one left (the launch-graph cache replays the feature half; the spare factor
     buffer alternates): every frame equals the two calls"""
