@@ -174,13 +174,15 @@ class SlamFeature:
     p_fej: np.ndarray = None
 
 
-def make_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_frac: float = 0.0, nui_frac: float = 0.0):
+def make_slam_features(win: "Window", n_feat: int, seed: int = 0, outlier_frac: float = 0.0, nui_frac: float = 0.0,
+                       sigma_px: float | None = None):
     """n_feat SLAM features anchored at random earlier clones and observed by the newest one (+ pixel noise; a
     fraction with gross errors that the 2-dof gate rejects).  nui_frac: fraction anchored at a Schmidt nuisance state
-    (anchor index N + j, win.nui)."""
+    (anchor index N + j, win.nui).  sigma_px: the observation noise if it is not the filter's noise_feature (kitti_raw.yaml sets
+    noise_feature 1 on normalised coordinates)."""
     rng = np.random.default_rng(20_000 + seed)
     k = win.N - 1
-    sig = win.flags.noise_feature
+    sig = win.flags.noise_feature if sigma_px is None else sigma_px
     out = []
     for _ in range(n_feat):
         a = int(rng.integers(0, win.N - 1))

@@ -55,17 +55,24 @@ def run(upd, win, slam, idp, on_device=False):
 @pytest.mark.parametrize('idp', [3, 1])
 @pytest.mark.parametrize('case', [dict(N=9, F=40, nf=6, flags={}), dict(N=14, F=90, nf=20, flags=dict(estimate_td=1)),
                                   dict(N=30, F=400, nf=12, flags={}), dict(N=8, F=0, nf=5, flags=dict(if_fej=1)),
-                                  dict(N=11, F=30, nf=9, flags=dict(if_fej=1, estimate_td=1))])
+                                  dict(N=11, F=30, nf=9, flags=dict(if_fej=1, estimate_td=1)),
+                                  # the OrcVIO Jacobians of the MSCKF rows beside the (always LARVIO-form) rows of the in-state features:
+                                  # kitti_raw.yaml's shipped set (:143-148: right perturbation, sigma 1) and the left-perturbation variant
+                                  dict(N=20, F=120, nf=12, flags=dict(use_larvio=0, use_left_perturbation=0, noise_feature=1.0, discard_large_update=1), sigma_px=0.008),
+                                  dict(N=12, F=60, nf=8, flags=dict(use_larvio=0, use_left_perturbation=1)),
+                                  dict(N=10, F=40, nf=7, flags=dict(use_larvio=0, use_left_perturbation=0, estimate_td=1)),
+                                  dict(N=10, F=40, nf=7, flags=dict(use_larvio=0, use_left_perturbation=1, if_fej=1))],
+                         ids=lambda c: 'N%d_F%d_%s' % (c['N'], c['F'], '_'.join('%s%s' % (k[:6], v) for k, v in c['flags'].items()) or 'larvio'))
 def test_joint_update_with_slam_rows(upd, idp, case, on_device):
-    fl = synth.Flags(use_larvio=1, **case['flags'])
+    fl = synth.Flags(**dict(dict(use_larvio=1), **case['flags']))
     w0 = synth.make_window(N=case['N'], F=case['F'], seed=31 + case['nf'], track_len=None if case['F'] == 400 else (3, min(case['N'], 9)),
-                           flags=fl)
-    slam = synth.make_slam_features(w0, case['nf'], seed=idp, outlier_frac=0.25)
+                           flags=fl, sigma_px=case.get('sigma_px'))
+    slam = synth.make_slam_features(w0, case['nf'], seed=idp, outlier_frac=0.25, sigma_px=case.get('sigma_px'))
     w = synth.with_extra_states(w0, idp * len(slam), seed=7)
     ref = mh.hybrid_update(w, slam, idp)
     got = run(upd, w, slam, idp, on_device)
     assert np.array_equal(got['ekf_accept'], ref['ekf_accept'])
-    assert 0 < ref['ekf_accept'].sum() < len(slam) or case['nf'] < 8   # the gate does both
+    assert 0 < ref['ekf_accept'].sum() < len(slam) or case['nf'] < 8 or fl.noise_feature == 1.0   # the gate does both (kitti_raw's sigma = 1 passes everything)
     assert rel(got['ekf_gamma'], ref['ekf_gamma']) < 1e-9
     assert np.array_equal(got['accept'], ref['accept'])
     assert rel(got['dx'], ref['dx']) < TOL
@@ -91,14 +98,19 @@ def test_anchor_equal_to_the_observing_state(upd):
     assert rel(got['P_new'], ref['P_new']) < TOL
 
 
+JAC = {'larvio': dict(use_larvio=1), 'orcvio_right': dict(use_larvio=0, use_left_perturbation=0), 'orcvio_left': dict(use_larvio=0, use_left_perturbation=1)}
+
+
+@pytest.mark.parametrize('jac', list(JAC))
 @pytest.mark.parametrize('idp', [3, 1])
-def test_frame_with_new_slam_features(upd, idp):
+def test_frame_with_new_slam_features(upd, idp, jac):
     """A frame in which NEW SLAM features enter the state, either parametrisation, through library calls only
     (INTEGRATION.md 7b): orcvio_msckf_gate_tracks (their MSCKF gate on the device), orcvio_msckf_new_feature_rows
     (featureJacobian_ekf_new and the W = [V | U] split, host arithmetic), the V-part rows as dense rows under the MSCKF
     tracks and the rows of the existing SLAM features in ONE device update, orcvio_msckf_augment_state for the H_1 / H_2
-    tail (src/orcvio.cpp:1811-1947).  Result: the reference's full hybrid update (oracle.hybrid_update_full)."""
-    w0 = synth.make_window(N=10, F=60, seed=17, track_len=(3, 10), flags=synth.Flags(use_larvio=1, estimate_td=1))
+    tail (src/orcvio.cpp:1811-1947).  Result: the reference's full hybrid update (oracle.hybrid_update_full).  Under each of the
+    three Jacobian conventions of the MSCKF rows (config/euroc.yaml:114-118, config/kitti_raw.yaml:143-148)."""
+    w0 = synth.make_window(N=10, F=60, seed=17, track_len=(3, 10), flags=synth.Flags(estimate_td=1, **JAC[jac]))
     slam = synth.make_slam_features(w0, 7, seed=5, outlier_frac=0.25)
     w = synth.with_extra_states(w0, idp * len(slam), seed=4)
     new = [mh.NewSlamFeature(**d) for d in synth.make_new_slam_features(w, 5, seed=9, outlier_frac=0.5)]
@@ -534,13 +546,15 @@ def test_reference_literal_h2_ldlt_for_new_features_listed_as_tracks(upd):
     assert rel(P_aug, lit['P_new']) < TOL
 
 
+@pytest.mark.parametrize('jac', ['larvio', 'orcvio_right', 'orcvio_left', 'kitti_raw'])
 @pytest.mark.parametrize('idp', [1, 3])
-def test_hybrid_update_through_the_in_place_call(upd, idp):
+def test_hybrid_update_through_the_in_place_call(upd, idp, jac):
     """The rows of the in-state features between orcvio_msckf_io_begin and orcvio_msckf_io_update: the hybrid update with the
     window written in place, the commit inside the launch and the results through the flag word -- equal to the staged form."""
-    fl = synth.Flags(use_larvio=1)
-    w0 = synth.make_window(N=20, F=120, seed=41, track_len=(3, 6), flags=fl, outlier_frac=0.05)
-    slam = synth.make_slam_features(w0, 12, seed=idp, outlier_frac=0.1)
+    # (kitti_raw: config/kitti_raw.yaml's shipped set -- OrcVIO right perturbation, noise_feature 1, discard flag on, :103, :143-158)
+    fl = synth.Flags(use_larvio=0, use_left_perturbation=0, noise_feature=1.0, discard_large_update=1) if jac == 'kitti_raw' else synth.Flags(**JAC[jac])
+    w0 = synth.make_window(N=20, F=120, seed=41, track_len=(3, 6), flags=fl, outlier_frac=0.05, sigma_px=0.008 if jac == 'kitti_raw' else None)
+    slam = synth.make_slam_features(w0, 12, seed=idp, outlier_frac=0.1, sigma_px=0.008 if jac == 'kitti_raw' else None)
     w = synth.with_extra_states(w0, idp * len(slam), seed=7)
     ref = mh.hybrid_update(w, slam, idp)
     staged = run(upd, w, slam, idp, True)
