@@ -48,6 +48,7 @@ static void so3_exp_decl(const double w[3], double R[9]);   // Sophus SO3d::exp 
 
 struct ObjUse { int t, row0, rows, ncol; size_t off_d, off_i; };   // a usable object track of the current object update
 
+struct IpcComm;
 struct orcvio_msckf_handle {
     int device = 0;
     int maxN = 0, maxF = 0, maxObs = 0;
@@ -188,6 +189,7 @@ struct orcvio_msckf_handle {
     // multi-GPU: RCCL communicator of this handle (orcvio_msckf_comm_init), the all-gather buffer [world][NAP_max^2] and
     // the gathered degrees of freedom of a sharded object update
     ncclComm_t comm = nullptr;
+    struct IpcComm* ipc = nullptr;      // the second transport (ORCVIO_COMM_TRANSPORT=ipc, capi_ipc.inc): shared memory + HIP IPC, ranks of one node
     int comm_rank = 0, comm_world = 0;
     double *d_gather = nullptr, *d_dofs = nullptr;
     hipStream_t comm_stream = nullptr;  // carries the early exchange of the degrees of freedom of a sharded object update
@@ -263,6 +265,7 @@ const char* orcvio_msckf_last_error(void) { return g_last_error.c_str(); }
 #include "capi_hybrid.inc"   // EKF-SLAM rows of the hybrid filter, features entering the state, the H_1 / H_2 tail
 #include "capi_io.inc"   // download, the zero-copy update (io_begin / io_update), the copying one-shot call, gate_tracks
 #include "capi_objects.inc"   // the object update: staging, compression pipeline, finish / download, ObjectLM messages, row evaluation
+#include "capi_ipc.inc"   // the second transport of the communicator: HIP IPC + shared memory (several ranks per device possible)
 #include "capi_comm.inc"   // the handle's RCCL communicator, bounded waits, the sharded updates
 #include "capi_cov.inc"   // per-kernel profile, the device-resident covariance and its square-root factor
 #include "capi_frame.inc"   // one frame in one call: feature update + object update, the objects' compression beside the features' solve

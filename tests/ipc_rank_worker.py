@@ -1,0 +1,123 @@
+"""One rank of the two-process test of the sharded entry points over the IPC transport (tests/test_gpu_ipc.py starts it twice on the
+ONE GPU of the box: ORCVIO_COMM_TRANSPORT=ipc, include/orcvio_msckf.h "Multi-GPU").  Started as a fresh process BEFORE anything has
+touched the GPU.  argv: rank world hex(id).  Prints one 'RESULT {json}' line; exit code 0 iff every check passed."""
+import dataclasses
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+
+from orcvio_amd import capi, sharding, synth
+from oracle import oracle
+from helpers import rel, objects_update_reference
+
+TOL = 1e-6
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    return h.hexdigest()[:16]
+
+
+def main():
+    rank, world, uid = int(sys.argv[1]), int(sys.argv[2]), bytes.fromhex(sys.argv[3])
+    out = dict(rank=rank, checks=[])
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    u.comm_init(uid, rank, world)
+    assert u.comm_info() == (rank, world)
+
+    def ok(name, cond, **extra):
+        out['checks'].append(dict(name=name, ok=bool(cond), **extra))
+
+    # ---- barrier and max over the ranks (host side of the transport)
+    u.comm_barrier()
+    v = u.comm_allreduce_max([float(rank), -float(rank), 3.5])
+    ok('allreduce_max', list(v) == [float(world - 1), 0.0, 3.5])
+
+    # ---- feature update: a 2 x 200-track window dealt over the ranks, against the single-call oracle (20 windows)
+    dig = []
+    for rep in range(20):
+        full = synth.make_window(N=12 + (rep % 5), F=200 * world, seed=100 + rep, track_len=(3, 9), outlier_frac=0.1)
+        share, _ = sharding.shard_window(full, rank, world)
+        ref = oracle.msckf_update(full, want_blocks=False, want_K=False)
+        got = u.update_features_sharded(share)
+        good = rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL and got['stats'][3] == 1
+        ok('features_%d' % rep, good, dx_err=rel(got['dx'], ref['dx']))
+        dig.append(digest(got['dx'], got['P_new']))
+    out['feature_digests'] = dig   # (the parent compares them across the ranks: rank-ordered sum -> identical bits everywhere)
+
+    # ---- the staged form, queued: four sharded updates in flight one behind the other (the two generations of slots)
+    full = synth.make_window(N=30, F=200 * world, seed=7, outlier_frac=0.05)
+    share, _ = sharding.shard_window(full, rank, world)
+    ref = oracle.msckf_update(full, want_blocks=False, want_K=False)
+    u.upload(share)
+    for _ in range(6):
+        u.run_update_sharded()
+    u.sync()
+    st = u.download()
+    ok('queued_staged', rel(st['dx'], ref['dx']) < TOL and rel(st['P_new'], ref['P_new']) < TOL, dx_err=rel(st['dx'], ref['dx']))
+    out['staged_digest'] = digest(st['dx'], st['P_new'])
+
+    # ---- a share whose tracks are ALL rejected by the gate (rank 1): its block is zero, the update is the other ranks'
+    full = synth.make_window(N=10, F=60 * world, seed=21, track_len=(3, 8))
+    idx = sharding.deal_features(full.obs_ptr, world)
+    z = full.obs_z.copy()
+    rng = np.random.default_rng(5)
+    for j in idx[world - 1]:   # gross errors (40 sigma, independent) on every observation of the last rank's tracks
+        z[full.obs_ptr[j]:full.obs_ptr[j + 1]] += 0.3 * rng.standard_normal((int(full.obs_ptr[j + 1] - full.obs_ptr[j]), 2))
+    full = dataclasses.replace(full, obs_z=z)
+    share, mine = sharding.shard_window(full, rank, world)
+    ref = oracle.msckf_update(full, want_blocks=False, want_K=False)
+    got = u.update_features_sharded(share)
+    ok('all_rejected_share', ref['accept'][idx[world - 1]].sum() == 0 and np.array_equal(got['accept'], ref['accept'][mine]) and
+       rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL)
+
+    # ---- a refused share: the last rank's index array is broken -> it returns ORCVIO_ERR_INVALID, everybody else ORCVIO_ERR_PEER
+    full = synth.make_window(N=8, F=20 * world, seed=4, track_len=(3, 8))
+    share, _ = sharding.shard_window(full, rank, world)
+    if rank == world - 1:
+        bad = share.obs_clone.copy()
+        bad[3] = 99
+        share = dataclasses.replace(share, obs_clone=bad)
+    code = 0
+    try:
+        u.update_features_sharded(share)
+    except capi.MsckfError as e:
+        code = e.code
+    ok('refused_share', code == (1 if rank == world - 1 else 8), code=code)
+    # ... and the communicator is still usable
+    full = synth.make_window(N=8, F=20 * world, seed=5, track_len=(3, 8))
+    share, _ = sharding.shard_window(full, rank, world)
+    ref = oracle.msckf_update(full, want_blocks=False, want_K=False)
+    got = u.update_features_sharded(share)
+    ok('after_refusal', rel(got['dx'], ref['dx']) < TOL)
+
+    # ---- object update: cars dealt round-robin, joint gate with the summed degrees of freedom
+    oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    owin = synth.make_window(N=12, F=4, seed=0, flags=oflags, track_len=4)
+    objs = synth.make_objects(owin, n_objects=5, seed=2, sigma_kp=0.004)
+    oref = objects_update_reference(owin, objs, owin.P, True, True, 0)
+    for rep in range(5):
+        got = u.update_object_tracks_sharded(oflags, owin.N, objs[rank::world], owin.P, owin.R_b2c[0], owin.t_c_b[0], True, True, 0)
+        ok('objects_%d' % rep, got['accept'] == oref['accept'] == 1 and abs(got['gamma'] - oref['gamma']) < 1e-6 * abs(oref['gamma']) and
+           rel(got['dx'], oref['dx']) < TOL and rel(got['P_new'], oref['P_new']) < TOL and got['stats'][0] == oref['dof'])
+    out['object_digest'] = digest(got['dx'], got['P_new'])
+    # ... one rank without any object
+    got = u.update_object_tracks_sharded(oflags, owin.N, objs if rank == 0 else [], owin.P, owin.R_b2c[0], owin.t_c_b[0], True, True, 0)
+    ok('objects_one_rank_empty', got['accept'] == oref['accept'] and rel(got['dx'], oref['dx']) < TOL)
+    u.comm_barrier()
+    u.close()
+    out['passed'] = all(c['ok'] for c in out['checks'])
+    print('RESULT ' + json.dumps(out), flush=True)
+    return 0 if out['passed'] else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())

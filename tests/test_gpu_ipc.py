@@ -1,0 +1,64 @@
+"""The sharded entry points with TWO RANKS on the one GPU of the test box: the handle's second transport
+(ORCVIO_COMM_TRANSPORT=ipc, csrc/capi_ipc.inc) -- every rank stores its compressed block straight into its peers' gather buffers
+(HIP IPC), flags in a shared-memory segment -- lets two processes share a device, which RCCL refuses.  Two fresh child processes
+(started before they touch the GPU; nothing is exec'ed afterwards) run tests/ipc_rank_worker.py: 20 sharded feature updates of a
+2 x 200-track window against the single-call oracle, six queued staged updates, an all-rejected share, a refused share
+(ORCVIO_ERR_INVALID on its rank, ORCVIO_ERR_PEER on the other), sharded object updates, barrier and max.  Both ranks must pass and
+return bit-identical results (rank-ordered sum, replicated solve)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(world, extra_env=None, timeout=900):
+    env = dict(os.environ, ORCVIO_COMM_TRANSPORT='ipc', ORCVIO_COMM_TIMEOUT_S='120', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(extra_env or {})
+    uid = os.urandom(128).hex()   # (what orcvio_msckf_comm_unique_id returns under this transport: 128 random bytes)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ipc_rank_worker.py'), str(r), str(world), uid],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, so, se))
+    return outs
+
+
+def test_two_ranks_on_one_device(built):
+    outs = _run_ranks(2)
+    res = []
+    for rc, so, se in outs:
+        lines = [ln for ln in so.splitlines() if ln.startswith('RESULT ')]
+        assert lines, (rc, so[-2000:], se[-3000:])
+        res.append(json.loads(lines[-1][7:]))
+    for r, (rc, so, se) in zip(res, outs):
+        failed = [c for c in r['checks'] if not c['ok']]
+        assert not failed and rc == 0 and r['passed'], (failed, se[-2000:])
+    assert len(res[0]['checks']) >= 30
+    # the replicated solve: every rank holds the same bits
+    assert res[0]['feature_digests'] == res[1]['feature_digests']
+    assert res[0]['staged_digest'] == res[1]['staged_digest']
+    assert res[0]['object_digest'] == res[1]['object_digest']
+
+
+def test_unique_id_of_the_ipc_transport(built):
+    """orcvio_msckf_comm_unique_id under ORCVIO_COMM_TRANSPORT=ipc: 128 random bytes (the name of the shared segment is derived from
+    them), no call into RCCL -- ORCVIO_RCCL_LIB points at nothing and the call still succeeds."""
+    code = ("import os, sys\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "from orcvio_amd import capi\n"
+            "a, b = capi.comm_unique_id(), capi.comm_unique_id()\n"
+            "assert len(a) == 128 and a != b\n"
+            "print('RESULT ok')\n")
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, ORCVIO_COMM_TRANSPORT='ipc', ORCVIO_RCCL_LIB='/nonexistent/librccl.so'), timeout=120)
+    assert 'RESULT ok' in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
