@@ -317,7 +317,7 @@ def stream_hybrid(upd, capi, synth, fl, sigma_px, label, frames=240, seed=0):
     assert P0.shape[0] == n18
     upd.set_extra_states(idp * n_slam)
     upd.set_ekf_rows_mode(True)
-    times, with_prune, n_upd, discards = [], [], 0, 0
+    times, with_prune, which, n_upd, discards = [], [], [], 0, 0
 
     def inplace(c, key, slam_call):
         win = c[key]
@@ -351,6 +351,7 @@ def stream_hybrid(upd, capi, synth, fl, sigma_px, label, frames=240, seed=0):
             if it >= 16:
                 times.append((time.perf_counter() - t) * 1e3)
                 with_prune.append(c['prune'] is not None)
+                which.append(it % len(cyc))
             if not np.all(np.isfinite(got)):
                 raise RuntimeError('non-finite dx in the stream')
         gc.enable()
@@ -368,8 +369,15 @@ def stream_hybrid(upd, capi, synth, fl, sigma_px, label, frames=240, seed=0):
         q = percentiles(ts)
         q['p95_over_median'] = q['p95_ms'] / q['median_ms']
         return q
+    # jitter proper: the SAME frame of the cycle (same tracks, same amount of work) repeated -- p95 / median per distinct frame
+    per_frame = {}
+    for t, k in zip(times, which):
+        per_frame.setdefault(k, []).append(t)
+    jitter = {str(k): round(percentiles(v)['p95_ms'] / percentiles(v)['median_ms'], 4) for k, v in sorted(per_frame.items())}
     return dict(p, frames_per_s=1e3 / p['mean_ms'], updates_per_frame=n_upd / (frames + 16), in_state_features=n_slam,
                 frames_with_prune_update=cls(tw), frames_without_prune_update=cls(tn), large_update_flags=discards,
+                p95_over_median_per_distinct_frame=jitter, worst_p95_over_median_same_frame=max(jitter.values()) if jitter else None,
+                tracks_per_frame=[int(c['w'].F) for c in cyc],
                 what=label + ': hybrid filter (12 in-state features, 1 parameter each), 19/20-clone window, 20-200 ragged tracks '
                      'per frame; per frame: propagate, augment, prefactor, hybrid update + commit (in place: orcvio_msckf_io_begin / _io_update), every second frame the prune update '
                      '+ commit + marginalisation of two clones; covariance resident in HBM; the C calls\' arguments are marshalled once per '
@@ -419,6 +427,8 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
+    if os.environ.get('ORCVIO_BENCH_ONE_DEVICE') == '1':   # every rank on device 0 (needs ORCVIO_COMM_TRANSPORT=ipc: RCCL refuses two ranks per
+        local_rank = 0                                     # device); exercises the N > 1 path on a one-GPU box -- not a scaling measurement
     torch.cuda.set_device(local_rank)
     # ORCVIO_BENCH_FORCE_DIST=1 drives the multi-GPU code path (communicator, all-gather) with world size 1
     use_dist = world > 1 or os.environ.get('ORCVIO_BENCH_FORCE_DIST') == '1'
