@@ -16,3 +16,6 @@ done
 # (GRBM_GUI_ACTIVE: summed over the 8 XCDs, MI355X_MICROARCH.md)
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_MFMA -o p -- python3 $ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_MFMA.log 2>&1
 find $OUT/${TAG}_trace $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_MFMA -name "*.csv" | head -20
+# the summaries (what gets committed under profiles/) next to the raw outputs; the raw traces are too large to travel back
+PROFILES_DST=$OUT/profiles_${TAG} python3 $ROOT/scripts/summarize_profiles.py ${TAG}
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_MFMA

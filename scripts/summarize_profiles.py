@@ -6,7 +6,8 @@ import csv, glob, json, os, shutil, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, 'gpurun_out')
-dst = os.path.join(ROOT, 'profiles')
+dst = os.environ.get('PROFILES_DST') or os.path.join(ROOT, 'profiles')   # (on the GPU box: a directory under gpurun_out/, the raw traces stay there)
+os.makedirs(dst, exist_ok=True)
 
 
 def find(pattern):
@@ -86,7 +87,8 @@ if os.path.exists(b) and os.path.getsize(b) > 10:
             obj = line.get('objects_update') or {}
             frames = {k: obj[k] for k in ('frame_config3', 'frame_config3_prefactored', 'frame_config3_one_call', 'frame_config3_one_call_prefactored') if k in obj}
             json.dump({'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'latency': line.get('latency'),
-                       'configs': line['configs'], 'config3_frame_legs': frames, 'stream_config1': line.get('stream_config1'),
+                       'configs': line['configs'], 'config3_frame_legs': frames, 'stream_config1': line.get('stream_config1'), 'stream_config5': line.get('stream_config5'),
+                       'sequential_updates_per_s': line.get('sequential_updates_per_s'), 'block_ms_per_step': line.get('block_ms_per_step'),
                        'cpu_baseline': line.get('cpu_baseline')}, open(os.path.join(dst, f'{tag}_configs.json'), 'w'), indent=1)
             print('configs ->', f'profiles/{tag}_configs.json')
     except Exception as e:
