@@ -123,6 +123,11 @@ typedef struct orcvio_msckf_result {
     double* r_thin;   /* [n-15]                                                              */
     double* K;        /* [n*(n-15)] row-major Kalman gain w.r.t. H_thin                       */
     double* G;        /* [n*n] row-major K*H_thin (basis independent, SURVEY.md note N1)      */
+    /* dx, P_out, gamma, accept and G are the results, accurate to ~1e-12 against the double restatement (bar: 1e-6).  H_thin,
+       r_thin and K are DIAGNOSTIC outputs: the update is computed in square-root form from the Gram block and never
+       needs them; they are derived afterwards from a Cholesky factor of the singular Gram with the shift above and reproduce
+       K * H_thin = G and K * r_thin = dx to ~1e-5 relative only (tests/test_gpu_parity.py).  K is basis dependent in any case
+       (SURVEY.md note N1): compare G, not K, across implementations. */
     int32_t stats[8]; /* [0] stacked rows (accepted)  [1] rows of H_thin  [2] accepted blocks
                          [3] 1 if an update was applied to P  [4] 1 if the reference's
                          large-update test (:4479) would discard delta_x  [5] zero-variance
