@@ -373,6 +373,28 @@ def test_explicit_basis_projection_on_every_object(upd, seed):
         assert not got['dx'].any()
 
 
+def test_explicit_basis_projection_in_a_wide_window(built):
+    """Windows wider than 256 active columns (N >= 42 clones at leg_dim 22) run border QR and substitution as separate launches, and the
+    explicit-basis projection as a third (k_obj_refine) over the Y the substitution wrote: every object through it, and the default
+    mode, against the mirror."""
+    u = capi.MsckfUpdater(device=0, max_clones=48, max_features=64, max_observations=1024)
+    try:
+        flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+        win = synth.make_window(N=44, F=4, seed=11, flags=flags, track_len=4)
+        objs = synth.make_objects(win, n_objects=3, seed=5, sigma_kp=0.004, frames_per_object=20)
+        ref = objects_update_reference(win, objs, win.P, True, False, 0, full_nullspace=True)
+        args = (flags, win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+        base = u.update_object_tracks(*args)
+        u.set_object_refine(2)
+        got = u.update_object_tracks(*args)
+        assert u.objects_refined() == len(ref['blocks']) == 3
+        for g in (base, got):
+            assert g['accept'] == ref['accept'] == 1
+            assert rel(g['dx'], ref['dx']) < TOL and rel(g['P_new'], ref['P_new']) < TOL
+    finally:
+        u.close()
+
+
 def test_object_gate_degrees_of_freedom_option(upd):
     """ORCVIO_OPT_OBJECT_DOF (VERDICT r2 'missing' 2): with a rank-deficient H_f the device projects onto the whole left null space
     (rows - rank directions); the default keeps the reference's count rows - columns for the threshold, the option counts
