@@ -373,6 +373,35 @@ def test_explicit_basis_projection_on_every_object(upd, seed):
         assert not got['dx'].any()
 
 
+def test_explicit_basis_projection_of_an_object_too_long_for_the_lds_staging(upd):
+    """An object of 16 keypoints seen in 30 frames has 1 080 rows: more than the LDS staging of the explicit-basis projection holds
+    (about 850), so its rows of Q~ go through global scratch (obj_refine_body<false>) -- same arithmetic, against the mirror; a 12-keypoint
+    car beside it takes the LDS staging in the same launch."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=30, F=4, seed=2, flags=flags, track_len=4)
+    objs = synth.make_objects(win, n_objects=2, seed=9, sigma_kp=0.004, missing_frac=0.0)
+    big = objs[0]
+    rng = np.random.default_rng(3)
+    extra = big.kps[:4] + np.array([0.2, -0.3, 0.25]) * rng.uniform(0.5, 1.0, (4, 3))
+    big.kps = np.vstack([big.kps, extra])
+    for fr in big.frames:   # observations of the new keypoints: the estimate's own projection + noise
+        X = (np.linalg.inv(fr['wTc']) @ big.wTo @ np.hstack([extra, np.ones((4, 1))]).T).T
+        fr['zs'] = np.vstack([fr['zs'], X[:, :2] / X[:, 2:3] + 0.004 * rng.standard_normal((4, 2))])
+    ref = objects_update_reference(win, objs, win.P, True, False, 0, full_nullspace=True)
+    assert ref['blocks'][0]['Hf'].shape == (30 * 36, 57)
+    args = (flags, win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+    base = upd.update_object_tracks(*args)
+    upd.set_object_refine(2)
+    try:
+        got = upd.update_object_tracks(*args)
+        assert upd.objects_refined() == 2
+    finally:
+        upd.set_object_refine(1)
+    for g in (base, got):
+        assert g['accept'] == ref['accept'] == 1
+        assert rel(g['dx'], ref['dx']) < TOL and rel(g['P_new'], ref['P_new']) < TOL
+
+
 def test_explicit_basis_projection_in_a_wide_window(built):
     """Windows wider than 256 active columns (N >= 42 clones at leg_dim 22) run border QR and substitution as separate launches, and the
     explicit-basis projection as a third (k_obj_refine) over the Y the substitution wrote: every object through it, and the default
