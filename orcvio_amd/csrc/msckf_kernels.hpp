@@ -3008,7 +3008,8 @@ __global__ __launch_bounds__(256) void k_obj_solve_assemble(int nb_solve, int so
 //   C  thread per window column: Y[:, col] from the rows of the column's clone, keypoints four at a time in registers, corrected and
 //      written over the object's block of Y
 #define OBJ_REFINE_COND 3e6
-#define OBJ_REFINE_ROW_DOUBLES 22   // per row of the staging: q 12 (+1 pad), [hx | r] 7, three ints (position, list entry, keypoint)
+#define OBJ_REFINE_ROW_DOUBLES 21   // per row of the staging: q 12 (+1 pad), [hx | r] 7, four 16-bit indices (position, list entry, keypoint, clone)
+#define OBJ_REFINE_SCRATCH 384      // doubles of static LDS the caller lends (partial tiles of T_bb)
 struct RefineArgs {
     const int2* kp_range; const int* kp_rows; const ObjGroup* groups; int ngroups; const int* ridx;
     const double* Hx6; const double* HfR; int ldf, no_max;
@@ -3091,27 +3092,36 @@ __device__ __forceinline__ double obj_arrow_cond2(const double* __restrict__ sR,
 // staging of this object's rows (LDS or global), m * OBJ_REFINE_ROW_DOUBLES doubles.  All 256 threads; writes the object's block of Y.
 template <bool INLDS>
 __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, const int Kmax, const double* __restrict__ sR,
-                                                double* __restrict__ sT, double* __restrict__ sYr, double* rowbuf, const RefineArgs& a,
-                                                double* __restrict__ Y, int NOP, int NAP, int NA) {
+                                                double* __restrict__ sT, double* __restrict__ sYr, int2* __restrict__ sTab, double* __restrict__ sPartR,
+                                                double* rowbuf, const RefineArgs& a, double* __restrict__ Y, int NOP, int NAP, int NA) {
     __shared__ int2 sRange[36];
     __shared__ int2 sGrp[ORCVIO_MAX_CLONES];
-    __shared__ double sPartR[4][54];
+    __shared__ int sOvf;   // some (clone, keypoint) pair has more than two rows (two frames of the object share a clone, or rows handed over
+                           // through orcvio_msckf_update_objects in another shape): phase C then takes the general form
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = ob.K, m = ob.rows, row0 = ob.row0;
+    const int KT = Kmax > 0 ? Kmax : 1;   // sTab[c * KT + k] = the (at most two) positions of the rows of keypoint k in clone c, -1: none
     const double tol = sR[36 * Kmax + 81];
     constexpr int QS = 13;              // row stride of q: odd, so that the groups of different clones start on different LDS banks
     double* q = rowbuf;                 // [m][QS]  3 keypoint entries, 9 border entries
     double* xr = rowbuf + (size_t)m * QS;   // [m][7]  hx (6), r
-    int* sPos = reinterpret_cast<int*>(rowbuf + (size_t)m * (QS + 7));   // [m] row - row0 -> position
-    int* sList = sPos + m;              // [m] the keypoint lists as positions
-    int* sK = sList + m;                // [m] keypoint block of the row at a position (K: border only)
+    typedef unsigned short u16;         // (an object has at most 2 048 rows, 34 keypoints, 60 clones)
+    u16* sPos = reinterpret_cast<u16*>(rowbuf + (size_t)m * (QS + 7));   // [m] row - row0 -> position
+    u16* sList = sPos + m;              // [m] the keypoint lists as positions
+    u16* sK = sList + m;                // [m] keypoint block of the row at a position (K: border only)
+    u16* sCl = sK + m;                  // [m] clone of the row at a position
     REFINE_STAMP(1);
     if (tid <= K) sRange[tid] = a.kp_range[ob.kp_off + tid];
     if (tid < ORCVIO_MAX_CLONES) sGrp[tid] = int2{0, 0};
+    if (tid == 0) sOvf = 0;
+    for (int i = tid; i < a.N * KT; i += 256) sTab[i] = int2{-1, -1};
     __syncthreads();
     for (int g = tid; g < a.ngroups; g += 256) {
         const ObjGroup gq = a.groups[g];
-        if (gq.obj == o) sGrp[gq.clone] = int2{gq.r0 - row0, gq.r1 - row0};
+        if (gq.obj == o) {
+            sGrp[gq.clone] = int2{gq.r0 - row0, gq.r1 - row0};
+            for (int lp = gq.r0 - row0; lp < gq.r1 - row0; ++lp) sCl[lp] = (u16)gq.clone;
+        }
     }
     // ---- P: positions, [hx | r] in group order; reciprocals of the kept pivots ---------------------------------------------------
     if (tid < 9 + 3 * K) {
@@ -3120,7 +3130,7 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
     }
     for (int lp = tid; lp < m; lp += 256) {
         const int row = a.ridx[row0 + lp];
-        sPos[row - row0] = lp;
+        sPos[row - row0] = (u16)lp;
         double v[7];
 #pragma unroll
         for (int e = 0; e < 6; ++e) v[e] = a.Hx6[(size_t)row * 6 + e];
@@ -3141,8 +3151,12 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
         while (k < K && p >= sRange[k].y) ++k;
         const int row = a.kp_rows[p];
         const int lp = sPos[row - row0];
-        sList[p - p0] = lp;
-        sK[lp] = k;
+        sList[p - p0] = (u16)lp;
+        sK[lp] = (u16)k;
+        if (k < K) {   // the row's slot in the (clone, keypoint) table
+            int* slot = reinterpret_cast<int*>(sTab + (int)sCl[lp] * KT + k);
+            if (atomicCAS(slot, -1, lp) != -1 && atomicCAS(slot + 1, -1, lp) != -1) sOvf = 1;
+        }
         const double* h = a.HfR + (size_t)row * a.ldf;
         double hb[9], qk[3] = {0.0, 0.0, 0.0}, qb[9];
 #pragma unroll
@@ -3180,74 +3194,80 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
     }
     __syncthreads();
     REFINE_STAMP(3);
-    // ---- B: T = Q~^T Q~ and Q~^T r ---------------------------------------------------------------------------------------------
-#pragma unroll 1
-    for (int it = tid; it < K * 39; it += 256) {   // keypoint blocks: T_kk (9), T_kb (27), q_k^T r (3); rows in list order
-        const int k = it / 39, v = it - 39 * k;
-        const int i = v < 9 ? v / 3 : (v < 36 ? (v - 9) / 9 : v - 36);
-        const int jb = v < 9 ? v % 3 : (v < 36 ? 3 + (v - 9) % 9 : -1);
-        double acc = 0.0;
-        const double* bbase = jb >= 0 ? q + jb : xr + 6;   // (one address computation, no branch per operand)
-        const int bstride = jb >= 0 ? QS : 7;
-        const int e0 = sRange[k].x - p0, e1 = sRange[k].y - p0;
-#pragma unroll 1
-        for (int e = e0; e < e1; e += 4) {   // (four rows' operands in flight; rows summed in list order)
-            double av[4], bv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = e + u < e1;
-                const int lp = sList[ok ? e + u : e0];
-                const double a0 = q[lp * QS + i];
-                const double b0 = bbase[lp * bstride];
-                av[u] = ok ? a0 : 0.0;
-                bv[u] = b0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc += av[u] * bv[u];
-        }
-        if (v < 36) sT[36 * k + v] = acc; else sYr[9 + 3 * k + i] = acc;   // (the reciprocals kept there were phase A's: dead behind its barrier)
-    }
-    REFINE_STAMP(4);
-    // border: T_bb (45 distinct entries) and q_b^T r (9): thread = (value, quarter of the rows), eight rows in flight
-    double bsum = 0.0;
-    const int bval = tid % 54, bpart = tid / 54;   // (threads 216..255 idle)
+    // ---- B: T = Q~^T Q~ and Q~^T r on the matrix cores (D = A B with A = operand rows of Q~ along the lanes' cc, four rows of the
+    // object per instruction along kk: mfma_f64's layout, a = A[cc][kk], b = B[kk][cc], D[kk + 4r][cc]) -------------------------------
+    // keypoint blocks: A = q_k (3 live rows), B = [q_k (3) | q_b (9) | r] (13 live columns) over the rows of keypoint k in list order;
+    // keypoints dealt to the wavefronts round-robin, one accumulation chain each: T_kk, T_kb and q_k^T r of a keypoint in one tile
     {
-        int c1 = 0, c2 = 0;
-        if (bval < 45) { int rem = bval; while (rem >= 9 - c1) { rem -= 9 - c1; ++c1; } c2 = c1 + rem; } else { c1 = bval - 45; c2 = -1; }
-        const int per = (m + 3) / 4, l0 = bpart * per, l1 = (l0 + per < m) ? l0 + per : m;
-        const double* bbase = c2 >= 0 ? q + 3 + c2 : xr + 6;
-        const int bstride = c2 >= 0 ? QS : 7;
-        if (bpart < 4) {
+        const int kk = lane >> 4, cc = lane & 15;
 #pragma unroll 1
-            for (int l = l0; l < l1; l += 8) {
-                double av[8], bv[8];
+        for (int k = wave; k < K; k += 4) {
+            const int e0 = sRange[k].x - p0, e1 = sRange[k].y - p0;
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll 1
+            for (int e = e0; e < e1; e += 64) {   // sixteen instructions' operands (64 rows) are read before the first of them issues
+                int lpv[16];
+                double av[16], bv[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool ok = l + u < l1;
-                    const int lp = ok ? l + u : l0;
-                    const double a0 = q[lp * QS + 3 + c1];
-                    const double b0 = bbase[lp * bstride];
-                    av[u] = ok ? a0 : 0.0;
-                    bv[u] = b0;
+                for (int u = 0; u < 16; ++u) {
+                    const int ee = e + 4 * u + kk;
+                    lpv[u] = sList[ee < e1 ? ee : e0];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) bsum += av[u] * bv[u];
+                for (int u = 0; u < 16; ++u) {
+                    const bool ok = e + 4 * u + kk < e1;
+                    const double a0 = q[lpv[u] * QS + (cc < 3 ? cc : 0)];
+                    const double b0 = cc < 12 ? q[lpv[u] * QS + cc] : xr[lpv[u] * 7 + 6];
+                    av[u] = (ok && cc < 3) ? a0 : 0.0;
+                    bv[u] = (ok && cc < 13) ? b0 : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (e + 4 * u < e1) acc = mfma_f64(av[u], bv[u], acc);   // (wave-uniform)
+            }
+            // D[i][j], i = kk + 4 r: rows 0..2 live (r == 0, kk < 3); j = cc: 0..2 T_kk, 3..11 T_kb, 12 q_k^T r
+            if (kk < 3) {
+                if (cc < 12) sT[36 * k + (cc < 3 ? 3 * kk + cc : 9 + 9 * kk + (cc - 3))] = acc[0];
+                else if (cc == 12) sYr[9 + 3 * k + kk] = acc[0];   // (the reciprocals kept there were phase A's: dead behind its barrier)
             }
         }
     }
-    if (bpart < 4) sPartR[bpart][bval] = bsum;
-    __syncthreads();
-    if (tid < 54) {
-        const double sres = (sPartR[0][tid] + sPartR[1][tid]) + (sPartR[2][tid] + sPartR[3][tid]);
-        if (tid < 45) {
-            int c1 = 0, rem = tid;
-            while (rem >= 9 - c1) { rem -= 9 - c1; ++c1; }
-            const int c2 = c1 + rem;
-            sT[36 * Kmax + 9 * c1 + c2] = sres;
-            sT[36 * Kmax + 9 * c2 + c1] = sres;
-        } else {
-            sYr[tid - 45] = sres;
+    REFINE_STAMP(4);
+    // border: A = q_b (9 live rows), B = [q_b (9) | r] (10 live columns) over ALL rows, every wavefront a quarter of them (position
+    // order), the four partial tiles summed through LDS in wave order
+    {
+        const int kk = lane >> 4, cc = lane & 15;
+        const int steps = (m + 3) >> 2, per = (steps + 3) >> 2, s0 = wave * per, s1 = (s0 + per < steps) ? s0 + per : steps;
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll 1
+        for (int st = s0; st < s1; st += 16) {   // sixteen instructions' operands (64 rows) are read before the first of them issues
+            double av[16], bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int lp0 = 4 * (st + u) + kk;
+                const bool ok = st + u < s1 && lp0 < m;
+                const int lp = ok ? lp0 : 0;
+                const double a0 = q[lp * QS + 3 + (cc < 9 ? cc : 0)];
+                const double r0 = xr[lp * 7 + 6];
+                av[u] = (ok && cc < 9) ? a0 : 0.0;
+                bv[u] = ok ? (cc < 9 ? a0 : (cc == 9 ? r0 : 0.0)) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (st + u < s1) acc = mfma_f64(av[u], bv[u], acc);   // (wave-uniform)
         }
+        // D[i = kk + 4 r][j = cc]: i < 9, j < 10 live -> sPartR[wave][10 i + j]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = kk + 4 * r;
+            if (i < 9 && cc < 10) sPartR[wave * 90 + 10 * i + cc] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (tid < 90) {
+        const double sres = (sPartR[tid] + sPartR[90 + tid]) + (sPartR[180 + tid] + sPartR[270 + tid]);
+        const int i = tid / 10, j = tid - 10 * i;
+        if (j < 9) sT[36 * Kmax + 9 * i + j] = sres; else sYr[i] = sres;
     }
     __syncthreads();
     REFINE_STAMP(5);
@@ -3293,50 +3313,77 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
             for (int c2 = 0; c2 < 9; ++c2) t += Tb[9 * c1 + c2] * yb[c2];
             tb[c1] = t;
         }
+        if (!sOvf) {   // (workgroup-uniform) at most two rows per (clone, keypoint): their positions come from the table
 #pragma unroll 1
-        for (int kc = 0; kc < K; kc += 4) {
-            double yk[4][3];
+            for (int k = 0; k < K; ++k) {
+                double yk[3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+                for (int j = 0; j < 3; ++j) yk[j] = rcol ? sYr[9 + 3 * k + j] : 0.0;
+                if (c >= 0) {
+                    const int2 tb2 = sTab[c * KT + k];
+                    const int la = tb2.x >= 0 ? tb2.x : 0, lb = tb2.y >= 0 ? tb2.y : 0;
+                    const double xa = xr[la * 7 + e], xb = xr[lb * 7 + e];
+                    const double wa = tb2.x >= 0 ? xa : 0.0, wb = tb2.y >= 0 ? xb : 0.0;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) yk[u][j] = (rcol && kc + u < K) ? sYr[9 + 3 * (kc + u) + j] : 0.0;
-            }
-#pragma unroll 1
-            for (int l = gr.x; l < gr.y; l += 4) {   // (four rows in flight; a row adds to the slot of its keypoint, if that is one of these four)
-                int kq[4];
-                double q0[4], q1[4], q2[4];
+                    for (int j = 0; j < 3; ++j) yk[j] = q[la * QS + j] * wa + q[lb * QS + j] * wb;
+                }
+                const double* Tk = sT + 36 * k;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const bool ok = l + w < gr.y;
-                    const int lp = ok ? l + w : gr.x;
-                    const int kv = sK[lp];
-                    kq[w] = ok ? kv - kc : -1;
-                    const double x = xr[lp * 7 + e];
-                    q0[w] = q[lp * QS] * x; q1[w] = q[lp * QS + 1] * x; q2[w] = q[lp * QS + 2] * x;
+                for (int j = 0; j < 3; ++j) {
+                    double t = (Tk[3 * j] * yk[0] + Tk[3 * j + 1] * yk[1]) + Tk[3 * j + 2] * yk[2];
+#pragma unroll
+                    for (int c2 = 0; c2 < 9; ++c2) t += Tk[9 + 9 * j + c2] * yb[c2];
+                    Yo[(size_t)(9 + 3 * k + j) * NAP + col] = 1.5 * yk[j] - 0.5 * t;
                 }
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool hit = kq[w] == u;
-                        yk[u][0] += hit ? q0[w] : 0.0; yk[u][1] += hit ? q1[w] : 0.0; yk[u][2] += hit ? q2[w] : 0.0;
+                for (int c2 = 0; c2 < 9; ++c2) tb[c2] += (Tk[9 + c2] * yk[0] + Tk[18 + c2] * yk[1]) + Tk[27 + c2] * yk[2];
+            }
+        } else {
+#pragma unroll 1
+            for (int kc = 0; kc < K; kc += 4) {
+                double yk[4][3];
+    #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+    #pragma unroll
+                    for (int j = 0; j < 3; ++j) yk[u][j] = (rcol && kc + u < K) ? sYr[9 + 3 * (kc + u) + j] : 0.0;
+                }
+    #pragma unroll 1
+                for (int l = gr.x; l < gr.y; l += 4) {   // (four rows in flight; a row adds to the slot of its keypoint, if that is one of these four)
+                    int kq[4];
+                    double q0[4], q1[4], q2[4];
+    #pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const bool ok = l + w < gr.y;
+                        const int lp = ok ? l + w : gr.x;
+                        const int kv = (int)sK[lp];
+                        kq[w] = ok ? kv - kc : -1;
+                        const double x = xr[lp * 7 + e];
+                        q0[w] = q[lp * QS] * x; q1[w] = q[lp * QS + 1] * x; q2[w] = q[lp * QS + 2] * x;
+                    }
+    #pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool hit = kq[w] == u;
+                            yk[u][0] += hit ? q0[w] : 0.0; yk[u][1] += hit ? q1[w] : 0.0; yk[u][2] += hit ? q2[w] : 0.0;
+                        }
                     }
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = kc + u;
-                if (k < K) {
-                    const double* Tk = sT + 36 * k;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        double t = (Tk[3 * j] * yk[u][0] + Tk[3 * j + 1] * yk[u][1]) + Tk[3 * j + 2] * yk[u][2];
-#pragma unroll
-                        for (int c2 = 0; c2 < 9; ++c2) t += Tk[9 + 9 * j + c2] * yb[c2];
-                        Yo[(size_t)(9 + 3 * k + j) * NAP + col] = 1.5 * yk[u][j] - 0.5 * t;
+    #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kc + u;
+                    if (k < K) {
+                        const double* Tk = sT + 36 * k;
+    #pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            double t = (Tk[3 * j] * yk[u][0] + Tk[3 * j + 1] * yk[u][1]) + Tk[3 * j + 2] * yk[u][2];
+    #pragma unroll
+                            for (int c2 = 0; c2 < 9; ++c2) t += Tk[9 + 9 * j + c2] * yb[c2];
+                            Yo[(size_t)(9 + 3 * k + j) * NAP + col] = 1.5 * yk[u][j] - 0.5 * t;
+                        }
+    #pragma unroll
+                        for (int c2 = 0; c2 < 9; ++c2) tb[c2] += (Tk[9 + c2] * yk[u][0] + Tk[18 + c2] * yk[u][1]) + Tk[27 + c2] * yk[u][2];
                     }
-#pragma unroll
-                    for (int c2 = 0; c2 < 9; ++c2) tb[c2] += (Tk[9 + c2] * yk[u][0] + Tk[18 + c2] * yk[u][1]) + Tk[27 + c2] * yk[u][2];
                 }
             }
         }
@@ -3346,24 +3393,27 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
     }
     REFINE_STAMP(6);
 }
-// sDyn: [factor (arrow_stride) | T (arrow_stride) | Q~^T r (NOP) | row staging (lds_rows * OBJ_REFINE_ROW_DOUBLES)]; the factor is in place.
+// sDyn: [factor (arrow_stride) | T (arrow_stride) | Q~^T r (NOP) | (clone, keypoint) table (N * max(Kmax, 1) int2) | row staging
+// (lds_rows * OBJ_REFINE_ROW_DOUBLES)]; the factor is in place.
 // Returns true if the object was refined (uniform over the workgroup).
 __device__ __forceinline__ bool obj_refine_if_needed(const int o, const ObjArrow ob, const int Kmax, double* __restrict__ sDyn,
-                                                     const RefineArgs& a, double* __restrict__ Y, int NOP, int NAP, int NA) {
+                                                     double* __restrict__ sScratch /* [OBJ_REFINE_SCRATCH] */, const RefineArgs& a,
+                                                     double* __restrict__ Y, int NOP, int NAP, int NA) {
     __shared__ double sCond[1];
     const int astr = arrow_stride(Kmax);
     double* sR = sDyn;
     double* sT = sDyn + astr;
     double* sYr = sT + astr;
-    double* sRows = sYr + NOP;
+    int2* sTab = reinterpret_cast<int2*>(sYr + NOP);   // [N][max(Kmax, 1)]
+    double* sRows = sYr + NOP + (size_t)a.N * (Kmax > 0 ? Kmax : 1);
     if (a.mode != 2) {
         const double c2 = obj_arrow_cond2(sR, sT, sCond, ob.K, Kmax);
         if (!(c2 > OBJ_REFINE_COND * OBJ_REFINE_COND)) return false;   // (NaN: the fast route's result stands)
         __syncthreads();   // (sT is rewritten)
     }
     if (threadIdx.x == 0 && a.refined) atomicAdd(a.refined, 1);
-    if (ob.rows <= a.lds_rows) obj_refine_body<true>(o, ob, Kmax, sR, sT, sYr, sRows, a, Y, NOP, NAP, NA);
-    else obj_refine_body<false>(o, ob, Kmax, sR, sT, sYr, a.scratch + (size_t)ob.row0 * OBJ_REFINE_ROW_DOUBLES, a, Y, NOP, NAP, NA);
+    if (ob.rows <= a.lds_rows) obj_refine_body<true>(o, ob, Kmax, sR, sT, sYr, sTab, sScratch, sRows, a, Y, NOP, NAP, NA);
+    else obj_refine_body<false>(o, ob, Kmax, sR, sT, sYr, sTab, sScratch, a.scratch + (size_t)ob.row0 * OBJ_REFINE_ROW_DOUBLES, a, Y, NOP, NAP, NA);
     return true;
 }
 // The stand-alone launch (windows wider than 256 columns, where border QR and substitution are separate launches): one workgroup per
@@ -3371,11 +3421,12 @@ __device__ __forceinline__ bool obj_refine_if_needed(const int o, const ObjArrow
 __global__ __launch_bounds__(256) void k_obj_refine(const ObjArrow* __restrict__ objs, int Kmax, const double* __restrict__ Rarrow, RefineArgs a,
                                                     double* __restrict__ Y, int NOP, int NAP, int NA) {
     extern __shared__ double sRef[];
+    __shared__ double sScratch[OBJ_REFINE_SCRATCH];
     const int o = blockIdx.x, astr = arrow_stride(Kmax);
     const double* Ro = Rarrow + (size_t)o * astr;
     for (int i = threadIdx.x; i < astr; i += 256) sRef[i] = Ro[i];
     __syncthreads();
-    obj_refine_if_needed(o, objs[o], Kmax, sRef, a, Y, NOP, NAP, NA);
+    obj_refine_if_needed(o, objs[o], Kmax, sRef, sScratch, a, Y, NOP, NAP, NA);
 }
 
 // Border QR, Y = R^-T C and sum_o B_o in ONE launch (windows with NAP <= 256: one solve workgroup per object).  Workgroup o < nobj:
@@ -3389,6 +3440,7 @@ __global__ __launch_bounds__(256) void k_obj_border_solve_assemble(const ObjArro
                                                                    const double* __restrict__ Cd, int NAP, int NA, double* __restrict__ Y,
                                                                    int* __restrict__ info, int nobj, int cb0, double* __restrict__ Bdst, RefineArgs ra) {
     extern __shared__ double sR[];   // arrow_stride(Kmax) doubles (solve role) [+ the scratch of obj_refine_if_needed when ra.mode != 0]
+    __shared__ double sShare[OBJ_REFINE_SCRATCH];   // object role: partial tiles of the explicit-basis route; assemble role: the corner's tree
     int b = blockIdx.x;
     if (b < nobj) {
         if (ra.stamps && b == 0 && threadIdx.x == 0) ra.stamps[7] = wall_clock64();
@@ -3396,7 +3448,7 @@ __global__ __launch_bounds__(256) void k_obj_border_solve_assemble(const ObjArro
         __syncthreads();   // (R_b and the tolerance in LDS; drains this workgroup's stores of H_f^T r)
         if (ra.stamps && b == 0 && threadIdx.x == 0) ra.stamps[0] = wall_clock64();
         // an ill-conditioned Hf takes Y from the explicit basis (and counts its dropped pivots like the substitution would)
-        if (ra.mode != 0 && obj_refine_if_needed(b, objs[b], Kmax, sR, ra, Y, NOP, NAP, NA)) {
+        if (ra.mode != 0 && obj_refine_if_needed(b, objs[b], Kmax, sR, sShare, ra, Y, NOP, NAP, NA)) {
             if (threadIdx.x == 0 && info) {
                 const ObjArrow ob = objs[b];
                 const double tol = sR[36 * Kmax + 81];
@@ -3413,7 +3465,7 @@ __global__ __launch_bounds__(256) void k_obj_border_solve_assemble(const ObjArro
         return;
     }
     b -= nobj;
-    __shared__ double sCorner[256];
+    double* sCorner = sShare;
     const int corner = NA * NAP + NA;
     const bool corner_block = corner >= b * 256 && corner < b * 256 + 256;   // (workgroup-uniform)
     if (corner_block) {
