@@ -62,3 +62,14 @@ def test_unique_id_of_the_ipc_transport(built):
             "print('RESULT ok')\n")
     p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, ORCVIO_COMM_TRANSPORT='ipc', ORCVIO_RCCL_LIB='/nonexistent/librccl.so'), timeout=120)
     assert 'RESULT ok' in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
+
+
+def test_one_rank_over_the_ipc_transport(built):
+    """The world-size-1 tests of tests/test_gpu_comm.py (sharded feature / object updates equal to the one-shot calls, barrier and
+    max, a refused share) with ORCVIO_COMM_TRANSPORT=ipc: the same entry points over the second transport, in a child pytest."""
+    env = dict(os.environ, ORCVIO_COMM_TRANSPORT='ipc', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_comm.py'), '-x', '-q', '-m', 'gpu', '-k',
+                        'world_1 or barrier or refused_share or need_a_communicator', '-p', 'no:cacheprovider'],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    tail = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ''
+    assert p.returncode == 0 and ' passed' in tail and 'failed' not in tail, p.stdout[-2000:] + p.stderr[-2000:]
