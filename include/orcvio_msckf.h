@@ -585,7 +585,11 @@ int32_t orcvio_msckf_update_object_lm_msgs(orcvio_msckf_handle* h, const orcvio_
  *                    by whatever channel it has (MPI, a TCP store, torch.distributed, a file)
  *   comm_init        ncclCommInitRank on the handle's device; allocates the gather buffer
  *   comm_destroy     (also done by orcvio_msckf_destroy)
- * RCCL (librccl.so.1) is loaded with dlopen on the first of these calls: a single-GPU caller never needs it. */
+ * RCCL (librccl.so.1) is loaded with dlopen on the first of these calls: a single-GPU caller never needs it.
+ * A second transport behind the same calls: with ORCVIO_COMM_TRANSPORT=ipc in the environment of every rank the blocks travel by
+ * direct stores into the peers' gather buffers (HIP IPC) announced through a shared-memory segment (ranks of ONE node;
+ * comm_unique_id then returns 128 random bytes and RCCL is never loaded).  Unlike RCCL it accepts several ranks on one device
+ * (INTEGRATION.md 7a). */
 #define ORCVIO_COMM_ID_BYTES 128
 int32_t orcvio_msckf_comm_unique_id(uint8_t* id /* [ORCVIO_COMM_ID_BYTES] */);
 int32_t orcvio_msckf_comm_init(orcvio_msckf_handle* h, const uint8_t* id, int32_t rank, int32_t world);
