@@ -73,3 +73,16 @@ def test_one_rank_over_the_ipc_transport(built):
                        capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     tail = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ''
     assert p.returncode == 0 and ' passed' in tail and 'failed' not in tail, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_three_ranks_on_one_device_random_windows(built):
+    """A bounded slice of scripts/gpu_soak_ipc.py (1 888 random windows through two / three processes on one GPU this round, no failure):
+    THREE ranks (an odd deal of the tracks), twelve seconds of random one-shot feature updates, queued staged updates and object
+    updates on the ranks' shares against the single-call oracle; identical bits on every rank."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'gpu_soak_ipc.py'), '12', '777', '3'], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    txt = p.stdout[p.stdout.index('{'):] if '{' in p.stdout else ''
+    assert txt, p.stdout[-1500:] + p.stderr[-1500:]
+    d = json.loads(txt)
+    assert d['world'] == 3 and d['failures'] == 0 and d['identical_results_on_every_rank'], d
+    assert all(r['feature_windows'] + r['object_windows'] >= 10 for r in d['ranks']), d
