@@ -22,7 +22,8 @@ while time.time() < t_end:
     nf = int(rng.integers(1, 31))
     idp = int(rng.choice([1, 3]))
     on_device = bool(rng.integers(0, 2))
-    fl = synth.Flags(use_larvio=1, if_fej=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)))
+    variant = int(rng.integers(0, 3))   # Jacobians of the MSCKF rows: LARVIO, OrcVIO left, OrcVIO right (config/euroc.yaml:114-118, kitti_raw.yaml:143-148)
+    fl = synth.Flags(use_larvio=int(variant == 0), use_left_perturbation=int(variant == 1), if_fej=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)))
     par = dict(seed=seed, N=N, F=F, nf=nf, idp=idp, on_device=on_device, fej=fl.if_fej, td=fl.estimate_td)
     try:
         w0 = synth.make_window(N=N, F=F, seed=seed, track_len=(min(3, N), min(N, 9)), flags=fl)

@@ -21,7 +21,8 @@ while time.time() < t_end:
     N = int(rng.integers(8, 21))
     F = int(rng.choice([0, rng.integers(1, 40), rng.integers(40, 120)]))
     ns = int(rng.integers(0, 11)); nn = int(rng.integers(1, 7)); idp = int(rng.choice([1, 3])); nui = int(rng.choice([0, 0, 1, 3]))
-    fl = synth.Flags(use_larvio=1, if_fej=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)))
+    variant = int(rng.integers(0, 3))   # Jacobians of the MSCKF rows: LARVIO, OrcVIO left, OrcVIO right (config/euroc.yaml:114-118, kitti_raw.yaml:143-148)
+    fl = synth.Flags(use_larvio=int(variant == 0), use_left_perturbation=int(variant == 1), if_fej=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)))
     par = dict(seed=seed, N=N, F=F, slam=ns, new=nn, idp=idp, nui=nui, fej=fl.if_fej, td=fl.estimate_td)
     try:
         w0 = synth.make_window(N=N, F=F, seed=seed, track_len=(3, min(N, 10)), flags=fl)
