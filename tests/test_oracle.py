@@ -118,6 +118,25 @@ def test_nullspace_projection_properties(built):
         assert rel(H.T @ H, Hx.T @ Pn @ Hx) < 1e-10
 
 
+def test_nullspace_trick_shapes_as_the_reference_test():
+    """reference src/tests/test_state_update.cpp:106-... (testObjectResidualNullSpaceTrick): 12 residuals, 5 object-state columns,
+    10 sensor-state columns -> the projection succeeds and leaves 12 - 5 = 7 rows; the reference compares its SVD form
+    (nullspace_project_inplace_svd, math_utils.hpp:287-312) with the QR twin (:315-344): both are bases of the same left null space,
+    so their Gram data agree.  Its second data case (12 x 21 against 12 x 130, rows <= columns) must return false and leave the inputs
+    as they are (math_utils.hpp:292)."""
+    rng = np.random.default_rng(12)
+    Hf, Hx, r = rng.uniform(-1, 1, (12, 5)), rng.uniform(-1, 1, (12, 10)), rng.uniform(-1, 1, 12)   # (Eigen's Random(): uniform in [-1, 1])
+    ok, H1, r1 = mirror.nullspace_project_svd(Hf, Hx, r)
+    assert ok and H1.shape == (7, 10) and r1.shape == (7,)
+    Q, _ = np.linalg.qr(Hf, mode='complete')   # the QR twin: Q2 = the last rows - cols columns of the Householder Q
+    H2, r2 = Q[:, 5:].T @ Hx, Q[:, 5:].T @ r
+    assert H2.shape == H1.shape
+    assert rel(H1.T @ H1, H2.T @ H2) < 1e-12 and rel(H1.T @ r1, H2.T @ r2) < 1e-12 and abs(r1 @ r1 - r2 @ r2) < 1e-12
+    Hf2, Hx2, r2 = rng.uniform(-1, 1, (12, 21)), rng.uniform(-1, 1, (12, 130)), rng.uniform(-1, 1, 12)
+    ok2, H3, r3 = mirror.nullspace_project_svd(Hf2, Hx2, r2)
+    assert not ok2 and H3 is Hx2 and r3 is r2
+
+
 def test_chi2_quantile_table(built):
     g = np.load(GOLDEN + '/chi2_095.npz')
     t = oracle.chi2_table(0.95, 500)
