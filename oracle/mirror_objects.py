@@ -29,6 +29,12 @@ def project_image_df(x):
     return np.array([[1 / z, 0, -x[0] / (z * z)], [0, 1 / z, -x[1] / (z * z)]])
 
 
+def project_object_points(P, wTo, points_w):
+    """se3_ops.hpp:351-355: uv = pi(P (wTo X)) for homogeneous object points X [K][4], P 3 x 4."""
+    uvh = np.asarray(P) @ (np.asarray(wTo) @ np.asarray(points_w).T)
+    return (uvh[:2] / uvh[2:3]).T
+
+
 def circled_circ(x4):
     """se3_ops.hpp:229-240: 6x4, rows 3:6 cols 0:3 = -skew(x[:3]), rows 0:3 col 3 = x[:3]."""
     T = np.zeros((6, 4))

@@ -17,6 +17,18 @@ def test_keypoint_rows_match_reference_golden():
     assert np.abs(Hf[:24] - g['jacobian']).max() < 1e-12
 
 
+def test_project_object_points_as_the_reference_tests():
+    """reference src/tests/test_se3.cpp:60-74 (the known answer f X / Z + x) and :76-90 (test_project_object_points_data: the projection
+    of the fixture's keypoints equals its stored error + its observations, 1e-6)."""
+    f, x, y, X, Y, Z = 0.25, 2.0, 2.0, 4.0, 4.0, 0.5
+    P = np.array([[f, 0, x, 0], [0, f, y, 0], [0, 0, 1.0, 0]])
+    uv = mo.project_object_points(P, np.eye(4), np.array([[X, Y, Z, 1.0]]))
+    assert np.array_equal(uv, np.array([[f * X / Z + x, f * Y / Z + y]]))
+    g = np.load(GOLDEN + '/ref_test_error_feature_quadric.npz')
+    uvs = mo.project_object_points(g['S'][:3], g['T'], g['M'])
+    assert np.linalg.norm(uvs - (g['error'].reshape(12, 2) + g['zs'])) < 1e-6
+
+
 def test_old_bbox_rows_match_reference_golden():
     """reference src/tests/test_object_lm.cpp:154-202 (error 4, jacobian 4x45)."""
     g = np.load(GOLDEN + '/ref_test_error_bbox_quadric.npz')
