@@ -539,13 +539,18 @@ def main():
         # SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; separate rocprofv3 passes) of the committed profile of
         # this round, per launch; null if that profile does not list the kernel
         traffic = None
+        traffic_source = None
         critical_path = None
         key_of = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<16>', 'k_potrf_solve(M)': 'k_potrf_solve<>',
                   'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt', 'k_gram': 'k_gram_pair', 'k_assemble': 'k_assemble_A',
                   'k_front': 'k_front<3, 16>', 'k_gemm(U)': 'k_gemm_asmA', 'k_gemm(M)': 'k_gemm'}
         try:
             import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]))['kernels']
+            pm_path = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]
+            pm_doc = json.load(open(pm_path))
+            pm = pm_doc['kernels']
+            # the counters are those of a COMMITTED profile, not of this run: say which file and which build
+            traffic_source = dict(file=os.path.relpath(pm_path, ROOT), build=pm_doc.get('build'), measured_in_this_run=False)
             if N == 30 and F == 400:
                 def pmc_of(k):   # (the template argument of the factorisation kernels is the block-column capacity: the smallest
                     #                  instantiation that holds this problem's active columns is the one the update launches)
@@ -586,8 +591,13 @@ def main():
                             mfma_busy_frac=critical_path[dom].get('mfma_busy_frac'),
                             what='FP64 matrix-core work this kernel EXECUTES (PMC SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flop of the committed profile) / '
                                  'its time in this run: the utilisation figure')
+        whole = None
+        if critical_path:   # FP64 matrix-core work EXECUTED by all launches of the step / the step time of this run
+            fl = sum(v.get('executed_mfma_flop', 0.0) for k, v in critical_path.items() if k != 'chain')
+            whole = fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if fl else None
         roofline = dict(bound='mfma', kernel=dom, achieved=achieved, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic, executed=executed,
+                        frac=achieved / FP64_PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_source if traffic is not None else None,
+                        kernel_us=prof[dom] * 1e3, whole_step_executed_frac=whole, executed=executed,
                         per_kernel_frac={k: round(kflops[k] / (prof[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) for k in prof},
                         longest_kernel=dict(
                             kernel=longest, ms=round(prof[longest], 5),
@@ -719,7 +729,12 @@ def main():
         # aggregate in the metric's own unit -- 400-feature update shards processed per second by all ranks =
         # world x joint updates/s -- so that value(N) / (N value(1)) is the usual weak-scaling efficiency T(1)/T(N);
         # the joint-update rate is reported beside it.
-        out = dict(metric='EKF updates/sec, 30 clones x 400 feats', value=world * args.steps / dt, unit='updates/s',
+        try:
+            import hashlib
+            lib_sha16 = hashlib.sha256(open(capi.LIB_PATH, 'rb').read()).hexdigest()[:16]
+        except Exception:
+            lib_sha16 = None
+        out = dict(lib_sha16=lib_sha16, metric='EKF updates/sec, 30 clones x 400 feats', value=world * args.steps / dt, unit='updates/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
                    config=dict(workload='config2: synthetic 30-clone window, 400 point features x 30 observations '
@@ -748,7 +763,97 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)   # the one JSON line, last thing on stdout
+        emit(out, block_dt)
+
+
+def _r(v, nd=6):
+    return None if v is None else round(float(v), nd)
+
+
+def compact_line(out, block_dt=None, detail_file=None):
+    """The contract line: <= 4 KB, the LAST line on stdout (the round driver keeps only the tail of stdout, and a
+    20 KB line with every side measurement in it could not be parsed).  Everything else goes to `bench_detail.json`."""
+    rf = out.get('roofline') or {}
+    cpu = out.get('cpu_baseline')
+    lat = out.get('latency') or {}
+    obj = out.get('objects_update') or {}
+    cfg = out.get('config') or {}
+    line = {k: out.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                    'vs_baseline', 'dtype', 'data')}
+    line['config'] = {k: cfg.get(k) for k in ('workload', 'clones', 'features_per_gpu', 'observations_per_feature', 'features_per_joint_update')}
+    line['config']['workload'] = (cfg.get('workload') or '')[:160]
+    line['config']['value_is'] = 'device-resident queued throughput (inputs in HBM); host-visible: sequential_updates_per_s'
+    line['timed_blocks'] = out.get('timed_blocks')
+    line['blocks_reported'] = out.get('blocks_reported')
+    if block_dt:
+        line['timed_region_s'] = _r(sum(block_dt), 5)           # every timed block of K steps, barriers included
+        line['reported_block_s'] = _r(out['ms_per_step'] * out['steps'] * 1e-3, 6)   # the median block: K steps
+    ex = rf.get('executed') or {}
+    line['roofline'] = dict(bound=rf.get('bound'), kernel=rf.get('kernel'), achieved=_r(rf.get('achieved'), 5), peak=rf.get('peak'),
+                            unit=rf.get('unit'), frac=_r(rf.get('frac'), 6), traffic=rf.get('traffic'),
+                            traffic_source=rf.get('traffic_source'), kernel_us=_r(rf.get('kernel_us'), 3),
+                            executed_mfma_frac=_r(ex.get('frac'), 6),
+                            whole_step_executed_frac=_r(rf.get('whole_step_executed_frac'), 6),
+                            kernel_ms=rf.get('kernel_ms'))
+    if cpu:
+        ac = cpu.get('all_cores') or {}
+        line['cpu_baseline'] = dict(value=_r(cpu.get('value'), 4), unit=cpu.get('unit'), cores=cpu.get('cores'), kind=cpu.get('kind'),
+                                    sample=(cpu.get('sample') or '')[:150], host_cores=cpu.get('host_cores'),
+                                    all_cores=dict(value=_r(ac.get('value'), 2), cores=ac.get('cores'), kind='port (minimum-work, OpenMP)')
+                                    if 'value' in ac else None)
+        if cpu.get('value'):
+            line['gpu_over_cpu_1core'] = _r(out['value'] / cpu['value'], 1)
+        if ac.get('value'):
+            line['gpu_over_cpu_all_cores'] = _r(out['value'] / ac['value'], 2)
+    else:
+        line['cpu_baseline'] = None
+    line['sequential_updates_per_s'] = _r(out.get('sequential_updates_per_s'), 1)
+    hv = lat.get('host_visible') or {}
+    line['host_visible_ms'] = _r(hv.get('median_ms'), 5)
+    line['host_visible_p95_ms'] = _r(hv.get('p95_ms'), 5)
+    line['device_resident_sync_ms'] = _r((lat.get('device_resident') or {}).get('median_ms'), 5)
+    line['host_visible_resident_cov_ms'] = _r((lat.get('host_visible_resident_cov') or {}).get('median_ms'), 5)
+    f1 = obj.get('frame_config3_one_call') or {}
+    line['config3_frame_ms'] = _r(f1.get('median_ms'), 5)
+    line['config3_object_update_ms'] = _r((obj.get('resident') or {}).get('median_ms'), 5)
+    oc = (obj.get('cpu_baseline') or {}).get('all_cores') or {}
+    ac = (cpu or {}).get('all_cores') or {}
+    if f1.get('median_ms') and oc.get('ms_per_update') and ac.get('value'):
+        cpu_frame = 1e3 / ac['value'] + oc['ms_per_update'] + (oc.get('rows_ms') or 0.0)
+        line['config3_frame_cpu_all_cores_ms'] = _r(cpu_frame, 4)
+        line['config3_frame_gpu_over_cpu_all_cores'] = _r(cpu_frame / f1['median_ms'], 2)
+    cf = out.get('configs') or {}
+    line['configs_device_resident_ms'] = {k: _r((v.get('device_resident') or {}).get('median_ms'), 5) for k, v in cf.items()
+                                          if isinstance(v, dict) and 'device_resident' in v} or None
+    for k in ('stream_config1', 'stream_config5'):
+        line[k + '_frames_per_s'] = _r((out.get(k) or {}).get('frames_per_s'), 1)
+    if out.get('comm') is not None:
+        line['comm'] = out['comm']
+    line['detail'] = detail_file
+    line['lib_sha16'] = out.get('lib_sha16')   # the library this run loaded (compare roofline.traffic_source.build)
+    s = json.dumps(line)
+    if len(s) > 4000:   # never again: drop the optional parts rather than outgrow the parser
+        for k in ('configs_device_resident_ms', 'stream_config1_frames_per_s', 'stream_config5_frames_per_s'):
+            line.pop(k, None)
+        line['roofline'].pop('kernel_ms', None)
+        s = json.dumps(line)
+    return s
+
+
+def emit(out, block_dt):
+    """Detail to bench_detail.json (beside bench.py, and under gpurun_out/ when that exists), the compact contract line last on stdout."""
+    detail_file = None
+    for d in (os.path.join(ROOT, 'gpurun_out'), ROOT):
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            try:
+                path = os.path.join(d, os.environ.get('ORCVIO_BENCH_DETAIL', 'bench_detail.json'))
+                with open(path, 'w') as f:
+                    json.dump(out, f, indent=1)
+                detail_file = detail_file or os.path.relpath(path, ROOT)
+            except OSError:
+                pass
+    print(f'bench.py: every side measurement (latency modes, configs, streams, objects, per-kernel roofline) is in {detail_file}', file=sys.stderr, flush=True)
+    print(compact_line(out, block_dt, detail_file), flush=True)   # the one JSON line, last thing on stdout
 
 
 def objects_section(upd, capi, synth, orc, np, win):

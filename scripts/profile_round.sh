@@ -7,7 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+ORCVIO_BENCH_DETAIL=${TAG}_bench_detail.json python3 $ROOT/bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+export ORCVIO_BENCH_DETAIL=${TAG}_scratch_detail.json   # (the profiled runs below must not overwrite the detail of the plain run)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o p -- python3 $ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_$C.log 2>&1

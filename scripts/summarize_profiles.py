@@ -69,8 +69,18 @@ calib = {}
 for k, known in (('k_fac_commit', None), ('k_gram_reduce', None)):
     if k in traffic:
         calib[k] = {kk: vv for kk, vv in traffic[k].items() if kk.endswith('_KB_median')}
+def build_tag():
+    """sha256 (first 16 hex digits) of the library the counters were taken on: bench.py quotes it beside `roofline.traffic`."""
+    import hashlib
+    so = os.path.join(ROOT, 'orcvio_amd', 'lib', 'liborcvio_msckf.so')
+    try:
+        return dict(tag=tag, liborcvio_msckf_sha16=hashlib.sha256(open(so, 'rb').read()).hexdigest()[:16])
+    except OSError:
+        return dict(tag=tag)
+
+
 if traffic:
-    json.dump({'calibration_kernels': calib, 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no trace domains) around bench.py --steps 20; '
+    json.dump({'build': build_tag(), 'calibration_kernels': calib, 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no trace domains) around bench.py --steps 20; '
                        'KB per dispatch, median over the dispatches of each kernel. gfx950 caveat (MI355X_MICROARCH.md): '
                        'FETCH_SIZE under-reports wide coalesced reads by 2x; these kernels read 8 B per lane. SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 = '
                        'FP64 flops executed on the matrix cores per dispatch; SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs.',
@@ -82,7 +92,11 @@ if os.path.exists(b) and os.path.getsize(b) > 10:
     print('bench ->', f'profiles/{tag}_bench.json')
     # the per-configuration table of the same line on its own (<tag>_configs.json): configs, the config-3 frame legs, the config-1 stream
     try:
-        line = json.load(open(b))
+        d = os.path.join(src, f'{tag}_bench_detail.json')   # the side measurements live in the detail file since round 5
+        if os.path.exists(d):
+            shutil.copy(d, os.path.join(dst, f'{tag}_bench_detail.json'))
+            print('bench detail ->', f'profiles/{tag}_bench_detail.json')
+        line = json.load(open(d if os.path.exists(d) else b))
         if line.get('configs'):
             obj = line.get('objects_update') or {}
             frames = {k: obj[k] for k in ('frame_config3', 'frame_config3_prefactored', 'frame_config3_one_call', 'frame_config3_one_call_prefactored') if k in obj}
