@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector / matrix peak (not listed in MI355X_MICROARCH.md)
 SIMDS = 256 * 4           # 256 CUs x 4 SIMDs
+MODEL_T1_US = 97.0        # single-GPU step of config 2 the scaling model of DESIGN.md section 5 is written for
 
 
 def algorithmic_flops(N, F, M, leg=22):
@@ -112,6 +113,18 @@ def ship_unique_id(capi, rank, world):
         if time.time() - t0 > 180:
             raise SystemExit(f'bench.py rank {rank}: no communicator id from rank 0 after 180 s ({path})')
         time.sleep(0.01)
+
+
+def scaling_model(transport, world):
+    """DESIGN.md section 5's T(N) for bench.py's weak-scaling step (400 tracks per rank), microseconds: T1 + a + X(N) + R(N) with T1 the
+    single-GPU step, a = 5 the assembly of the block inside k_front, X the exchange (RCCL ~ 20: one latency-bound all-gather launch;
+    ipc ~ 8 + (N - 1)), R = 3 + 0.5 N the rank-ordered sum; at N = 1 nothing is exchanged (plain step)."""
+    T1, a = MODEL_T1_US, 5.0
+    if world <= 1:
+        return dict(model_us=T1, model='T1 (no exchange at N = 1; the forced world-1 path adds a + X + R)')
+    X = 20.0 if transport == 'rccl' else 8.0 + (world - 1)
+    R = 3.0 + 0.5 * world
+    return dict(model_us=round(T1 + a + X + R, 1), model=f'T1 {T1} + a {a} + X {X} + R {R} (DESIGN.md 5)')
 
 
 def percentiles(samples_ms):
@@ -376,6 +389,7 @@ def stream_hybrid(upd, capi, synth, fl, sigma_px, label, frames=240, seed=0):
     jitter = {str(k): round(percentiles(v)['p95_ms'] / percentiles(v)['median_ms'], 4) for k, v in sorted(per_frame.items())}
     return dict(p, frames_per_s=1e3 / p['mean_ms'], updates_per_frame=n_upd / (frames + 16), in_state_features=n_slam,
                 frames_with_prune_update=cls(tw), frames_without_prune_update=cls(tn), large_update_flags=discards,
+                front_fallbacks=upd.counters()['front_fallbacks'],   # (cumulative for the handle: 0 = no fused front end lost its co-residency bet)
                 p95_over_median_per_distinct_frame=jitter, worst_p95_over_median_same_frame=max(jitter.values()) if jitter else None,
                 tracks_per_frame=[int(c['w'].F) for c in cyc],
                 what=label + ': hybrid filter (12 in-state features, 1 parameter each), 19/20-clone window, 20-200 ragged tracks '
@@ -499,7 +513,17 @@ def main():
         step()
         upd.sync()
     lat_dev = timed_calls(one_sync, max(200, args.latency_updates))   # every rank: the sharded step holds a collective
+    comm = None
     if use_dist:
+        upd.comm_barrier()
+        # where the joint update's time goes on this rank (HIP events on the handle's stream between its three parts; collective)
+        try:
+            parts = upd.profile_sharded(reps=20)
+            comm = dict(upd.comm_details(), **{k: round(v, 2) for k, v in parts.items()})
+            comm.pop('rank', None)
+            comm.update(scaling_model(comm['transport'], world))
+        except Exception as e:
+            comm = dict(error=repr(e))
         upd.comm_barrier()
 
     out = None
@@ -752,9 +776,14 @@ def main():
                    sequential_is='what a filter sees: 1 / median host-visible latency of orcvio_msckf_io_update (tracks, poses and P written '
                                  'in place by the caller -> dx, P+, gamma, accept in host memory), one update at a time because update k+1 '
                                  'needs the state update k left; `value` is the queued device-resident throughput the bench contract defines',
-                   roofline=roofline, cpu_baseline=cpu, latency=latency, objects_update=objects, configs=configs, stream_config1=stream1, stream_config5=stream5)
+                   comm=comm, roofline=roofline, cpu_baseline=cpu, latency=latency, objects_update=objects, configs=configs, stream_config1=stream1, stream_config5=stream5)
     if use_dist:
         upd.comm_barrier()
+    if out is not None:
+        try:   # cumulative counters of the handle (front_fallbacks: fused front ends re-run because another tenant held compute units)
+            out['counters'] = upd.counters()
+        except Exception:
+            pass
     upd.close()
     if rank == 0:
         sys.stdout.flush()

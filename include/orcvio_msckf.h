@@ -409,7 +409,10 @@ int32_t orcvio_msckf_update_objects(orcvio_msckf_handle* h, const orcvio_msckf_f
  * OrcVIO::constructObjectResidualJacobians (src/orcvio.cpp:2017-2151), evaluated on the device.  Output rows are
  * interleaved per in-window frame [keypoint rows ; 4 bbox rows] and can be passed to
  * orcvio_msckf_update_objects as they are.  The LM *solver* is not part of this library: the caller supplies
- * the state at which the rows are evaluated. */
+ * the state at which the rows are evaluated.
+ * The rows are evaluated with UNIT residual weights and the Huber loss OFF: the functors' `residual_weight` and
+ * `use_valid` / huber arguments (src/obj/ObjectResJacCam.cpp:535, 567-576; src/obj/ObjectLM.cpp:775-811) are ones / infinity
+ * at every shipped call site (include/orcvio/obj/ObjectFeatureInitializer.h:40, ObjectLM.h:301), so no entry point exposes them. */
 typedef struct orcvio_object_eval_flags {
     int32_t use_left_perturbation;      /* the object mapper's flag (ObjectInitNode.cpp:140)             */
     int32_t use_new_bbox_residual;      /* use_new_bbox_residual_flag (:206).  1: the reference's rows LITERALLY -- its Jacobians take the
@@ -506,6 +509,18 @@ int32_t orcvio_msckf_objects_local(orcvio_msckf_handle* h, const orcvio_msckf_fl
 int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_blocks, int32_t n_blocks,
                                     int32_t dof_total, void* stream);
 int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_result* result);
+/* Cumulative counters of the handle since orcvio_msckf_create (count <= ORCVIO_COUNTERS values are written):
+ *   [0] front_fallbacks   updates whose fused front end (k_front, ORCVIO_OPT_FUSED_FRONT) lost its co-residency bet -- a workgroup gave
+ *                         up at the launch's device-wide counter because another tenant of the device (a second handle, another
+ *                         stream's long kernel, another process) held compute units -- and were re-run on the forked seven-launch
+ *                         path inside the same call.  The results are the same; each such update costs the bounded wait (tens of ms)
+ *                         plus a second run.  A caller that sees this grow shares the device: set ORCVIO_OPT_FUSED_FRONT = 0
+ *                         
+ *   [1] launch sequences captured into a hipGraph   [2] replayed from one   [3] enqueued as plain launches
+ *   [4] 1 while the communicator blocks the fused front end (ipc transport with ranks sharing this device)   [5..7] 0 */
+#define ORCVIO_COUNTERS 8
+int32_t orcvio_msckf_counters(orcvio_msckf_handle* h, int64_t* counters, int32_t count);
+
 /* Objects of the last downloaded object update (any entry point) whose projection against H_f went through the explicit basis
  * (ORCVIO_OPT_OBJECT_REFINE; math_utils.hpp:287-312 is the step it stands for): this rank's objects only. */
 int32_t orcvio_msckf_objects_refined(orcvio_msckf_handle* h, int32_t* count);
@@ -589,12 +604,26 @@ int32_t orcvio_msckf_update_object_lm_msgs(orcvio_msckf_handle* h, const orcvio_
  * A second transport behind the same calls: with ORCVIO_COMM_TRANSPORT=ipc in the environment of every rank the blocks travel by
  * direct stores into the peers' gather buffers (HIP IPC) announced through a shared-memory segment (ranks of ONE node;
  * comm_unique_id then returns 128 random bytes and RCCL is never loaded).  Unlike RCCL it accepts several ranks on one device
- * (INTEGRATION.md 7a). */
+ * (INTEGRATION.md 7a).  It has run with several ranks on ONE device only: ranks on DIFFERENT devices are unverified
+ * (no multi-GPU machine was available; the gather buffer is fine-grained / uncached and every pushing thread fences at system scope,
+ * which is what the case needs on paper).  Its device-side wait for a peer's block gives up after
+ * min(ORCVIO_COMM_TIMEOUT_S, ORCVIO_IPC_WAIT_S [default 20]) seconds: the update then reports ORCVIO_ERR_TIMEOUT (no update); a block
+ * that arrives with another update's sequence number (a rank whose call count has slipped) reports ORCVIO_ERR_PEER. */
 #define ORCVIO_COMM_ID_BYTES 128
 int32_t orcvio_msckf_comm_unique_id(uint8_t* id /* [ORCVIO_COMM_ID_BYTES] */);
 int32_t orcvio_msckf_comm_init(orcvio_msckf_handle* h, const uint8_t* id, int32_t rank, int32_t world);
 int32_t orcvio_msckf_comm_destroy(orcvio_msckf_handle* h);
 int32_t orcvio_msckf_comm_info(orcvio_msckf_handle* h, int32_t* rank, int32_t* world); /* world = 0: no communicator */
+/* What the communicator is, for logs and benchmarks (count <= 8 values are written): out[0] transport (0 none, 1 RCCL, 2 ipc),
+ * [1] rank, [2] world, [3] ranks_seen: slots of the last sharded update that carried their sender's own number behind the block
+ * (= world when every rank's block arrived), [4] 1 if a peer shares this rank's device (ipc), [5] 1 if the ipc gather buffer is
+ * fine-grained / uncached memory. */
+int32_t orcvio_msckf_comm_details(orcvio_msckf_handle* h, int32_t* out, int32_t count);
+/* Device time of the three parts of orcvio_msckf_run_update_sharded on THIS rank (HIP events on the handle's stream, medians over
+ * `reps` updates of the uploaded share), microseconds: us[0] local tracks + compression, us[1] the exchange (the RCCL all-gather, or
+ * the ipc push + signal + wait; the wait for the slowest peer is part of it), us[2] rank-ordered sum + replicated solve, us[3] the
+ * whole update.  COLLECTIVE: every rank calls it with the same reps.  What bench.py --gpus N reports beside DESIGN.md 5's model. */
+int32_t orcvio_msckf_profile_sharded(orcvio_msckf_handle* h, int32_t reps, double* us /* [4] */);
 /* Bounded waits: nothing here hangs on a rank that never arrives.  comm_unique_id / comm_init give up after ORCVIO_COMM_TIMEOUT_S
  * seconds (environment, default 180) and return ORCVIO_ERR_TIMEOUT; so does every call below that waits for a stream carrying a
  * collective (comm_barrier, comm_allreduce_max, the one-shot sharded updates, orcvio_msckf_sync on a handle with a communicator) --
@@ -703,6 +732,8 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
 
 /* ---- Environment switches (read once per process; diagnostics and A/B measurements -- every one of them leaves the results unchanged) ----
  *   ORCVIO_COMM_TIMEOUT_S   bound of every wait another rank can strand, seconds (default 180)
+ *   ORCVIO_IPC_WAIT_S       ipc transport: bound of the device-side wait for a peer's block, seconds (default 20, at most the above)
+ *   ORCVIO_IPC_COARSE       1: ipc transport's gather buffer in plain (coarse-grained) hipMalloc memory instead of fine-grained / uncached
  *   ORCVIO_RCCL_LIB         path of the RCCL library to dlopen first (then librccl.so.1 / librccl.so by the loader's search -- an already
  *                           loaded one, e.g. torch's bundled copy, wins --, then /opt/rocm/lib)
  *   ORCVIO_FRAME_OVERLAP    0: orcvio_msckf_io_update_frame runs its two halves one behind the other

@@ -42,7 +42,7 @@ EXPORTS = [
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
     'orcvio_msckf_comm_barrier', 'orcvio_msckf_comm_allreduce_max', 'orcvio_msckf_io_begin', 'orcvio_msckf_io_update',
     'orcvio_msckf_augment_state_ref_ldlt', 'orcvio_msckf_io_update_frame', 'orcvio_msckf_io_submit', 'orcvio_msckf_io_collect',
-    'orcvio_msckf_objects_refined',
+    'orcvio_msckf_objects_refined', 'orcvio_msckf_counters', 'orcvio_msckf_comm_details', 'orcvio_msckf_profile_sharded',
 ]
 
 
@@ -449,10 +449,33 @@ class MsckfUpdater:
     def comm_destroy(self):
         self._chk(self.lib.orcvio_msckf_comm_destroy(self.h), 'orcvio_msckf_comm_destroy')
 
+    def counters(self):
+        """Cumulative counters of the handle: front_fallbacks (fused front end re-run on the forked path because another tenant of the
+        device held compute units), launch sequences captured / replayed from a graph / run as plain launches."""
+        v = (C.c_int64 * 8)()
+        self.lib.orcvio_msckf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+        self._chk(self.lib.orcvio_msckf_counters(self.h, v, 8), 'orcvio_msckf_counters')
+        return dict(front_fallbacks=int(v[0]), graph_captures=int(v[1]), graph_replays=int(v[2]), plain_runs=int(v[3]),
+                    front_blocked_by_comm=int(v[4]))
+
     def comm_info(self):
         r, w = C.c_int32(0), C.c_int32(0)
         self._chk(self.lib.orcvio_msckf_comm_info(self.h, C.byref(r), C.byref(w)), 'orcvio_msckf_comm_info')
         return r.value, w.value
+
+    def comm_details(self):
+        v = (C.c_int32 * 8)()
+        self.lib.orcvio_msckf_comm_details.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
+        self._chk(self.lib.orcvio_msckf_comm_details(self.h, v, 8), 'orcvio_msckf_comm_details')
+        return dict(transport={0: 'none', 1: 'rccl', 2: 'ipc'}[int(v[0])], rank=int(v[1]), world=int(v[2]), ranks_seen=int(v[3]),
+                    shared_device=bool(v[4]), gather_uncached=bool(v[5]))
+
+    def profile_sharded(self, reps=20):
+        """COLLECTIVE.  Device microseconds of this rank's sharded update: local, exchange, replicated solve, total (medians)."""
+        us = (C.c_double * 4)()
+        self.lib.orcvio_msckf_profile_sharded.argtypes = [C.c_void_p, C.c_int32, _dp]
+        self._chk(self.lib.orcvio_msckf_profile_sharded(self.h, int(reps), us), 'orcvio_msckf_profile_sharded')
+        return dict(local_us=us[0], exchange_us=us[1], replicated_solve_us=us[2], total_us=us[3])
 
     def comm_barrier(self):
         """Everything enqueued on the handle's stream is finished on every rank (bounded wait: ERR_TIMEOUT, never a hang)."""

@@ -91,17 +91,20 @@ __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
     }
 }
 
-// Block [status | dof | accepted rows | accepted tracks | 0 ...] behind a rank's compressed block in the all-gather slot:
-// what the other ranks must know about this rank's share (sharded calls; ORCVIO_ERR_PEER).
+// Block [status | dof | accepted rows | accepted tracks | sequence number | rank + 1 | 0 ...] behind a rank's compressed block in the all-gather
+// slot: what the other ranks must know about this rank's share (sharded calls; ORCVIO_ERR_PEER).  The sequence number is the ipc
+// transport's update counter q (0 under RCCL): the receiving rank checks it against its own before it sums the slot.
 #define ORCVIO_SHARD_META 16
+#define ORCVIO_SHARD_META_SEQ 4
+#define ORCVIO_SHARD_META_RANK 5   /* the sending rank + 1: the receiver counts the slots that carry their own number (ranks_seen) */
 __global__ __launch_bounds__(64) void k_shard_meta(double* __restrict__ meta, int status, int dof, const int* __restrict__ accept,
-                                                   const int* __restrict__ row_ptr, int F) {
+                                                   const int* __restrict__ row_ptr, int F, unsigned long long q = 0ull, int rank = 0) {
     int rows = 0, cnt = 0;
     if (accept)
         for (int j = threadIdx.x; j < F; j += 64)
             if (accept[j]) { rows += row_ptr[j + 1] - row_ptr[j]; ++cnt; }
     for (int o = 32; o > 0; o >>= 1) { rows += __shfl_down(rows, o); cnt += __shfl_down(cnt, o); }
     if (threadIdx.x == 0) { meta[0] = (double)status; meta[1] = (double)dof; meta[2] = (double)rows; meta[3] = (double)cnt; }
-    if (threadIdx.x >= 4 && threadIdx.x < ORCVIO_SHARD_META) meta[threadIdx.x] = 0.0;
+    if (threadIdx.x >= 4 && threadIdx.x < ORCVIO_SHARD_META) meta[threadIdx.x] = threadIdx.x == ORCVIO_SHARD_META_SEQ ? (double)q : (threadIdx.x == ORCVIO_SHARD_META_RANK ? (double)(rank + 1) : 0.0);
 }
 }  // namespace orcvio_amd

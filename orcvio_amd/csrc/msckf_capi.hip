@@ -103,6 +103,8 @@ struct orcvio_msckf_handle {
     bool io_open = false, io_with_P = false;  // orcvio_msckf_io_begin has laid the arena out and the caller is filling it
     double io_spin_seconds = 2.0;             // bound of the host's wait on h_flag (then: stream synchronisation, then ERR_TIMEOUT)
     bool last_sharded = false;                // the last finished update went through the handle's all-gather (status words in info[9..12])
+    hipEvent_t* shard_ev = nullptr;           // orcvio_msckf_profile_sharded: four events the next run_update_sharded records between its parts
+    int ranks_seen = 0;                       // ranks whose block was present in the last sharded update looked at (orcvio_msckf_comm_details)
     int shard_status = 0;                     // sharded calls: this rank's own status travelling with its block (ORCVIO_ERR_PEER)
     hipStream_t last_stream = nullptr;   // stream of the last run_update / run_finish (download waits for it)
     double *d_Pres = nullptr, *d_Ptmp = nullptr, *d_covT = nullptr;   // resident covariance, scratch, Phi*P rows
@@ -121,6 +123,7 @@ struct orcvio_msckf_handle {
     bool ref_stack_hf = false;          // ORCVIO_OPT_REF_STACK_HF: the reference's literal shared-Hf stacking of several objects
     int obj_refine_mode = 1;            // ORCVIO_OPT_OBJECT_REFINE: 0 never, 1 objects with cond_F(R) above 3e6 (default), 2 every object
     int obj_refined = 0;                // objects of the last downloaded object update that took the explicit-basis projection (k_obj_refine)
+    size_t obj_lds_budget = 0;          // dynamic LDS the border launch of the object update may take on THIS handle's device (0: not asked yet)
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
     bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P
     // The prior's Cholesky is taken of the REVERSED matrix (potrf_reg_body, rev): P = S S^T with S(i, c) = L'(n-1-i, c), whose
@@ -150,7 +153,8 @@ struct orcvio_msckf_handle {
     int last_run_kind = 0;              // 0: run_update (single GPU), 1: run_local / run_finish (staged or sharded), 2: objects
     bool front_retry_forked = false;    // (download: the fused front end lost a hand-off; re-running on the forked path)
     int front_spin_limit = 1 << 19;    // polls before a workgroup of k_front gives up at the device-wide counter (tens of ms)
-    int front_fallbacks = 0;            // how often that happened (orcvio_msckf_debug_read 'fallbacks')
+    int front_fallbacks = 0;            // how often that happened (orcvio_msckf_counters [0])
+    long long cnt_graph_captures = 0, cnt_graph_replays = 0, cnt_plain_runs = 0;   // launch sequences captured / replayed from a graph / enqueued as plain launches
     bool last_update_objects = false;   // the last finished update was a (gated) object update
     bool prior_forked = false;          // the Cholesky of the prior runs on the side stream (ev_side must be joined)
     int kf = 0;                         // columns of the prior's factor = dimension of M (n unless a resident factor is used)
@@ -165,6 +169,7 @@ struct orcvio_msckf_handle {
     int *d_obs_ptr = nullptr, *d_obs_clone = nullptr, *d_row_ptr = nullptr, *d_accept = nullptr, *d_info = nullptr;
     double *d_chi2 = nullptr, *d_Hs = nullptr, *d_gamma = nullptr, *d_Gpart = nullptr, *d_Ab = nullptr, *d_A = nullptr;
     int front_fused = 1;                // ORCVIO_OPT_FUSED_FRONT
+    bool front_blocked_by_comm = false; // ipc transport, ranks sharing this device: k_front's co-residency cannot be had (capi_ipc.inc); the option above is not touched
     int n_extra = 0;                    // ORCVIO_OPT_EXTRA_STATES
     int ekf_mode = 0;                   // ORCVIO_OPT_EKF_ROWS: the extra states are active columns (EKF-SLAM rows may follow an upload)
     int ekf_F = 0, ekf_idp = 3;         // SLAM features of the current upload (orcvio_msckf_upload_ekf_rows)

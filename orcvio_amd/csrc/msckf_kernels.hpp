@@ -1040,22 +1040,23 @@ __global__ __launch_bounds__(1024) void k_gram_pair(const double* __restrict__ T
 // Sums `nparts` blocks into dst (full symmetric result); used for the chunk partials of one
 // rank (lower tiles valid) and for the all-gathered blocks of all ranks.
 // shard_meta (sharded updates): ORCVIO_SHARD_META status words stand behind every rank's block, the first at shard_meta; block
-// 0 leaves [first failing rank + 1 (0: none), its status, total dof, total accepted rows] in shard_info[0..3] -- the same four
+// 0 leaves [first failing rank + 1 (0: none), its status, total dof, total accepted rows, ranks present] in shard_info[0..4] -- the same
 // numbers on every rank, from the same gathered bytes (zeros when there are no status words).
 __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ parts, int nparts, size_t part_stride,
                                                      int NAP, double* __restrict__ dst, const double* __restrict__ shard_meta = nullptr,
                                                      int* __restrict__ shard_info = nullptr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx == 0 && shard_info) {
-        int bad = 0, st = 0;
+        int bad = 0, st = 0, seen = 0;
         long dof = 0, rows = 0;
         if (shard_meta)
             for (int r = 0; r < nparts; ++r) {
                 const double* m = shard_meta + (size_t)r * part_stride;
                 if (bad == 0 && m[0] != 0.0) { bad = r + 1; st = (int)m[0]; }
                 dof += (long)m[1]; rows += (long)m[2];
+                seen += m[5] == (double)(r + 1) ? 1 : 0;   // (ORCVIO_SHARD_META_RANK: the slot carries its sender's number)
             }
-        shard_info[0] = bad; shard_info[1] = st; shard_info[2] = (int)dof; shard_info[3] = (int)rows;
+        shard_info[0] = bad; shard_info[1] = st; shard_info[2] = (int)dof; shard_info[3] = (int)rows; shard_info[4] = seen;
     }
     if (idx >= NAP * NAP) return;
     const int i = idx / NAP, jj = idx - i * NAP;

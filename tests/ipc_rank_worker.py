@@ -26,8 +26,45 @@ def digest(*arrays):
     return h.hexdigest()[:16]
 
 
+def skew_main(rank, world, uid):
+    """A rank whose update counter has slipped by one (the state a rank-local early return used to leave behind): the next
+    sharded update is a loud error on EVERY rank -- ORCVIO_ERR_TIMEOUT (7) on the rank that waits for a block nobody sends,
+    ORCVIO_ERR_PEER (8) on the ranks that find another update's sequence number behind the block -- never a silent wrong sum."""
+    import ctypes as C
+    out = dict(rank=rank, checks=[])
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536, debug_hooks=True)
+    u.comm_init(uid, rank, world)
+    full = synth.make_window(N=8, F=20 * world, seed=5, track_len=(3, 8))
+    share, _ = sharding.shard_window(full, rank, world)
+    ref = oracle.msckf_update(full, want_blocks=False, want_K=False)
+    got = u.update_features_sharded(share)
+    out['checks'].append(dict(name='before', ok=bool(rel(got['dx'], ref['dx']) < TOL)))
+    u.comm_barrier()
+    if rank == world - 1:
+        u.lib.orcvio_msckf_debug_ipc_skew.argtypes = [C.c_void_p, C.c_int32]
+        assert u.lib.orcvio_msckf_debug_ipc_skew(u.h, 1) == 0
+    code = 0
+    try:
+        u.update_features_sharded(share)
+    except capi.MsckfError as e:
+        code = e.code
+    out['checks'].append(dict(name='skewed_update_is_an_error', ok=code == (7 if rank == world - 1 else 8), code=code))
+    try:
+        u.cov_commit()
+        committed = True
+    except capi.MsckfError:
+        committed = False
+    out['checks'].append(dict(name='nothing_to_commit', ok=not committed))
+    u.close()
+    out['passed'] = all(c['ok'] for c in out['checks'])
+    print('RESULT ' + json.dumps(out), flush=True)
+    return 0 if out['passed'] else 1
+
+
 def main():
     rank, world, uid = int(sys.argv[1]), int(sys.argv[2]), bytes.fromhex(sys.argv[3])
+    if len(sys.argv) > 4 and sys.argv[4] == 'skew':
+        return skew_main(rank, world, uid)
     out = dict(rank=rank, checks=[])
     u = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
     u.comm_init(uid, rank, world)
@@ -64,6 +101,10 @@ def main():
     st = u.download()
     ok('queued_staged', rel(st['dx'], ref['dx']) < TOL and rel(st['P_new'], ref['P_new']) < TOL, dx_err=rel(st['dx'], ref['dx']))
     out['staged_digest'] = digest(st['dx'], st['P_new'])
+    d = u.comm_details()   # what bench.py --gpus N prints: transport, world, the ranks whose block arrived
+    ok('comm_details', d['transport'] == 'ipc' and d['world'] == world and d['ranks_seen'] == world and d['shared_device'], **d)
+    parts = u.profile_sharded(reps=5)   # (collective)
+    ok('profile_sharded', all(v > 0.0 for v in parts.values()), **{k: round(v, 1) for k, v in parts.items()})
 
     # ---- a share whose tracks are ALL rejected by the gate (rank 1): its block is zero, the update is the other ranks'
     full = synth.make_window(N=10, F=60 * world, seed=21, track_len=(3, 8))

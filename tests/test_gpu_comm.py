@@ -107,6 +107,27 @@ def test_bench_distributed_path_world_1(built):
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['steps'] == 5 and line['value'] > 1000.0
     assert 'torch.distributed' not in p.stderr or 'init_process_group' not in p.stderr
+    # VERDICT r4 'next' 6: the line an N > 1 run prints must be judgeable -- transport, world, the ranks whose block arrived, measured
+    # exchange / replicated solve beside DESIGN.md 5's model
+    c = line['comm']
+    assert c['transport'] == 'rccl' and c['world'] == 1 and c['ranks_seen'] == 1, c
+    for k in ('local_us', 'exchange_us', 'replicated_solve_us', 'total_us', 'model_us'):
+        assert c[k] > 0.0, (k, c)
+    assert c['local_us'] + c['exchange_us'] + c['replicated_solve_us'] <= 1.05 * c['total_us'] + 1.0
+    assert len(p.stdout.strip().splitlines()[-1]) < 4096
+
+
+def test_comm_details_and_the_sharded_profile(upd):
+    d = upd.comm_details()
+    assert d['transport'] == 'rccl' and d['world'] == 1 and d['rank'] == 0
+    win = synth.make_window(N=8, F=20, seed=4, track_len=(3, 8))
+    upd.upload(win)
+    parts = upd.profile_sharded(reps=5)
+    assert all(v > 0.0 for v in parts.values()) and parts['total_us'] < 5000.0
+    assert upd.comm_details()['ranks_seen'] == 1
+    got = upd.update_features_sharded(win)
+    ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    assert rel(got['dx'], ref['dx']) < 1e-6
 
 
 def test_a_refused_share_reaches_every_rank(upd):

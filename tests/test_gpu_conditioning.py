@@ -135,9 +135,12 @@ def test_conditioning_sweep_object_update(built):
                         # Round 4 (VERDICT r3 'next' 1): the bar is north_star's 1e-6 for BOTH objects.  The reference's real car seen in
                         # four frames has cond(H_f) = 3e8; the semi-normal equations Y = R^-T (H_f^T X) lose cond * eps there (1.4e-6 in
                         # delta_x at P x 100, round 3) -- ill-conditioned objects now take Y from an explicit basis (k_obj_refine).
-                        lim = max(1e-6, 100 * e['dbl_dx'])
+                        # VERDICT r4 'next' 4: assert the bar that is reached.  1e-6 outright wherever the reference's own double arithmetic
+                        # (the restatement) is within 1e-8 of the 50-digit result; the 100 x slack only where the restatement itself is worse.
+                        lim = 1e-6 if e['dbl_dx'] < 1e-8 else max(1e-6, 100 * e['dbl_dx'])
                         assert e['dev_dx'] < lim and e['dev_P'] < lim, e
                         e['inside_1e-6'] = bool(e['dev_dx'] < 1e-6)
+                        assert e['inside_1e-6'], e   # every row of the object sweep (round 4: worst 8.6e-10)
                     assert e['dev_gamma'] < max(1e-6, 100 * e['dbl_gamma']), e
                     rows.append(e)
     finally:
@@ -185,7 +188,7 @@ def test_conditioning_sweep_hybrid_frame(built):
                     if same and (ref['accept'].sum() + ref['ekf_accept'].sum()) > 0:
                         e.update(dev_dx=rel(got['dx'], ref['dx']), dbl_dx=rel(dbl['dx'], ref['dx']), dev_P=rel(got['P_new'], ref['P_new']),
                                  dbl_P=rel(dbl['P_new'], ref['P_new']))
-                        lim = max(1e-6, 100 * e['dbl_dx'])
+                        lim = 1e-6 if e['dbl_dx'] < 1e-8 else max(1e-6, 100 * e['dbl_dx'])
                         assert e['dev_dx'] < lim and e['dev_P'] < lim, e
                     rows.append(e)
     finally:

@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_ranks(world, extra_env=None, timeout=900):
+def _run_ranks(world, extra_env=None, timeout=900, mode=None):
     env = dict(os.environ, ORCVIO_COMM_TRANSPORT='ipc', ORCVIO_COMM_TIMEOUT_S='120', HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.update(extra_env or {})
     uid = os.urandom(128).hex()   # (what orcvio_msckf_comm_unique_id returns under this transport: 128 random bytes)
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ipc_rank_worker.py'), str(r), str(world), uid],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ipc_rank_worker.py'), str(r), str(world), uid] + ([mode] if mode else []),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     outs = []
     for p in procs:
@@ -49,6 +49,19 @@ def test_two_ranks_on_one_device(built):
     assert res[0]['feature_digests'] == res[1]['feature_digests']
     assert res[0]['staged_digest'] == res[1]['staged_digest']
     assert res[0]['object_digest'] == res[1]['object_digest']
+
+
+def test_a_slipped_update_counter_is_a_loud_error_on_every_rank(built):
+    """the ipc transport's sequence numbers used to be free-running host counters nothing checked; a rank that took
+    a rank-local early return stayed one count behind and summed its peers' PREVIOUS blocks.  Now every block carries its update's
+    number and the counters advance at the top of each call: a rank made to slip (debug hook) gets ORCVIO_ERR_TIMEOUT, its peer
+    ORCVIO_ERR_PEER, and nobody has an update to commit."""
+    outs = _run_ranks(2, extra_env=dict(ORCVIO_IPC_WAIT_S='2', ORCVIO_COMM_TIMEOUT_S='30'), timeout=300, mode='skew')
+    for rc, so, se in outs:
+        lines = [ln for ln in so.splitlines() if ln.startswith('RESULT ')]
+        assert lines, (rc, so[-2000:], se[-3000:])
+        r = json.loads(lines[-1][7:])
+        assert r['passed'] and rc == 0, (r, se[-2000:])
 
 
 def test_unique_id_of_the_ipc_transport(built):

@@ -37,6 +37,11 @@ def test_update_survives_a_kernel_that_holds_half_the_device(built):
         assert np.array_equal(got['accept'], ref['accept'])
         assert rel(got['dx'], ref['dx']) < 1e-6 and rel(got['P_new'], ref['P_new']) < 1e-6
         assert _fallbacks(upd) == 1, 'the stranded launch should have been re-run on the forked path'
+        assert upd.counters()['front_fallbacks'] == 1   # ... and the caller can see it through the product ABI (orcvio_msckf_counters)
+        upd.set_fused_front(False)                           # bit-identical to the unfused form (the re-run IS the unfused form)
+        unf = upd.update_features(win)
+        upd.set_fused_front(True)
+        assert np.array_equal(unf['dx'], got['dx']) and np.array_equal(unf['P_new'], got['P_new']) and np.array_equal(unf['gamma'], got['gamma'])
         assert dt < 2.0
         upd.sync()
         time.sleep(0.5)                                      # the occupying kernel is gone: the fused path again, no fallback
