@@ -110,20 +110,23 @@ def test_bench_distributed_path_world_1(built):
     # VERDICT r4 'next' 6: the line an N > 1 run prints must be judgeable -- transport, world, the ranks whose block arrived, measured
     # exchange / replicated solve beside DESIGN.md 5's model
     c = line['comm']
-    assert c['transport'] == 'rccl' and c['world'] == 1 and c['ranks_seen'] == 1, c
-    for k in ('local_us', 'exchange_us', 'replicated_solve_us', 'total_us', 'model_us'):
+    want = 'ipc' if os.environ.get('ORCVIO_COMM_TRANSPORT', '').lower() == 'ipc' else 'rccl'   # (tests/test_gpu_ipc.py re-runs this file over the second transport)
+    assert c['transport'] == want and c['world'] == 1 and c['ranks_seen'] == 1, c
+    for k in ('local_us', 'replicated_solve_us', 'total_us', 'model_us'):
         assert c[k] > 0.0, (k, c)
+    assert c['exchange_us'] >= 0.0   # (world 1 over the ipc transport: nothing is pushed)
     assert c['local_us'] + c['exchange_us'] + c['replicated_solve_us'] <= 1.05 * c['total_us'] + 1.0
     assert len(p.stdout.strip().splitlines()[-1]) < 4096
 
 
 def test_comm_details_and_the_sharded_profile(upd):
+    import os
     d = upd.comm_details()
-    assert d['transport'] == 'rccl' and d['world'] == 1 and d['rank'] == 0
+    assert d['transport'] == ('ipc' if os.environ.get('ORCVIO_COMM_TRANSPORT', '').lower() == 'ipc' else 'rccl') and d['world'] == 1 and d['rank'] == 0
     win = synth.make_window(N=8, F=20, seed=4, track_len=(3, 8))
     upd.upload(win)
     parts = upd.profile_sharded(reps=5)
-    assert all(v > 0.0 for v in parts.values()) and parts['total_us'] < 5000.0
+    assert all(v >= 0.0 for v in parts.values()) and parts['local_us'] > 0.0 and 0.0 < parts['total_us'] < 5000.0
     assert upd.comm_details()['ranks_seen'] == 1
     got = upd.update_features_sharded(win)
     ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
