@@ -213,7 +213,10 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * reference's full-U SVD (math_utils.hpp:287-312) is backward stable.  1: objects whose triangular factor R has |R|_F |R^-1|_F above 3e6
  * (an estimate of cond(H_f) from above, formed on the device; every real car: cond(H_f) ~ 3e8 on the reference's one_car frames) form the basis explicitly, row by row (q_i R = h_i), take
  * Y from it and correct for its loss of orthonormality -- delta_x within 1e-9 of a 50-digit evaluation where the fast
- * route has 1.4e-6.  0: never.  2: every object.  orcvio_msckf_objects_refined reports how many objects of the last update took it. */
+ * route has 1.4e-6.  0: never.  2: every object.  orcvio_msckf_objects_refined reports how many objects of the last update took it.
+ * Object TRACKS that qualify for the one-launch compression (orcvio_msckf_counters [5]) take the explicit basis for every object in
+ * modes 1 and 2 alike -- there it is the only route, with the orthonormalisation applied to the rows of the basis (to first order,
+ * like the correction above); mode 0 sends the tracks through the three-launch pipeline and its fast route. */
 enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
        ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6, ORCVIO_OPT_RESIDENT_FACTOR = 7, ORCVIO_OPT_OBJECT_QR = 8,
        ORCVIO_OPT_REF_STACK_HF = 9, ORCVIO_OPT_SCHMIDT_STATES = 10, ORCVIO_OPT_OBJECT_DOF = 11, ORCVIO_OPT_REF_H2_LDLT = 12,
@@ -517,7 +520,11 @@ int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_resul
  *                         plus a second run.  A caller that sees this grow shares the device: set ORCVIO_OPT_FUSED_FRONT = 0
  *                         
  *   [1] launch sequences captured into a hipGraph   [2] replayed from one   [3] enqueued as plain launches
- *   [4] 1 while the communicator blocks the fused front end (ipc transport with ranks sharing this device)   [5..7] 0 */
+ *   [4] 1 while the communicator blocks the fused front end (ipc transport with ranks sharing this device)
+ *   [5] 1 if the last object update from tracks compressed its objects in ONE launch (k_obj_fused: rows evaluated into LDS, never
+ *       materialised; every object through the explicit basis), 0 if it took the three-launch pipeline over materialised rows
+ *       (an object with two frames on one clone, more than 32 in-window frames or 16 keypoints, rows beyond the LDS staging,
+ *       ORCVIO_OPT_OBJECT_REFINE = 0, ORCVIO_OPT_REF_STACK_HF, ORCVIO_OPT_OBJECT_QR = 0)   [6..7] 0 */
 #define ORCVIO_COUNTERS 8
 int32_t orcvio_msckf_counters(orcvio_msckf_handle* h, int64_t* counters, int32_t count);
 

@@ -11,7 +11,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16 bytes pe
 
 // d_in <- pinned host arena (device-visible).  One pass, every lane one 16-byte load in flight per iteration; the grid is
 // sized by the caller so that an iteration or two covers the block (PCIe reads want many requests outstanding).
-__global__ __launch_bounds__(256) void k_ingest(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+// zero / zero_mask: workgroup 0 also clears the words zero[i] whose bit i of zero_mask is set (the pivot counters and shard status
+// words an object update accumulates into: no fill launch in front of its compression).
+__global__ __launch_bounds__(256) void k_ingest(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16, int* __restrict__ zero = nullptr,
+                                                unsigned zero_mask = 0u) {
+    if (zero && blockIdx.x == 0 && threadIdx.x < 32 && (zero_mask >> threadIdx.x & 1u)) zero[threadIdx.x] = 0;
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
 }

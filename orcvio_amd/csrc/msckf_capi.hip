@@ -23,6 +23,7 @@
 #include "cov_ops.hpp"
 #include "ekf_rows.hpp"
 #include "object_rows.hpp"
+#include "object_fused.hpp"
 #include "io_ops.hpp"
 #include <immintrin.h>
 #include <condition_variable>
@@ -123,6 +124,9 @@ struct orcvio_msckf_handle {
     bool ref_stack_hf = false;          // ORCVIO_OPT_REF_STACK_HF: the reference's literal shared-Hf stacking of several objects
     int obj_refine_mode = 1;            // ORCVIO_OPT_OBJECT_REFINE: 0 never, 1 objects with cond_F(R) above 3e6 (default), 2 every object
     int obj_refined = 0;                // objects of the last downloaded object update that took the explicit-basis projection (k_obj_refine)
+    size_t obj_fused_budget = 0;        // dynamic LDS a workgroup of k_obj_fused may take on this device (0: not asked yet)
+    int obj_fused_opt = 1;              // ORCVIO_OBJ_FUSED=0: object tracks always through the three-launch pipeline (rows materialised)
+    bool obj_last_fused = false;        // the last object update from tracks took the one-launch compression
     size_t obj_lds_budget = 0;          // dynamic LDS the border launch of the object update may take on THIS handle's device (0: not asked yet)
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)
     bool use_factor = false;            // the current upload's prior comes with its factor: no Cholesky of P

@@ -604,112 +604,18 @@ __device__ __forceinline__ double obj_arrow_cond2(const double* __restrict__ sR,
     __syncthreads();
     return sOut[0];
 }
-// sR: the object's arrow factor (with the pivot tolerance); sT (arrow_stride doubles), sYr (NOP doubles): LDS scratch; rowbuf: the
-// staging of this object's rows (LDS or global), m * OBJ_REFINE_ROW_DOUBLES doubles.  All 256 threads; writes the object's block of Y.
-template <bool INLDS>
-__device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, const int Kmax, const double* __restrict__ sR,
-                                                double* __restrict__ sT, double* __restrict__ sYr, int2* __restrict__ sTab, double* __restrict__ sPartR,
-                                                double* rowbuf, const RefineArgs& a, double* __restrict__ Y, int NOP, int NAP, int NA) {
-    __shared__ int2 sRange[36];
-    __shared__ int2 sGrp[ORCVIO_MAX_CLONES];
-    __shared__ int sOvf;   // some (clone, keypoint) pair has more than two rows (two frames of the object share a clone, or rows handed over
-                           // through orcvio_msckf_update_objects in another shape): phase C then takes the general form
+// Phases B and C of the explicit-basis projection on rows that stand in LDS / scratch (q: the rows of Q~, xr: [hx | r], the keypoint
+// lists as positions in sList with ranges sRange[k] - p0, the clone groups sGrp, the (clone, keypoint) table sTab): shared by
+// obj_refine_body (rows staged from device memory, four wavefronts) and k_obj_fused (rows evaluated in place, eight wavefronts).
+// sPartR: 90 NW doubles of scratch.
+template <int NW>
+__device__ __forceinline__ void obj_refine_B(const int o, const int K, const int m, const int Kmax, double* __restrict__ sT, double* __restrict__ sYr,
+                                             double* __restrict__ sPartR, const double* __restrict__ q, const double* __restrict__ xr,
+                                             const unsigned short* __restrict__ sList, const int2* __restrict__ sRange, const int p0,
+                                             const RefineArgs& a) {
+    static_assert(NW == 4 || NW == 8, "four or eight wavefronts");
+    constexpr int QS = 13;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = ob.K, m = ob.rows, row0 = ob.row0;
-    const int KT = Kmax > 0 ? Kmax : 1;   // sTab[c * KT + k] = the (at most two) positions of the rows of keypoint k in clone c, -1: none
-    const double tol = sR[36 * Kmax + 81];
-    constexpr int QS = 13;              // row stride of q: odd, so that the groups of different clones start on different LDS banks
-    double* q = rowbuf;                 // [m][QS]  3 keypoint entries, 9 border entries
-    double* xr = rowbuf + (size_t)m * QS;   // [m][7]  hx (6), r
-    typedef unsigned short u16;         // (an object has at most 2 048 rows, 34 keypoints, 60 clones)
-    u16* sPos = reinterpret_cast<u16*>(rowbuf + (size_t)m * (QS + 7));   // [m] row - row0 -> position
-    u16* sList = sPos + m;              // [m] the keypoint lists as positions
-    u16* sK = sList + m;                // [m] keypoint block of the row at a position (K: border only)
-    u16* sCl = sK + m;                  // [m] clone of the row at a position
-    REFINE_STAMP(1);
-    if (tid <= K) sRange[tid] = a.kp_range[ob.kp_off + tid];
-    if (tid < ORCVIO_MAX_CLONES) sGrp[tid] = int2{0, 0};
-    if (tid == 0) sOvf = 0;
-    for (int i = tid; i < a.N * KT; i += 256) sTab[i] = int2{-1, -1};
-    __syncthreads();
-    for (int g = tid; g < a.ngroups; g += 256) {
-        const ObjGroup gq = a.groups[g];
-        if (gq.obj == o) {
-            sGrp[gq.clone] = int2{gq.r0 - row0, gq.r1 - row0};
-            for (int lp = gq.r0 - row0; lp < gq.r1 - row0; ++lp) sCl[lp] = (u16)gq.clone;
-        }
-    }
-    // ---- P: positions, [hx | r] in group order; reciprocals of the kept pivots ---------------------------------------------------
-    if (tid < 9 + 3 * K) {
-        const double pv = tid < 9 ? sR[36 * Kmax + 10 * tid] : sR[36 * ((tid - 9) / 3) + 13 * ((tid - 9) % 3)];
-        sYr[tid] = fabs(pv) > tol ? 1.0 / pv : 0.0;
-    }
-    for (int lp = tid; lp < m; lp += 256) {
-        const int row = a.ridx[row0 + lp];
-        sPos[row - row0] = (u16)lp;
-        double v[7];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) v[e] = a.Hx6[(size_t)row * 6 + e];
-        v[6] = a.HfR[(size_t)row * a.ldf + a.no_max];
-#pragma unroll
-        for (int e = 0; e < 7; ++e) xr[lp * 7 + e] = v[e];
-    }
-    __syncthreads();
-    REFINE_STAMP(2);
-    // ---- A: the rows of Q~ (thread per entry of the keypoint lists).  (Straight-line code that runs once is bound by instruction
-    // fetch: every loop here is kept rolled except where a register array needs constant indices.) ------------------------------------
-    const int p0 = sRange[0].x, p1 = sRange[K].y;   // (the K + 1 row lists of an object are contiguous in kp_rows)
-    const double* Rb = sR + 36 * Kmax;
-    const double* sRi = sYr;   // reciprocals of the pivots (0: dropped), written in phase P: [9 border | 3 per keypoint]
-#pragma unroll 1
-    for (int p = p0 + tid; p < p1; p += 256) {
-        int k = 0;
-        while (k < K && p >= sRange[k].y) ++k;
-        const int row = a.kp_rows[p];
-        const int lp = sPos[row - row0];
-        sList[p - p0] = (u16)lp;
-        sK[lp] = (u16)k;
-        if (k < K) {   // the row's slot in the (clone, keypoint) table
-            int* slot = reinterpret_cast<int*>(sTab + (int)sCl[lp] * KT + k);
-            if (atomicCAS(slot, -1, lp) != -1 && atomicCAS(slot + 1, -1, lp) != -1) sOvf = 1;
-        }
-        const double* h = a.HfR + (size_t)row * a.ldf;
-        double hb[9], qk[3] = {0.0, 0.0, 0.0}, qb[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) hb[c] = h[c];
-        if (k < K) {
-            const double* Rk = sR + 36 * k;
-            const double* rik = sRi + 9 + 3 * k;
-            double hk[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) hk[j] = h[9 + 3 * k + j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double t = hk[j];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    if (i < j) t -= qk[i] * Rk[12 * i + j];
-                qk[j] = t * rik[j];
-            }
-#pragma unroll
-            for (int c = 0; c < 9; ++c) hb[c] -= (qk[0] * Rk[3 + c] + qk[1] * Rk[15 + c]) + qk[2] * Rk[27 + c];
-        }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            double t = hb[j];
-#pragma unroll
-            for (int i = 0; i < 9; ++i)
-                if (i < j) t -= qb[i] * Rb[9 * i + j];
-            qb[j] = t * sRi[j];
-        }
-        double* qo = q + lp * QS;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) qo[j] = qk[j];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) qo[3 + j] = qb[j];
-    }
-    __syncthreads();
-    REFINE_STAMP(3);
     // ---- B: T = Q~^T Q~ and Q~^T r on the matrix cores (D = A B with A = operand rows of Q~ along the lanes' cc, four rows of the
     // object per instruction along kk: mfma_f64's layout, a = A[cc][kk], b = B[kk][cc], D[kk + 4r][cc]) -------------------------------
     // keypoint blocks: A = q_k (3 live rows), B = [q_k (3) | q_b (9) | r] (13 live columns) over the rows of keypoint k in list order;
@@ -717,7 +623,7 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
     {
         const int kk = lane >> 4, cc = lane & 15;
 #pragma unroll 1
-        for (int k = wave; k < K; k += 4) {
+        for (int k = wave; k < K; k += NW) {
             const int e0 = sRange[k].x - p0, e1 = sRange[k].y - p0;
             d4 acc = {0, 0, 0, 0};
 #pragma unroll 1
@@ -753,7 +659,7 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
     // order), the four partial tiles summed through LDS in wave order
     {
         const int kk = lane >> 4, cc = lane & 15;
-        const int steps = (m + 3) >> 2, per = (steps + 3) >> 2, s0 = wave * per, s1 = (s0 + per < steps) ? s0 + per : steps;
+        const int steps = (m + 3) >> 2, per = (steps + NW - 1) / NW, s0 = wave * per, s1 = (s0 + per < steps) ? s0 + per : steps;
         d4 acc = {0, 0, 0, 0};
 #pragma unroll 1
         for (int st = s0; st < s1; st += 16) {   // sixteen instructions' operands (64 rows) are read before the first of them issues
@@ -781,17 +687,28 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
     }
     __syncthreads();
     if (tid < 90) {
-        const double sres = (sPartR[tid] + sPartR[90 + tid]) + (sPartR[180 + tid] + sPartR[270 + tid]);
+        double sres = (sPartR[tid] + sPartR[90 + tid]) + (sPartR[180 + tid] + sPartR[270 + tid]);
+        if (NW == 8) sres += (sPartR[360 + tid] + sPartR[450 + tid]) + (sPartR[540 + tid] + sPartR[630 + tid]);   // (fixed order: deterministic)
         const int i = tid / 10, j = tid - 10 * i;
         if (j < 9) sT[36 * Kmax + 9 * i + j] = sres; else sYr[i] = sres;
     }
     __syncthreads();
     REFINE_STAMP(5);
+}
+template <int NW>
+__device__ __forceinline__ void obj_refine_C(const int o, const int K, const int Kmax, const double* __restrict__ sT, const double* __restrict__ sYr,
+                                             const int2* __restrict__ sTab, const double* __restrict__ q, const double* __restrict__ xr,
+                                             const unsigned short* __restrict__ sK, const int2* __restrict__ sGrp, const int* __restrict__ sOvfp,
+                                             const RefineArgs& a, double* __restrict__ Y, int NOP, int NAP, int NA) {
+    constexpr int QS = 13;
+    const int tid = threadIdx.x;
+    const int KT = Kmax > 0 ? Kmax : 1;
+    const int sOvf = *sOvfp;
     // ---- C: Y[:, col] from the rows, then Y'' = 1.5 Y - 0.5 T Y ----------------------------------------------------------------
     double* Yo = Y + (size_t)o * NOP * NAP;
     const double* Tb = sT + 36 * Kmax;
 #pragma unroll 1
-    for (int col = tid; col < NAP; col += 256) {
+    for (int col = tid; col < NAP; col += 64 * NW) {
         if (col > NA) {
             for (int i = 0; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;
             continue;
@@ -908,6 +825,125 @@ __device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, 
         for (int i = 9 + 3 * K; i < NOP; ++i) Yo[(size_t)i * NAP + col] = 0.0;
     }
     REFINE_STAMP(6);
+}
+template <int NW>
+__device__ __forceinline__ void obj_refine_BC(const int o, const int K, const int m, const int Kmax, double* __restrict__ sT, double* __restrict__ sYr,
+                                              const int2* __restrict__ sTab, double* __restrict__ sPartR, const double* __restrict__ q,
+                                              const double* __restrict__ xr, const unsigned short* __restrict__ sList,
+                                              const unsigned short* __restrict__ sK, const int2* __restrict__ sRange, const int p0,
+                                              const int2* __restrict__ sGrp, const int* __restrict__ sOvfp, const RefineArgs& a,
+                                              double* __restrict__ Y, int NOP, int NAP, int NA) {
+    obj_refine_B<NW>(o, K, m, Kmax, sT, sYr, sPartR, q, xr, sList, sRange, p0, a);
+    obj_refine_C<NW>(o, K, Kmax, sT, sYr, sTab, q, xr, sK, sGrp, sOvfp, a, Y, NOP, NAP, NA);
+}
+
+// sR: the object's arrow factor (with the pivot tolerance); sT (arrow_stride doubles), sYr (NOP doubles): LDS scratch; rowbuf: the
+// staging of this object's rows (LDS or global), m * OBJ_REFINE_ROW_DOUBLES doubles.  All 256 threads; writes the object's block of Y.
+template <bool INLDS>
+__device__ __forceinline__ void obj_refine_body(const int o, const ObjArrow ob, const int Kmax, const double* __restrict__ sR,
+                                                double* __restrict__ sT, double* __restrict__ sYr, int2* __restrict__ sTab, double* __restrict__ sPartR,
+                                                double* rowbuf, const RefineArgs& a, double* __restrict__ Y, int NOP, int NAP, int NA) {
+    __shared__ int2 sRange[36];
+    __shared__ int2 sGrp[ORCVIO_MAX_CLONES];
+    __shared__ int sOvf;   // some (clone, keypoint) pair has more than two rows (two frames of the object share a clone, or rows handed over
+                           // through orcvio_msckf_update_objects in another shape): phase C then takes the general form
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = ob.K, m = ob.rows, row0 = ob.row0;
+    const int KT = Kmax > 0 ? Kmax : 1;   // sTab[c * KT + k] = the (at most two) positions of the rows of keypoint k in clone c, -1: none
+    const double tol = sR[36 * Kmax + 81];
+    constexpr int QS = 13;              // row stride of q: odd, so that the groups of different clones start on different LDS banks
+    double* q = rowbuf;                 // [m][QS]  3 keypoint entries, 9 border entries
+    double* xr = rowbuf + (size_t)m * QS;   // [m][7]  hx (6), r
+    typedef unsigned short u16;         // (an object has at most 2 048 rows, 34 keypoints, 60 clones)
+    u16* sPos = reinterpret_cast<u16*>(rowbuf + (size_t)m * (QS + 7));   // [m] row - row0 -> position
+    u16* sList = sPos + m;              // [m] the keypoint lists as positions
+    u16* sK = sList + m;                // [m] keypoint block of the row at a position (K: border only)
+    u16* sCl = sK + m;                  // [m] clone of the row at a position
+    REFINE_STAMP(1);
+    if (tid <= K) sRange[tid] = a.kp_range[ob.kp_off + tid];
+    if (tid < ORCVIO_MAX_CLONES) sGrp[tid] = int2{0, 0};
+    if (tid == 0) sOvf = 0;
+    for (int i = tid; i < a.N * KT; i += 256) sTab[i] = int2{-1, -1};
+    __syncthreads();
+    for (int g = tid; g < a.ngroups; g += 256) {
+        const ObjGroup gq = a.groups[g];
+        if (gq.obj == o) {
+            sGrp[gq.clone] = int2{gq.r0 - row0, gq.r1 - row0};
+            for (int lp = gq.r0 - row0; lp < gq.r1 - row0; ++lp) sCl[lp] = (u16)gq.clone;
+        }
+    }
+    // ---- P: positions, [hx | r] in group order; reciprocals of the kept pivots ---------------------------------------------------
+    if (tid < 9 + 3 * K) {
+        const double pv = tid < 9 ? sR[36 * Kmax + 10 * tid] : sR[36 * ((tid - 9) / 3) + 13 * ((tid - 9) % 3)];
+        sYr[tid] = fabs(pv) > tol ? 1.0 / pv : 0.0;
+    }
+    for (int lp = tid; lp < m; lp += 256) {
+        const int row = a.ridx[row0 + lp];
+        sPos[row - row0] = (u16)lp;
+        double v[7];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) v[e] = a.Hx6[(size_t)row * 6 + e];
+        v[6] = a.HfR[(size_t)row * a.ldf + a.no_max];
+#pragma unroll
+        for (int e = 0; e < 7; ++e) xr[lp * 7 + e] = v[e];
+    }
+    __syncthreads();
+    REFINE_STAMP(2);
+    // ---- A: the rows of Q~ (thread per entry of the keypoint lists).  (Straight-line code that runs once is bound by instruction
+    // fetch: every loop here is kept rolled except where a register array needs constant indices.) ------------------------------------
+    const int p0 = sRange[0].x, p1 = sRange[K].y;   // (the K + 1 row lists of an object are contiguous in kp_rows)
+    const double* Rb = sR + 36 * Kmax;
+    const double* sRi = sYr;   // reciprocals of the pivots (0: dropped), written in phase P: [9 border | 3 per keypoint]
+#pragma unroll 1
+    for (int p = p0 + tid; p < p1; p += 256) {
+        int k = 0;
+        while (k < K && p >= sRange[k].y) ++k;
+        const int row = a.kp_rows[p];
+        const int lp = sPos[row - row0];
+        sList[p - p0] = (u16)lp;
+        sK[lp] = (u16)k;
+        if (k < K) {   // the row's slot in the (clone, keypoint) table
+            int* slot = reinterpret_cast<int*>(sTab + (int)sCl[lp] * KT + k);
+            if (atomicCAS(slot, -1, lp) != -1 && atomicCAS(slot + 1, -1, lp) != -1) sOvf = 1;
+        }
+        const double* h = a.HfR + (size_t)row * a.ldf;
+        double hb[9], qk[3] = {0.0, 0.0, 0.0}, qb[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) hb[c] = h[c];
+        if (k < K) {
+            const double* Rk = sR + 36 * k;
+            const double* rik = sRi + 9 + 3 * k;
+            double hk[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) hk[j] = h[9 + 3 * k + j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double t = hk[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (i < j) t -= qk[i] * Rk[12 * i + j];
+                qk[j] = t * rik[j];
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) hb[c] -= (qk[0] * Rk[3 + c] + qk[1] * Rk[15 + c]) + qk[2] * Rk[27 + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            double t = hb[j];
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i < j) t -= qb[i] * Rb[9 * i + j];
+            qb[j] = t * sRi[j];
+        }
+        double* qo = q + lp * QS;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) qo[j] = qk[j];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) qo[3 + j] = qb[j];
+    }
+    __syncthreads();
+    REFINE_STAMP(3);
+    obj_refine_BC<4>(o, K, m, Kmax, sT, sYr, sTab, sPartR, q, xr, sList, sK, sRange, p0, sGrp, &sOvf, a, Y, NOP, NAP, NA);
 }
 // sDyn: [factor (arrow_stride) | T (arrow_stride) | Q~^T r (NOP) | (clone, keypoint) table (N * max(Kmax, 1) int2) | row staging
 // (lds_rows * OBJ_REFINE_ROW_DOUBLES)]; the factor is in place.

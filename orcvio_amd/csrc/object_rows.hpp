@@ -50,13 +50,21 @@ __device__ __forceinline__ void mat4_vec(const double* T, const double* x, doubl
     for (int i = 0; i < 4; ++i) y[i] = T[i * 4] * x[0] + T[i * 4 + 1] * x[1] + T[i * 4 + 2] * x[2] + T[i * 4 + 3] * x[3];
 }
 
-__device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int f, const int t) {
-    const int clone = p.frame_clone[f];
-    if (clone < 0) return;
+// The rows of ONE in-window frame, one lane per row pair: lane role t < K is keypoint t (two rows if it was detected), roles
+// K..K+3 are the four bbox lines; `lpf` lanes of the wavefront (a power of two >= K + 4, or 64) belong to one frame, so that a
+// wavefront evaluates 64 / lpf frames side by side (k_obj_fused) or one (lpf = 64: k_object_rows).  f < 0: an idle lane group.
+// Every lane of the wavefront must call it (it holds a ballot).  emit(row_in_frame, r, hx6, hpose, hshape | nullptr, kp | -1,
+// hkp | nullptr, nrows_of_frame) is called once per row by the lane that owns it: hx6 = J_cam D (the row's six window columns),
+// hpose / hshape / hkp the structural non-zeros of its H_f row.
+template <class Emit>
+__device__ __forceinline__ void object_rows_lane(const ObjEvalArgs& p, const int f, const int t, const int lpf, Emit&& emit) {
+    const int clone = f >= 0 ? p.frame_clone[f] : -1;
+    const bool live = clone >= 0;
     const int K = p.K;
+    const int fq = live ? f : 0;
     // frame transforms
     double wTc[16], cTw[16], wTo[16];
-    for (int i = 0; i < 16; ++i) { wTc[i] = p.frame_wTc[(size_t)f * 16 + i]; wTo[i] = p.wTo[i]; }
+    for (int i = 0; i < 16; ++i) { wTc[i] = p.frame_wTc[(size_t)fq * 16 + i]; wTo[i] = p.wTo[i]; }
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) cTw[i * 4 + j] = wTc[j * 4 + i];
         cTw[i * 4 + 3] = -(wTc[0 * 4 + i] * wTc[3] + wTc[1 * 4 + i] * wTc[7] + wTc[2 * 4 + i] * wTc[11]);
@@ -93,43 +101,25 @@ __device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int
     // valid keypoints of this frame and their rank (row position)
     bool valid = false;
     double z0 = 0, z1 = 0;
-    if (t < K) {
+    if (live && t < K) {
         z0 = p.frame_zs[((size_t)f * K + t) * 2];
         z1 = p.frame_zs[((size_t)f * K + t) * 2 + 1];
         valid = isfinite(z0) && isfinite(z1);
     }
-    const unsigned long long mask = __ballot(valid);
+    const unsigned long long mask_all = __ballot(valid);
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned long long mask = lpf >= 64 ? mask_all : (mask_all >> ((lane / lpf) * lpf)) & ((1ull << lpf) - 1ull);
     const int nvalid = __popcll(mask);
     const int rank = __popcll(mask & ((1ull << t) - 1ull));
-    const int row0 = p.frame_row0[f];
-    const int ncol = p.ncol;
-
-    // The rows of one frame are consecutive (keypoint rows, then the four bbox rows) and mostly zero: a row written by its lane
-    // alone is ldhf scalar stores 8 * ldhf bytes apart from the next lane's (13.6 us for the 20 x 30 frames of config 3).  Up to
-    // 28 rows x 48 columns (12 keypoints) the block is put together in LDS -- zeroed by the wavefront, the ten structural
-    // non-zeros of a row written by its lane -- and streamed out with full-width stores.
-    constexpr int LDS_ROWS = 28, LDS_LD = 48;
-    __shared__ double sHf[LDS_ROWS * LDS_LD];
     const int nrows = 2 * nvalid + 4;
-    const bool via_lds = p.ldhf <= LDS_LD && nrows <= LDS_ROWS;   // (wave-uniform)
-    if (via_lds)
-        for (int i = t; i < nrows * p.ldhf; i += 64) sHf[i] = 0.0;   // (the LDS executes one wavefront's operations in order)
-    auto emit = [&](int row, double r, const double* jc, const double* hpose, const double* hshape, int kpid, const double* hkp) {
-        p.res[row] = r;
-        p.row_clone[row] = clone;
+    auto out = [&](int row_in_frame, double r, const double* jc, const double* hpose, const double* hshape, int kpid, const double* hkp) {
+        double hx6[6];
         for (int c = 0; c < 6; ++c) {
             double s = 0;
             for (int k = 0; k < 6; ++k) s += jc[k] * D[k * 6 + c];
-            p.Hx6[(size_t)row * 6 + c] = s;
+            hx6[c] = s;
         }
-        double* hf = via_lds ? sHf + (size_t)(row - row0) * p.ldhf : p.Hf + (size_t)row * p.ldhf;
-        if (!via_lds)
-            for (int c = 0; c < p.ldhf; ++c) hf[c] = 0.0;
-        if (p.rcol >= 0) hf[p.rcol] = r;
-        if (p.row_cols) p.row_cols[row] = ncol;
-        for (int c = 0; c < 6; ++c) hf[c] = hpose[c];
-        if (hshape) for (int c = 0; c < 3; ++c) hf[6 + c] = hshape[c];
-        if (hkp) for (int c = 0; c < 3; ++c) hf[9 + 3 * kpid + c] = hkp[c];
+        emit(row_in_frame, r, hx6, hpose, hshape, kpid, hkp, nrows);
     };
 
     if (valid) {
@@ -172,10 +162,10 @@ __device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int
             }
             for (int c = 0; c < 3; ++c) hk[c] = dpi[s * 3] * Rco[c] + dpi[s * 3 + 1] * Rco[3 + c] + dpi[s * 3 + 2] * Rco[6 + c];
             const double r = (s == 0 ? Xc[0] * iz - z0 : Xc[1] * iz - z1);
-            emit(row0 + 2 * rank + s, r, jc, hp, nullptr, t, hk);
+            out(2 * rank + s, r, jc, hp, nullptr, t, hk);
         }
     }
-    if (t >= K && t < K + 4) {
+    if (live && t >= K && t < K + 4) {
         // ---- bbox rows (ObjectResJacCam.cpp:308-494, ObjectLM.cpp:441-616) --------------------------------
         const int j = t - K;
         const double* bb = p.frame_bbox + (size_t)f * 4;
@@ -236,9 +226,44 @@ __device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int
             }
             for (int c = 0; c < 3; ++c) hs[c] = (corrected ? -sg : 1.0) * p.shape[c] * ub[c] * ub[c] / (bn * sq);
         }
-        emit(row0 + 2 * nvalid + j, r, jc, hp, hs, 0, nullptr);
+        out(2 * nvalid + j, r, jc, hp, hs, -1, nullptr);
     }
-    if (via_lds) {
+}
+
+// One wavefront per in-window frame, rows to the compact row arrays in device memory (k_object_rows / k_object_rows_batch).
+__device__ __forceinline__ void object_rows_body(const ObjEvalArgs& p, const int f, const int t) {
+    const int clone = p.frame_clone[f];
+    if (clone < 0) return;   // (wave-uniform)
+    const int row0 = p.frame_row0[f];
+    const int ncol = p.ncol;
+    // The rows of one frame are consecutive (keypoint rows, then the four bbox rows) and mostly zero: a row written by its lane
+    // alone is ldhf scalar stores 8 * ldhf bytes apart from the next lane's (13.6 us for the 20 x 30 frames of config 3).  Up to
+    // 28 rows x 48 columns (12 keypoints) the block is put together in LDS -- zeroed by the wavefront, the ten structural
+    // non-zeros of a row written by its lane -- and streamed out with full-width stores.
+    constexpr int LDS_ROWS = 28, LDS_LD = 48;
+    __shared__ double sHf[LDS_ROWS * LDS_LD];
+    const bool small = p.ldhf <= LDS_LD && 2 * p.K + 4 <= LDS_ROWS;   // (wave-uniform; the frame's own row count is at most 2 K + 4)
+    if (small)
+        for (int i = t; i < (2 * p.K + 4) * p.ldhf; i += 64) sHf[i] = 0.0;   // (the LDS executes one wavefront's operations in order)
+    int nrows_frame = 0;
+    object_rows_lane(p, f, t, 64, [&](int rif, double r, const double* hx6, const double* hpose, const double* hshape, int kpid, const double* hkp, int nrows) {
+        const int row = row0 + rif;
+        nrows_frame = nrows;
+        p.res[row] = r;
+        p.row_clone[row] = clone;
+        for (int c = 0; c < 6; ++c) p.Hx6[(size_t)row * 6 + c] = hx6[c];
+        double* hf = small ? sHf + (size_t)rif * p.ldhf : p.Hf + (size_t)row * p.ldhf;
+        if (!small)
+            for (int c = 0; c < p.ldhf; ++c) hf[c] = 0.0;
+        if (p.rcol >= 0) hf[p.rcol] = r;
+        if (p.row_cols) p.row_cols[row] = ncol;
+        for (int c = 0; c < 6; ++c) hf[c] = hpose[c];
+        if (hshape) for (int c = 0; c < 3; ++c) hf[6 + c] = hshape[c];
+        if (hkp) for (int c = 0; c < 3; ++c) hf[9 + 3 * kpid + c] = hkp[c];
+    });
+    if (small) {
+        // the frame's row count: the bbox lanes know it (they always emit); lane K broadcasts
+        const int nrows = __shfl(nrows_frame, p.K);
         double* dst = p.Hf + (size_t)row0 * p.ldhf;
         for (int i = t; i < nrows * p.ldhf; i += 64) dst[i] = sHf[i];
     }
