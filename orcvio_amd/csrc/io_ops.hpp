@@ -40,6 +40,8 @@ struct EpilogueArgs {
     const double* Z; int ldz, kf, n; double sigma;
     const double* prior; long sLi, sLj; double* Sout; int ldo;
     const double* dx; const int* info;
+    const int* accept;            // optional (gated object update): *accept == 0 -> the update was rejected by its chi-square gate: P+ = P
+                                  // stands in Pout already (k_finish_sqrt), the factor to keep is the prior's own
     int* counter;                 // device memory, zero between launches
     unsigned long long* seq;      // device memory: publications so far
     unsigned long long* flag;     // host-coherent memory: the caller waits for *flag >= its expected sequence number
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
         if (bad) s_bad = 1;
         __syncthreads();
         const bool refused = a.info[2] != 0 || a.info[3] != 0 || a.info[8] != 0 || s_bad != 0;
-        const bool applied = a.info[2] == 0 && a.info[3] == 0;
+        const bool applied = a.info[2] == 0 && a.info[3] == 0 && (a.accept == nullptr || *a.accept != 0);
         const int nbc = nb - 1 - a.nb_P, bc = b - 1 - a.nb_P;
         const size_t stride = (size_t)nbc * 256;
         if (!refused)

@@ -126,6 +126,11 @@ struct orcvio_msckf_handle {
     int obj_refined = 0;                // objects of the last downloaded object update that took the explicit-basis projection (k_obj_refine)
     size_t obj_fused_budget = 0;        // dynamic LDS a workgroup of k_obj_fused may take on this device (0: not asked yet)
     int obj_fused_opt = 1;              // ORCVIO_OBJ_FUSED=0: object tracks always through the three-launch pipeline (rows materialised)
+    unsigned* d_obj_done = nullptr;     // completion counter of k_gemm_objA (cumulative; never reset)
+    unsigned obj_done_total = 0u;       // what that counter reads once every compression enqueued so far has finished
+    const unsigned* join_wait = nullptr;   // the next ST_FORM_U product polls this counter (frame call) ...
+    unsigned join_expect = 0u;          // ... until it reaches this value
+    bool obj_early_done = false;        // orcvio_msckf_io_update_frame has enqueued this update's compression already (objects_local_tracks skips it)
     bool obj_last_fused = false;        // the last object update from tracks took the one-launch compression
     size_t obj_lds_budget = 0;          // dynamic LDS the border launch of the object update may take on THIS handle's device (0: not asked yet)
     bool arrow_opt = true;              // ORCVIO_OPT_OBJECT_QR: structured Householder QR of Hf (0: chol(Hf^T Hf), round 1's route)

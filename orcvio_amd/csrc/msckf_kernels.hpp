@@ -1957,9 +1957,26 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
 __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
                                               long sBk, long sBj, int M, int N, int K, double alpha, double diag_add,
                                               int upper_only, double* __restrict__ C, long sCi, long sCj,
-                                              const double* __restrict__ Cin = nullptr, int* __restrict__ clear = nullptr) {
+                                              const double* __restrict__ Cin = nullptr, int* __restrict__ clear = nullptr,
+                                              const unsigned* __restrict__ wait = nullptr, unsigned expect = 0u, int* __restrict__ lost = nullptr,
+                                              int spin_limit = 0) {
     // clear: step counter of the k_potrf_solve launch that follows in the stream (reset here, one kernel ahead)
     if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // wait: completion counter of a launch on ANOTHER stream whose output this product reads (the frame call: A' of the objects'
+    // compression, k_gemm_objA).  A stream-level join (hipStreamWaitEvent) costs ~10 us of dispatch even when the event fired long ago;
+    // one relaxed poll per workgroup costs nothing when it did.  Bounded: a count that never comes sets *lost (the update is void).
+    if (wait) {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while ((int)(__hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
+                if (++spins > spin_limit) { if (lost) atomicExch(lost, 1); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
     __shared__ double sPart[3][4][64];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int ntj = (N + 15) >> 4;

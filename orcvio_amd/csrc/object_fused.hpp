@@ -623,7 +623,10 @@ __global__ __launch_bounds__(512) void k_obj_fused(ObjFusedArgs fa) {
 // A' = sum_o B_o - Y^T Y with B assembled on the fly from the clone tiles (obj_assemble_B_body's entries): one workgroup of eight
 // wavefronts per 16 x 16 tile, split-K over the wavefronts (K = nobj * NOP rows of Y), partial tiles summed through LDS in wave order.
 __global__ __launch_bounds__(512) void k_gemm_objA(const double* __restrict__ Y, int NAP, int Krows, const double* __restrict__ Sg, int nobj, int N,
-                                                   const double* __restrict__ rr, int rr_stride, int cb0, int NA, double* __restrict__ dst) {
+                                                   const double* __restrict__ rr, int rr_stride, int cb0, int NA, double* __restrict__ dst,
+                                                   unsigned* __restrict__ done) {
+    // done: completion counter (one count per workgroup, behind its stores and an agent-scope release): what the object solve's first
+    // launch polls instead of a stream-level join (k_gemm `wait`)
     __shared__ double sPart[7][4][64];
     __shared__ double sBsum[4][64];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -674,6 +677,14 @@ __global__ __launch_bounds__(512) void k_gemm_objA(const double* __restrict__ Y,
         for (int w = 0; w < 7; ++w) v += sPart[w][r][l];
         const int i = 16 * bi + kk + 4 * r, j = 16 * bj + cc;
         dst[(size_t)i * NAP + j] = sBsum[r][l] - v;
+    }
+    if (done) {   // (one wavefront stored the tile: its own wait covers every store of the workgroup)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (l == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

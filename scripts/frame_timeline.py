@@ -18,7 +18,7 @@ for name, a, b in ev:
         cur = []
     cur.append((name, a, b))
 if cur: frames.append(cur)
-frames = [f for f in frames if any(n == 'k_object_rows_batch' for n, _, _ in f) and any(n.startswith('k_front') for n, _, _ in f)][5:]
+frames = [f for f in frames if any(n in ('k_object_rows_batch', 'k_obj_fused') for n, _, _ in f) and any(n.startswith('k_front') for n, _, _ in f)][5:]
 sig = max(set(tuple(n for n, _, _ in f) for f in frames), key=lambda s: sum(1 for f in frames if tuple(n for n, _, _ in f) == s))
 sel = [f for f in frames if tuple(n for n, _, _ in f) == sig]
 out = dict(frames=len(sel), kernels=[])
@@ -28,12 +28,14 @@ for i, name in enumerate(sig):
     out['kernels'].append(dict(kernel=name, start_us=round(st, 2), end_us=round(en, 2)))
 names = list(sig)
 feat_end = next(k['end_us'] for k in out['kernels'] if k['kernel'] == 'k_epilogue')
-obj = [k for k in out['kernels'] if k['kernel'] in ('k_object_rows_batch', 'k_obj_front') or k['kernel'].startswith('k_obj_border')]
+obj = [k for k in out['kernels'] if k['kernel'] in ('k_object_rows_batch', 'k_obj_front', 'k_obj_fused', 'k_gemm_objA') or k['kernel'].startswith('k_obj_border')]
 gemmA = None
 # the k_gemm that follows the border kernel is A' = sum B - Y^T Y
 for i, k in enumerate(out['kernels']):
     if k['kernel'].startswith('k_obj_border'):
         gemmA = out['kernels'][i + 1]
+    if k['kernel'] == 'k_gemm_objA':   # (round 5: the one-launch compression is followed by its own product kernel)
+        gemmA = k
 comp_start = min(k['start_us'] for k in obj)
 comp_end = gemmA['end_us'] if gemmA else max(k['end_us'] for k in obj)
 out['feature_half_done_us'] = feat_end
