@@ -278,6 +278,34 @@ def config_table(upd, capi, synth, orc, reps, cpu_budget_s):
             what='orcvio_msckf_io_update_frame: 500 tracks + 25 objects, both updates committed, host tracks in, dx out twice')
     except Exception as ex:
         out['config4_one_rank_share']['objects'] = dict(error=repr(ex))
+    # BASELINE config 5 as it is WORDED ("bbox-only OrcVIO-lite"): beside the 2 000 tracks under kitti_raw.yaml's flags, 100 object
+    # tracks WITHOUT keypoints -- object state [pose 6 | shape 3], four bbox rows per in-window frame.  A labelled extension: the
+    # reference's lite mode sends no residuals at all (SURVEY note N4: config5_one_gpu above is that reading).
+    try:
+        import ctypes as C
+        import numpy as np
+        w5 = synth.config_window(5)
+        oflags = synth.Flags(use_larvio=0, use_left_perturbation=0, noise_feature=w5.flags.noise_feature)
+        owin = synth.make_window(N=w5.N, F=4, seed=0, flags=oflags, track_len=4)
+        objs = synth.make_objects(owin, n_objects=100, seed=6, sigma_kp=0.004, bbox_only=True)
+        ofl = capi.make_flags(oflags)
+        ef, arr, keep = upd._object_tracks(objs, owin.R_b2c[0], owin.t_c_b[0], True, False, 0, False)
+        upd.cov_set(owin.P); upd.cov_prefactor(); upd.sync()
+        o2, res2 = upd._result(owin.n, 1)
+        res2.P_out = None
+
+        def bbox_resident():
+            assert upd.lib.orcvio_msckf_update_object_tracks(upd.h, C.byref(ofl), C.byref(ef), owin.N, arr, len(objs), None, C.byref(res2)) == 0
+        lat = percentiles(timed_calls(bbox_resident, reps, warm=5))
+        out['config5_bbox_only'] = dict(
+            what='EXTENSION, not reference behaviour (SURVEY note N4): 100 bbox-only object tracks (no keypoints: object state 9 columns, 4 rows '
+                 'per frame) x 30 frames = 12 000 rows, orcvio_msckf_update_object_tracks on the resident covariance; the 2 000-track feature '
+                 'update of the same frame is config5_one_gpu',
+            objects=100, rows=int(sum(4 * sum(1 for fr in ob.frames if fr['clone'] >= 0) for ob in objs)), accepted=int(o2['accept'][0]),
+            dof=int(res2.stats[0]), one_launch_compression=upd.counters()['obj_fused'], host_visible_resident_cov=lat,
+            frame_ms_with_the_feature_update=round(out['config5_one_gpu']['host_visible_resident_cov']['median_ms'] + lat['median_ms'], 5))
+    except Exception as ex:
+        out['config5_bbox_only'] = dict(error=repr(ex))
     return out, cases
 
 

@@ -430,7 +430,10 @@ typedef struct orcvio_object_eval_flags {
 } orcvio_object_eval_flags;
 
 typedef struct orcvio_object_track {
-    int32_t n_keypoints;        /* K (12 for the car class, config/object_feat_unity.yaml)              */
+    int32_t n_keypoints;        /* K (12 for the car class, config/object_feat_unity.yaml).  K = 0: a BBOX-ONLY track -- object state
+                                   [pose 6 | shape 3], four bbox rows per in-window frame (src/obj/ObjectResJacCam.cpp:308-519 alone), H_f
+                                   has 9 columns; kps / frame_zs are not read.  An EXTENSION (BASELINE config 5's "bbox-only OrcVIO-lite"
+                                   read literally): the reference's lite mode sends no residuals at all (SURVEY note N4) */
     int32_t n_frames;
     const double* wTo;          /* [16] row-major object -> world                                        */
     const double* shape;        /* [3]  ellipsoid semi-axes                                              */

@@ -818,13 +818,18 @@ class MsckfUpdater:
         for k, obj in enumerate(objs):
             wTo = np.ascontiguousarray(obj.wTo, dtype=np.float64)
             shape = np.ascontiguousarray(obj.shape, dtype=np.float64)
-            kps = np.ascontiguousarray(obj.kps, dtype=np.float64)
+            kps = np.ascontiguousarray(np.asarray(obj.kps, dtype=np.float64).reshape(-1, 3))
+            K = kps.shape[0]
             wTc = np.ascontiguousarray(np.stack([fr['wTc'] for fr in obj.frames]), dtype=np.float64)
-            zs = np.ascontiguousarray(np.stack([fr['zs'] for fr in obj.frames]), dtype=np.float64)
             bb = np.ascontiguousarray(np.stack([fr['bbox'] for fr in obj.frames]), dtype=np.float64)
             cl = np.ascontiguousarray([fr['clone'] for fr in obj.frames], dtype=np.int32)
+            if K == 0:   # bbox-only track: no keypoints (the library reads neither kps nor frame_zs; one-element dummies keep the pointers valid)
+                kps = np.zeros((1, 3))
+                zs = np.zeros((len(obj.frames), 1, 2))
+            else:
+                zs = np.ascontiguousarray(np.stack([np.asarray(fr['zs'], dtype=np.float64).reshape(-1, 2) for fr in obj.frames]))
             keep += [wTo, shape, kps, wTc, zs, bb, cl]
-            arr[k] = ObjectTrackC(kps.shape[0], len(obj.frames), _d(wTo), _d(shape), _d(kps), _d(wTc), _d(zs), _d(bb), _i(cl))
+            arr[k] = ObjectTrackC(K, len(obj.frames), _d(wTo), _d(shape), _d(kps), _d(wTc), _d(zs), _d(bb), _i(cl))
         return fl, arr, keep
 
     def update_object_tracks(self, flags, n_clones, objs, P, R_b2c, t_c_b, obj_left, new_bbox, vio_left, fix_D=False, want_G=False):

@@ -358,7 +358,9 @@ def camera_poses(win: Window) -> np.ndarray:
 
 
 def make_objects(win: Window, n_objects: int = 20, seed: int = 0, missing_frac: float = 0.1,
-                 frames_per_object=None, sigma_kp: float | None = None) -> list:
+                 frames_per_object=None, sigma_kp: float | None = None, bbox_only: bool = False) -> list:
+    """bbox_only: object tracks WITHOUT keypoints (object state [pose 6 | shape 3], four bbox rows per frame) -- BASELINE config 5's
+    "bbox-only OrcVIO-lite" read literally; an extension, the reference's lite mode sends no residuals at all (SURVEY note N4)."""
     rng = np.random.default_rng(seed + 7919)
     sig = win.flags.noise_feature if sigma_kp is None else sigma_kp
     wTc = camera_poses(win)
@@ -398,5 +400,9 @@ def make_objects(win: Window, n_objects: int = 20, seed: int = 0, missing_frac: 
             cuv = Cc[:, :2] / Cc[:, 2:3]
             bbox = np.array([cuv[:, 0].min(), cuv[:, 1].min(), cuv[:, 0].max(), cuv[:, 1].max()]) + sig * rng.standard_normal(4)
             frames.append(dict(clone=int(i), wTc=wTc[i].copy(), zs=zs, bbox=bbox))
+        if bbox_only:
+            kps_est = np.zeros((0, 3))
+            for fr in frames:
+                fr['zs'] = np.zeros((0, 2))
         objs.append(ObjectTrack(wTo=T_est, shape=shape, kps=kps_est, frames=frames))
     return objs

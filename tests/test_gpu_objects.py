@@ -453,3 +453,57 @@ def test_object_gate_degrees_of_freedom_option(upd):
         if found >= 6:
             break
     assert found >= 3
+
+
+# ---- bbox-only object tracks (BASELINE config 5's "bbox-only OrcVIO-lite" read literally; an extension: SURVEY note N4) -----------
+@pytest.mark.parametrize('fused', [1, 0])
+@pytest.mark.parametrize('n_objects,frames,obj_left,new_bbox,vio_left', [
+    (1, 3, True, False, 0), (3, 8, False, False, 0), (8, 30, True, True, 0), (4, 12, False, True, 1), (2, 30, True, 2, 0), (5, 2, True, False, 0)])
+def test_bbox_only_object_tracks(built, monkeypatch, fused, n_objects, frames, obj_left, new_bbox, vio_left):
+    """Object tracks WITHOUT keypoints (n_keypoints = 0): object state [pose 6 | shape 3], four bbox rows per in-window frame
+    (src/obj/ObjectResJacCam.cpp:308-519 alone), projected against the 9-column H_f, joint gate -- against the mirror, through the
+    one-launch compression (k_obj_fused) and through the three-launch pipeline (ORCVIO_OBJ_FUSED=0); old / new / corrected bbox
+    residual, both perturbations, 1-8 objects x 2-30 frames.  Two frames give 8 rows <= 9 columns: the reference's projection
+    returns false (math_utils.hpp:292) and the object contributes nothing."""
+    monkeypatch.setenv('ORCVIO_OBJ_FUSED', str(fused))
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=64, max_observations=1024)
+    try:
+        flags = synth.Flags(use_larvio=0, use_left_perturbation=vio_left)
+        win = synth.make_window(N=30, F=4, seed=21 + frames, flags=flags, track_len=4)
+        objs = synth.make_objects(win, n_objects=n_objects, seed=3 + n_objects, sigma_kp=0.004, bbox_only=True,
+                                  frames_per_object=None if frames == 30 else frames)
+        assert all(len(o.kps) == 0 for o in objs)
+        # the rows of one track against the mirror's
+        Hx, Hf, r, rc, hx6 = _rows_for(win, objs[0], obj_left, new_bbox, vio_left)
+        ev = u.object_rows_eval(objs[0], win.R_b2c[0], win.t_c_b[0], obj_left, new_bbox, vio_left)
+        assert ev['Hf'].shape == Hf.shape == (4 * frames, 9)
+        assert rel(ev['Hf'], Hf) < 1e-10 and rel(ev['res'], r) < 1e-9 and rel(ev['Hx6'], hx6) < 1e-10 and list(ev['row_clone']) == list(rc)   # (the bars of test_object_rows_eval_matches_mirror)
+        ref = objects_update_reference(win, objs, win.P, obj_left, new_bbox, vio_left, full_nullspace=True)
+        got = u.update_object_tracks(flags, win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], obj_left, new_bbox, vio_left)
+        assert got['accept'] == ref['accept'] and got['stats'][0] == (ref['dof'] if ref['accept'] else 0)
+        if frames >= 3:
+            assert u.counters()['obj_fused'] == fused
+            assert abs(got['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+        if ref['accept']:
+            assert rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL
+        else:
+            assert not got['dx'].any() and rel(got['P_new'], win.P) < 1e-15
+    finally:
+        u.close()
+
+
+def test_bbox_only_tracks_beside_keypoint_tracks_in_one_update(built):
+    """Mixed update: cars with twelve keypoints and bbox-only tracks in the same call (different object-state widths, per-object
+    projection), against the mirror."""
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=64, max_observations=1024)
+    try:
+        flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+        win = synth.make_window(N=20, F=4, seed=5, flags=flags, track_len=4)
+        objs = synth.make_objects(win, n_objects=3, seed=8, sigma_kp=0.004) + synth.make_objects(win, n_objects=4, seed=9, sigma_kp=0.004, bbox_only=True)
+        ref = objects_update_reference(win, objs, win.P, True, False, 0, full_nullspace=True)
+        got = u.update_object_tracks(flags, win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+        assert got['accept'] == ref['accept'] == 1 and got['stats'][0] == ref['dof']
+        assert abs(got['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+        assert rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL
+    finally:
+        u.close()
