@@ -47,7 +47,13 @@ static thread_local std::string g_last_error;
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static void so3_exp_decl(const double w[3], double R[9]);   // Sophus SO3d::exp (defined with incrementState_IMUCam below)
 
-struct ObjUse { int t, row0, rows, ncol; size_t off_d, off_i; };   // a usable object track of the current object update
+struct ObjUse {   // a usable object track of the current object update
+    int t, row0, rows, ncol;
+    size_t off_d, off_i;
+    int fin;        // in-window frames
+    int distinct;   // 1: every in-window frame on a clone of its own (the one-launch compression's condition)
+    size_t off_nv;  // first entry of the track's per-frame keypoint counts in the handle's obj_nv (-1 entries: frame not in the window)
+};
 
 struct IpcComm;
 struct orcvio_msckf_handle {
@@ -130,6 +136,7 @@ struct orcvio_msckf_handle {
     unsigned obj_done_total = 0u;       // what that counter reads once every compression enqueued so far has finished
     const unsigned* join_wait = nullptr;   // the next ST_FORM_U product polls this counter (frame call) ...
     unsigned join_expect = 0u;          // ... until it reaches this value
+    int early_rows_tot = 0, early_no_max = 0, early_dof = 0, early_Fmax = 1; size_t early_nd = 0, early_ni = 0;   // ... and what its scan of the tracks found
     bool obj_early_done = false;        // orcvio_msckf_io_update_frame has enqueued this update's compression already (objects_local_tracks skips it)
     bool obj_last_fused = false;        // the last object update from tracks took the one-launch compression
     size_t obj_lds_budget = 0;          // dynamic LDS the border launch of the object update may take on THIS handle's device (0: not asked yet)
@@ -227,6 +234,7 @@ struct orcvio_msckf_handle {
     size_t obj_stage_cap = 0;
     std::vector<ObjUse> obj_use;        // (objects_local_tracks: per-track records, kept across calls: no allocation per frame)
     std::vector<int> obj_fnr;           // rows of every frame of the track being staged
+    std::vector<signed char> obj_nv;    // (objects_tracks_scan) detected keypoints of every frame of every usable track: the ONE pass over the observations
     std::vector<int> obj_rowkp, obj_Ks; // keypoint block of every row / keypoint count of every object (structured QR of Hf)
     std::vector<unsigned long long> obj_vmask;   // (objects_local_tracks) observed keypoints of every frame of the track being staged
     // per-stage device times of the last object update (orcvio_msckf_profile_stages): events recorded between the stages
