@@ -1217,11 +1217,11 @@ __global__ __launch_bounds__(1024) void k_potrf(double* __restrict__ A, int n, i
 // generic small FP64-MFMA product: one wavefront per 16x16 output tile.
 //   C[i][j] = sum_k A(i,k) * B(k,j),  A(i,k) = A[i*sAi + k*sAk], B(k,j) = B[k*sBk + j*sBj]
 // ---------------------------------------------------------------------------------------
+template <int TP_BATCH = 12>
 __device__ __forceinline__ d4 tile_product(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
                                            long sBk, long sBj, int M, int N, int K, int i0, int j0, int l) {
     // Operands of TP_BATCH k-steps are loaded before the first MFMA of the batch: the kernels built on
     // this are latency-bound (one tile per wavefront), so loads must be in flight together.
-    constexpr int TP_BATCH = 12;
     // Out-of-range rows / columns are loaded from a clamped (valid) address and zeroed by a select (a
     // predicated load is a branch and serialises the loads); full batches advance plain pointers, only the
     // K tail pays for index clamping.

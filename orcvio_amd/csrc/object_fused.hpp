@@ -663,7 +663,8 @@ __global__ __launch_bounds__(512) void k_gemm_objA(const double* __restrict__ Y,
     const int KS = (((Krows + 7) >> 3) + 3) & ~3;   // k-slice per wavefront, a multiple of the MFMA depth
     const int k0 = wave * KS;
     const int Kw = (Krows - k0 < KS) ? (Krows - k0) : KS;
-    d4 acc = tile_product(Y + (long)k0 * NAP, 1L, (long)NAP, Y + (long)k0 * NAP, (long)NAP, 1L, NAP, NAP, Kw, 16 * bi, 16 * bj, l);
+    // (a slice of 120 rows -- twenty cars -- is ONE batch of loads: three dependent round trips to L2 were most of this launch's 13 us)
+    d4 acc = tile_product<32>(Y + (long)k0 * NAP, 1L, (long)NAP, Y + (long)k0 * NAP, (long)NAP, 1L, NAP, NAP, Kw, 16 * bi, 16 * bj, l);
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sPart[wave - 1][r][l] = acc[r];
@@ -678,14 +679,14 @@ __global__ __launch_bounds__(512) void k_gemm_objA(const double* __restrict__ Y,
         const int i = 16 * bi + kk + 4 * r, j = 16 * bj + cc;
         dst[(size_t)i * NAP + j] = sBsum[r][l] - v;
     }
-    if (done) {   // (one wavefront stored the tile: its own wait covers every store of the workgroup)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (l == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    (void)done;
+}
+// "the compression enqueued as number `value` is complete": one store, in a launch of its own BEHIND k_gemm_objA on the same stream -- the
+// kernel boundary makes A' visible device-wide before the word changes.  (Counting the finished workgroups inside k_gemm_objA needed an
+// agent-scope release -- an L2 write-back -- per workgroup: 6 of that launch's 13 us.)  The object solve's first product polls the word
+// (k_gemm `wait`): no stream-level join.
+__global__ __launch_bounds__(64) void k_obj_done(unsigned* __restrict__ done, unsigned value) {
+    if (threadIdx.x == 0) __hip_atomic_store(done, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace orcvio_amd

@@ -70,33 +70,28 @@ __device__ __forceinline__ void object_rows_lane(const ObjEvalArgs& p, const int
         cTw[i * 4 + 3] = -(wTc[0 * 4 + i] * wTc[3] + wTc[1 * 4 + i] * wTc[7] + wTc[2 * 4 + i] * wTc[11]);
     }
     cTw[12] = cTw[13] = cTw[14] = 0.0; cTw[15] = 1.0;
-    // D = d(camera se3) / d(IMU [theta, p])
-    double D[36];
-    for (int i = 0; i < 36; ++i) D[i] = 0.0;
+    // D = d(camera se3) / d(IMU [theta, p]) (get_cam_wrt_imu_se3_jacobian, se3_ops.hpp:531-552) in its 3 x 3 blocks
+    //     D = [ D00  D01 ]      right perturbation: D00 = -R_b2c skew(t_c_b), D01 = R_w2c, D10 = R_b2c
+    //         [ D10   0  ]      left perturbation:  D00 = skew(t_b_w),        D01 = I,     D10 = I
+    // Only D00 is kept per lane (D10 is uniform or the identity, D01 is the rotation of cTw or the identity): the 36-entry matrix,
+    // more than half of it zeros, cost 72 registers that the one-launch compression (k_obj_fused: 256 per lane) did not have.
+    double D00[9];
     if (p.fix_D) {
-        for (int i = 0; i < 6; ++i) D[i * 6 + i] = 1.0;
-    } else {
-        double v[3], tbw[3], S[9];
+        for (int i = 0; i < 9; ++i) D00[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    } else if (p.vio_left) {
+        double v[3], tbw[3];
         for (int i = 0; i < 3; ++i) v[i] = -(p.R_b2c[i * 3] * p.t_c_b[0] + p.R_b2c[i * 3 + 1] * p.t_c_b[1] + p.R_b2c[i * 3 + 2] * p.t_c_b[2]);
         for (int i = 0; i < 3; ++i) tbw[i] = wTc[i * 4] * v[0] + wTc[i * 4 + 1] * v[1] + wTc[i * 4 + 2] * v[2] + wTc[i * 4 + 3];
-        if (p.vio_left) {
-            skew3d(tbw, S);
-            for (int i = 0; i < 3; ++i) {
-                for (int j = 0; j < 3; ++j) D[i * 6 + j] = S[i * 3 + j];
-                D[(3 + i) * 6 + i] = 1.0;
-                D[i * 6 + 3 + i] = 1.0;
+        skew3d(tbw, D00);
+    } else {
+        double S[9];
+        skew3d(p.t_c_b, S);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += p.R_b2c[i * 3 + k] * S[k * 3 + j];
+                D00[i * 3 + j] = -s;
             }
-        } else {
-            skew3d(p.t_c_b, S);
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) {
-                    double s = 0;
-                    for (int k = 0; k < 3; ++k) s += p.R_b2c[i * 3 + k] * S[k * 3 + j];
-                    D[i * 6 + j] = -s;
-                    D[(3 + i) * 6 + j] = p.R_b2c[i * 3 + j];
-                    D[i * 6 + 3 + j] = cTw[i * 4 + j];   // R_w2c
-                }
-        }
     }
     // valid keypoints of this frame and their rank (row position)
     bool valid = false;
@@ -113,11 +108,15 @@ __device__ __forceinline__ void object_rows_lane(const ObjEvalArgs& p, const int
     const int rank = __popcll(mask & ((1ull << t) - 1ull));
     const int nrows = 2 * nvalid + 4;
     auto out = [&](int row_in_frame, double r, const double* jc, const double* hpose, const double* hshape, int kpid, const double* hkp) {
-        double hx6[6];
-        for (int c = 0; c < 6; ++c) {
-            double s = 0;
-            for (int k = 0; k < 6; ++k) s += jc[k] * D[k * 6 + c];
-            hx6[c] = s;
+        double hx6[6];   // = jc D, block by block (the terms that multiply D's zero block are left out: they add exact zeros)
+        for (int c = 0; c < 3; ++c) {
+            const double a = (jc[0] * D00[c] + jc[1] * D00[3 + c]) + jc[2] * D00[6 + c];
+            if (p.fix_D) { hx6[c] = a; hx6[3 + c] = jc[3 + c]; }
+            else if (p.vio_left) { hx6[c] = a + jc[3 + c]; hx6[3 + c] = jc[c]; }
+            else {
+                hx6[c] = a + ((jc[3] * p.R_b2c[c] + jc[4] * p.R_b2c[3 + c]) + jc[5] * p.R_b2c[6 + c]);
+                hx6[3 + c] = (jc[0] * cTw[c] + jc[1] * cTw[4 + c]) + jc[2] * cTw[8 + c];   // D01 = R_w2c
+            }
         }
         emit(row_in_frame, r, hx6, hpose, hshape, kpid, hkp, nrows);
     };
