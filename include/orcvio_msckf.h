@@ -747,6 +747,13 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
  *   ORCVIO_RCCL_LIB         path of the RCCL library to dlopen first (then librccl.so.1 / librccl.so by the loader's search -- an already
  *                           loaded one, e.g. torch's bundled copy, wins --, then /opt/rocm/lib)
  *   ORCVIO_FRAME_OVERLAP    0: orcvio_msckf_io_update_frame runs its two halves one behind the other
+ *   ORCVIO_FRAME_GRAPH      1: the frame call's feature half as a replayed launch graph (default: plain launches, with the objects'
+ *                           compression enqueued in the middle of them: a graph's completion marker delays the object solve by ~14 us)
+ *   ORCVIO_FRAME_EVENT_JOIN 1: the frame call's object solve joins the compression's stream with an event (default: its first product
+ *                           polls the compression's completion word: a stream-level join costs ~10 us of dispatch even when long satisfied)
+ *   ORCVIO_OBJ_FUSED        0: object tracks always through the three-launch compression over materialised rows (default 1: the one-launch
+ *                           compression k_obj_fused whenever every track qualifies, orcvio_msckf_counters [5])
+ *   ORCVIO_FUSED_STAMPS     phase stamps of k_obj_fused (object 0) on stderr
  *   ORCVIO_EARLY_INGEST     0: the whole arena is pulled by the ingest node of the launch graph (no early pull under the validation)
  *   ORCVIO_REV_PRIOR        0: plain Cholesky of the prior (M keeps its 15 IMU columns)
  *   ORCVIO_SPLIT_TRACKS     track count from which the tracks front end is two launches (default 1800; 0: never)
