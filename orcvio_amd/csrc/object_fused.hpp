@@ -36,6 +36,7 @@ struct ObjFusedArgs {
     int* info;                  // [0] += dropped pivots, [1] += objects above OBJ_REFINE_COND (mode 1) / all objects (mode 2)
     int mode;                   // ORCVIO_OPT_OBJECT_REFINE (1 or 2; 0 never comes here)
     unsigned long long* stamps; // diagnostics: wall-clock stamps of object 0's phases
+    double* dbg;                // diagnostics (ORCVIO_FUSED_DBG): [64] pivots of object 0 (9 border, 3 per keypoint), then the tolerance
 };
 #define FUSED_STAMP(i) do { if (fa.stamps && o == 0 && threadIdx.x == 0) fa.stamps[i] = wall_clock64(); } while (0)
 
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(512) void k_obj_fused(ObjFusedArgs fa) {
     // (unused keypoint blocks of the factor -- objects with fewer keypoints than Kmax -- read as zero)
     for (int i = 36 * K + tid; i < 36 * Kmax; i += 64 * NW) sR[i] = 0.0;
     __syncthreads();
-    // pivot tolerance (1e-11 of the largest pivot, obj_border_qr_body), dropped pivots, reciprocals of the kept ones [9 border | 3 per
+    // pivot tolerance, dropped pivots, reciprocals of the kept ones [9 border | 3 per
     // keypoint]: wavefront 0, one pivot per lane (9 + 3 K <= 57)
     if (wave == 0) {
         const bool has = lane < 9 + 3 * K;
@@ -328,9 +329,15 @@ __global__ __launch_bounds__(512) void k_obj_fused(ObjFusedArgs fa) {
         double mx = fabs(pv);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
-        const double tol0 = 1e-11 * mx;
+        // 1e-10 of the largest pivot.  The three-launch pipeline drops at 1e-11 (obj_border_qr_body: real pivots of the reference's own
+        // car stay above 4e-9 of the largest, the noise pivot of an exactly dependent border column had reached 1e-13 in its soaks).  Here
+        // the soak met a noise pivot of 1.03e-11 (scripts/gpu_soak_objects.py seed 90033: a car seen in two frames, H_f of rank 44 with
+        // a next-to-last pivot of 1.3e-7 that amplifies the rounding of the last) -- kept, it is a garbage column of the basis and the
+        // update came back 3 % off.  A factor 10 above that noise, 40 below the smallest real pivot met.
+        const double tol0 = 1e-10 * mx;
         const bool kept = fabs(pv) > tol0;
         const int dropped = __popcll(__ballot(has && !kept));
+        if (fa.dbg && o == 0) { fa.dbg[lane] = has ? pv : 0.0; if (lane == 0) fa.dbg[64] = tol0; }
         if (has) sYr[lane] = kept ? 1.0 / pv : 0.0;
         if (lane == 0) {
             sR[36 * Kmax + 81] = tol0;

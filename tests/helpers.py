@@ -115,7 +115,7 @@ def objects_update_reference(win, objs, P, obj_left=True, new_bbox=False, vio_le
     return dict(gamma=gamma, accept=accept, dof=dof, dx=dx, P_new=Pn, blocks=blocks, rank_deficient=deficient)
 
 
-def random_object_case(seed):
+def random_object_case(seed, bbox_only_frac=0.0):
     """A random window with object tracks for the randomised object-update checks (scripts/gpu_soak_objects.py and
     test_gpu_objects.py): number of objects, keypoints per object, frames inside / outside the window, missing keypoints,
     residual form, perturbation sides, keypoint noise.  Small windows with few frames give rank-deficient H_f blocks."""
@@ -141,5 +141,12 @@ def random_object_case(seed):
             for fr in ob.frames:
                 if rng.random() < 0.4:
                     fr['clone'] = -1
+    if bbox_only_frac > 0.0:   # (a stream of its own: the cases of the default call are the same as ever)
+        rng2 = np.random.default_rng(770000 + seed)
+        for ob in objs:
+            if rng2.random() < bbox_only_frac:   # a bbox-only track (no keypoints: object state 9 columns)
+                ob.kps = np.zeros((0, 3))
+                for fr in ob.frames:
+                    fr['zs'] = np.zeros((0, 2))
     return dict(win=win, objs=objs, obj_left=obj_left, new_bbox=new_bbox, vio_left=vio_left, flags=flags, par=par,
                 resident=bool(rng.integers(0, 2)))
