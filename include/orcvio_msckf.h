@@ -754,6 +754,7 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
  *   ORCVIO_OBJ_FUSED        0: object tracks always through the three-launch compression over materialised rows (default 1: the one-launch
  *                           compression k_obj_fused whenever every track qualifies, orcvio_msckf_counters [5])
  *   ORCVIO_FUSED_STAMPS     phase stamps of k_obj_fused (object 0) on stderr
+ *   ORCVIO_FUSED_TOL        k_obj_fused's pivot tolerance relative to the largest pivot (default 1e-10; tests of its verification step)
  *   ORCVIO_EARLY_INGEST     0: the whole arena is pulled by the ingest node of the launch graph (no early pull under the validation)
  *   ORCVIO_REV_PRIOR        0: plain Cholesky of the prior (M keeps its 15 IMU columns)
  *   ORCVIO_SPLIT_TRACKS     track count from which the tracks front end is two launches (default 1800; 0: never)

@@ -36,6 +36,7 @@ struct ObjFusedArgs {
     int* info;                  // [0] += dropped pivots, [1] += objects above OBJ_REFINE_COND (mode 1) / all objects (mode 2)
     int mode;                   // ORCVIO_OPT_OBJECT_REFINE (1 or 2; 0 never comes here)
     unsigned long long* stamps; // diagnostics: wall-clock stamps of object 0's phases
+    double tol_rel;             // pivot tolerance relative to the largest pivot (1e-10; ORCVIO_FUSED_TOL for tests of the verification)
     double* dbg;                // diagnostics (ORCVIO_FUSED_DBG): [64] pivots of object 0 (9 border, 3 per keypoint), then the tolerance
 };
 #define FUSED_STAMP(i) do { if (fa.stamps && o == 0 && threadIdx.x == 0) fa.stamps[i] = wall_clock64(); } while (0)
@@ -334,22 +335,26 @@ __global__ __launch_bounds__(512) void k_obj_fused(ObjFusedArgs fa) {
         // the soak met a noise pivot of 1.03e-11 (scripts/gpu_soak_objects.py seed 90033: a car seen in two frames, H_f of rank 44 with
         // a next-to-last pivot of 1.3e-7 that amplifies the rounding of the last) -- kept, it is a garbage column of the basis and the
         // update came back 3 % off.  A factor 10 above that noise, 40 below the smallest real pivot met.
-        const double tol0 = 1e-10 * mx;
-        const bool kept = fabs(pv) > tol0;
-        const int dropped = __popcll(__ballot(has && !kept));
+        const double tol0 = fa.tol_rel * mx;
         if (fa.dbg && o == 0) { fa.dbg[lane] = has ? pv : 0.0; if (lane == 0) fa.dbg[64] = tol0; }
-        if (has) sYr[lane] = kept ? 1.0 / pv : 0.0;
-        if (lane == 0) {
-            sR[36 * Kmax + 81] = tol0;
-            if (fa.info) {
-                atomicAdd(fa.info + 1, 1);   // (every object of this launch is projected through the explicit basis)
-                if (dropped > 0) atomicAdd(fa.info, dropped);
-            }
-        }
+        if (lane == 0) sR[36 * Kmax + 81] = tol0;
     }
     __syncthreads();
     FUSED_STAMP(3);
     FUSED_STAMP(11);
+    // The rank decision above is a threshold on the pivots of an UNPIVOTED factor: a noise pivot that slips through is a garbage column
+    // of the basis (a unit vector in a direction H_f does not span) and a wrong update, silently.  So the decision is VERIFIED: with the
+    // kept pivots Q~^T Q~ must be the identity to ~cond * eps; an entry further than 1e-3 from it means a dependent column was kept --
+    // the rows are restored (h = q R), the tolerance raised a hundredfold, the basis formed again (at most twice).
+#pragma unroll 1
+    for (int attempt = 0;; ++attempt) {
+    // reciprocals of the kept pivots [9 border | 3 per keypoint]
+    if (tid < 9 + 3 * K) {
+        const double pv = tid < 9 ? sR[36 * Kmax + 10 * tid] : sR[36 * ((tid - 9) / 3) + 13 * ((tid - 9) % 3)];
+        sYr[tid] = fabs(pv) > sR[36 * Kmax + 81] ? 1.0 / pv : 0.0;
+    }
+    if (tid == 0) sOvf = 0;   // (free here: "some entry of T is far from the identity")
+    __syncthreads();
     // A: the rows of Q~ in place (q_i R = h_i), a thread per row
     {
         const double* Rb = sR + 36 * Kmax;
@@ -452,6 +457,77 @@ __global__ __launch_bounds__(512) void k_obj_fused(ObjFusedArgs fa) {
             sT[36 * Kmax + tid] = t;
         }
         __syncthreads();
+    }
+    {   // every entry of T between two kept columns against the identity
+        bool bad = false;
+        for (int e = tid; e < 36 * K + 81; e += 64 * NW) {
+            int ci, cj;
+            double v;
+            if (e < 36 * K) {
+                const int k = e / 36, w = e - 36 * k;
+                if (w < 9) { ci = 9 + 3 * k + w / 3; cj = 9 + 3 * k + w % 3; }
+                else { ci = 9 + 3 * k + (w - 9) / 9; cj = (w - 9) % 9; }
+                v = sT[e];
+            } else {
+                const int w = e - 36 * K;
+                ci = w / 9; cj = w - 9 * ci;
+                v = sT[36 * Kmax + w];
+            }
+            if (sYr[ci] != 0.0 && sYr[cj] != 0.0 && !(fabs(v - (ci == cj ? 1.0 : 0.0)) < 1e-3)) bad = true;
+        }
+        if (bad) sOvf = 1;
+        __syncthreads();
+        const bool again = sOvf != 0 && attempt < 2;
+        __syncthreads();
+        if (!again) break;
+        // restore the rows: h = q R (a dropped column comes back without its residual: noise in a direction that is dependent anyway)
+        const double* Rb = sR + 36 * Kmax;
+#pragma unroll 1
+        for (int lp = tid; lp < m; lp += 64 * NW) {
+            const int k = (int)sK[lp];
+            double* h = q + lp * QS;
+            double qk[3], qb[9], hk[3] = {0.0, 0.0, 0.0}, hb[9];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) qk[c] = h[c];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) qb[c] = h[3 + c];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    if (i <= c) t += qb[i] * Rb[9 * i + c];
+                hb[c] = t;
+            }
+            if (k < K) {
+                const double* Rk = sR + 36 * k;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (i <= j) t += qk[i] * Rk[12 * i + j];
+                    hk[j] = t;
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) hb[c] += (qk[0] * Rk[3 + c] + qk[1] * Rk[15 + c]) + qk[2] * Rk[27 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h[c] = hk[c];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) h[3 + c] = hb[c];
+        }
+        if (tid == 0) sR[36 * Kmax + 81] *= 100.0;
+        __syncthreads();
+    }
+    }   // (attempts)
+    if (wave == 0) {   // counters: dropped pivots; every object of this launch is projected through the explicit basis
+        const bool has = lane < 9 + 3 * K;
+        const int dropped = __popcll(__ballot(has && sYr[has ? lane : 0] == 0.0));
+        if (lane == 0 && fa.info) {
+            atomicAdd(fa.info + 1, 1);
+            if (dropped > 0) atomicAdd(fa.info, dropped);
+        }
     }
     FUSED_STAMP(7);
     // Q~ is orthonormal to cond * eps only: T = I + D.  First-order orthonormalisation of the ROWS, Q~ <- Q~ (I - U) with

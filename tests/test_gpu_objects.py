@@ -507,3 +507,25 @@ def test_bbox_only_tracks_beside_keypoint_tracks_in_one_update(built):
         assert rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL
     finally:
         u.close()
+
+
+@pytest.mark.parametrize('tol', ['1e-11', '1e-14'])
+def test_a_noise_pivot_that_passes_the_threshold_is_caught_by_the_orthogonality_check(built, monkeypatch, tol):
+    """The one-launch compression decides the rank of H_f by a threshold on the pivots of an unpivoted factor and VERIFIES the decision:
+    Q~^T Q~ must be the identity.  Seed 90033 of the soak (a car seen in two frames: H_f of rank 44, last pivot 1.03e-11 of the largest)
+    with the tolerance lowered so that the noise pivot is kept at first: the check finds the garbage column, the tolerance is raised, the
+    basis formed again -- same result as with the shipped tolerance, and the dropped pivot is counted."""
+    monkeypatch.setenv('ORCVIO_FUSED_TOL', tol)
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=64, max_observations=1024)
+    try:
+        case = random_object_case(90033)
+        win, objs = case['win'], case['objs']
+        ref = objects_update_reference(win, objs, win.P, case['obj_left'], case['new_bbox'], case['vio_left'], full_nullspace=True)
+        assert ref['rank_deficient'] == 1
+        got = u.update_object_tracks(case['flags'], win.N, objs, win.P, win.R_b2c[0], win.t_c_b[0], case['obj_left'], case['new_bbox'], case['vio_left'])
+        assert u.counters()['obj_fused'] == 1
+        assert got['accept'] == ref['accept'] == 1 and got['stats'][7] >= 1
+        assert abs(got['gamma'] - ref['gamma']) < 1e-6 * abs(ref['gamma'])
+        assert rel(got['dx'], ref['dx']) < TOL and rel(got['P_new'], ref['P_new']) < TOL
+    finally:
+        u.close()
