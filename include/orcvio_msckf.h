@@ -757,7 +757,8 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
  *   ORCVIO_FUSED_TOL        k_obj_fused's pivot tolerance relative to the largest pivot (default 1e-10; tests of its verification step)
  *   ORCVIO_EARLY_INGEST     0: the whole arena is pulled by the ingest node of the launch graph (no early pull under the validation)
  *   ORCVIO_REV_PRIOR        0: plain Cholesky of the prior (M keeps its 15 IMU columns)
- *   ORCVIO_SPLIT_TRACKS     track count from which the tracks front end is two launches (default 1800; 0: never)
+ *   ORCVIO_SPLIT_TRACKS     track count from which the tracks front end is two launches over E scratch in HBM (k_feature_e + k_feature_gate);
+ *                           default 0 = never (round 5: no faster than k_feature at 2 000 tracks, 85 MB of scratch traffic per update)
  *   ORCVIO_FUSED_FRONT, ORCVIO_FUSED_SOLVE   0: the forked seven-launch front end / the two-launch solve (same as the options)
  *   ORCVIO_FRONT_SPIN, ORCVIO_IO_SPIN_SECONDS   bounds of the in-launch hand-off of k_front (polls) and of the host's flag spin
  *   ORCVIO_OBJ_INGEST, ORCVIO_OBJ_PUBLISH   object update: 0 = copy engine instead of the ingest kernel; 1 = results through the flag word

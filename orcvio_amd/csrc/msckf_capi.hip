@@ -205,7 +205,9 @@ struct orcvio_msckf_handle {
     double* d_Rf = nullptr;             // [maxF][6] R factor of every track's H_f (k_feature), for orcvio_msckf_augment_new_features
     double* d_split = nullptr;          // scratch of the two-kernel front end for many tracks (feature_split.hpp): E and the gate's right-hand sides per track
     size_t split_cap = 0;
-    int split_min_tracks = 1800;        // ORCVIO_SPLIT_TRACKS: track count from which k_feature_e + k_feature_gate replace k_feature (0 = never)
+    int split_min_tracks = 0;           // ORCVIO_SPLIT_TRACKS: track count from which k_feature_e + k_feature_gate replace k_feature (0 = never: the
+                                        // default since round 5 -- at 2 000 tracks the two-launch form measured 0.208 ms against 0.211 for k_feature
+                                        // with E in LDS, inside the run-to-run spread, and moves 85 MB of E scratch through HBM per update for it)
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     // multi-GPU: RCCL communicator of this handle (orcvio_msckf_comm_init), the all-gather buffer [world][NAP_max^2] and
     // the gathered degrees of freedom of a sharded object update

@@ -51,7 +51,7 @@ def test_2000_features_against_the_oracle(upd, cfg):
                                   dict(F=700, track_len=None, outlier_frac=0.05, seed=4, estimate_extrin=True),
                                   dict(F=1, track_len=5, seed=5)])
 def test_split_tracks_front_end_against_the_fused_one(built, monkeypatch, case):
-    """k_feature_e + k_feature_gate (the form for F >= ORCVIO_SPLIT_TRACKS, 1 800 by default: the 2 000-track tests above run it)
+    """k_feature_e + k_feature_gate (the opt-in form for F >= ORCVIO_SPLIT_TRACKS; round 4 took it from 1 800 tracks by default)
     forced on small ragged windows with rejected tracks, against k_feature on the same window: same gate decisions, same update."""
     win = synth.make_window(N=30, flags=synth.Flags(use_larvio=1), **case)
     out = {}
