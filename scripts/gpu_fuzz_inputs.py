@@ -190,5 +190,8 @@ o = copy.deepcopy(objs); o[0].frames[0]['bbox'][:] = np.inf
 ocase('Inf in a bounding box', o, 'no_update')
 o = copy.deepcopy(objs); o[0].kps = np.zeros((0, 3))
 for fr in o[0].frames: fr['zs'] = np.zeros((0, 2))
-ocase('an object with no keypoint', o, 'error')
+ocase('an object with no keypoint (a bbox-only track: accepted since round 5, INTEGRATION.md 5)', o, 'any')
+o = copy.deepcopy(objs); o[0].kps = np.zeros((35, 3))
+for fr in o[0].frames: fr['zs'] = np.zeros((35, 2))
+ocase('an object with 35 keypoints (object state beyond 112 columns)', o, 'error')
 print(json.dumps(dict(cases=report, problems=bad), indent=1, default=str))
