@@ -1209,3 +1209,24 @@ def debug_trsm(upd: MsckfUpdater, X, B):
     if rc != 0:
         raise MsckfError(rc, 'debug_trsm')
     return Z
+
+
+def debug_potrf_solve(upd: MsckfUpdater, X, B, la=0, stamps=False, reps=0):
+    """Test helper / diagnostic: L = chol(X) and Z = L^-1 B in ONE launch -- k_potrf_solve (la = 0) or k_potrf_solve_la
+    (la = 2, 3: the trailing update spread over far workgroups).  Returns dict(L, Z, info[dropped, non-positive, lost], stamps, us)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    n, nrhs = B.shape
+    L = np.zeros((n, n))
+    Z = np.zeros((n, nrhs))
+    info = np.zeros(3, dtype=np.int32)
+    st = np.zeros(512, dtype=np.uint64)
+    us = C.c_double(0.0)
+    lib = upd.lib
+    lib.orcvio_msckf_debug_potrf_solve.argtypes = [C.c_void_p, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp, _dp, C.c_void_p, C.c_void_p,
+                                                   C.c_int32, C.POINTER(C.c_double)]
+    rc = lib.orcvio_msckf_debug_potrf_solve(upd.h, _d(X), n, _d(B), nrhs, int(la), _d(L), _d(Z), info.ctypes.data,
+                                            st.ctypes.data if stamps else None, int(reps), C.byref(us))
+    if rc != 0:
+        raise MsckfError(rc, 'debug_potrf_solve')
+    return dict(L=L, Z=Z, info=info, stamps=st.astype(np.int64) if stamps else None, us=us.value)

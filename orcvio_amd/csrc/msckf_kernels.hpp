@@ -1959,9 +1959,11 @@ __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long
                                               int upper_only, double* __restrict__ C, long sCi, long sCj,
                                               const double* __restrict__ Cin = nullptr, int* __restrict__ clear = nullptr,
                                               const unsigned* __restrict__ wait = nullptr, unsigned expect = 0u, int* __restrict__ lost = nullptr,
-                                              int spin_limit = 0) {
-    // clear: step counter of the k_potrf_solve launch that follows in the stream (reset here, one kernel ahead)
+                                              int spin_limit = 0, int* __restrict__ clear16 = nullptr) {
+    // clear: step counter of the k_potrf_solve launch that follows in the stream (reset here, one kernel ahead); clear16: the sixteen
+    // block-row words of k_potrf_solve_la
     if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (clear16 && blockIdx.x == 0 && threadIdx.x < 16) __hip_atomic_store(clear16 + threadIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // wait: completion counter of a launch on ANOTHER stream whose output this product reads (the frame call: A' of the objects'
     // compression, k_gemm_objA).  A stream-level join (hipStreamWaitEvent) costs ~10 us of dispatch even when the event fired long ago;
     // one relaxed poll per workgroup costs nothing when it did.  Bounded: a count that never comes sets *lost (the update is void).
@@ -2337,26 +2339,17 @@ __global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, 
 // the factorisation instead of a whole k_trsm later.  SOLVE_WPB live wavefronts per solver workgroup (one per SIMD).
 #define SOLVE_WPB 4
 #define SOLVE_CH 4
-template <int NSLOT>
-__global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ X, int ldx, int n, double tol_rel,
-                                                     double* __restrict__ R, int ldr, double* __restrict__ Dinv,
-                                                     int* __restrict__ info, int* __restrict__ flag, int* __restrict__ lost_flag,
-                                                     const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
-                                                     const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
-                                                     int tail = 0, double tail_scale = 0.0) {
-    // tail: M = diag(X (n x n), s2 I_tail) -- the right-hand sides B1 have `tail` more rows behind the n that take part in the
-    // factorisation (the last columns of the prior's factor, zero in the active rows: potrf_reg_body, rev); their rows of Z are
-    // B1 / sigma (tail_scale), the extra column's are zero.
-    if (blockIdx.x == 0) {
-        __shared__ __attribute__((aligned(16))) double sPotrf[POTRF_LDS_DOUBLES];
-        potrf_reg_body<NSLOT, true>(sPotrf, X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag, nullptr, 1, 0);   // lower tiles: kept zero by the handle
-        return;
-    }
+// One solver workgroup of k_potrf_solve / k_potrf_solve_la (block index `sb` among the solver workgroups): see k_potrf_solve.
+__device__ __forceinline__ void potrf_solver_wg(const int sb, int n, const double* __restrict__ R, int ldr, const double* __restrict__ Dinv,
+                                                int* __restrict__ flag, int* __restrict__ lost_flag,
+                                                const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
+                                                const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
+                                                int tail, double tail_scale) {
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nblk = (n + 15) >> 4;
     const int ncols = nc1 + (bx ? 1 : 0);
-    const int cb = (blockIdx.x - 1) * SOLVE_WPB + wave;
+    const int cb = sb * SOLVE_WPB + wave;
     if (wave >= SOLVE_WPB || cb * 16 >= ncols) return;
     const int col = cb * 16 + cc;
     for (int e = l; e < 16 * tail; e += 64) {   // (independent of the factorisation: out of the way first)
@@ -2444,6 +2437,24 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
     if (lost && l == 0) atomicAdd(lost_flag, 1);   // reported as an error by the host
 }
 
+template <int NSLOT>
+__global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ X, int ldx, int n, double tol_rel,
+                                                     double* __restrict__ R, int ldr, double* __restrict__ Dinv,
+                                                     int* __restrict__ info, int* __restrict__ flag, int* __restrict__ lost_flag,
+                                                     const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
+                                                     const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
+                                                     int tail = 0, double tail_scale = 0.0) {
+    // tail: M = diag(X (n x n), s2 I_tail) -- the right-hand sides B1 have `tail` more rows behind the n that take part in the
+    // factorisation (the last columns of the prior's factor, zero in the active rows: potrf_reg_body, rev); their rows of Z are
+    // B1 / sigma (tail_scale), the extra column's are zero.
+    if (blockIdx.x == 0) {
+        __shared__ __attribute__((aligned(16))) double sPotrf[POTRF_LDS_DOUBLES];
+        potrf_reg_body<NSLOT, true>(sPotrf, X, ldx, n, tol_rel, R, ldr, Dinv, info, 0, 0, flag, nullptr, 1, 0);   // lower tiles: kept zero by the handle
+        return;
+    }
+    potrf_solver_wg(blockIdx.x - 1, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
+}
+
 // P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (kdim x (n+1), ldz).  One workgroup per lower
 // tile, split-K over its 4 wavefronts (as k_gemm).
 // Joint chi-square gate of an object update (gatingTest on the stacked, projected rows, src/orcvio.cpp:2172-2182), decided inside
@@ -2510,6 +2521,7 @@ __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ 
 
 }  // namespace orcvio_amd
 
+#include "potrf_lookahead.hpp"   // k_potrf_solve_la: chol(M) + solve with the trailing update spread over several CUs
 #include "object_kernels.hpp"   // k_obj_front, k_obj_border_solve_assemble (+ obj_refine_body), k_obj_border_qr, k_obj_solve_assemble, k_obj_refine
 
 namespace orcvio_amd {

@@ -65,3 +65,34 @@ def test_trsm(upd, n, nrhs):
     Z = capi.debug_trsm(upd, X, B)
     L = np.linalg.cholesky(X)
     assert rel(Z, np.linalg.solve(L, B)) < 1e-10
+
+
+@pytest.mark.parametrize('la', [0, 2, 3])
+@pytest.mark.parametrize('n,nrhs', [(5, 3), (16, 16), (17, 40), (94, 95), (96, 112), (100, 33), (142, 143), (160, 161), (176, 177), (187, 203),
+                                    (192, 208), (202, 203), (208, 17), (224, 225)])
+def test_fused_potrf_solve(upd, n, nrhs, la):
+    """chol(X) and Z = L^-1 B in one launch: k_potrf_solve (la = 0) and k_potrf_solve_la (the trailing update spread over far
+    workgroups, look-ahead 2 and 3) against numpy; no hand-off may be lost."""
+    X = _spd(n, 11 * n + la, cond=1e6)
+    rng = np.random.default_rng(n + nrhs)
+    B = rng.standard_normal((n, nrhs))
+    r = capi.debug_potrf_solve(upd, X, B, la=la)
+    assert r['info'].tolist() == [0, 0, 0]
+    L = np.linalg.cholesky(X)
+    assert rel(r['L'], L) < 1e-11
+    assert np.abs(np.triu(r['L'], 1)).max() == 0.0
+    assert rel(r['Z'], np.linalg.solve(L, B)) < 1e-9
+
+
+def test_fused_potrf_solve_lookahead_repeats(upd):
+    """The look-ahead form two hundred times on one matrix: every launch identical to the first (no hand-off read early)."""
+    n, nrhs = 187, 203
+    X = _spd(n, 77, cond=1e5)
+    B = np.random.default_rng(3).standard_normal((n, nrhs))
+    first = capi.debug_potrf_solve(upd, X, B, la=3)
+    old = capi.debug_potrf_solve(upd, X, B, la=0)   # (the panels are applied in the same order: the two kernels agree bit for bit)
+    assert np.array_equal(old['Z'], first['Z']) and np.array_equal(old['L'], first['L'])
+    for it in range(200):
+        r = capi.debug_potrf_solve(upd, X, B, la=3 if it % 2 else 2)
+        assert r['info'].tolist() == [0, 0, 0]
+        assert np.array_equal(r['Z'], first['Z']) and np.array_equal(r['L'], first['L'])
