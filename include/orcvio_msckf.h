@@ -158,6 +158,13 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
  * update itself never needs them; tests and callers that want H' switch it on. */
 /* ORCVIO_OPT_FUSED_SOLVE (default 1): factor M and solve for Z in one launch (solver workgroups trail the
  * factorisation block step by block step); 0 = two launches (k_potrf_reg, k_trsm_lds).  Same arithmetic. */
+/* ORCVIO_OPT_LOOKAHEAD_SOLVE (default 3; with ORCVIO_OPT_FUSED_SOLVE on, from six block steps = 81 active states): the one-launch solve
+ * spreads the trailing update of chol(M) over one "far" workgroup per block row (k_potrf_solve_la, look-ahead depth 3: a far workgroup
+ * applies the published panels to its row and hands it to the factorising workgroup three block steps before it is due); 0 = the whole
+ * trailing matrix in the registers of ONE workgroup (k_potrf_solve).  Same arithmetic in the same order: bit-identical results; 32 against
+ * 38 us at 30 clones.  The far workgroups are eight to ten more workgroups that must become resident while the launch runs: every wait is
+ * bounded (seconds), and an update whose hand-off was lost is run again through k_potrf_solve inside the same call (counted in
+ * orcvio_msckf_counters [0]); object updates report ORCVIO_ERR_TIMEOUT instead, as they do for k_potrf_solve's own hand-off. */
 /* ORCVIO_OPT_FUSED_FRONT (default 1): the Cholesky of the prior runs as workgroup 0 of the feature launch (k_front)
  * whenever the whole front end is co-resident (n <= 224, 1 + ceil(F/2) workgroups <= compute units); 0 = always fork
  * it to the handle's side stream around k_feature.  Same kernels' bodies, same arithmetic. */
@@ -220,7 +227,7 @@ void orcvio_msckf_destroy(orcvio_msckf_handle* h);
 enum { ORCVIO_OPT_MATERIALIZE_STACK = 1, ORCVIO_OPT_FUSED_SOLVE = 2, ORCVIO_OPT_FUSED_FRONT = 3, ORCVIO_OPT_EXTRA_STATES = 4,
        ORCVIO_OPT_EKF_ROWS = 5, ORCVIO_OPT_STAGE_PROFILE = 6, ORCVIO_OPT_RESIDENT_FACTOR = 7, ORCVIO_OPT_OBJECT_QR = 8,
        ORCVIO_OPT_REF_STACK_HF = 9, ORCVIO_OPT_SCHMIDT_STATES = 10, ORCVIO_OPT_OBJECT_DOF = 11, ORCVIO_OPT_REF_H2_LDLT = 12,
-       ORCVIO_OPT_OBJECT_REFINE = 13 };
+       ORCVIO_OPT_OBJECT_REFINE = 13, ORCVIO_OPT_LOOKAHEAD_SOLVE = 14 };
 int32_t orcvio_msckf_set_option(orcvio_msckf_handle* h, int32_t option, int32_t value);
 
 /* EKF-SLAM rows of the hybrid filter (existing SLAM features).  For every SLAM feature the current
@@ -516,7 +523,8 @@ int32_t orcvio_msckf_objects_finish(orcvio_msckf_handle* h, const double* d_bloc
                                     int32_t dof_total, void* stream);
 int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_result* result);
 /* Cumulative counters of the handle since orcvio_msckf_create (count <= ORCVIO_COUNTERS values are written):
- *   [0] front_fallbacks   updates whose fused front end (k_front, ORCVIO_OPT_FUSED_FRONT) lost its co-residency bet -- a workgroup gave
+ *   [0] front_fallbacks   updates whose fused front end (k_front, ORCVIO_OPT_FUSED_FRONT) or look-ahead solve (ORCVIO_OPT_LOOKAHEAD_SOLVE) lost
+ *                         an in-launch hand-off: for k_front its co-residency bet -- a workgroup gave
  *                         up at the launch's device-wide counter because another tenant of the device (a second handle, another
  *                         stream's long kernel, another process) held compute units -- and were re-run on the forked seven-launch
  *                         path inside the same call.  The results are the same; each such update costs the bounded wait (tens of ms)
@@ -760,6 +768,8 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
  *   ORCVIO_SPLIT_TRACKS     track count from which the tracks front end is two launches over E scratch in HBM (k_feature_e + k_feature_gate);
  *                           default 0 = never (round 5: no faster than k_feature at 2 000 tracks, 85 MB of scratch traffic per update)
  *   ORCVIO_FUSED_FRONT, ORCVIO_FUSED_SOLVE   0: the forked seven-launch front end / the two-launch solve (same as the options)
+ *   ORCVIO_LA_SOLVE         0 / 2 / 3: default of ORCVIO_OPT_LOOKAHEAD_SOLVE;  ORCVIO_LA_SPIN: polls before a wait inside k_potrf_solve_la gives up
+ *                           (default 4 M, seconds; 0 makes every hand-off fail at once: the test of the fall-back)
  *   ORCVIO_FRONT_SPIN, ORCVIO_IO_SPIN_SECONDS   bounds of the in-launch hand-off of k_front (polls) and of the host's flag spin
  *   ORCVIO_OBJ_INGEST, ORCVIO_OBJ_PUBLISH   object update: 0 = copy engine instead of the ingest kernel; 1 = results through the flag word
  *   ORCVIO_TIMING           host wall times of the parts of the one-shot calls on stderr

@@ -293,6 +293,12 @@ class MsckfUpdater:
         if rc != 0:
             raise MsckfError(rc, 'orcvio_msckf_set_option')
 
+    def set_lookahead_solve(self, depth: int):
+        """ORCVIO_OPT_LOOKAHEAD_SOLVE: 3 (default) / 2 = k_potrf_solve_la with that look-ahead depth, 0 = k_potrf_solve (one workgroup)."""
+        rc = self.lib.orcvio_msckf_set_option(self.h, 14, int(depth))
+        if rc != 0:
+            raise MsckfError(rc, 'orcvio_msckf_set_option')
+
     def set_fused_front(self, on: bool):
         """ORCVIO_OPT_FUSED_FRONT: chol(P) as workgroup 0 of the feature launch (default) or forked to a side stream."""
         rc = self.lib.orcvio_msckf_set_option(self.h, 3, int(bool(on)))

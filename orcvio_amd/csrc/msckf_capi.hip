@@ -211,6 +211,7 @@ struct orcvio_msckf_handle {
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
     int* d_la_rdy = nullptr;            // k_potrf_solve_la: one word per block row a far workgroup brings forward (own 128-byte line, cleared by the k_gemm ahead of it)
     int la_solve = 3;                   // look-ahead depth of the fused solve (0: k_potrf_solve, one workgroup holds the whole trailing matrix; 2 / 3: k_potrf_solve_la)
+    int la_spin = 1 << 22;              // polls (~1 us each) before a wait inside k_potrf_solve_la gives up: the update is then run again through k_potrf_solve
     bool la_attr = false;               // the dynamic-LDS opt-in of k_potrf_solve_la is set for this handle's device
     // multi-GPU: RCCL communicator of this handle (orcvio_msckf_comm_init), the all-gather buffer [world][NAP_max^2] and
     // the gathered degrees of freedom of a sharded object update

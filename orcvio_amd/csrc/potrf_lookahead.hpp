@@ -76,7 +76,6 @@ __device__ __forceinline__ bool la_wait_ge(const int* p, int need, int limit) { 
 // gfx940+: bit 0 = A) -- four v_xor of the sign bit per product less on an issue-bound instruction stream
 __device__ __forceinline__ d4 mfma_f64_na(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1); }
 
-#define LA_SPIN (1 << 22)
 // stamps (diagnostic, scripts/gpu_potrf_la_stamps.py): [0..63] chain wave, [64..127] worker 0, [128..191] wave 4, [192..255] the far
 // workgroup of row min(LA+4, nb-2), [256], [257] wall clock at start / end, [320 + 16 wi + kb] / [416 + 16 wi + kb] every worker's end of products / arrival at the barrier
 #define LA_STAMP(ptr, idx) do { if constexpr (ST) { if ((ptr) && l == 0) (ptr)[idx] = clock64(); } } while (0)
@@ -85,7 +84,7 @@ template <int LA, bool ST>
 __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, const double* __restrict__ X, int ldx, int n,
                                                   double* __restrict__ R, int ldr, double* __restrict__ Dinv, int* __restrict__ info,
                                                   int* __restrict__ flag, const int* __restrict__ rdy, int* __restrict__ lost,
-                                                  unsigned long long* __restrict__ stamps) {
+                                                  const int spin, unsigned long long* __restrict__ stamps) {
     double (*sD)[17] = reinterpret_cast<double (*)[17]>(lds);                      // diagonal tile being factored (row view)
     double (*sDi)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + 272);       // inv(L11) of block step kb in sDi[kb & 1]
     double (*sL)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + 816);        // L11 of block step kb (rows) in sL[kb & 1]
@@ -379,7 +378,7 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
             LA_STAMP(stw, 2 + 4 * kb);
             // ---- the arrivals of the next step: fetched here, more than half a step ahead of their use (ONE site, unconditional); the
             //      word sampled at the top of the step has come back under the products above ----
-            if (w >= 0 && __builtin_amdgcn_readfirstlane(rv) < 1 && !gone && !la_wait_ge(&rdy[w], 1, LA_SPIN)) gone = true;
+            if (w >= 0 && __builtin_amdgcn_readfirstlane(rv) < 1 && !gone && !la_wait_ge(&rdy[w], 1, spin)) gone = true;
             fetch(kb + 1 < nb ? kb + 1 : nb - 1, n0, n1, nd);
             LA_STAMP(stw, 3 + 4 * kb);
             if (live) {
@@ -433,7 +432,7 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
 template <int LA, bool ST>
 __device__ __forceinline__ void potrf_la_far_wg(const int a, const double* __restrict__ X, int ldx, int n, double* __restrict__ R, int ldr,
                                                 const int* __restrict__ flag, int* __restrict__ rdy, int* __restrict__ lost,
-                                                unsigned long long* __restrict__ stamps) {
+                                                const int spin, unsigned long long* __restrict__ stamps) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nb = (n + 15) >> 4;
@@ -458,7 +457,7 @@ __device__ __forceinline__ void potrf_la_far_wg(const int a, const double* __res
     if (wave == 0) LA_STAMP(stf, 0);
     for (int p = 0; p <= plast; ++p) {
         if (wave == 0) {   // one wave polls the step counter for the workgroup
-            if (!gone && !la_wait_ge(flag, p + 1, LA_SPIN)) gone = true;
+            if (!gone && !la_wait_ge(flag, p + 1, spin)) gone = true;
             LA_STAMP(stf, 1 + 3 * p);
         }
         __syncthreads();
@@ -501,17 +500,17 @@ __global__ __launch_bounds__(512) void k_potrf_solve_la(const double* __restrict
                                                         int* __restrict__ lost_flag, int nsolve,
                                                         const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
                                                         const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
-                                                        int tail, double tail_scale, unsigned long long* __restrict__ stamps) {
+                                                        int tail, double tail_scale, int spin, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) double sLaLds[];
     if (blockIdx.x == 0) {
-        potrf_la_chain_wg<LA, ST>(sLaLds, X, ldx, n, R, ldr, Dinv, info, flag, rdy, lost_flag, stamps);
+        potrf_la_chain_wg<LA, ST>(sLaLds, X, ldx, n, R, ldr, Dinv, info, flag, rdy, lost_flag, spin, stamps);
         return;
     }
     if ((int)blockIdx.x <= nsolve) {
         potrf_solver_wg(blockIdx.x - 1, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
         return;
     }
-    potrf_la_far_wg<LA, ST>(LA + 1 + ((int)blockIdx.x - nsolve - 1), X, ldx, n, R, ldr, flag, rdy, lost_flag, stamps);
+    potrf_la_far_wg<LA, ST>(LA + 1 + ((int)blockIdx.x - nsolve - 1), X, ldx, n, R, ldr, flag, rdy, lost_flag, spin, stamps);
 }
 
 #undef LA_STAMP

@@ -51,6 +51,41 @@ def test_update_survives_a_kernel_that_holds_half_the_device(built):
         upd.close()
 
 
+def test_lookahead_solve_is_bit_identical_and_falls_back_when_a_hand_off_is_lost(built, monkeypatch):
+    """k_potrf_solve_la (far workgroups bring the block rows forward) against k_potrf_solve (one workgroup): the same panels in the
+    same order, bit-identical updates.  With ORCVIO_LA_SPIN = 0 every wait on another workgroup gives up at once: the launch flags
+    itself, and the update is run again through k_potrf_solve inside the same call -- same results, one fall-back counted."""
+    win = synth.config_window(2)
+    ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384)
+    try:
+        la = upd.update_features(win)
+        upd.set_lookahead_solve(0)
+        one = upd.update_features(win)
+        upd.set_lookahead_solve(2)
+        la2 = upd.update_features(win)
+        for got in (la, one, la2):
+            assert rel(got['dx'], ref['dx']) < 1e-6 and rel(got['P_new'], ref['P_new']) < 1e-6
+        assert np.array_equal(la['dx'], one['dx']) and np.array_equal(la['P_new'], one['P_new'])
+        assert np.array_equal(la2['dx'], one['dx']) and np.array_equal(la2['P_new'], one['P_new'])
+        assert upd.counters()['front_fallbacks'] == 0
+        upd.set_fused_front(False)   # (the re-run of a lost hand-off is the forked form, with k_potrf_solve)
+        upd.set_lookahead_solve(0)
+        unf = upd.update_features(win)
+    finally:
+        upd.close()
+    monkeypatch.setenv('ORCVIO_LA_SPIN', '0')
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384)
+    try:
+        for it in range(3):   # (plain launches, then the captured graph)
+            got = upd.update_features(win)
+            assert np.array_equal(got['dx'], unf['dx']) and np.array_equal(got['P_new'], unf['P_new'])
+            assert rel(got['dx'], one['dx']) < 1e-10 and rel(got['P_new'], one['P_new']) < 1e-12
+            assert upd.counters()['front_fallbacks'] == it + 1
+    finally:
+        upd.close()
+
+
 @pytest.mark.parametrize('F', [509, 510, 511, 2000])
 def test_track_counts_around_the_co_residency_limit(built, F):
     """Up to 2 (CUs - 1) = 510 tracks the front end is ONE co-resident launch (k_front); beyond that the update takes the forked
