@@ -1830,6 +1830,8 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
                                  gridDim.x == 1 ? 1 : 0, zero_lower, rev);
 }
 
+#include "potrf_lookahead.hpp"   // potrf_la_chain_wg / potrf_la_far_wg: the factorisation with its trailing update spread over far workgroups
+
 // ---------------------------------------------------------------------------------------
 // k_front: the two independent front ends of the update in ONE launch -- workgroup 0 factors the prior
 // (potrf_reg_body, depends on P only), every other workgroup runs two feature tracks (feature_body, one
@@ -1842,6 +1844,8 @@ struct FrontPotrfArgs {
     const double* X; int ldx; int n; double tol_rel; double* R; int ldr; double* Dinv; int* info;
     int skip;   // the prior's factor is resident (orcvio_msckf_cov_commit): workgroup 0 has nothing to do
     int rev;    // factor the reversed matrix (potrf_reg_body): the last 15 columns of the factor are zero in the active rows
+    int nfar;   // > 0: the look-ahead form (potrf_lookahead.hpp, depth 3) -- workgroups 1 .. nfar are the far workgroups of the block rows 4 ..
+    int* la_flag; int* la_rdy; int la_spin;   // its step counter, its block-row words (both zero between launches), its bound on the waits
 };
 // The compression (both Grams, then the assembly of A) can run in the same launch: the feature workgroups meet at a
 // device-wide counter (they are all resident: the launch has at most as many workgroups as the device has CUs, one
@@ -1886,8 +1890,14 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     if (blockIdx.x == 0) {
         if (q.skip) return;
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[0] = wall_clock64();
-        potrf_reg_body<NSLOT, false>(smem, q.X, q.ldx, q.n, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, 0, 0, nullptr, nullptr, 1, 0, q.rev);
+        if (q.nfar > 0) potrf_la_chain_wg<3, false, true>(smem, LaIn{q.X, q.ldx, q.n, q.rev}, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, q.la_flag, q.la_rdy, g.lost, q.la_spin, nullptr);
+        else potrf_reg_body<NSLOT, false>(smem, q.X, q.ldx, q.n, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, 0, 0, nullptr, nullptr, 1, 0, q.rev);
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[6] = wall_clock64();
+        return;
+    }
+    if ((int)blockIdx.x <= q.nfar) {   // the far workgroups of the prior's factorisation (block rows 4 .. nb-2)
+        if (q.skip) return;
+        potrf_la_far_wg<3, false>(3 + (int)blockIdx.x, LaIn{q.X, q.ldx, q.n, q.rev}, q.R, q.ldr, q.la_flag, q.la_rdy, g.lost, q.la_spin, nullptr);
         return;
     }
     // (Persistent teams -- a loop over track pairs so that any track count stays in this launch -- were tried in round 2: with
@@ -1895,7 +1905,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     // k_feature / k_gram_pair / k_assemble_A, whose two workgroups per CU also keep more tracks in flight.  Not kept: beyond
     // 2 (CUs - 1) tracks the update takes the forked form.)
     const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-    const int j = 2 * ((int)blockIdx.x - 1) + team;
+    const int j = 2 * ((int)blockIdx.x - 1 - q.nfar) + team;
     const int local = threadIdx.x & 255;
     if (j < p.F) {
         feature_body<NPASS, true>(p, j, team ? ((local + 128) & 255) : local, smem + (size_t)team * team_doubles);
@@ -1903,7 +1913,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
         __syncthreads(); __syncthreads(); __syncthreads();
     }
     if (!g.enabled) return;
-    const int nfb = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
+    const int nfb = (int)gridDim.x - 1 - q.nfar, me = (int)blockIdx.x - 1 - q.nfar;
     unsigned long long* stamp = reinterpret_cast<unsigned long long*>(g.counter) + 8;   // diagnostic (bytes 64..): 100 MHz clock
 #define FRONT_STAMP(i) do { if (me == 0 && threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
     FRONT_STAMP(1);
@@ -2455,6 +2465,31 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
     potrf_solver_wg(blockIdx.x - 1, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
 }
 
+// k_potrf_solve_la: k_potrf_solve with the trailing update of the factorisation spread over far workgroups (potrf_lookahead.hpp).
+// grid: [0] the chain workgroup, [1 .. nsolve] the solver workgroups (potrf_solver_wg), [nsolve+1 ..] the far workgroups of the
+// block rows LA+1 .. nb-2.  Dynamic LDS: la_lds_doubles<LA>() doubles.  rdy[16]: zero at launch (k_gemm clears it with the step
+// counter, one kernel ahead).
+template <int LA, bool ST>
+__global__ __launch_bounds__(512) void k_potrf_solve_la(const double* __restrict__ X, int ldx, int n,
+                                                        double* __restrict__ R, int ldr, double* __restrict__ Dinv,
+                                                        int* __restrict__ info, int* __restrict__ flag, int* __restrict__ rdy,
+                                                        int* __restrict__ lost_flag, int nsolve,
+                                                        const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
+                                                        const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
+                                                        int tail, double tail_scale, int spin, unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) double sLaLds[];
+    if (blockIdx.x == 0) {
+        potrf_la_chain_wg<LA, ST, false>(sLaLds, LaIn{X, ldx, n, 0}, 0.0, R, ldr, Dinv, info, flag, rdy, lost_flag, spin, stamps);
+        return;
+    }
+    if ((int)blockIdx.x <= nsolve) {
+        potrf_solver_wg(blockIdx.x - 1, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
+        return;
+    }
+    potrf_la_far_wg<LA, ST>(LA + 1 + ((int)blockIdx.x - nsolve - 1), LaIn{X, ldx, n, 0}, R, ldr, flag, rdy, lost_flag, spin, stamps);
+}
+
+
 // P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (kdim x (n+1), ldz).  One workgroup per lower
 // tile, split-K over its 4 wavefronts (as k_gemm).
 // Joint chi-square gate of an object update (gatingTest on the stacked, projected rows, src/orcvio.cpp:2172-2182), decided inside
@@ -2521,7 +2556,6 @@ __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ 
 
 }  // namespace orcvio_amd
 
-#include "potrf_lookahead.hpp"   // k_potrf_solve_la: chol(M) + solve with the trailing update spread over several CUs
 #include "object_kernels.hpp"   // k_obj_front, k_obj_border_solve_assemble (+ obj_refine_body), k_obj_border_qr, k_obj_solve_assemble, k_obj_refine
 
 namespace orcvio_amd {

@@ -1,5 +1,7 @@
 // potrf_lookahead.hpp -- k_potrf_solve_la: the Cholesky of M and the triangular solve in one launch, with the trailing update
-// spread over several compute units ("look-ahead" form).  Included from msckf_kernels.hpp.
+// spread over several compute units ("look-ahead" form): the chain workgroup and the far workgroups.  The kernel itself
+// (k_potrf_solve_la) is in msckf_kernels.hpp behind the solver workgroups it shares with k_potrf_solve; k_front runs the same two
+// bodies on the prior.
 //
 // k_potrf_solve keeps the whole trailing matrix in the registers of ONE workgroup: its first block steps are bound by the FP64
 // matrix rate of one CU (66 + 55 + 45 + ... tile products on three SIMDs, 8-13 k cycles per step against the 4.9 k of the
@@ -23,31 +25,36 @@
 // sc1 after its poll matched).  Every wait is bounded; a wait that gives up sets *lost (the host runs the update again through
 // k_potrf_solve).
 #pragma once
-
-namespace orcvio_amd {
+// (included from msckf_kernels.hpp INSIDE namespace orcvio_amd, behind potrf_reg_body: it uses DiagStep, the LDS barriers, st_tile)
 
 #define LA_NBMAX 14
 template <int LA>
 __host__ __device__ constexpr int la_lds_doubles() { return 1360 + 16 + (LA + 1) * LA_NBMAX * 256 + 2 * 256; }
 __host__ __device__ inline int la_far_workgroups(int nb, int LA) { return nb - 2 - LA > 0 ? nb - 2 - LA : 0; }
 
-// Tile loads are RAW (four sc1 loads, no edge handling): nothing waits for them where they are issued, the consumer masks the
-// rows / columns beyond the matrix where it uses them (unit diagonal, zero elsewhere).  X must be readable over all of its
-// 16 nb x 16 nb tile grid (the handle's M: NP x NP, ld NP).
-__device__ __forceinline__ d4 la_load_raw(const double* __restrict__ base, int ld, int a, int b, int kk, int cc) {
-    d4 v;
-    const double* p = base + (size_t)(16 * a + kk) * ld + 16 * b + cc;
+// Tile loads are RAW (four sc1 loads through 32-bit byte offsets from a wave-uniform base, no edge handling where they are issued):
+// nothing waits for them there, the consumer masks the rows / columns beyond the matrix where it uses them (unit diagonal, zero
+// elsewhere).  The offsets of a tile of the INPUT clamp row and column into the matrix (the prior is n x n with ld = n: nothing
+// beyond it may be read) and, with rev, count down from the far corner: tile (a, b) of X'(i, j) = X(n-1-i, n-1-j) (potrf_reg_body).
+struct LaIn { const double* X; int ld; int n; int rev; };
+__device__ __forceinline__ void la_x_offsets(unsigned (&off)[4], const LaIn& in, int a, int b, int kk, int cc) {
+    int j = 16 * b + cc;
+    j = j < in.n ? j : in.n - 1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = ld_pub(p + (size_t)(4 * r) * ld);
-    return v;
+    for (int r = 0; r < 4; ++r) {
+        int i = 16 * a + kk + 4 * r;
+        i = i < in.n ? i : in.n - 1;
+        off[r] = (unsigned)((in.rev ? (in.n - 1 - i) * in.ld + (in.n - 1 - j) : i * in.ld + j) * 8);
+    }
 }
-// the same with a wave-uniform tile base (SGPRs) and ONE 32-bit lane offset in bytes ((kk * ld + cc) * 8): the saddr form of
-// global_load, no 64-bit VALU address arithmetic per load (the workers issue twelve of these per step)
-__device__ __forceinline__ void la_load_raw_u(d4& v, const double* __restrict__ base, int ld, int a, int b, unsigned lane_b) {
-    const char* t = reinterpret_cast<const char*>(base);   // (wave-uniform; every offset below fits 32 bits: ld <= 224)
-    const unsigned o = (unsigned)(((16 * a) * ld + 16 * b) * 8) + lane_b;
+__device__ __forceinline__ void la_r_offsets(unsigned (&off)[4], int ldr, int a, int b, unsigned lane_br) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = ld_pub(reinterpret_cast<const double*>(t + (o + (unsigned)(32 * r * ld))));
+    for (int r = 0; r < 4; ++r) off[r] = lane_br + (unsigned)(((16 * a + 4 * r) * ldr + 16 * b) * 8);
+}
+__device__ __forceinline__ void la_load_off(d4& v, const double* __restrict__ base, const unsigned (&off)[4]) {
+    const char* t = reinterpret_cast<const char*>(base);   // (wave-uniform: the saddr form of global_load, no 64-bit VALU address arithmetic)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ld_pub(reinterpret_cast<const double*>(t + off[r]));
 }
 __device__ __forceinline__ d4 la_mask_edge(d4 v, int n, int a, int b, int kk, int cc) {
     const int j = 16 * b + cc;
@@ -58,11 +65,22 @@ __device__ __forceinline__ d4 la_mask_edge(d4 v, int n, int a, int b, int kk, in
     }
     return v;
 }
-__device__ __forceinline__ d4 la_load_x(const double* __restrict__ X, int ldx, int n, int a, int b, int kk, int cc) {
-    return la_mask_edge(la_load_raw(X, ldx, a, b, kk, cc), n, a, b, kk, cc);
+__device__ __forceinline__ d4 la_load_x_raw(const LaIn& in, int a, int b, int kk, int cc) {
+    unsigned off[4];
+    la_x_offsets(off, in, a, b, kk, cc);
+    d4 v;
+    la_load_off(v, in.X, off);
+    return v;
 }
-// tile (a, b) of R as another workgroup stored it (sc1 loads)
-__device__ __forceinline__ d4 la_load_r(const double* __restrict__ R, int ldr, int a, int b, int kk, int cc) { return la_load_raw(R, ldr, a, b, kk, cc); }
+__device__ __forceinline__ d4 la_load_x(const LaIn& in, int a, int b, int kk, int cc) { return la_mask_edge(la_load_x_raw(in, a, b, kk, cc), in.n, a, b, kk, cc); }
+// tile (a, b) of R as another workgroup stored it
+__device__ __forceinline__ d4 la_load_r(const double* __restrict__ R, int ldr, int a, int b, int kk, int cc) {
+    unsigned off[4];
+    la_r_offsets(off, ldr, a, b, (unsigned)((kk * ldr + cc) * 8));
+    d4 v;
+    la_load_off(v, R, off);
+    return v;
+}
 __device__ __forceinline__ bool la_wait_ge(const int* p, int need, int limit) {   // bounded poll of a word another workgroup raises
 #pragma unroll 1
     for (int it = 0; it < limit; ++it) {
@@ -80,11 +98,15 @@ __device__ __forceinline__ d4 mfma_f64_na(double a, double b, d4 c) { return __b
 // workgroup of row min(LA+4, nb-2), [256], [257] wall clock at start / end, [320 + 16 wi + kb] / [416 + 16 wi + kb] every worker's end of products / arrival at the barrier
 #define LA_STAMP(ptr, idx) do { if constexpr (ST) { if ((ptr) && l == 0) (ptr)[idx] = clock64(); } } while (0)
 
-template <int LA, bool ST>
-__device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, const double* __restrict__ X, int ldx, int n,
+// PRIOR: the input is a covariance (semi-definite: pivots <= tol_rel * largest diagonal entry are dropped, DiagStep<.., true>; n x n
+// with any ld, optionally read reversed) and nobody trails the factorisation but the far workgroups: flag and rdy are put back to
+// zero at the end (no kernel ahead of k_front clears them).  !PRIOR: M = s2 I + ..., positive definite, NP x NP.
+template <int LA, bool ST, bool PRIOR>
+__device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, const LaIn in, const double tol_rel,
                                                   double* __restrict__ R, int ldr, double* __restrict__ Dinv, int* __restrict__ info,
-                                                  int* __restrict__ flag, const int* __restrict__ rdy, int* __restrict__ lost,
+                                                  int* __restrict__ flag, int* __restrict__ rdy, int* __restrict__ lost,
                                                   const int spin, unsigned long long* __restrict__ stamps) {
+    const int n = in.n;
     double (*sD)[17] = reinterpret_cast<double (*)[17]>(lds);                      // diagonal tile being factored (row view)
     double (*sDi)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + 272);       // inv(L11) of block step kb in sDi[kb & 1]
     double (*sL)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + 816);        // L11 of block step kb (rows) in sL[kb & 1]
@@ -103,8 +125,21 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
         // ================================ the pivot chain ================================
         LA_STAMP(stamps, 0);
         double dmin = INFINITY;
+        double tol = 0.0;
         {
-            const d4 d0 = la_load_x(X, ldx, n, 0, 0, kk, cc);
+            const d4 d0 = la_load_x(in, 0, 0, kk, cc);
+            if (PRIOR && tol_rel > 0.0) {   // pivot tolerance: relative to the largest diagonal entry (one gather)
+                double mx = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = l + 64 * r;
+                    const double dv = in.X[(size_t)(e < n ? e : 0) * (in.ld + 1)];
+                    mx = fmax(mx, e < n ? dv : 0.0);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+                tol = tol_rel * mx;
+            }
             int z = 0;
             asm volatile("" : "+v"(z));
 #pragma unroll
@@ -123,7 +158,7 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
                 v[c] = (c <= cc) ? a : 0.0;
                 y[c] = (c == cc) ? 1.0 : 0.0;
             }
-            DiagStep<0, false>::run(v, y, 0.0, dmin);   // (M is positive definite by construction: no pivot test on the chain)
+            DiagStep<0, PRIOR>::run(v, y, tol, dmin);   // (M is positive definite by construction: no pivot test on its chain)
             if (l < 16) {
                 double* pL = &sL[0][0][0] + z + (kb & 1) * 272;
 #pragma unroll
@@ -172,14 +207,14 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (l == 0) info[1] = !(dmin > 0.0) ? 1 : 0;   // any pivot that is not positive is a failure
+        if (l == 0) info[1] = PRIOR ? ((dmin < -tol) ? 1 : 0) : (!(dmin > 0.0) ? 1 : 0);   // (M: any pivot that is not positive is a failure)
         LA_STAMP(stamps, 63);
     } else if (wave == 4) {
         // ================================ the publisher ================================
         const unsigned lane_b = (unsigned)((kk * ldr + cc) * 8);
         unsigned long long* st4 = stamps ? stamps + 128 : nullptr;
         if (nb > 1) {
-            const d4 d1 = la_load_x(X, ldx, n, 1, 1, kk, cc);
+            const d4 d1 = la_load_x(in, 1, 1, kk, cc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sDiag[256 + r * 64 + l] = d1[r];
         }
@@ -245,7 +280,7 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int b = 1 + wi + POTRF_NW * q;
-                if (b < nb) t0[q] = la_load_raw(X, ldx, 0, b, kk, cc);
+                if (b < nb) t0[q] = la_load_x_raw(in, 0, b, kk, cc);
             }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -259,16 +294,26 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
         }
         // what arrives in step k: the tiles (k+1, b) of block row k+1, b = k+2+wi (and one more: see the dealing above), and the diagonal tile k+2 (worker 5);
         // from X while no far workgroup has touched them (rows <= LA, diagonal tiles <= LA+1), else from R behind rdy[]
-        const unsigned lane_bx = (unsigned)((kk * ldx + cc) * 8), lane_br = (unsigned)((kk * ldr + cc) * 8);
+        const unsigned lane_br = (unsigned)((kk * ldr + cc) * 8);
         auto fetch = [&](int k, d4& f0, d4& f1, d4& fd) {   // (raw: masked where they are used)
             // ONE site per step, and a tile this worker does not have keeps its register as it is (no second definition from another
             // load site): the compiler then leaves the loads in flight over the step instead of copying them -- behind a vmcnt(0) --
             // where two definitions would meet
             const int ra = k + 1, da = k + 2, b0 = k + 2 + wi, b1 = k + 2 + POTRF_NW + w2;
-            const bool rx = ra <= LA, dx = da <= LA + 1;
-            if (b0 < nb) la_load_raw_u(f0, rx ? X : R, rx ? ldx : ldr, ra, b0, rx ? lane_bx : lane_br);
-            if (b1 < nb) la_load_raw_u(f1, rx ? X : R, rx ? ldx : ldr, ra, b1, rx ? lane_bx : lane_br);
-            if (da < nb && wi == POTRF_NW - 1) la_load_raw_u(fd, dx ? X : R, dx ? ldx : ldr, da, da, dx ? lane_bx : lane_br);
+            const bool rx = ra <= LA, dx = da <= LA + 1;   // (from the input while no far workgroup has touched them)
+            unsigned o[4];
+            if (b0 < nb) {
+                if (rx) la_x_offsets(o, in, ra, b0, kk, cc); else la_r_offsets(o, ldr, ra, b0, lane_br);
+                la_load_off(f0, rx ? in.X : R, o);
+            }
+            if (b1 < nb) {
+                if (rx) la_x_offsets(o, in, ra, b1, kk, cc); else la_r_offsets(o, ldr, ra, b1, lane_br);
+                la_load_off(f1, rx ? in.X : R, o);
+            }
+            if (da < nb && wi == POTRF_NW - 1) {
+                if (dx) la_x_offsets(o, in, da, da, kk, cc); else la_r_offsets(o, ldr, da, da, lane_br);
+                la_load_off(fd, dx ? in.X : R, o);
+            }
         };
         const bool ragged = (n & 15) != 0;   // the last block row / column reaches past the matrix
         // the word step k's arrivals of THIS worker wait for (-1: none): row k+1 and the diagonal tile k+2 are one far workgroup's
@@ -425,14 +470,23 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
         LA_STAMP(stw, 63);
     }
     if constexpr (ST) { if (stamps && tid == 0) stamps[257] = wall_clock64(); }
+    if constexpr (PRIOR) {   // every far workgroup has handed its row over (they were all picked up): nobody reads the words any more
+        __syncthreads();
+        if (wave == 4) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's last store of the step counter has landed)
+            if (l < 16) __hip_atomic_store(rdy + l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l == 16) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // The far workgroup of block row a (LA+1 <= a <= nb-2): tiles (a, b), b = a+1 .. nb-1, and the diagonal tile (a+1, a+1); the
 // panels 0 .. a-1-LA; one or two tiles per wavefront.
 template <int LA, bool ST>
-__device__ __forceinline__ void potrf_la_far_wg(const int a, const double* __restrict__ X, int ldx, int n, double* __restrict__ R, int ldr,
+__device__ __forceinline__ void potrf_la_far_wg(const int a, const LaIn in, double* __restrict__ R, int ldr,
                                                 const int* __restrict__ flag, int* __restrict__ rdy, int* __restrict__ lost,
                                                 const int spin, unsigned long long* __restrict__ stamps) {
+    const int n = in.n;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
     const int nb = (n + 15) >> 4;
@@ -451,7 +505,7 @@ __device__ __forceinline__ void potrf_la_far_wg(const int a, const double* __res
     d4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        if (live[u]) acc[u] = la_load_x(X, ldx, n, ta[u], tb[u], kk, cc);
+        if (live[u]) acc[u] = la_load_x(in, ta[u], tb[u], kk, cc);
     const int plast = a - 1 - LA;
     bool gone = false;
     if (wave == 0) LA_STAMP(stf, 0);
@@ -490,29 +544,4 @@ __device__ __forceinline__ void potrf_la_far_wg(const int a, const double* __res
     if (wave == 0) LA_STAMP(stf, 3 * (plast + 1) + 1);
 }
 
-// grid: [0] the chain workgroup, [1 .. nsolve] the solver workgroups (potrf_solver_wg), [nsolve+1 ..] the far workgroups of the
-// block rows LA+1 .. nb-2.  Dynamic LDS: la_lds_doubles<LA>() doubles.  rdy[16]: zero at launch (k_gemm clears it with the step
-// counter, one kernel ahead).
-template <int LA, bool ST>
-__global__ __launch_bounds__(512) void k_potrf_solve_la(const double* __restrict__ X, int ldx, int n,
-                                                        double* __restrict__ R, int ldr, double* __restrict__ Dinv,
-                                                        int* __restrict__ info, int* __restrict__ flag, int* __restrict__ rdy,
-                                                        int* __restrict__ lost_flag, int nsolve,
-                                                        const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
-                                                        const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
-                                                        int tail, double tail_scale, int spin, unsigned long long* __restrict__ stamps) {
-    extern __shared__ __attribute__((aligned(16))) double sLaLds[];
-    if (blockIdx.x == 0) {
-        potrf_la_chain_wg<LA, ST>(sLaLds, X, ldx, n, R, ldr, Dinv, info, flag, rdy, lost_flag, spin, stamps);
-        return;
-    }
-    if ((int)blockIdx.x <= nsolve) {
-        potrf_solver_wg(blockIdx.x - 1, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
-        return;
-    }
-    potrf_la_far_wg<LA, ST>(LA + 1 + ((int)blockIdx.x - nsolve - 1), X, ldx, n, R, ldr, flag, rdy, lost_flag, spin, stamps);
-}
-
 #undef LA_STAMP
-
-}  // namespace orcvio_amd
