@@ -573,6 +573,7 @@ def main():
             'k_potrf(M)': n ** 3 / 3.0,
             'k_trsm': 1.0 * n * n * (n + 1),
             'k_potrf_solve(M)': n ** 3 / 3.0 + 1.0 * n * n * (n + 1),   # factorisation + trailing solve, one launch
+            'k_potrf_solve_la(M)': n ** 3 / 3.0 + 1.0 * n * n * (n + 1),   # the same launch with the trailing update on far workgroups
             'k_finish': 1.0 * n * (n + 1) * (n + 1),
         }
         # k_front = the tracks, the compression and chol(P) in one launch (the default whenever they are co-resident)
@@ -585,7 +586,8 @@ def main():
         # SURVEY count (n^3/3 + n^2 (n+1)) is the work it executes.  k_front is a few us LONGER (the max of chol P and the tracks),
         # but the SURVEY count of what it covers is the dense H'PH'^T / QR-of-the-stack count that it does not execute: its
         # dense-equivalent and executed figures are in `longest_kernel`.
-        dom = 'k_potrf_solve(M)' if 'k_potrf_solve(M)' in crit and 'k_front' in crit else longest
+        solve = 'k_potrf_solve_la(M)' if 'k_potrf_solve_la(M)' in crit else 'k_potrf_solve(M)'
+        dom = solve if solve in crit and 'k_front' in crit else longest
         achieved = kflops[dom] / (prof[dom] * 1e-3) / 1e12
         # HBM traffic and executed matrix-core work of every kernel: PMC counters (FETCH_SIZE + WRITE_SIZE,
         # SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; separate rocprofv3 passes) of the committed profile of
@@ -593,7 +595,7 @@ def main():
         traffic = None
         traffic_source = None
         critical_path = None
-        key_of = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<16>', 'k_potrf_solve(M)': 'k_potrf_solve<>',
+        key_of = {'k_feature': 'k_feature<3>', 'k_potrf(M)': 'k_potrf_reg<16>', 'k_potrf_solve(M)': 'k_potrf_solve<>', 'k_potrf_solve_la(M)': 'k_potrf_solve_la<3, false>',
                   'k_trsm': 'k_trsm_lds', 'k_finish': 'k_finish_sqrt', 'k_gram': 'k_gram_pair', 'k_assemble': 'k_assemble_A',
                   'k_front': 'k_front<3, 16>', 'k_gemm(U)': 'k_gemm_asmA', 'k_gemm(M)': 'k_gemm'}
         try:
@@ -629,11 +631,11 @@ def main():
                         item['mfma_busy_frac'] = e['SQ_VALU_MFMA_BUSY_CYCLES_median'] / (e['GRBM_GUI_ACTIVE_median'] * SIMDS)
                     critical_path[k] = item
                 critical_path['chain'] = dict(
-                    what='two dependent single-workgroup 202 x 202 Cholesky chains (chol P inside k_front, chol M in '
-                         'k_potrf_solve): 13 block steps x 16 pivots each, 180-250 cycles per pivot + one LDS hand-off and eight '
-                         'dependent MFMAs per block step; 92-94 k cycles per factorisation = 11.8 k of tile loads (one CU takes in '
-                         '~26 B per cycle) + steps 0-5 bound by the trailing update on three SIMDs + steps 6-12 bound by the chain '
-                         '(DESIGN.md 6); the launches are latency-bound, not MFMA- or HBM-bound',
+                    what='two dependent 202- and 187-pivot Cholesky chains (chol P inside k_front, chol M in k_potrf_solve_la): 13 / 12 block '
+                         'steps x 16 pivots each, 180 cycles per pivot + one LDS hand-off and eight dependent MFMAs per block step '
+                         '(4.6 k cycles); since round 5 the trailing update is spread over far workgroups (look-ahead 3), the chain '
+                         "workgroup's workers apply three panels to the arriving row: 65 k cycles for chol M (first five steps still "
+                         'bound by the workers, 6 k each; DESIGN.md 3.3, 6); latency-bound, not MFMA- or HBM-bound',
                     pivots=2 * n, block_steps=2 * ((n + 15) // 16))
         except Exception:
             pass
