@@ -45,6 +45,9 @@ struct EpilogueArgs {
     int* counter;                 // device memory, zero between launches
     unsigned long long* seq;      // device memory: publications so far
     unsigned long long* flag;     // host-coherent memory: the caller waits for *flag >= its expected sequence number
+    const int* info_also;         // optional: a second status block whose refusal refuses this commit too (the feature half's, for the chained object solve)
+    int pub_all;                  // 1: the flag rises behind the COMMIT workgroups too (the frame call's chained object solve runs on a stream of its
+                                  // own: whatever the caller does next on the handle's stream must find the commit done)
 };
 __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
     const int nb = gridDim.x, b = blockIdx.x, t = threadIdx.x;
@@ -61,8 +64,9 @@ __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
         for (int i = t; i < a.n; i += 256) { const double v = a.dx[i]; bad |= !(v - v == 0.0); }
         if (bad) s_bad = 1;
         __syncthreads();
-        const bool refused = a.info[2] != 0 || a.info[3] != 0 || a.info[8] != 0 || s_bad != 0;
-        const bool applied = a.info[2] == 0 && a.info[3] == 0 && (a.accept == nullptr || *a.accept != 0);
+        const bool also = a.info_also && (a.info_also[2] != 0 || a.info_also[3] != 0 || a.info_also[8] != 0);
+        const bool refused = a.info[2] != 0 || a.info[3] != 0 || a.info[8] != 0 || s_bad != 0 || also;
+        const bool applied = a.info[2] == 0 && a.info[3] == 0 && !also && (a.accept == nullptr || *a.accept != 0);
         const int nbc = nb - 1 - a.nb_P, bc = b - 1 - a.nb_P;
         const size_t stride = (size_t)nbc * 256;
         if (!refused)
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
     }
     // the flag rises when what the HOST reads is out (workgroups 0 .. nb_P); the commit workgroups write device memory only, which
     // whatever comes next on the stream sees by stream order -- the caller has its results 3-4 us before they are done
-    const int npub = 1 + a.nb_P;
+    const int npub = a.pub_all ? nb : 1 + a.nb_P;
     if (b >= npub) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -94,6 +98,24 @@ __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
             const unsigned long long v = atomicAdd(a.seq, 1ull) + 1ull;
             __hip_atomic_store(a.flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (release: behind everything above)
         }
+    }
+}
+
+// One workgroup that ends when *word has reached `expect` (cumulative counter written by a launch on ANOTHER stream): the launch behind
+// it starts behind this kernel's boundary, i.e. its start-of-kernel acquire comes after the other stream's work (the frame call's chained
+// object solve: k_finish_sqrt reads the covariance the feature half's epilogue committed).  Bounded: *lost is raised if it gives up.
+__global__ __launch_bounds__(64) void k_wait_word(const unsigned* __restrict__ word, unsigned expect, int* __restrict__ lost, int spin_limit,
+                                                  const int* __restrict__ info_src = nullptr, int* __restrict__ info_dst = nullptr) {
+    if (threadIdx.x != 0) return;
+    int spins = 0;
+    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
+        if (++spins > spin_limit) { if (lost) atomicExch(lost, 1); break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (info_src) {   // the status words the object half reports that other launches left in the FIRST status block: the prior's pivot counters
+                      // (k_front) and the compression's (rank-deficient directions, objects through the explicit basis)
+        const int idx[4] = {0, 1, 4, 5};
+        for (int q = 0; q < 4; ++q) info_dst[idx[q]] = __hip_atomic_load(info_src + idx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

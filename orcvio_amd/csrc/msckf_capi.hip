@@ -212,6 +212,14 @@ struct orcvio_msckf_handle {
     int* d_la_rdy = nullptr;            // k_potrf_solve_la: one word per block row a far workgroup brings forward (own 128-byte line, cleared by the k_gemm ahead of it)
     int la_solve = 3;                   // look-ahead depth of the fused solve (0: k_potrf_solve, one workgroup holds the whole trailing matrix; 2 / 3: k_potrf_solve_la)
     int la_spin = 1 << 22;              // polls (~1 us each) before a wait inside k_potrf_solve_la gives up: the update is then run again through k_potrf_solve
+    // second solve context of the frame call's chained object solve (capi_frame.inc, ORCVIO_FRAME_CHAIN): allocated on first use
+    double *d_U2 = nullptr, *d_M2 = nullptr, *d_RM2 = nullptr, *d_DinvM2 = nullptr, *d_Z2 = nullptr;
+    char* d_outs2 = nullptr;
+    unsigned* d_chain_words = nullptr;  // [0] feature half: M formed, [1] feature half: committed (cumulative values); [32] step counter, [48..63] block-row words of the second solve
+    unsigned chain_seq = 0u;
+    bool frame_chain = false;           // ORCVIO_FRAME_CHAIN (read at create): orcvio_msckf_io_update_frame runs the object solve chained (capi_frame.inc)
+    unsigned* mark_M_word = nullptr;    // launch_solve_stage(ST_FORM_M) stores mark_M_val there from a launch of its own behind the product (once)
+    unsigned mark_M_val = 0u;
     bool la_attr = false;               // the dynamic-LDS opt-in of k_potrf_solve_la is set for this handle's device
     // multi-GPU: RCCL communicator of this handle (orcvio_msckf_comm_init), the all-gather buffer [world][NAP_max^2] and
     // the gathered degrees of freedom of a sharded object update

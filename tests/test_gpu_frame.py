@@ -268,3 +268,40 @@ def test_frame_without_feature_tracks(upd):
     f, o = _frame(upd, none, objs)
     assert not f['stats'][3] and not np.any(f['dx'])
     assert o['accept'] == ref['accept'] == 1 and rel(o['dx'], ref['dx']) < TOL and rel(upd.cov_get(), ref['P_new']) < TOL
+
+
+@pytest.mark.parametrize('N,F,nobj,new_bbox', [(30, 400, 20, False), (30, 400, 20, True), (20, 120, 1, False), (12, 90, 3, False)])
+def test_frame_with_the_chained_object_solve(built, monkeypatch, N, F, nobj, new_bbox):
+    """ORCVIO_FRAME_CHAIN=1 (read at create): the object solve of the frame runs from the FEATURE update's prior factor and its M
+    (M12 = M1 + L_a^T A' L_a: the sequential update of the reference by Woodbury), on a stream and solve buffers of its own, beside
+    the feature half's solve and commit.  Another factor of the same matrix: the results agree with the two calls to rounding, not
+    bit for bit; the gate decision, the committed covariance and the oracle step by step are checked, five frames in a row."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=N, F=F, seed=4, flags=flags, track_len=None if N == 30 else (3, N), outlier_frac=0.05)
+    objs = synth.make_objects(win, n_objects=nobj, seed=2, sigma_kp=0.004)
+    plain = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    try:
+        plain.cov_set(win.P)
+        f0, o0 = _frame(plain, win, objs, new_bbox)
+        P0 = plain.cov_get()
+    finally:
+        plain.close()
+    monkeypatch.setenv('ORCVIO_FRAME_CHAIN', '1')
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    try:
+        ref1 = oracle.msckf_update(win, want_blocks=False, want_K=False)
+        ref2 = objects_update_reference(win, objs, ref1['P_new'], True, new_bbox, 0)
+        for it in range(5):
+            upd.cov_set(win.P)
+            f1, o1 = _frame(upd, win, objs, new_bbox)
+            P1 = upd.cov_get()
+            assert _same(f1['dx'], f0['dx']) and _same(f1['gamma'], f0['gamma']) and _same(f1['accept'], f0['accept'])   # the feature half is the same launches
+            assert o1['accept'] == o0['accept'] and _same(o1['stats'], o0['stats'])
+            assert abs(o1['gamma'] - o0['gamma']) < 1e-9 * abs(o0['gamma'])
+            assert rel(o1['dx'], o0['dx']) < 1e-9 and rel(P1, P0) < 1e-10
+            assert o1['accept'] == ref2['accept'] and rel(o1['dx'], ref2['dx']) < TOL and rel(P1, ref2['P_new']) < TOL
+        # the factor the chained commit left is a factor of the committed covariance: the next frame runs on it
+        f2, o2 = _frame(upd, win, objs, new_bbox)
+        assert np.isfinite(o2['dx']).all() and np.isfinite(f2['dx']).all()
+    finally:
+        upd.close()
