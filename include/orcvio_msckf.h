@@ -535,7 +535,8 @@ int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_resul
  *   [5] 1 if the last object update from tracks compressed its objects in ONE launch (k_obj_fused: rows evaluated into LDS, never
  *       materialised; every object through the explicit basis), 0 if it took the three-launch pipeline over materialised rows
  *       (an object with two frames on one clone, more than 32 in-window frames or 16 keypoints, rows beyond the LDS staging,
- *       ORCVIO_OPT_OBJECT_REFINE = 0, ORCVIO_OPT_REF_STACK_HF, ORCVIO_OPT_OBJECT_QR = 0)   [6..7] 0 */
+ *       ORCVIO_OPT_OBJECT_REFINE = 0, ORCVIO_OPT_REF_STACK_HF, ORCVIO_OPT_OBJECT_QR = 0)
+ *   [6] frames (orcvio_msckf_io_update_frame) whose object solve ran chained to the feature update's factor (ORCVIO_FRAME_CHAIN)   [7] 0 */
 #define ORCVIO_COUNTERS 8
 int32_t orcvio_msckf_counters(orcvio_msckf_handle* h, int64_t* counters, int32_t count);
 

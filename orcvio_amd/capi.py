@@ -462,7 +462,7 @@ class MsckfUpdater:
         self.lib.orcvio_msckf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
         self._chk(self.lib.orcvio_msckf_counters(self.h, v, 8), 'orcvio_msckf_counters')
         return dict(front_fallbacks=int(v[0]), graph_captures=int(v[1]), graph_replays=int(v[2]), plain_runs=int(v[3]),
-                    front_blocked_by_comm=int(v[4]), obj_fused=int(v[5]))
+                    front_blocked_by_comm=int(v[4]), obj_fused=int(v[5]), chained_frames=int(v[6]))
 
     def comm_info(self):
         r, w = C.c_int32(0), C.c_int32(0)

@@ -217,6 +217,7 @@ struct orcvio_msckf_handle {
     char* d_outs2 = nullptr;
     unsigned* d_chain_words = nullptr;  // [0] feature half: M formed, [1] feature half: committed (cumulative values); [32] step counter, [48..63] block-row words of the second solve
     unsigned chain_seq = 0u;
+    long long cnt_chained = 0;          // frames whose object solve ran chained (orcvio_msckf_counters [6])
     bool frame_chain = false;           // ORCVIO_FRAME_CHAIN (read at create): orcvio_msckf_io_update_frame runs the object solve chained (capi_frame.inc)
     unsigned* mark_M_word = nullptr;    // launch_solve_stage(ST_FORM_M) stores mark_M_val there from a launch of its own behind the product (once)
     unsigned mark_M_val = 0u;

@@ -39,7 +39,7 @@ while time.time() < t_end:
     variant = int(rng.integers(0, 3))
     flags = synth.Flags(use_larvio=int(variant == 0), use_left_perturbation=int(variant == 1), if_fej=int(rng.integers(0, 2)),
                         estimate_td=int(rng.integers(0, 2)), leg_dim=leg, noise_feature=float(rng.choice([0.008, 0.05])))
-    N = int(rng.integers(2, 10))
+    N = int(rng.integers(2, 10)) if not os.environ.get('ORCVIO_FRAME_CHAIN') else int(rng.integers(9, 16))   # (the chained object solve takes windows from six block steps)
     cap = int(rng.integers(N + 1, 25))
     frames = int(rng.integers(3, 9))
     par = dict(seed=seed, leg=leg, variant=variant, N0=N, cap=cap, frames=frames)
@@ -63,7 +63,7 @@ while time.time() < t_end:
             w = synth.make_window(N=N, F=F, seed=1000 * seed + fr, flags=flags, track_len=(min(3, N), N), outlier_frac=out_frac, sigma_px=0.008)
             w.P[:] = P
             ref = oracle.msckf_update(w, want_blocks=False, want_K=False)
-            one_call = N >= 4 and rng.integers(0, 4) == 0   # features + objects of the frame in ONE call (orcvio_msckf_io_update_frame)
+            one_call = N >= 4 and rng.integers(0, 4 if not os.environ.get('ORCVIO_FRAME_CHAIN') else 2) == 0   # features + objects of the frame in ONE call (orcvio_msckf_io_update_frame; every other frame when the chained form is being soaked)
             if one_call:
                 objs = synth.make_objects(w, n_objects=int(rng.integers(1, 4)), seed=seed + fr, sigma_kp=float(rng.choice([0.004, 0.1])))
                 ol, nb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
@@ -118,4 +118,5 @@ while time.time() < t_end:
         fails.append(dict(par, error=repr(e)[:300]))
     n_runs += 1
     seed += 1
-print(json.dumps(dict(runs=n_runs, frames=n_frames, updates=n_updates, first_seed=seed0, failures=fails, worst=worst), indent=1, default=str))
+print(json.dumps(dict(runs=n_runs, frames=n_frames, updates=n_updates, first_seed=seed0, frames_with_a_chained_object_solve=upd.counters().get('chained_frames'),
+                      failures=fails, worst=worst), indent=1, default=str))
