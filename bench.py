@@ -874,7 +874,7 @@ def compact_line(out, block_dt=None, detail_file=None):
     line['host_visible_resident_cov_ms'] = _r((lat.get('host_visible_resident_cov') or {}).get('median_ms'), 5)
     f1 = obj.get('frame_config3_one_call') or {}
     line['config3_frame_ms'] = _r(f1.get('median_ms'), 5)
-    line['config3_frame_chained_ms'] = _r((obj.get('frame_config3_one_call_chained') or {}).get('median_ms'), 5)   # (ORCVIO_FRAME_CHAIN=1: opt-in)
+    line['config3_frame_unchained_ms'] = _r((obj.get('frame_config3_one_call_unchained') or {}).get('median_ms'), 5)   # (ORCVIO_FRAME_CHAIN=0: the object solve behind the feature half, bit-identical to the two calls)
     line['config3_object_update_ms'] = _r((obj.get('resident') or {}).get('median_ms'), 5)
     oc = (obj.get('cpu_baseline') or {}).get('all_cores') or {}
     ac = (cpu or {}).get('all_cores') or {}
@@ -994,8 +994,9 @@ def objects_section(upd, capi, synth, orc, np, win):
     objects['frame_config3_one_call'] = dict(
         percentiles(lat_frame1), object_update_accepted=int(frame_call['last']()[1]['accept']),
         what='orcvio_msckf_io_update_frame: the same frame in one call -- feature update + commit, object update + commit, the object '
-             'tracks\' compression (rows, structured QR, A\') on its own stream beside the feature update\'s solve; results identical to '
-             'the two calls (tests/test_gpu_frame.py)')
+             'tracks\' compression (rows, structured QR, A\') on its own stream beside the feature update\'s solve, the object solve chained to '
+             'the feature update\'s prior factor and M (M12 = M1 + L_a^T A\' L_a) on that stream too; equal to the two calls to rounding '
+             '(tests/test_gpu_frame.py; ORCVIO_FRAME_CHAIN=0: bit for bit)')
 
     def renew_frame_pre():
         renew_frame(True)
@@ -1003,11 +1004,10 @@ def objects_section(upd, capi, synth, orc, np, win):
     objects['frame_config3_one_call_prefactored'] = dict(
         percentiles(timed_calls(run_frame, 100, warm=5, after=renew_frame_pre)),
         what='as frame_config3_one_call, the Cholesky of the frame\'s prior started ahead of the call')
-    # ... and with the object solve CHAINED to the feature update's prior factor and M (ORCVIO_FRAME_CHAIN=1, read at create: opt-in --
-    # the same update by Woodbury, from another factor of the same matrix: equal to the two calls to rounding (1e-10), not bit for bit;
-    # DESIGN.md 3.6): the object solve runs on the compression's stream beside the feature half's solve, finish and commit
+    # ... and with ORCVIO_FRAME_CHAIN=0 (read at create): the object solve BEHIND the feature half, on the covariance it leaves -- the form that is
+    # bit-identical to the two calls (the default chains the object solve to the feature update's prior factor and M: DESIGN.md 3.6)
     try:
-        os.environ['ORCVIO_FRAME_CHAIN'] = '1'
+        os.environ['ORCVIO_FRAME_CHAIN'] = '0'
         upc = capi.MsckfUpdater(device=upd.device if hasattr(upd, 'device') else 0, max_clones=32, max_features=2048, max_observations=65536)
         os.environ.pop('ORCVIO_FRAME_CHAIN', None)
         chained = {}
@@ -1025,15 +1025,14 @@ def objects_section(upd, capi, synth, orc, np, win):
         lat_c = timed_calls(run_chained, 100, warm=5, after=renew_chained)
         ref_o = frame_call['last']()[1]
         got_o = chained['last']()[1]
-        objects['frame_config3_one_call_chained'] = dict(
+        objects['frame_config3_one_call_unchained'] = dict(
             percentiles(lat_c), object_update_accepted=int(got_o['accept']),
-            dx_rel_diff_to_the_plain_one_call_form=float(np.linalg.norm(got_o['dx'] - ref_o['dx']) / max(np.linalg.norm(ref_o['dx']), 1e-300)),
-            what='orcvio_msckf_io_update_frame with ORCVIO_FRAME_CHAIN=1: the object solve from the feature update\'s prior factor and M '
-                 '(M12 = M1 + L_a^T A\' L_a), on the objects\' stream and solve buffers of its own, beside the feature half\'s solve / finish / commit')
+            dx_rel_diff_to_the_default_one_call_form=float(np.linalg.norm(got_o['dx'] - ref_o['dx']) / max(np.linalg.norm(ref_o['dx']), 1e-300)),
+            what='orcvio_msckf_io_update_frame with ORCVIO_FRAME_CHAIN=0: the object solve behind the feature half\'s commit, on the factor it leaves')
         upc.close()
     except Exception as e:   # (a side measurement: never in the way of the contract line)
         os.environ.pop('ORCVIO_FRAME_CHAIN', None)
-        objects['frame_config3_one_call_chained'] = dict(error=repr(e))
+        objects['frame_config3_one_call_unchained'] = dict(error=repr(e))
     restore()
     # the same frame with the prior factored ahead (orcvio_msckf_cov_prefactor when the image arrives)
 

@@ -756,10 +756,12 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
  *   ORCVIO_RCCL_LIB         path of the RCCL library to dlopen first (then librccl.so.1 / librccl.so by the loader's search -- an already
  *                           loaded one, e.g. torch's bundled copy, wins --, then /opt/rocm/lib)
  *   ORCVIO_FRAME_OVERLAP    0: orcvio_msckf_io_update_frame runs its two halves one behind the other
- *   ORCVIO_FRAME_CHAIN      1 (read at create; the ONE switch of this list that changes results, in the last bits): the frame call's object
- *                           solve is chained to the FEATURE update's prior factor and M (M12 = M1 + L_a^T A' L_a, the same sequential update by
- *                           Woodbury) and runs on the objects' stream beside the feature half's solve and commit: 6 % of the config-3 frame;
- *                           equal to the two calls to rounding (1e-10), not bit for bit
+ *   ORCVIO_FRAME_CHAIN      0 (read at create; the ONE switch of this list that changes results, in the last bits): the frame call's object
+ *                           solve runs BEHIND the feature half, on the covariance and factor it commits -- bit-identical to the two calls.
+ *                           Default 1 (windows from six block steps): the object solve is chained to the FEATURE update's prior factor and
+ *                           M (M12 = M1 + L_a^T A' L_a: the same sequential update, by Woodbury) and runs on the objects' stream beside the
+ *                           feature half's solve and commit -- 7 % of the config-3 frame; equal to the two calls to rounding (1e-10;
+ *                           DESIGN.md 3.6), counted in orcvio_msckf_counters [6]
  *   ORCVIO_FRAME_GRAPH      1: the frame call's feature half as a replayed launch graph (default: plain launches, with the objects'
  *                           compression enqueued in the middle of them: a graph's completion marker delays the object solve by ~14 us)
  *   ORCVIO_FRAME_EVENT_JOIN 1: the frame call's object solve joins the compression's stream with an event (default: its first product

@@ -218,7 +218,7 @@ struct orcvio_msckf_handle {
     unsigned* d_chain_words = nullptr;  // [0] feature half: M formed, [1] feature half: committed (cumulative values); [32] step counter, [48..63] block-row words of the second solve
     unsigned chain_seq = 0u;
     long long cnt_chained = 0;          // frames whose object solve ran chained (orcvio_msckf_counters [6])
-    bool frame_chain = false;           // ORCVIO_FRAME_CHAIN (read at create): orcvio_msckf_io_update_frame runs the object solve chained (capi_frame.inc)
+    bool frame_chain = true;            // ORCVIO_FRAME_CHAIN (read at create, default 1): orcvio_msckf_io_update_frame runs the object solve chained (capi_frame.inc)
     unsigned* mark_M_word = nullptr;    // launch_solve_stage(ST_FORM_M) stores mark_M_val there from a launch of its own behind the product (once)
     unsigned mark_M_val = 0u;
     bool la_attr = false;               // the dynamic-LDS opt-in of k_potrf_solve_la is set for this handle's device

@@ -45,6 +45,19 @@ def _same(a, b):
     return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
+def _chained(upd):
+    return upd.counters()['chained_frames']
+
+
+def _obj_agree(chained, a, b):
+    """the object half of the one-call form against the two calls: bit for bit -- unless the frame's object solve ran CHAINED to the
+    feature update's factor (windows from six block steps: another factor of the same matrix), then to rounding"""
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    if not chained:
+        return np.array_equal(a, b, equal_nan=True)
+    return float(np.linalg.norm(a - b)) <= 1e-9 * max(float(np.linalg.norm(b)), 1e-300)
+
+
 @pytest.mark.parametrize('N,F,nobj,new_bbox', [(10, 60, 3, False), (30, 400, 20, False), (30, 400, 20, True), (20, 120, 1, False)])
 def test_frame_equals_the_two_calls_and_the_oracle(upd, N, F, nobj, new_bbox):
     flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
@@ -54,13 +67,16 @@ def test_frame_equals_the_two_calls_and_the_oracle(upd, N, F, nobj, new_bbox):
     f0, o0 = _two_calls(upd, win, objs, new_bbox)
     P0 = upd.cov_get()
     upd.cov_set(win.P)
+    c0 = _chained(upd)
     f1, o1 = _frame(upd, win, objs, new_bbox)
+    ch = _chained(upd) > c0
+    assert ch == (N >= 20)   # (the chained object solve: windows from six block steps)
     P1 = upd.cov_get()
-    # the two forms: identical
+    # the two forms: identical (the object half to rounding where its solve ran chained)
     assert _same(f1['dx'], f0['dx']) and _same(f1['gamma'], f0['gamma']) and _same(f1['accept'], f0['accept'])
     assert _same(f1['stats'][:5], f0['stats'][:5])
-    assert o1['accept'] == o0['accept'] and _same(o1['gamma'], o0['gamma']) and _same(o1['dx'], o0['dx']) and _same(o1['stats'], o0['stats'])
-    assert _same(P1, P0)
+    assert o1['accept'] == o0['accept'] and _obj_agree(ch, o1['gamma'], o0['gamma']) and _obj_agree(ch, o1['dx'], o0['dx']) and _same(o1['stats'], o0['stats'])
+    assert _obj_agree(ch, P1, P0)
     # ... and the oracle, step by step
     ref1 = oracle.msckf_update(win, want_blocks=False, want_K=False)
     ref2 = objects_update_reference(win, objs, ref1['P_new'], True, new_bbox, 0)
@@ -234,8 +250,8 @@ def test_frame_survives_a_kernel_that_holds_half_the_device(built):
         for _ in range(5):   # ordinary frames: the objects' kernels beside the feature update never strand its front end
             u.cov_set(win.P)
             f1, o1 = _frame(u, win, objs)
-            assert _same(f1['dx'], f0['dx']) and _same(o1['dx'], o0['dx'])
-        assert _fallbacks(u) == 0
+            assert _same(f1['dx'], f0['dx']) and _obj_agree(True, o1['dx'], o0['dx'])   # (30 clones: the object solve runs chained)
+        assert _fallbacks(u) == 0 and _chained(u) == 5
         u.cov_set(win.P)
         u.lib.orcvio_msckf_debug_occupy.argtypes = [C.c_void_p, C.c_int32, C.c_double]
         assert u.lib.orcvio_msckf_debug_occupy(u.h, 128, 400.0) == 0   # 128 CUs held for 0.4 s on another stream
@@ -250,7 +266,7 @@ def test_frame_survives_a_kernel_that_holds_half_the_device(built):
         time.sleep(0.5)
         u.cov_set(win.P)
         f3, o3 = _frame(u, win, objs)   # the occupying kernel is gone: the overlapped form again
-        assert _same(f3['dx'], f0['dx']) and _same(o3['dx'], o0['dx']) and _fallbacks(u) == 1
+        assert _same(f3['dx'], f0['dx']) and _obj_agree(True, o3['dx'], o0['dx']) and _fallbacks(u) == 1
     finally:
         u.close()
 
@@ -272,21 +288,26 @@ def test_frame_without_feature_tracks(upd):
 
 @pytest.mark.parametrize('N,F,nobj,new_bbox', [(30, 400, 20, False), (30, 400, 20, True), (20, 120, 1, False), (12, 90, 3, False)])
 def test_frame_with_the_chained_object_solve(built, monkeypatch, N, F, nobj, new_bbox):
-    """ORCVIO_FRAME_CHAIN=1 (read at create): the object solve of the frame runs from the FEATURE update's prior factor and its M
+    """The default from six block steps (ORCVIO_FRAME_CHAIN=0 at create: off): the object solve of the frame runs from the FEATURE update's prior factor and its M
     (M12 = M1 + L_a^T A' L_a: the sequential update of the reference by Woodbury), on a stream and solve buffers of its own, beside
     the feature half's solve and commit.  Another factor of the same matrix: the results agree with the two calls to rounding, not
     bit for bit; the gate decision, the committed covariance and the oracle step by step are checked, five frames in a row."""
     flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
     win = synth.make_window(N=N, F=F, seed=4, flags=flags, track_len=None if N == 30 else (3, N), outlier_frac=0.05)
     objs = synth.make_objects(win, n_objects=nobj, seed=2, sigma_kp=0.004)
+    monkeypatch.setenv('ORCVIO_FRAME_CHAIN', '0')
     plain = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
     try:
         plain.cov_set(win.P)
         f0, o0 = _frame(plain, win, objs, new_bbox)
         P0 = plain.cov_get()
+        assert plain.counters()['chained_frames'] == 0
+        plain.cov_set(win.P)   # ... and with the chain off the one-call form IS the two calls, bit for bit
+        f00, o00 = _two_calls(plain, win, objs, new_bbox)
+        assert _same(o00['dx'], o0['dx']) and _same(plain.cov_get(), P0) and _same(f00['dx'], f0['dx'])
     finally:
         plain.close()
-    monkeypatch.setenv('ORCVIO_FRAME_CHAIN', '1')
+    monkeypatch.delenv('ORCVIO_FRAME_CHAIN')
     upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
     try:
         ref1 = oracle.msckf_update(win, want_blocks=False, want_K=False)
@@ -300,6 +321,7 @@ def test_frame_with_the_chained_object_solve(built, monkeypatch, N, F, nobj, new
             assert abs(o1['gamma'] - o0['gamma']) < 1e-9 * abs(o0['gamma'])
             assert rel(o1['dx'], o0['dx']) < 1e-9 and rel(P1, P0) < 1e-10
             assert o1['accept'] == ref2['accept'] and rel(o1['dx'], ref2['dx']) < TOL and rel(P1, ref2['P_new']) < TOL
+        assert upd.counters()['chained_frames'] == (5 if N >= 20 else 0)
         # the factor the chained commit left is a factor of the committed covariance: the next frame runs on it
         f2, o2 = _frame(upd, win, objs, new_bbox)
         assert np.isfinite(o2['dx']).all() and np.isfinite(f2['dx']).all()
