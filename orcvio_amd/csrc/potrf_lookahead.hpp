@@ -4,21 +4,21 @@
 // bodies on the prior.
 //
 // k_potrf_solve keeps the whole trailing matrix in the registers of ONE workgroup: its first block steps are bound by the FP64
-// matrix rate of one CU (66 + 55 + 45 + ... tile products on three SIMDs, 8-13 k cycles per step against the 4.9 k of the
+// matrix rate of one CU (66 + 55 + 45 + ... tile products on three SIMDs, 8-13 k cycles per step against the 4.6 k of the
 // pivot chain) and its prologue by one CU's memory pipeline (190 KB of tiles).  Here the chain workgroup only ever holds
 //   * the block row it is about to turn into a panel (sRow), and the last LA panels (sPan),
 // and every other block row a is brought forward by a FAR workgroup of its own (one workgroup per row a = LA+1 .. nb-2: the
 // tiles (a, b > a) and the diagonal tile (a+1, a+1)): it applies the panels 0 .. a-1-LA as they are published (the step counter
-// the solver workgroups poll as well), stores the row into R's own tiles and raises rdy[a].  The chain workgroup picks row a up
-// in step a-1 (its workers prefetch the tiles a step ahead), applies the LA panels the far workgroup has not seen, and the row is
-// the panel of step a.  Nothing of this sits on the chain: a far workgroup has LA-1 block steps (+ what is left of the step in
+// the solver workgroups poll as well), stores the row into R's own tiles and raises rdy[a].  The chain workgroup's workers fetch row a
+// in the middle of step a-2 (raw loads that stay in flight until step a-1), apply the LA panels the far workgroup has not seen
+// during step a-1, and the row is the panel of step a.  Nothing of this sits on the chain: a far workgroup has LA-1 block steps (+ what is left of the step in
 // which the panel was published) for two hand-offs through L2 (~1.3 us each) and LA panels' products.
 //
 // Roles of the chain workgroup (8 wavefronts): wave 0 the pivot chain (as potrf_reg_body: own panel tile, next diagonal tile,
 // DPP sweep); waves 1-3, 5-7 the workers (panel tiles of the step, then the arriving row); wave 4 the publisher: it alone writes
 // R and inv(L11) to memory (from LDS), drains its stores and raises the step counter -- the workers' prefetches stay in flight
-// across the block steps (no vmcnt wait in the step barrier), and the counter rises in the middle of a step instead of at the
-// next barrier.
+// across the block steps (no vmcnt wait in the step barrier).  (The long early rows take the publisher 2-3 k cycles to drain: it
+// raises their counter at the top of the next step instead of holding the step barrier; the last rows at once.)
 //
 // Inter-workgroup hand-offs follow MI355X_MICROARCH.md "Valid forms" (one lane of the storing workgroup signals for all of
 // that workgroup's sc1 stores, behind every storing wave's vmcnt(0) and a workgroup barrier; the consumer's polling wave loads
