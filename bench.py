@@ -278,8 +278,9 @@ def config_table(upd, capi, synth, orc, reps, cpu_budget_s):
             what='orcvio_msckf_io_update_frame: 500 tracks + 25 objects, both updates committed, host tracks in, dx out twice')
     except Exception as ex:
         out['config4_one_rank_share']['objects'] = dict(error=repr(ex))
-    # beyond the register-resident factorisations (n <= 224): 38 clones, n = 250 -- the LDS-panel Cholesky and k_trsm_rl
-    # ("tested, not timed" until round 5)
+    # beyond the register-resident factorisations (n <= 224): 38 clones, n = 250 -- both factorisations and the solve by 2 x 2 blocks out
+    # of the register kernels (capi_update.inc blk2; the LDS-panel Cholesky and k_trsm_rl it replaces took 1.0 ms here: "tested, not
+    # timed" until round 5)
     try:
         big = capi.MsckfUpdater(device=getattr(upd, 'device', 0), max_clones=40, max_features=512, max_observations=16384)
         wbig = synth.make_window(N=38, F=400, seed=3, flags=synth.Flags(use_larvio=1), track_len=(20, 30))
@@ -289,7 +290,7 @@ def config_table(upd, capi, synth, orc, reps, cpu_budget_s):
             big.run_update()
             big.sync()
         out['window_38_clones'] = dict(what='38 clones, 400 tracks of 20-30 observations, n = 250: beyond the register-resident factorisations '
-                                            '(LDS-panel Cholesky + k_trsm_rl, forked front end)', clones=38, tracks=wbig.F, n=int(wbig.n),
+                                            '(2 x 2 block factorisation out of the register kernels, forked front end; ORCVIO_BLK2=0: the LDS-panel kernels, 1.0 ms)', clones=38, tracks=wbig.F, n=int(wbig.n),
                                        device_resident=percentiles(timed_calls(one_big, reps)))
         big.close()
     except Exception as ex:

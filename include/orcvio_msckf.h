@@ -775,6 +775,9 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
  *   ORCVIO_SPLIT_TRACKS     track count from which the tracks front end is two launches over E scratch in HBM (k_feature_e + k_feature_gate);
  *                           default 0 = never (round 5: no faster than k_feature at 2 000 tracks, 85 MB of scratch traffic per update)
  *   ORCVIO_FUSED_FRONT, ORCVIO_FUSED_SOLVE   0: the forked seven-launch front end / the two-launch solve (same as the options)
+ *   ORCVIO_BLK2             0 (read at create): windows beyond the register-resident factorisations (n > 224: 34 .. 60 clones) through the LDS-panel
+ *                           Cholesky and k_trsm_rl (0.95-2.1 ms per update) instead of the 2 x 2 block factorisation out of the register kernels
+ *                           (0.26-0.41 ms); same results to rounding
  *   ORCVIO_LA_SOLVE         0 / 2 / 3: default of ORCVIO_OPT_LOOKAHEAD_SOLVE;  ORCVIO_LA_SPIN: polls before a wait inside k_potrf_solve_la gives up
  *                           (default 4 M, seconds; 0 makes every hand-off fail at once: the test of the fall-back)
  *   ORCVIO_FRONT_SPIN, ORCVIO_IO_SPIN_SECONDS   bounds of the in-launch hand-off of k_front (polls) and of the host's flag spin

@@ -119,6 +119,27 @@ __global__ __launch_bounds__(64) void k_wait_word(const unsigned* __restrict__ w
     }
 }
 
+// ---- helpers of the 2 x 2 block factorisation of windows beyond the register-resident kernels (capi_update.inc: blk2) ----
+// lower factor (row-major, ld ldl) from the upper factor the register kernels write (R row-major ld ldr, X = R^T R): L = R^T, zero above
+__global__ __launch_bounds__(256) void k_factor_to_lower(const double* __restrict__ Rf, int ldr, int n, double* __restrict__ L, int ldl) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    L[(size_t)i * ldl + j] = (j <= i) ? Rf[(size_t)j * ldr + i] : 0.0;
+}
+// rows [i0, i0 + rows) of the right-hand sides [B1 (strided) | bx] into Z
+__global__ __launch_bounds__(256) void k_copy_rhs(const double* __restrict__ B1, long sB1i, long sB1c, int nc1, const double* __restrict__ bx, long sbx,
+                                                  int i0, int rows, double* __restrict__ Z, int ldz) {
+    const int nc = nc1 + 1;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nc) return;
+    const int r = idx / nc, c = idx - r * nc, i = i0 + r;
+    Z[(size_t)i * ldz + c] = c < nc1 ? B1[(long)i * sB1i + (long)c * sB1c] : (bx ? bx[(long)i * sbx] : 0.0);
+}
+__global__ void k_info_merge(int* __restrict__ dst, const int* __restrict__ a) {   // dst[0..1] += a[0..1] (pivot counters of the two diagonal blocks)
+    if (threadIdx.x < 2) dst[threadIdx.x] += a[threadIdx.x];
+}
+
 // Block [status | dof | accepted rows | accepted tracks | sequence number | rank + 1 | 0 ...] behind a rank's compressed block in the all-gather
 // slot: what the other ranks must know about this rank's share (sharded calls; ORCVIO_ERR_PEER).  The sequence number is the ipc
 // transport's update counter q (0 under RCCL): the receiving rank checks it against its own before it sums the slot.

@@ -221,6 +221,7 @@ struct orcvio_msckf_handle {
     bool frame_chain = true;            // ORCVIO_FRAME_CHAIN (read at create, default 1): orcvio_msckf_io_update_frame runs the object solve chained (capi_frame.inc)
     unsigned* mark_M_word = nullptr;    // launch_solve_stage(ST_FORM_M) stores mark_M_val there from a launch of its own behind the product (once)
     unsigned mark_M_val = 0u;
+    bool blk2_opt = true;               // ORCVIO_BLK2 (read at create): windows of 15 .. 26 block steps factor by 2 x 2 blocks out of the register kernels
     bool la_attr = false;               // the dynamic-LDS opt-in of k_potrf_solve_la is set for this handle's device
     // multi-GPU: RCCL communicator of this handle (orcvio_msckf_comm_init), the all-gather buffer [world][NAP_max^2] and
     // the gathered degrees of freedom of a sharded object update

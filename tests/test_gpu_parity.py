@@ -307,11 +307,41 @@ def test_extra_states_behind_the_clones(upd, k):
 
 
 def test_large_window_takes_the_lds_panel_path(upd):
-    """N = 38 clones: n = 250 > 224, so both factorisations use the LDS-panel kernel (k_potrf) and the solve k_trsm_rl
-    instead of the register-resident / fused kernels."""
+    """N = 38 clones: n = 250 > 224, beyond the register-resident factorisations: both factorisations and the solve by 2 x 2 blocks out
+    of the register kernels (round 5: capi_update.inc blk2; before: the LDS-panel k_potrf and k_trsm_rl)."""
     w = synth.make_window(N=38, F=60, seed=21, track_len=(3, 12))
     assert w.n > 224
     _compare(upd.update_features(w, want_G=True), oracle.msckf_update(w), w)
+
+
+@pytest.mark.parametrize('N,F', [(34, 80), (38, 60), (47, 50), (60, 40)])
+def test_large_windows_block_factorisation_against_the_lds_panel_kernels(built, monkeypatch, N, F):
+    """Windows of 15 .. 26 block steps: the 2 x 2 block factorisation (R11 = chol(X11), W = R11^-T X12, S = X22 - W^T W, R22 = chol(S),
+    the solve through the same blocks) against the LDS-panel kernels it replaces (ORCVIO_BLK2=0) and the oracle; a semi-definite prior
+    (zero-variance extrinsics) in both leading and trailing block positions; the resident factor of the update before it as the prior."""
+    w = synth.make_window(N=N, F=F, seed=100 + N, track_len=(3, min(N, 24)))
+    ref = oracle.msckf_update(w)
+    monkeypatch.setenv('ORCVIO_BLK2', '0')
+    old = capi.MsckfUpdater(device=0, max_clones=60, max_features=256, max_observations=8192)
+    monkeypatch.delenv('ORCVIO_BLK2')
+    new = capi.MsckfUpdater(device=0, max_clones=60, max_features=256, max_observations=8192)
+    try:
+        a = old.update_features(w, want_G=True)
+        b = new.update_features(w, want_G=True)
+        _compare(b, ref, w)
+        assert np.array_equal(a['accept'], b['accept'])
+        assert rel(b['dx'], a['dx']) < 1e-9 and rel(b['P_new'], a['P_new']) < 1e-10 and rel(b['G'], a['G']) < 1e-8
+        # two updates in a row on the resident covariance: the second takes the factor the first committed (kf x kf block solve)
+        new.cov_set(w.P)
+        r1 = new.update_features(w, resident_cov=True, want_P=True)
+        new.cov_commit()
+        w2 = dataclasses.replace(w, P=r1['P_new'])
+        r2 = new.update_features(w2, resident_cov=True, want_P=True)
+        ref2 = oracle.msckf_update(w2)
+        assert rel(r1['dx'], ref['dx']) < 1e-6 and rel(r2['dx'], ref2['dx']) < 1e-6 and rel(r2['P_new'], ref2['P_new']) < 1e-6
+    finally:
+        old.close()
+        new.close()
 
 
 def test_maximum_window_of_60_clones(built):
