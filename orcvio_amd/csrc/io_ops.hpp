@@ -101,24 +101,6 @@ __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
     }
 }
 
-// One workgroup that ends when *word has reached `expect` (cumulative counter written by a launch on ANOTHER stream): the launch behind
-// it starts behind this kernel's boundary, i.e. its start-of-kernel acquire comes after the other stream's work (the frame call's chained
-// object solve: k_finish_sqrt reads the covariance the feature half's epilogue committed).  Bounded: *lost is raised if it gives up.
-__global__ __launch_bounds__(64) void k_wait_word(const unsigned* __restrict__ word, unsigned expect, int* __restrict__ lost, int spin_limit,
-                                                  const int* __restrict__ info_src = nullptr, int* __restrict__ info_dst = nullptr) {
-    if (threadIdx.x != 0) return;
-    int spins = 0;
-    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
-        if (++spins > spin_limit) { if (lost) atomicExch(lost, 1); break; }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    if (info_src) {   // the status words the object half reports that other launches left in the FIRST status block: the prior's pivot counters
-                      // (k_front) and the compression's (rank-deficient directions, objects through the explicit basis)
-        const int idx[4] = {0, 1, 4, 5};
-        for (int q = 0; q < 4; ++q) info_dst[idx[q]] = __hip_atomic_load(info_src + idx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // ---- helpers of the 2 x 2 block factorisation of windows beyond the register-resident kernels (capi_update.inc: blk2) ----
 // lower factor (row-major, ld ldl) from the upper factor the register kernels write (R row-major ld ldr, X = R^T R): L = R^T, zero above
 __global__ __launch_bounds__(256) void k_factor_to_lower(const double* __restrict__ Rf, int ldr, int n, double* __restrict__ L, int ldl) {

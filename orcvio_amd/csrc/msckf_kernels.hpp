@@ -2465,6 +2465,11 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
     potrf_solver_wg(blockIdx.x - 1, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
 }
 
+// LaEnd (optional): the factorising workgroup does not END before *word has reached `expect` (a cumulative counter another stream's launch
+// stores), and copies four status words -- the frame call's chained object solve: the launch behind this one (k_finish_sqrt) reads what the
+// feature half's commit wrote, and its start-of-kernel acquire must come after that commit.  Long satisfied when this kernel ends: no wait
+// in practice, and no launch of its own for it.
+struct LaEnd { const unsigned* word = nullptr; unsigned expect = 0u; const int* info_src = nullptr; int* info_dst = nullptr; };
 // k_potrf_solve_la: k_potrf_solve with the trailing update of the factorisation spread over far workgroups (potrf_lookahead.hpp).
 // grid: [0] the chain workgroup, [1 .. nsolve] the solver workgroups (potrf_solver_wg), [nsolve+1 ..] the far workgroups of the
 // block rows LA+1 .. nb-2.  Dynamic LDS: la_lds_doubles<LA>() doubles.  rdy[16]: zero at launch (k_gemm clears it with the step
@@ -2476,10 +2481,20 @@ __global__ __launch_bounds__(512) void k_potrf_solve_la(const double* __restrict
                                                         int* __restrict__ lost_flag, int nsolve,
                                                         const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
                                                         const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
-                                                        int tail, double tail_scale, int spin, unsigned long long* __restrict__ stamps) {
+                                                        int tail, double tail_scale, int spin, unsigned long long* __restrict__ stamps,
+                                                        LaEnd end = LaEnd()) {
     extern __shared__ __attribute__((aligned(16))) double sLaLds[];
     if (blockIdx.x == 0) {
         potrf_la_chain_wg<LA, ST, false>(sLaLds, LaIn{X, ldx, n, 0}, 0.0, R, ldr, Dinv, info, flag, rdy, lost_flag, spin, stamps);
+        if (end.word && threadIdx.x == 0) {   // (the frame call's chained object solve: see LaEnd)
+            int spins = 0;
+            while ((int)(__hip_atomic_load(end.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - end.expect) < 0) {
+                if (++spins > spin) { atomicExch(lost_flag, 1); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const int idx[4] = {0, 1, 4, 5};
+            for (int q = 0; q < 4; ++q) end.info_dst[idx[q]] = __hip_atomic_load(end.info_src + idx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     if ((int)blockIdx.x <= nsolve) {
