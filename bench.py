@@ -593,6 +593,8 @@ def main():
             'k_potrf_solve_la(M)': n ** 3 / 3.0 + 1.0 * n * n * (n + 1),   # the same launch with the trailing update on far workgroups
             'k_finish': 1.0 * n * (n + 1) * (n + 1),
         }
+        if 'k_finish' not in prof:   # P+ = s2 Z^T Z and dx by finish workgroups of the factorisation + solve launch (LaFin): its work too
+            kflops['k_potrf_solve_la(M)'] += kflops['k_finish']
         # k_front = the tracks, the compression and chol(P) in one launch (the default whenever they are co-resident)
         kflops['k_front'] = kflops['k_feature'] + kflops['k_gram'] + kflops['k_potrf(P)']
         # k_potrf(P) runs on a side stream, overlapped with k_feature/k_gram: not on the critical path
@@ -681,8 +683,10 @@ def main():
                                  'would have to run to match (it can exceed the peak), executed_mfma_tflops what the matrix cores do'),
                         note='achieved = algorithmic FP64 work of the reference algorithm attributed to the kernel (SURVEY 8d: n^3/3 + '
                              'n^2 (n+1) for the factorisation of M and the two triangular solves, n = 202 -- the count of the full-size '
-                             'problem although the launch factors the 187 active columns only) / kernel time, median of 20 launches '
-                             'measured with HIP events on the launch stream.  0.3-0.4 % of the FP64 matrix peak: a latency-bound chain '
+                             'problem although the launch factors the 187 active columns only' + (
+                                 '; + n (n+1)^2 for P+ = s2 Z^T Z and dx, which finish workgroups of the same launch compute' if 'k_finish' not in prof else '')
+                             + ') / kernel time, median of 20 passes of the update\'s launches, HIP events between the stages on the launch '
+                             'stream.  Well under 1 % of the FP64 matrix peak: a latency-bound chain '
                              '(critical_path.chain), as is chol P inside k_front; per_kernel_frac lists every launch of the step by the '
                              'same rule.',
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},

@@ -209,13 +209,20 @@ struct orcvio_msckf_handle {
                                         // default since round 5 -- at 2 000 tracks the two-launch form measured 0.208 ms against 0.211 for k_feature
                                         // with E in LDS, inside the run-to-run spread, and moves 85 MB of E scratch through HBM per update for it)
     int* d_sync = nullptr;              // device-wide counter of k_front (own allocation, zero between launches)
-    int* d_la_rdy = nullptr;            // k_potrf_solve_la: one word per block row a far workgroup brings forward (own 128-byte line, cleared by the k_gemm ahead of it)
+    int* d_la_rdy = nullptr;            // k_potrf_solve_la: one word per block row a far workgroup brings forward (own 128-byte line, cleared by the k_gemm ahead of it); [16..31] / [32] the same and the step counter for chol(P) inside k_front; [48] the finish workgroups' counter (LaFin)
     int la_solve = 3;                   // look-ahead depth of the fused solve (0: k_potrf_solve, one workgroup holds the whole trailing matrix; 2 / 3: k_potrf_solve_la)
+    size_t chain_fin_oo = 0;            // ... and where in the second outputs arena it put P++ (checked against the object half's layout)
+    int chain_fin_dof = -1;             // degrees of freedom the chained object solve's in-launch finish gated with (-1: it did not)
+    int fuse_finish = 1;                // P+ / dx (and an object update's gate) by finish workgroups of k_potrf_solve_la (LaFin) instead of a k_finish_sqrt
+                                        // launch behind it: 1 = in the chained frame call (both halves: 8-9 us off the frame), 2 = every update whose solve
+                                        // takes the look-ahead form (measured 2 us SLOWER per queued update: the in-launch hand-off costs what the launch
+                                        // boundary does, and the longer launch delays the next replay), 0 = never (ORCVIO_FUSE_FINISH)
+    bool fin_frame = false;             // the chained frame call is enqueueing its feature half
     int la_spin = 1 << 22;              // polls (~1 us each) before a wait inside k_potrf_solve_la gives up: the update is then run again through k_potrf_solve
     // second solve context of the frame call's chained object solve (capi_frame.inc, ORCVIO_FRAME_CHAIN): allocated on first use
     double *d_U2 = nullptr, *d_M2 = nullptr, *d_RM2 = nullptr, *d_DinvM2 = nullptr, *d_Z2 = nullptr;
     char* d_outs2 = nullptr;
-    unsigned* d_chain_words = nullptr;  // [0] feature half: M formed, [1] feature half: committed (cumulative values); [32] step counter, [48..63] block-row words of the second solve
+    unsigned* d_chain_words = nullptr;  // [0] feature half: M formed, [1] feature half: committed (cumulative values); [32] step counter, [48..63] block-row words of the second solve, [64] its finish workgroups' counter (LaFin)
     unsigned chain_seq = 0u;
     long long cnt_chained = 0;          // frames whose object solve ran chained (orcvio_msckf_counters [6])
     bool frame_chain = true;            // ORCVIO_FRAME_CHAIN (read at create, default 1): orcvio_msckf_io_update_frame runs the object solve chained (capi_frame.inc)

@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(1024) void k_potrf(double* __restrict__ A, int n, i
 // generic small FP64-MFMA product: one wavefront per 16x16 output tile.
 //   C[i][j] = sum_k A(i,k) * B(k,j),  A(i,k) = A[i*sAi + k*sAk], B(k,j) = B[k*sBk + j*sBj]
 // ---------------------------------------------------------------------------------------
-template <int TP_BATCH = 12>
+template <int TP_BATCH = 12, bool PUB = false>   // PUB: operands another workgroup of this launch stored (st_pub): L1-bypassing loads
 __device__ __forceinline__ d4 tile_product(const double* __restrict__ A, long sAi, long sAk, const double* __restrict__ B,
                                            long sBk, long sBj, int M, int N, int K, int i0, int j0, int l) {
     // Operands of TP_BATCH k-steps are loaded before the first MFMA of the batch: the kernels built on
@@ -1236,7 +1236,7 @@ __device__ __forceinline__ d4 tile_product(const double* __restrict__ A, long sA
         double a[TP_BATCH], b[TP_BATCH];
 #pragma unroll
         for (int q = 0; q < TP_BATCH; ++q) {
-            const double av = pa[q * stepA], bv = pb[q * stepB];
+            const double av = ld_sel<PUB>(pa + q * stepA), bv = ld_sel<PUB>(pb + q * stepB);
             a[q] = ia ? av : 0.0;
             b[q] = jb ? bv : 0.0;
         }
@@ -1256,8 +1256,8 @@ __device__ __forceinline__ d4 tile_product(const double* __restrict__ A, long sA
             const bool kin = 4 * q <= klast;
             const int qc = kin ? q : 0;
             const bool any = klast >= 0;
-            const double av = pa[(any ? qc : 0) * stepA - (any ? 0 : (long)kk * sAk)];
-            const double bv = pb[(any ? qc : 0) * stepB - (any ? 0 : (long)kk * sBk)];
+            const double av = ld_sel<PUB>(pa + ((any ? qc : 0) * stepA - (any ? 0 : (long)kk * sAk)));
+            const double bv = ld_sel<PUB>(pb + ((any ? qc : 0) * stepB - (any ? 0 : (long)kk * sBk)));
             a[q] = (ia && kin) ? av : 0.0;
             b[q] = (jb && kin) ? bv : 0.0;
         }
@@ -1969,9 +1969,10 @@ __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long
                                               int upper_only, double* __restrict__ C, long sCi, long sCj,
                                               const double* __restrict__ Cin = nullptr, int* __restrict__ clear = nullptr,
                                               const unsigned* __restrict__ wait = nullptr, unsigned expect = 0u, int* __restrict__ lost = nullptr,
-                                              int spin_limit = 0, int* __restrict__ clear16 = nullptr) {
+                                              int spin_limit = 0, int* __restrict__ clear16 = nullptr, int* __restrict__ clear1 = nullptr) {
     // clear: step counter of the k_potrf_solve launch that follows in the stream (reset here, one kernel ahead); clear16: the sixteen
-    // block-row words of k_potrf_solve_la
+    // block-row words of k_potrf_solve_la; clear1: the counter its finish workgroups wait for (LaFin; a cache line of its own)
+    if (clear1 && blockIdx.x == 0 && threadIdx.x == 16) __hip_atomic_store(clear1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (clear16 && blockIdx.x == 0 && threadIdx.x < 16) __hip_atomic_store(clear16 + threadIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // wait: completion counter of a launch on ANOTHER stream whose output this product reads (the frame call: A' of the objects'
@@ -2350,7 +2351,9 @@ __global__ __launch_bounds__(256) void k_trsm_lds(const double* __restrict__ R, 
 #define SOLVE_WPB 4
 #define SOLVE_CH 4
 // One solver workgroup of k_potrf_solve / k_potrf_solve_la (block index `sb` among the solver workgroups): see k_potrf_solve.
-__device__ __forceinline__ void potrf_solver_wg(const int sb, int n, const double* __restrict__ R, int ldr, const double* __restrict__ Dinv,
+// PUB: Z is consumed inside the launch (LaFin): stored past the caches.
+template <bool PUB>
+__device__ __forceinline__ void potrf_solver_body(const int sb, int n, const double* __restrict__ R, int ldr, const double* __restrict__ Dinv,
                                                 int* __restrict__ flag, int* __restrict__ lost_flag,
                                                 const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
                                                 const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
@@ -2364,7 +2367,7 @@ __device__ __forceinline__ void potrf_solver_wg(const int sb, int n, const doubl
     const int col = cb * 16 + cc;
     for (int e = l; e < 16 * tail; e += 64) {   // (independent of the factorisation: out of the way first)
         const int i = n + (e >> 4), c = cb * 16 + (e & 15);
-        if (c < ncols) Z[(size_t)i * ldz + c] = (c < nc1) ? tail_scale * B1[(long)i * sB1i + (long)c * sB1c] : 0.0;
+        if (c < ncols) st_pub<PUB>(&Z[(size_t)i * ldz + c], (c < nc1) ? tail_scale * B1[(long)i * sB1i + (long)c * sB1c] : 0.0);
     }
     d4 acc[14];
 #pragma unroll
@@ -2421,7 +2424,7 @@ __device__ __forceinline__ void potrf_solver_wg(const int sb, int n, const doubl
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * kb + kk + 4 * r;
-                if (col < ncols && i < n) Z[(size_t)i * ldz + col] = x[r];
+                if (col < ncols && i < n) st_pub<PUB>(&Z[(size_t)i * ldz + col], x[r]);
             }
 #pragma unroll
             for (int c = 0; c * SOLVE_CH < 13 - kb; ++c) {
@@ -2446,6 +2449,13 @@ __device__ __forceinline__ void potrf_solver_wg(const int sb, int n, const doubl
     }
     if (lost && l == 0) atomicAdd(lost_flag, 1);   // reported as an error by the host
 }
+__device__ __forceinline__ void potrf_solver_wg(const int sb, int n, const double* __restrict__ R, int ldr, const double* __restrict__ Dinv,
+                                                int* __restrict__ flag, int* __restrict__ lost_flag,
+                                                const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
+                                                const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
+                                                int tail, double tail_scale) {
+    potrf_solver_body<false>(sb, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
+}
 
 template <int NSLOT>
 __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ X, int ldx, int n, double tol_rel,
@@ -2469,44 +2479,10 @@ __global__ __launch_bounds__(512) void k_potrf_solve(const double* __restrict__ 
 // stores), and copies four status words -- the frame call's chained object solve: the launch behind this one (k_finish_sqrt) reads what the
 // feature half's commit wrote, and its start-of-kernel acquire must come after that commit.  Long satisfied when this kernel ends: no wait
 // in practice, and no launch of its own for it.
-struct LaEnd { const unsigned* word = nullptr; unsigned expect = 0u; const int* info_src = nullptr; int* info_dst = nullptr; };
-// k_potrf_solve_la: k_potrf_solve with the trailing update of the factorisation spread over far workgroups (potrf_lookahead.hpp).
-// grid: [0] the chain workgroup, [1 .. nsolve] the solver workgroups (potrf_solver_wg), [nsolve+1 ..] the far workgroups of the
-// block rows LA+1 .. nb-2.  Dynamic LDS: la_lds_doubles<LA>() doubles.  rdy[16]: zero at launch (k_gemm clears it with the step
-// counter, one kernel ahead).
-template <int LA, bool ST>
-__global__ __launch_bounds__(512) void k_potrf_solve_la(const double* __restrict__ X, int ldx, int n,
-                                                        double* __restrict__ R, int ldr, double* __restrict__ Dinv,
-                                                        int* __restrict__ info, int* __restrict__ flag, int* __restrict__ rdy,
-                                                        int* __restrict__ lost_flag, int nsolve,
-                                                        const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
-                                                        const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
-                                                        int tail, double tail_scale, int spin, unsigned long long* __restrict__ stamps,
-                                                        LaEnd end = LaEnd()) {
-    extern __shared__ __attribute__((aligned(16))) double sLaLds[];
-    if (blockIdx.x == 0) {
-        potrf_la_chain_wg<LA, ST, false>(sLaLds, LaIn{X, ldx, n, 0}, 0.0, R, ldr, Dinv, info, flag, rdy, lost_flag, spin, stamps);
-        if (end.word && threadIdx.x == 0) {   // (the frame call's chained object solve: see LaEnd)
-            int spins = 0;
-            while ((int)(__hip_atomic_load(end.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - end.expect) < 0) {
-                if (++spins > spin) { atomicExch(lost_flag, 1); break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            const int idx[4] = {0, 1, 4, 5};
-            for (int q = 0; q < 4; ++q) end.info_dst[idx[q]] = __hip_atomic_load(end.info_src + idx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    if ((int)blockIdx.x <= nsolve) {
-        potrf_solver_wg(blockIdx.x - 1, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
-        return;
-    }
-    potrf_la_far_wg<LA, ST>(LA + 1 + ((int)blockIdx.x - nsolve - 1), LaIn{X, ldx, n, 0}, R, ldr, flag, rdy, lost_flag, spin, stamps);
-}
-
-
-// P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (kdim x (n+1), ldz).  One workgroup per lower
-// tile, split-K over its 4 wavefronts (as k_gemm).
+// `mark` (optional, independent of the rest): a word the factorising workgroup stores as its first instruction -- "every launch ahead of
+// this one in the stream is complete", for a launch on another stream that polls it (the chained object solve waits for M this way).
+struct LaEnd { const unsigned* word = nullptr; unsigned expect = 0u; const int* info_src = nullptr; int* info_dst = nullptr;
+               unsigned* mark = nullptr; unsigned mark_val = 0u; };
 // Joint chi-square gate of an object update (gatingTest on the stacked, projected rows, src/orcvio.cpp:2172-2182), decided inside
 // k_finish_sqrt by every workgroup for itself (same arithmetic, same order: same decision): gamma = (|r'|^2 - |z|^2) / s2 with
 // |r'|^2 = *rr (corner of the compressed block) and z = Z[:, n].  Workgroup 0 writes gamma / accept for the consumers after this
@@ -2520,6 +2496,170 @@ struct ObjGate {
                                  // (non-finite or absurdly scaled input) and the update is not applied (P+ = P, dx = 0), for feature
                                  // and object updates alike
 };
+// LaFin (kernel template argument FIN): P+ = s2 Zn^T Zn and dx = Zn^T z inside this launch instead of a k_finish_sqrt behind it -- a
+// feature update's (no chi-square gate).  `nfin` finish workgroups behind the far ones, two tiles each, wait for the counter `done` (zero at
+// launch: rdy[15], cleared with the rest): every solver workgroup adds 1 when its stores of Z have landed (stored past the caches), the
+// chain workgroup 1, and 1 << 16 more if M was not positive definite (then P+ = P, dx = 0, as k_finish_sqrt decides from the status
+// words).  The arithmetic is k_finish_sqrt's tile by tile -- the same split of K over four wavefronts, the same order: the same bits.
+struct LaFin {
+    int first = 0;              // block index of the first finish workgroup
+    unsigned* done = nullptr;
+    const int* step = nullptr;  // the factorisation's step counter (flag), last_step: its value when the last but one block step is out
+    int last_step = 0;
+    int acq = 0;
+    int nstate = 0, kdim = 0;   // Z = [Zn | z] is kdim x (nstate + 1)
+    double s2 = 0.0;
+    double* P_out = nullptr;
+    double* dx = nullptr;
+    const double* P = nullptr;
+    int keep_tail = 0;
+    ObjGate gate;               // object updates: the joint chi-square gate, as k_finish_sqrt decides it (gate.fail is not read: the counter carries it)
+    const unsigned* wait_word = nullptr;   // the chained frame: P is what ANOTHER stream's launch commits; its word has reached wait_expect
+    unsigned wait_expect = 0u;             // when that is done (read past the caches then)
+};
+__device__ __forceinline__ void la_finish_wg(const int fb, const LaFin f, const double* __restrict__ Z, const int ldz, const int expect,
+                                             int* __restrict__ lost_flag, const int spin) {
+    __shared__ double sPart[2][3][4][64];
+    __shared__ unsigned sSeen;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int half = wave >> 2, w = wave & 3, n = f.nstate;
+    const int nbt = (n + 1 + 15) >> 4, t = 2 * fb + half;
+    const bool live = t < nbt * (nbt + 1) / 2;
+    int bi = 0, bj = 0;
+    if (live) tile_from_linear(t, bi, bj);
+    if (wave == 0) {   // (one wave polls, the others load behind the barrier it joins: MI355X_MICROARCH.md, valid forms, first row)
+        // While the factorisation is under way: a look at its step counter every few microseconds (the solver wavefronts poll that word
+        // all the time; the counter this workgroup waits for cannot rise before the last block step).
+#pragma unroll 1
+        for (int it = 0; it < spin && __hip_atomic_load(f.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.last_step; ++it)
+            __builtin_amdgcn_s_sleep(64);
+        unsigned v = 0u;
+#pragma unroll 1
+        for (int it = 0; it <= spin; ++it) {
+            v = __hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(v & 0xffffu) >= expect) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (f.wait_word) {
+#pragma unroll 1
+            for (int it = 0; it <= spin && (int)(__hip_atomic_load(f.wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - f.wait_expect) < 0; ++it) {
+                if (it == spin) v = 0u;   // reported below
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (l == 0) sSeen = v;
+        if (f.acq) {   // (experiment: one agent acquire, then plain loads that the XCD's L2 serves to all its finish workgroups)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    const unsigned seen = sSeen;
+    if ((int)(seen & 0xffffu) < expect) {   // never on a healthy device: reported, the host runs the update again in separate launches
+        if (threadIdx.x == 0) atomicAdd(lost_flag, 1);
+        return;
+    }
+    const bool failed = (seen >> 16) != 0u;
+    __shared__ double sZZ[2][4];
+    if (f.gate.rr) {   // |z|^2, by every half workgroup for itself (k_finish_sqrt's partition and order: the same gamma)
+        double zz = 0.0;
+        for (int i = threadIdx.x & 255; i < f.kdim; i += 256) { const double v = ld_pub(Z + (size_t)i * ldz + n); zz += v * v; }
+        zz = wave_sum(zz);
+        if (l == 0) sZZ[half][w] = zz;
+    }
+    d4 acc = {0, 0, 0, 0};
+    if (live) {
+        const int KS = ((f.kdim + 15) >> 4) << 2;
+        const int k0 = w * KS;
+        const int Kw = (f.kdim - k0 < KS) ? (f.kdim - k0) : KS;
+        // (sixteen k-steps in flight at once: the 50-odd rows of a wavefront in ONE round trip; the k-steps alternate between the two
+        //  accumulators whatever the batch size, so the sums are k_finish_sqrt's)
+        if (f.acq) acc = tile_product<16, false>(Z + (size_t)k0 * ldz, 1, ldz, Z + (size_t)k0 * ldz, ldz, 1, n + 1, n + 1, Kw, 16 * bi, 16 * bj, l);
+        else acc = tile_product<16, true>(Z + (size_t)k0 * ldz, 1, ldz, Z + (size_t)k0 * ldz, ldz, 1, n + 1, n + 1, Kw, 16 * bi, 16 * bj, l);
+        if (w > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sPart[half][w - 1][r][l] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (!live || w > 0) return;
+    const int kk = l >> 4, cc = l & 15;
+    bool app = !failed;
+    if (f.gate.rr) {
+        const double g = (*f.gate.rr - ((sZZ[half][0] + sZZ[half][1]) + (sZZ[half][2] + sZZ[half][3]))) / f.s2;
+        app = !failed && (g == g && g < f.gate.thr);
+        if (t == 0 && l == 0) { *f.gate.gamma = g; *f.gate.accept = app ? 1 : 0; *f.gate.gamma_out = g; *f.gate.accept_out = app ? 1 : 0; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = ((acc[r] + sPart[half][0][r][l]) + sPart[half][1][r][l]) + sPart[half][2][r][l];
+        const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+        if (i < n && jj < n && jj <= i) {
+            const bool prior = !app || (i >= n - f.keep_tail && jj >= n - f.keep_tail);
+            double pv = f.s2 * v;
+            if (prior) pv = f.wait_word ? 0.5 * (ld_pub(f.P + (size_t)i * n + jj) + ld_pub(f.P + (size_t)jj * n + i))
+                                        : 0.5 * (f.P[(size_t)i * n + jj] + f.P[(size_t)jj * n + i]);
+            f.P_out[(size_t)i * n + jj] = pv;
+            f.P_out[(size_t)jj * n + i] = pv;
+        } else if (i == n && jj < n) {
+            f.dx[jj] = app ? v : 0.0;
+        }
+    }
+}
+// k_potrf_solve_la: k_potrf_solve with the trailing update of the factorisation spread over far workgroups (potrf_lookahead.hpp).
+// grid: [0] the chain workgroup, [1 .. nsolve] the solver workgroups (potrf_solver_wg), [nsolve+1 ..] the far workgroups of the
+// block rows LA+1 .. nb-2, [fin.first ..] the finish workgroups (FIN).  Dynamic LDS: la_lds_doubles<LA>() doubles.  rdy[16]: zero at
+// launch (k_gemm clears it with the step counter, one kernel ahead).
+template <int LA, bool ST, bool FIN = false>
+__global__ __launch_bounds__(512) void k_potrf_solve_la(const double* __restrict__ X, int ldx, int n,
+                                                        double* __restrict__ R, int ldr, double* __restrict__ Dinv,
+                                                        int* __restrict__ info, int* __restrict__ flag, int* __restrict__ rdy,
+                                                        int* __restrict__ lost_flag, int nsolve,
+                                                        const double* __restrict__ B1, long sB1i, long sB1c, int nc1,
+                                                        const double* __restrict__ bx, long sbx, double* __restrict__ Z, int ldz,
+                                                        int tail, double tail_scale, int spin, unsigned long long* __restrict__ stamps,
+                                                        LaEnd end = LaEnd(), LaFin fin = LaFin()) {
+    extern __shared__ __attribute__((aligned(16))) double sLaLds[];
+    if (FIN && (int)blockIdx.x >= fin.first) {
+        la_finish_wg((int)blockIdx.x - fin.first, fin, Z, ldz, nsolve + 1, lost_flag, spin);
+        return;
+    }
+    if (blockIdx.x == 0) {
+        if (end.mark && threadIdx.x == 0) __hip_atomic_store(end.mark, end.mark_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        potrf_la_chain_wg<LA, ST, false>(sLaLds, LaIn{X, ldx, n, 0}, 0.0, R, ldr, Dinv, info, flag, rdy, lost_flag, spin, stamps);
+        if (FIN) {   // (the two pivot counters: sCnt[30..31] of the chain workgroup's LDS)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int* c = reinterpret_cast<const int*>(sLaLds + 1360);
+                __hip_atomic_fetch_add(fin.done, 1u + ((c[30] != 0 || c[31] != 0) ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (end.word && threadIdx.x == 0) {   // (the frame call's chained object solve: see LaEnd)
+            int spins = 0;
+            while ((int)(__hip_atomic_load(end.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - end.expect) < 0) {
+                if (++spins > spin) { atomicExch(lost_flag, 1); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const int idx[4] = {0, 1, 4, 5};
+            for (int q = 0; q < 4; ++q) end.info_dst[idx[q]] = __hip_atomic_load(end.info_src + idx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if ((int)blockIdx.x <= nsolve) {
+        potrf_solver_body<FIN>(blockIdx.x - 1, n, R, ldr, Dinv, flag, lost_flag, B1, sB1i, sB1c, nc1, bx, sbx, Z, ldz, tail, tail_scale);
+        if (FIN) {   // every storing wave waits for its stores, the workgroup's barrier, one lane signals
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(fin.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    potrf_la_far_wg<LA, ST>(LA + 1 + ((int)blockIdx.x - nsolve - 1), LaIn{X, ldx, n, 0}, R, ldr, flag, rdy, lost_flag, spin, stamps);
+}
+
+
+// P_out = s2 * Zn^T Zn (symmetric), dx = Zn^T z, with Z = [Zn | z] (kdim x (n+1), ldz).  One workgroup per lower
+// tile, split-K over its 4 wavefronts (as k_gemm).
 __global__ __launch_bounds__(256) void k_finish_sqrt(const double* __restrict__ Z, int ldz, int n, int kdim, double s2,
                                                      double* __restrict__ P_out, double* __restrict__ dx,
                                                      ObjGate gate = ObjGate(), const double* __restrict__ P = nullptr, int keep_tail = 0) {

@@ -207,7 +207,11 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (l == 0) info[1] = PRIOR ? ((dmin < -tol) ? 1 : 0) : (!(dmin > 0.0) ? 1 : 0);   // (M: any pivot that is not positive is a failure)
+        if (l == 0) {   // (M: any pivot that is not positive is a failure; sCnt[30..31]: the two counters for the launch's own finish, LaFin)
+            const int bad = PRIOR ? ((dmin < -tol) ? 1 : 0) : (!(dmin > 0.0) ? 1 : 0);
+            info[1] = bad;
+            sCnt[31] = bad;
+        }
         LA_STAMP(stamps, 63);
     } else if (wave == 4) {
         // ================================ the publisher ================================
@@ -265,7 +269,7 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
                 pend = true;
             }
         }
-        if (l == 0) info[0] = ndrop;
+        if (l == 0) { info[0] = ndrop; sCnt[30] = ndrop; }
     } else {
         // ================================ the workers ================================
         const int wi = (wave < 4) ? wave - 1 : 10 - wave;   // 0 .. POTRF_NW-1; the SIMDs 1, 2, 3 hold the pairs (0, 5), (1, 4), (2, 3)

@@ -86,6 +86,41 @@ def test_lookahead_solve_is_bit_identical_and_falls_back_when_a_hand_off_is_lost
         upd.close()
 
 
+@pytest.mark.parametrize('cfg', [1, 2])
+def test_finish_inside_the_solve_launch_is_bit_identical_to_the_finish_launch(built, monkeypatch, cfg):
+    """P+ = s2 Z^T Z, dx (and an object update's chi-square gate) by finish workgroups of k_potrf_solve_la (LaFin: they wait for the solver
+    workgroups' counter and read Z past the caches; ORCVIO_FUSE_FINISH=2: every update -- by default the chained frame call only, where
+    it pays) against the k_finish_sqrt launch behind it (ORCVIO_FUSE_FINISH=0): the same tiles, the same split of K, the same order --
+    the same bits, for the feature update (plain launches and the captured graph) and for the object update on the covariance it leaves."""
+    win = synth.config_window(cfg)
+    ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    owin = synth.make_window(N=win.N, F=4, seed=0, flags=oflags, track_len=4)
+    objs = synth.make_objects(owin, n_objects=6, seed=1, sigma_kp=0.004)
+
+    def run(mode):
+        monkeypatch.setenv('ORCVIO_FUSE_FINISH', mode)
+        upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384)
+        try:
+            feats = [upd.update_features(win) for _ in range(4)]
+            upd.cov_set(win.P)
+            obj = upd.update_object_tracks(oflags, owin.N, objs, None, owin.R_b2c[0], owin.t_c_b[0], True, False, 0)
+            return feats, obj
+        finally:
+            upd.close()
+
+    fused, ofused = run('2')
+    plain, oplain = run('0')
+    assert rel(plain[0]['dx'], ref['dx']) < 1e-6 and rel(plain[0]['P_new'], ref['P_new']) < 1e-6
+    for got in fused + plain[1:]:
+        assert np.array_equal(got['dx'], plain[0]['dx']) and np.array_equal(got['P_new'], plain[0]['P_new'])
+        assert np.array_equal(got['accept'], plain[0]['accept'])
+    assert oplain['accept'] == 1 and ofused['accept'] == oplain['accept']
+    assert np.array_equal(ofused['gamma'], oplain['gamma']) and np.array_equal(ofused['dx'], oplain['dx'])
+    if 'P_new' in oplain:
+        assert np.array_equal(ofused['P_new'], oplain['P_new'])
+
+
 @pytest.mark.parametrize('F', [509, 510, 511, 2000])
 def test_track_counts_around_the_co_residency_limit(built, F):
     """Up to 2 (CUs - 1) = 510 tracks the front end is ONE co-resident launch (k_front); beyond that the update takes the forked
