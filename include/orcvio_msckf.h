@@ -762,6 +762,10 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
  *                           M (M12 = M1 + L_a^T A' L_a: the same sequential update, by Woodbury) and runs on the objects' stream beside the
  *                           feature half's solve and commit -- 7 % of the config-3 frame; equal to the two calls to rounding (1e-10;
  *                           DESIGN.md 3.6), counted in orcvio_msckf_counters [6]
+ *   ORCVIO_FUSE_FINISH      (read at create) P+ = s2 Z^T Z, dx and an object update's gate by finish workgroups of the factorisation + solve
+ *                           launch instead of a k_finish_sqrt launch behind it (bit-identical either way): 1 (default) in the chained frame
+ *                           call, both halves (0.167-0.170 -> 0.160 ms); 2 in every update whose solve takes the look-ahead form (measured
+ *                           ~2 us slower per queued update); 0 never
  *   ORCVIO_FRAME_GRAPH      1: the frame call's feature half as a replayed launch graph (default: plain launches, with the objects'
  *                           compression enqueued in the middle of them: a graph's completion marker delays the object solve by ~14 us)
  *   ORCVIO_FRAME_EVENT_JOIN 1: the frame call's object solve joins the compression's stream with an event (default: its first product
