@@ -624,6 +624,11 @@ def main():
             pm = pm_doc['kernels']
             # the counters are those of a COMMITTED profile, not of this run: say which file and which build
             traffic_source = dict(file=os.path.relpath(pm_path, ROOT), build=pm_doc.get('build'), measured_in_this_run=False)
+            # (the solve launch's template arguments: look-ahead depth, stamps, finish inside the launch -- two arguments in profiles older than r5i)
+            for cand in (('k_potrf_solve_la<3, false, true>',) if 'k_finish' not in prof else ()) + ('k_potrf_solve_la<3, false, false>', 'k_potrf_solve_la<3, false>'):
+                if cand in pm:
+                    key_of['k_potrf_solve_la(M)'] = cand
+                    break
             if N == 30 and F == 400:
                 def pmc_of(k):   # (the template argument of the factorisation kernels is the block-column capacity: the smallest
                     #                  instantiation that holds this problem's active columns is the one the update launches)
@@ -685,8 +690,11 @@ def main():
                              'n^2 (n+1) for the factorisation of M and the two triangular solves, n = 202 -- the count of the full-size '
                              'problem although the launch factors the 187 active columns only' + (
                                  '; + n (n+1)^2 for P+ = s2 Z^T Z and dx, which finish workgroups of the same launch compute' if 'k_finish' not in prof else '')
-                             + ') / kernel time, median of 20 passes of the update\'s launches, HIP events between the stages on the launch '
-                             'stream.  Well under 1 % of the FP64 matrix peak: a latency-bound chain '
+                             + ') / kernel time by HIP events on the launch stream, median of 20 measurements of (10 x [k_gemm(M); this '
+                             'launch] - 10 x [k_gemm(M)]) / 10 -- the launch with one launch gap, as it sits in the update\'s graph (an event '
+                             'record on either side of a single launch adds 3-5 us to it; the other stages in kernel_ms are timed that way, '
+                             'one pass of the update\'s launches back to back with an event between two stages).  Well under 1 % of the FP64 '
+                             'matrix peak: a latency-bound chain '
                              '(critical_path.chain), as is chol P inside k_front; per_kernel_frac lists every launch of the step by the '
                              'same rule.',
                         kernel_ms={k: round(v, 5) for k, v in prof.items()},
