@@ -327,3 +327,32 @@ def test_frame_with_the_chained_object_solve(built, monkeypatch, N, F, nobj, new
         assert np.isfinite(o2['dx']).all() and np.isfinite(f2['dx']).all()
     finally:
         upd.close()
+
+
+def test_frame_runs_again_as_two_calls_when_an_in_launch_hand_off_is_lost(built, monkeypatch):
+    """ORCVIO_LA_SPIN=0: every wait on another workgroup inside the look-ahead solve launches (the far workgroups' block rows, the finish
+    workgroups' counter) gives up at once.  The frame call notices on the feature half's status word, drains, rolls its book-keeping
+    back and runs the frame again as the two calls, with plain launches and the one-workgroup factorisation -- the caller gets the
+    frame's results (equal to the two calls'), one fall-back counted per frame, and the handle stays usable."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=30, F=400, seed=4, flags=flags, outlier_frac=0.05)
+    objs = synth.make_objects(win, n_objects=20, seed=2, sigma_kp=0.004)
+    ref = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    try:
+        ref.cov_set(win.P)
+        f0, o0 = _two_calls(ref, win, objs)
+        P0 = ref.cov_get()
+    finally:
+        ref.close()
+    monkeypatch.setenv('ORCVIO_LA_SPIN', '0')
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    try:
+        for it in range(3):
+            upd.cov_set(win.P)
+            f1, o1 = _frame(upd, win, objs)
+            P1 = upd.cov_get()
+            assert np.array_equal(f1['accept'], f0['accept']) and rel(f1['dx'], f0['dx']) < 1e-9
+            assert o1['accept'] == o0['accept'] == 1 and rel(o1['dx'], o0['dx']) < 1e-9 and rel(P1, P0) < 1e-10
+            assert upd.counters()['front_fallbacks'] >= it + 1
+    finally:
+        upd.close()
