@@ -762,6 +762,8 @@ int32_t orcvio_msckf_cov_clones_to_nuisance(orcvio_msckf_handle* h, int32_t leg_
  *                           M (M12 = M1 + L_a^T A' L_a: the same sequential update, by Woodbury) and runs on the objects' stream beside the
  *                           feature half's solve and commit -- 7 % of the config-3 frame; equal to the two calls to rounding (1e-10;
  *                           DESIGN.md 3.6), counted in orcvio_msckf_counters [6]
+ *   ORCVIO_FRONT_U          1 (read at create): U = [A; b^T] L_a by the feature workgroups of k_front behind their Grams instead of the
+ *                           k_gemm_asmA launch (bit-identical; measured 6 us slower per update: docs/LAB_NOTES.md); default 0
  *   ORCVIO_FUSE_FINISH      (read at create) P+ = s2 Z^T Z, dx and an object update's gate by finish workgroups of the factorisation + solve
  *                           launch instead of a k_finish_sqrt launch behind it (bit-identical either way): 1 (default) in the chained frame
  *                           call, both halves (0.167-0.170 -> 0.160 ms); 2 in every update whose solve takes the look-ahead form (measured

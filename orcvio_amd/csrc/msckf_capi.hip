@@ -212,6 +212,10 @@ struct orcvio_msckf_handle {
     int* d_la_rdy = nullptr;            // k_potrf_solve_la: one word per block row a far workgroup brings forward (own 128-byte line, cleared by the k_gemm ahead of it); [16..31] / [32] the same and the step counter for chol(P) inside k_front; [48] the finish workgroups' counter (LaFin)
     int la_solve = 3;                   // look-ahead depth of the fused solve (0: k_potrf_solve, one workgroup holds the whole trailing matrix; 2 / 3: k_potrf_solve_la)
     size_t chain_fin_oo = 0;            // ... and where in the second outputs arena it put P++ (checked against the object half's layout)
+    bool front_u = false;               // ORCVIO_FRONT_U=1: U = [A; b^T] L_a by the feature workgroups of k_front, behind the Grams (FrontUArgs) instead of the
+                                        // k_gemm_asmA launch -- bit-identical, tested, and SLOWER (k_front 39.5 -> 54.9 us for a launch of 8.3 + gap: a
+                                        // second device-wide barrier, and 144 strips of A read past the caches): a measured negative, kept opt-in
+    bool front_did_U = false;           // ... the launch_front of this update did
     int chain_fin_dof = -1;             // degrees of freedom the chained object solve's in-launch finish gated with (-1: it did not)
     int fuse_finish = 1;                // P+ / dx (and an object update's gate) by finish workgroups of k_potrf_solve_la (LaFin) instead of a k_finish_sqrt
                                         // launch behind it: 1 = in the chained frame call (both halves: 8-9 us off the frame), 2 = every update whose solve

@@ -1832,6 +1832,169 @@ __global__ __launch_bounds__(512) void k_potrf_reg(const double* __restrict__ X,
 
 #include "potrf_lookahead.hpp"   // potrf_la_chain_wg / potrf_la_far_wg: the factorisation with its trailing update spread over far workgroups
 
+// k_gemm_asmA: C (M x Nc) = A (M x K) * B (K x Nc) where A is NOT in memory: entry (i,k) of the compressed block is
+// assembled on the fly as k_assemble_A would, scatter(S)(i,k) - sum_c Gpart[c](i,k).  Used for U = [A; b^T] L_a right
+// behind k_front, whose in-launch compression then ends with the Grams (no second device-wide barrier, no assembly
+// pass).  Same tiling as k_gemm: one workgroup per 16x16 tile of C, split-K over its four wavefronts; every load of a
+// batch (one S tile entry, <= 4 partial-Gram entries and one B entry per k-step) is issued before the first use.
+struct AsmArgs {
+    const double* S; int N, cb0, NA, NAP; const double* parts; int nparts; size_t stride; int dbg;
+    const double* plus;   // optional Gram added to A (EKF-SLAM rows), lower tiles valid
+};
+// One 16 x 16 tile of C = [A; b^T] B with the strip of A assembled in LDS: the body of k_gemm_asmA, 256 threads (tid), LDS handed in
+// (sA: 16 x 193, sPartF: 3 x 4 x 64, sSharedF: 4 x 64 doubles).  PUB: the Grams, the clone tiles and B were stored by other workgroups
+// of THIS launch (k_front with the product inside, FrontUArgs): read past the caches.  !active: the barriers only (no store).
+constexpr int ASM_LDS_DOUBLES = 16 * 193 + 3 * 4 * 64 + 4 * 64;
+template <bool PUB>
+__device__ __forceinline__ void asm_gemm_tile(const AsmArgs& aa, const double* __restrict__ B, long sBk, long sBj, int M, int Nc, int K,
+                                              double* __restrict__ C, long sCi, long sCj, const int tile_index, const bool active, const int tid,
+                                              double* __restrict__ sA, double* __restrict__ sPartF, double* __restrict__ sSharedF) {
+    constexpr int KMAX = 192, LDA = KMAX + 1;   // (193: one row per lane group without bank conflicts)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    const int kk = l >> 4, cc = l & 15;
+    const int ntj = (Nc + 15) >> 4;
+    const int bi = tile_index / ntj, bj = tile_index - bi * ntj;
+    const int KS = ((K + 15) >> 4) << 2;   // k-slice per wavefront, a multiple of the MFMA depth (<= 48 for K <= 192)
+    const int kbeg = wave * KS;
+    const int kend = (kbeg + KS < K) ? kbeg + KS : K;
+    // B operands of this wavefront's slice: in flight while the strip is assembled
+    constexpr int GB = 12;
+    const int jc = 16 * bj + cc;
+    const bool jb = jc < Nc;
+    const double* pb = B + (long)(jb ? jc : Nc - 1) * sBj;
+    double bv[GB];
+#pragma unroll
+    for (int q = 0; q < GB; ++q) {
+        const int k = kbeg + 4 * q + kk;
+        bv[q] = ld_sel<PUB>(pb + (long)(k < kend ? k : (kend > 0 ? kend - 1 : 0)) * sBk);
+    }
+    // ---- the (ext|r) x (ext|r) entries sum EVERY clone tile: once per workgroup that owns such rows, 64 entries x N
+    //      tiles over the 256 threads (clone c on thread group c % 4, then a fixed-order sum of the four partials)
+    const bool has_shared = (bi == 0 || bi == (aa.NA >> 4)) && aa.N > 0;   // rows 0..6 or row NA
+    if (has_shared) {
+        const int g4 = tid >> 6, en = tid & 63;
+        const int ea = en >> 3, eb = en & 7;                      // entry classes 0..6 -> e = 0..6, 7 -> e = 13
+        const int e0 = ea == 7 ? 13 : ea, e1 = eb == 7 ? 13 : eb;
+        const int e16 = (e0 >= e1) ? e0 * 16 + e1 : e1 * 16 + e0;
+        double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = g4; c < aa.N; c += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cu = c + 4 * u;
+                const double v = ld_sel<PUB>(aa.S + (size_t)(cu < aa.N ? cu : aa.N - 1) * 256 + e16);
+                acc8[u] += cu < aa.N ? v : 0.0;
+            }
+        }
+        sSharedF[g4 * 64 + en] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+    }
+    // ---- strip: thread (wave w, lane l) owns rows w, w+4, w+8, w+12 and columns l, l+64, l+128 -----------------------
+    double sv[4][3], gv[4][3][4], pv[4][3];
+    int cls[4][3];   // 0: no S contribution, 1: one clone tile (sv), 2: shared entry (index in cls >> 2)
+    int ekj[3], ckj[3];   // column classes: three per thread, shared by its four rows
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = l + 64 * j;
+        const int kc = k < K ? k : 0;
+        ekj[j] = -1; ckj[j] = -1;
+        if (kc < 7) ekj[j] = kc; else if (kc >= aa.cb0 && kc < aa.cb0 + 6 * aa.N) { ckj[j] = (kc - aa.cb0) / 6; ekj[j] = 7 + (kc - aa.cb0) - 6 * ckj[j]; }
+    }
+    // (32-bit element offsets from wave-uniform bases: the loads take the SGPR-base form, and the row part of every
+    //  index is scalar -- the per-element code is a dozen instructions, not a hundred)
+    const bool use_S = aa.N > 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave + 4 * rr;
+        const int i = 16 * bi + r;          // (wave-uniform)
+        const bool rin = i < M;
+        const int ic = rin ? i : 0;
+        int ei = -1, ci = -1;
+        if (ic < 7) ei = ic; else if (ic == aa.NA) ei = 13; else if (ic >= aa.cb0 && ic < aa.cb0 + 6 * aa.N) { ci = (ic - aa.cb0) / 6; ei = 7 + (ic - aa.cb0) - 6 * ci; }
+        const unsigned rowoff = (unsigned)(ic * aa.NAP);
+        const int ea = ei == 13 ? 7 : ei;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = l + 64 * j;
+            const bool in = rin && k < K;
+            const unsigned kc = k < K ? (unsigned)k : 0u;
+            const int ek = ekj[j], ck = ckj[j];
+            // clone tile and kind of S contribution: 0 none, 1 one clone tile, 2 every clone tile (shared block)
+            int c0 = ci >= 0 ? ci : ck, n1 = 0;
+            if (ei >= 0 && ek >= 0) n1 = (ci < 0 && ck < 0) ? 2 : ((ci >= 0 && ck >= 0 && ci != ck) ? 0 : 1);
+            if (!in || !use_S) n1 = 0;
+            const int e16 = (ei >= ek) ? ei * 16 + ek : ek * 16 + ei;   // the S tiles hold both triangles: [max][min]
+            cls[rr][j] = n1 == 2 ? (2 | ((ea * 8 + (ek == 13 ? 7 : ek)) << 2)) : n1;
+            sv[rr][j] = ld_sel<PUB>(aa.S + (n1 == 1 ? (unsigned)(c0 * 256 + e16) : 0u));
+            const unsigned src = rowoff + kc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < aa.nparts) gv[rr][j][u] = ld_sel<PUB>(aa.parts + (size_t)u * aa.stride + src);   // (wave-uniform count and base)
+            pv[rr][j] = 0.0;
+            if (aa.plus) pv[rr][j] = aa.plus[((ic >> 4) >= (int)(kc >> 4)) ? src : kc * (unsigned)aa.NAP + (unsigned)ic];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave + 4 * rr;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = l + 64 * j;
+            double sS = cls[rr][j] == 1 ? sv[rr][j] : 0.0;
+            if (has_shared && (cls[rr][j] & 3) == 2) {
+                const int en = cls[rr][j] >> 2;
+                sS = (sSharedF[en] + sSharedF[64 + en]) + (sSharedF[128 + en] + sSharedF[192 + en]);
+            }
+            double g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = u < aa.nparts ? gv[rr][j][u] : 0.0;
+            const bool in = 16 * bi + r < M && k < K;
+            sA[r * LDA + k] = in ? sS - ((g[0] + g[1]) + (g[2] + g[3])) + pv[rr][j] : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- split-K product from the strip ---------------------------------------------------------------------------
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    {
+        double a[GB];
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+            const int k = kbeg + 4 * q + kk;
+            const bool kin = k < kend;
+            a[q] = kin ? sA[cc * LDA + (kin ? k : 0)] : 0.0;
+            bv[q] = (jb && kin) ? bv[q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < GB; q += 2) {
+            acc0 = mfma_f64(a[q], bv[q], acc0);
+            acc1 = mfma_f64(a[q + 1], bv[q + 1], acc1);
+        }
+    }
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPartF[((wave - 1) * 4 + r) * 64 + l] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0 || !active) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = ((acc[r] + sPartF[r * 64 + l]) + sPartF[(4 + r) * 64 + l]) + sPartF[(8 + r) * 64 + l];
+        const int io = 16 * bi + kk + 4 * r, jo = 16 * bj + cc;
+        if (io < M && jo < Nc) C[(long)io * sCi + (long)jo * sCj] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __restrict__ B, long sBk, long sBj, int M, int Nc, int K,
+                                                   double* __restrict__ C, long sCi, long sCj, int* __restrict__ clear) {
+    // The 16 x K strip of A this tile needs is assembled into LDS first, with the k index along the lanes (coalesced
+    // reads of the partial Grams, whose two triangles are both written by k_front), then read back as MFMA operands.
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ double sAsm[ASM_LDS_DOUBLES];
+    asm_gemm_tile<false>(aa, B, sBk, sBj, M, Nc, K, C, sCi, sCj, (int)blockIdx.x, true, (int)threadIdx.x, sAsm, sAsm + 16 * 193, sAsm + 16 * 193 + 768);
+}
+
 // ---------------------------------------------------------------------------------------
 // k_front: the two independent front ends of the update in ONE launch -- workgroup 0 factors the prior
 // (potrf_reg_body, depends on P only), every other workgroup runs two feature tracks (feature_body, one
@@ -1861,6 +2024,18 @@ struct FrontGramArgs {
     const double* plus;           // optional Gram added to A (EKF-SLAM rows), lower tiles valid
     int spin_limit;               // polls of the flag line before a waiting workgroup gives up (a few tens of ms)
 };
+// U = [A; b^T] L_a inside the launch (g.enabled == 3): behind the Grams and a second device-wide barrier, every team takes one tile of U
+// with k_gemm_asmA's body -- same arithmetic, same bits -- as soon as the prior's factorisation has published the block row of R the
+// tile's columns of L_a come from (its step counter q.la_flag; nothing to wait for when the factor is resident).  The launch then ends
+// ~3 us later than the factorisation does, and the k_gemm_asmA launch behind it (8 us + a launch gap) is gone.  The factorising
+// workgroup puts its hand-off words back to zero only when every feature workgroup has said it is through (u.done).
+struct FrontUArgs {
+    AsmArgs aa;
+    const double* B; long sBk, sBj;
+    int M, Nc, K;
+    double* C; long sCi, sCj;
+    int* done;   // zero between launches
+};
 __device__ __forceinline__ void front_grid_barrier(int* counter, int target, int* lost, int spin_limit, unsigned long long* dbg = nullptr) {
     // Everything that crosses this barrier is written with write-through (sc1) stores and read with sc1 loads
     // (st_pub / ld_sel<true>), so no cache write-back or invalidate is needed: every wavefront waits for its own stores
@@ -1885,12 +2060,26 @@ __device__ __forceinline__ void front_grid_barrier(int* counter, int target, int
     __syncthreads();
 }
 template <int NPASS, int NSLOT>
-__global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int team_doubles, FrontGramArgs g) {
+__global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int team_doubles, FrontGramArgs g, FrontUArgs u) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (blockIdx.x == 0) {
         if (q.skip) return;
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[0] = wall_clock64();
-        if (q.nfar > 0) potrf_la_chain_wg<3, false, true>(smem, LaIn{q.X, q.ldx, q.n, q.rev}, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, q.la_flag, q.la_rdy, g.lost, q.la_spin, nullptr);
+        if (q.nfar > 0 && g.enabled == 3) {   // (the feature workgroups read the step counter until their tiles of U are out)
+            potrf_la_chain_wg<3, false, true, true>(smem, LaIn{q.X, q.ldx, q.n, q.rev}, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, q.la_flag, q.la_rdy, g.lost, q.la_spin, nullptr);
+            __syncthreads();
+            if ((threadIdx.x >> 6) == 4) {   // (the wavefront that stored the step counter)
+                const int l = threadIdx.x & 63, nfb = (int)gridDim.x - 1 - q.nfar;
+                int it = 0;
+                while (__hip_atomic_load(u.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfb && it < g.spin_limit) { __builtin_amdgcn_s_sleep(8); ++it; }
+                if (it >= g.spin_limit && l == 0) atomicAdd(g.lost, 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (l < 16) __hip_atomic_store(q.la_rdy + l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (l == 16) __hip_atomic_store(q.la_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (l == 17) __hip_atomic_store(u.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        else if (q.nfar > 0) potrf_la_chain_wg<3, false, true>(smem, LaIn{q.X, q.ldx, q.n, q.rev}, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, q.la_flag, q.la_rdy, g.lost, q.la_spin, nullptr);
         else potrf_reg_body<NSLOT, false>(smem, q.X, q.ldx, q.n, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, 0, 0, nullptr, nullptr, 1, 0, q.rev);
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[6] = wall_clock64();
         return;
@@ -1940,6 +2129,31 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     }
     FRONT_STAMP(3);
     int phases = 2;
+    if (g.enabled == 3) {   // ---- U = [A; b^T] L_a: one tile per team (FrontUArgs) ------------------------------------------
+        front_grid_barrier(g.counter, 2 * nfb, g.lost, g.spin_limit, me == 0 ? stamp + 7 : nullptr);
+        FRONT_STAMP(4);
+        const int ntj = (u.Nc + 15) >> 4, ntu = ((u.M + 15) >> 4) * ntj;
+        double* sU = smem + (size_t)team * ASM_LDS_DOUBLES;
+        for (int t0 = 2 * me; t0 < ntu; t0 += 2 * nfb) {
+            const int tile = t0 + team;
+            const bool active = tile < ntu;
+            if (!q.skip && active && local == 0) {   // block row (tile's column block) of R published?  (bounded; one lane polls, the barrier below)
+                const int need = tile % ntj + 1;
+                int it = 0;
+                while (__hip_atomic_load(q.la_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && it < q.la_spin) { __builtin_amdgcn_s_sleep(4); ++it; }
+                if (it >= q.la_spin) { atomicAdd(g.lost, 1); }
+            }
+            __syncthreads();
+            asm_gemm_tile<true>(u.aa, u.B, u.sBk, u.sBj, u.M, u.Nc, u.K, u.C, u.sCi, u.sCj, active ? tile : 0, active, local, sU, sU + 16 * 193, sU + 16 * 193 + 768);
+            __syncthreads();   // (the strip and the partial tiles are reused by the next item)
+        }
+        FRONT_STAMP(5);
+        if (!q.skip && q.nfar > 0) {   // this workgroup reads the factorisation's words no more
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(u.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        phases = 3;
+    }
     if (g.enabled == 1) {   // (enabled == 2: the consumer, k_gemm_asmA, assembles A on the fly)
         front_grid_barrier(g.counter, 2 * nfb, g.lost, g.spin_limit, me == 0 ? stamp + 7 : nullptr);
         FRONT_STAMP(4);
@@ -2013,160 +2227,6 @@ __global__ __launch_bounds__(256) void k_gemm(const double* __restrict__ A, long
         const int i = 16 * bi + kk + 4 * r, j = 16 * bj + cc;
         if (i < M && j < N)
             C[(long)i * sCi + (long)j * sCj] = alpha * v + ((i == j) ? diag_add : 0.0) + (Cin ? Cin[(long)i * sCi + (long)j * sCj] : 0.0);
-    }
-}
-
-// k_gemm_asmA: C (M x Nc) = A (M x K) * B (K x Nc) where A is NOT in memory: entry (i,k) of the compressed block is
-// assembled on the fly as k_assemble_A would, scatter(S)(i,k) - sum_c Gpart[c](i,k).  Used for U = [A; b^T] L_a right
-// behind k_front, whose in-launch compression then ends with the Grams (no second device-wide barrier, no assembly
-// pass).  Same tiling as k_gemm: one workgroup per 16x16 tile of C, split-K over its four wavefronts; every load of a
-// batch (one S tile entry, <= 4 partial-Gram entries and one B entry per k-step) is issued before the first use.
-struct AsmArgs {
-    const double* S; int N, cb0, NA, NAP; const double* parts; int nparts; size_t stride; int dbg;
-    const double* plus;   // optional Gram added to A (EKF-SLAM rows), lower tiles valid
-};
-__global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __restrict__ B, long sBk, long sBj, int M, int Nc, int K,
-                                                   double* __restrict__ C, long sCi, long sCj, int* __restrict__ clear) {
-    // The 16 x K strip of A this tile needs is assembled into LDS first, with the k index along the lanes (coalesced
-    // reads of the partial Grams, whose two triangles are both written by k_front), then read back as MFMA operands.
-    if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    constexpr int KMAX = 192, LDA = KMAX + 1;   // (193: one row per lane group without bank conflicts)
-    __shared__ double sA[16 * LDA];
-    __shared__ double sPart[3][4][64];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
-    const int kk = l >> 4, cc = l & 15;
-    const int ntj = (Nc + 15) >> 4;
-    const int bi = (int)blockIdx.x / ntj, bj = (int)blockIdx.x - bi * ntj;
-    const int KS = ((K + 15) >> 4) << 2;   // k-slice per wavefront, a multiple of the MFMA depth (<= 48 for K <= 192)
-    const int kbeg = wave * KS;
-    const int kend = (kbeg + KS < K) ? kbeg + KS : K;
-    // B operands of this wavefront's slice: in flight while the strip is assembled
-    constexpr int GB = 12;
-    const int jc = 16 * bj + cc;
-    const bool jb = jc < Nc;
-    const double* pb = B + (long)(jb ? jc : Nc - 1) * sBj;
-    double bv[GB];
-#pragma unroll
-    for (int q = 0; q < GB; ++q) {
-        const int k = kbeg + 4 * q + kk;
-        bv[q] = pb[(long)(k < kend ? k : (kend > 0 ? kend - 1 : 0)) * sBk];
-    }
-    // ---- the (ext|r) x (ext|r) entries sum EVERY clone tile: once per workgroup that owns such rows, 64 entries x N
-    //      tiles over the 256 threads (clone c on thread group c % 4, then a fixed-order sum of the four partials)
-    __shared__ double sShared[4][64];
-    const bool has_shared = (bi == 0 || bi == (aa.NA >> 4)) && aa.N > 0;   // rows 0..6 or row NA
-    if (has_shared) {
-        const int g4 = tid >> 6, en = tid & 63;
-        const int ea = en >> 3, eb = en & 7;                      // entry classes 0..6 -> e = 0..6, 7 -> e = 13
-        const int e0 = ea == 7 ? 13 : ea, e1 = eb == 7 ? 13 : eb;
-        const int e16 = (e0 >= e1) ? e0 * 16 + e1 : e1 * 16 + e0;
-        double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int c = g4; c < aa.N; c += 32) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int cu = c + 4 * u;
-                const double v = aa.S[(size_t)(cu < aa.N ? cu : aa.N - 1) * 256 + e16];
-                acc8[u] += cu < aa.N ? v : 0.0;
-            }
-        }
-        sShared[g4][en] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-    }
-    // ---- strip: thread (wave w, lane l) owns rows w, w+4, w+8, w+12 and columns l, l+64, l+128 -----------------------
-    double sv[4][3], gv[4][3][4], pv[4][3];
-    int cls[4][3];   // 0: no S contribution, 1: one clone tile (sv), 2: shared entry (index in cls >> 2)
-    int ekj[3], ckj[3];   // column classes: three per thread, shared by its four rows
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int k = l + 64 * j;
-        const int kc = k < K ? k : 0;
-        ekj[j] = -1; ckj[j] = -1;
-        if (kc < 7) ekj[j] = kc; else if (kc >= aa.cb0 && kc < aa.cb0 + 6 * aa.N) { ckj[j] = (kc - aa.cb0) / 6; ekj[j] = 7 + (kc - aa.cb0) - 6 * ckj[j]; }
-    }
-    // (32-bit element offsets from wave-uniform bases: the loads take the SGPR-base form, and the row part of every
-    //  index is scalar -- the per-element code is a dozen instructions, not a hundred)
-    const bool use_S = aa.N > 0;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave + 4 * rr;
-        const int i = 16 * bi + r;          // (wave-uniform)
-        const bool rin = i < M;
-        const int ic = rin ? i : 0;
-        int ei = -1, ci = -1;
-        if (ic < 7) ei = ic; else if (ic == aa.NA) ei = 13; else if (ic >= aa.cb0 && ic < aa.cb0 + 6 * aa.N) { ci = (ic - aa.cb0) / 6; ei = 7 + (ic - aa.cb0) - 6 * ci; }
-        const unsigned rowoff = (unsigned)(ic * aa.NAP);
-        const int ea = ei == 13 ? 7 : ei;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = l + 64 * j;
-            const bool in = rin && k < K;
-            const unsigned kc = k < K ? (unsigned)k : 0u;
-            const int ek = ekj[j], ck = ckj[j];
-            // clone tile and kind of S contribution: 0 none, 1 one clone tile, 2 every clone tile (shared block)
-            int c0 = ci >= 0 ? ci : ck, n1 = 0;
-            if (ei >= 0 && ek >= 0) n1 = (ci < 0 && ck < 0) ? 2 : ((ci >= 0 && ck >= 0 && ci != ck) ? 0 : 1);
-            if (!in || !use_S) n1 = 0;
-            const int e16 = (ei >= ek) ? ei * 16 + ek : ek * 16 + ei;   // the S tiles hold both triangles: [max][min]
-            cls[rr][j] = n1 == 2 ? (2 | ((ea * 8 + (ek == 13 ? 7 : ek)) << 2)) : n1;
-            sv[rr][j] = aa.S[n1 == 1 ? (unsigned)(c0 * 256 + e16) : 0u];
-            const unsigned src = rowoff + kc;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u < aa.nparts) gv[rr][j][u] = (aa.parts + (size_t)u * aa.stride)[src];   // (wave-uniform count and base)
-            pv[rr][j] = 0.0;
-            if (aa.plus) pv[rr][j] = aa.plus[((ic >> 4) >= (int)(kc >> 4)) ? src : kc * (unsigned)aa.NAP + (unsigned)ic];
-        }
-    }
-    if (has_shared) __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave + 4 * rr;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = l + 64 * j;
-            double sS = cls[rr][j] == 1 ? sv[rr][j] : 0.0;
-            if (has_shared && (cls[rr][j] & 3) == 2) {
-                const int en = cls[rr][j] >> 2;
-                sS = (sShared[0][en] + sShared[1][en]) + (sShared[2][en] + sShared[3][en]);
-            }
-            double g[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) g[u] = u < aa.nparts ? gv[rr][j][u] : 0.0;
-            const bool in = 16 * bi + r < M && k < K;
-            sA[r * LDA + k] = in ? sS - ((g[0] + g[1]) + (g[2] + g[3])) + pv[rr][j] : 0.0;
-        }
-    }
-    __syncthreads();
-    // ---- split-K product from the strip ---------------------------------------------------------------------------
-    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    {
-        double a[GB];
-#pragma unroll
-        for (int q = 0; q < GB; ++q) {
-            const int k = kbeg + 4 * q + kk;
-            const bool kin = k < kend;
-            a[q] = kin ? sA[cc * LDA + (kin ? k : 0)] : 0.0;
-            bv[q] = (jb && kin) ? bv[q] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < GB; q += 2) {
-            acc0 = mfma_f64(a[q], bv[q], acc0);
-            acc1 = mfma_f64(a[q + 1], bv[q + 1], acc1);
-        }
-    }
-    d4 acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
-    if (wave > 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sPart[wave - 1][r][l] = acc[r];
-    }
-    __syncthreads();
-    if (wave > 0) return;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double v = ((acc[r] + sPart[0][r][l]) + sPart[1][r][l]) + sPart[2][r][l];
-        const int io = 16 * bi + kk + 4 * r, jo = 16 * bj + cc;
-        if (io < M && jo < Nc) C[(long)io * sCi + (long)jo * sCj] = v;
     }
 }
 

@@ -101,7 +101,7 @@ __device__ __forceinline__ d4 mfma_f64_na(double a, double b, d4 c) { return __b
 // PRIOR: the input is a covariance (semi-definite: pivots <= tol_rel * largest diagonal entry are dropped, DiagStep<.., true>; n x n
 // with any ld, optionally read reversed) and nobody trails the factorisation but the far workgroups: flag and rdy are put back to
 // zero at the end (no kernel ahead of k_front clears them).  !PRIOR: M = s2 I + ..., positive definite, NP x NP.
-template <int LA, bool ST, bool PRIOR>
+template <int LA, bool ST, bool PRIOR, bool KEEP_WORDS = false>   // KEEP_WORDS: the caller puts flag / rdy back to zero (others still read them)
 __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, const LaIn in, const double tol_rel,
                                                   double* __restrict__ R, int ldr, double* __restrict__ Dinv, int* __restrict__ info,
                                                   int* __restrict__ flag, int* __restrict__ rdy, int* __restrict__ lost,
@@ -474,7 +474,7 @@ __device__ __forceinline__ void potrf_la_chain_wg(double* __restrict__ lds, cons
         LA_STAMP(stw, 63);
     }
     if constexpr (ST) { if (stamps && tid == 0) stamps[257] = wall_clock64(); }
-    if constexpr (PRIOR) {   // every far workgroup has handed its row over (they were all picked up): nobody reads the words any more
+    if constexpr (PRIOR && !KEEP_WORDS) {   // every far workgroup has handed its row over (they were all picked up): nobody reads the words any more
         __syncthreads();
         if (wave == 4) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's last store of the step counter has landed)

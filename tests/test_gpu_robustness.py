@@ -121,6 +121,41 @@ def test_finish_inside_the_solve_launch_is_bit_identical_to_the_finish_launch(bu
         assert np.array_equal(ofused['P_new'], oplain['P_new'])
 
 
+@pytest.mark.parametrize('cfg', [1, 2])
+def test_U_inside_k_front_is_bit_identical_to_the_product_launch(built, monkeypatch, cfg):
+    """U = [A; b^T] L_a by the feature workgroups of k_front, behind the Grams, each tile as soon as the prior's factorisation has
+    published the block row of the factor it needs (FrontUArgs; ORCVIO_FRONT_U=1: opt-in, it measured slower) against the k_gemm_asmA launch
+    behind k_front (the default): the same body, the same bits -- with the prior factored inside the launch (plain launches, then the captured
+    graph) and with its factor resident (cov_prefactor: nothing to wait for)."""
+    win = synth.config_window(cfg)
+    ref = oracle.msckf_update(win, want_blocks=False, want_K=False)
+    nobs = int(win.obs_ptr[-1])
+
+    def run(mode):
+        monkeypatch.setenv('ORCVIO_FRONT_U', mode)
+        upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384)
+        try:
+            feats = [upd.update_features(win) for _ in range(4)]
+            upd.cov_set(win.P)
+            upd.cov_prefactor()
+            io = upd.io_begin(win.flags, win.N, win.F, nobs, with_P=False)
+            upd.io_fill(io, win, with_P=False)
+            upd.io_update(want_P=False, commit=True)
+            return feats, io['dx'].copy(), upd.cov_get(), upd.counters()['front_fallbacks']
+        finally:
+            upd.close()
+
+    inside, dx_in, P_in, fb_in = run('1')
+    launch, dx_l, P_l, fb_l = run('0')
+    assert fb_in == 0 and fb_l == 0
+    assert rel(launch[0]['dx'], ref['dx']) < 1e-6 and rel(launch[0]['P_new'], ref['P_new']) < 1e-6
+    for got in inside + launch[1:]:
+        assert np.array_equal(got['dx'], launch[0]['dx']) and np.array_equal(got['P_new'], launch[0]['P_new'])
+        assert np.array_equal(got['accept'], launch[0]['accept']) and np.array_equal(got['gamma'], launch[0]['gamma'])
+    assert np.array_equal(dx_in, dx_l) and np.array_equal(P_in, P_l)
+    assert rel(dx_in, ref['dx']) < 1e-6 and rel(P_in, ref['P_new']) < 1e-6
+
+
 @pytest.mark.parametrize('F', [509, 510, 511, 2000])
 def test_track_counts_around_the_co_residency_limit(built, F):
     """Up to 2 (CUs - 1) = 510 tracks the front end is ONE co-resident launch (k_front); beyond that the update takes the forked
