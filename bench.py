@@ -629,6 +629,10 @@ def main():
                 if cand in pm:
                     key_of['k_potrf_solve_la(M)'] = cand
                     break
+            for cand in ('k_front<3, 16, false>', 'k_front<3, 16>'):   # (a third template argument since the end of round 5)
+                if cand in pm:
+                    key_of['k_front'] = cand
+                    break
             if N == 30 and F == 400:
                 def pmc_of(k):   # (the template argument of the factorisation kernels is the block-column capacity: the smallest
                     #                  instantiation that holds this problem's active columns is the one the update launches)

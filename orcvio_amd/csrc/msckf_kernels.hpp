@@ -2059,13 +2059,13 @@ __device__ __forceinline__ void front_grid_barrier(int* counter, int target, int
     }
     __syncthreads();
 }
-template <int NPASS, int NSLOT>
+template <int NPASS, int NSLOT, bool WITH_U = false>   // WITH_U: the instantiation that can form U behind the Grams (g.enabled == 3, FrontUArgs)
 __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int team_doubles, FrontGramArgs g, FrontUArgs u) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (blockIdx.x == 0) {
         if (q.skip) return;
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[0] = wall_clock64();
-        if (q.nfar > 0 && g.enabled == 3) {   // (the feature workgroups read the step counter until their tiles of U are out)
+        if (WITH_U && q.nfar > 0 && g.enabled == 3) {   // (the feature workgroups read the step counter until their tiles of U are out)
             potrf_la_chain_wg<3, false, true, true>(smem, LaIn{q.X, q.ldx, q.n, q.rev}, q.tol_rel, q.R, q.ldr, q.Dinv, q.info, q.la_flag, q.la_rdy, g.lost, q.la_spin, nullptr);
             __syncthreads();
             if ((threadIdx.x >> 6) == 4) {   // (the wavefront that stored the step counter)
@@ -2129,7 +2129,7 @@ __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int
     }
     FRONT_STAMP(3);
     int phases = 2;
-    if (g.enabled == 3) {   // ---- U = [A; b^T] L_a: one tile per team (FrontUArgs) ------------------------------------------
+    if (WITH_U && g.enabled == 3) {   // ---- U = [A; b^T] L_a: one tile per team (FrontUArgs) ------------------------------------------
         front_grid_barrier(g.counter, 2 * nfb, g.lost, g.spin_limit, me == 0 ? stamp + 7 : nullptr);
         FRONT_STAMP(4);
         const int ntj = (u.Nc + 15) >> 4, ntu = ((u.M + 15) >> 4) * ntj;
