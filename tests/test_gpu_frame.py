@@ -356,3 +356,41 @@ def test_frame_runs_again_as_two_calls_when_an_in_launch_hand_off_is_lost(built,
             assert upd.counters()['front_fallbacks'] >= it + 1
     finally:
         upd.close()
+
+
+@pytest.mark.parametrize('what', ['chi2_prob', 'noise_feature'])
+def test_frame_with_object_flags_that_differ_from_the_feature_flags(built, what):
+    """The object update of the frame takes its OWN flags: a chi-square probability of its own changes the gate's threshold (the chained
+    solve's in-launch gate must use it, not the feature half's), a measurement noise of its own takes the frame off the chain
+    (M12 = M1 + L_a^T A' L_a holds for one sigma): either way the one-call form agrees with the two calls."""
+    import dataclasses
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=30, F=400, seed=4, flags=flags, outlier_frac=0.05)
+    objs = synth.make_objects(win, n_objects=20, seed=2, sigma_kp=0.004)
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    try:
+        # the threshold that sits just below / above this frame's gamma: the decision flips with the object flags' probability
+        upd.cov_set(win.P)
+        _, o_ref = _two_calls(upd, win, objs)
+        assert o_ref['accept'] == 1
+        for val in ((1e-9, 0.95) if what == 'chi2_prob' else (0.008 * 1.5,)):
+            oflags = dataclasses.replace(flags, **{what: val})
+            upd.cov_set(win.P)
+            io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+            upd.io_fill(io, win, with_P=False)
+            upd.io_update(want_P=False, commit=True)
+            o0 = upd.update_object_tracks(oflags, win.N, objs, None, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+            upd.cov_commit()
+            P0 = upd.cov_get()
+            upd.cov_set(win.P)
+            c0 = _chained(upd)
+            f1, o1 = upd.update_frame(win, oflags, objs, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+            P1 = upd.cov_get()
+            ch = _chained(upd) > c0
+            assert ch == (what == 'chi2_prob')
+            assert o1['accept'] == o0['accept'] and _obj_agree(ch, o1['gamma'], o0['gamma']) and _obj_agree(ch, o1['dx'], o0['dx'])
+            assert _obj_agree(ch, P1, P0)
+            if what == 'chi2_prob':
+                assert o1['accept'] == (1 if val > 0.5 else 0)   # (a probability of 1e-9 rejects everything: P++ = P+, dx = 0)
+    finally:
+        upd.close()
