@@ -907,6 +907,7 @@ def compact_line(out, block_dt=None, detail_file=None):
     line['host_visible_resident_cov_ms'] = _r((lat.get('host_visible_resident_cov') or {}).get('median_ms'), 5)
     f1 = obj.get('frame_config3_one_call') or {}
     line['config3_frame_ms'] = _r(f1.get('median_ms'), 5)
+    line['config3_frame_objects_staged_ahead_ms'] = _r((obj.get('frame_config3_one_call_objects_staged_ahead') or {}).get('median_ms'), 5)   # (orcvio_msckf_io_stage_object_tracks before the call)
     line['config3_frame_unchained_ms'] = _r((obj.get('frame_config3_one_call_unchained') or {}).get('median_ms'), 5)   # (ORCVIO_FRAME_CHAIN=0: the object solve behind the feature half, bit-identical to the two calls)
     line['config3_object_update_ms'] = _r((obj.get('resident') or {}).get('median_ms'), 5)
     oc = (obj.get('cpu_baseline') or {}).get('all_cores') or {}
@@ -1030,6 +1031,20 @@ def objects_section(upd, capi, synth, orc, np, win):
              'tracks\' compression (rows, structured QR, A\') on its own stream beside the feature update\'s solve, the object solve chained to '
              'the feature update\'s prior factor and M (M12 = M1 + L_a^T A\' L_a) on that stream too; equal to the two calls to rounding '
              '(tests/test_gpu_frame.py; ORCVIO_FRAME_CHAIN=0: bit for bit)')
+
+    # ... with the object tracks staged AHEAD of the call (orcvio_msckf_io_stage_object_tracks, outside the timed part like the feature
+    # tracks' io_fill: the object mapper's results are at hand before the frame's feature update starts)
+    def renew_frame_staged():
+        renew_frame()
+        frame_call['c'].stage()
+    renew_frame_staged()
+    lat_frame_staged = timed_calls(run_frame, 100, warm=5, after=renew_frame_staged)
+    objects['frame_config3_one_call_objects_staged_ahead'] = dict(
+        percentiles(lat_frame_staged), object_update_accepted=int(frame_call['last']()[1]['accept']),
+        prestaged_frames=int(upd.counters().get('prestaged_frames', 0)),
+        what='as frame_config3_one_call, the object tracks scanned and packed into the pinned staging arena before the call '
+             '(orcvio_msckf_io_stage_object_tracks): ~14 us of host time that otherwise stands between the tracks\' launch and the '
+             'compression\'s; bit-identical results (tests/test_gpu_frame.py)')
 
     def renew_frame_pre():
         renew_frame(True)

@@ -536,7 +536,8 @@ int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_resul
  *       materialised; every object through the explicit basis), 0 if it took the three-launch pipeline over materialised rows
  *       (an object with two frames on one clone, more than 32 in-window frames or 16 keypoints, rows beyond the LDS staging,
  *       ORCVIO_OPT_OBJECT_REFINE = 0, ORCVIO_OPT_REF_STACK_HF, ORCVIO_OPT_OBJECT_QR = 0)
- *   [6] frames (orcvio_msckf_io_update_frame) whose object solve ran chained to the feature update's factor (ORCVIO_FRAME_CHAIN)   [7] 0 */
+ *   [6] frames (orcvio_msckf_io_update_frame) whose object solve ran chained to the feature update's factor (ORCVIO_FRAME_CHAIN)
+ *   [7] frame calls that found their object tracks staged ahead (orcvio_msckf_io_stage_object_tracks) */
 #define ORCVIO_COUNTERS 8
 int32_t orcvio_msckf_counters(orcvio_msckf_handle* h, int64_t* counters, int32_t count);
 
@@ -557,6 +558,18 @@ int32_t orcvio_msckf_objects_local_tracks(orcvio_msckf_handle* h, const orcvio_m
                                           const orcvio_object_eval_flags* eval_flags, int32_t n_clones,
                                           const orcvio_object_track* tracks, int32_t n_tracks, const double* P,
                                           double* d_dst, int32_t* dof_out, void* stream);
+
+/* The object tracks of the NEXT orcvio_msckf_io_update_frame call, scanned and staged ahead of it.  The caller has them before the
+ * frame's feature update starts -- they come from the object mapper (ros_wrapper/src/orcvio/src/System.cpp:622-708), not from the
+ * image -- so their packing into the handle's pinned staging arena (~14 us of host time for twenty objects) need not sit inside the
+ * frame call, between the tracks' launch and the compression's: it is done here, as the feature tracks are written into the arena by
+ * the caller before the call.  Call between orcvio_msckf_io_begin (with_P = 0; the window's clone count is taken from it) and
+ * orcvio_msckf_io_update_frame, and hand the SAME `tracks` pointer, count, flags and eval flags to the frame call: anything else -- or
+ * any other object call in between -- and the frame call stages for itself, as without this call (orcvio_msckf_counters [7] counts the
+ * frames that found their tracks staged).  The track data are COPIED here: later changes to them are not seen by the frame call.
+ * Results are the frame call's, bit for bit, either way. */
+int32_t orcvio_msckf_io_stage_object_tracks(orcvio_msckf_handle* h, const orcvio_msckf_flags* object_flags,
+                                            const orcvio_object_eval_flags* eval_flags, const orcvio_object_track* tracks, int32_t n_tracks);
 
 /* ---- One frame in one call: the feature update, then the object update on the covariance it leaves -------------------------
  * System::imageCallback runs Estimator->processFeatures (its last update: OrcVIO::removeLostFeatures / pruneImuStateBuffer) and

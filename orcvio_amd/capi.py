@@ -194,6 +194,7 @@ def _bind(lib):
                                                       C.POINTER(ObjectTrackC), C.c_int32, _dp, C.c_void_p, _ip, C.c_void_p]
     lib.orcvio_msckf_io_update_frame.argtypes = [C.c_void_p, C.POINTER(MsckfResult), C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags),
                                                  C.POINTER(ObjectTrackC), C.c_int32, C.c_int32, C.POINTER(MsckfResult)]
+    lib.orcvio_msckf_io_stage_object_tracks.argtypes = [C.c_void_p, C.POINTER(MsckfFlags), C.POINTER(ObjectEvalFlags), C.POINTER(ObjectTrackC), C.c_int32]
     lib.orcvio_msckf_comm_unique_id.argtypes = [C.c_char_p]
     lib.orcvio_msckf_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
     lib.orcvio_msckf_comm_destroy.argtypes = [C.c_void_p]
@@ -462,7 +463,7 @@ class MsckfUpdater:
         self.lib.orcvio_msckf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
         self._chk(self.lib.orcvio_msckf_counters(self.h, v, 8), 'orcvio_msckf_counters')
         return dict(front_fallbacks=int(v[0]), graph_captures=int(v[1]), graph_replays=int(v[2]), plain_runs=int(v[3]),
-                    front_blocked_by_comm=int(v[4]), obj_fused=int(v[5]), chained_frames=int(v[6]))
+                    front_blocked_by_comm=int(v[4]), obj_fused=int(v[5]), chained_frames=int(v[6]), prestaged_frames=int(v[7]))
 
     def comm_info(self):
         r, w = C.c_int32(0), C.c_int32(0)
@@ -879,6 +880,13 @@ class MsckfUpdater:
             rc = lib.orcvio_msckf_io_update_frame(h, C.byref(res_f), C.byref(ofl), C.byref(ef), arr, nobj, co, C.byref(res_o))
             if rc != 0:
                 raise MsckfError(rc, 'orcvio_msckf_io_update_frame')
+
+        def stage():
+            # orcvio_msckf_io_stage_object_tracks: the same tracks staged AHEAD of the call (between io_fill and call())
+            rc = lib.orcvio_msckf_io_stage_object_tracks(h, C.byref(ofl), C.byref(ef), arr, nobj)
+            if rc != 0:
+                raise MsckfError(rc, 'orcvio_msckf_io_stage_object_tracks')
+        call.stage = stage
 
         def outs():
             f = self._finish(dict(out_f), res_f, win.F)

@@ -217,6 +217,9 @@ struct orcvio_msckf_handle {
                                         // second device-wide barrier, and 144 strips of A read past the caches): a measured negative, kept opt-in
     bool front_did_U = false;           // ... the launch_front of this update did
     double chain_fin_thr = 0.0;         // ... and the threshold it used
+    std::shared_ptr<void> prestage;     // ObjPrestage (capi_objects.inc): what orcvio_msckf_io_stage_object_tracks left for the next frame call
+    unsigned long long cnt_prestaged = 0;   // frame calls that found their object tracks staged ahead
+    bool prestage_valid = false;        // ... still stands (no other scan of object tracks since)
     int chain_fin_dof = -1;             // degrees of freedom the chained object solve's in-launch finish gated with (-1: it did not)
     int fuse_finish = 1;                // P+ / dx (and an object update's gate) by finish workgroups of k_potrf_solve_la (LaFin) instead of a k_finish_sqrt
                                         // launch behind it: 1 = in the chained frame call (both halves: 8-9 us off the frame), 2 = every update whose solve

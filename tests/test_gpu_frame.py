@@ -394,3 +394,48 @@ def test_frame_with_object_flags_that_differ_from_the_feature_flags(built, what)
                 assert o1['accept'] == (1 if val > 0.5 else 0)   # (a probability of 1e-9 rejects everything: P++ = P+, dx = 0)
     finally:
         upd.close()
+
+
+def test_frame_with_the_object_tracks_staged_ahead(built):
+    """orcvio_msckf_io_stage_object_tracks between io_fill and the frame call: the frame call finds the scan and the pinned staging arena
+    done and goes straight to the launches -- the same results bit for bit, counted in counters()['prestaged_frames']; a frame call with
+    OTHER tracks than the staged ones (or a second call on one staging) stages for itself."""
+    flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    win = synth.make_window(N=30, F=400, seed=4, flags=flags, outlier_frac=0.05)
+    objs = synth.make_objects(win, n_objects=20, seed=2, sigma_kp=0.004)
+    objs2 = synth.make_objects(win, n_objects=7, seed=5, sigma_kp=0.004)
+    upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=2048, max_observations=65536)
+    nobs = int(win.obs_ptr[-1])
+
+    def frame(ob, stage, stage_other=None):
+        upd.cov_set(win.P)
+        io = upd.io_begin(win.flags, win.N, win.F, nobs, with_P=False)
+        upd.io_fill(io, win, with_P=False)
+        call, outs = upd.make_frame_call(win, win.flags, ob, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+        keep = None
+        if stage_other is not None:   # stage OTHER tracks: the call below must not use them
+            keep = upd.make_frame_call(win, win.flags, stage_other, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+            keep[0].stage()
+        if stage:
+            call.stage()
+        call()
+        f, o = outs()
+        return f, o, upd.cov_get()
+    try:
+        f0, o0, P0 = frame(objs, False)
+        n0 = upd.counters()['prestaged_frames']
+        for it in range(3):
+            f1, o1, P1 = frame(objs, True)
+            assert upd.counters()['prestaged_frames'] == n0 + it + 1
+            assert _same(f1['dx'], f0['dx']) and _same(o1['dx'], o0['dx']) and _same(o1['gamma'], o0['gamma']) and o1['accept'] == o0['accept'] == 1
+            assert _same(P1, P0) and _same(o1['stats'], o0['stats'])
+        n1 = upd.counters()['prestaged_frames']
+        f2, o2, P2 = frame(objs, False, stage_other=objs2)   # the staging is of other tracks: ignored
+        assert upd.counters()['prestaged_frames'] == n1
+        assert _same(o2['dx'], o0['dx']) and _same(P2, P0)
+        f3, o3, P3 = frame(objs2, False)
+        f4, o4, P4 = frame(objs2, True)
+        assert upd.counters()['prestaged_frames'] == n1 + 1
+        assert _same(o4['dx'], o3['dx']) and _same(P4, P3) and o4['accept'] == o3['accept']
+    finally:
+        upd.close()
