@@ -41,7 +41,7 @@ EXPORTS = [
     'orcvio_msckf_comm_unique_id', 'orcvio_msckf_comm_init', 'orcvio_msckf_comm_destroy', 'orcvio_msckf_comm_info',
     'orcvio_msckf_run_update_sharded', 'orcvio_msckf_update_features_sharded', 'orcvio_msckf_update_object_tracks_sharded',
     'orcvio_msckf_comm_barrier', 'orcvio_msckf_comm_allreduce_max', 'orcvio_msckf_io_begin', 'orcvio_msckf_io_update',
-    'orcvio_msckf_augment_state_ref_ldlt', 'orcvio_msckf_io_update_frame', 'orcvio_msckf_io_submit', 'orcvio_msckf_io_collect',
+    'orcvio_msckf_augment_state_ref_ldlt', 'orcvio_msckf_io_update_frame', 'orcvio_msckf_io_stage_object_tracks', 'orcvio_msckf_io_submit', 'orcvio_msckf_io_collect',
     'orcvio_msckf_objects_refined', 'orcvio_msckf_counters', 'orcvio_msckf_comm_details', 'orcvio_msckf_profile_sharded',
 ]
 
