@@ -1932,7 +1932,7 @@ __device__ __forceinline__ void asm_gemm_tile(const AsmArgs& aa, const double* _
             if (aa.plus) pv[rr][j] = aa.plus[((ic >> 4) >= (int)(kc >> 4)) ? src : kc * (unsigned)aa.NAP + (unsigned)ic];
         }
     }
-    __syncthreads();
+    if (PUB || has_shared) __syncthreads();   // (workgroup-uniform in k_gemm_asmA: one tile per workgroup; the two teams of k_front hold different tiles)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int r = wave + 4 * rr;
@@ -1986,13 +1986,152 @@ __device__ __forceinline__ void asm_gemm_tile(const AsmArgs& aa, const double* _
     }
 }
 
+// (k_gemm_asmA keeps its own copy of the body below rather than calling asm_gemm_tile<false>: through the shared function the compiler
+//  allocates it differently -- 66 spilled SGPRs instead of 7 -- and the launch takes 8.65 instead of 8.3 us; asm_gemm_tile serves the
+//  opt-in in-launch form of k_front only.  The two must stay the same arithmetic: test_U_inside_k_front_is_bit_identical_...)
 __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __restrict__ B, long sBk, long sBj, int M, int Nc, int K,
                                                    double* __restrict__ C, long sCi, long sCj, int* __restrict__ clear) {
     // The 16 x K strip of A this tile needs is assembled into LDS first, with the k index along the lanes (coalesced
     // reads of the partial Grams, whose two triangles are both written by k_front), then read back as MFMA operands.
     if (clear && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(clear, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __shared__ double sAsm[ASM_LDS_DOUBLES];
-    asm_gemm_tile<false>(aa, B, sBk, sBj, M, Nc, K, C, sCi, sCj, (int)blockIdx.x, true, (int)threadIdx.x, sAsm, sAsm + 16 * 193, sAsm + 16 * 193 + 768);
+    constexpr int KMAX = 192, LDA = KMAX + 1;   // (193: one row per lane group without bank conflicts)
+    __shared__ double sA[16 * LDA];
+    __shared__ double sPart[3][4][64];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    const int kk = l >> 4, cc = l & 15;
+    const int ntj = (Nc + 15) >> 4;
+    const int bi = (int)blockIdx.x / ntj, bj = (int)blockIdx.x - bi * ntj;
+    const int KS = ((K + 15) >> 4) << 2;   // k-slice per wavefront, a multiple of the MFMA depth (<= 48 for K <= 192)
+    const int kbeg = wave * KS;
+    const int kend = (kbeg + KS < K) ? kbeg + KS : K;
+    // B operands of this wavefront's slice: in flight while the strip is assembled
+    constexpr int GB = 12;
+    const int jc = 16 * bj + cc;
+    const bool jb = jc < Nc;
+    const double* pb = B + (long)(jb ? jc : Nc - 1) * sBj;
+    double bv[GB];
+#pragma unroll
+    for (int q = 0; q < GB; ++q) {
+        const int k = kbeg + 4 * q + kk;
+        bv[q] = pb[(long)(k < kend ? k : (kend > 0 ? kend - 1 : 0)) * sBk];
+    }
+    // ---- the (ext|r) x (ext|r) entries sum EVERY clone tile: once per workgroup that owns such rows, 64 entries x N
+    //      tiles over the 256 threads (clone c on thread group c % 4, then a fixed-order sum of the four partials)
+    __shared__ double sShared[4][64];
+    const bool has_shared = (bi == 0 || bi == (aa.NA >> 4)) && aa.N > 0;   // rows 0..6 or row NA
+    if (has_shared) {
+        const int g4 = tid >> 6, en = tid & 63;
+        const int ea = en >> 3, eb = en & 7;                      // entry classes 0..6 -> e = 0..6, 7 -> e = 13
+        const int e0 = ea == 7 ? 13 : ea, e1 = eb == 7 ? 13 : eb;
+        const int e16 = (e0 >= e1) ? e0 * 16 + e1 : e1 * 16 + e0;
+        double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = g4; c < aa.N; c += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cu = c + 4 * u;
+                const double v = aa.S[(size_t)(cu < aa.N ? cu : aa.N - 1) * 256 + e16];
+                acc8[u] += cu < aa.N ? v : 0.0;
+            }
+        }
+        sShared[g4][en] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+    }
+    // ---- strip: thread (wave w, lane l) owns rows w, w+4, w+8, w+12 and columns l, l+64, l+128 -----------------------
+    double sv[4][3], gv[4][3][4], pv[4][3];
+    int cls[4][3];   // 0: no S contribution, 1: one clone tile (sv), 2: shared entry (index in cls >> 2)
+    int ekj[3], ckj[3];   // column classes: three per thread, shared by its four rows
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = l + 64 * j;
+        const int kc = k < K ? k : 0;
+        ekj[j] = -1; ckj[j] = -1;
+        if (kc < 7) ekj[j] = kc; else if (kc >= aa.cb0 && kc < aa.cb0 + 6 * aa.N) { ckj[j] = (kc - aa.cb0) / 6; ekj[j] = 7 + (kc - aa.cb0) - 6 * ckj[j]; }
+    }
+    // (32-bit element offsets from wave-uniform bases: the loads take the SGPR-base form, and the row part of every
+    //  index is scalar -- the per-element code is a dozen instructions, not a hundred)
+    const bool use_S = aa.N > 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave + 4 * rr;
+        const int i = 16 * bi + r;          // (wave-uniform)
+        const bool rin = i < M;
+        const int ic = rin ? i : 0;
+        int ei = -1, ci = -1;
+        if (ic < 7) ei = ic; else if (ic == aa.NA) ei = 13; else if (ic >= aa.cb0 && ic < aa.cb0 + 6 * aa.N) { ci = (ic - aa.cb0) / 6; ei = 7 + (ic - aa.cb0) - 6 * ci; }
+        const unsigned rowoff = (unsigned)(ic * aa.NAP);
+        const int ea = ei == 13 ? 7 : ei;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = l + 64 * j;
+            const bool in = rin && k < K;
+            const unsigned kc = k < K ? (unsigned)k : 0u;
+            const int ek = ekj[j], ck = ckj[j];
+            // clone tile and kind of S contribution: 0 none, 1 one clone tile, 2 every clone tile (shared block)
+            int c0 = ci >= 0 ? ci : ck, n1 = 0;
+            if (ei >= 0 && ek >= 0) n1 = (ci < 0 && ck < 0) ? 2 : ((ci >= 0 && ck >= 0 && ci != ck) ? 0 : 1);
+            if (!in || !use_S) n1 = 0;
+            const int e16 = (ei >= ek) ? ei * 16 + ek : ek * 16 + ei;   // the S tiles hold both triangles: [max][min]
+            cls[rr][j] = n1 == 2 ? (2 | ((ea * 8 + (ek == 13 ? 7 : ek)) << 2)) : n1;
+            sv[rr][j] = aa.S[n1 == 1 ? (unsigned)(c0 * 256 + e16) : 0u];
+            const unsigned src = rowoff + kc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < aa.nparts) gv[rr][j][u] = (aa.parts + (size_t)u * aa.stride)[src];   // (wave-uniform count and base)
+            pv[rr][j] = 0.0;
+            if (aa.plus) pv[rr][j] = aa.plus[((ic >> 4) >= (int)(kc >> 4)) ? src : kc * (unsigned)aa.NAP + (unsigned)ic];
+        }
+    }
+    if (has_shared) __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave + 4 * rr;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = l + 64 * j;
+            double sS = cls[rr][j] == 1 ? sv[rr][j] : 0.0;
+            if (has_shared && (cls[rr][j] & 3) == 2) {
+                const int en = cls[rr][j] >> 2;
+                sS = (sShared[0][en] + sShared[1][en]) + (sShared[2][en] + sShared[3][en]);
+            }
+            double g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = u < aa.nparts ? gv[rr][j][u] : 0.0;
+            const bool in = 16 * bi + r < M && k < K;
+            sA[r * LDA + k] = in ? sS - ((g[0] + g[1]) + (g[2] + g[3])) + pv[rr][j] : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- split-K product from the strip ---------------------------------------------------------------------------
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    {
+        double a[GB];
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+            const int k = kbeg + 4 * q + kk;
+            const bool kin = k < kend;
+            a[q] = kin ? sA[cc * LDA + (kin ? k : 0)] : 0.0;
+            bv[q] = (jb && kin) ? bv[q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < GB; q += 2) {
+            acc0 = mfma_f64(a[q], bv[q], acc0);
+            acc1 = mfma_f64(a[q + 1], bv[q + 1], acc1);
+        }
+    }
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPart[wave - 1][r][l] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = ((acc[r] + sPart[0][r][l]) + sPart[1][r][l]) + sPart[2][r][l];
+        const int io = 16 * bi + kk + 4 * r, jo = 16 * bj + cc;
+        if (io < M && jo < Nc) C[(long)io * sCi + (long)jo * sCj] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
