@@ -364,7 +364,8 @@ int32_t orcvio_msckf_update_features(orcvio_msckf_handle* h, const orcvio_msckf_
  * copies the caller's arrays into the handle's pinned input arena and the results out of its pinned output block; a caller that
  * flattens its containers (StateServer / MapServer, src/orcvio.cpp:2497-2527, :2803-2848) STRAIGHT INTO the arena and reads the
  * results where they land saves both copies (326 KB of P each way at 30 clones).
- *   io_begin   lays the arena out for (n_clones, n_features, n_observations; with_P = 0: the prior is the resident covariance)
+ *   io_begin   lays the arena out for (n_clones, n_features, n_observations; with_P = 0: the prior is the resident covariance; 2: ... as the propagation and
+ *              augmentation of orcvio_msckf_io_step_frame will leave it, for that call)
  *              and returns the pointers.  Inputs, to be written by the caller: poses [N][ORCVIO_POSE_STRIDE] (one record per
  *              clone: R_b2w 9 row-major | t_b_w 3 | t_fej 3 | R_b2c 9 | t_c_b 3 | 1 unused), p_w [F][3], obs_ptr [F+1] (CSR,
  *              obs_ptr[F] == n_observations), obs_clone, obs_z [nobs][2], obs_zvel [nobs][2] (NULL unless flags->estimate_td),
@@ -589,6 +590,61 @@ int32_t orcvio_msckf_io_stage_object_tracks(orcvio_msckf_handle* h, const orcvio
 int32_t orcvio_msckf_io_update_frame(orcvio_msckf_handle* h, orcvio_msckf_result* features, const orcvio_msckf_flags* object_flags,
                                      const orcvio_object_eval_flags* eval_flags, const orcvio_object_track* tracks, int32_t n_tracks,
                                      int32_t commit_objects, orcvio_msckf_result* objects);
+
+/* ---- One FILTER frame in one call: propagate, augment, update, prune update, marginalise -- on the resident covariance ---------
+ * What OrcVIO::processFeatures does to state_cov per image (src/orcvio.cpp:567-594): batchImuProcessing -> processModel's
+ * covariance propagation (:800-816), stateAugmentation (:962-1010), removeLostFeatures' update (:2497-2560), pruneImuStateBuffer's
+ * update on the clones that leave (:2803-2851) and their marginalisation (:2874-2956).  As separate calls these are
+ * cov_propagate, cov_augment, io_begin + upload_slam_features + io_update(commit), io_begin + io_update(commit), cov_remove_clones:
+ * ~30 launches and copies and two host round trips per frame.  Here everything is enqueued at once on the handle's stream -- the
+ * covariance never leaves HBM, the calling thread waits ONCE, for the flag word behind the last update -- with the small steps
+ * folded into a few launches (frame_ops.hpp).  Same arithmetic in the same order as the separate calls: bit-identical results
+ * (tests/test_gpu_stream.py).
+ * Call order:  io_begin(flags, N, F, nobs, with_P = 2)   N = clones AFTER this frame's augmentation; with_P = 2: "the prior is the
+ *                                                         resident covariance as this frame's propagation + augmentation leave it"
+ *              the caller writes poses / tracks of the first update into the arena (as for io_update)
+ *              io_step_frame(step, result)
+ *   Phi, Q           [leg][leg] accumulated state transition and process noise of the IMU block (NULL, NULL: no propagation)
+ *   augment          != 0: a clone is appended behind the window's clones (in front of the extra states)
+ *   slam_features    hybrid filter (ORCVIO_OPT_EKF_ROWS): the in-state features the current state observes; NULL: none
+ *   prune_tracks     the second update of the frame: observations of the clones that leave only (CSR, window indices, p_w given);
+ *                    NULL: none.  Its window is the first update's, its prior what the first update commits.
+ *   prune_apply_dx   != 0: the window poses of the second update are the arena's poses incremented by the first update's dx ON THE
+ *                    DEVICE (incrementState_IMUCam, src/orcvio.cpp:4468-4567: clone orientation / position and the extrinsics;
+ *                    skipped when discard_large_update discards dx) -- what the reference's state is when pruneImuStateBuffer runs;
+ *                    0: the same poses as the first update (the caller's state increment does not reach into this call)
+ *   remove_clones    window indices (ascending) of the clones marginalised at the end; n_remove <= 8
+ * Results: pointers into the handle's pinned output blocks, valid until the next call on the handle that takes tracks.
+ * Status: a validation failure returns its code with NOTHING done.  A refusal on the device (ORCVIO_ERR_NOT_SPD: M not positive definite or
+ * non-finite input) of the first update refuses the second as well; the covariance bookkeeping of the frame (propagation, augmentation,
+ * marginalisation) stands either way, stats[3] / prune_stats[3] say which updates were applied, n_after is the dimension left.  A lost
+ * in-launch hand-off is repaired inside the call (the affected updates run again in separate launches; orcvio_msckf_counters [0]). */
+typedef struct orcvio_msckf_frame_step {
+    int32_t leg_dim;
+    const double* Phi;
+    const double* Q;
+    int32_t augment;
+    const orcvio_msckf_slam_features* slam_features;
+    const orcvio_msckf_tracks* prune_tracks;
+    int32_t prune_apply_dx;
+    const int32_t* remove_clones;
+    int32_t n_remove;
+} orcvio_msckf_frame_step;
+typedef struct orcvio_msckf_frame_result {
+    int32_t stats[8];              /* first update, as orcvio_msckf_result.stats                        */
+    int32_t prune_stats[8];        /* second update                                                     */
+    const double* dx;              /* [n]                                                               */
+    const double* gamma;           /* [F]                                                               */
+    const int32_t* accept;         /* [F]                                                               */
+    const double* prune_dx;        /* [n]   NULL without prune_tracks                                   */
+    const double* prune_gamma;     /* [F2]                                                              */
+    const int32_t* prune_accept;   /* [F2]                                                              */
+    int32_t n_after;               /* dimension of the resident covariance when the call returns        */
+    int32_t status_first;          /* ORCVIO_OK or the refusal of the first update                      */
+    int32_t status_prune;          /* ... of the second                                                 */
+    int32_t repaired;              /* updates of this frame that were run again after a lost hand-off   */
+} orcvio_msckf_frame_result;
+int32_t orcvio_msckf_io_step_frame(orcvio_msckf_handle* h, const orcvio_msckf_frame_step* step, orcvio_msckf_frame_result* result);
 
 /* ---- Object update straight from the wire format of the object mapper ------------------------------
  * One element per orcvio_ros_msgs/ObjectLM message (ros_wrapper/src/orcvio_ros_msgs/msg/ObjectLM.msg) as ObjectInitNode fills it

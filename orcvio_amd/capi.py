@@ -43,6 +43,7 @@ EXPORTS = [
     'orcvio_msckf_comm_barrier', 'orcvio_msckf_comm_allreduce_max', 'orcvio_msckf_io_begin', 'orcvio_msckf_io_update',
     'orcvio_msckf_augment_state_ref_ldlt', 'orcvio_msckf_io_update_frame', 'orcvio_msckf_io_stage_object_tracks', 'orcvio_msckf_io_submit', 'orcvio_msckf_io_collect',
     'orcvio_msckf_objects_refined', 'orcvio_msckf_counters', 'orcvio_msckf_comm_details', 'orcvio_msckf_profile_sharded',
+    'orcvio_msckf_io_step_frame',
 ]
 
 
@@ -206,6 +207,7 @@ def _bind(lib):
     lib.orcvio_msckf_io_update.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _ip]
     lib.orcvio_msckf_io_submit.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.orcvio_msckf_io_collect.argtypes = [C.c_void_p, _ip]
+    lib.orcvio_msckf_io_step_frame.argtypes = [C.c_void_p, C.POINTER(FrameStep), C.POINTER(FrameResult)]
     lib.orcvio_msckf_update_features_sharded.argtypes = lib.orcvio_msckf_update_features.argtypes
     lib.orcvio_msckf_update_object_tracks_sharded.argtypes = lib.orcvio_msckf_update_object_tracks.argtypes
     return lib
@@ -252,6 +254,21 @@ class SlamFeatures(C.Structure):
                 ('anchor', C.POINTER(C.c_int32)), ('state', C.POINTER(C.c_int32)), ('slot', C.POINTER(C.c_int32)),
                 ('param', C.POINTER(C.c_double)), ('inv_depth', C.POINTER(C.c_double)), ('p_w', C.POINTER(C.c_double)),
                 ('p_fej', C.POINTER(C.c_double)), ('z', C.POINTER(C.c_double)), ('z_vel', C.POINTER(C.c_double))]
+
+
+class FrameStep(C.Structure):
+    """orcvio_msckf_frame_step (include/orcvio_msckf.h)."""
+    _fields_ = [('leg_dim', C.c_int32), ('Phi', C.POINTER(C.c_double)), ('Q', C.POINTER(C.c_double)), ('augment', C.c_int32),
+                ('slam_features', C.POINTER(SlamFeatures)), ('prune_tracks', C.POINTER(MsckfTracks)), ('prune_apply_dx', C.c_int32),
+                ('remove_clones', C.POINTER(C.c_int32)), ('n_remove', C.c_int32)]
+
+
+class FrameResult(C.Structure):
+    """orcvio_msckf_frame_result (include/orcvio_msckf.h)."""
+    _fields_ = [('stats', C.c_int32 * 8), ('prune_stats', C.c_int32 * 8), ('dx', C.POINTER(C.c_double)), ('gamma', C.POINTER(C.c_double)),
+                ('accept', C.POINTER(C.c_int32)), ('prune_dx', C.POINTER(C.c_double)), ('prune_gamma', C.POINTER(C.c_double)),
+                ('prune_accept', C.POINTER(C.c_int32)), ('n_after', C.c_int32), ('status_first', C.c_int32), ('status_prune', C.c_int32),
+                ('repaired', C.c_int32)]
 
 
 class MsckfNewFeatures(C.Structure):
@@ -599,7 +616,7 @@ class MsckfUpdater:
         obs_clone, obs_z, obs_zvel or None, P or None) and outputs to read after io_update (dx, gamma, accept, P_out)."""
         fl = make_flags(flags)
         io = MsckfIo()
-        self._chk(self.lib.orcvio_msckf_io_begin(self.h, C.byref(fl), int(N), int(F), int(nobs), int(bool(with_P)), C.byref(io)), 'orcvio_msckf_io_begin')
+        self._chk(self.lib.orcvio_msckf_io_begin(self.h, C.byref(fl), int(N), int(F), int(nobs), 2 if with_P == 2 and with_P is not True else int(bool(with_P)), C.byref(io)), 'orcvio_msckf_io_begin')
         n = int(io.n)
         view = lambda ptr, shape: None if not ptr else np.ctypeslib.as_array(ptr, shape=shape)
         self.n, self.F = n, int(F)
@@ -925,6 +942,53 @@ class MsckfUpdater:
         self._chk(self.lib.orcvio_msckf_cov_get(self.h, C.byref(n), _d(P)), 'orcvio_msckf_cov_get')
         return P
 
+    def io_step_frame(self, win, Phi=None, Q=None, augment=True, slam=None, idp_dim=1, prune=None, prune_apply_dx=False, remove=(),
+                      raise_on_refusal=True):
+        """orcvio_msckf_io_step_frame: ONE filter frame on the resident covariance -- propagation, augmentation, the update on `win`'s
+        tracks (+ the in-state features `slam`), the prune update on `prune`'s tracks (a synth.Window sharing win's poses), the
+        marginalisation of `remove`.  Returns dict(dx, gamma, accept, stats, prune_dx, prune_gamma, prune_accept, prune_stats, n_after,
+        status_first, status_prune, repaired) with copies of the results."""
+        io = self.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=2)
+        self.io_fill(io, win, with_P=False)
+        keep = []
+        st = FrameStep()
+        st.leg_dim = int(win.flags.leg_dim)
+        if Phi is not None:
+            Ph = np.ascontiguousarray(Phi, dtype=np.float64); Qc = np.ascontiguousarray(Q, dtype=np.float64)
+            keep += [Ph, Qc]
+            st.Phi = _d(Ph); st.Q = _d(Qc)
+        st.augment = int(bool(augment))
+        if slam is not None and len(slam) > 0:
+            call = self.make_slam_call(idp_dim, slam)
+            keep.append(call)
+            st.slam_features = C.pointer(call.hold[-1])
+        F2 = 0
+        if prune is not None:
+            F2 = int(prune.F)
+            arrs = [np.ascontiguousarray(prune.p_w, dtype=np.float64), np.ascontiguousarray(prune.obs_ptr, dtype=np.int32),
+                    np.ascontiguousarray(prune.obs_clone, dtype=np.int32), np.ascontiguousarray(prune.obs_z, dtype=np.float64),
+                    np.ascontiguousarray(prune.obs_zvel, dtype=np.float64)]
+            tr = MsckfTracks(F2, _d(arrs[0]), _i(arrs[1]), _i(arrs[2]), _d(arrs[3]), _d(arrs[4]) if win.flags.estimate_td else None)
+            keep += arrs + [tr]
+            st.prune_tracks = C.pointer(tr)
+        st.prune_apply_dx = int(bool(prune_apply_dx))
+        rm = np.ascontiguousarray(list(remove), dtype=np.int32)
+        keep.append(rm)
+        if len(rm):
+            st.remove_clones = _i(rm)
+        st.n_remove = len(rm)
+        res = FrameResult()
+        rc = self.lib.orcvio_msckf_io_step_frame(self.h, C.byref(st), C.byref(res))
+        if rc != 0 and (raise_on_refusal or rc != 6):
+            raise MsckfError(rc, 'orcvio_msckf_io_step_frame')
+        n = int(io['n'])
+        arr = lambda p, k, dt: np.ctypeslib.as_array(p, shape=(max(k, 1),))[:k].astype(dt, copy=True) if p else None
+        return dict(rc=rc, dx=arr(res.dx, n, np.float64), gamma=arr(res.gamma, win.F, np.float64), accept=arr(res.accept, win.F, np.int32),
+                    stats=np.array(res.stats[:], dtype=np.int32), prune_dx=arr(res.prune_dx, n, np.float64),
+                    prune_gamma=arr(res.prune_gamma, F2, np.float64), prune_accept=arr(res.prune_accept, F2, np.int32),
+                    prune_stats=np.array(res.prune_stats[:], dtype=np.int32), n_after=int(res.n_after), status_first=int(res.status_first),
+                    status_prune=int(res.status_prune), repaired=int(res.repaired))
+
     def cov_propagate(self, Phi, Q):
         Ph = np.ascontiguousarray(Phi, dtype=np.float64)
         Qc = np.ascontiguousarray(Q, dtype=np.float64)
@@ -1166,6 +1230,30 @@ def augment_state(idp_dim, H_1, H_2, r_1, sigma2, dx, P_upd):
     if rc != 0:
         raise MsckfError(rc, 'orcvio_msckf_augment_state')
     return dx_new, P_aug
+
+
+def increment_window(win, dx):
+    """incrementState_IMUCam (orcvio_msckf_increment_state, host arithmetic) applied to the clone poses and the extrinsics of a
+    synth.Window: the window a caller flattens for the NEXT update of the frame.  Returns (window, applied)."""
+    import dataclasses
+    N = win.N
+    s = MsckfState()
+    s.R_b2w_imu[:] = list(np.eye(3).reshape(-1))
+    s.R_b2c[:] = list(np.ascontiguousarray(win.R_b2c[0]).reshape(-1))
+    s.t_c_b[:] = list(win.t_c_b[0])
+    s.n_clones = N
+    R = np.ascontiguousarray(win.R_b2w, dtype=np.float64).copy()
+    t = np.ascontiguousarray(win.t_b_w, dtype=np.float64).copy()
+    s.clone_R_b2w = _d(R); s.clone_t_b_w = _d(t)
+    fl = make_flags(win.flags)
+    dxc = np.ascontiguousarray(dx, dtype=np.float64)
+    rc = load().orcvio_msckf_increment_state(C.byref(fl), _d(dxc), C.byref(s))
+    if rc < 0:
+        raise MsckfError(1, 'orcvio_msckf_increment_state')
+    Rc = np.array(s.R_b2c[:]).reshape(3, 3)
+    tc = np.array(s.t_c_b[:])
+    return dataclasses.replace(win, R_b2w=R, t_b_w=t, R_b2c=np.ascontiguousarray(np.repeat(Rc[None], N, 0)),
+                               t_c_b=np.ascontiguousarray(np.repeat(tc[None], N, 0))), rc == 1
 
 
 def chi2_quantile(dof, prob=0.95):

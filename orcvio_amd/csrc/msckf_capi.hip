@@ -25,6 +25,7 @@
 #include "object_rows.hpp"
 #include "object_fused.hpp"
 #include "io_ops.hpp"
+#include "frame_ops.hpp"
 #include <immintrin.h>
 #include <condition_variable>
 #include <memory>
@@ -294,6 +295,12 @@ struct orcvio_msckf_handle {
     std::vector<int> h_row_ptr;
     std::vector<unsigned char> track_is_run;   // upload_finalize: the track's clones are a contiguous run
     std::vector<int> frame_row_ptr;     // orcvio_msckf_io_update_frame: the feature half's row offsets while the object half uses h_row_ptr
+    // orcvio_msckf_io_step_frame (capi_step.inc): the second update of a frame goes through an arena pair of its own, swapped in and out
+    char *d_in2 = nullptr, *h_stage2 = nullptr, *h_stage2_dev = nullptr;
+    bool arena_swapped = false;
+    int* d_step_words = nullptr;        // [0..15] status words of the frame's first update, kept for the second update's commit (info_also)
+    std::vector<int> step_row_ptr;      // the second update's row offsets
+    long long cnt_step_frames = 0;      // frames through orcvio_msckf_io_step_frame
     double chi2_prob_cached = -1.0;
 };
 
@@ -322,6 +329,7 @@ const char* orcvio_msckf_last_error(void) { return g_last_error.c_str(); }
 #include "capi_comm.inc"   // the handle's RCCL communicator, bounded waits, the sharded updates
 #include "capi_cov.inc"   // per-kernel profile, the device-resident covariance and its square-root factor
 #include "capi_frame.inc"   // one frame in one call: feature update + object update, the objects' compression beside the features' solve
+#include "capi_step.inc"   // one FILTER frame in one call: propagate, augment, update, prune update, marginalise on the resident covariance
 #include "capi_state.inc"   // triangulation, incrementState_IMUCam (host arithmetic)
 #include "capi_debug.inc"   // diagnostics build only: test hooks and ablation timers
 

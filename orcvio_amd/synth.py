@@ -406,3 +406,82 @@ def make_objects(win: Window, n_objects: int = 20, seed: int = 0, missing_frac: 
                 fr['zs'] = np.zeros((0, 2))
         objs.append(ObjectTrack(wTo=T_est, shape=shape, kps=kps_est, frames=frames))
     return objs
+
+
+# ---- streams of filter frames (bench.py's stream legs, tests/cpp/stream_bench.cpp) ----------------------------------------------
+def subset_tracks(win: "Window", clone_ids, min_obs: int = 0) -> "Window":
+    """CSR restricted to the observations of `clone_ids` (what pruneImuStateBuffer lists, reference src/orcvio.cpp:2810-2845);
+    min_obs: tracks with fewer listed observations are emptied (the reference uses features seen in BOTH clones that leave)."""
+    keep = np.isin(win.obs_clone, np.asarray(clone_ids))
+    csum = np.concatenate([[0], np.cumsum(keep.astype(np.int64))])
+    cnt = csum[win.obs_ptr[1:]] - csum[win.obs_ptr[:-1]]
+    use = cnt >= max(min_obs, 0)
+    keep = keep & np.repeat(use, np.diff(win.obs_ptr))
+    ptr = np.concatenate([[0], np.cumsum(np.where(use, cnt, 0))]).astype(np.int32)
+    return dataclasses.replace(win, obs_ptr=ptr, obs_clone=win.obs_clone[keep].copy(), obs_z=win.obs_z[keep].copy(),
+                               obs_zvel=win.obs_zvel[keep].copy())
+
+
+def make_stream(flags: "Flags", sigma_px=None, cycle: int = 8, seed: int = 0, n_slam: int = 12, idp: int = 1, leg: int = LEG_DIM):
+    """A cycle of pre-generated filter frames at the reference's shipped operating point (sw_size 20, max_track_len 6,
+    max_features_in_one_grid 1 -> hybrid filter with `n_slam` in-state features of `idp` parameter(s); config/euroc.yaml:49-109,
+    config/kitti_raw.yaml:77-148): 19 / 20 clones alternating, 20-200 lost features per frame with 3-6 observations each; the
+    20-clone frames carry the prune update on the two oldest clones (features seen in both) and their marginalisation.  Returns
+    (frames, P0): frames[k] = dict(w, slam, prune | None, Phi, Q, remove), P0 the 18-clone covariance the loop starts from."""
+    rng = np.random.default_rng(seed)
+    frames = []
+    for k in range(cycle):
+        N = 20 if k % 2 else 19
+        F = int(rng.integers(20, 201))
+        w0 = make_window(N=N, F=F, seed=1000 + k, track_len=(3, 6), flags=flags, outlier_frac=0.05, sigma_px=sigma_px)
+        w = with_extra_states(w0, idp * n_slam, seed=k)
+        slam = make_slam_features(w, n_slam, seed=k, outlier_frac=0.1, sigma_px=sigma_px)
+        prune = None
+        if N == 20:
+            sub = subset_tracks(w, [0, 1], min_obs=2)
+            if int(sub.obs_ptr[-1]) > 0:
+                prune = sub
+        Phi = np.eye(leg) + 0.002 * rng.standard_normal((leg, leg))
+        G = rng.standard_normal((leg, 12))
+        frames.append(dict(w=w, slam=slam, prune=prune, Phi=np.ascontiguousarray(Phi), Q=np.ascontiguousarray(1e-7 * G @ G.T),
+                           remove=[0, 1] if N == 20 else []))
+    P0 = with_extra_states(make_window(N=18, F=1, seed=5, flags=flags), idp * n_slam, seed=1).P
+    return frames, np.ascontiguousarray(P0)
+
+
+def pack_poses(win: "Window") -> np.ndarray:
+    """[N][28] pose records of the input arena (include/orcvio_msckf.h ORCVIO_POSE_STRIDE)."""
+    p = np.zeros((win.N, 28))
+    p[:, 0:9] = win.R_b2w.reshape(win.N, 9); p[:, 9:12] = win.t_b_w; p[:, 12:15] = win.t_fej
+    p[:, 15:24] = win.R_b2c.reshape(win.N, 9); p[:, 24:27] = win.t_c_b
+    return p
+
+
+def write_stream(path: str, frames, P0: np.ndarray, flags: "Flags", idp: int = 1):
+    """The frames of make_stream as one little-endian binary file for tests/cpp/stream_bench.cpp (its reader mirrors this writer):
+    'ORCSTRM2', header, P0, then per frame the window's pose records, the tracks, the in-state features, the prune tracks, Phi, Q."""
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32).tobytes()
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64).tobytes()
+    n_slam = len(frames[0]['slam'])
+    with open(path, 'wb') as f:
+        f.write(b'ORCSTRM2')
+        f.write(i32([len(frames), P0.shape[0], idp, n_slam, flags.leg_dim, flags.use_larvio, flags.use_left_perturbation, flags.if_fej,
+                     flags.estimate_td, flags.discard_large_update]))
+        f.write(f64([flags.noise_feature, flags.chi2_prob]))
+        f.write(f64(P0))
+        for fr in frames:
+            w, pr = fr['w'], fr['prune']
+            nobs = int(w.obs_ptr[-1])
+            F2 = pr.F if pr is not None else 0
+            nobs2 = int(pr.obs_ptr[-1]) if pr is not None else 0
+            rem = list(fr['remove'])
+            f.write(i32([w.N, w.F, nobs, 1 if pr is not None else 0, F2, nobs2, len(rem)] + rem + [0] * (4 - len(rem))))
+            f.write(f64(pack_poses(w))); f.write(f64(w.p_w)); f.write(i32(w.obs_ptr)); f.write(i32(w.obs_clone)); f.write(f64(w.obs_z))
+            sl = fr['slam']
+            f.write(i32([s.anchor for s in sl])); f.write(i32([s.state for s in sl])); f.write(i32(list(range(len(sl)))))
+            f.write(f64([s.inv_param if idp == 3 else s.obs_anchor for s in sl])); f.write(f64([s.inv_depth for s in sl]))
+            f.write(f64([s.p_w for s in sl])); f.write(f64([s.p_fej if s.p_fej is not None else s.p_w for s in sl]))
+            f.write(f64([s.z for s in sl])); f.write(f64([s.z_vel for s in sl]))
+            if pr is not None:
+                f.write(f64(pr.p_w)); f.write(i32(pr.obs_ptr)); f.write(i32(pr.obs_clone)); f.write(f64(pr.obs_z))
+            f.write(f64(fr['Phi'])); f.write(f64(fr['Q']))

@@ -1,0 +1,182 @@
+"""One filter frame in one call (orcvio_msckf_io_step_frame: propagation, augmentation, the update, the prune update and the
+marginalisation of reference src/orcvio.cpp:567-594 enqueued at once on the resident covariance) against the separate calls it
+replaces -- bit for bit -- and against the oracle; its refusals; and the C++ stream harness (tests/cpp/stream_bench.cpp), which
+replays the same frames through the C-ABI without Python."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from orcvio_amd import capi, synth
+from helpers import rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LEG, IDP, NSLAM = 22, 1, 12
+
+
+def _handle():
+    u = capi.MsckfUpdater(device=0, max_clones=24, max_features=256, max_observations=4096)
+    u.set_extra_states(IDP * NSLAM)
+    u.set_ekf_rows_mode(True)
+    return u
+
+
+def _frame_by_calls(u, fr, prune_poses=None):
+    """The separate calls of the round-5 ABI for one frame; returns (dx1, gamma1, accept1, dx2 | None)."""
+    w = fr['w']
+    u.cov_propagate(fr['Phi'], fr['Q'])
+    u.cov_augment()
+    io = u.io_begin(w.flags, w.N, w.F, int(w.obs_ptr[-1]), with_P=False)
+    u.io_fill(io, w, with_P=False)
+    u.make_slam_call(IDP, fr['slam'])()
+    u.io_update(want_P=False, commit=True)
+    out = [io['dx'].copy(), io['gamma'].copy(), io['accept'].copy(), None]
+    if fr['prune'] is not None:
+        p = fr['prune'] if prune_poses is None else prune_poses(fr['prune'], out[0])
+        io = u.io_begin(p.flags, p.N, p.F, int(p.obs_ptr[-1]), with_P=False)
+        u.io_fill(io, p, with_P=False)
+        u.io_update(want_P=False, commit=True)
+        out[3] = io['dx'].copy()
+    if fr['remove']:
+        u.cov_remove_clones(LEG, fr['remove'])
+    return out
+
+
+@pytest.mark.parametrize('which', ['euroc', 'kitti'])
+def test_step_frame_equals_the_separate_calls_bit_for_bit(built, which):
+    fl = synth.Flags(use_larvio=1) if which == 'euroc' else synth.Flags(use_larvio=0, use_left_perturbation=0, noise_feature=1.0, discard_large_update=1)
+    frames, P0 = synth.make_stream(fl, sigma_px=None if which == 'euroc' else 0.008)
+    a, b = _handle(), _handle()
+    try:
+        a.cov_set(P0); b.cov_set(P0)
+        for it in range(24):
+            fr = frames[it % len(frames)]
+            ref = _frame_by_calls(a, fr)
+            got = b.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, fr['remove'])
+            assert got['repaired'] == 0 and got['status_first'] == 0 and got['status_prune'] == 0
+            assert np.array_equal(got['dx'], ref[0]), it
+            assert np.array_equal(got['gamma'], ref[1], equal_nan=True) and np.array_equal(got['accept'], ref[2])
+            assert got['stats'][3] == 1 and got['stats'][2] == int(ref[2].sum())
+            if fr['prune'] is not None:
+                assert np.array_equal(got['prune_dx'], ref[3]), it
+            else:
+                assert got['prune_dx'] is None
+            Pa, Pb = a.cov_get(), b.cov_get()
+            assert got['n_after'] == Pb.shape[0] == Pa.shape[0]
+            assert np.array_equal(Pa, Pb), it
+    finally:
+        a.close(); b.close()
+
+
+def test_cpp_stream_harness_both_modes_agree(built, tmp_path):
+    """tests/cpp/stream_bench.cpp: the stream through the C-ABI from C++ -- separate calls against one call per frame, same dx and
+    same final covariance (hashes), and a sane figure."""
+    fl = synth.Flags(use_larvio=1)
+    frames, P0 = synth.make_stream(fl)
+    path = str(tmp_path / 'config1.bin')
+    synth.write_stream(path, frames, P0, fl, IDP)
+    exe = str(tmp_path / 'stream_bench')
+    lib = os.path.join(ROOT, 'orcvio_amd', 'lib')
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-DORCVIO_HAVE_STEP_FRAME', '-o', exe, os.path.join(ROOT, 'tests', 'cpp', 'stream_bench.cpp'),
+                           '-L', lib, '-lorcvio_msckf', f'-Wl,-rpath,{lib}'])
+    outs = {}
+    for mode in ('calls', 'step'):
+        r = subprocess.run([exe, '--stream', path, '--mode', mode, '--frames', '96', '--warmup', '16'], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs['calls']['dx_hash'] == outs['step']['dx_hash']
+    assert outs['calls']['P_hash'] == outs['step']['P_hash']
+    assert outs['step']['frames_per_s'] > outs['calls']['frames_per_s']
+    assert outs['step']['front_fallbacks'] == 0
+
+
+def test_step_frame_with_the_state_increment_on_the_device(built):
+    """prune_apply_dx: the second update's window = the first update's poses incremented by its dx (incrementState_IMUCam,
+    reference src/orcvio.cpp:4468-4567) on the device -- against the separate calls with the host's increment between them."""
+    import dataclasses
+    for fl in (synth.Flags(use_larvio=1), synth.Flags(use_larvio=0, use_left_perturbation=0), synth.Flags(use_larvio=0, use_left_perturbation=1)):
+        frames, P0 = synth.make_stream(fl)
+        a, b = _handle(), _handle()
+
+        def incremented(p, dx):
+            return capi.increment_window(p, dx)[0]
+        try:
+            a.cov_set(P0); b.cov_set(P0)
+            for it in range(8):
+                fr = frames[it % len(frames)]
+                ref = _frame_by_calls(a, fr, prune_poses=incremented)
+                got = b.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], True, fr['remove'])
+                assert np.array_equal(got['dx'], ref[0])
+                if fr['prune'] is not None:
+                    assert rel(got['prune_dx'], ref[3]) < 1e-9, (it, rel(got['prune_dx'], ref[3]))
+                assert rel(b.cov_get(), a.cov_get()) < 1e-10
+        finally:
+            a.close(); b.close()
+
+
+def test_step_frame_validation_leaves_nothing_done(built):
+    import dataclasses
+    fl = synth.Flags(use_larvio=1)
+    frames, P0 = synth.make_stream(fl)
+    u = _handle()
+    try:
+        u.cov_set(P0)
+        fr0, fr = frames[0], frames[1]
+        got = u.io_step_frame(fr0['w'], fr0['Phi'], fr0['Q'], True, fr0['slam'], IDP, None, False, [])
+        assert got['rc'] == 0 and got['stats'][3] == 1 and got['n_after'] == P0.shape[0] + 6
+        P1 = u.cov_get()
+        bad = synth.subset_tracks(fr['w'], [0, 1], min_obs=2)
+        bad.obs_clone[0] = 99
+        with pytest.raises(capi.MsckfError) as e:   # the prune tracks are checked before anything is enqueued
+            u.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, bad, False, fr['remove'])
+        assert e.value.code == 1
+        assert np.array_equal(u.cov_get(), P1)
+        w_bad = dataclasses.replace(fr['w'], obs_clone=fr['w'].obs_clone.copy())
+        w_bad.obs_clone[3] = 77
+        with pytest.raises(capi.MsckfError):   # ... and so are the first update's
+            u.io_step_frame(w_bad, fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, fr['remove'])
+        assert np.array_equal(u.cov_get(), P1)
+        with pytest.raises(capi.MsckfError):   # the window of io_begin must be the augmented one
+            u.io_step_frame(fr['w'], fr['Phi'], fr['Q'], False, fr['slam'], IDP, None, False, [])
+        with pytest.raises(capi.MsckfError):   # descending removal list
+            u.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, [1, 0])
+        assert np.array_equal(u.cov_get(), P1)
+        # ... and the frame goes through afterwards
+        got = u.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, fr['remove'])
+        assert got['rc'] == 0 and got['stats'][3] == 1 and got['n_after'] == P0.shape[0]
+    finally:
+        u.close()
+
+
+def test_step_frame_refusal_of_the_first_update_refuses_the_second(built):
+    """A prior 1e30 times the noise in scale: sigma^2 is lost beside L^T A L and M is not positive definite in double -- the device
+    refuses the first update (ORCVIO_ERR_NOT_SPD, nothing applied) and the second with it; the covariance bookkeeping of the frame
+    stands: the result equals propagate + augment + remove alone."""
+    fl = synth.Flags(use_larvio=1)
+    frames, P0 = synth.make_stream(fl)
+    a, b = _handle(), _handle()
+    try:
+        a.cov_set(P0 * 1e30); b.cov_set(P0 * 1e30)
+        for k in (0, 1):
+            fr = frames[k]
+            got = a.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, fr['remove'], raise_on_refusal=False)
+            assert got['rc'] == 6 and got['status_first'] == 6, got
+            assert got['stats'][3] == 0
+            if fr['prune'] is not None:
+                assert got['status_prune'] == 6 and got['prune_stats'][3] == 0
+            b.cov_propagate(fr['Phi'], fr['Q']); b.cov_augment()
+            if fr['remove']:
+                b.cov_remove_clones(LEG, fr['remove'])
+            Pb = b.cov_get()
+            assert got['n_after'] == Pb.shape[0]
+            assert np.array_equal(a.cov_get(), Pb)
+        # the handle goes on with a sane covariance
+        a.cov_set(P0)
+        fr0 = frames[0]
+        got = a.io_step_frame(fr0['w'], fr0['Phi'], fr0['Q'], True, fr0['slam'], IDP, None, False, [])
+        assert got['rc'] == 0 and got['stats'][3] == 1
+    finally:
+        a.close(); b.close()
