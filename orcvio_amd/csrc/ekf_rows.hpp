@@ -23,8 +23,7 @@ struct EkfGateArgs {
 };
 
 // one wavefront per SLAM feature; lane t < 22 holds non-zero t of the row pair: column c_t and the two values
-__global__ __launch_bounds__(64) void k_ekf_gate(EkfGateArgs p) {
-    const int f = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void ekf_gate_body(const EkfGateArgs& p, const int f, const int t) {
     if (f >= p.F) return;
     const int d = p.idp_dim;
     const int a = p.anchor[f], k = p.state[f];
@@ -47,7 +46,8 @@ __global__ __launch_bounds__(64) void k_ekf_gate(EkfGateArgs p) {
     }
     // w_b[t] = sum_u P[c_t][c_u] v_b[u]
     double w0 = 0.0, w1 = 0.0;
-    for (int u = 0; u < 22; ++u) {
+#pragma unroll
+    for (int u = 0; u < 22; ++u) {   // (unrolled: the 22 loads of P in flight together; the sums keep their order)
         const int cu = __shfl(col, u);
         const double x0 = __shfl(v0, u), x1 = __shfl(v1, u);
         if (cu >= 0 && col >= 0) {
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(64) void k_ekf_gate(EkfGateArgs p) {
         p.E[(size_t)(2 * f + 1) * p.NAP + p.NA] = r1;
     }
 }
+__global__ __launch_bounds__(64) void k_ekf_gate(EkfGateArgs p) { ekf_gate_body(p, blockIdx.x, threadIdx.x); }
 
 
 // ---- the four blocks themselves, from the SLAM features (measurementJacobian_ekf_3didp :1229-1353, _1didp :1356-1478) ----
@@ -206,8 +207,7 @@ ORC_HD void ekf_row_blocks(const double* Pk, const double* Pa, bool same, int d,
 }
 
 // one thread per SLAM feature (a handful to a few dozen per frame)
-__global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
-    const int f = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void ekf_eval_body(const EkfEvalArgs& p, const int f) {
     if (f >= p.F) return;
     const int d = p.idp_dim, a = p.anchor[f], k = p.state[f];
     double He[12], Ha[12], Hx[12], Hf[6], r[2];
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) {
     for (int i = 0; i < 2 * d; ++i) p.Hf[(size_t)f * 2 * d + i] = Hf[i];
     p.r[2 * f] = r[0]; p.r[2 * f + 1] = r[1];
 }
+__global__ __launch_bounds__(64) void k_ekf_eval(EkfEvalArgs p) { ekf_eval_body(p, blockIdx.x * 64 + threadIdx.x); }
 
 // ---- features ENTERING the state: featureJacobian_ekf_new (src/orcvio.cpp:1481-1572) and the W = [V | U] split (:2416-2436) ----
 // One workgroup per new feature.  Its 2 M rows [H_x | r] are written dense over the active columns (rows of d_dense, the

@@ -51,9 +51,9 @@ __device__ __forceinline__ void dev_mat3_mul(const double* A, const double* B, d
 // discard_large_update discards dx (:4479-4494).  t_fej is the first estimate and stays.
 // Thread 0 also copies the status words info[0..15] of the update that has just run into `keep` (the second update's commit
 // refuses itself when the first was refused: EpilogueArgs.info_also).
-__global__ __launch_bounds__(64) void k_pose_step(const double* __restrict__ src, double* __restrict__ dst, int N, int stride, const double* __restrict__ dx,
-                                                  int leg, int apply, int left, int discard_large, const int* __restrict__ info, int* __restrict__ keep) {
-    const int c = threadIdx.x;
+struct PoseStepArgs { const double* src; double* dst; int N, stride; const double* dx; int leg, apply, left, discard_large; const int* info; int* keep; };
+__device__ __forceinline__ void pose_step_body(const double* __restrict__ src, double* __restrict__ dst, int N, int stride, const double* __restrict__ dx,
+                                               int leg, int apply, int left, int discard_large, const int* __restrict__ info, int* __restrict__ keep, const int c) {
     if (c < 16 && keep) keep[c] = info[c];
     if (c >= N) return;
     double r[28];
@@ -87,6 +87,294 @@ __global__ __launch_bounds__(64) void k_pose_step(const double* __restrict__ src
         r[24] += dx[18]; r[25] += dx[19]; r[26] += dx[20];
     }
     for (int i = 0; i < 28; ++i) dst[(size_t)c * stride + i] = r[i];
+}
+__global__ __launch_bounds__(64) void k_pose_step(PoseStepArgs p) {
+    pose_step_body(p.src, p.dst, p.N, p.stride, p.dx, p.leg, p.apply, p.left, p.discard_large, p.info, p.keep, threadIdx.x);
+}
+
+
+// ---- k_frame_head --------------------------------------------------------------------------------------------------------------
+// Byte segments pulled out of the pinned arena (host-coherent, device-visible) into HBM: the tracks and derived index arrays of the
+// frame's first update in one piece, the records of the in-state features in their nine arrays.  Every segment is cut into pieces of
+// FH_PIECE bytes; piece p goes to ingest workgroup p mod nb_ing (PCIe reads want many requests in flight, and the small segments
+// must not queue behind the large one).  16 bytes per lane where source, destination and length allow, else 4.
+#define FH_SEGS 12
+#define FH_PIECE 4096
+struct FrameHeadArgs {
+    // covariance: out (m x m) from P (n x n); Phi / Q: pinned, nullptr = no propagation; pose < 0 = no augmentation (m == n)
+    const double* P; int n; double* out; int m; const double* Phi; const double* Q; int leg; int pose;
+    int nb_cov;                 // workgroups of the covariance part (0: none)
+    int nb_ing;                 // ingest workgroups behind them
+    int nseg;
+    const char* src[FH_SEGS]; char* dst[FH_SEGS]; unsigned bytes[FH_SEGS];
+    int pose_block;             // ingest workgroup that also runs the pose step of the frame's second update (-1: none)
+    PoseStepArgs ps;
+};
+
+// The arithmetic of k_cov_propagate_rows / k_cov_propagate_finish / k_cov_augment (cov_ops.hpp), element by element in the same order --
+// the separate calls and this launch give the same bits (tests/test_gpu_stream.py):
+//   P' = [[sym(Phi P_LL Phi^T + Q), Phi P_LC], [(Phi P_LC)^T, P_CC]]   (src/orcvio.cpp:800-816)
+//   out = P' with the new clone's rows / columns copied from the IMU's (theta, p) and (X + X^T) / 2 (:962-1010)
+// One thread per output element, enumerated so that the elements whose source lies in the IMU rows come first: L_out = the output
+// indices whose source index is < leg (the IMU block and, when augmenting, the new clone), C_out the others.
+//   region 1  (a, b) in L_out x L_out   needs T_LL = Phi P_LL (leg x leg, formed in LDS by every workgroup of the region: 2 products per thread)
+//   region 2  (a, b) in L_out x C_out   T(sa, sb) = sum_l Phi(sa, l) P(l, sb), written to (a, b) and (b, a)
+//   region 3  (a, b) in C_out x C_out   P(sa, sb), symmetrised as the augmentation does
+// Only regions 1 and 2 (a fifth of the matrix) read Phi from the pinned arena.
+template <int LEG>   // 22 or 46 (leg_dim): the products over the IMU block unroll completely -- their loads in flight together, the sums in the same order
+__global__ __launch_bounds__(256) void k_frame_head(FrameHeadArgs a) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b >= a.nb_cov) {
+        const int w = b - a.nb_cov;
+        if (w == a.pose_block && t < 64) pose_step_body(a.ps.src, a.ps.dst, a.ps.N, a.ps.stride, a.ps.dx, a.ps.leg, a.ps.apply, a.ps.left, a.ps.discard_large, a.ps.info, a.ps.keep, t);
+        int p0 = 0;   // pieces of the segments before this one
+        for (int sgi = 0; sgi < a.nseg; ++sgi) {
+            const unsigned bytes = a.bytes[sgi];
+            const int np = (int)((bytes + FH_PIECE - 1) / FH_PIECE);
+            for (int q = 0; q < np; ++q) {
+                if ((p0 + q) % a.nb_ing != w) continue;
+                const unsigned off = (unsigned)q * FH_PIECE;
+                const unsigned len = bytes - off < FH_PIECE ? bytes - off : FH_PIECE;
+                const char* sp = a.src[sgi] + off;
+                char* dp = a.dst[sgi] + off;
+                if ((((size_t)sp | (size_t)dp | (size_t)len) & 15) == 0) {
+                    const u32x4* s16 = reinterpret_cast<const u32x4*>(sp);
+                    u32x4* d16 = reinterpret_cast<u32x4*>(dp);
+                    for (unsigned i = t; i < len / 16; i += 256) d16[i] = __builtin_nontemporal_load(s16 + i);
+                } else {
+                    const unsigned* s4 = reinterpret_cast<const unsigned*>(sp);
+                    unsigned* d4 = reinterpret_cast<unsigned*>(dp);
+                    for (unsigned i = t; i < len / 4; i += 256) d4[i] = __builtin_nontemporal_load(s4 + i);
+                }
+            }
+            p0 += np;
+        }
+        return;
+    }
+    __shared__ double sPhi[LEG * LEG];
+    __shared__ double sT[LEG * LEG];
+    const int n = a.n, m = a.m, pose = a.pose;
+    constexpr int leg = LEG;
+    const int nL = a.Phi ? leg + (pose >= 0 ? 6 : 0) : 0, nC = m - nL;
+    const int E1 = nL * nL, E2 = nL * nC, E3 = nC * nC;
+    const int e0 = b * 256;
+    if (e0 < E1 + E2) {   // (this workgroup has elements of regions 1 / 2)
+        for (int i = t; i < leg * leg; i += 256) sPhi[i] = a.Phi[i];
+        __syncthreads();
+        if (e0 < E1) {
+            for (int idx = t; idx < leg * leg; idx += 256) {
+                const int i = idx / leg, j = idx - i * leg;
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < leg; ++k) s += sPhi[i * leg + k] * a.P[(size_t)k * n + j];
+                sT[idx] = s;
+            }
+            __syncthreads();
+        }
+    }
+    const int e = e0 + t;
+    if (e >= E1 + E2 + E3) return;
+    // output indices (oa, ob)
+    auto Lout = [&](int k) { return k < leg ? k : pose + (k - leg); };
+    auto Cout = [&](int k) { int q = leg + k; if (pose >= 0 && q >= pose) q += 6; return q; };
+    auto src = [&](int o, bool& isnew) {
+        isnew = pose >= 0 && o >= pose && o < pose + 6;
+        if (pose < 0) return o;
+        if (isnew) { const int r = o - pose; return r < 3 ? r : r + 3; }
+        return o < pose ? o : o - 6;
+    };
+    int oa, ob, region;
+    if (e < E1) { region = 1; oa = Lout(e / nL); ob = Lout(e % nL); }
+    else if (e < E1 + E2) { region = 2; const int q = e - E1; oa = Lout(q / nC); ob = Cout(q % nC); }
+    else { region = 3; const int q = e - E1 - E2; if (nL == 0) { oa = q / m; ob = q - oa * m; } else { oa = Cout(q / nC); ob = Cout(q % nC); } }
+    bool na, nb;
+    const int sa = src(oa, na), sb = src(ob, nb);
+    if (region == 1) {
+        double x = a.Q[sa * leg + sb], y = a.Q[sb * leg + sa];
+#pragma unroll
+        for (int k = 0; k < leg; ++k) { x += sT[sa * leg + k] * sPhi[sb * leg + k]; y += sT[sb * leg + k] * sPhi[sa * leg + k]; }
+        a.out[(size_t)oa * m + ob] = 0.5 * (x + y);
+    } else if (region == 2) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < leg; ++k) s += sPhi[sa * leg + k] * a.P[(size_t)k * n + sb];
+        a.out[(size_t)oa * m + ob] = s;
+        a.out[(size_t)ob * m + oa] = s;
+    } else {
+        const double p1 = a.P[(size_t)sa * n + sb], p2 = a.P[(size_t)sb * n + sa];
+        double v;
+        if (pose < 0) v = p1;   // (no augmentation: the propagation copies P_CC as it stands)
+        else if (na == nb) v = 0.5 * (p1 + p2);
+        else if (na) v = p1;
+        else v = p2;
+        a.out[(size_t)oa * m + ob] = v;
+    }
+}
+
+// ---- marginalisation of the covariance and of its resident factor in one launch (k_cov_remove + k_fac_remove, cov_ops.hpp) ----------
+// The removed clones come by value (ascending window indices): new index -> old index by walking the list.  Workgroups [0, nb_P):
+// out (mm x mm) = P without the removed rows / columns; the others: the factor's rows (k x mm, ld ldo) likewise (fac_k = 0: none).
+struct RemoveArgs { int leg, count, clone[8]; };
+__device__ __forceinline__ int remove_map(const RemoveArgs& r, int i) {
+    int o = i;
+    for (int q = 0; q < r.count; ++q)
+        if (o >= r.leg + 6 * r.clone[q]) o += 6;
+    return o;
+}
+__global__ __launch_bounds__(256) void k_cov_remove_fac(const double* __restrict__ P, int n, int mm, RemoveArgs r, double* __restrict__ out, int nb_P,
+                                                        const double* __restrict__ F, int ld, int k, double* __restrict__ Fout, int ldo) {
+    const int b = blockIdx.x;
+    if (b < nb_P) {
+        const int idx = b * 256 + threadIdx.x;
+        if (idx >= mm * mm) return;
+        const int i = idx / mm, j = idx - i * mm;
+        out[idx] = P[(size_t)remove_map(r, i) * n + remove_map(r, j)];
+        return;
+    }
+    const int idx = (b - nb_P) * 256 + threadIdx.x;
+    if (idx >= k * mm) return;
+    const int i = idx / mm, j = idx - i * mm;
+    Fout[(size_t)i * ldo + j] = F[(size_t)i * ld + remove_map(r, j)];
+}
+
+
+// ---- the rows of the in-state features: k_ekf_eval + (fill) + k_ekf_gate of ekf_rows.hpp in ONE launch ---------------------------------
+// A wavefront per feature: lane 0 evaluates the four blocks (measurementJacobian_ekf_{3,1}didp), the wavefront clears the feature's two
+// dense rows, gates the row pair against the prior (2 degrees of freedom, src/orcvio.cpp:2457) and writes them if accepted.  The
+// bodies are the separate kernels': the same bits.  k_gram of the dense rows follows as before.
+__global__ __launch_bounds__(64) void k_ekf_evalgate(EkfEvalArgs e, int do_eval, EkfGateArgs g) {
+    const int f = blockIdx.x, l = threadIdx.x;
+    for (int i = l; i < 2 * g.NAP; i += 64) g.E[(size_t)2 * f * g.NAP + i] = 0.0;
+    if (do_eval && l == 0) ekf_eval_body(e, f);
+    __syncthreads();   // (one wavefront: the stores of lane 0 and of the fill are out before the gate reads / writes)
+    ekf_gate_body(g, f, l);
+}
+
+// ---- k_finish_pub: k_finish_sqrt + k_epilogue in ONE launch (a feature update's last two launches) -----------------------------------
+// The tiles of P+ = s2 Zn^T Zn and dx = Zn^T z exactly as k_finish_sqrt forms them (one workgroup per lower tile, the same split of K
+// over four wavefronts, the same order: the same bits).  What k_epilogue did behind it rides along:
+//   commit     P+ is written straight into the SPARE covariance buffer -- the host swaps the two buffers instead of a copy over the
+//              resident one -- and every workgroup writes its share of S+ = sigma Z^T (or of the prior's own factor) into the spare
+//              factor buffer.  Refusals known at launch (the pivot counters of chol(M), a lost in-launch hand-off, the frame's first
+//              update refused: info_also) are decided by every workgroup for itself: the spare buffers then receive the PRIOR and its
+//              factor, so that the swap is right either way.  A non-finite dx -- which only shows once the tiles are done -- is caught
+//              by the workgroup that arrives last: it rewrites both buffers with the prior (never on sane input).
+//   publish    the workgroup that arrives last (a device counter behind an agent-scope fence) copies the small result block
+//              [info | dx | gamma | accept] into host-coherent memory and raises the flag word the calling thread spins on.
+//   P_host     (optional, want_P) P+ also goes tile by tile into the pinned output block: the mirrored half through an LDS transpose so
+//              that both halves leave as 128-byte rows.
+struct FinishPubArgs {
+    const double* Z; int ldz, n, kdim; double s2;
+    const double* P;        // the prior
+    double* P_dst;          // commit: the spare covariance buffer; no commit: the outputs arena's P_out
+    double* dx;
+    int commit;             // 0: none (k_finish_sqrt's semantics), 1: P+ only, 2: P+ and the factor
+    double sigma; const double* prior; long sLi, sLj; double* Sout; int ldo;
+    const int* info; const int* info_also;
+    double* P_host;         // pinned output block (want_P) or nullptr
+    const u32x4* small_src; u32x4* small_dst; size_t small16;
+    int* counter; unsigned long long* seq; unsigned long long* flag;
+};
+__global__ __launch_bounds__(256) void k_finish_pub(FinishPubArgs a) {
+    __shared__ double sPart[3][4][64];
+    __shared__ double sTr[16][17];
+    __shared__ int sLast, sBad;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, t = threadIdx.x;
+    const int n = a.n, kdim = a.kdim, ldz = a.ldz;
+    int bi, bj;
+    tile_from_linear(blockIdx.x, bi, bj);
+    const bool failed = a.info[2] != 0 || a.info[3] != 0;
+    const bool also = a.info_also && (a.info_also[2] != 0 || a.info_also[3] != 0 || a.info_also[8] != 0);
+    const bool refuse_up = failed || a.info[8] != 0 || also;
+    // what the host reads besides dx -- info, gamma, accept: older launches' results -- leaves with the first workgroup, under the products
+    const size_t dx0 = 256 / 4, dx1 = dx0 + (((size_t)n * 8 + 255) & ~(size_t)255) / 4;   // (words of the small block that hold dx: layout_outputs)
+    if (blockIdx.x == 0) {
+        const unsigned* s4 = reinterpret_cast<const unsigned*>(a.small_src);
+        unsigned* d4p = reinterpret_cast<unsigned*>(a.small_dst);
+        for (size_t i = t; i < a.small16 * 4; i += 256)
+            if (i < dx0 || i >= dx1) d4p[i] = s4[i];
+    }
+    const int KS = ((kdim + 15) >> 4) << 2;
+    const int k0 = wave * KS;
+    const int Kw = (kdim - k0 < KS) ? (kdim - k0) : KS;
+    d4 acc = tile_product(a.Z + (size_t)k0 * ldz, 1, ldz, a.Z + (size_t)k0 * ldz, ldz, 1, n + 1, n + 1, Kw, 16 * bi, 16 * bj, l);
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPart[wave - 1][r][l] = acc[r];
+    }
+    __syncthreads();
+    const int kk = l >> 4, cc = l & 15;
+    double* dx_host = reinterpret_cast<double*>(reinterpret_cast<char*>(a.small_dst) + 256);
+    if (wave == 0) {
+        const bool app = !failed;   // (dx as k_finish_sqrt decides it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = ((acc[r] + sPart[0][r][l]) + sPart[1][r][l]) + sPart[2][r][l];
+            const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
+            double pv = 0.0, pm = 0.0;   // (i, jj) and its mirror
+            if (i < n && jj < n && jj <= i) {
+                if (a.commit) {
+                    if (refuse_up) { pv = a.P[(size_t)i * n + jj]; pm = a.P[(size_t)jj * n + i]; }
+                    else pv = pm = a.s2 * v;
+                } else pv = pm = app ? a.s2 * v : 0.5 * (a.P[(size_t)i * n + jj] + a.P[(size_t)jj * n + i]);
+                a.P_dst[(size_t)i * n + jj] = pv;
+                a.P_dst[(size_t)jj * n + i] = pm;
+                if (a.P_host) a.P_host[(size_t)i * n + jj] = pv;
+            } else if (i == n && jj < n) {
+                const double d = app ? v : 0.0;
+                st_pub<true>(a.dx + jj, d);   // (read back by the workgroup that arrives last: past the caches)
+                dx_host[jj] = d;
+            }
+            if (a.P_host) sTr[kk + 4 * r][cc] = pm;   // (row kk + 4r, column cc of the tile: transposed below)
+        }
+    }
+    if (a.P_host) {   // the mirrored half of the tile, row by row
+        __syncthreads();
+        {
+            const int rr = t >> 4, c2 = t & 15;   // 256 threads: element (rr, c2) of the TRANSPOSED tile
+            const int i = 16 * bj + rr, jj = 16 * bi + c2;
+            if ((bi > bj || rr < c2) && i < n && jj < n) a.P_host[(size_t)i * n + jj] = sTr[c2][rr];   // (a diagonal tile: its strict upper part)
+        }
+    }
+    if (a.commit == 2) {   // this workgroup's share of the factor
+        const size_t kn = (size_t)a.kdim * n, stride = (size_t)gridDim.x * 256;
+        for (size_t idx = (size_t)blockIdx.x * 256 + t; idx < kn; idx += stride) {
+            const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
+            a.Sout[(size_t)i * a.ldo + j] = refuse_up ? a.prior[(long)j * a.sLi + (long)i * a.sLj] : a.sigma * a.Z[(size_t)i * ldz + j];
+        }
+    }
+    // arrive: this workgroup's stores have been acknowledged (the host-coherent ones too) before it counts itself in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        const int old = __hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sLast = (old == (int)gridDim.x - 1) ? 1 : 0;
+        sBad = 0;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    int bad = 0;
+    for (int i = t; i < n; i += 256) { const double v = ld_pub(a.dx + i); bad |= !(v - v == 0.0); }
+    if (bad) sBad = 1;
+    __syncthreads();
+    if (a.commit && sBad && !refuse_up) {   // non-finite result: the spare buffers get the prior and its factor after all
+        for (size_t i = t; i < (size_t)n * n; i += 256) a.P_dst[i] = a.P[i];
+        if (a.commit == 2) {
+            const size_t kn = (size_t)a.kdim * n;
+            for (size_t idx = t; idx < kn; idx += 256) {
+                const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
+                a.Sout[(size_t)i * a.ldo + j] = a.prior[(long)j * a.sLi + (long)i * a.sLj];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (t == 0) {
+        __threadfence_system();
+        __hip_atomic_store(a.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long v = atomicAdd(a.seq, 1ull) + 1ull;
+        __hip_atomic_store(a.flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace orcvio_amd

@@ -301,6 +301,12 @@ struct orcvio_msckf_handle {
     int* d_step_words = nullptr;        // [0..15] status words of the frame's first update, kept for the second update's commit (info_also)
     std::vector<int> step_row_ptr;      // the second update's row offsets
     long long cnt_step_frames = 0;      // frames through orcvio_msckf_io_step_frame
+    bool step_ingested = false;         // k_frame_head has pulled the arena of the update being enqueued (io_enqueue skips its ingest launch)
+    bool ekf_one_launch = true;         // the in-state features' evaluation, fill and gate in ONE launch (k_ekf_evalgate) instead of three (ORCVIO_EKF_ONE_LAUNCH=0, diagnostics)
+    bool finpub_opt = true;             // a feature update's k_finish_sqrt + k_epilogue as ONE launch (k_finish_pub) on the in-place paths (ORCVIO_FINISH_PUB=0, diagnostics)
+    FinishPubArgs* fin_pub = nullptr;   // set by io_enqueue around enqueue_update: launch_solve_stage(ST_FINISH) launches k_finish_pub with it
+    bool last_finpub_commit = false;    // the update enqueued last committed by writing P+ into the spare covariance buffer: the host swaps d_Pres / d_Ptmp
+    bool step_fused = true;             // ORCVIO_STEP_FUSED=0 (diagnostics build): the frame's small steps as the separate launches and copies of the round-5 calls
     double chi2_prob_cached = -1.0;
 };
 

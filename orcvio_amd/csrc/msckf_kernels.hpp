@@ -919,19 +919,10 @@ __device__ __forceinline__ void tile_from_linear(int tl, int& bi, int& bj) {
     bj = tl - b * (b + 1) / 2;
 }
 
-__device__ __forceinline__ void gram_body(const double* __restrict__ X, int m, int NAP, int rows_per_chunk,
-                                          double* __restrict__ Gpart, const int* __restrict__ chunk_ptr, int bx, int chunk) {
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nb = NAP >> 4;
-    const int ntiles = nb * (nb + 1) / 2;
-    const int tl = bx * 4 + wave;
-    if (tl >= ntiles) return;
+// lower tile `tl` of the Gram of the rows [r0, r1) of X, by ONE wavefront (lane l), into `out` (NAP x NAP)
+__device__ __forceinline__ void gram_tile(const double* __restrict__ X, int NAP, int r0, int r1, double* __restrict__ out, const int tl, const int l) {
     int bi, bj;
     tile_from_linear(tl, bi, bj);
-    int r0 = chunk * rows_per_chunk;
-    int r1 = r0 + rows_per_chunk;
-    if (chunk_ptr) { r0 = chunk_ptr[chunk]; r1 = chunk_ptr[chunk + 1]; }   // ragged chunks (one per object block)
-    if (r1 > m) r1 = m;
     const int kk = l >> 4, cc = l & 15;
     const double* pa = X + 16 * bi + cc;
     const double* pb = X + 16 * bj + cc;
@@ -954,12 +945,24 @@ __device__ __forceinline__ void gram_body(const double* __restrict__ X, int m, i
         }
     }
     if (r1 <= r0) { acc0 = d4{0, 0, 0, 0}; acc1 = d4{0, 0, 0, 0}; }
-    double* out = Gpart + (size_t)chunk * NAP * NAP;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = 16 * bi + kk + 4 * r, jj = 16 * bj + cc;
         out[(size_t)i * NAP + jj] = acc0[r] + acc1[r];
     }
+}
+__device__ __forceinline__ void gram_body(const double* __restrict__ X, int m, int NAP, int rows_per_chunk,
+                                          double* __restrict__ Gpart, const int* __restrict__ chunk_ptr, int bx, int chunk) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nb = NAP >> 4;
+    const int ntiles = nb * (nb + 1) / 2;
+    const int tl = bx * 4 + wave;
+    if (tl >= ntiles) return;
+    int r0 = chunk * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    if (chunk_ptr) { r0 = chunk_ptr[chunk]; r1 = chunk_ptr[chunk + 1]; }   // ragged chunks (one per object block)
+    if (r1 > m) r1 = m;
+    gram_tile(X, NAP, r0, r1, Gpart + (size_t)chunk * NAP * NAP, tl, l);
 }
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ X, int m, int NAP, int rows_per_chunk,
                                               double* __restrict__ Gpart, const int* __restrict__ chunk_ptr = nullptr) {

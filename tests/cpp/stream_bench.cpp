@@ -187,7 +187,7 @@ static double pct(std::vector<double> v, double q) {
 int main(int argc, char** argv) {
     std::string path, mode = "calls", dump;
     int frames = 480, warm = 32, device = 0;
-    bool prefactor = true, apply_dx = false;
+    bool prefactor = true, apply_dx = false, sync_each = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() { return i + 1 < argc ? std::string(argv[++i]) : std::string(); };
@@ -198,6 +198,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = atoi(next().c_str());
         else if (a == "--no-prefactor") prefactor = false;
         else if (a == "--apply-dx") apply_dx = true;
+        else if (a == "--sync-each") sync_each = true;
         else if (a == "--dump") dump = next();
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -214,6 +215,7 @@ int main(int argc, char** argv) {
     FrameOut out;
     FILE* df = dump.empty() ? nullptr : fopen(dump.c_str(), "wb");
     int n_updates = 0, discards = 0;
+    auto t_loop0 = std::chrono::steady_clock::now();
     for (int it = 0; it < frames + warm; ++it) {
         const Frame& fr = s.frames[it % s.n_frames];
         const auto t0 = std::chrono::steady_clock::now();
@@ -224,8 +226,9 @@ int main(int argc, char** argv) {
 #endif
         else { std::fprintf(stderr, "unknown --mode %s\n", mode.c_str()); return 2; }
         if (rc != ORCVIO_OK) return rc;
-        CHK(orcvio_msckf_sync(h, nullptr));
+        if (sync_each) CHK(orcvio_msckf_sync(h, nullptr));   // (the results are in host memory when the calls return; what is still in flight -- the marginalisation -- is ordered in front of the next frame by the stream)
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (it == warm - 1) { CHK(orcvio_msckf_sync(h, nullptr)); t_loop0 = std::chrono::steady_clock::now(); }
         n_updates += 1 + (fr.has_prune ? 1 : 0);
         discards += out.st1[4];
         for (double v : out.dx1) if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite dx in frame %d\n", it); return 3; }
@@ -241,6 +244,8 @@ int main(int argc, char** argv) {
             per_frame[it % s.n_frames].push_back(ms);
         }
     }
+    CHK(orcvio_msckf_sync(h, nullptr));   // (inside the timed loop: frames_per_s counts everything the frames enqueued)
+    const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count();
     int32_t n_end = 0;
     CHK(orcvio_msckf_cov_get(h, &n_end, nullptr));
     std::vector<double> P((size_t)n_end * n_end);
@@ -261,7 +266,7 @@ int main(int argc, char** argv) {
                 "\"worst_p95_over_median_same_frame\": %.4f, \"updates_per_frame\": %.3f, \"large_update_flags\": %d, \"front_fallbacks\": %" PRId64 ", "
                 "\"graph_captures\": %" PRId64 ", \"graph_replays\": %" PRId64 ", \"plain_runs\": %" PRId64 ", "
                 "\"n_end\": %d, \"dx_hash\": \"%016" PRIx64 "\", \"P_hash\": \"%016" PRIx64 "\"}\n",
-                mode.c_str(), prefactor ? 1 : 0, apply_dx ? 1 : 0, frames, 1e3 / mean, mean, pct(t_all, 0.5), pct(t_all, 0.95),
+                mode.c_str(), prefactor ? 1 : 0, apply_dx ? 1 : 0, frames, frames / loop_s, mean, pct(t_all, 0.5), pct(t_all, 0.95),
                 pct(t_prune, 0.5), pct(t_prune, 0.95), t_prune.empty() ? 0.0 : pct(t_prune, 0.95) / pct(t_prune, 0.5), t_prune.size(),
                 pct(t_plain, 0.5), pct(t_plain, 0.95), t_plain.empty() ? 0.0 : pct(t_plain, 0.95) / pct(t_plain, 0.5), t_plain.size(),
                 worst_jit, (double)n_updates / (frames + warm), discards, cnt[0], cnt[1], cnt[2], cnt[3], n_end, hash, hash_P);

@@ -109,7 +109,7 @@ def test_step_frame_with_the_state_increment_on_the_device(built):
                 fr = frames[it % len(frames)]
                 ref = _frame_by_calls(a, fr, prune_poses=incremented)
                 got = b.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], True, fr['remove'])
-                assert np.array_equal(got['dx'], ref[0])
+                assert rel(got['dx'], ref[0]) < 1e-9   # (not bit for bit: the device's sin / cos against the host's, carried by the covariance from the first prune update on)
                 if fr['prune'] is not None:
                     assert rel(got['prune_dx'], ref[3]) < 1e-9, (it, rel(got['prune_dx'], ref[3]))
                 assert rel(b.cov_get(), a.cov_get()) < 1e-10
