@@ -538,8 +538,9 @@ int32_t orcvio_msckf_objects_download(orcvio_msckf_handle* h, orcvio_msckf_resul
  *       (an object with two frames on one clone, more than 32 in-window frames or 16 keypoints, rows beyond the LDS staging,
  *       ORCVIO_OPT_OBJECT_REFINE = 0, ORCVIO_OPT_REF_STACK_HF, ORCVIO_OPT_OBJECT_QR = 0)
  *   [6] frames (orcvio_msckf_io_update_frame) whose object solve ran chained to the feature update's factor (ORCVIO_FRAME_CHAIN)
- *   [7] frame calls that found their object tracks staged ahead (orcvio_msckf_io_stage_object_tracks) */
-#define ORCVIO_COUNTERS 8
+ *   [7] frame calls that found their object tracks staged ahead (orcvio_msckf_io_stage_object_tracks)
+ *   [8] filter frames through orcvio_msckf_io_step_frame   [9] updates of such frames run again after a lost in-launch hand-off */
+#define ORCVIO_COUNTERS 10
 int32_t orcvio_msckf_counters(orcvio_msckf_handle* h, int64_t* counters, int32_t count);
 
 /* Objects of the last downloaded object update (any entry point) whose projection against H_f went through the explicit basis

@@ -476,11 +476,12 @@ class MsckfUpdater:
     def counters(self):
         """Cumulative counters of the handle: front_fallbacks (fused front end re-run on the forked path because another tenant of the
         device held compute units), launch sequences captured / replayed from a graph / run as plain launches."""
-        v = (C.c_int64 * 8)()
+        v = (C.c_int64 * 10)()
         self.lib.orcvio_msckf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
-        self._chk(self.lib.orcvio_msckf_counters(self.h, v, 8), 'orcvio_msckf_counters')
+        self._chk(self.lib.orcvio_msckf_counters(self.h, v, 10), 'orcvio_msckf_counters')
         return dict(front_fallbacks=int(v[0]), graph_captures=int(v[1]), graph_replays=int(v[2]), plain_runs=int(v[3]),
-                    front_blocked_by_comm=int(v[4]), obj_fused=int(v[5]), chained_frames=int(v[6]), prestaged_frames=int(v[7]))
+                    front_blocked_by_comm=int(v[4]), obj_fused=int(v[5]), chained_frames=int(v[6]), prestaged_frames=int(v[7]),
+                    step_frames=int(v[8]), step_repairs=int(v[9]))
 
     def comm_info(self):
         r, w = C.c_int32(0), C.c_int32(0)

@@ -347,6 +347,9 @@ __global__ __launch_bounds__(256) void k_finish_pub(FinishPubArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
+        // (a workgroup that stored to host memory -- P_host tiles, dx, the first workgroup's block -- makes those stores visible at system
+        //  scope before it counts itself in, as k_epilogue's workgroups do: the flag must not overtake them on another path of the fabric)
+        if (a.P_host || blockIdx.x == 0 || 16 * bi + 15 >= n) __threadfence_system();
         const int old = __hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sLast = (old == (int)gridDim.x - 1) ? 1 : 0;
         sBad = 0;

@@ -46,12 +46,15 @@ struct EpilogueArgs {
     unsigned long long* seq;      // device memory: publications so far
     unsigned long long* flag;     // host-coherent memory: the caller waits for *flag >= its expected sequence number
     const int* info_also;         // optional: a second status block whose refusal refuses this commit too (the feature half's, for the chained object solve)
+    int* info_keep;               // optional: a copy of info[0..15] for a LATER update's commit to look at (its info_also) once this one's status words
+                                  // have been overwritten: the frame call's object half on the stream behind this launch
     int pub_all;                  // 1: the flag rises behind the COMMIT workgroups too (the frame call's chained object solve runs on a stream of its
                                   // own: whatever the caller does next on the handle's stream must find the commit done)
 };
 __global__ __launch_bounds__(256) void k_epilogue(EpilogueArgs a) {
     const int nb = gridDim.x, b = blockIdx.x, t = threadIdx.x;
     if (b == 0) {
+        if (a.info_keep && t < 16) a.info_keep[t] = a.info[t];
         for (size_t i = t; i < a.small16; i += 256) a.small_dst[i] = a.small_src[i];
     } else if (b <= a.nb_P) {
         const size_t stride = (size_t)a.nb_P * 256;

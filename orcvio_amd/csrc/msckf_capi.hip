@@ -298,9 +298,10 @@ struct orcvio_msckf_handle {
     // orcvio_msckf_io_step_frame (capi_step.inc): the second update of a frame goes through an arena pair of its own, swapped in and out
     char *d_in2 = nullptr, *h_stage2 = nullptr, *h_stage2_dev = nullptr;
     bool arena_swapped = false;
+    int* epi_info_keep = nullptr;       // io_enqueue hands it to k_epilogue (EpilogueArgs.info_keep); set by orcvio_msckf_io_update_frame around its feature half
     int* d_step_words = nullptr;        // [0..15] status words of the frame's first update, kept for the second update's commit (info_also)
     std::vector<int> step_row_ptr;      // the second update's row offsets
-    long long cnt_step_frames = 0;      // frames through orcvio_msckf_io_step_frame
+    long long cnt_step_frames = 0, cnt_step_repairs = 0;   // frames through orcvio_msckf_io_step_frame; updates of such frames run again after a lost hand-off
     bool step_ingested = false;         // k_frame_head has pulled the arena of the update being enqueued (io_enqueue skips its ingest launch)
     bool ekf_one_launch = true;         // the in-state features' evaluation, fill and gate in ONE launch (k_ekf_evalgate) instead of three (ORCVIO_EKF_ONE_LAUNCH=0, diagnostics)
     bool finpub_opt = true;             // a feature update's k_finish_sqrt + k_epilogue as ONE launch (k_finish_pub) on the in-place paths (ORCVIO_FINISH_PUB=0, diagnostics)

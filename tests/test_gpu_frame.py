@@ -173,6 +173,34 @@ def test_refused_feature_half_applies_nothing(upd):
     assert _same(f1['dx'], f0['dx']) and _same(o1['dx'], o0['dx']) and o1['accept'] == o0['accept']
 
 
+def test_refused_feature_half_with_a_finite_prior_refuses_the_object_commit_too(upd):
+    """a FINITE prior on which only the feature half fails -- its noise so small that sigma^2 is lost beside
+    L^T A L and chol(M1) meets a non-positive pivot -- while the object half, with a sane noise of its own, would go through.  The
+    object half's commit rides in its own epilogue launch, enqueued before the host has seen the feature half's outcome: it must
+    refuse itself on the feature half's status words (kept by the feature half's epilogue), or the resident covariance would hold an
+    object update applied to a prior the call reports as untouched."""
+    import dataclasses
+    oflags = synth.Flags(use_larvio=0, use_left_perturbation=0)
+    fflags = dataclasses.replace(oflags, noise_feature=1e-40)
+    win = synth.make_window(N=10, F=40, seed=4, flags=oflags, track_len=(3, 10))
+    objs = synth.make_objects(win, n_objects=2, seed=2, sigma_kp=0.004)
+    wf = dataclasses.replace(win, flags=fflags)
+    upd.cov_set(win.P)
+    try:
+        upd.update_frame(wf, oflags, objs, win.R_b2c[0], win.t_c_b[0], True, False, 0)
+    except capi.MsckfError as e:
+        assert e.code == 6, e
+        assert np.array_equal(upd.cov_get(), win.P)   # nothing of the frame was applied: the object half's commit refused itself
+    else:
+        pytest.skip('chol(M1) went through at sigma = 1e-40 on this window: the refusal could not be provoked')
+    # the handle goes on
+    upd.cov_set(win.P)
+    f0, o0 = _two_calls(upd, win, objs)
+    upd.cov_set(win.P)
+    f1, o1 = _frame(upd, win, objs)
+    assert _same(f1['dx'], f0['dx']) and _same(o1['dx'], o0['dx'])
+
+
 def test_refused_object_half_keeps_the_feature_update(upd):
     flags = synth.Flags(use_larvio=0, use_left_perturbation=0)
     win = synth.make_window(N=10, F=40, seed=4, flags=flags, track_len=(3, 10))

@@ -180,3 +180,35 @@ def test_step_frame_refusal_of_the_first_update_refuses_the_second(built):
         assert got['rc'] == 0 and got['stats'][3] == 1
     finally:
         a.close(); b.close()
+
+
+def test_step_frame_repairs_a_lost_hand_off(built, monkeypatch):
+    """ORCVIO_LA_SPIN = 0: every wait of the look-ahead factorisation on another workgroup gives up at once -- each update of each
+    frame flags itself and refuses its commit on the device (and the second update with the first).  The call takes the
+    marginalisation back, runs the lost updates again in separate launches (the one-workgroup factorisation, the outcome checked by
+    the host) and marginalises: the same filter as the separate calls on an undisturbed handle."""
+    fl = synth.Flags(use_larvio=1)
+    frames, P0 = synth.make_stream(fl)
+    a = _handle()
+    monkeypatch.setenv('ORCVIO_LA_SPIN', '0')
+    b = _handle()
+    monkeypatch.delenv('ORCVIO_LA_SPIN')
+    try:
+        a.cov_set(P0); b.cov_set(P0)
+        repaired = 0
+        for it in range(10):
+            fr = frames[it % len(frames)]
+            ref = _frame_by_calls(a, fr)
+            got = b.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, fr['remove'])
+            assert got['rc'] == 0 and got['stats'][3] == 1
+            repaired += got['repaired']
+            assert got['repaired'] == (2 if fr['prune'] is not None else 1), (it, got['repaired'])
+            assert rel(got['dx'], ref[0]) < 1e-9 and np.array_equal(got['accept'], ref[2])
+            if fr['prune'] is not None:
+                assert rel(got['prune_dx'], ref[3]) < 1e-9
+            Pa, Pb = a.cov_get(), b.cov_get()
+            assert Pa.shape == Pb.shape and rel(Pb, Pa) < 1e-10
+        c = b.counters()
+        assert c['step_frames'] == 10 and c['step_repairs'] == repaired and c['front_fallbacks'] >= 10
+    finally:
+        a.close(); b.close()
