@@ -18,6 +18,23 @@
  *       td(21) [IMU intrinsics 22:46 if leg_dim==46] | clone i: theta,p at leg_dim+6i
  *   - one update in flight per handle; calls return after the result is in the
  *     caller's buffers unless the name says _async / _device.
+ *
+ * Environment.  The library reads TEN environment variables, all of them here (tests/test_abi.py checks the built
+ * library against this list); every ablation / stamp / experiment switch of docs/LAB_NOTES.md exists in the diagnostics
+ * build only (liborcvio_msckf_dbg.so, -DORCVIO_DEBUG_HOOKS):
+ *   ORCVIO_COMM_TRANSPORT    "ipc": the communicator uses HIP IPC + shared memory instead of RCCL (ranks of one node)
+ *   ORCVIO_COMM_TIMEOUT_S    bound of every wait another rank can strand, seconds (default 60)
+ *   ORCVIO_IPC_WAIT_S        bound of the ipc transport's device-side wait for a peer's block, seconds (default 20)
+ *   ORCVIO_IPC_XDEV          "1": allow the ipc transport between ranks on DIFFERENT devices (unverified: refused otherwise)
+ *   ORCVIO_RCCL_LIB          path of the RCCL library to dlopen (default librccl.so.1 / librccl.so)
+ *   ORCVIO_IO_SPIN_SECONDS   how long the calling thread spins on the result flag before it falls back to a stream
+ *                            synchronisation (default 2)
+ *   ORCVIO_LA_SPIN           polls (~1 us each) before a wait inside the look-ahead factorisation gives up and the update is
+ *                            run again in separate launches (default 1 << 22)
+ *   ORCVIO_FRONT_SPIN        the same for the device-wide counter of the fused front end (default 1 << 19)
+ *   ORCVIO_FRAME_CHAIN       "0": orcvio_msckf_io_update_frame solves the object update behind the feature update's commit
+ *                            (bit-identical to the two calls) instead of chained to its factor (equal to rounding; default 1)
+ *   ORCVIO_FRAME_OVERLAP     "0": orcvio_msckf_io_update_frame runs its two halves one behind the other
  */
 #ifndef ORCVIO_MSCKF_H
 #define ORCVIO_MSCKF_H
@@ -706,7 +723,8 @@ int32_t orcvio_msckf_comm_info(orcvio_msckf_handle* h, int32_t* rank, int32_t* w
 /* What the communicator is, for logs and benchmarks (count <= 8 values are written): out[0] transport (0 none, 1 RCCL, 2 ipc),
  * [1] rank, [2] world, [3] ranks_seen: slots of the last sharded update that carried their sender's own number behind the block
  * (= world when every rank's block arrived), [4] 1 if a peer shares this rank's device (ipc), [5] 1 if the ipc gather buffer is
- * fine-grained / uncached memory. */
+ * fine-grained / uncached memory, [6] 1 if a peer runs on ANOTHER device under the ipc transport: that case is UNVERIFIED (the transport
+ * has only ever run with several ranks on one device) and comm_init refuses it unless ORCVIO_IPC_XDEV=1 is set. */
 int32_t orcvio_msckf_comm_details(orcvio_msckf_handle* h, int32_t* out, int32_t count);
 /* Device time of the three parts of orcvio_msckf_run_update_sharded on THIS rank (HIP events on the handle's stream, medians over
  * `reps` updates of the uploaded share), microseconds: us[0] local tracks + compression, us[1] the exchange (the RCCL all-gather, or

@@ -493,7 +493,7 @@ class MsckfUpdater:
         self.lib.orcvio_msckf_comm_details.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
         self._chk(self.lib.orcvio_msckf_comm_details(self.h, v, 8), 'orcvio_msckf_comm_details')
         return dict(transport={0: 'none', 1: 'rccl', 2: 'ipc'}[int(v[0])], rank=int(v[1]), world=int(v[2]), ranks_seen=int(v[3]),
-                    shared_device=bool(v[4]), gather_uncached=bool(v[5]))
+                    shared_device=bool(v[4]), gather_uncached=bool(v[5]), ipc_across_devices_unverified=bool(v[6]))
 
     def profile_sharded(self, reps=20):
         """COLLECTIVE.  Device microseconds of this rank's sharded update: local, exchange, replicated solve, total (medians)."""

@@ -36,6 +36,16 @@ using namespace orcvio_amd;
 
 static thread_local std::string g_last_error;
 
+// Environment switches.  The PRODUCT library reads ten, all documented in include/orcvio_msckf.h ("Environment"): the communicator's
+// transport and bounds, the bounds of the in-launch waits, the two numerics-relevant forms of the frame call.  Every ablation, stamp and
+// measured-slower path of the lab notes is read through dbg_getenv, which the product build compiles to "unset" (VERDICT r5 #6): those
+// switches exist in the diagnostics build only (liborcvio_msckf_dbg.so, -DORCVIO_DEBUG_HOOKS; tests/test_abi.py checks the strings).
+#ifdef ORCVIO_DEBUG_HOOKS
+static inline const char* dbg_getenv(const char* name) { return getenv(name); }
+#else
+static inline const char* dbg_getenv(const char*) { return nullptr; }
+#endif
+
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "msckf_math.hpp"
+#include "host/ipc_protocol.hpp"
 
 namespace orcvio_amd {
 
@@ -1065,15 +1066,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
     const int i = idx / NAP, jj = idx - i * NAP;
     // parts hold lower tiles only; mirror them so that dst is the full symmetric block
     const int src = ((i >> 4) >= (jj >> 4)) ? idx : jj * NAP + i;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int c = 0;
-    for (; c + 4 <= nparts; c += 4) {   // four loads in flight; fixed summation order (deterministic)
-        const double v0 = parts[(size_t)c * part_stride + src], v1 = parts[(size_t)(c + 1) * part_stride + src];
-        const double v2 = parts[(size_t)(c + 2) * part_stride + src], v3 = parts[(size_t)(c + 3) * part_stride + src];
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-    }
-    for (; c < nparts; ++c) s0 += parts[(size_t)c * part_stride + src];
-    dst[idx] = (s0 + s1) + (s2 + s3);
+    dst[idx] = rank_ordered_sum(parts, nparts, part_stride, (size_t)src);   // (host/ipc_protocol.hpp: fixed order, the same bits on every rank)
 }
 
 // ---------------------------------------------------------------------------------------

@@ -118,3 +118,26 @@ def test_no_cpu_fallback(built):
     assert rc == 2   # ORCVIO_ERR_NO_DEVICE
     with pytest.raises(capi.MsckfError):
         capi.MsckfUpdater()
+
+
+def test_the_product_library_reads_only_the_documented_environment_variables(built):
+    """the header documents ten environment variables; nothing else that looks like a switch may be left in the
+    product library (the ablation / stamp / experiment switches are compiled out of it: dbg_getenv, msckf_capi.hip), while the
+    diagnostics build still knows them."""
+    import re
+    from orcvio_amd import build as b
+    header = open(os.path.join(ROOT, 'include', 'orcvio_msckf.h')).read()
+    block = header[header.index(' * Environment.'):header.index('#ifndef ORCVIO_MSCKF_H')]
+    documented = set(re.findall(r'^ \*   (ORCVIO_[A-Z_0-9]+) ', block, flags=re.M))
+    assert len(documented) == 10, documented
+    not_env = ('ORCVIO_OPT_', 'ORCVIO_ERR_', 'ORCVIO_MAX_', 'ORCVIO_OK', 'ORCVIO_CHI2_', 'ORCVIO_POSE_', 'ORCVIO_COUNTERS', 'ORCVIO_COMM_ID_BYTES',
+               'ORCVIO_SHARD_', 'ORCVIO_IPC_MAX_', 'ORCVIO_DEBUG_HOOKS', 'ORCVIO_MSCKF_')
+
+    def names(path):
+        blob = open(path, 'rb').read()
+        return {m.decode() for m in re.findall(rb'ORCVIO_[A-Z][A-Z_0-9]+', blob) if not m.decode().startswith(not_env)}
+    prod = names(b.LIB)
+    assert prod <= documented, prod - documented
+    assert {'ORCVIO_COMM_TRANSPORT', 'ORCVIO_LA_SPIN', 'ORCVIO_FRAME_CHAIN'} <= prod
+    dbg = names(b.LIB_DBG)
+    assert {'ORCVIO_FUSE_FINISH', 'ORCVIO_BLK2', 'ORCVIO_SPLIT_TRACKS', 'ORCVIO_TIMING'} <= dbg

@@ -56,8 +56,8 @@ def test_split_tracks_front_end_against_the_fused_one(built, monkeypatch, case):
     win = synth.make_window(N=30, flags=synth.Flags(use_larvio=1), **case)
     out = {}
     for name, thr in (('fused', '0'), ('split', '1')):
-        monkeypatch.setenv('ORCVIO_SPLIT_TRACKS', thr)   # read when the handle is created
-        u = capi.MsckfUpdater(device=0, max_clones=32, max_features=1024, max_observations=32768)
+        monkeypatch.setenv('ORCVIO_SPLIT_TRACKS', thr)   # read when the handle is created (a switch of the diagnostics build)
+        u = capi.MsckfUpdater(device=0, max_clones=32, max_features=1024, max_observations=32768, debug_hooks=True)
         try:
             out[name] = u.update_features(win)
         finally:

@@ -465,8 +465,8 @@ def test_bbox_only_object_tracks(built, monkeypatch, fused, n_objects, frames, o
     one-launch compression (k_obj_fused) and through the three-launch pipeline (ORCVIO_OBJ_FUSED=0); old / new / corrected bbox
     residual, both perturbations, 1-8 objects x 2-30 frames.  Two frames give 8 rows <= 9 columns: the reference's projection
     returns false (math_utils.hpp:292) and the object contributes nothing."""
-    monkeypatch.setenv('ORCVIO_OBJ_FUSED', str(fused))
-    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=64, max_observations=1024)
+    monkeypatch.setenv('ORCVIO_OBJ_FUSED', str(fused))   # (a switch of the diagnostics build)
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=64, max_observations=1024, debug_hooks=True)
     try:
         flags = synth.Flags(use_larvio=0, use_left_perturbation=vio_left)
         win = synth.make_window(N=30, F=4, seed=21 + frames, flags=flags, track_len=4)
@@ -515,8 +515,8 @@ def test_a_noise_pivot_that_passes_the_threshold_is_caught_by_the_orthogonality_
     Q~^T Q~ must be the identity.  Seed 90033 of the soak (a car seen in two frames: H_f of rank 44, last pivot 1.03e-11 of the largest)
     with the tolerance lowered so that the noise pivot is kept at first: the check finds the garbage column, the tolerance is raised, the
     basis formed again -- same result as with the shipped tolerance, and the dropped pivot is counted."""
-    monkeypatch.setenv('ORCVIO_FUSED_TOL', tol)
-    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=64, max_observations=1024)
+    monkeypatch.setenv('ORCVIO_FUSED_TOL', tol)   # (a switch of the diagnostics build)
+    u = capi.MsckfUpdater(device=0, max_clones=32, max_features=64, max_observations=1024, debug_hooks=True)
     try:
         case = random_object_case(90033)
         win, objs = case['win'], case['objs']

@@ -322,7 +322,7 @@ def test_large_windows_block_factorisation_against_the_lds_panel_kernels(built, 
     w = synth.make_window(N=N, F=F, seed=100 + N, track_len=(3, min(N, 24)))
     ref = oracle.msckf_update(w)
     monkeypatch.setenv('ORCVIO_BLK2', '0')
-    old = capi.MsckfUpdater(device=0, max_clones=60, max_features=256, max_observations=8192)
+    old = capi.MsckfUpdater(device=0, max_clones=60, max_features=256, max_observations=8192, debug_hooks=True)   # (the switch exists in the diagnostics build only)
     monkeypatch.delenv('ORCVIO_BLK2')
     new = capi.MsckfUpdater(device=0, max_clones=60, max_features=256, max_observations=8192)
     try:

@@ -99,8 +99,8 @@ def test_finish_inside_the_solve_launch_is_bit_identical_to_the_finish_launch(bu
     objs = synth.make_objects(owin, n_objects=6, seed=1, sigma_kp=0.004)
 
     def run(mode):
-        monkeypatch.setenv('ORCVIO_FUSE_FINISH', mode)
-        upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384)
+        monkeypatch.setenv('ORCVIO_FUSE_FINISH', mode)   # (a switch of the diagnostics build)
+        upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384, debug_hooks=True)
         try:
             feats = [upd.update_features(win) for _ in range(4)]
             upd.cov_set(win.P)
@@ -132,8 +132,8 @@ def test_U_inside_k_front_is_bit_identical_to_the_product_launch(built, monkeypa
     nobs = int(win.obs_ptr[-1])
 
     def run(mode):
-        monkeypatch.setenv('ORCVIO_FRONT_U', mode)
-        upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384)
+        monkeypatch.setenv('ORCVIO_FRONT_U', mode)   # (a switch of the diagnostics build)
+        upd = capi.MsckfUpdater(device=0, max_clones=32, max_features=512, max_observations=16384, debug_hooks=True)
         try:
             feats = [upd.update_features(win) for _ in range(4)]
             upd.cov_set(win.P)

@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEG, IDP, NSLAM = 22, 1, 12
 
 
-def _handle():
-    u = capi.MsckfUpdater(device=0, max_clones=24, max_features=256, max_observations=4096)
+def _handle(debug_hooks=False):
+    u = capi.MsckfUpdater(device=0, max_clones=24, max_features=256, max_observations=4096, debug_hooks=debug_hooks)
     u.set_extra_states(IDP * NSLAM)
     u.set_ekf_rows_mode(True)
     return u
@@ -210,5 +210,30 @@ def test_step_frame_repairs_a_lost_hand_off(built, monkeypatch):
             assert Pa.shape == Pb.shape and rel(Pb, Pa) < 1e-10
         c = b.counters()
         assert c['step_frames'] == 10 and c['step_repairs'] == repaired and c['front_fallbacks'] >= 10
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize('off', ['ORCVIO_STEP_FUSED', 'ORCVIO_FINISH_PUB', 'ORCVIO_EKF_ONE_LAUNCH', 'all'])
+def test_the_folded_launches_equal_the_separate_ones_bit_for_bit(built, monkeypatch, off):
+    """k_frame_head / k_cov_remove_fac (ORCVIO_STEP_FUSED), k_finish_pub (ORCVIO_FINISH_PUB) and k_ekf_evalgate (ORCVIO_EKF_ONE_LAUNCH) each
+    switched off in the diagnostics build -- the frame then runs the separate launches and copies of the round-5 calls, enqueued at
+    once -- against the default: the same dx, the same covariance, bit for bit."""
+    fl = synth.Flags(use_larvio=1)
+    frames, P0 = synth.make_stream(fl)
+    a = _handle(debug_hooks=True)
+    for name in (['ORCVIO_STEP_FUSED', 'ORCVIO_FINISH_PUB', 'ORCVIO_EKF_ONE_LAUNCH'] if off == 'all' else [off]):
+        monkeypatch.setenv(name, '0')
+    b = _handle(debug_hooks=True)
+    try:
+        a.cov_set(P0); b.cov_set(P0)
+        for it in range(16):
+            fr = frames[it % len(frames)]
+            ra = a.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, fr['remove'])
+            rb = b.io_step_frame(fr['w'], fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, fr['remove'])
+            assert np.array_equal(ra['dx'], rb['dx']) and np.array_equal(ra['gamma'], rb['gamma'], equal_nan=True), it
+            if fr['prune'] is not None:
+                assert np.array_equal(ra['prune_dx'], rb['prune_dx']), it
+            assert np.array_equal(a.cov_get(), b.cov_get()), it
     finally:
         a.close(); b.close()
