@@ -380,4 +380,190 @@ __global__ __launch_bounds__(256) void k_finish_pub(FinishPubArgs a) {
     }
 }
 
+
+// ---- the thin update: a stack of a few projected rows, applied in the reference's own direct form ------------------------------------
+// pruneImuStateBuffer's update (src/orcvio.cpp:2803-2851) stacks ONE row per feature seen in both clones that leave: a handful of rows
+// against ~150 states.  measurementUpdate_msckf skips its QR for such a stack (H.rows() <= H.cols(), :1664-1681) and applies
+//     S = H P H^T + s2 I,  K = P H^T S^-1,  dx = K r,  P+ = (I - K H) P, symmetrised                       (:1684-1753)
+// directly.  The square-root form of the general path (chol P, M = s2 I + L^T A L of dimension n, chol M, triangular solves: ~70 us
+// of latency-bound launches) is the wrong tool for m <= 16 rows; here, from the materialised projected rows H' (k_feature):
+//   k_thin_gain   ONE workgroup: W = P_a H'^T (n x m), S = H' W_a + s2 I (m x m) = L L^T, V = W L^-T (n x m), u = L^-1 r
+//   k_thin_apply  P+ = sym(P) - V V^T, dx = V u, elementwise over the n x n matrix; the commit into the spare covariance buffer and
+//                 the publication ride along exactly as in k_finish_pub (the last workgroup raises the flag)
+// S is s2 I plus a positive semi-definite matrix: well conditioned whatever the prior's rank; a non-positive or non-finite pivot
+// (non-finite input) refuses the update (info[2]: P+ = P, dx = 0), as the general path's chol(M) does.
+#define THIN_MAX_ROWS 16
+struct ThinGainArgs { const double* Hs; int m, NAP, NA, n; const double* P; double s2; double* V; double* u; int* info; };
+__global__ __launch_bounds__(1024) void k_thin_gain(ThinGainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sThin[];
+    const int m = a.m, n = a.n, NA = a.NA, t = threadIdx.x;
+    double* sH = sThin;                       // [m][NA + 1]  (the residual in column NA)
+    double* sW = sH + (size_t)m * (NA + 1);   // [n][m]
+    double* sS = sW + (size_t)n * m;          // [m][m] -> its lower Cholesky factor
+    __shared__ int sFail;
+    // the columns ANY row touches, ascending: a projected row has non-zeros in the extrinsic columns and the clones of its track, and
+    // pruneImuStateBuffer's tracks all sit on the two clones that leave -- ~20 of NA columns.  The products below run over this list
+    // only (the same terms in the same ascending order as the dense loops, the zero terms left out).
+    __shared__ unsigned char sUse[512];
+    __shared__ short sU[512];
+    __shared__ int sNU;
+    for (int idx = t; idx < m * (NA + 1); idx += 1024) { const int k = idx / (NA + 1), c = idx - k * (NA + 1); sH[idx] = a.Hs[(size_t)k * a.NAP + c]; }
+    if (t == 0) sFail = 0;
+    __syncthreads();
+    if (t < NA) {
+        bool nz = false;
+        for (int k = 0; k < m; ++k) nz = nz || sH[(size_t)k * (NA + 1) + t] != 0.0;
+        sUse[t] = nz ? 1 : 0;
+    }
+    __syncthreads();
+    if (t < 64) {   // ascending compaction by one wavefront: ballot + prefix count, 64 columns per step
+        int cnt = 0;
+        for (int base = 0; base < NA; base += 64) {
+            const int c = base + t;
+            const bool use = c < NA && sUse[c] != 0;
+            const unsigned long long mask = __ballot(use);
+            if (use) sU[cnt + __popcll(mask & ((1ull << t) - 1ull))] = (short)c;
+            cnt += __popcll(mask);
+        }
+        if (t == 0) sNU = cnt;
+    }
+    __syncthreads();
+    const int nU = sNU;
+    if (t < n) {   // row t of W = P(:, active) H'^T
+        const double* Pi = a.P + (size_t)t * n + 15;
+        double acc[THIN_MAX_ROWS];
+#pragma unroll
+        for (int k = 0; k < THIN_MAX_ROWS; ++k) acc[k] = 0.0;
+#pragma unroll 8
+        for (int q = 0; q < nU; ++q) {
+            const int c = sU[q];
+            const double pv = Pi[c];
+#pragma unroll
+            for (int k = 0; k < THIN_MAX_ROWS; ++k) if (k < m) acc[k] += pv * sH[(size_t)k * (NA + 1) + c];
+        }
+#pragma unroll
+        for (int k = 0; k < THIN_MAX_ROWS; ++k) if (k < m) sW[(size_t)t * m + k] = acc[k];
+    }
+    __syncthreads();
+    for (int idx = t; idx < m * m; idx += 1024) {   // S = H' W(active rows) + s2 I
+        const int k = idx / m, l = idx - k * m;
+        const double* Hk = sH + (size_t)k * (NA + 1);
+        double s = (k == l) ? a.s2 : 0.0;
+        for (int q = 0; q < nU; ++q) { const int c = sU[q]; s += Hk[c] * sW[(size_t)(15 + c) * m + l]; }
+        sS[idx] = s;
+    }
+    __syncthreads();
+    if (t == 0) {   // Cholesky of the m x m matrix, in place (lower), m <= 16
+        int fail = 0;
+        for (int k = 0; k < m; ++k) {
+            double d = sS[k * m + k];
+            for (int q = 0; q < k; ++q) d -= sS[k * m + q] * sS[k * m + q];
+            if (!(d > 0.0) || !(d - d == 0.0)) { fail = 1; d = 1.0; }
+            const double lk = sqrt(d);
+            sS[k * m + k] = lk;
+            for (int i = k + 1; i < m; ++i) {
+                double v = sS[i * m + k];
+                for (int q = 0; q < k; ++q) v -= sS[i * m + q] * sS[k * m + q];
+                sS[i * m + k] = v / lk;
+            }
+        }
+        sFail = fail;
+        a.info[2] = fail; a.info[3] = 0;
+        a.info[0] = 0; a.info[1] = 0;   // (no factorisation of the prior on this path)
+    }
+    __syncthreads();
+    if (t < n) {   // row t of V = W L^-T: v L^T = w, forward over the columns, in place in LDS (no private arrays: they would live in scratch)
+        double* w = sW + (size_t)t * m;
+        for (int k = 0; k < m; ++k) {
+            double x = w[k];
+            for (int q = 0; q < k; ++q) x -= w[q] * sS[k * m + q];
+            x /= sS[k * m + k];
+            w[k] = x;
+            a.V[(size_t)t * THIN_MAX_ROWS + k] = x;
+        }
+    } else if (t == n) {   // u = L^-1 r, in place in the residual column of sH
+        for (int k = 0; k < m; ++k) {
+            double x = sH[(size_t)k * (NA + 1) + NA];
+            for (int q = 0; q < k; ++q) x -= sS[k * m + q] * sH[(size_t)q * (NA + 1) + NA];
+            x /= sS[k * m + k];
+            sH[(size_t)k * (NA + 1) + NA] = x;
+            a.u[k] = x;
+        }
+    }
+    (void)sFail;
+}
+
+struct ThinApplyArgs {
+    const double* V; const double* u; int m, n;
+    const double* P; double* P_dst; double* dx; int commit;
+    const int* info; const int* info_also;
+    const u32x4* small_src; u32x4* small_dst; size_t small16;
+    int* counter; unsigned long long* seq; unsigned long long* flag;
+};
+__global__ __launch_bounds__(256) void k_thin_apply(ThinApplyArgs a) {
+    __shared__ int sLast, sBad;
+    const int t = threadIdx.x, n = a.n, m = a.m;
+    const bool failed = a.info[2] != 0 || a.info[3] != 0;
+    const bool also = a.info_also && (a.info_also[2] != 0 || a.info_also[3] != 0 || a.info_also[8] != 0);
+    const bool refuse_up = failed || also;
+    const size_t dx0 = 256 / 4, dx1 = dx0 + (((size_t)n * 8 + 255) & ~(size_t)255) / 4;
+    if (blockIdx.x == 0) {   // what the host reads besides dx: info, gamma, accept (written by the launches in front)
+        const unsigned* s4 = reinterpret_cast<const unsigned*>(a.small_src);
+        unsigned* d4p = reinterpret_cast<unsigned*>(a.small_dst);
+        for (size_t i = t; i < a.small16 * 4; i += 256)
+            if (i < dx0 || i >= dx1) d4p[i] = s4[i];
+    }
+    double* dx_host = reinterpret_cast<double*>(reinterpret_cast<char*>(a.small_dst) + 256);
+    const int idx = blockIdx.x * 256 + t;
+    bool wrote_dx = false;
+    if (idx < n * n) {
+        const int i = idx / n, j = idx - i * n;
+        double pv;
+        if (a.commit && refuse_up) pv = a.P[idx];   // (refused: the spare buffer receives the prior as it stands)
+        else {
+            pv = 0.5 * (a.P[idx] + a.P[(size_t)j * n + i]);
+            if (!failed) {
+                double s = 0.0;
+                for (int k = 0; k < m; ++k) s += a.V[(size_t)i * THIN_MAX_ROWS + k] * a.V[(size_t)j * THIN_MAX_ROWS + k];
+                pv -= s;
+            }
+        }
+        a.P_dst[idx] = pv;
+    } else if (idx < n * n + n) {
+        const int i = idx - n * n;
+        double s = 0.0;
+        if (!failed)
+            for (int k = 0; k < m; ++k) s += a.V[(size_t)i * THIN_MAX_ROWS + k] * a.u[k];
+        st_pub<true>(a.dx + i, s);
+        dx_host[i] = s;
+        wrote_dx = true;
+    }
+    const int any_dx = __syncthreads_or(wrote_dx ? 1 : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        if (blockIdx.x == 0 || any_dx) __threadfence_system();   // (host-coherent stores out before this workgroup counts itself in)
+        const int old = __hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sLast = (old == (int)gridDim.x - 1) ? 1 : 0;
+        sBad = 0;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    int bad = 0;
+    for (int i = t; i < n; i += 256) { const double v = ld_pub(a.dx + i); bad |= !(v - v == 0.0); }
+    if (bad) sBad = 1;
+    __syncthreads();
+    if (a.commit && sBad && !refuse_up) {   // non-finite result: the spare buffer gets the prior after all
+        for (size_t i = t; i < (size_t)n * n; i += 256) a.P_dst[i] = a.P[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (t == 0) {
+        __threadfence_system();
+        __hip_atomic_store(a.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long v = atomicAdd(a.seq, 1ull) + 1ull;
+        __hip_atomic_store(a.flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace orcvio_amd

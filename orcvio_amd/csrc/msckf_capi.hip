@@ -317,6 +317,11 @@ struct orcvio_msckf_handle {
     bool finpub_opt = true;             // a feature update's k_finish_sqrt + k_epilogue as ONE launch (k_finish_pub) on the in-place paths (ORCVIO_FINISH_PUB=0, diagnostics)
     FinishPubArgs* fin_pub = nullptr;   // set by io_enqueue around enqueue_update: launch_solve_stage(ST_FINISH) launches k_finish_pub with it
     bool last_finpub_commit = false;    // the update enqueued last committed by writing P+ into the spare covariance buffer: the host swaps d_Pres / d_Ptmp
+    bool thin_opt = true;               // updates of at most THIN_MAX_ROWS projected rows on the in-place paths take the reference's direct form (k_thin_gain / k_thin_apply;
+                                        // ORCVIO_THIN_UPDATE=0, diagnostics): pruneImuStateBuffer's update is a handful of rows
+    double *d_Hthin = nullptr, *d_Vthin = nullptr, *d_uthin = nullptr;   // its projected rows [THIN_MAX_ROWS][NAP_max], V [n_max][THIN_MAX_ROWS], u
+    bool thin_blocked = false;          // orcvio_msckf_update_features with K / G / H_thin requested: those are derived from the general path's factors
+    bool last_update_thin = false;      // the update enqueued last took it: its commit leaves NO square-root factor
     bool step_fused = true;             // ORCVIO_STEP_FUSED=0 (diagnostics build): the frame's small steps as the separate launches and copies of the round-5 calls
     double chi2_prob_cached = -1.0;
 };

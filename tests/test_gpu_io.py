@@ -157,3 +157,71 @@ def test_submit_and_collect_equal_io_update(upd):
     upd.io_submit(want_P=False, commit=True)
     upd.io_collect()
     assert rel(io['dx'], ref['dx']) < 1e-6 and rel(upd.cov_get(), ref['P_new']) < 1e-6
+
+
+@pytest.mark.parametrize('shape', [dict(N=20, F=1, track_len=2), dict(N=20, F=5, track_len=2), dict(N=20, F=4, track_len=3), dict(N=12, F=8, track_len=(2, 3)),
+                                   dict(N=30, F=3, track_len=(2, 4)), dict(N=32, F=6, track_len=2)])
+def test_thin_stack_takes_the_direct_form_and_equals_the_oracle(upd, shape):
+    """A stack of at most sixteen projected rows -- pruneImuStateBuffer's update: one row per feature seen in both clones that leave
+    (reference src/orcvio.cpp:2803-2851) -- is applied in the reference's own direct form (S = H P H^T + s2 I of dimension m,
+    measurementUpdate_msckf without its QR, :1664-1753) instead of the square-root form of dimension n (k_thin_gain / k_thin_apply):
+    same gate decisions, dx and P+ against the oracle; the commit leaves the covariance resident for the next update."""
+    win = synth.make_window(seed=31, outlier_frac=0.0, **shape)
+    ref = _ref(win)
+    rows = int(sum(max(2 * int(m) - 3, 0) for m in np.diff(win.obs_ptr)))
+    assert 0 < rows <= 16
+    upd.cov_set(win.P)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win, with_P=False)
+    stats = upd.io_update(want_P=False, commit=True)
+    assert np.array_equal(io['accept'], ref['accept'])
+    assert np.allclose(io['gamma'], ref['gamma'], rtol=1e-8, equal_nan=True)
+    assert rel(io['dx'], ref['dx']) < 1e-6, rel(io['dx'], ref['dx'])
+    P1 = upd.cov_get()
+    assert rel(P1, ref['P_new']) < 1e-6 and np.array_equal(P1, P1.T)
+    assert stats[2] == int(ref['accept'].sum()) and stats[3] == (1 if ref['accept'].any() else 0)
+    # the same update through the general (square-root) path: with P+ sent to the host the thin form is not taken
+    upd.cov_set(win.P)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win, with_P=False)
+    upd.io_update(want_P=True, commit=False)
+    assert rel(io['dx'], ref['dx']) < 1e-6 and rel(io['P_out'], P1) < 1e-9
+    # ... and the handle goes on from the covariance the thin update committed (no factor is resident: the next update factors P itself)
+    upd.cov_set(P1)
+    win2 = synth.make_window(N=win.N, F=30, seed=32, track_len=(3, 6))
+    import dataclasses
+    win2 = dataclasses.replace(win2, P=P1)
+    io = upd.io_begin(win2.flags, win2.N, win2.F, int(win2.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win2, with_P=False)
+    upd.io_update(want_P=False, commit=True)
+    ref2 = _ref(win2)
+    assert rel(io['dx'], ref2['dx']) < 1e-6 and rel(upd.cov_get(), ref2['P_new']) < 1e-6
+
+
+def test_thin_update_refuses_a_non_finite_prior(upd):
+    """A NaN in the prior where the gate never looks (an IMU row against an extrinsic column: the gate reads the active block only) but
+    the gain does (W = P H^T runs over every row of P): dx comes out non-finite, the launch's last workgroup puts the prior back
+    into the spare buffer, the call reports ORCVIO_ERR_NOT_SPD and the resident covariance is the prior, bit for bit."""
+    win = synth.make_window(N=20, F=4, seed=33, track_len=2)
+    bad = win.P.copy()
+    bad[3, 15] = bad[15, 3] = np.nan
+    upd.cov_set(bad)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win, with_P=False)
+    with pytest.raises(capi.MsckfError) as e:
+        upd.io_update(want_P=False, commit=True)
+    assert e.value.code == 6
+    assert np.array_equal(upd.cov_get(), bad, equal_nan=True)
+    # ... and a NaN the gate does see rejects the tracks: no update, the covariance stays what it was
+    bad = win.P.copy()
+    bad[25, 25] = np.nan
+    upd.cov_set(bad)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win, with_P=False)
+    try:
+        stats = upd.io_update(want_P=False, commit=True)
+        assert stats[3] == 0 or np.isfinite(io['dx']).all()
+    except capi.MsckfError as e2:
+        assert e2.code == 6
+    got = upd.cov_get()
+    assert np.array_equal(np.isnan(got), np.isnan(bad))
