@@ -632,6 +632,8 @@ int32_t orcvio_msckf_io_update_frame(orcvio_msckf_handle* h, orcvio_msckf_result
  *                    skipped when discard_large_update discards dx) -- what the reference's state is when pruneImuStateBuffer runs;
  *                    0: the same poses as the first update (the caller's state increment does not reach into this call)
  *   remove_clones    window indices (ascending) of the clones marginalised at the end; n_remove <= 8
+ * Not in this call: features ENTERING the state (orcvio_msckf_upload_new_features / _cov_commit_new_features change the state's dimension
+ * between the updates: such frames take the separate calls), Schmidt nuisance poses, a communicator on the handle.
  * Results: pointers into the handle's pinned output blocks, valid until the next call on the handle that takes tracks.
  * Status: a validation failure returns its code with NOTHING done.  A refusal on the device (ORCVIO_ERR_NOT_SPD: M not positive definite or
  * non-finite input) of the first update refuses the second as well; the covariance bookkeeping of the frame (propagation, augmentation,

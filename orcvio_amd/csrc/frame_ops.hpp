@@ -261,8 +261,8 @@ __global__ __launch_bounds__(64) void k_ekf_evalgate(EkfEvalArgs e, int do_eval,
 //              by the workgroup that arrives last: it rewrites both buffers with the prior (never on sane input).
 //   publish    the workgroup that arrives last (a device counter behind an agent-scope fence) copies the small result block
 //              [info | dx | gamma | accept] into host-coherent memory and raises the flag word the calling thread spins on.
-//   P_host     (optional, want_P) P+ also goes tile by tile into the pinned output block: the mirrored half through an LDS transpose so
-//              that both halves leave as 128-byte rows.
+// Not with P+ to the host (want_P): the tiles written one by one into the pinned block measured SLOWER than k_epilogue's forty copy
+// workgroups behind k_finish_sqrt (13.3 against 5.2 + 6.3 us, profiles/r6a): that form keeps the two launches.
 struct FinishPubArgs {
     const double* Z; int ldz, n, kdim; double s2;
     const double* P;        // the prior
@@ -271,13 +271,11 @@ struct FinishPubArgs {
     int commit;             // 0: none (k_finish_sqrt's semantics), 1: P+ only, 2: P+ and the factor
     double sigma; const double* prior; long sLi, sLj; double* Sout; int ldo;
     const int* info; const int* info_also;
-    double* P_host;         // pinned output block (want_P) or nullptr
     const u32x4* small_src; u32x4* small_dst; size_t small16;
     int* counter; unsigned long long* seq; unsigned long long* flag;
 };
 __global__ __launch_bounds__(256) void k_finish_pub(FinishPubArgs a) {
     __shared__ double sPart[3][4][64];
-    __shared__ double sTr[16][17];
     __shared__ int sLast, sBad;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, t = threadIdx.x;
     const int n = a.n, kdim = a.kdim, ldz = a.ldz;
@@ -319,21 +317,11 @@ __global__ __launch_bounds__(256) void k_finish_pub(FinishPubArgs a) {
                 } else pv = pm = app ? a.s2 * v : 0.5 * (a.P[(size_t)i * n + jj] + a.P[(size_t)jj * n + i]);
                 a.P_dst[(size_t)i * n + jj] = pv;
                 a.P_dst[(size_t)jj * n + i] = pm;
-                if (a.P_host) a.P_host[(size_t)i * n + jj] = pv;
             } else if (i == n && jj < n) {
                 const double d = app ? v : 0.0;
                 st_pub<true>(a.dx + jj, d);   // (read back by the workgroup that arrives last: past the caches)
                 dx_host[jj] = d;
             }
-            if (a.P_host) sTr[kk + 4 * r][cc] = pm;   // (row kk + 4r, column cc of the tile: transposed below)
-        }
-    }
-    if (a.P_host) {   // the mirrored half of the tile, row by row
-        __syncthreads();
-        {
-            const int rr = t >> 4, c2 = t & 15;   // 256 threads: element (rr, c2) of the TRANSPOSED tile
-            const int i = 16 * bj + rr, jj = 16 * bi + c2;
-            if ((bi > bj || rr < c2) && i < n && jj < n) a.P_host[(size_t)i * n + jj] = sTr[c2][rr];   // (a diagonal tile: its strict upper part)
         }
     }
     if (a.commit == 2) {   // this workgroup's share of the factor
@@ -347,9 +335,9 @@ __global__ __launch_bounds__(256) void k_finish_pub(FinishPubArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-        // (a workgroup that stored to host memory -- P_host tiles, dx, the first workgroup's block -- makes those stores visible at system
+        // (a workgroup that stored to host memory -- dx, the first workgroup's block -- makes those stores visible at system
         //  scope before it counts itself in, as k_epilogue's workgroups do: the flag must not overtake them on another path of the fabric)
-        if (a.P_host || blockIdx.x == 0 || 16 * bi + 15 >= n) __threadfence_system();
+        if (blockIdx.x == 0 || 16 * bi + 15 >= n) __threadfence_system();
         const int old = __hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sLast = (old == (int)gridDim.x - 1) ? 1 : 0;
         sBad = 0;
