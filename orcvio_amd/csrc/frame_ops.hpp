@@ -54,7 +54,7 @@ __device__ __forceinline__ void dev_mat3_mul(const double* A, const double* B, d
 struct PoseStepArgs { const double* src; double* dst; int N, stride; const double* dx; int leg, apply, left, discard_large; const int* info; int* keep; };
 __device__ __forceinline__ void pose_step_body(const double* __restrict__ src, double* __restrict__ dst, int N, int stride, const double* __restrict__ dx,
                                                int leg, int apply, int left, int discard_large, const int* __restrict__ info, int* __restrict__ keep, const int c) {
-    if (c < 16 && keep) keep[c] = info[c];
+    if (c < 16 && keep) keep[c] = info ? info[c] : 0;   // (info == nullptr: the frame had no first update)
     if (c >= N) return;
     double r[28];
     for (int i = 0; i < 28; ++i) r[i] = src[(size_t)c * stride + i];

@@ -244,3 +244,96 @@ def test_the_folded_launches_equal_the_separate_ones_bit_for_bit(built, monkeypa
             assert same(a.cov_get(), b.cov_get()), it
     finally:
         a.close(); b.close()
+
+
+def test_step_frame_without_a_first_update_and_without_propagation(built):
+    """Frames the reference meets at start-up and on quiet images: no lost feature and no in-state feature (removeLostFeatures returns
+    before any arithmetic) -- the covariance bookkeeping and the prune update are the whole frame; and a frame without propagation
+    (Phi == NULL: augmentation alone, the resident factor's rows copied along).  Against the separate calls, bit for bit."""
+    import dataclasses
+    fl = synth.Flags(use_larvio=1)
+    frames, P0 = synth.make_stream(fl)
+    a, b = _handle(), _handle()
+    try:
+        a.cov_set(P0); b.cov_set(P0)
+        fr0, fr1 = frames[0], frames[1]
+        empty = lambda w: dataclasses.replace(w, p_w=w.p_w[:0].copy(), obs_ptr=np.zeros(1, np.int32), obs_clone=w.obs_clone[:0].copy(),
+                                              obs_z=w.obs_z[:0].copy(), obs_zvel=w.obs_zvel[:0].copy())
+        # frame 0: nothing to update at all
+        a.cov_propagate(fr0['Phi'], fr0['Q']); a.cov_augment()
+        got = b.io_step_frame(empty(fr0['w']), fr0['Phi'], fr0['Q'], True, None, IDP, None, False, [])
+        assert got['rc'] == 0 and got['stats'][3] == 0 and not np.any(got['dx']) and got['n_after'] == P0.shape[0] + 6
+        assert np.array_equal(a.cov_get(), b.cov_get())
+        # frame 1: no first update, but the prune update and the marginalisation
+        a.cov_propagate(fr1['Phi'], fr1['Q']); a.cov_augment()
+        p = fr1['prune']
+        io = a.io_begin(p.flags, p.N, p.F, int(p.obs_ptr[-1]), with_P=False)
+        a.io_fill(io, p, with_P=False)
+        a.io_update(want_P=False, commit=True)
+        ref_dx = io['dx'].copy()
+        a.cov_remove_clones(LEG, fr1['remove'])
+        got = b.io_step_frame(empty(fr1['w']), fr1['Phi'], fr1['Q'], True, None, IDP, p, True, fr1['remove'])
+        assert got['rc'] == 0 and got['stats'][3] == 0 and got['prune_stats'][3] == 1
+        assert np.array_equal(got['prune_dx'], ref_dx)
+        assert np.array_equal(a.cov_get(), b.cov_get())
+        # frame 2: augmentation without propagation, behind an update that left its factor resident (frame 0's window, 19 clones)
+        fr2 = frames[2]
+        for u in (a, b):   # (an update that commits a square-root factor: the tracks of frame 2 on the 18-clone window would not fit; use the augment-only call first)
+            pass
+        a.cov_augment()
+        io = a.io_begin(fr2['w'].flags, fr2['w'].N, fr2['w'].F, int(fr2['w'].obs_ptr[-1]), with_P=False)
+        a.io_fill(io, fr2['w'], with_P=False)
+        a.make_slam_call(IDP, fr2['slam'])()
+        a.io_update(want_P=False, commit=True)
+        ref_dx = io['dx'].copy()
+        got = b.io_step_frame(fr2['w'], None, None, True, fr2['slam'], IDP, None, False, [])
+        assert got['rc'] == 0 and np.array_equal(got['dx'], ref_dx)
+        assert np.array_equal(a.cov_get(), b.cov_get())
+        # ... and once more without propagation, now WITH the resident factor of that update: its rows are copied along
+        fr3 = frames[3]
+        a.cov_augment()
+        io = a.io_begin(fr3['w'].flags, fr3['w'].N, fr3['w'].F, int(fr3['w'].obs_ptr[-1]), with_P=False)
+        a.io_fill(io, fr3['w'], with_P=False)
+        a.make_slam_call(IDP, fr3['slam'])()
+        a.io_update(want_P=False, commit=True)
+        ref_dx = io['dx'].copy()
+        got = b.io_step_frame(fr3['w'], None, None, True, fr3['slam'], IDP, None, False, [])
+        assert got['rc'] == 0 and np.array_equal(got['dx'], ref_dx)
+        assert np.array_equal(a.cov_get(), b.cov_get())
+    finally:
+        a.close(); b.close()
+
+
+def test_step_frame_with_imu_intrinsics_in_the_state(built):
+    """leg_dim 46 (calib_imu_instrinsic, reference src/orcvio.cpp:196-199): k_frame_head's other instantiation -- against the
+    separate calls, bit for bit."""
+    fl = synth.Flags(use_larvio=1, leg_dim=46)
+    frames, P0 = synth.make_stream(fl, leg=46)
+    a, b = _handle(), _handle()
+    try:
+        a.cov_set(P0); b.cov_set(P0)
+        for it in range(6):
+            fr = frames[it % len(frames)]
+            w = fr['w']
+            a.cov_propagate(fr['Phi'], fr['Q']); a.cov_augment()
+            io = a.io_begin(w.flags, w.N, w.F, int(w.obs_ptr[-1]), with_P=False)
+            a.io_fill(io, w, with_P=False)
+            a.make_slam_call(IDP, fr['slam'])()
+            a.io_update(want_P=False, commit=True)
+            ref = io['dx'].copy()
+            ref2 = None
+            if fr['prune'] is not None:
+                p = fr['prune']
+                io = a.io_begin(p.flags, p.N, p.F, int(p.obs_ptr[-1]), with_P=False)
+                a.io_fill(io, p, with_P=False)
+                a.io_update(want_P=False, commit=True)
+                ref2 = io['dx'].copy()
+            if fr['remove']:
+                a.cov_remove_clones(46, fr['remove'])
+            got = b.io_step_frame(w, fr['Phi'], fr['Q'], True, fr['slam'], IDP, fr['prune'], False, fr['remove'])
+            assert got['rc'] == 0 and np.array_equal(got['dx'], ref), it
+            if ref2 is not None:
+                assert np.array_equal(got['prune_dx'], ref2), it
+            assert np.array_equal(a.cov_get(), b.cov_get()), it
+    finally:
+        a.close(); b.close()
