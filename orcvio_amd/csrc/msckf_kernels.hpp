@@ -826,8 +826,8 @@ __device__ __forceinline__ void feature_body(const FeatArgs& p, const int j, con
     }
 }
 
-template <int NPASS>
-__global__ __launch_bounds__(256, 2) void k_feature(FeatArgs p) {
+template <int NPASS>   // (windows beyond 33 clones, NPASS >= 5: one workgroup per CU -- 512 registers per lane instead of 256: no scratch; their E tile fills the LDS anyway)
+__global__ __launch_bounds__(256, NPASS >= 5 ? 1 : 2) void k_feature(FeatArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     feature_body<NPASS>(p, blockIdx.x, threadIdx.x, smem);
 }

@@ -225,3 +225,28 @@ def test_thin_update_refuses_a_non_finite_prior(upd):
         assert e2.code == 6
     got = upd.cov_get()
     assert np.array_equal(np.isnan(got), np.isnan(bad))
+
+
+def test_explicit_commit_behind_a_thin_update(upd):
+    """io_update WITHOUT the commit in the launch, then orcvio_msckf_cov_commit: behind the direct form of a thin stack there is no
+    square-root factor to keep (no Z): the commit keeps P+ only and the next update factors it -- against the oracle."""
+    import dataclasses
+    win = synth.make_window(N=20, F=5, seed=41, track_len=2)
+    ref = _ref(win)
+    upd.cov_set(win.P)
+    io = upd.io_begin(win.flags, win.N, win.F, int(win.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win, with_P=False)
+    upd.io_update(want_P=False, commit=False)
+    assert rel(io['dx'], ref['dx']) < 1e-6
+    upd.cov_commit()
+    P1 = upd.cov_get()
+    assert rel(P1, ref['P_new']) < 1e-6
+    win2 = dataclasses.replace(synth.make_window(N=20, F=40, seed=42, track_len=(3, 6)), P=P1)
+    ref2 = _ref(win2)
+    io = upd.io_begin(win2.flags, win2.N, win2.F, int(win2.obs_ptr[-1]), with_P=False)
+    upd.io_fill(io, win2, with_P=False)
+    upd.io_update(want_P=False, commit=True)
+    assert rel(io['dx'], ref2['dx']) < 1e-6 and rel(upd.cov_get(), ref2['P_new']) < 1e-6
+    # the copying call with the optional outputs asked for takes the square-root path (they are derived from its factors)
+    got = upd.update_features(win, want_G=True)
+    assert rel(got['dx'], ref['dx']) < 1e-6 and rel(got['G'], ref['G']) < 1e-6
