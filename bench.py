@@ -763,7 +763,9 @@ def main():
             pm_doc = json.load(open(pm_path))
             pm = pm_doc['kernels']
             lib_now = hashlib.sha256(open(capi.LIB_PATH, 'rb').read()).hexdigest()[:16]
-            if pm_doc.get('build') != lib_now:   # counters of ANOTHER build say nothing about this one: traffic stays null
+            pm_build = pm_doc.get('build')
+            pm_sha = pm_build.get('liborcvio_msckf_sha16') if isinstance(pm_build, dict) else pm_build
+            if pm_sha != lib_now:   # counters of ANOTHER build say nothing about this one: traffic stays null
                 traffic_source = dict(file=os.path.relpath(pm_path, ROOT), build=pm_doc.get('build'), measured_in_this_run=False,
                                       refused='taken on another build of the library (this one: %s)' % lib_now)
                 raise LookupError('stale pmc profile')
