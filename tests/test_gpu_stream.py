@@ -337,3 +337,14 @@ def test_step_frame_with_imu_intrinsics_in_the_state(built):
             assert np.array_equal(a.cov_get(), b.cov_get()), it
     finally:
         a.close(); b.close()
+
+
+def test_a_slice_of_the_randomised_soak(built):
+    """scripts/gpu_soak_step.py for a few seconds: random flags / leg_dim / window sizes / track counts (none .. 250, sometimes all
+    outliers), prune updates in the direct form and through the square-root path, frames without propagation or augmentation,
+    the state increment on the device -- every dx, accept mask and covariance against the host chain (C oracle + numpy mirrors)."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'gpu_soak_step.py'), '8', '4242'], capture_output=True, text=True, timeout=300)
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and rec['failures'] == 0 and rec['frames'] > 50, rec
+    assert rec['worst']['dx'] < 1e-6 and rec['worst']['P'] < 1e-6
