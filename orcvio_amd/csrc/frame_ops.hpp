@@ -441,25 +441,28 @@ __global__ __launch_bounds__(1024) void k_thin_gain(ThinGainArgs a) {
         sS[idx] = s;
     }
     __syncthreads();
-    if (t == 0) {   // Cholesky of the m x m matrix, in place (lower), m <= 16
-        int fail = 0;
-        for (int k = 0; k < m; ++k) {
-            double d = sS[k * m + k];
-            for (int q = 0; q < k; ++q) d -= sS[k * m + q] * sS[k * m + q];
-            if (!(d > 0.0) || !(d - d == 0.0)) { fail = 1; d = 1.0; }
-            const double lk = sqrt(d);
-            sS[k * m + k] = lk;
-            for (int i = k + 1; i < m; ++i) {
-                double v = sS[i * m + k];
-                for (int q = 0; q < k; ++q) v -= sS[i * m + q] * sS[k * m + q];
-                sS[i * m + k] = v / lk;
-            }
+    // Cholesky of the m x m matrix, in place (lower), right-looking, the whole workgroup: per pivot the column scaled by m threads,
+    // the trailing block updated by m x m (thread 0 alone -- FP64 sqrt and divide in one dependent chain -- took 4.5 us at m = 5)
+    for (int k = 0; k < m; ++k) {
+        const double d = sS[k * m + k];
+        const bool badp = !(d > 0.0) || !(d - d == 0.0);
+        const double lk = sqrt(badp ? 1.0 : d);
+        double lik = 0.0;
+        if (t > k && t < m) lik = sS[t * m + k] / lk;
+        __syncthreads();   // (every thread has read the pivot and its column entry)
+        if (t == k) { sS[k * m + k] = lk; if (badp) sFail = 1; }
+        if (t > k && t < m) sS[t * m + k] = lik;
+        __syncthreads();
+        if (t < m * m) {
+            const int i = t / m, j = t - i * m;
+            if (i > k && j > k && j <= i) sS[i * m + j] -= sS[i * m + k] * sS[j * m + k];
         }
-        sFail = fail;
-        a.info[2] = fail; a.info[3] = 0;
+        __syncthreads();
+    }
+    if (t == 0) {
+        a.info[2] = sFail; a.info[3] = 0;
         a.info[0] = 0; a.info[1] = 0;   // (no factorisation of the prior on this path)
     }
-    __syncthreads();
     if (t < n) {   // row t of V = W L^-T: v L^T = w, forward over the columns, in place in LDS (no private arrays: they would live in scratch)
         double* w = sW + (size_t)t * m;
         for (int k = 0; k < m; ++k) {
@@ -478,7 +481,6 @@ __global__ __launch_bounds__(1024) void k_thin_gain(ThinGainArgs a) {
             a.u[k] = x;
         }
     }
-    (void)sFail;
 }
 
 struct ThinApplyArgs {
