@@ -238,12 +238,24 @@ __global__ __launch_bounds__(256) void k_cov_remove_fac(const double* __restrict
 }
 
 
+// ---- one wavefront that waits for a word: the launches enqueued behind it on ITS stream start once another stream has reached the
+// point the word stands for (k_front's first instruction stores it: the frame head in front of k_front is complete).  The kernel
+// boundary behind this launch is the acquire; bounded like every wait on the device (the update is flagged and run again).
+__global__ __launch_bounds__(64) void k_wait_word(const unsigned* __restrict__ word, unsigned expect, int spin_limit, int* __restrict__ lost) {
+    if (threadIdx.x != 0) return;
+    int it = 0;
+    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0 && it < spin_limit) { __builtin_amdgcn_s_sleep(8); ++it; }
+    if (it >= spin_limit) atomicAdd(lost, 1);
+}
+
 // ---- the rows of the in-state features: k_ekf_eval + (fill) + k_ekf_gate of ekf_rows.hpp in ONE launch ---------------------------------
 // A wavefront per feature: lane 0 evaluates the four blocks (measurementJacobian_ekf_{3,1}didp), the wavefront clears the feature's two
 // dense rows, gates the row pair against the prior (2 degrees of freedom, src/orcvio.cpp:2457) and writes them if accepted.  The
 // bodies are the separate kernels': the same bits.  k_gram of the dense rows follows as before.
-__global__ __launch_bounds__(64) void k_ekf_evalgate(EkfEvalArgs e, int do_eval, EkfGateArgs g) {
+// bail: optional word (the update's lost-hand-off counter) -- behind a wait that gave up the records may not be there yet: nothing is touched.
+__global__ __launch_bounds__(64) void k_ekf_evalgate(EkfEvalArgs e, int do_eval, EkfGateArgs g, const int* __restrict__ bail) {
     const int f = blockIdx.x, l = threadIdx.x;
+    if (bail && __hip_atomic_load(bail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     for (int i = l; i < 2 * g.NAP; i += 64) g.E[(size_t)2 * f * g.NAP + i] = 0.0;
     if (do_eval && l == 0) ekf_eval_body(e, f);
     __syncthreads();   // (one wavefront: the stores of lane 0 and of the fill are out before the gate reads / writes)

@@ -323,6 +323,14 @@ struct orcvio_msckf_handle {
     bool thin_blocked = false;          // orcvio_msckf_update_features with K / G / H_thin requested: those are derived from the general path's factors
     bool last_update_thin = false;      // the update enqueued last took it: its commit leaves NO square-root factor
     bool step_fused = true;             // ORCVIO_STEP_FUSED=0 (diagnostics build): the frame's small steps as the separate launches and copies of the round-5 calls
+    // the frame call's in-state rows beside k_front (enqueue_update): k_wait_word -> k_ekf_evalgate -> k_gram -> k_obj_done on `side`, joined
+    // by two polled words (d_step_words[32]: k_front has started = the frame head is complete; [33]: the rows' Gram is complete, k_gemm_asmA_w)
+    bool ekf_side_opt = true;           // ORCVIO_STEP_EKF_SIDE=0 (diagnostics build): the rows on the update's own stream, in front of k_front
+    bool ekf_side_now = false;          // set by orcvio_msckf_io_step_frame around its first update
+    bool ekf_side_used = false;         // the frame being enqueued has work on `side` (a repair drains it)
+    unsigned ekf_side_seq = 0;
+    unsigned* front_mark = nullptr; unsigned front_mark_val = 0;       // launch_front: FrontGramArgs.started
+    const unsigned* asm_wait = nullptr; unsigned asm_wait_val = 0;     // launch_solve_stage(ST_FORM_U): k_gemm_asmA_w
     double chi2_prob_cached = -1.0;
 };
 

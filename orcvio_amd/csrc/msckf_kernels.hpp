@@ -1841,10 +1841,13 @@ struct AsmArgs {
 // (sA: 16 x 193, sPartF: 3 x 4 x 64, sSharedF: 4 x 64 doubles).  PUB: the Grams, the clone tiles and B were stored by other workgroups
 // of THIS launch (k_front with the product inside, FrontUArgs): read past the caches.  !active: the barriers only (no store).
 constexpr int ASM_LDS_DOUBLES = 16 * 193 + 3 * 4 * 64 + 4 * 64;
-template <bool PUB>
+// PLUSW: aa.plus is being written by ANOTHER stream (k_gemm_asmA_w): its loads stand behind a poll of the completion word `wait`, issued
+// once every other load of the strip is in flight, and go past the caches (agent-scope loads: no acquire fence, nothing else is re-read).
+template <bool PUB, bool PLUSW = false>
 __device__ __forceinline__ void asm_gemm_tile(const AsmArgs& aa, const double* __restrict__ B, long sBk, long sBj, int M, int Nc, int K,
                                               double* __restrict__ C, long sCi, long sCj, const int tile_index, const bool active, const int tid,
-                                              double* __restrict__ sA, double* __restrict__ sPartF, double* __restrict__ sSharedF) {
+                                              double* __restrict__ sA, double* __restrict__ sPartF, double* __restrict__ sSharedF,
+                                              const unsigned* __restrict__ wait = nullptr, unsigned expect = 0u, int spin_limit = 0, int* __restrict__ lost = nullptr) {
     constexpr int KMAX = 192, LDA = KMAX + 1;   // (193: one row per lane group without bank conflicts)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int kk = l >> 4, cc = l & 15;
@@ -1925,7 +1928,26 @@ __device__ __forceinline__ void asm_gemm_tile(const AsmArgs& aa, const double* _
             for (int u = 0; u < 4; ++u)
                 if (u < aa.nparts) gv[rr][j][u] = ld_sel<PUB>(aa.parts + (size_t)u * aa.stride + src);   // (wave-uniform count and base)
             pv[rr][j] = 0.0;
-            if (aa.plus) pv[rr][j] = aa.plus[((ic >> 4) >= (int)(kc >> 4)) ? src : kc * (unsigned)aa.NAP + (unsigned)ic];
+            if (!PLUSW && aa.plus) pv[rr][j] = aa.plus[((ic >> 4) >= (int)(kc >> 4)) ? src : kc * (unsigned)aa.NAP + (unsigned)ic];
+        }
+    }
+    if constexpr (PLUSW) {
+        if (tid == 0) {
+            int it = 0;
+            while ((int)(__hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0 && it < spin_limit) { __builtin_amdgcn_s_sleep(4); ++it; }
+            if (it >= spin_limit) atomicAdd(lost, 1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 16 * bi + wave + 4 * rr;
+            const unsigned ic = i < M ? (unsigned)i : 0u;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int k = l + 64 * j;
+                const unsigned kc = k < K ? (unsigned)k : 0u;
+                pv[rr][j] = ld_pub(aa.plus + (((ic >> 4) >= (kc >> 4)) ? ic * (unsigned)aa.NAP + kc : kc * (unsigned)aa.NAP + ic));
+            }
         }
     }
     if (PUB || has_shared) __syncthreads();   // (workgroup-uniform in k_gemm_asmA: one tile per workgroup; the two teams of k_front hold different tiles)
@@ -2130,6 +2152,18 @@ __global__ __launch_bounds__(256) void k_gemm_asmA(AsmArgs aa, const double* __r
     }
 }
 
+// k_gemm_asmA behind a completion word: the Gram of the in-state features' rows (aa.plus) is formed on ANOTHER stream while k_front
+// runs (orcvio_msckf_io_step_frame, capi_step.inc) and a one-word launch behind it stores the frame's sequence number; every workgroup
+// polls the word (bounded: a wait that gives up flags the update, which is then run again in separate launches) once its other loads
+// are in flight and reads that Gram past the caches; the shared body -- the same arithmetic as k_gemm_asmA, the same bits.
+__global__ __launch_bounds__(256) void k_gemm_asmA_w(AsmArgs aa, const double* __restrict__ B, long sBk, long sBj, int M, int Nc, int K,
+                                                     double* __restrict__ C, long sCi, long sCj, const unsigned* __restrict__ wait, unsigned expect,
+                                                     int spin_limit, int* __restrict__ lost) {
+    __shared__ double sU[ASM_LDS_DOUBLES];
+    asm_gemm_tile<false, true>(aa, B, sBk, sBj, M, Nc, K, C, sCi, sCj, (int)blockIdx.x, true, (int)threadIdx.x, sU, sU + 16 * 193, sU + 16 * 193 + 768,
+                               wait, expect, spin_limit, lost);
+}
+
 // ---------------------------------------------------------------------------------------
 // k_front: the two independent front ends of the update in ONE launch -- workgroup 0 factors the prior
 // (potrf_reg_body, depends on P only), every other workgroup runs two feature tracks (feature_body, one
@@ -2158,6 +2192,8 @@ struct FrontGramArgs {
     double* A_dst; int cb0;
     const double* plus;           // optional Gram added to A (EKF-SLAM rows), lower tiles valid
     int spin_limit;               // polls of the flag line before a waiting workgroup gives up (a few tens of ms)
+    unsigned* started;            // optional: workgroup 0 stores started_val here with its first instruction -- "everything enqueued in front
+    unsigned started_val;         //   of this launch is complete", read by a wait launch on another stream (the frame call's in-state rows)
 };
 // U = [A; b^T] L_a inside the launch (g.enabled == 3): behind the Grams and a second device-wide barrier, every team takes one tile of U
 // with k_gemm_asmA's body -- same arithmetic, same bits -- as soon as the prior's factorisation has published the block row of R the
@@ -2198,6 +2234,7 @@ template <int NPASS, int NSLOT, bool WITH_U = false>   // WITH_U: the instantiat
 __global__ __launch_bounds__(512) void k_front(FeatArgs p, FrontPotrfArgs q, int team_doubles, FrontGramArgs g, FrontUArgs u) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (blockIdx.x == 0) {
+        if (g.started && threadIdx.x == 0) __hip_atomic_store(g.started, g.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (q.skip) return;
         if (g.enabled && threadIdx.x == 0) (reinterpret_cast<unsigned long long*>(g.counter) + 8)[0] = wall_clock64();
         if (WITH_U && q.nfar > 0 && g.enabled == 3) {   // (the feature workgroups read the step counter until their tiles of U are out)

@@ -182,17 +182,19 @@ def test_step_frame_refusal_of_the_first_update_refuses_the_second(built):
         a.close(); b.close()
 
 
-def test_step_frame_repairs_a_lost_hand_off(built, monkeypatch):
+@pytest.mark.parametrize('spin', ['ORCVIO_LA_SPIN', 'ORCVIO_FRONT_SPIN'])
+def test_step_frame_repairs_a_lost_hand_off(built, monkeypatch, spin):
     """ORCVIO_LA_SPIN = 0: every wait of the look-ahead factorisation on another workgroup gives up at once -- each update of each
     frame flags itself and refuses its commit on the device (and the second update with the first).  The call takes the
     marginalisation back, runs the lost updates again in separate launches (the one-workgroup factorisation, the outcome checked by
-    the host) and marginalises: the same filter as the separate calls on an undisturbed handle."""
+    the host) and marginalises: the same filter as the separate calls on an undisturbed handle.  ORCVIO_FRONT_SPIN = 0: the waits of
+    k_front's device-wide counter and the two words that join the in-state rows' side stream (k_wait_word, k_gemm_asmA_w) give up instead."""
     fl = synth.Flags(use_larvio=1)
     frames, P0 = synth.make_stream(fl)
     a = _handle()
-    monkeypatch.setenv('ORCVIO_LA_SPIN', '0')
+    monkeypatch.setenv(spin, '0')
     b = _handle()
-    monkeypatch.delenv('ORCVIO_LA_SPIN')
+    monkeypatch.delenv(spin)
     try:
         a.cov_set(P0); b.cov_set(P0)
         repaired = 0
@@ -214,12 +216,13 @@ def test_step_frame_repairs_a_lost_hand_off(built, monkeypatch):
         a.close(); b.close()
 
 
-@pytest.mark.parametrize('off', ['ORCVIO_STEP_FUSED', 'ORCVIO_FINISH_PUB', 'ORCVIO_EKF_ONE_LAUNCH', 'all', 'ORCVIO_THIN_UPDATE'])
+@pytest.mark.parametrize('off', ['ORCVIO_STEP_FUSED', 'ORCVIO_FINISH_PUB', 'ORCVIO_EKF_ONE_LAUNCH', 'ORCVIO_STEP_EKF_SIDE', 'all', 'ORCVIO_THIN_UPDATE'])
 def test_the_folded_launches_equal_the_separate_ones_bit_for_bit(built, monkeypatch, off):
     """k_frame_head / k_cov_remove_fac (ORCVIO_STEP_FUSED), k_finish_pub (ORCVIO_FINISH_PUB) and k_ekf_evalgate (ORCVIO_EKF_ONE_LAUNCH) each
     switched off in the diagnostics build -- the frame then runs the separate launches and copies of the round-5 calls, enqueued at
     once -- against the default: the same dx, the same covariance, bit for bit.  (The direct form of a thin stack rides on
-    k_finish_pub's publication, so both sides run without it where that launch is switched off.)  ORCVIO_THIN_UPDATE = 0 alone: the
+    k_finish_pub's publication, so both sides run without it where that launch is switched off.)  ORCVIO_STEP_EKF_SIDE = 0: the in-state
+    features' rows in front of k_front on the update's own stream instead of beside it on the side stream.  ORCVIO_THIN_UPDATE = 0 alone: the
     prune update through the general square-root path instead of the direct form -- another algorithm for the same update: equal to
     rounding."""
     fl = synth.Flags(use_larvio=1)
@@ -228,7 +231,7 @@ def test_the_folded_launches_equal_the_separate_ones_bit_for_bit(built, monkeypa
     if off in ('ORCVIO_FINISH_PUB', 'all'):
         monkeypatch.setenv('ORCVIO_THIN_UPDATE', '0')
     a = _handle(debug_hooks=True)
-    for name in (['ORCVIO_STEP_FUSED', 'ORCVIO_FINISH_PUB', 'ORCVIO_EKF_ONE_LAUNCH'] if off == 'all' else [off]):
+    for name in (['ORCVIO_STEP_FUSED', 'ORCVIO_FINISH_PUB', 'ORCVIO_EKF_ONE_LAUNCH', 'ORCVIO_STEP_EKF_SIDE'] if off == 'all' else [off]):
         monkeypatch.setenv(name, '0')
     b = _handle(debug_hooks=True)
     same = (lambda x, y: rel(x, y) < 1e-9) if thin_cmp else (lambda x, y: np.array_equal(x, y, equal_nan=True))
