@@ -393,6 +393,8 @@ __global__ __launch_bounds__(256) void k_finish_pub(FinishPubArgs a) {
 // S is s2 I plus a positive semi-definite matrix: well conditioned whatever the prior's rank; a non-positive or non-finite pivot
 // (non-finite input) refuses the update (info[2]: P+ = P, dx = 0), as the general path's chol(M) does.
 #define THIN_MAX_ROWS 16
+#define THIN_CHUNK 32
+__host__ __device__ inline size_t thin_gain_lds_doubles(int m, int NA, int n) { return (size_t)m * (NA + 1) + (size_t)n * m + (size_t)m * m + (size_t)n * (THIN_CHUNK + 1); }
 struct ThinGainArgs { const double* Hs; int m, NAP, NA, n; const double* P; double s2; double* V; double* u; int* info; };
 __global__ __launch_bounds__(1024) void k_thin_gain(ThinGainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sThin[];
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(1024) void k_thin_gain(ThinGainArgs a) {
     double* sH = sThin;                       // [m][NA + 1]  (the residual in column NA)
     double* sW = sH + (size_t)m * (NA + 1);   // [n][m]
     double* sS = sW + (size_t)n * m;          // [m][m] -> its lower Cholesky factor
+    double* sP = sS + (size_t)m * m;          // [n][THIN_CHUNK + 1]  the entries of P of the current chunk of columns
     __shared__ int sFail;
     // the columns ANY row touches, ascending: a projected row has non-zeros in the extrinsic columns and the clones of its track, and
     // pruneImuStateBuffer's tracks all sit on the two clones that leave -- ~20 of NA columns.  The products below run over this list
@@ -429,20 +432,34 @@ __global__ __launch_bounds__(1024) void k_thin_gain(ThinGainArgs a) {
     }
     __syncthreads();
     const int nU = sNU;
-    if (t < n) {   // row t of W = P(:, active) H'^T
-        const double* Pi = a.P + (size_t)t * n + 15;
+    // W = P(:, active) H'^T, row t by thread t.  The entries of P it needs are brought into LDS by the WHOLE workgroup first, 32 columns
+    // of the list at a time: n x 32 independent loads in flight together = one round trip to memory per chunk (a thread walking its own
+    // row eight loads at a time paid four round trips of ~2 us each: P was written by the launch in front, on other compute units).
+    {
         double acc[THIN_MAX_ROWS];
 #pragma unroll
         for (int k = 0; k < THIN_MAX_ROWS; ++k) acc[k] = 0.0;
-#pragma unroll 8
-        for (int q = 0; q < nU; ++q) {
-            const int c = sU[q];
-            const double pv = Pi[c];
+        for (int q0 = 0; q0 < nU; q0 += THIN_CHUNK) {
+            const int nc = nU - q0 < THIN_CHUNK ? nU - q0 : THIN_CHUNK;
+            if (q0 > 0) __syncthreads();
+            for (int idx = t; idx < n * nc; idx += 1024) {
+                const int i = idx / nc, q = idx - i * nc;
+                sP[i * (THIN_CHUNK + 1) + q] = a.P[(size_t)i * n + 15 + sU[q0 + q]];
+            }
+            __syncthreads();
+            if (t < n) {
+                for (int q = 0; q < nc; ++q) {
+                    const int c = sU[q0 + q];
+                    const double pv = sP[t * (THIN_CHUNK + 1) + q];
 #pragma unroll
-            for (int k = 0; k < THIN_MAX_ROWS; ++k) if (k < m) acc[k] += pv * sH[(size_t)k * (NA + 1) + c];
+                    for (int k = 0; k < THIN_MAX_ROWS; ++k) if (k < m) acc[k] += pv * sH[(size_t)k * (NA + 1) + c];
+                }
+            }
         }
+        if (t < n) {
 #pragma unroll
-        for (int k = 0; k < THIN_MAX_ROWS; ++k) if (k < m) sW[(size_t)t * m + k] = acc[k];
+            for (int k = 0; k < THIN_MAX_ROWS; ++k) if (k < m) sW[(size_t)t * m + k] = acc[k];
+        }
     }
     __syncthreads();
     for (int idx = t; idx < m * m; idx += 1024) {   // S = H' W(active rows) + s2 I
