@@ -328,6 +328,8 @@ struct orcvio_msckf_handle {
     bool ekf_side_opt = true;           // ORCVIO_STEP_EKF_SIDE=0 (diagnostics build): the rows on the update's own stream, in front of k_front
     bool ekf_side_now = false;          // set by orcvio_msckf_io_step_frame around its first update
     bool ekf_side_used = false;         // the frame being enqueued has work on `side` (a repair drains it)
+    long long ekf_side_skip_until = 0;  // a frame whose side-stream join gave up was repaired: the next 4 096 frames keep the rows on the update's own stream
+                                        // (a profiler that serialises dispatches, another tenant: the join must not cost its bound on every frame)
     unsigned ekf_side_seq = 0;
     unsigned* front_mark = nullptr; unsigned front_mark_val = 0;       // launch_front: FrontGramArgs.started
     const unsigned* asm_wait = nullptr; unsigned asm_wait_val = 0;     // launch_solve_stage(ST_FORM_U): k_gemm_asmA_w
