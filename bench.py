@@ -765,12 +765,19 @@ def main():
             lib_now = hashlib.sha256(open(capi.LIB_PATH, 'rb').read()).hexdigest()[:16]
             pm_build = pm_doc.get('build')
             pm_sha = pm_build.get('liborcvio_msckf_sha16') if isinstance(pm_build, dict) else pm_build
-            if pm_sha != lib_now:   # counters of ANOTHER build say nothing about this one: traffic stays null
+            # counters of ANOTHER build say nothing about this one: traffic stays null -- unless that build was made from
+            # the SAME sources (hipcc's output is not reproducible byte for byte: a rebuild of this tree has another hash, the same kernels)
+            from orcvio_amd import build as _build
+            src_now = _build.source_sha16()
+            pm_src = pm_build.get('source_sha16') if isinstance(pm_build, dict) else None
+            same_sources = pm_sha != lib_now and pm_src is not None and pm_src == src_now
+            if pm_sha != lib_now and not same_sources:
                 traffic_source = dict(file=os.path.relpath(pm_path, ROOT), build=pm_doc.get('build'), measured_in_this_run=False,
-                                      refused='taken on another build of the library (this one: %s)' % lib_now)
+                                      refused='taken on another build of the library (this one: %s, sources %s)' % (lib_now, src_now))
                 raise LookupError('stale pmc profile')
             # the counters are those of a COMMITTED profile, not of this run: say which file and which build
             traffic_source = dict(file=os.path.relpath(pm_path, ROOT), build=pm_doc.get('build'), measured_in_this_run=False)
+            if same_sources: traffic_source['matched_by'] = 'sources (another build of the same sources: %s)' % lib_now
             # (the solve launch's template arguments: look-ahead depth, stamps, finish inside the launch -- two arguments in profiles older than r5i)
             for cand in (('k_potrf_solve_la<3, false, true>',) if 'k_finish' not in prof else ()) + ('k_potrf_solve_la<3, false, false>', 'k_potrf_solve_la<3, false>'):
                 if cand in pm:

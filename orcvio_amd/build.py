@@ -21,6 +21,19 @@ def _stale(lib) -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+def source_sha16() -> str:
+    """sha256 (first 16 hex digits) over the names and contents of every file the library is built from (DEPS).  hipcc's output is
+    not reproducible byte for byte (two builds of the same sources differ), so a profile records this beside the binary's hash:
+    bench.py accepts counters taken on another BUILD of the same SOURCES."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for d in DEPS:
+        hsh.update(os.path.basename(d).encode() + b'\0')
+        with open(os.path.join(CSRC, d), 'rb') as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
+
+
 def build_library(force: bool = False, verbose: bool = False, debug_hooks: bool = False) -> str:
     """Compiles every HIP source for gfx950 into orcvio_amd/lib/liborcvio_msckf.so (the product: the C-ABI of
     include/orcvio_msckf.h and nothing else), or with debug_hooks the diagnostics build liborcvio_msckf_dbg.so, which adds the

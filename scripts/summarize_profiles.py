@@ -74,7 +74,9 @@ def build_tag():
     import hashlib
     so = os.path.join(ROOT, 'orcvio_amd', 'lib', 'liborcvio_msckf.so')
     try:
-        return dict(tag=tag, liborcvio_msckf_sha16=hashlib.sha256(open(so, 'rb').read()).hexdigest()[:16])
+        sys.path.insert(0, ROOT)
+        from orcvio_amd import build as _b
+        return dict(tag=tag, liborcvio_msckf_sha16=hashlib.sha256(open(so, 'rb').read()).hexdigest()[:16], source_sha16=_b.source_sha16())
     except OSError:
         return dict(tag=tag)
 

@@ -141,3 +141,23 @@ def test_the_product_library_reads_only_the_documented_environment_variables(bui
     assert {'ORCVIO_COMM_TRANSPORT', 'ORCVIO_LA_SPIN', 'ORCVIO_FRAME_CHAIN'} <= prod
     dbg = names(b.LIB_DBG)
     assert {'ORCVIO_FUSE_FINISH', 'ORCVIO_BLK2', 'ORCVIO_SPLIT_TRACKS', 'ORCVIO_TIMING'} <= dbg
+
+
+def test_the_committed_pmc_profile_is_of_these_sources():
+    """bench.py quotes roofline.traffic from the newest profiles/r*_pmc_traffic.json only if that profile was taken on the loaded
+    library or on another build of the SAME sources (hipcc's output is not reproducible byte for byte): the hash over the library's
+    source files is stable, and the committed profile of the round's last build carries the hash of the tree as it stands."""
+    import glob
+    import json
+    import re
+    from orcvio_amd import build as b
+    s1, s2 = b.source_sha16(), b.source_sha16()
+    assert s1 == s2 and len(s1) == 16
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def key(p):
+        m = re.match(r'r(\d+)([a-z]*)_', os.path.basename(p))
+        return (int(m.group(1)), m.group(2)) if m else (-1, '')
+    newest = sorted(glob.glob(os.path.join(root, 'profiles', 'r*_pmc_traffic.json')), key=key)[-1]
+    rec = json.load(open(newest)).get('build')
+    assert isinstance(rec, dict) and rec.get('source_sha16') == s1, (newest, rec, s1)
